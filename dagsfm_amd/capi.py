@@ -1,0 +1,186 @@
+"""ctypes binding of the C-ABI in include/dagsfm_mi355x.h (no torch types cross it)."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdagsfm_mi355x.so")
+
+u8p = ctypes.POINTER(ctypes.c_uint8)
+u32p = ctypes.POINTER(ctypes.c_uint32)
+u64p = ctypes.POINTER(ctypes.c_uint64)
+f32p = ctypes.POINTER(ctypes.c_float)
+
+
+class DsmError(RuntimeError):
+    pass
+
+
+class MatchOptions(ctypes.Structure):
+    """SiftMatchingOptions (matching half), /root/reference/src/feature/sift.h:116-165."""
+    _fields_ = [("max_ratio", ctypes.c_double), ("max_distance", ctypes.c_double),
+                ("cross_check", ctypes.c_int32), ("max_num_matches", ctypes.c_int32)]
+
+
+class TwoViewOptions(ctypes.Structure):
+    """TwoViewGeometry::Options + RANSACOptions, two_view_geometry.h:105-157, ransac.h:47-72."""
+    _fields_ = [("min_num_inliers", ctypes.c_uint64), ("min_E_F_inlier_ratio", ctypes.c_double),
+                ("max_H_inlier_ratio", ctypes.c_double), ("watermark_min_inlier_ratio", ctypes.c_double),
+                ("watermark_border_size", ctypes.c_double), ("detect_watermark", ctypes.c_int32),
+                ("multiple_models", ctypes.c_int32), ("max_error", ctypes.c_double),
+                ("min_inlier_ratio", ctypes.c_double), ("confidence", ctypes.c_double),
+                ("min_num_trials", ctypes.c_uint64), ("max_num_trials", ctypes.c_uint64)]
+
+
+class Camera(ctypes.Structure):
+    _fields_ = [("model_id", ctypes.c_int32), ("has_prior_focal_length", ctypes.c_int32),
+                ("width", ctypes.c_uint64), ("height", ctypes.c_uint64), ("params", ctypes.c_double * 12)]
+
+
+class TwoViewGeometry(ctypes.Structure):
+    _fields_ = [("config", ctypes.c_int32), ("num_inliers", ctypes.c_uint32), ("num_matches", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32), ("F", ctypes.c_double * 9), ("E", ctypes.c_double * 9),
+                ("H", ctypes.c_double * 9), ("qvec", ctypes.c_double * 4), ("tvec", ctypes.c_double * 3),
+                ("tri_angle", ctypes.c_double), ("num_trials", ctypes.c_uint32 * 4),
+                ("num_models", ctypes.c_uint32 * 4)]
+
+
+_lib = None
+
+
+def lib():
+    """Loads the shared library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DsmError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(make -C dagsfm_amd/csrc)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        vp = ctypes.c_void_p
+        L.dsm_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+        L.dsm_ctx_destroy.argtypes = [vp]
+        L.dsm_ctx_destroy.restype = None
+        L.dsm_last_error.argtypes = [vp]
+        L.dsm_last_error.restype = ctypes.c_char_p
+        L.dsm_sync.argtypes = [vp]
+        L.dsm_set_images.argtypes = [vp, ctypes.c_uint32, u32p, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                     ctypes.c_uint32, ctypes.POINTER(Camera)]
+        L.dsm_match_pairs.argtypes = [vp, ctypes.c_uint32, u32p, ctypes.POINTER(MatchOptions)]
+        L.dsm_get_match_counts.argtypes = [vp, vp]
+        L.dsm_get_matches.argtypes = [vp, vp, vp, ctypes.c_uint64]
+        L.dsm_match_sift_features.argtypes = [vp, ctypes.POINTER(MatchOptions), u8p, ctypes.c_uint32, u8p,
+                                              ctypes.c_uint32, u32p, u32p]
+        L.dsm_get_match_kernel_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double), u32p]
+        L.dsm_default_match_options.argtypes = [ctypes.POINTER(MatchOptions)]
+        L.dsm_default_match_options.restype = None
+        L.dsm_default_two_view_options.argtypes = [ctypes.POINTER(TwoViewOptions)]
+        L.dsm_default_two_view_options.restype = None
+        _lib = L
+    return _lib
+
+
+def default_match_options(**kw):
+    o = MatchOptions()
+    lib().dsm_default_match_options(ctypes.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def default_two_view_options(**kw):
+    o = TwoViewOptions()
+    lib().dsm_default_two_view_options(ctypes.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class Context:
+    """One context = one GPU (SiftFeatureMatcher + FeatureMatcherCache of the reference)."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        rc = lib().dsm_ctx_create(device, ctypes.byref(self._h))
+        if rc != 0:
+            raise DsmError("dsm_ctx_create failed (%d): %s" % (rc, lib().dsm_last_error(None).decode()))
+        self.n_pairs = 0
+
+    def close(self):
+        if self._h:
+            lib().dsm_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DsmError("dsm error %d: %s" % (rc, lib().dsm_last_error(self._h).decode()))
+
+    def sync(self):
+        self._chk(lib().dsm_sync(self._h))
+
+    def set_images(self, descriptors, keypoints=None, cameras=None):
+        """descriptors: list of (n_i,128) uint8; keypoints: list of (n_i,>=2) float32; cameras: list of Camera."""
+        n = len(descriptors)
+        descs = [np.ascontiguousarray(d, dtype=np.uint8).reshape(-1, 128) for d in descriptors]
+        nf = np.array([d.shape[0] for d in descs], dtype=np.uint32)
+        vp = ctypes.c_void_p
+        dptr = (vp * max(n, 1))(*[d.ctypes.data for d in descs])
+        kptr = None
+        stride = 0
+        kps = None
+        if keypoints is not None:
+            kps = [np.ascontiguousarray(k, dtype=np.float32) for k in keypoints]
+            kps = [k.reshape(-1, k.shape[-1] if k.ndim == 2 else 2) for k in kps]
+            stride = kps[0].shape[1] if n else 2
+            for k, d in zip(kps, descs):
+                assert k.shape[0] == d.shape[0] and k.shape[1] == stride
+            kptr = (vp * max(n, 1))(*[k.ctypes.data for k in kps])
+        cptr = None
+        if cameras is not None:
+            cptr = (Camera * max(n, 1))(*cameras)
+        self._chk(lib().dsm_set_images(self._h, n, nf.ctypes.data_as(u32p), dptr, kptr, stride, cptr))
+        self._keep = (descs, kps)
+
+    def match_pairs(self, pairs, options=None):
+        options = options or default_match_options()
+        p = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        self.n_pairs = p.shape[0]
+        self._chk(lib().dsm_match_pairs(self._h, self.n_pairs, p.ctypes.data_as(u32p), ctypes.byref(options)))
+
+    def match_counts(self):
+        c = np.zeros(max(self.n_pairs, 1), dtype=np.uint32)
+        self._chk(lib().dsm_get_match_counts(self._h, c.ctypes.data))
+        return c[:self.n_pairs]
+
+    def matches(self):
+        """Returns (offsets[n_pairs+1], matches[total,2])."""
+        offs = np.zeros(self.n_pairs + 1, dtype=np.uint64)
+        self._chk(lib().dsm_get_matches(self._h, offs.ctypes.data, None, 0))
+        total = int(offs[-1])
+        m = np.zeros((max(total, 1), 2), dtype=np.uint32)
+        self._chk(lib().dsm_get_matches(self._h, None, m.ctypes.data, total))
+        return offs, m[:total]
+
+    def match_sift_features(self, desc1, desc2, options=None):
+        """MatchSiftFeaturesCPU-shaped leaf, /root/reference/src/feature/sift.h:214-217."""
+        options = options or default_match_options()
+        d1 = np.ascontiguousarray(desc1, dtype=np.uint8).reshape(-1, 128)
+        d2 = np.ascontiguousarray(desc2, dtype=np.uint8).reshape(-1, 128)
+        out = np.zeros((max(min(d1.shape[0], d2.shape[0]), 1), 2), dtype=np.uint32)
+        n = ctypes.c_uint32(0)
+        self._chk(lib().dsm_match_sift_features(self._h, ctypes.byref(options), d1.ctypes.data_as(u8p), d1.shape[0],
+                                                d2.ctypes.data_as(u8p), d2.shape[0], out.ctypes.data_as(u32p),
+                                                ctypes.byref(n)))
+        return out[:n.value].copy()
+
+    def match_kernel_time(self):
+        ms = ctypes.c_double(0)
+        n = ctypes.c_uint32(0)
+        self._chk(lib().dsm_get_match_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,473 @@
+// capi.hip -- the C-ABI (include/dagsfm_mi355x.h) over the HIP kernels.
+//
+// Host-side orchestration only: HBM layout, pair scheduling, kernel launches, result
+// fetches.  No arithmetic of the hot path is done on the host; if no HIP device is
+// present dsm_ctx_create fails with DSM_ERR_NO_DEVICE (there is no CPU fallback).
+//
+// HBM layout (one context = one GPU):
+//   desc_s8   [total_rows][128] int8   all images back to back, each padded with zero rows
+//                                      to a multiple of 256 rows (zero rows never match)
+//   rterm     [total_rows]      int32  128 * sum(row as s8)
+//   kp        [total_rows][2]   double keypoint (x,y) as FeatureKeypointsToPointsVector
+//                                      (/root/reference/src/feature/utils.cc:38-46) makes them
+//   m         [sum rows(a)]     int32  K1 output per directed pair (scratch, per chunk)
+//   matches   [total][2]        uint32 compact FeatureMatches of all pairs, list order
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/dagsfm_mi355x.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      e = hipMalloc(&p, bytes);
+      want = bytes;
+    }
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  // reserve keeping the old contents (first `keep` bytes)
+  hipError_t grow(size_t bytes, size_t keep, hipStream_t st) {
+    if (bytes <= cap) return hipSuccess;
+    void* np = nullptr;
+    size_t want = bytes + bytes / 2 + 256;
+    hipError_t e = hipMalloc(&np, want);
+    if (e != hipSuccess) {
+      want = bytes;
+      e = hipMalloc(&np, want);
+    }
+    if (e != hipSuccess) return e;
+    if (p && keep) {
+      e = hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (p) (void)hipFree(p);
+    p = np;
+    cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct dsm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // resident images
+  uint32_t n_images = 0;
+  uint64_t total_rows = 0;
+  std::vector<uint32_t> nfeat, row0, rows;
+  std::vector<dsm_camera> cameras;
+  bool have_kp = false;
+  DevBuf d_desc, d_rterm, d_kp, d_img_row0, d_img_rows, d_lut;
+
+  // last dsm_match_pairs
+  bool matched = false;
+  uint32_t n_pairs = 0;
+  std::vector<uint32_t> pairs;  // n_pairs x 2
+  DevBuf d_dpairs, d_doutoff, d_pair_dir, d_m, d_counts, d_offsets, d_matches, d_total;
+  uint64_t total_matches = 0;
+  double k1_ms = 0.0;
+  uint32_t k1_launches = 0;
+  std::vector<hipEvent_t> ev;
+
+  dsm_ctx* leaf = nullptr;  // private context of dsm_match_sift_features
+};
+
+#define HIPCHK(ctx, call)                                                              \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+      return DSM_ERR_HIP;                                                              \
+    }                                                                                  \
+  } while (0)
+
+static int fail(dsm_ctx* ctx, int code, const char* msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+extern "C" {
+
+void dsm_default_match_options(dsm_match_options* o) {
+  if (!o) return;
+  o->max_ratio = 0.8;       // sift.h:129
+  o->max_distance = 0.7;    // sift.h:132
+  o->cross_check = 1;       // sift.h:135
+  o->max_num_matches = 32768;  // sift.h:138
+}
+
+void dsm_default_two_view_options(dsm_two_view_options* o) {
+  if (!o) return;
+  o->min_num_inliers = 15;              // two_view_geometry.h:107
+  o->min_E_F_inlier_ratio = 0.95;       // :112
+  o->max_H_inlier_ratio = 0.8;          // :117
+  o->watermark_min_inlier_ratio = 0.7;  // :122
+  o->watermark_border_size = 0.1;       // :127
+  o->detect_watermark = 1;              // :130
+  o->multiple_models = 0;               // sift.h:159
+  o->max_error = 4.0;                   // sift.h:141
+  o->min_inlier_ratio = 0.25;           // sift.h:152
+  o->confidence = 0.999;                // sift.h:144
+  o->min_num_trials = 30;               // sift.h:148
+  o->max_num_trials = 10000;            // sift.h:149
+}
+
+int dsm_ctx_create(int device, dsm_ctx** out_ctx) {
+  if (!out_ctx) return DSM_ERR_INVALID_ARGUMENT;
+  *out_ctx = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_create_error = "no HIP device visible (hipGetDeviceCount)";
+    return DSM_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    g_create_error = "device index out of range";
+    return DSM_ERR_NO_DEVICE;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    g_create_error = "hipSetDevice failed";
+    return DSM_ERR_NO_DEVICE;
+  }
+  dsm_ctx* c = new dsm_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    g_create_error = "hipStreamCreate failed";
+    return DSM_ERR_HIP;
+  }
+  // acos LUT over the integer dot product, built with the host libm so that the float
+  // compares of sift.cc:140-155 are reproduced bit for bit.
+  std::vector<float> lut(262145);
+  const float kDistNorm = 1.0f / (512.0f * 512.0f);  // sift.cc:115
+  for (int d = 0; d <= 262144; ++d) lut[d] = acosf(fminf(kDistNorm * (float)d, 1.0f));
+  if (c->d_lut.reserve(lut.size() * sizeof(float)) != hipSuccess ||
+      hipMemcpy(c->d_lut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+      c->d_total.reserve(sizeof(uint64_t)) != hipSuccess) {
+    g_create_error = "device allocation failed";
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return DSM_ERR_HIP;
+  }
+  *out_ctx = c;
+  return DSM_OK;
+}
+
+void dsm_ctx_destroy(dsm_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->leaf) dsm_ctx_destroy(ctx->leaf);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+  DevBuf* bufs[] = {&ctx->d_desc, &ctx->d_rterm, &ctx->d_kp, &ctx->d_img_row0, &ctx->d_img_rows, &ctx->d_lut,
+                    &ctx->d_dpairs, &ctx->d_doutoff, &ctx->d_pair_dir, &ctx->d_m, &ctx->d_counts,
+                    &ctx->d_offsets, &ctx->d_matches, &ctx->d_total};
+  for (DevBuf* b : bufs) b->release();
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* dsm_last_error(const dsm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int dsm_sync(dsm_ctx* ctx) {
+  if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return DSM_OK;
+}
+
+int dsm_set_images(dsm_ctx* ctx, uint32_t n_images, const uint32_t* n_feats, const uint8_t* const* desc,
+                   const float* const* kp_xy, uint32_t kp_stride, const dsm_camera* cameras) {
+  if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
+  if (n_images && (!n_feats || !desc)) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "null image arrays");
+  if (kp_xy && kp_stride < 2) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "kp_stride must be >= 2");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->matched = false;
+  ctx->n_images = n_images;
+  ctx->nfeat.assign(n_feats, n_feats + n_images);
+  ctx->row0.resize(n_images);
+  ctx->rows.resize(n_images);
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < n_images; ++i) {
+    if (n_feats[i] > 0 && !desc[i]) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "null descriptor pointer");
+    const uint64_t r = ((uint64_t)n_feats[i] + 255) / 256 * 256;
+    if (total + r > 0xffffff00ull) return fail(ctx, DSM_ERR_OUT_OF_RANGE, "too many feature rows for one context");
+    ctx->row0[i] = (uint32_t)total;
+    ctx->rows[i] = (uint32_t)r;
+    total += r;
+  }
+  ctx->total_rows = total;
+  ctx->cameras.clear();
+  if (cameras) ctx->cameras.assign(cameras, cameras + n_images);
+  ctx->have_kp = kp_xy != nullptr;
+
+  HIPCHK(ctx, ctx->d_desc.reserve(std::max<uint64_t>(total, 1) * 128));
+  HIPCHK(ctx, ctx->d_rterm.reserve(std::max<uint64_t>(total, 1) * 4));
+  HIPCHK(ctx, ctx->d_img_row0.reserve(std::max<uint32_t>(n_images, 1) * 4));
+  HIPCHK(ctx, ctx->d_img_rows.reserve(std::max<uint32_t>(n_images, 1) * 4));
+  if (n_images) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_img_row0.p, ctx->row0.data(), n_images * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_img_rows.p, ctx->rows.data(), n_images * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (total) {
+    // stage the padded u8 image in a temporary device buffer, convert in place with K0
+    DevBuf tmp;
+    HIPCHK(ctx, tmp.reserve(total * 128));
+    HIPCHK(ctx, hipMemsetAsync(tmp.p, 0, total * 128, ctx->stream));
+    for (uint32_t i = 0; i < n_images; ++i) {
+      if (!n_feats[i]) continue;
+      HIPCHK(ctx, hipMemcpyAsync(tmp.as<uint8_t>() + (uint64_t)ctx->row0[i] * 128, desc[i], (uint64_t)n_feats[i] * 128,
+                                 hipMemcpyHostToDevice, ctx->stream));
+    }
+    launch_k0(tmp.as<uint8_t>(), ctx->d_desc.as<int8_t>(), ctx->d_rterm.as<int32_t>(), total, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    tmp.release();
+  }
+  if (kp_xy && total) {
+    std::vector<double> kp(total * 2, 0.0);
+    for (uint32_t i = 0; i < n_images; ++i) {
+      if (!n_feats[i]) continue;
+      if (!kp_xy[i]) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "null keypoint pointer");
+      double* dst = kp.data() + (uint64_t)ctx->row0[i] * 2;
+      for (uint32_t k = 0; k < n_feats[i]; ++k) {
+        dst[2 * k + 0] = (double)kp_xy[i][(uint64_t)k * kp_stride + 0];
+        dst[2 * k + 1] = (double)kp_xy[i][(uint64_t)k * kp_stride + 1];
+      }
+    }
+    HIPCHK(ctx, ctx->d_kp.reserve(total * 16));
+    HIPCHK(ctx, hipMemcpy(ctx->d_kp.p, kp.data(), total * 16, hipMemcpyHostToDevice));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return DSM_OK;
+}
+
+int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const dsm_match_options* options) {
+  if (!ctx || !options || (n_pairs && !pairs)) return DSM_ERR_INVALID_ARGUMENT;
+  // SiftMatchingOptions::Check, sift.cc:236-250
+  if (!(options->max_ratio > 0.0) || !(options->max_distance > 0.0))
+    return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "max_ratio and max_distance must be > 0");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  ctx->matched = false;
+  ctx->n_pairs = n_pairs;
+  ctx->pairs.assign(pairs, pairs + (size_t)n_pairs * 2);
+  ctx->k1_ms = 0.0;
+  ctx->k1_launches = 0;
+  ctx->total_matches = 0;
+  const bool cross = options->cross_check != 0;
+  for (uint32_t i = 0; i < n_pairs; ++i) {
+    const uint32_t a = pairs[2 * i], b = pairs[2 * i + 1];
+    if (a >= ctx->n_images || b >= ctx->n_images) return fail(ctx, DSM_ERR_OUT_OF_RANGE, "image index out of range");
+    if ((int64_t)ctx->nfeat[a] > options->max_num_matches || (int64_t)ctx->nfeat[b] > options->max_num_matches)
+      return fail(ctx, DSM_ERR_OUT_OF_RANGE, "image has more features than max_num_matches");
+    if (ctx->rows[a] > 8192 || ctx->rows[b] > 8192)
+      return fail(ctx, DSM_ERR_OUT_OF_RANGE, "more than 8192 features per image not supported by this build");
+  }
+  HIPCHK(ctx, ctx->d_counts.reserve(std::max<uint32_t>(n_pairs, 1) * 4));
+  HIPCHK(ctx, ctx->d_offsets.reserve(((size_t)n_pairs + 1) * 8));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_total.p, 0, 8, st));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_offsets.p, 0, 8, st));
+
+  // Chunk the pair list so that the K1 output scratch stays below a fixed budget.
+  const uint64_t budget_rows = (6ull << 30) / 4;
+  std::vector<uint2> dpairs;
+  std::vector<uint64_t> doff;
+  std::vector<uint4> pdir;
+  std::vector<uint32_t> cnt_b(ctx->n_images + 1);
+  size_t ev_used = 0;
+  uint32_t c0 = 0;
+  while (c0 < n_pairs) {
+    // chunk extent
+    uint64_t rows_acc = 0;
+    uint32_t c1 = c0;
+    while (c1 < n_pairs) {
+      const uint32_t a = pairs[2 * c1], b = pairs[2 * c1 + 1];
+      const uint64_t r = (uint64_t)ctx->rows[a] + (cross ? ctx->rows[b] : 0);
+      if (c1 > c0 && rows_acc + r > budget_rows) break;
+      rows_acc += r;
+      ++c1;
+    }
+    const uint32_t nc = c1 - c0;
+    const uint32_t nd = cross ? 2 * nc : nc;
+    // directed list, counting-sorted by column image b so that workgroups running at the
+    // same time stream the same B image out of L2.
+    std::fill(cnt_b.begin(), cnt_b.end(), 0u);
+    for (uint32_t i = c0; i < c1; ++i) {
+      const uint32_t a = pairs[2 * i], b = pairs[2 * i + 1];
+      cnt_b[b + 1]++;
+      if (cross) cnt_b[a + 1]++;
+    }
+    for (uint32_t k = 0; k < ctx->n_images; ++k) cnt_b[k + 1] += cnt_b[k];
+    dpairs.resize(nd);
+    pdir.resize(nc);
+    for (uint32_t i = c0; i < c1; ++i) {
+      const uint32_t a = pairs[2 * i], b = pairs[2 * i + 1];
+      const uint32_t dab = cnt_b[b]++;
+      dpairs[dab] = make_uint2(a, b);
+      uint32_t dba = 0;
+      if (cross) {
+        dba = cnt_b[a]++;
+        dpairs[dba] = make_uint2(b, a);
+      }
+      pdir[i - c0] = make_uint4(dab, dba, ctx->nfeat[a], ctx->nfeat[b]);
+    }
+    doff.resize(nd);
+    uint64_t off = 0;
+    uint32_t max_rb = 0;
+    for (uint32_t k = 0; k < nd; ++k) {
+      doff[k] = off;
+      off += ctx->rows[dpairs[k].x];
+      max_rb = std::max(max_rb, ctx->rows[dpairs[k].x] / 256);
+    }
+    HIPCHK(ctx, ctx->d_dpairs.reserve(std::max<uint32_t>(nd, 1) * sizeof(uint2)));
+    HIPCHK(ctx, ctx->d_doutoff.reserve(std::max<uint32_t>(nd, 1) * 8));
+    HIPCHK(ctx, ctx->d_pair_dir.reserve(std::max<uint32_t>(nc, 1) * sizeof(uint4)));
+    HIPCHK(ctx, ctx->d_m.reserve(std::max<uint64_t>(off, 1) * 4));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_dpairs.p, dpairs.data(), nd * sizeof(uint2), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_doutoff.p, doff.data(), nd * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_pair_dir.p, pdir.data(), nc * sizeof(uint4), hipMemcpyHostToDevice, st));
+
+    K1Params k1;
+    k1.desc = ctx->d_desc.as<int8_t>();
+    k1.rterm = ctx->d_rterm.as<int32_t>();
+    k1.dpairs = ctx->d_dpairs.as<uint2>();
+    k1.img_row0 = ctx->d_img_row0.as<uint32_t>();
+    k1.img_rows = ctx->d_img_rows.as<uint32_t>();
+    k1.d_out_off = ctx->d_doutoff.as<uint64_t>();
+    k1.lut = ctx->d_lut.as<float>();
+    k1.max_ratio = (float)options->max_ratio;        // narrowed as at sift.cc:164-166
+    k1.max_distance = (float)options->max_distance;
+    k1.out = ctx->d_m.as<int32_t>();
+    while (ctx->ev.size() < ev_used + 2) {
+      hipEvent_t e;
+      HIPCHK(ctx, hipEventCreate(&e));
+      ctx->ev.push_back(e);
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used], st));
+    launch_k1(k1, nd, max_rb, st);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 1], st));
+    ev_used += 2;
+    if (max_rb) ctx->k1_launches++;
+
+    K2Params k2;
+    k2.pair_dir = ctx->d_pair_dir.as<uint4>();
+    k2.d_out_off = ctx->d_doutoff.as<uint64_t>();
+    k2.m = ctx->d_m.as<int32_t>();
+    k2.cross_check = cross ? 1 : 0;
+    k2.counts = ctx->d_counts.as<uint32_t>() + c0;
+    k2.offsets = ctx->d_offsets.as<uint64_t>() + c0;
+    k2.matches = nullptr;
+    launch_k2(k2, nc, false, st);
+    HIPCHK(ctx, hipGetLastError());
+    launch_scan(ctx->d_counts.as<uint32_t>() + c0, ctx->d_offsets.as<uint64_t>() + c0, nc, ctx->d_total.as<uint64_t>(), st);
+    HIPCHK(ctx, hipGetLastError());
+    uint64_t total = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&total, ctx->d_total.p, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, ctx->d_matches.grow(std::max<uint64_t>(total, 1) * 8, ctx->total_matches * 8, st));
+    k2.matches = ctx->d_matches.as<uint32_t>();
+    launch_k2(k2, nc, true, st);
+    HIPCHK(ctx, hipGetLastError());
+    ctx->total_matches = total;
+    // the scratch of this chunk is reused by the next one
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    c0 = c1;
+  }
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  for (size_t k = 0; k + 1 < ev_used; k += 2) {
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[k], ctx->ev[k + 1]));
+    ctx->k1_ms += ms;
+  }
+  ctx->matched = true;
+  return DSM_OK;
+}
+
+int dsm_get_match_counts(dsm_ctx* ctx, uint32_t* counts) {
+  if (!ctx || !counts) return DSM_ERR_INVALID_ARGUMENT;
+  if (!ctx->matched) return fail(ctx, DSM_ERR_NOT_READY, "dsm_match_pairs has not run");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->n_pairs) HIPCHK(ctx, hipMemcpy(counts, ctx->d_counts.p, (size_t)ctx->n_pairs * 4, hipMemcpyDefault));
+  return DSM_OK;
+}
+
+int dsm_get_matches(dsm_ctx* ctx, uint64_t* offsets, uint32_t* matches, uint64_t matches_capacity) {
+  if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
+  if (!ctx->matched) return fail(ctx, DSM_ERR_NOT_READY, "dsm_match_pairs has not run");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (offsets) HIPCHK(ctx, hipMemcpy(offsets, ctx->d_offsets.p, ((size_t)ctx->n_pairs + 1) * 8, hipMemcpyDefault));
+  if (matches) {
+    if (matches_capacity < ctx->total_matches) return fail(ctx, DSM_ERR_OUT_OF_RANGE, "matches buffer too small");
+    if (ctx->total_matches)
+      HIPCHK(ctx, hipMemcpy(matches, ctx->d_matches.p, ctx->total_matches * 8, hipMemcpyDefault));
+  }
+  return DSM_OK;
+}
+
+int dsm_match_sift_features(dsm_ctx* ctx, const dsm_match_options* options, const uint8_t* desc1, uint32_t n1,
+                            const uint8_t* desc2, uint32_t n2, uint32_t* matches, uint32_t* n_matches) {
+  if (!ctx || !options || !n_matches) return DSM_ERR_INVALID_ARGUMENT;
+  *n_matches = 0;
+  if (!ctx->leaf) {
+    int rc = dsm_ctx_create(ctx->device, &ctx->leaf);
+    if (rc != DSM_OK) return fail(ctx, rc, dsm_last_error(nullptr));
+  }
+  dsm_ctx* lf = ctx->leaf;
+  const uint32_t nf[2] = {n1, n2};
+  const uint8_t* dp[2] = {desc1, desc2};
+  int rc = dsm_set_images(lf, 2, nf, dp, nullptr, 0, nullptr);
+  if (rc != DSM_OK) return fail(ctx, rc, lf->err.c_str());
+  const uint32_t pr[2] = {0, 1};
+  rc = dsm_match_pairs(lf, 1, pr, options);
+  if (rc != DSM_OK) return fail(ctx, rc, lf->err.c_str());
+  uint64_t offs[2] = {0, 0};
+  rc = dsm_get_matches(lf, offs, nullptr, 0);
+  if (rc != DSM_OK) return fail(ctx, rc, lf->err.c_str());
+  if (offs[1] && !matches) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "null matches buffer");
+  rc = dsm_get_matches(lf, nullptr, matches, std::min<uint64_t>(n1, n2));
+  if (rc != DSM_OK) return fail(ctx, rc, lf->err.c_str());
+  *n_matches = (uint32_t)offs[1];
+  return DSM_OK;
+}
+
+int dsm_get_match_kernel_time(dsm_ctx* ctx, double* total_ms, uint32_t* n_launches) {
+  if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
+  if (!ctx->matched) return fail(ctx, DSM_ERR_NOT_READY, "dsm_match_pairs has not run");
+  if (total_ms) *total_ms = ctx->k1_ms;
+  if (n_launches) *n_launches = ctx->k1_launches;
+  return DSM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+"""Synthetic image sets of the shapes BASELINE.json names (no datasets are reachable offline).
+
+A scene is a pool of 3-D points, each with a SIFT-like base descriptor made with the recipe
+of the reference's matcher tests (/root/reference/src/feature/sift_test.cc:243-253: 128 x
+U(0,1)^2, L2-normalised, x512, rounded, saturated to uint8).  Every image observes a random
+subset of the pool through a random SIMPLE_PINHOLE camera (f=800, 1000x750, sigma=0.5 px
+keypoint noise, small descriptor noise) and is filled up with clutter features (random
+descriptors, uniform keypoints).  Two images share about n_obs^2 / n_pool true
+correspondences (256 at the default 4096-feature shape), so matching has real matches to find
+and two-view verification has real geometry to verify.
+"""
+import numpy as np
+
+
+def _sift_like(rng, n):
+    x = rng.random((n, 128), dtype=np.float32)
+    x *= x
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
+
+
+def _to_u8(x):
+    return np.clip(np.rint(512.0 * x), 0, 255).astype(np.uint8)
+
+
+def _look_at(cam_pos, target, up):
+    z = target - cam_pos
+    z /= np.linalg.norm(z)
+    x = np.cross(up, z)
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    R = np.stack([x, y, z], axis=0)  # world -> camera
+    t = -R @ cam_pos
+    return R, t
+
+
+class Scene:
+    def __init__(self, n_images, n_feats, seed=0, n_obs=None, n_pool=None, focal=800.0, width=1000, height=750,
+                 kp_sigma=0.5, desc_sigma=0.012, planar=False, outlier_frac=0.2):
+        self.n_images, self.n_feats, self.seed = n_images, n_feats, seed
+        self.n_obs = n_obs if n_obs is not None else n_feats // 2
+        self.n_pool = n_pool if n_pool is not None else max(4 * n_feats, self.n_obs)
+        self.focal, self.width, self.height = focal, width, height
+        self.kp_sigma, self.desc_sigma = kp_sigma, desc_sigma
+        self.outlier_frac = outlier_frac
+        rng = np.random.default_rng([seed, 0xD5F])
+        self.points = rng.uniform(-5.0, 5.0, (self.n_pool, 3))
+        if planar:
+            self.points[:, 2] = 0.05 * self.points[:, 2]
+        self.base = _sift_like(rng, self.n_pool)
+
+    def image(self, i):
+        """Returns (descriptors u8 [n,128], keypoints f32 [n,2], (R,t), observed pool ids [n] (-1 = clutter))."""
+        rng = np.random.default_rng([self.seed, 1 + i])
+        n, k = self.n_feats, min(self.n_obs, self.n_feats)
+        # camera on a shell around the scene, looking at a jittered centre
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        d[2] = -abs(d[2]) - 0.6  # keep cameras on one side so that planar scenes stay visible
+        d /= np.linalg.norm(d)
+        pos = d * rng.uniform(14.0, 20.0)
+        R, t = _look_at(pos, rng.uniform(-1.0, 1.0, 3), np.array([0.0, 1.0, 0.0]) + 0.2 * rng.normal(size=3))
+        ids = np.full(n, -1, dtype=np.int64)
+        obs = rng.choice(self.n_pool, size=k, replace=False)
+        desc = np.empty((n, 128), dtype=np.float32)
+        kp = np.empty((n, 2), dtype=np.float64)
+        pc = self.points[obs] @ R.T + t
+        kp[:k, 0] = self.focal * pc[:, 0] / pc[:, 2] + self.width / 2.0
+        kp[:k, 1] = self.focal * pc[:, 1] / pc[:, 2] + self.height / 2.0
+        kp[:k] += rng.normal(scale=self.kp_sigma, size=(k, 2))
+        # geometric outliers: the descriptor still matches but the keypoint is somewhere else
+        bad = rng.random(k) < self.outlier_frac
+        kp[:k][bad, 0] = rng.uniform(0.0, self.width, int(bad.sum()))
+        kp[:k][bad, 1] = rng.uniform(0.0, self.height, int(bad.sum()))
+        d_obs = self.base[obs] + rng.normal(scale=self.desc_sigma, size=(k, 128)).astype(np.float32)
+        np.maximum(d_obs, 0.0, out=d_obs)
+        d_obs /= np.linalg.norm(d_obs, axis=1, keepdims=True)
+        desc[:k] = d_obs
+        ids[:k] = obs
+        if n > k:
+            desc[k:] = _sift_like(rng, n - k)
+            kp[k:, 0] = rng.uniform(0.0, self.width, n - k)
+            kp[k:, 1] = rng.uniform(0.0, self.height, n - k)
+        perm = rng.permutation(n)
+        return _to_u8(desc[perm]), kp[perm].astype(np.float32), (R, t), ids[perm]
+
+    def camera_params(self):
+        """SIMPLE_PINHOLE (model_id 0): f, cx, cy."""
+        return [self.focal, self.width / 2.0, self.height / 2.0]
+
+
+def exhaustive_pairs(n_images):
+    """All image pairs i<j in the order ExhaustiveFeatureMatcher visits a single block
+    (/root/reference/src/feature/matching.cc:853-915 with one block: idx1 < idx2)."""
+    i, j = np.triu_indices(n_images, k=1)
+    return np.stack([i, j], axis=1).astype(np.uint32)

@@ -1,0 +1,174 @@
+/*
+ * dagsfm_mi355x.h -- C-ABI of the MI355X-native matching + two-view verification path.
+ *
+ * This is the drop-in boundary for DAGSfM's data-parallel hot path
+ * (SURVEY.md section 8b).  Every entry point is `extern "C"`, takes plain pointers
+ * and sizes only, returns an int status (0 = DSM_OK) and never aborts.  The
+ * reference interfaces each entry point replaces are cited as
+ * `/root/reference/<file>:<line>`.
+ *
+ * Vocabulary follows the reference: images, features (keypoints + 128-D uint8
+ * SIFT descriptors), image pairs, FeatureMatches, TwoViewGeometry.
+ */
+#ifndef DAGSFM_MI355X_H_
+#define DAGSFM_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+enum {
+  DSM_OK = 0,
+  DSM_ERR_INVALID_ARGUMENT = 1, /* reference: CHECK(...) fatal in matching.cc */
+  DSM_ERR_NO_DEVICE = 2,        /* reference: Setup() returns false, matching.cc:732-742 */
+  DSM_ERR_HIP = 3,              /* a HIP runtime call failed; see dsm_last_error */
+  DSM_ERR_OUT_OF_RANGE = 4,
+  DSM_ERR_NOT_READY = 5         /* results requested before the producing call */
+};
+
+/* ------------------------------------------------------------------ options */
+
+/* Mirrors the matching half of SiftMatchingOptions, src/feature/sift.h:116-165.
+ * max_ratio / max_distance are doubles there and are narrowed to float exactly
+ * where the reference narrows them (FindBestMatches signature, sift.cc:164-166). */
+typedef struct dsm_match_options {
+  double max_ratio;        /* default 0.8  */
+  double max_distance;     /* default 0.7  */
+  int32_t cross_check;     /* default 1    */
+  int32_t max_num_matches; /* default 32768; features per image beyond this are an error */
+} dsm_match_options;
+
+/* Mirrors TwoViewGeometry::Options (src/estimators/two_view_geometry.h:105-157)
+ * with its embedded RANSACOptions (src/optim/ransac.h:47-72), filled from
+ * SiftMatchingOptions exactly as TwoViewGeometryVerifier's ctor does
+ * (src/feature/matching.cc:559-568). */
+typedef struct dsm_two_view_options {
+  uint64_t min_num_inliers;          /* 15   */
+  double min_E_F_inlier_ratio;       /* 0.95 */
+  double max_H_inlier_ratio;         /* 0.8  */
+  double watermark_min_inlier_ratio; /* 0.7  */
+  double watermark_border_size;      /* 0.1  */
+  int32_t detect_watermark;          /* 1    */
+  int32_t multiple_models;           /* 0 (EstimateMultiple is a "next" row) */
+  /* RANSACOptions */
+  double max_error;        /* 4.0   */
+  double min_inlier_ratio; /* 0.25  */
+  double confidence;       /* 0.999 */
+  uint64_t min_num_trials; /* 30    */
+  uint64_t max_num_trials; /* 10000 */
+} dsm_two_view_options;
+
+/* Camera as used by the verification path (src/base/camera.h; models
+ * src/base/camera_models.h).  model_id follows the reference's numbering:
+ * 0 SIMPLE_PINHOLE (f,cx,cy), 1 PINHOLE (fx,fy,cx,cy), 2 SIMPLE_RADIAL (f,cx,cy,k). */
+typedef struct dsm_camera {
+  int32_t model_id;
+  int32_t has_prior_focal_length; /* Camera::HasPriorFocalLength, camera.h:191 */
+  uint64_t width;
+  uint64_t height;
+  double params[12];
+} dsm_camera;
+
+/* TwoViewGeometry::ConfigurationType, src/estimators/two_view_geometry.h:83-102 */
+enum {
+  DSM_CONFIG_UNDEFINED = 0,
+  DSM_CONFIG_DEGENERATE = 1,
+  DSM_CONFIG_CALIBRATED = 2,
+  DSM_CONFIG_UNCALIBRATED = 3,
+  DSM_CONFIG_PLANAR = 4,
+  DSM_CONFIG_PANORAMIC = 5,
+  DSM_CONFIG_PLANAR_OR_PANORAMIC = 6,
+  DSM_CONFIG_WATERMARK = 7,
+  DSM_CONFIG_MULTIPLE = 8
+};
+
+/* Fixed-size part of a TwoViewGeometry (two_view_geometry.h:286-303).  Matrices
+ * are row-major 3x3.  The variable-length inlier_matches are fetched separately. */
+typedef struct dsm_two_view_geometry {
+  int32_t config;
+  uint32_t num_inliers;  /* == inlier_matches.size() */
+  uint32_t num_matches;  /* putative matches that went into Estimate */
+  uint32_t reserved;
+  double F[9];
+  double E[9];
+  double H[9];
+  double qvec[4];
+  double tvec[3];
+  double tri_angle;
+  /* bookkeeping for the hypotheses/s metric: LO-RANSAC trials and
+   * models scored (minimal-sample models + local-optimisation models). */
+  uint32_t num_trials[4];  /* E, F, H, watermark-translation */
+  uint32_t num_models[4];
+} dsm_two_view_geometry;
+
+/* ------------------------------------------------------------------ context */
+typedef struct dsm_ctx dsm_ctx;
+
+/* Creates a context bound to HIP device `device`.  Replaces SiftFeatureMatcher's
+ * ctor + Setup() (src/feature/matching.cc:610-675, 713-747): returns
+ * DSM_ERR_NO_DEVICE where Setup() would return false. */
+int dsm_ctx_create(int device, dsm_ctx** out_ctx);
+void dsm_ctx_destroy(dsm_ctx* ctx);
+/* Last error text for this context (or for ctx creation when ctx == NULL). */
+const char* dsm_last_error(const dsm_ctx* ctx);
+/* Blocks until all work queued by this context has finished. */
+int dsm_sync(dsm_ctx* ctx);
+
+/* Makes `n_images` images resident in HBM.  Replaces FeatureMatcherCache::Setup /
+ * GetDescriptors / GetKeypoints (src/feature/matching.cc:221-316) and
+ * SiftMatchGPU::SetDescriptors (lib/SiftGPU/SiftGPU.h:303-336).
+ *   n_feats[i]      number of features of image i (may be 0)
+ *   desc[i]         n_feats[i] x 128 uint8, row-major (FeatureDescriptors, types.h:102)
+ *   kp_xy[i]        n_feats[i] x 2 float (x,y) with stride kp_stride floats between
+ *                   keypoints (6 for FeatureKeypoint, types.h:44-81); may be NULL when
+ *                   only matching is wanted
+ *   cameras[i]      camera of image i; may be NULL when only matching is wanted
+ * Pointers are host pointers, borrowed for the duration of the call. */
+int dsm_set_images(dsm_ctx* ctx, uint32_t n_images, const uint32_t* n_feats,
+                   const uint8_t* const* desc, const float* const* kp_xy,
+                   uint32_t kp_stride, const dsm_camera* cameras);
+
+/* Brute-force matches every listed image pair on the device.  Replaces the
+ * matcher stage of SiftFeatureMatcher::Match (src/feature/matching.cc:749-839)
+ * = MatchSiftFeaturesCPU per pair (src/feature/sift.cc:810-822).
+ *   pairs   n_pairs x 2 image indices (into the dsm_set_images order)
+ * Results stay in HBM until fetched or consumed by dsm_verify_pairs. */
+int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs,
+                    const dsm_match_options* options);
+
+/* Per-pair number of matches of the last dsm_match_pairs; `counts` has n_pairs
+ * entries (host or device pointer). */
+int dsm_get_match_counts(dsm_ctx* ctx, uint32_t* counts);
+/* All matches of the last dsm_match_pairs, pair after pair in list order:
+ * `offsets` gets n_pairs+1 prefix offsets (in matches), `matches` gets
+ * offsets[n_pairs] x 2 uint32 (point2D_idx1, point2D_idx2) in ascending idx1
+ * per pair (FeatureMatches, types.h:86-104).  Either pointer may be NULL.
+ * `matches_capacity` is in matches (pairs of uint32). */
+int dsm_get_matches(dsm_ctx* ctx, uint64_t* offsets, uint32_t* matches,
+                    uint64_t matches_capacity);
+
+/* One-shot leaf with the signature shape of MatchSiftFeaturesCPU
+ * (src/feature/sift.h:214-217) / MatchSiftFeaturesGPU (sift.h:229-239):
+ * host descriptors in, FeatureMatches out.  `matches` must hold
+ * min(n1,n2) x 2 uint32. */
+int dsm_match_sift_features(dsm_ctx* ctx, const dsm_match_options* options,
+                            const uint8_t* desc1, uint32_t n1,
+                            const uint8_t* desc2, uint32_t n2,
+                            uint32_t* matches, uint32_t* n_matches);
+
+/* Device timing of the dominant kernel (descriptor distance + fused top-2) of the
+ * last dsm_match_pairs, measured with HIP events on the stream the kernel was
+ * launched on: total milliseconds and number of launches. */
+int dsm_get_match_kernel_time(dsm_ctx* ctx, double* total_ms, uint32_t* n_launches);
+
+void dsm_default_match_options(dsm_match_options* o);
+void dsm_default_two_view_options(dsm_two_view_options* o);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAGSFM_MI355X_H_ */

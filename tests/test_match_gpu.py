@@ -1,0 +1,174 @@
+"""GPU parity of the HIP matcher (through the C-ABI) against the CPU oracle: bit-exact
+FeatureMatches.  Patterns follow /root/reference/src/feature/sift_test.cc:300-325, 448-578
+(CPU == GPU index-by-index equality)."""
+import numpy as np
+import pytest
+
+from dagsfm_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def check_equal(m_gpu, m_cpu):
+    # CheckEqualMatches, sift_test.cc:255-262
+    assert m_gpu.shape == m_cpu.shape, (m_gpu.shape, m_cpu.shape)
+    assert (m_gpu == m_cpu).all()
+
+
+def rand_sift(rng, n, dup=0):
+    """SIFT-like descriptors: 128 x U(0,1)^2, L2-normalised, x512, rounded, saturated to u8."""
+    x = rng.random((n, 128), dtype=np.float32) ** 2
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    d = np.clip(np.rint(512.0 * x), 0, 255).astype(np.uint8)
+    for _ in range(dup):
+        if n >= 2:
+            i, j = rng.integers(0, n, 2)
+            d[i] = d[j]
+    return d
+
+
+def test_reference_known_answers(dsm, oracle):
+    d1 = oracle.create_random_feature_descriptors(2)
+    d2 = d1[::-1].copy()
+    assert dsm.match_sift_features(d1, d2).tolist() == [[0, 1], [1, 0]]
+    empty = np.zeros((0, 128), np.uint8)
+    assert len(dsm.match_sift_features(empty, d2)) == 0
+    assert len(dsm.match_sift_features(d1, empty)) == 0
+    assert len(dsm.match_sift_features(empty, empty)) == 0
+
+    d1 = oracle.create_random_feature_descriptors(100)
+    d2 = d1[::-1].copy()
+    m = dsm.match_sift_features(d1, d2)
+    assert len(m) == 100
+    check_equal(m, oracle.match_sift_features_cpu(d1, d2))
+
+    d2 = d1.copy()
+    assert len(dsm.match_sift_features(d1, d2)) == 100
+    d2[99] = d2[0]
+    d2[0, 0] = np.uint8((int(d2[0, 0]) + 50) & 0xFF)
+    d2[0] = oracle.l2_normalize_to_u8(d2[0].astype(np.float32))
+    d2[99, 0] = np.uint8((int(d2[99, 0]) + 100) & 0xFF)
+    d2[99] = oracle.l2_normalize_to_u8(d2[99].astype(np.float32))
+    o = capi.default_match_options(max_ratio=0.4)
+    m = dsm.match_sift_features(d1[:99], d2, o)
+    assert len(m) == 98
+    check_equal(m, oracle.match_sift_features_cpu(d1[:99], d2, max_ratio=0.4))
+    o = capi.default_match_options(max_ratio=0.5)
+    m = dsm.match_sift_features(d1, d2, o)
+    assert len(m) == 99
+    check_equal(m, oracle.match_sift_features_cpu(d1, d2, max_ratio=0.5))
+
+    d1 = oracle.create_random_feature_descriptors(100)
+    d2 = d1.copy()
+    d1[0] = d1[1]
+    assert len(dsm.match_sift_features(d1, d2, capi.default_match_options(cross_check=0))) == 100
+    assert len(dsm.match_sift_features(d1, d2, capi.default_match_options(cross_check=1))) == 98
+
+
+@pytest.mark.parametrize("n1,n2", [(1, 1), (1, 5), (7, 3), (63, 65), (100, 100), (255, 257), (256, 256),
+                                   (300, 1000), (1024, 1024), (1000, 333), (2049, 640)])
+@pytest.mark.parametrize("cross", [1, 0])
+def test_random_sift_ragged(dsm, oracle, n1, n2, cross):
+    rng = np.random.default_rng(1000 * n1 + n2 + cross)
+    base = rand_sift(rng, max(n1, n2), dup=3)
+    # image 2 = noisy permutation of image 1 plus clutter, so that many matches survive
+    d1 = base[:n1]
+    perm = rng.permutation(max(n1, n2))[:n2]
+    noise = rng.integers(-6, 7, (n2, 128))
+    d2 = np.clip(base[perm].astype(np.int32) + noise, 0, 255).astype(np.uint8)
+    for ratio, dist in [(0.8, 0.7), (0.95, 1.2), (0.5, 0.3)]:
+        o = capi.default_match_options(max_ratio=ratio, max_distance=dist, cross_check=cross)
+        m = dsm.match_sift_features(d1, d2, o)
+        check_equal(m, oracle.match_sift_features_cpu(d1, d2, ratio, dist, bool(cross)))
+
+
+def test_full_u8_range_and_ties(dsm, oracle):
+    """Arbitrary bytes (dots far above 2^18, saturating acos), exact duplicates, all-zero rows."""
+    rng = np.random.default_rng(7)
+    d1 = rng.integers(0, 256, (300, 128), dtype=np.uint8)
+    d2 = rng.integers(0, 256, (280, 128), dtype=np.uint8)
+    d1[5] = 255
+    d2[9] = 255
+    d2[10] = 255          # duplicate of the best column -> ratio test must reject (sift.cc:151-155)
+    d1[17] = 0            # all dots 0 -> best_i2 stays -1 (sift.cc:136)
+    d2[33] = 0
+    d2[100] = d2[50]
+    d1[200] = d2[50]
+    for cross in (0, 1):
+        for ratio, dist in [(0.8, 0.7), (1.5, 2.0), (0.99, 1.6)]:
+            o = capi.default_match_options(max_ratio=ratio, max_distance=dist, cross_check=cross)
+            check_equal(dsm.match_sift_features(d1, d2, o),
+                        oracle.match_sift_features_cpu(d1, d2, ratio, dist, bool(cross)))
+    # low-magnitude descriptors: everything fails max_distance
+    d1s = (d1 // 16).astype(np.uint8)
+    d2s = (d2 // 16).astype(np.uint8)
+    check_equal(dsm.match_sift_features(d1s, d2s), oracle.match_sift_features_cpu(d1s, d2s))
+    o = capi.default_match_options(max_ratio=1.0, max_distance=1.7, cross_check=0)
+    check_equal(dsm.match_sift_features(d1s, d2s, o), oracle.match_sift_features_cpu(d1s, d2s, 1.0, 1.7, False))
+
+
+def test_equal_dots_resolve_to_lowest_index(dsm, oracle):
+    """Several identical columns in different 32-column tiles and lanes (H2 tie rules)."""
+    rng = np.random.default_rng(11)
+    d1 = rand_sift(rng, 96)
+    d2 = rand_sift(rng, 200)
+    for c in (3, 35, 64, 131, 199):
+        d2[c] = d1[10]
+    d2[77] = d1[20]
+    d2[78] = d1[20]
+    o = capi.default_match_options(max_ratio=2.0, max_distance=3.0, cross_check=0)  # ratio never rejects
+    m = dsm.match_sift_features(d1, d2, o)
+    check_equal(m, oracle.match_sift_features_cpu(d1, d2, 2.0, 3.0, False))
+
+
+def test_pair_list_many_images(dsm, oracle):
+    """dsm_set_images + dsm_match_pairs over a ragged image set, all pairs, both orders."""
+    rng = np.random.default_rng(3)
+    sizes = [0, 1, 40, 256, 300, 513, 1024, 77]
+    base = rand_sift(rng, 1100)
+    descs = []
+    for n in sizes:
+        idx = rng.permutation(1100)[:n]
+        noise = rng.integers(-5, 6, (n, 128))
+        descs.append(np.clip(base[idx].astype(np.int32) + noise, 0, 255).astype(np.uint8))
+    dsm.set_images(descs)
+    pairs = [(i, j) for i in range(len(sizes)) for j in range(len(sizes)) if i != j]
+    pairs.append((2, 2))
+    dsm.match_pairs(np.array(pairs, dtype=np.uint32))
+    offs, m = dsm.matches()
+    counts = dsm.match_counts()
+    assert (np.diff(offs.astype(np.int64)) == counts.astype(np.int64)).all()
+    for k, (i, j) in enumerate(pairs):
+        ref = oracle.match_sift_features_cpu(descs[i], descs[j])
+        check_equal(m[int(offs[k]):int(offs[k + 1])], ref)
+    ms, nl = dsm.match_kernel_time()
+    assert ms > 0 and nl >= 1
+
+
+def test_4096_features_bit_exact_and_properties(dsm, oracle):
+    """BASELINE size (4 096 feats/image): bit-exact on two pairs, plus size-independent
+    properties on a block of pairs: ascending idx1, unique idx2, symmetry under image swap."""
+    rng = np.random.default_rng(4096)
+    pool = rand_sift(rng, 6000)
+    descs = []
+    for _ in range(4):
+        idx = rng.permutation(6000)[:4096]
+        noise = rng.integers(-4, 5, (4096, 128))
+        descs.append(np.clip(pool[idx].astype(np.int32) + noise, 0, 255).astype(np.uint8))
+    dsm.set_images(descs)
+    pairs = [(0, 1), (1, 0), (0, 2), (2, 0), (1, 3), (3, 1), (2, 3)]
+    dsm.match_pairs(np.array(pairs, dtype=np.uint32))
+    offs, m = dsm.matches()
+    get = lambda k: m[int(offs[k]):int(offs[k + 1])]
+    for k in (0, 6):
+        check_equal(get(k), oracle.match_sift_features_cpu(descs[pairs[k][0]], descs[pairs[k][1]]))
+    for k in range(len(pairs)):
+        mk = get(k)
+        assert len(mk) > 1000
+        assert (np.diff(mk[:, 0].astype(np.int64)) > 0).all()
+        assert len(np.unique(mk[:, 1])) == len(mk)
+    for k in (0, 2, 4):  # cross-checked matching is symmetric: swap images <=> swap columns
+        a = get(k)
+        b = get(k + 1)[:, ::-1]
+        b = b[np.argsort(b[:, 0], kind="stable")]
+        check_equal(a, b)
