@@ -172,7 +172,7 @@ class Context:
         options = options or default_match_options()
         d1 = np.ascontiguousarray(desc1, dtype=np.uint8).reshape(-1, 128)
         d2 = np.ascontiguousarray(desc2, dtype=np.uint8).reshape(-1, 128)
-        out = np.zeros((max(min(d1.shape[0], d2.shape[0]), 1), 2), dtype=np.uint32)
+        out = np.zeros((max(d1.shape[0], 1), 2), dtype=np.uint32)
         n = ctypes.c_uint32(0)
         self._chk(lib().dsm_match_sift_features(self._h, ctypes.byref(options), d1.ctypes.data_as(u8p), d1.shape[0],
                                                 d2.ctypes.data_as(u8p), d2.shape[0], out.ctypes.data_as(u32p),

@@ -456,7 +456,7 @@ int dsm_match_sift_features(dsm_ctx* ctx, const dsm_match_options* options, cons
   rc = dsm_get_matches(lf, offs, nullptr, 0);
   if (rc != DSM_OK) return fail(ctx, rc, lf->err.c_str());
   if (offs[1] && !matches) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "null matches buffer");
-  rc = dsm_get_matches(lf, nullptr, matches, std::min<uint64_t>(n1, n2));
+  rc = dsm_get_matches(lf, nullptr, matches, options->cross_check ? std::min<uint64_t>(n1, n2) : n1);
   if (rc != DSM_OK) return fail(ctx, rc, lf->err.c_str());
   *n_matches = (uint32_t)offs[1];
   return DSM_OK;

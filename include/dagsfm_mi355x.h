@@ -154,7 +154,7 @@ int dsm_get_matches(dsm_ctx* ctx, uint64_t* offsets, uint32_t* matches,
 /* One-shot leaf with the signature shape of MatchSiftFeaturesCPU
  * (src/feature/sift.h:214-217) / MatchSiftFeaturesGPU (sift.h:229-239):
  * host descriptors in, FeatureMatches out.  `matches` must hold
- * min(n1,n2) x 2 uint32. */
+ * min(n1,n2) x 2 uint32 with cross_check, n1 x 2 uint32 without. */
 int dsm_match_sift_features(dsm_ctx* ctx, const dsm_match_options* options,
                             const uint8_t* desc1, uint32_t n1,
                             const uint8_t* desc2, uint32_t n2,

@@ -66,7 +66,7 @@ static size_t find_best_matches_one_way(const int* dists, int rows, int cols, si
 }
 
 /* MatchSiftFeaturesCPU (sift.cc:810-822) = distance matrix + FindBestMatches (sift.cc:164-198).
- * matches_out holds min(n1,n2) x 2 uint32; returns the number of matches. */
+ * matches_out holds n1 x 2 uint32; returns the number of matches. */
 int oracle_match_sift_features_cpu(double max_ratio_d, double max_distance_d, int cross_check, const uint8_t* d1,
                                    int n1, const uint8_t* d2, int n2, uint32_t* matches_out) {
   if (n1 <= 0 || n2 <= 0) return 0; /* Eigen 0-row matrices: no matches (sift_test.cc:316-324) */

@@ -39,7 +39,7 @@ class Oracle:
         d1 = np.ascontiguousarray(desc1, dtype=np.uint8).reshape(-1, 128)
         d2 = np.ascontiguousarray(desc2, dtype=np.uint8).reshape(-1, 128)
         n1, n2 = d1.shape[0], d2.shape[0]
-        out = np.zeros((max(min(n1, n2), 1), 2), dtype=np.uint32)
+        out = np.zeros((max(n1, 1), 2), dtype=np.uint32)
         n = self.lib.oracle_match_sift_features_cpu(max_ratio, max_distance, int(bool(cross_check)),
                                                     d1.ctypes.data_as(u8p), n1, d2.ctypes.data_as(u8p), n2,
                                                     out.ctypes.data_as(u32p))
