@@ -33,6 +33,7 @@ class Oracle:
         lib.oracle_create_random_feature_descriptors.argtypes = [ctypes.c_int, u8p]
         lib.oracle_l2_normalize_to_u8.restype = None
         lib.oracle_l2_normalize_to_u8.argtypes = [f32p, u8p]
+        self._init_two_view()
 
     # MatchSiftFeaturesCPU, /root/reference/src/feature/sift.cc:810-822
     def match_sift_features_cpu(self, desc1, desc2, max_ratio=0.8, max_distance=0.7, cross_check=True):
@@ -50,6 +51,167 @@ class Oracle:
         out = np.zeros((n, 128), dtype=np.uint8)
         if n:
             self.lib.oracle_create_random_feature_descriptors(n, out.ctypes.data_as(u8p))
+        return out
+
+    # ---------------------------------------------------------------- two-view verification
+    def _init_two_view(self):
+        from dagsfm_amd import capi
+        L = self.lib
+        cam_p = ctypes.POINTER(capi.Camera)
+        L.oracle_estimate_two_view_geometry.restype = None
+        L.oracle_estimate_two_view_geometry.argtypes = [cam_p, f64p, ctypes.c_int, cam_p, f64p, ctypes.c_int, u32p,
+                                                        ctypes.c_int, ctypes.POINTER(capi.TwoViewOptions),
+                                                        ctypes.c_uint32, ctypes.POINTER(capi.TwoViewGeometry), u32p]
+        L.oracle_compute_num_trials.restype = ctypes.c_uint64
+        L.oracle_compute_num_trials.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_double, ctypes.c_int]
+        L.oracle_estimate_model.restype = ctypes.c_int
+        L.oracle_estimate_model.argtypes = [ctypes.c_int, f64p, f64p, ctypes.c_int, f64p]
+        L.oracle_residuals.restype = None
+        L.oracle_residuals.argtypes = [ctypes.c_int, f64p, f64p, ctypes.c_int, f64p, f64p]
+        L.oracle_center_and_normalize.restype = None
+        L.oracle_center_and_normalize.argtypes = [f64p, ctypes.c_int, f64p, f64p]
+        L.oracle_poly_roots.restype = ctypes.c_int
+        L.oracle_poly_roots.argtypes = [f64p, ctypes.c_int, f64p, f64p]
+        L.oracle_jacobi_svd.restype = None
+        L.oracle_jacobi_svd.argtypes = [f64p, ctypes.c_int, ctypes.c_int, f64p, f64p, f64p]
+        L.oracle_eigenvalues.restype = ctypes.c_int
+        L.oracle_eigenvalues.argtypes = [f64p, ctypes.c_int, f64p, f64p]
+        L.oracle_loransac.restype = ctypes.c_uint64
+        L.oracle_loransac.argtypes = [ctypes.c_int, f64p, f64p, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                      ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
+                                      ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, f64p]
+        L.oracle_decompose_essential.restype = None
+        L.oracle_decompose_essential.argtypes = [f64p, f64p, f64p, f64p]
+        L.oracle_pose_from_essential.restype = ctypes.c_int
+        L.oracle_pose_from_essential.argtypes = [f64p, f64p, f64p, ctypes.c_int, f64p, f64p]
+        L.oracle_decompose_homography.restype = ctypes.c_int
+        L.oracle_decompose_homography.argtypes = [f64p, f64p, f64p, f64p, f64p, f64p]
+        L.oracle_triangulate_point.restype = None
+        L.oracle_triangulate_point.argtypes = [f64p, f64p, f64p, f64p, f64p]
+        L.oracle_rotation_to_quaternion.restype = None
+        L.oracle_rotation_to_quaternion.argtypes = [f64p, f64p]
+        L.oracle_image_to_world.restype = None
+        L.oracle_image_to_world.argtypes = [cam_p, f64p, f64p]
+        L.oracle_sample_sequence.restype = None
+        L.oracle_sample_sequence.argtypes = [ctypes.c_uint32] * 4 + [u32p]
+
+    @staticmethod
+    def _d(a):
+        return np.ascontiguousarray(a, dtype=np.float64)
+
+    # TwoViewGeometry::Estimate, /root/reference/src/estimators/two_view_geometry.cc:113-126
+    def estimate_two_view_geometry(self, cam1, pts1, cam2, pts2, matches, options, seed):
+        from dagsfm_amd import capi
+        p1, p2 = self._d(pts1).reshape(-1, 2), self._d(pts2).reshape(-1, 2)
+        m = np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 2)
+        out = capi.TwoViewGeometry()
+        inl = np.zeros((max(len(m), 1), 2), dtype=np.uint32)
+        self.lib.oracle_estimate_two_view_geometry(ctypes.byref(cam1), p1.ctypes.data_as(f64p), len(p1),
+                                                   ctypes.byref(cam2), p2.ctypes.data_as(f64p), len(p2),
+                                                   m.ctypes.data_as(u32p), len(m), ctypes.byref(options),
+                                                   ctypes.c_uint32(seed), ctypes.byref(out), inl.ctypes.data_as(u32p))
+        return out, inl[:out.num_inliers].copy()
+
+    def compute_num_trials(self, num_inliers, num_samples, confidence, min_samples):
+        return int(self.lib.oracle_compute_num_trials(num_inliers, num_samples, confidence, min_samples))
+
+    def estimate_model(self, kind, pts1, pts2):
+        p1, p2 = self._d(pts1).reshape(-1, 2), self._d(pts2).reshape(-1, 2)
+        out = np.zeros((10, 3, 3))
+        n = self.lib.oracle_estimate_model(kind, p1.ctypes.data_as(f64p), p2.ctypes.data_as(f64p), len(p1),
+                                           out.ctypes.data_as(f64p))
+        return out[:n].copy()
+
+    def residuals(self, kind, pts1, pts2, model):
+        p1, p2, M = self._d(pts1).reshape(-1, 2), self._d(pts2).reshape(-1, 2), self._d(model).reshape(9)
+        out = np.zeros(len(p1))
+        self.lib.oracle_residuals(kind, p1.ctypes.data_as(f64p), p2.ctypes.data_as(f64p), len(p1),
+                                  M.ctypes.data_as(f64p), out.ctypes.data_as(f64p))
+        return out
+
+    def center_and_normalize(self, pts):
+        p = self._d(pts).reshape(-1, 2)
+        normed, M = np.zeros_like(p), np.zeros((3, 3))
+        self.lib.oracle_center_and_normalize(p.ctypes.data_as(f64p), len(p), normed.ctypes.data_as(f64p),
+                                             M.ctypes.data_as(f64p))
+        return normed, M
+
+    def poly_roots(self, coeffs):
+        c = self._d(coeffs)
+        re, im = np.zeros(len(c) + 2), np.zeros(len(c) + 2)
+        n = self.lib.oracle_poly_roots(c.ctypes.data_as(f64p), len(c), re.ctypes.data_as(f64p), im.ctypes.data_as(f64p))
+        return (None, None) if n < 0 else (re[:n].copy(), im[:n].copy())
+
+    def jacobi_svd(self, A):
+        A = self._d(A)
+        r, c = A.shape
+        U, S, V = np.zeros((r, r)), np.zeros(min(r, c)), np.zeros((c, c))
+        self.lib.oracle_jacobi_svd(A.ctypes.data_as(f64p), r, c, U.ctypes.data_as(f64p), S.ctypes.data_as(f64p),
+                                   V.ctypes.data_as(f64p))
+        return U, S, V
+
+    def eigenvalues(self, A):
+        A = self._d(A)
+        n = A.shape[0]
+        re, im = np.zeros(n), np.zeros(n)
+        k = self.lib.oracle_eigenvalues(A.ctypes.data_as(f64p), n, re.ctypes.data_as(f64p), im.ctypes.data_as(f64p))
+        return None if k < 0 else re + 1j * im
+
+    def loransac(self, family, pts1, pts2, max_error, min_inlier_ratio=0.25, confidence=0.999, min_trials=30,
+                 max_trials=10000, seed=0):
+        p1, p2 = self._d(pts1).reshape(-1, 2), self._d(pts2).reshape(-1, 2)
+        ok, nt = ctypes.c_int(0), ctypes.c_uint64(0)
+        mask = ctypes.create_string_buffer(max(len(p1), 1))
+        model = np.zeros(9)
+        ninl = self.lib.oracle_loransac(family, p1.ctypes.data_as(f64p), p2.ctypes.data_as(f64p), len(p1), max_error,
+                                        min_inlier_ratio, confidence, min_trials, max_trials, seed, ctypes.byref(ok),
+                                        ctypes.byref(nt), mask, model.ctypes.data_as(f64p))
+        m = np.frombuffer(mask.raw, dtype=np.uint8)[:len(p1)].copy() if ok.value else np.zeros(0, np.uint8)
+        return dict(success=bool(ok.value), num_trials=nt.value, num_inliers=int(ninl), mask=m, model=model)
+
+    def decompose_essential(self, E):
+        E = self._d(E)
+        R1, R2, t = np.zeros((3, 3)), np.zeros((3, 3)), np.zeros(3)
+        self.lib.oracle_decompose_essential(E.ctypes.data_as(f64p), R1.ctypes.data_as(f64p), R2.ctypes.data_as(f64p),
+                                            t.ctypes.data_as(f64p))
+        return R1, R2, t
+
+    def pose_from_essential(self, E, pts1, pts2):
+        E, p1, p2 = self._d(E), self._d(pts1).reshape(-1, 2), self._d(pts2).reshape(-1, 2)
+        R, t = np.zeros((3, 3)), np.zeros(3)
+        n = self.lib.oracle_pose_from_essential(E.ctypes.data_as(f64p), p1.ctypes.data_as(f64p), p2.ctypes.data_as(f64p),
+                                                len(p1), R.ctypes.data_as(f64p), t.ctypes.data_as(f64p))
+        return R, t, n
+
+    def decompose_homography(self, H, K1, K2):
+        H, K1, K2 = self._d(H), self._d(K1), self._d(K2)
+        R, t, n = np.zeros((4, 3, 3)), np.zeros((4, 3)), np.zeros((4, 3))
+        k = self.lib.oracle_decompose_homography(H.ctypes.data_as(f64p), K1.ctypes.data_as(f64p), K2.ctypes.data_as(f64p),
+                                                 R.ctypes.data_as(f64p), t.ctypes.data_as(f64p), n.ctypes.data_as(f64p))
+        return R[:k], t[:k], n[:k]
+
+    def triangulate_point(self, P1, P2, p1, p2):
+        P1, P2, p1, p2 = self._d(P1), self._d(P2), self._d(p1), self._d(p2)
+        X = np.zeros(3)
+        self.lib.oracle_triangulate_point(P1.ctypes.data_as(f64p), P2.ctypes.data_as(f64p), p1.ctypes.data_as(f64p),
+                                          p2.ctypes.data_as(f64p), X.ctypes.data_as(f64p))
+        return X
+
+    def rotation_to_quaternion(self, R):
+        R = self._d(R)
+        q = np.zeros(4)
+        self.lib.oracle_rotation_to_quaternion(R.ctypes.data_as(f64p), q.ctypes.data_as(f64p))
+        return q
+
+    def image_to_world(self, cam, p):
+        p = self._d(p)
+        w = np.zeros(2)
+        self.lib.oracle_image_to_world(ctypes.byref(cam), p.ctypes.data_as(f64p), w.ctypes.data_as(f64p))
+        return w
+
+    def sample_sequence(self, seed, k, total, n_draws):
+        out = np.zeros((n_draws, k), dtype=np.uint32)
+        self.lib.oracle_sample_sequence(seed, k, total, n_draws, out.ctypes.data_as(u32p))
         return out
 
     def l2_normalize_to_u8(self, row):
