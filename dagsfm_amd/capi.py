@@ -72,12 +72,34 @@ def lib():
         L.dsm_match_sift_features.argtypes = [vp, ctypes.POINTER(MatchOptions), u8p, ctypes.c_uint32, u8p,
                                               ctypes.c_uint32, u32p, u32p]
         L.dsm_get_match_kernel_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double), u32p]
+        L.dsm_pair_seed.argtypes = [ctypes.c_uint32] * 3
+        L.dsm_pair_seed.restype = ctypes.c_uint32
+        L.dsm_verify_pairs.argtypes = [vp, ctypes.POINTER(TwoViewOptions), u32p, ctypes.c_uint32, ctypes.c_int32]
+        L.dsm_get_two_view_geometries.argtypes = [vp, vp]
+        L.dsm_get_inlier_matches.argtypes = [vp, vp, vp, ctypes.c_uint64]
+        L.dsm_get_verify_kernel_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+        L.dsm_estimate_two_view_geometry.argtypes = [vp, ctypes.POINTER(Camera), ctypes.POINTER(ctypes.c_double),
+                                                     ctypes.c_uint32, ctypes.POINTER(Camera),
+                                                     ctypes.POINTER(ctypes.c_double), ctypes.c_uint32, u32p, ctypes.c_uint32,
+                                                     ctypes.POINTER(TwoViewOptions), ctypes.c_uint32,
+                                                     ctypes.POINTER(TwoViewGeometry), u32p]
+        L.dsm_debug_sample_sequence.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, u32p]
         L.dsm_default_match_options.argtypes = [ctypes.POINTER(MatchOptions)]
         L.dsm_default_match_options.restype = None
         L.dsm_default_two_view_options.argtypes = [ctypes.POINTER(TwoViewOptions)]
         L.dsm_default_two_view_options.restype = None
         _lib = L
     return _lib
+
+
+def pair_seed(id1, id2, user_seed=0):
+    return int(lib().dsm_pair_seed(id1, id2, user_seed))
+
+
+def simple_pinhole(f, cx, cy, width, height, prior=True):
+    c = Camera(model_id=0, has_prior_focal_length=int(bool(prior)), width=width, height=height)
+    c.params[0], c.params[1], c.params[2] = f, cx, cy
+    return c
 
 
 def default_match_options(**kw):
@@ -178,6 +200,53 @@ class Context:
                                                 d2.ctypes.data_as(u8p), d2.shape[0], out.ctypes.data_as(u32p),
                                                 ctypes.byref(n)))
         return out[:n.value].copy()
+
+    def verify_pairs(self, options=None, seeds=None, user_seed=0, stage_filter=True):
+        options = options or default_two_view_options()
+        sp = None
+        if seeds is not None:
+            self._seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+            assert len(self._seeds) == self.n_pairs
+            sp = self._seeds.ctypes.data_as(u32p)
+        self._chk(lib().dsm_verify_pairs(self._h, ctypes.byref(options), sp, user_seed, int(bool(stage_filter))))
+
+    def two_view_geometries(self):
+        arr = (TwoViewGeometry * max(self.n_pairs, 1))()
+        self._chk(lib().dsm_get_two_view_geometries(self._h, ctypes.addressof(arr)))
+        return list(arr)[:self.n_pairs]
+
+    def inlier_matches(self):
+        offs = np.zeros(self.n_pairs + 1, dtype=np.uint64)
+        self._chk(lib().dsm_get_inlier_matches(self._h, offs.ctypes.data, None, 0))
+        total = int(offs[-1])
+        m = np.zeros((max(total, 1), 2), dtype=np.uint32)
+        self._chk(lib().dsm_get_inlier_matches(self._h, None, m.ctypes.data, total))
+        return offs, m[:total]
+
+    def verify_kernel_time(self):
+        ms = ctypes.c_double(0)
+        self._chk(lib().dsm_get_verify_kernel_time(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def estimate_two_view_geometry(self, cam1, pts1, cam2, pts2, matches, options=None, seed=0):
+        """TwoViewGeometry::Estimate-shaped leaf, /root/reference/src/estimators/two_view_geometry.h:180-184."""
+        options = options or default_two_view_options()
+        p1 = np.ascontiguousarray(pts1, dtype=np.float64).reshape(-1, 2)
+        p2 = np.ascontiguousarray(pts2, dtype=np.float64).reshape(-1, 2)
+        m = np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 2)
+        out = TwoViewGeometry()
+        inl = np.zeros((max(len(m), 1), 2), dtype=np.uint32)
+        dp = ctypes.POINTER(ctypes.c_double)
+        self._chk(lib().dsm_estimate_two_view_geometry(self._h, ctypes.byref(cam1), p1.ctypes.data_as(dp), len(p1),
+                                                       ctypes.byref(cam2), p2.ctypes.data_as(dp), len(p2),
+                                                       m.ctypes.data_as(u32p), len(m), ctypes.byref(options), seed,
+                                                       ctypes.byref(out), inl.ctypes.data_as(u32p)))
+        return out, inl[:out.num_inliers].copy()
+
+    def debug_sample_sequence(self, seed, k, total, n_draws):
+        out = np.zeros((n_draws, k), dtype=np.uint32)
+        self._chk(lib().dsm_debug_sample_sequence(self._h, seed, k, total, n_draws, out.ctypes.data_as(u32p)))
+        return out
 
     def match_kernel_time(self):
         ms = ctypes.c_double(0)

@@ -99,7 +99,20 @@ struct dsm_ctx {
   uint32_t k1_launches = 0;
   std::vector<hipEvent_t> ev;
 
-  dsm_ctx* leaf = nullptr;  // private context of dsm_match_sift_features
+  // last dsm_verify_pairs
+  bool verified = false;
+  DevBuf d_cams, d_pairs_dev, d_seeds, d_tvg, d_inl, d_inl_counts, d_inl_off, d_inl_compact, d_vscratch, d_inl_total;
+  DevBuf d_nt_table, d_nt_off, d_nt_off_t;
+  uint64_t total_inliers = 0;
+  double verify_ms = 0.0;
+  // cache of the tabulated RANSAC::ComputeNumTrials (host libm), keyed by confidence
+  double nt_confidence = -1.0;
+  std::vector<uint32_t> nt_table;        // all tables back to back
+  std::vector<uint64_t> nt_off, nt_off_t;  // per N (0 = absent; offsets are stored +1)
+  bool nt_dirty = true;
+  hipEvent_t vev0 = nullptr, vev1 = nullptr;
+
+  dsm_ctx* leaf = nullptr;  // private context of the one-shot leaf entry points
 };
 
 #define HIPCHK(ctx, call)                                                              \
@@ -191,7 +204,11 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
   for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&ctx->d_desc, &ctx->d_rterm, &ctx->d_kp, &ctx->d_img_row0, &ctx->d_img_rows, &ctx->d_lut,
                     &ctx->d_dpairs, &ctx->d_doutoff, &ctx->d_pair_dir, &ctx->d_m, &ctx->d_counts,
-                    &ctx->d_offsets, &ctx->d_matches, &ctx->d_total};
+                    &ctx->d_offsets, &ctx->d_matches, &ctx->d_total, &ctx->d_cams, &ctx->d_pairs_dev, &ctx->d_seeds,
+                    &ctx->d_tvg, &ctx->d_inl, &ctx->d_inl_counts, &ctx->d_inl_off, &ctx->d_inl_compact,
+                    &ctx->d_vscratch, &ctx->d_inl_total, &ctx->d_nt_table, &ctx->d_nt_off, &ctx->d_nt_off_t};
+  if (ctx->vev0) (void)hipEventDestroy(ctx->vev0);
+  if (ctx->vev1) (void)hipEventDestroy(ctx->vev1);
   for (DevBuf* b : bufs) b->release();
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -213,6 +230,7 @@ int dsm_set_images(dsm_ctx* ctx, uint32_t n_images, const uint32_t* n_feats, con
   if (kp_xy && kp_stride < 2) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "kp_stride must be >= 2");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->matched = false;
+  ctx->verified = false;
   ctx->n_images = n_images;
   ctx->nfeat.assign(n_feats, n_feats + n_images);
   ctx->row0.resize(n_images);
@@ -280,6 +298,7 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   ctx->matched = false;
+  ctx->verified = false;
   ctx->n_pairs = n_pairs;
   ctx->pairs.assign(pairs, pairs + (size_t)n_pairs * 2);
   ctx->k1_ms = 0.0;
@@ -459,6 +478,301 @@ int dsm_match_sift_features(dsm_ctx* ctx, const dsm_match_options* options, cons
   rc = dsm_get_matches(lf, nullptr, matches, options->cross_check ? std::min<uint64_t>(n1, n2) : n1);
   if (rc != DSM_OK) return fail(ctx, rc, lf->err.c_str());
   *n_matches = (uint32_t)offs[1];
+  return DSM_OK;
+}
+
+
+// ------------------------------------------------------------------------------------ verification
+
+// RANSAC::ComputeNumTrials, /root/reference/src/optim/ransac.h:150-167, evaluated with the host libm.
+// static_cast<size_t> of a non-finite / negative quotient is what x86-64 cvttsd2si makes of it
+// (0x8000...): "never stop"; stored saturated.
+static uint32_t host_num_trials(uint64_t num_inliers, uint64_t num_samples, double confidence, int min_samples) {
+  const double inlier_ratio = num_inliers / static_cast<double>(num_samples);
+  const double nom = 1 - confidence;
+  if (nom <= 0) return 0xffffffffu;
+  const double denom = 1 - pow(inlier_ratio, min_samples);
+  if (denom <= 0) return 1;
+  const double v = ceil(log(nom) / log(denom));
+  if (!(v >= 0.0) || !(v < 4294967295.0)) return 0xffffffffu;
+  return (uint32_t)v;
+}
+
+static uint32_t ransac_ctor_max_trials(const dsm_two_view_options* o, double min_inlier_ratio, int min_samples) {
+  // RANSAC ctor, ransac.h:135-148
+  const uint64_t kNumSamples = 100000;
+  const uint32_t dyn = host_num_trials((uint64_t)(min_inlier_ratio * kNumSamples), kNumSamples, o->confidence, min_samples);
+  const uint64_t mx = o->max_num_trials;
+  return (uint32_t)std::min<uint64_t>(std::min<uint64_t>(mx, dyn), 0xffffffffull);
+}
+
+static const int kMinSamples[4] = {5, 7, 4, 1};
+
+// makes sure the ComputeNumTrials tables for the given match counts (E/F/H) and for every inlier
+// count up to n_max (translation) exist on the device
+static int ensure_nt_tables(dsm_ctx* ctx, const dsm_two_view_options* o, const std::vector<uint32_t>& counts, uint32_t n_max) {
+  if (ctx->nt_confidence != o->confidence) {
+    ctx->nt_confidence = o->confidence;
+    ctx->nt_table.clear();
+    ctx->nt_off.clear();
+    ctx->nt_off_t.clear();
+    ctx->nt_dirty = true;
+  }
+  if (ctx->nt_off.size() < (size_t)n_max + 1) {
+    ctx->nt_off.resize((size_t)n_max + 1, 0);
+    ctx->nt_dirty = true;
+  }
+  const size_t old_t = ctx->nt_off_t.size();
+  if (old_t < (size_t)n_max + 1) {
+    ctx->nt_off_t.resize((size_t)n_max + 1, 0);
+    for (size_t N = old_t; N <= n_max; ++N) {
+      ctx->nt_off_t[N] = ctx->nt_table.size();
+      for (size_t k = 0; k <= N; ++k) ctx->nt_table.push_back(host_num_trials(k, N, o->confidence, kMinSamples[3]));
+    }
+    ctx->nt_dirty = true;
+  }
+  for (uint32_t N : counts) {
+    if (N > n_max || ctx->nt_off[N] != 0) continue;
+    ctx->nt_off[N] = ctx->nt_table.size() + 1;  // +1: 0 means absent
+    for (int f = 0; f < 3; ++f)
+      for (size_t k = 0; k <= N; ++k) ctx->nt_table.push_back(host_num_trials(k, N, o->confidence, kMinSamples[f]));
+    ctx->nt_dirty = true;
+  }
+  if (ctx->nt_dirty) {
+    std::vector<uint64_t> off(ctx->nt_off.size());
+    for (size_t i = 0; i < off.size(); ++i) off[i] = ctx->nt_off[i] ? ctx->nt_off[i] - 1 : 0;
+    HIPCHK(ctx, ctx->d_nt_table.reserve(std::max<size_t>(ctx->nt_table.size(), 1) * 4));
+    HIPCHK(ctx, ctx->d_nt_off.reserve(off.size() * 8));
+    HIPCHK(ctx, ctx->d_nt_off_t.reserve(ctx->nt_off_t.size() * 8));
+    HIPCHK(ctx, hipMemcpy(ctx->d_nt_table.p, ctx->nt_table.data(), ctx->nt_table.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_nt_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_nt_off_t.p, ctx->nt_off_t.data(), ctx->nt_off_t.size() * 8, hipMemcpyHostToDevice));
+    ctx->nt_dirty = false;
+  }
+  return DSM_OK;
+}
+
+// core: verifies n_pairs pairs whose matches/keypoints/cameras are already on the device
+static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, const uint64_t* d_match_off,
+                       const uint32_t* d_matches, uint64_t total_matches, const std::vector<uint32_t>& counts,
+                       const double* d_kp, const uint32_t* d_img_row0, const dsm_camera* d_cams,
+                       const dsm_two_view_options* o, const uint32_t* d_seeds, int stage_filter) {
+  hipStream_t st = ctx->stream;
+  uint32_t n_max = 1;
+  for (uint32_t c : counts) n_max = std::max(n_max, c);
+  int rc = ensure_nt_tables(ctx, o, counts, n_max);
+  if (rc != DSM_OK) return rc;
+  HIPCHK(ctx, ctx->d_tvg.reserve(std::max<uint32_t>(n_pairs, 1) * sizeof(dsm_two_view_geometry)));
+  HIPCHK(ctx, ctx->d_inl.reserve(std::max<uint64_t>(total_matches, 1) * 8));
+  HIPCHK(ctx, ctx->d_inl_counts.reserve(std::max<uint32_t>(n_pairs, 1) * 4));
+  HIPCHK(ctx, ctx->d_inl_off.reserve(((size_t)n_pairs + 1) * 8));
+  HIPCHK(ctx, ctx->d_inl_total.reserve(8));
+  int dev_cus = 256;
+  (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+  const uint32_t n_blocks = std::min<uint32_t>(n_pairs, (uint32_t)dev_cus * 8u);
+  HIPCHK(ctx, ctx->d_vscratch.reserve(std::max<size_t>(1, (size_t)n_blocks * verify_scratch_bytes_per_block(n_max))));
+  VerifyParams vp;
+  vp.pairs = d_pairs;
+  vp.match_off = d_match_off;
+  vp.matches = d_matches;
+  vp.kp = d_kp;
+  vp.img_row0 = d_img_row0;
+  vp.cams = d_cams;
+  vp.opt = *o;
+  vp.seeds = d_seeds;
+  vp.nt_table = ctx->d_nt_table.as<uint32_t>();
+  vp.nt_off = ctx->d_nt_off.as<uint64_t>();
+  vp.nt_off_t = ctx->d_nt_off_t.as<uint64_t>();
+  vp.max_trials[0] = ransac_ctor_max_trials(o, o->min_inlier_ratio, kMinSamples[0]);
+  vp.max_trials[1] = ransac_ctor_max_trials(o, o->min_inlier_ratio, kMinSamples[1]);
+  vp.max_trials[2] = ransac_ctor_max_trials(o, o->min_inlier_ratio, kMinSamples[2]);
+  vp.max_trials[3] = ransac_ctor_max_trials(o, o->watermark_min_inlier_ratio, kMinSamples[3]);  // two_view_geometry.cc:541-542
+  vp.tvg = ctx->d_tvg.as<dsm_two_view_geometry>();
+  vp.inlier_matches = ctx->d_inl.as<uint32_t>();
+  vp.inl_counts = ctx->d_inl_counts.as<uint32_t>();
+  vp.scratch = ctx->d_vscratch.as<double>();
+  vp.n_pairs = n_pairs;
+  vp.n_max = n_max;
+  vp.stage_filter = stage_filter;
+  if (!ctx->vev0) {
+    HIPCHK(ctx, hipEventCreate(&ctx->vev0));
+    HIPCHK(ctx, hipEventCreate(&ctx->vev1));
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->vev0, st));
+  launch_verify(vp, n_blocks, st);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipEventRecord(ctx->vev1, st));
+  // compact inlier matches in list order
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_inl_total.p, 0, 8, st));
+  launch_scan(ctx->d_inl_counts.as<uint32_t>(), ctx->d_inl_off.as<uint64_t>(), n_pairs, ctx->d_inl_total.as<uint64_t>(), st);
+  HIPCHK(ctx, hipGetLastError());
+  uint64_t total = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&total, ctx->d_inl_total.p, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  ctx->total_inliers = total;
+  HIPCHK(ctx, ctx->d_inl_compact.reserve(std::max<uint64_t>(total, 1) * 8));
+  launch_compact_inliers(d_match_off, ctx->d_inl_off.as<uint64_t>(), ctx->d_inl_counts.as<uint32_t>(), ctx->d_inl.as<uint32_t>(),
+                         ctx->d_inl_compact.as<uint32_t>(), n_pairs, st);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  float ms = 0.f;
+  HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->vev0, ctx->vev1));
+  ctx->verify_ms = ms;
+  return DSM_OK;
+}
+
+uint32_t dsm_pair_seed(uint32_t image_id1, uint32_t image_id2, uint32_t user_seed) {
+  // pair_id as Database::ImagePairToPairId (/root/reference/src/base/database.h:336-347), then a 32-bit mix
+  const uint64_t kMaxNumImages = 2147483647ull;
+  const uint64_t a = std::min(image_id1, image_id2), b = std::max(image_id1, image_id2);
+  uint64_t h = kMaxNumImages * a + b;
+  h ^= h >> 33;
+  h *= 0xff51afd7ed558ccdull;
+  h ^= h >> 33;
+  h *= 0xc4ceb9fe1a85ec53ull;
+  h ^= h >> 33;
+  return (uint32_t)h ^ user_seed;
+}
+
+int dsm_verify_pairs(dsm_ctx* ctx, const dsm_two_view_options* options, const uint32_t* seeds, uint32_t user_seed,
+                     int32_t stage_filter) {
+  if (!ctx || !options) return DSM_ERR_INVALID_ARGUMENT;
+  if (!ctx->matched) return fail(ctx, DSM_ERR_NOT_READY, "dsm_match_pairs has not run");
+  if (!ctx->have_kp || ctx->cameras.size() != ctx->n_images)
+    return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "dsm_set_images was called without keypoints/cameras");
+  // RANSACOptions::Check, ransac.h:63-71; TwoViewGeometry::Options::Check
+  if (!(options->max_error > 0) || options->min_inlier_ratio < 0 || options->min_inlier_ratio > 1 ||
+      options->confidence < 0 || options->confidence > 1 || options->min_num_trials > options->max_num_trials)
+    return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "invalid RANSAC options");
+  if (options->multiple_models) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "multiple_models is not supported");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->verified = false;
+  const uint32_t np = ctx->n_pairs;
+  std::vector<uint32_t> counts(np), sd(np);
+  if (np) HIPCHK(ctx, hipMemcpy(counts.data(), ctx->d_counts.p, (size_t)np * 4, hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < np; ++i)
+    sd[i] = seeds ? seeds[i] : dsm_pair_seed(ctx->pairs[2 * i], ctx->pairs[2 * i + 1], user_seed);
+  HIPCHK(ctx, ctx->d_cams.reserve(std::max<uint32_t>(ctx->n_images, 1) * sizeof(dsm_camera)));
+  HIPCHK(ctx, ctx->d_pairs_dev.reserve(std::max<uint32_t>(np, 1) * 8));
+  HIPCHK(ctx, ctx->d_seeds.reserve(std::max<uint32_t>(np, 1) * 4));
+  if (ctx->n_images)
+    HIPCHK(ctx, hipMemcpy(ctx->d_cams.p, ctx->cameras.data(), ctx->n_images * sizeof(dsm_camera), hipMemcpyHostToDevice));
+  if (np) {
+    HIPCHK(ctx, hipMemcpy(ctx->d_pairs_dev.p, ctx->pairs.data(), (size_t)np * 8, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_seeds.p, sd.data(), (size_t)np * 4, hipMemcpyHostToDevice));
+  }
+  int rc = verify_core(ctx, np, ctx->d_pairs_dev.as<uint32_t>(), ctx->d_offsets.as<uint64_t>(), ctx->d_matches.as<uint32_t>(),
+                       ctx->total_matches, counts, ctx->d_kp.as<double>(), ctx->d_img_row0.as<uint32_t>(),
+                       ctx->d_cams.as<dsm_camera>(), options, ctx->d_seeds.as<uint32_t>(), stage_filter);
+  if (rc != DSM_OK) return rc;
+  ctx->verified = true;
+  return DSM_OK;
+}
+
+int dsm_get_two_view_geometries(dsm_ctx* ctx, dsm_two_view_geometry* out) {
+  if (!ctx || !out) return DSM_ERR_INVALID_ARGUMENT;
+  if (!ctx->verified) return fail(ctx, DSM_ERR_NOT_READY, "dsm_verify_pairs has not run");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->n_pairs)
+    HIPCHK(ctx, hipMemcpy(out, ctx->d_tvg.p, (size_t)ctx->n_pairs * sizeof(dsm_two_view_geometry), hipMemcpyDefault));
+  return DSM_OK;
+}
+
+int dsm_get_inlier_matches(dsm_ctx* ctx, uint64_t* offsets, uint32_t* inlier_matches, uint64_t capacity) {
+  if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
+  if (!ctx->verified) return fail(ctx, DSM_ERR_NOT_READY, "dsm_verify_pairs has not run");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (offsets) HIPCHK(ctx, hipMemcpy(offsets, ctx->d_inl_off.p, ((size_t)ctx->n_pairs + 1) * 8, hipMemcpyDefault));
+  if (inlier_matches) {
+    if (capacity < ctx->total_inliers) return fail(ctx, DSM_ERR_OUT_OF_RANGE, "inlier_matches buffer too small");
+    if (ctx->total_inliers)
+      HIPCHK(ctx, hipMemcpy(inlier_matches, ctx->d_inl_compact.p, ctx->total_inliers * 8, hipMemcpyDefault));
+  }
+  return DSM_OK;
+}
+
+int dsm_get_verify_kernel_time(dsm_ctx* ctx, double* total_ms) {
+  if (!ctx || !total_ms) return DSM_ERR_INVALID_ARGUMENT;
+  if (!ctx->verified) return fail(ctx, DSM_ERR_NOT_READY, "dsm_verify_pairs has not run");
+  *total_ms = ctx->verify_ms;
+  return DSM_OK;
+}
+
+int dsm_estimate_two_view_geometry(dsm_ctx* ctx, const dsm_camera* camera1, const double* points1, uint32_t n1,
+                                   const dsm_camera* camera2, const double* points2, uint32_t n2,
+                                   const uint32_t* matches, uint32_t n_matches, const dsm_two_view_options* options,
+                                   uint32_t seed, dsm_two_view_geometry* out, uint32_t* inlier_matches) {
+  if (!ctx || !camera1 || !camera2 || !options || !out || (n_matches && (!matches || !points1 || !points2)))
+    return DSM_ERR_INVALID_ARGUMENT;
+  for (uint32_t i = 0; i < n_matches; ++i)
+    if (matches[2 * i] >= n1 || matches[2 * i + 1] >= n2) return fail(ctx, DSM_ERR_OUT_OF_RANGE, "match index out of range");
+  if (!ctx->leaf) {
+    int rc = dsm_ctx_create(ctx->device, &ctx->leaf);
+    if (rc != DSM_OK) return fail(ctx, rc, dsm_last_error(nullptr));
+  }
+  dsm_ctx* lf = ctx->leaf;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  DevBuf kp, row0, cams, pr, off, mt, sd;
+  const uint32_t rows0[2] = {0, n1};
+  const dsm_camera cc[2] = {*camera1, *camera2};
+  const uint32_t prs[2] = {0, 1};
+  const uint64_t offs[2] = {0, n_matches};
+  int rc = DSM_OK;
+#define LCHK(call)                                                      \
+  do {                                                                  \
+    hipError_t e_ = (call);                                             \
+    if (e_ != hipSuccess && rc == DSM_OK) {                             \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);     \
+      rc = DSM_ERR_HIP;                                                 \
+    }                                                                   \
+  } while (0)
+  LCHK(kp.reserve(std::max<size_t>((size_t)(n1 + n2) * 16, 16)));
+  LCHK(row0.reserve(8));
+  LCHK(cams.reserve(2 * sizeof(dsm_camera)));
+  LCHK(pr.reserve(8));
+  LCHK(off.reserve(16));
+  LCHK(mt.reserve(std::max<size_t>((size_t)n_matches * 8, 8)));
+  LCHK(sd.reserve(4));
+  if (rc == DSM_OK) {
+    if (n1) LCHK(hipMemcpy(kp.p, points1, (size_t)n1 * 16, hipMemcpyHostToDevice));
+    if (n2) LCHK(hipMemcpy(kp.as<double>() + 2 * (size_t)n1, points2, (size_t)n2 * 16, hipMemcpyHostToDevice));
+    LCHK(hipMemcpy(row0.p, rows0, 8, hipMemcpyHostToDevice));
+    LCHK(hipMemcpy(cams.p, cc, sizeof(cc), hipMemcpyHostToDevice));
+    LCHK(hipMemcpy(pr.p, prs, 8, hipMemcpyHostToDevice));
+    LCHK(hipMemcpy(off.p, offs, 16, hipMemcpyHostToDevice));
+    if (n_matches) LCHK(hipMemcpy(mt.p, matches, (size_t)n_matches * 8, hipMemcpyHostToDevice));
+    LCHK(hipMemcpy(sd.p, &seed, 4, hipMemcpyHostToDevice));
+  }
+  if (rc == DSM_OK) {
+    std::vector<uint32_t> counts(1, n_matches);
+    lf->n_pairs = 1;
+    rc = verify_core(lf, 1, pr.as<uint32_t>(), off.as<uint64_t>(), mt.as<uint32_t>(), n_matches, counts, kp.as<double>(),
+                     row0.as<uint32_t>(), cams.as<dsm_camera>(), options, sd.as<uint32_t>(), 0);
+    if (rc != DSM_OK) ctx->err = lf->err;
+  }
+  if (rc == DSM_OK) {
+    LCHK(hipMemcpy(out, lf->d_tvg.p, sizeof(dsm_two_view_geometry), hipMemcpyDeviceToHost));
+    if (rc == DSM_OK && inlier_matches && out->num_inliers)
+      LCHK(hipMemcpy(inlier_matches, lf->d_inl_compact.p, (size_t)out->num_inliers * 8, hipMemcpyDeviceToHost));
+  }
+#undef LCHK
+  DevBuf* bufs[] = {&kp, &row0, &cams, &pr, &off, &mt, &sd};
+  for (DevBuf* b : bufs) b->release();
+  return rc;
+}
+
+int dsm_debug_sample_sequence(dsm_ctx* ctx, uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out) {
+  if (!ctx || !out || k == 0 || k > total) return DSM_ERR_INVALID_ARGUMENT;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  DevBuf o, idx;
+  HIPCHK(ctx, o.reserve((size_t)k * n_draws * 4 + 4));
+  HIPCHK(ctx, idx.reserve((size_t)total * 4));
+  launch_debug_samples(seed, k, total, n_draws, o.as<uint32_t>(), idx.as<uint32_t>(), ctx->stream);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpy(out, o.p, (size_t)k * n_draws * 4, hipMemcpyDeviceToHost));
+  o.release();
+  idx.release();
   return DSM_OK;
 }
 

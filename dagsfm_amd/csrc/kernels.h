@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/dagsfm_mi355x.h"
+
 // K1: one directed matching pass per blockIdx.x, one 256-row block of image a per blockIdx.y.
 struct K1Params {
   const int8_t* desc;         // s8 descriptors (u8 ^ 0x80), all images, rows padded per image to 256
@@ -29,6 +31,36 @@ struct K2Params {
   const uint64_t* offsets;    // [n_pairs] absolute offsets into matches (write pass)
   uint32_t* matches;          // [total][2]
 };
+
+// Two-view verification: one 64-lane workgroup per image pair (grid-stride over the pair list).
+struct VerifyParams {
+  const uint32_t* pairs;       // [n_pairs][2] image indices
+  const uint64_t* match_off;   // [n_pairs+1] offsets into matches
+  const uint32_t* matches;     // [total][2]
+  const double* kp;            // [total_rows][2] keypoints (x, y)
+  const uint32_t* img_row0;    // first keypoint row of every image
+  const dsm_camera* cams;      // per image
+  dsm_two_view_options opt;
+  const uint32_t* seeds;       // per pair PRNG seed
+  const uint32_t* nt_table;    // tabulated RANSAC::ComputeNumTrials (host libm)
+  const uint64_t* nt_off;      // [n_max+1]: offset of the E/F/H tables (3 x (N+1)) for N matches
+  const uint64_t* nt_off_t;    // [n_max+1]: offset of the translation table (N+1) for N inliers
+  uint32_t max_trials[4];      // RANSAC ctor's max_num_trials per family (E, F, H, T)
+  dsm_two_view_geometry* tvg;  // [n_pairs]
+  uint32_t* inlier_matches;    // [total][2], pair p at match_off[p]
+  uint32_t* inl_counts;        // [n_pairs]
+  double* scratch;             // per workgroup work area
+  uint32_t n_pairs;
+  uint32_t n_max;              // max matches of any pair in this launch
+  int32_t stage_filter;        // apply SiftFeatureMatcher::Match's min_num_inliers post-filter
+};
+
+size_t verify_scratch_bytes_per_block(uint32_t n_max);
+size_t verify_smem_bytes(uint32_t n_max);
+void launch_verify(const VerifyParams& p, uint32_t n_blocks, hipStream_t st);
+void launch_debug_samples(uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out, uint32_t* idx, hipStream_t st);
+void launch_compact_inliers(const uint64_t* match_off, const uint64_t* inl_off, const uint32_t* inl_counts,
+                            const uint32_t* src, uint32_t* dst, uint32_t n_pairs, hipStream_t st);
 
 void launch_k0(const uint8_t* in_u8, int8_t* out_s8, int32_t* rterm, uint64_t n_rows, hipStream_t st);
 void launch_k1(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st);

@@ -1,0 +1,350 @@
+// verify_estimators.h -- device-side two-view model estimators and residuals.
+//
+// Minimal solvers run one hypothesis per lane (private memory); the local-optimisation
+// estimators (all inliers) run once per wave through the cooperative SVD in verify_linalg.h and
+// finish on lane 0.  Each function cites the reference code it replaces.
+#ifndef DAGSFM_AMD_CSRC_VERIFY_ESTIMATORS_H_
+#define DAGSFM_AMD_CSRC_VERIFY_ESTIMATORS_H_
+
+#include "verify_linalg.h"
+
+// ---------------------------------------------------------------------------------- residuals
+// ComputeSquaredSampsonError, /root/reference/src/estimators/utils.cc:87-131 (one correspondence)
+DSM_DEV double sampson_residual(const double* E, double x1_0, double x1_1, double x2_0, double x2_1) {
+  const double Ex1_0 = E[0] * x1_0 + E[1] * x1_1 + E[2];
+  const double Ex1_1 = E[3] * x1_0 + E[4] * x1_1 + E[5];
+  const double Ex1_2 = E[6] * x1_0 + E[7] * x1_1 + E[8];
+  const double Etx2_0 = E[0] * x2_0 + E[3] * x2_1 + E[6];
+  const double Etx2_1 = E[1] * x2_0 + E[4] * x2_1 + E[7];
+  const double x2tEx1 = x2_0 * Ex1_0 + x2_1 * Ex1_1 + Ex1_2;
+  return x2tEx1 * x2tEx1 / (Ex1_0 * Ex1_0 + Ex1_1 * Ex1_1 + Etx2_0 * Etx2_0 + Etx2_1 * Etx2_1);
+}
+// HomographyMatrixEstimator::Residuals, /root/reference/src/estimators/homography_matrix.cc:94-131
+DSM_DEV double homography_residual(const double* H, double s_0, double s_1, double d_0, double d_1) {
+  const double pd_0 = H[0] * s_0 + H[1] * s_1 + H[2];
+  const double pd_1 = H[3] * s_0 + H[4] * s_1 + H[5];
+  const double pd_2 = H[6] * s_0 + H[7] * s_1 + H[8];
+  const double inv_pd_2 = 1.0 / pd_2;
+  const double dd_0 = d_0 - pd_0 * inv_pd_2;
+  const double dd_1 = d_1 - pd_1 * inv_pd_2;
+  return dd_0 * dd_0 + dd_1 * dd_1;
+}
+// TranslationTransformEstimator<2>::Residuals, /root/reference/src/estimators/translation_transform.h:106-118
+DSM_DEV double translation_residual(const double* t, double x1_0, double x1_1, double x2_0, double x2_1) {
+  const double ex = x2_0 - x1_0 - t[0];
+  const double ey = x2_1 - x1_1 - t[1];
+  return ex * ex + ey * ey;
+}
+
+// ---------------------------------------------------------------------------------- normalisation
+// CenterAndNormalizeImagePoints, utils.cc:38-85, over points pts[idx(i)] for i < n (4 doubles
+// per correspondence: x1 y1 x2 y2; `which` selects image 1 or 2).  Sequential sums; returns the
+// matrix entries (norm_factor, -nf*cx, -nf*cy).
+template <typename IdxFn>
+DSM_DEV void center_and_normalize(const double* pts, int which, int n, IdxFn idx, double* nf, double* m02, double* m12) {
+  double cx = 0, cy = 0;
+  for (int i = 0; i < n; ++i) {
+    const double* p = pts + (size_t)idx(i) * 4 + which * 2;
+    cx += p[0];
+    cy += p[1];
+  }
+  cx /= n;
+  cy /= n;
+  double rms = 0;
+  for (int i = 0; i < n; ++i) {
+    const double* p = pts + (size_t)idx(i) * 4 + which * 2;
+    const double dx = p[0] - cx, dy = p[1] - cy;
+    rms += dx * dx + dy * dy;
+  }
+  rms = sqrt(rms / n);
+  const double norm_factor = sqrt(2.0) / rms;
+  *nf = norm_factor;
+  *m02 = -norm_factor * cx;
+  *m12 = -norm_factor * cy;
+}
+// applies M = [[nf,0,m02],[0,nf,m12],[0,0,1]] exactly like utils.cc:66-84
+DSM_DEV void apply_norm(double nf, double m02, double m12, double p_0, double p_1, double* o0, double* o1) {
+  const double np_0 = nf * p_0 + 0.0 * p_1 + m02;
+  const double np_1 = 0.0 * p_0 + nf * p_1 + m12;
+  const double np_2 = 0.0 * p_0 + 0.0 * p_1 + 1.0;
+  const double inv_np_2 = 1.0 / np_2;
+  *o0 = np_0 * inv_np_2;
+  *o1 = np_1 * inv_np_2;
+}
+
+// ---------------------------------------------------------------------------------- 7-point F
+// FundamentalMatrixSevenPointEstimator::Estimate, /root/reference/src/estimators/fundamental_matrix.cc:47-142
+// xs: 7 correspondences (x1 y1 x2 y2).  Returns the number of models written to models[k*9].
+DSM_DEVN int seven_point(const double* xs, double* models) {
+  double At[63];  // A^T, 9 x 7 column-major: At[i*9 + c] = A(i, c)
+  for (int i = 0; i < 7; ++i) {
+    const double x0 = xs[i * 4 + 0], y0 = xs[i * 4 + 1], x1 = xs[i * 4 + 2], y1 = xs[i * 4 + 3];
+    double* r = At + i * 9;
+    r[0] = x1 * x0; r[1] = x1 * y0; r[2] = x1;
+    r[3] = y1 * x0; r[4] = y1 * y0; r[5] = y1;
+    r[6] = x0; r[7] = y0; r[8] = 1;
+  }
+  double nv[18];
+  pl_nullspace_9xm(At, 7, 7, nv);
+  double* f1 = nv;
+  double* f2 = nv + 9;
+  for (int k = 0; k < 9; ++k) f1[k] -= f2[k];
+  const double t0 = f1[4] * f1[8] - f1[5] * f1[7];
+  const double t1 = f1[3] * f1[8] - f1[5] * f1[6];
+  const double t2 = f1[3] * f1[7] - f1[4] * f1[6];
+  const double t3 = f2[4] * f2[8] - f2[5] * f2[7];
+  const double t4 = f2[3] * f2[8] - f2[5] * f2[6];
+  const double t5 = f2[3] * f2[7] - f2[4] * f2[6];
+  double coeffs[4];
+  coeffs[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
+  coeffs[1] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2 - f2[3] * (f1[1] * f1[8] - f1[2] * f1[7]) +
+              f2[4] * (f1[0] * f1[8] - f1[2] * f1[6]) - f2[5] * (f1[0] * f1[7] - f1[1] * f1[6]) +
+              f2[6] * (f1[1] * f1[5] - f1[2] * f1[4]) - f2[7] * (f1[0] * f1[5] - f1[2] * f1[3]) +
+              f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
+  coeffs[2] = f1[0] * t3 - f1[1] * t4 + f1[2] * t5 - f1[3] * (f2[1] * f2[8] - f2[2] * f2[7]) +
+              f1[4] * (f2[0] * f2[8] - f2[2] * f2[6]) - f1[5] * (f2[0] * f2[7] - f2[1] * f2[6]) +
+              f1[6] * (f2[1] * f2[5] - f2[2] * f2[4]) - f1[7] * (f2[0] * f2[5] - f2[2] * f2[3]) +
+              f1[8] * (f2[0] * f2[4] - f2[1] * f2[3]);
+  coeffs[3] = f2[0] * t3 - f2[1] * t4 + f2[2] * t5;
+  double rr[4], ri[4];
+  const int nroots = pl_poly_roots<4>(coeffs, 4, rr, ri);
+  if (nroots < 0) return 0;
+  int nm = 0;
+  for (int i = 0; i < nroots; ++i) {
+    if (fabs(ri[i]) > 1e-10) continue;
+    const double lambda = rr[i];
+    const double mu = 1;
+    double F[9];
+    for (int k = 0; k < 9; ++k) F[k] = lambda * f1[k] + mu * f2[k];
+    if (fabs(F[8]) < 1e-10) continue;
+    const double f22 = F[8];
+    for (int k = 0; k < 9; ++k) models[nm * 9 + k] = F[k] / f22;
+    ++nm;
+  }
+  return nm;
+}
+
+// Rank-2 projection + de-normalisation of the 8-point estimator (fundamental_matrix.cc:172-191);
+// nullvec = cmatrix_svd.matrixV().col(8); N1/N2 given as (nf, m02, m12).
+DSM_DEVN void eight_point_finish(const double* nullvec, const double* n1, const double* n2, double* Fout) {
+  double U[9], V[9], sv[3];
+  pl_jacobi_svd_square<3, true>(nullvec, U, V, sv);  // ematrix_t.transpose() == row-major reshape
+  sv[2] = 0.0;
+  double US[9], Vrm_t[9], F[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) US[i * 3 + j] = U[j * 3 + i] * sv[j];   // U is column-major
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Vrm_t[i * 3 + j] = V[i * 3 + j];        // (V^T)(i,j) = V(j,i) = V_cm[i*3+j]
+  m3_mul(US, Vrm_t, F);
+  const double N1[9] = {n1[0], 0, n1[1], 0, n1[0], n1[2], 0, 0, 1};
+  const double N2t[9] = {n2[0], 0, 0, 0, n2[0], 0, n2[1], n2[2], 1};
+  double T[9];
+  m3_mul(N2t, F, T);
+  m3_mul(T, N1, Fout);
+}
+
+// ---------------------------------------------------------------------------------- homography
+// De-normalisation of HomographyMatrixEstimator::Estimate, homography_matrix.cc:86-91
+DSM_DEV void homography_finish(const double* nullvec, const double* n1, const double* n2, double* Hout) {
+  const double N1[9] = {n1[0], 0, n1[1], 0, n1[0], n1[2], 0, 0, 1};
+  const double N2[9] = {n2[0], 0, n2[1], 0, n2[0], n2[2], 0, 0, 1};
+  double N2inv[9], T[9];
+  m3_inverse(N2, N2inv);
+  m3_mul(N2inv, nullvec, T);  // H_t.transpose() == row-major reshape of the null vector
+  m3_mul(T, N1, Hout);
+}
+
+// HomographyMatrixEstimator::Estimate for the minimal sample (N = 4), homography_matrix.cc:44-92
+DSM_DEVN int homography_four_point(const double* xs, double* models) {
+  double n1[3], n2[3];
+  auto ident = [](int i) { return i; };
+  center_and_normalize(xs, 0, 4, ident, &n1[0], &n1[1], &n1[2]);
+  center_and_normalize(xs, 1, 4, ident, &n2[0], &n2[1], &n2[2]);
+  double At[72];  // A^T, 9 x 8 column-major: row r of A is At[r*9 .. r*9+8]
+  for (int i = 0; i < 72; ++i) At[i] = 0.0;
+  for (int i = 0, j = 4; i < 4; ++i, ++j) {
+    double s_0, s_1, d_0, d_1;
+    apply_norm(n1[0], n1[1], n1[2], xs[i * 4 + 0], xs[i * 4 + 1], &s_0, &s_1);
+    apply_norm(n2[0], n2[1], n2[2], xs[i * 4 + 2], xs[i * 4 + 3], &d_0, &d_1);
+    double* ri = At + i * 9;
+    double* rj = At + j * 9;
+    ri[0] = -s_0; ri[1] = -s_1; ri[2] = -1;
+    ri[6] = s_0 * d_0; ri[7] = s_1 * d_0; ri[8] = d_0;
+    rj[3] = -s_0; rj[4] = -s_1; rj[5] = -1;
+    rj[6] = s_0 * d_1; rj[7] = s_1 * d_1; rj[8] = d_1;
+  }
+  double nv[9];
+  pl_nullspace_9xm(At, 8, 8, nv);
+  homography_finish(nv, n1, n2, models);
+  return 1;
+}
+
+// ---------------------------------------------------------------------------------- 5-point E
+// Monomial tables of the generic polynomial construction of Nister's 10 x 20 system (see
+// oracle/two_view.cc: the reference's generated essential_matrix_poly.h / _coeffs.h are replaced by
+// generic polynomial arithmetic; column order x^3 y^3 x^2y xy^2 x^2z x^2 y^2z y^2 xyz xy | xz^2 xz x yz^2 yz y z^3 z^2 z 1).
+__device__ const int kLL[4][4] = {{0, 3, 4, 6}, {3, 1, 5, 7}, {4, 5, 2, 8}, {6, 7, 8, 9}};
+__device__ const int kQL[10][4] = {{0, 2, 4, 5},   {3, 1, 6, 7},   {10, 13, 16, 17}, {2, 3, 8, 9},    {4, 8, 10, 11},
+                                   {8, 6, 13, 14}, {5, 9, 11, 12}, {9, 7, 14, 15},   {11, 14, 17, 18}, {12, 15, 18, 19}};
+
+DSM_DEV void lin_mul_acc(const double* a, const double* b, double* quad) {
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) quad[kLL[i][j]] += a[i] * b[j];
+}
+DSM_DEV void quad_lin_mul_acc(const double* q, const double* l, double sign, double* cubic) {
+  for (int i = 0; i < 10; ++i)
+    for (int j = 0; j < 4; ++j) cubic[kQL[i][j]] += sign * (q[i] * l[j]);
+}
+DSM_DEV void poly_mul(const double* a, int na, const double* b, int nb, double* out) {
+  for (int i = 0; i < na + nb - 1; ++i) out[i] = 0.0;
+  for (int i = 0; i < na; ++i)
+    for (int j = 0; j < nb; ++j) out[i + j] += a[i] * b[j];
+}
+
+// Steps 3-5 of EssentialMatrixFivePointEstimator::Estimate (/root/reference/src/estimators/essential_matrix.cc:76-147)
+// from the 9 x 4 null-space basis Eb[r*4 + c] = svd.matrixV()(r, 5 + c).  Up to 10 models.
+DSM_DEVN int five_point_finish(const double* Eb, double* models) {
+  double A[200];  // A[r*20 + c]
+  for (int i = 0; i < 200; ++i) A[i] = 0.0;
+  // lin(r, c) = Eb row (3r + c): 4 coefficients (x, y, z, 1)
+#define LIN(r, c) (Eb + ((r) * 3 + (c)) * 4)
+  {
+    double m0[10], m1[10], m2[10], tmp[10];
+    for (int i = 0; i < 10; ++i) m0[i] = m1[i] = m2[i] = tmp[i] = 0.0;
+    lin_mul_acc(LIN(1, 1), LIN(2, 2), m0);
+    lin_mul_acc(LIN(1, 2), LIN(2, 1), tmp);
+    for (int i = 0; i < 10; ++i) {
+      m0[i] -= tmp[i];
+      tmp[i] = 0.0;
+    }
+    lin_mul_acc(LIN(1, 0), LIN(2, 2), m1);
+    lin_mul_acc(LIN(1, 2), LIN(2, 0), tmp);
+    for (int i = 0; i < 10; ++i) {
+      m1[i] -= tmp[i];
+      tmp[i] = 0.0;
+    }
+    lin_mul_acc(LIN(1, 0), LIN(2, 1), m2);
+    lin_mul_acc(LIN(1, 1), LIN(2, 0), tmp);
+    for (int i = 0; i < 10; ++i) m2[i] -= tmp[i];
+    quad_lin_mul_acc(m0, LIN(0, 0), 1.0, A);
+    quad_lin_mul_acc(m1, LIN(0, 1), -1.0, A);
+    quad_lin_mul_acc(m2, LIN(0, 2), 1.0, A);
+  }
+  {
+    double EEt[90];  // [i][j][10]
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double* e = EEt + (i * 3 + j) * 10;
+        for (int q = 0; q < 10; ++q) e[q] = 0.0;
+        for (int k = 0; k < 3; ++k) lin_mul_acc(LIN(i, k), LIN(j, k), e);
+      }
+    double half_trace[10];
+    for (int q = 0; q < 10; ++q) half_trace[q] = 0.5 * (EEt[0 * 10 + q] + EEt[4 * 10 + q] + EEt[8 * 10 + q]);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double* row = A + (1 + i * 3 + j) * 20;
+        for (int k = 0; k < 3; ++k) quad_lin_mul_acc(EEt + (i * 3 + k) * 10, LIN(k, j), 1.0, row);
+        quad_lin_mul_acc(half_trace, LIN(i, j), -1.0, row);
+      }
+  }
+#undef LIN
+  double A1[100], AA[100];  // column-major 10 x 10
+  for (int r = 0; r < 10; ++r)
+    for (int c = 0; c < 10; ++c) {
+      A1[c * 10 + r] = A[r * 20 + c];
+      AA[c * 10 + r] = A[r * 20 + 10 + c];
+    }
+  pl_lu_solve_10(A1, AA);
+#define AAe(r, c) AA[(c) * 10 + (r)]
+  double B[39];  // B[row*3 + col]
+  for (int i = 0; i < 3; ++i) {
+    B[0 * 3 + i] = 0; B[4 * 3 + i] = 0; B[8 * 3 + i] = 0;
+    for (int k = 0; k < 3; ++k) {
+      B[(1 + k) * 3 + i] = AAe(i * 2 + 4, k);
+      B[(5 + k) * 3 + i] = AAe(i * 2 + 4, 3 + k);
+    }
+    for (int k = 0; k < 4; ++k) B[(9 + k) * 3 + i] = AAe(i * 2 + 4, 6 + k);
+    for (int k = 0; k < 3; ++k) {
+      B[(0 + k) * 3 + i] -= AAe(i * 2 + 5, k);
+      B[(4 + k) * 3 + i] -= AAe(i * 2 + 5, 3 + k);
+    }
+    for (int k = 0; k < 4; ++k) B[(8 + k) * 3 + i] -= AAe(i * 2 + 5, 6 + k);
+  }
+#undef AAe
+  // determinant polynomial of B(z), highest degree first
+  double coeffs[11];
+  {
+    double b[45];  // b[(j*3 + c)*5 + deg], lowest degree first
+    for (int j = 0; j < 3; ++j) {
+      for (int d = 0; d < 4; ++d) {
+        b[(j * 3 + 0) * 5 + d] = B[(3 - d) * 3 + j];
+        b[(j * 3 + 1) * 5 + d] = B[(7 - d) * 3 + j];
+      }
+      b[(j * 3 + 0) * 5 + 4] = 0.0;
+      b[(j * 3 + 1) * 5 + 4] = 0.0;
+      for (int d = 0; d < 5; ++d) b[(j * 3 + 2) * 5 + d] = B[(12 - d) * 3 + j];
+    }
+    double det[11];
+    for (int i = 0; i < 11; ++i) det[i] = 0.0;
+    for (int j = 0; j < 3; ++j) {
+      const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      double p1[8], p2[8], minor[8], term[11];
+      poly_mul(b + (j1 * 3 + 1) * 5, 4, b + (j2 * 3 + 2) * 5, 5, p1);
+      poly_mul(b + (j2 * 3 + 1) * 5, 4, b + (j1 * 3 + 2) * 5, 5, p2);
+      for (int i = 0; i < 8; ++i) minor[i] = p1[i] - p2[i];
+      poly_mul(b + (j * 3 + 0) * 5, 4, minor, 8, term);
+      for (int i = 0; i < 11; ++i) det[i] += term[i];
+    }
+    for (int i = 0; i < 11; ++i) coeffs[i] = det[10 - i];
+  }
+  double rr[11], ri[11];
+  const int nroots = pl_poly_roots<11>(coeffs, 11, rr, ri);
+  if (nroots < 0) return 0;
+  int nm = 0;
+  for (int i = 0; i < nroots; ++i) {
+    if (fabs(ri[i]) > 1e-10) continue;
+    const double z1 = rr[i];
+    const double z2 = z1 * z1;
+    const double z3 = z2 * z1;
+    const double z4 = z3 * z1;
+    double Bz[9];
+    for (int j = 0; j < 3; ++j) {
+      Bz[j * 3 + 0] = B[0 * 3 + j] * z3 + B[1 * 3 + j] * z2 + B[2 * 3 + j] * z1 + B[3 * 3 + j];
+      Bz[j * 3 + 1] = B[4 * 3 + j] * z3 + B[5 * 3 + j] * z2 + B[6 * 3 + j] * z1 + B[7 * 3 + j];
+      Bz[j * 3 + 2] = B[8 * 3 + j] * z4 + B[9 * 3 + j] * z3 + B[10 * 3 + j] * z2 + B[11 * 3 + j] * z1 + B[12 * 3 + j];
+    }
+    double Vz[9], svz[3];
+    pl_jacobi_svd_square<3, false>(Bz, nullptr, Vz, svz);
+    const double X0 = Vz[2 * 3 + 0], X1 = Vz[2 * 3 + 1], X2 = Vz[2 * 3 + 2];
+    if (fabs(X2) < 1e-10) continue;
+    const double sx = X0 / X2, sy = X1 / X2;
+    double ev[9];
+    for (int k = 0; k < 9; ++k) ev[k] = Eb[k * 4 + 0] * sx + Eb[k * 4 + 1] * sy + Eb[k * 4 + 2] * z1 + Eb[k * 4 + 3];
+    double nn = 0.0;
+    for (int k = 0; k < 9; ++k) nn += ev[k] * ev[k];
+    const double norm = sqrt(nn);
+    for (int k = 0; k < 9; ++k) models[nm * 9 + k] = ev[k] / norm;
+    ++nm;
+  }
+  return nm;
+}
+
+// EssentialMatrixFivePointEstimator::Estimate for the minimal sample, essential_matrix.cc:46-150
+DSM_DEVN int five_point_minimal(const double* xs, double* models) {
+  double At[45];  // Q^T, 9 x 5
+  for (int i = 0; i < 5; ++i) {
+    const double x1_0 = xs[i * 4 + 0], x1_1 = xs[i * 4 + 1], x2_0 = xs[i * 4 + 2], x2_1 = xs[i * 4 + 3];
+    double* r = At + i * 9;
+    r[0] = x1_0 * x2_0; r[1] = x1_1 * x2_0; r[2] = x2_0;
+    r[3] = x1_0 * x2_1; r[4] = x1_1 * x2_1; r[5] = x2_1;
+    r[6] = x1_0; r[7] = x1_1; r[8] = 1;
+  }
+  double nv[36];  // columns 5..8 of V, nv[c*9 + r]
+  pl_nullspace_9xm(At, 5, 5, nv);
+  double Eb[36];
+  for (int r = 0; r < 9; ++r)
+    for (int c = 0; c < 4; ++c) Eb[r * 4 + c] = nv[c * 9 + r];
+  return five_point_finish(Eb, models);
+}
+
+#endif  // DAGSFM_AMD_CSRC_VERIFY_ESTIMATORS_H_

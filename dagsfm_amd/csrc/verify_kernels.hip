@@ -1,0 +1,1203 @@
+// verify_kernels.hip -- two-view geometric verification on MI355X (gfx950).
+//
+// One 64-lane wavefront (one-wave workgroup) verifies one image pair at a time and walks the
+// pair list with a grid stride.  Per pair it reproduces, decision for decision, the reference's
+//   TwoViewGeometry::Estimate            /root/reference/src/estimators/two_view_geometry.cc:113-126
+//   EstimateCalibrated / Uncalibrated    :292-489      EstimateWithRelativePose :232-290
+//   DetectWatermark                      :491-555
+//   LORANSAC<E, LE>::Estimate            /root/reference/src/optim/loransac.h:91-233
+//   RandomSampler / Shuffle / mt19937    /root/reference/src/optim/random_sampler.cc:43-62, util/random.h:122-129
+// with a defined per-pair seed (the reference seeds from the wall clock, random.cc:40-56).
+//
+// LO-RANSAC is sequential ("first best wins", adaptive stop).  The wave speculates a batch of 64
+// trials: lane 0 draws the 64 minimal samples from the pair's MT19937 stream (libstdc++'s
+// Lemire uniform_int mapping), every lane solves one minimal problem, the wave then scores every
+// model of the batch (wavefront-per-hypothesis: lanes stride over the correspondences,
+// __ballot/popc for the inlier count) and finally replays the batch in trial order: support
+// comparison, in-order residual_sum for candidates, local optimisation on improvement, dynamic
+// stop.  On an early stop the PRNG is rewound to the state after the last consumed sample, so
+// the next model family continues on exactly the stream position the sequential code would.
+//
+// FP64 throughout, compiled with -ffp-contract=off; every reduction is summed in index order.
+// RANSAC::ComputeNumTrials (ransac.h:150-167) needs libm pow/log/ceil; it is tabulated on the
+// host with the host libm per (num_samples, min_samples, confidence) and looked up here, the
+// same construction as the acos LUT of the matcher.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dagsfm_mi355x.h"
+#include "kernels.h"
+#include "verify_estimators.h"
+
+#define BATCH 64
+
+// ------------------------------------------------------------------------------------ shared state
+struct VSmem {
+  uint32_t mt[624];
+  uint32_t mt_bak[624];
+  int mti, mti_bak;
+  uint32_t calls;          // raw generator calls since the backup
+  WvSvdShared svd;
+  double sv[9];
+  int sample[BATCH * 7];
+  uint32_t draws_end[BATCH];
+  int nmodels[BATCH];
+  int counts[BATCH * 10];
+  double lo_models[90];
+  double cur_model[9];
+  double bcast[16];
+  int ibcast[8];
+};
+
+// ------------------------------------------------------------------------------------ MT19937 (lane 0)
+DSM_DEV void mt_seed(VSmem* s, uint32_t seed) {
+  s->mt[0] = seed;
+  for (int i = 1; i < 624; ++i) s->mt[i] = 1812433253u * (s->mt[i - 1] ^ (s->mt[i - 1] >> 30)) + (uint32_t)i;
+  s->mti = 624;
+}
+DSM_DEV uint32_t mt_next(VSmem* s) {
+  if (s->mti >= 624) {
+    uint32_t* mt = s->mt;
+    int kk;
+    for (kk = 0; kk < 624 - 397; ++kk) {
+      const uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+      mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    for (; kk < 623; ++kk) {
+      const uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+      mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    const uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+    mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    s->mti = 0;
+  }
+  uint32_t y = s->mt[s->mti++];
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  s->calls++;
+  return y;
+}
+// std::uniform_int_distribution<uint32_t>(a, b)(mt19937) of libstdc++ (GCC 11,
+// bits/uniform_int_dist.h:246-317): Lemire's nearly divisionless method on 32-bit draws.
+DSM_DEV uint32_t uniform_u32(VSmem* s, uint32_t a, uint32_t b) {
+  const uint64_t urange = (uint64_t)b - (uint64_t)a;
+  if (urange == 0xffffffffull) return mt_next(s) + a;
+  const uint32_t range = (uint32_t)(urange + 1);
+  uint64_t product = (uint64_t)mt_next(s) * (uint64_t)range;
+  uint32_t low = (uint32_t)product;
+  if (low < range) {
+    const uint32_t threshold = (0u - range) % range;
+    while (low < threshold) {
+      product = (uint64_t)mt_next(s) * (uint64_t)range;
+      low = (uint32_t)product;
+    }
+  }
+  return (uint32_t)(product >> 32) + a;
+}
+
+// ------------------------------------------------------------------------------------ families
+enum { FAM_E = 0, FAM_F = 1, FAM_H = 2, FAM_T = 3 };
+
+template <int FAM> struct Fam;
+template <> struct Fam<FAM_E> { static constexpr int K = 5, MAXM = 10, LO_MIN = 5, MSZ = 9; };
+template <> struct Fam<FAM_F> { static constexpr int K = 7, MAXM = 3, LO_MIN = 8, MSZ = 9; };
+template <> struct Fam<FAM_H> { static constexpr int K = 4, MAXM = 1, LO_MIN = 4, MSZ = 9; };
+template <> struct Fam<FAM_T> { static constexpr int K = 1, MAXM = 1, LO_MIN = 1, MSZ = 9; };
+
+template <int FAM>
+DSM_DEV double fam_residual(const double* M, const double* p) {
+  if (FAM == FAM_H) return homography_residual(M, p[0], p[1], p[2], p[3]);
+  if (FAM == FAM_T) return translation_residual(M, p[0], p[1], p[2], p[3]);
+  return sampson_residual(M, p[0], p[1], p[2], p[3]);
+}
+
+template <int FAM>
+DSM_DEV int fam_minimal(const double* xs, double* models) {
+  if (FAM == FAM_E) return five_point_minimal(xs, models);
+  if (FAM == FAM_F) return seven_point(xs, models);
+  if (FAM == FAM_H) return homography_four_point(xs, models);
+  // TranslationTransformEstimator<2>::Estimate with one point, translation_transform.h:81-104
+  const double sx = (0.0 + xs[0]) / 1, sy = (0.0 + xs[1]) / 1, dx = (0.0 + xs[2]) / 1, dy = (0.0 + xs[3]) / 1;
+  models[0] = dx - sx;
+  models[1] = dy - sy;
+  for (int k = 2; k < 9; ++k) models[k] = 0.0;
+  return 1;
+}
+
+// ------------------------------------------------------------------------------------ per-pair work area
+struct PairWork {
+  int n;                 // correspondences
+  const double* pts;     // n x 4 (x1 y1 x2 y2) of the family's coordinate frame
+  double* resid;         // n
+  int* inl;              // n: ordered inlier indices of the last compaction
+  double* tall;          // >= 18 n + 81 doubles: LO constraint matrix (+ 81 for the transposed small case)
+  double* models;        // BATCH * MAXM * 9
+  VSmem* sm;
+  const uint32_t* nt_table;  // ComputeNumTrials(k, n) for k = 0..n of this family
+  int lane;
+};
+
+// residuals of all correspondences for model M -> resid[]; returns inlier count (uniform)
+template <int FAM>
+DSM_DEV int score_model(const PairWork& w, const double* M, double max_residual, bool store) {
+  int count = 0;
+  for (int base = 0; base < w.n; base += 64) {
+    const int i = base + w.lane;
+    bool in = false;
+    if (i < w.n) {
+      const double r = fam_residual<FAM>(M, w.pts + (size_t)i * 4);
+      if (store) w.resid[i] = r;
+      in = r <= max_residual;
+    }
+    count += __popcll(__ballot(in));
+  }
+  return count;
+}
+
+// InlierSupportMeasurer::Evaluate's residual_sum (support_measurement.cc:43-48): in index order.
+DSM_DEV double ordered_residual_sum(const PairWork& w, double max_residual) {
+  wv_sync();
+  if (w.lane == 0) {
+    double s = 0;
+    for (int i = 0; i < w.n; ++i) {
+      const double r = w.resid[i];
+      if (r <= max_residual) s += r;
+    }
+    w.sm->bcast[0] = s;
+  }
+  wv_sync();
+  return w.sm->bcast[0];
+}
+
+// ordered compaction of the inliers of resid[] into inl[]; returns the count
+DSM_DEV int compact_inliers(const PairWork& w, double max_residual) {
+  int total = 0;
+  for (int base = 0; base < w.n; base += 64) {
+    const int i = base + w.lane;
+    const bool in = (i < w.n) && (w.resid[i] <= max_residual);
+    const unsigned long long bal = __ballot(in);
+    if (in) w.inl[total + __popcll(bal & ((1ull << w.lane) - 1ull))] = i;
+    total += __popcll(bal);
+  }
+  wv_sync();
+  return total;
+}
+
+// ------------------------------------------------------------------------------------ local estimators
+// Writes up to MAXM models into sm->lo_models; returns their number (uniform).
+template <int FAM>
+DSM_DEV int fam_local(const PairWork& w, int ninl) {
+  VSmem* sm = w.sm;
+  const int lane = w.lane;
+  const int* inl = w.inl;
+  auto idx = [inl](int i) { return inl[i]; };
+  if (FAM == FAM_T) {
+    // TranslationTransformEstimator<2>::Estimate, translation_transform.h:81-104
+    if (lane == 0) {
+      double sx = 0, sy = 0, dx = 0, dy = 0;
+      for (int i = 0; i < ninl; ++i) {
+        const double* p = w.pts + (size_t)inl[i] * 4;
+        sx += p[0]; sy += p[1];
+        dx += p[2]; dy += p[3];
+      }
+      sx /= ninl; sy /= ninl;
+      dx /= ninl; dy /= ninl;
+      sm->lo_models[0] = dx - sx;
+      sm->lo_models[1] = dy - sy;
+      for (int k = 2; k < 9; ++k) sm->lo_models[k] = 0.0;
+    }
+    wv_sync();
+    return 1;
+  }
+  if (FAM == FAM_E) {
+    // EssentialMatrixFivePointEstimator::Estimate with all inliers, essential_matrix.cc:46-150
+    const int m = ninl;
+    double* Q = w.tall;
+    for (int i = lane; i < m; i += 64) {
+      const double* p = w.pts + (size_t)inl[i] * 4;
+      const double x1_0 = p[0], x1_1 = p[1], x2_0 = p[2], x2_1 = p[3];
+      Q[(size_t)0 * m + i] = x1_0 * x2_0; Q[(size_t)1 * m + i] = x1_1 * x2_0; Q[(size_t)2 * m + i] = x2_0;
+      Q[(size_t)3 * m + i] = x1_0 * x2_1; Q[(size_t)4 * m + i] = x1_1 * x2_1; Q[(size_t)5 * m + i] = x2_1;
+      Q[(size_t)6 * m + i] = x1_0; Q[(size_t)7 * m + i] = x1_1; Q[(size_t)8 * m + i] = 1;
+    }
+    wv_sync();
+    wv_svd_V_mx9(Q, Q + (size_t)9 * m, m, &sm->svd, sm->sv, lane);
+    if (lane == 0) {
+      double Eb[36];
+      for (int r = 0; r < 9; ++r)
+        for (int c = 0; c < 4; ++c) Eb[r * 4 + c] = sm->svd.V[(5 + c) * 9 + r];
+      sm->ibcast[0] = five_point_finish(Eb, sm->lo_models);
+    }
+    wv_sync();
+    return sm->ibcast[0];
+  }
+  // F (8-point) and H share the normalisation prologue.
+  if (lane == 0) {
+    center_and_normalize(w.pts, 0, ninl, idx, &sm->bcast[0], &sm->bcast[1], &sm->bcast[2]);
+    center_and_normalize(w.pts, 1, ninl, idx, &sm->bcast[3], &sm->bcast[4], &sm->bcast[5]);
+  }
+  wv_sync();
+  double n1[3] = {sm->bcast[0], sm->bcast[1], sm->bcast[2]};
+  double n2[3] = {sm->bcast[3], sm->bcast[4], sm->bcast[5]};
+  if (FAM == FAM_F) {
+    // FundamentalMatrixEightPointEstimator::Estimate, fundamental_matrix.cc:150-192
+    const int m = ninl;
+    double* C = w.tall;
+    for (int i = lane; i < m; i += 64) {
+      const double* p = w.pts + (size_t)inl[i] * 4;
+      double a0, a1, b0, b1;
+      apply_norm(n1[0], n1[1], n1[2], p[0], p[1], &a0, &a1);
+      apply_norm(n2[0], n2[1], n2[2], p[2], p[3], &b0, &b1);
+      const double h[3] = {a0, a1, 1.0};
+      for (int k = 0; k < 3; ++k) {
+        C[(size_t)k * m + i] = h[k] * b0;
+        C[(size_t)(3 + k) * m + i] = h[k] * b1;
+        C[(size_t)(6 + k) * m + i] = h[k];
+      }
+    }
+    wv_sync();
+    wv_svd_V_mx9(C, C + (size_t)9 * m, m, &sm->svd, sm->sv, lane);
+    if (lane == 0) {
+      double nv[9];
+      for (int k = 0; k < 9; ++k) nv[k] = sm->svd.V[8 * 9 + k];
+      eight_point_finish(nv, n1, n2, sm->lo_models);
+    }
+    wv_sync();
+    return 1;
+  }
+  {
+    // HomographyMatrixEstimator::Estimate, homography_matrix.cc:44-92
+    const int N = ninl, m = 2 * ninl;
+    double* A = w.tall;
+    for (int e = lane; e < 9 * m; e += 64) A[e] = 0.0;
+    wv_sync();
+    for (int i = lane; i < N; i += 64) {
+      const double* p = w.pts + (size_t)inl[i] * 4;
+      double s_0, s_1, d_0, d_1;
+      apply_norm(n1[0], n1[1], n1[2], p[0], p[1], &s_0, &s_1);
+      apply_norm(n2[0], n2[1], n2[2], p[2], p[3], &d_0, &d_1);
+      const int j = N + i;
+      A[(size_t)0 * m + i] = -s_0; A[(size_t)1 * m + i] = -s_1; A[(size_t)2 * m + i] = -1;
+      A[(size_t)6 * m + i] = s_0 * d_0; A[(size_t)7 * m + i] = s_1 * d_0; A[(size_t)8 * m + i] = d_0;
+      A[(size_t)3 * m + j] = -s_0; A[(size_t)4 * m + j] = -s_1; A[(size_t)5 * m + j] = -1;
+      A[(size_t)6 * m + j] = s_0 * d_1; A[(size_t)7 * m + j] = s_1 * d_1; A[(size_t)8 * m + j] = d_1;
+    }
+    wv_sync();
+    wv_svd_V_mx9(A, A + (size_t)9 * m, m, &sm->svd, sm->sv, lane);
+    if (lane == 0) {
+      double nv[9];
+      for (int k = 0; k < 9; ++k) nv[k] = sm->svd.V[8 * 9 + k];
+      homography_finish(nv, n1, n2, sm->lo_models);
+    }
+    wv_sync();
+    return 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------ LO-RANSAC
+struct RansacReport {
+  bool success;
+  uint32_t num_trials;
+  uint32_t num_models;
+  uint32_t num_inliers;
+  double residual_sum;
+  double model[9];
+};
+
+struct RansacOpt {
+  double max_error;
+  uint32_t min_num_trials;
+  uint32_t max_num_trials;  // already min(options.max_num_trials, ctor's dyn_max), ransac.h:135-148
+};
+
+// LORANSAC<Estimator, LocalEstimator>::Estimate, loransac.h:91-233.  The final inlier mask stays in
+// w.resid (residuals of the returned model) for the caller.  sidx: LDS index array (n entries).
+template <int FAM>
+DSM_DEV void lo_ransac(const PairWork& w, const RansacOpt& opt, uint32_t* sidx, RansacReport* rep) {
+  typedef Fam<FAM> F;
+  VSmem* sm = w.sm;
+  const int lane = w.lane;
+  const int n = w.n;
+  rep->success = false;
+  rep->num_trials = 0;
+  rep->num_models = 0;
+  rep->num_inliers = 0;
+  rep->residual_sum = DBL_MAX;
+  for (int k = 0; k < 9; ++k) rep->model[k] = 0.0;
+  if (n < F::K) return;
+
+  uint32_t best_n = 0;
+  double best_sum = DBL_MAX;
+  double best_model[9];
+  for (int k = 0; k < 9; ++k) best_model[k] = 0.0;
+  bool abort = false;
+  const double max_residual = opt.max_error * opt.max_error;
+  for (int i = lane; i < n; i += 64) sidx[i] = (uint32_t)i;  // sampler.Initialize: iota
+  wv_sync();
+  const uint32_t max_num_trials = opt.max_num_trials;
+  uint32_t dyn_max_num_trials = max_num_trials;
+  uint32_t trial = 0;  // report.num_trials
+
+  while (trial < max_num_trials && !abort) {
+    const int nb = (int)((max_num_trials - trial) < (uint32_t)BATCH ? (max_num_trials - trial) : (uint32_t)BATCH);
+    // ---- backup of the generator, then nb samples by lane 0 (RandomSampler::Sample)
+    for (int i = lane; i < 624; i += 64) sm->mt_bak[i] = sm->mt[i];
+    if (lane == 0) {
+      sm->mti_bak = sm->mti;
+      sm->calls = 0;
+      const uint32_t last_idx = (uint32_t)(n - 1);
+      for (int t = 0; t < nb; ++t) {
+        for (uint32_t i = 0; i < (uint32_t)F::K; ++i) {
+          const uint32_t j = uniform_u32(sm, i, last_idx);
+          const uint32_t a = sidx[i];
+          sidx[i] = sidx[j];
+          sidx[j] = a;
+        }
+        for (int i = 0; i < F::K; ++i) sm->sample[t * 7 + i] = (int)sidx[i];
+        sm->draws_end[t] = sm->calls;
+      }
+    }
+    wv_sync();
+    // ---- one minimal problem per lane
+    {
+      int nm = 0;
+      if (lane < nb) {
+        double xs[F::K * 4];
+        for (int i = 0; i < F::K; ++i) {
+          const double* p = w.pts + (size_t)sm->sample[lane * 7 + i] * 4;
+          xs[i * 4 + 0] = p[0]; xs[i * 4 + 1] = p[1]; xs[i * 4 + 2] = p[2]; xs[i * 4 + 3] = p[3];
+        }
+        double mloc[F::MAXM * 9];
+        nm = fam_minimal<FAM>(xs, mloc);
+        double* dst = w.models + (size_t)lane * F::MAXM * 9;
+        for (int k = 0; k < nm * 9; ++k) dst[k] = mloc[k];
+      }
+      if (lane < BATCH) sm->nmodels[lane] = nm;
+    }
+    wv_sync();
+    // ---- wavefront-per-hypothesis scoring of every model of the batch
+    for (int t = 0; t < nb; ++t) {
+      const int nm = sm->nmodels[t];
+      for (int m = 0; m < nm; ++m) {
+        const int c = score_model<FAM>(w, w.models + ((size_t)t * F::MAXM + m) * 9, max_residual, false);
+        if (lane == 0) sm->counts[t * 10 + m] = c;
+      }
+    }
+    wv_sync();
+    // ---- in-order replay
+    int t_stop = nb - 1;
+    for (int t = 0; t < nb && !abort; ++t, ++trial) {
+      const int nm = sm->nmodels[t];
+      for (int m = 0; m < nm; ++m) {
+        rep->num_models += 1;
+        const uint32_t cnt = (uint32_t)sm->counts[t * 10 + m];
+        const double* M = w.models + ((size_t)t * F::MAXM + m) * 9;
+        bool better = false;
+        double sum = 0.0;
+        if (cnt > best_n || cnt == best_n) {
+          // candidate: residuals + in-order residual_sum (Compare, support_measurement.cc:52-60)
+          score_model<FAM>(w, M, max_residual, true);
+          sum = ordered_residual_sum(w, max_residual);
+          better = (cnt > best_n) || (cnt == best_n && sum < best_sum);
+        }
+        if (better) {
+          best_n = cnt;
+          best_sum = sum;
+          for (int k = 0; k < 9; ++k) best_model[k] = M[k];
+          if (cnt > (uint32_t)F::K && cnt >= (uint32_t)F::LO_MIN) {
+            const int ninl = compact_inliers(w, max_residual);
+            const int nlo = fam_local<FAM>(w, ninl);
+            for (int l = 0; l < nlo; ++l) {
+              rep->num_models += 1;
+              const uint32_t lc = (uint32_t)score_model<FAM>(w, sm->lo_models + l * 9, max_residual, true);
+              const double lsum = ordered_residual_sum(w, max_residual);
+              if (lc > best_n || (lc == best_n && lsum < best_sum)) {
+                best_n = lc;
+                best_sum = lsum;
+                for (int k = 0; k < 9; ++k) best_model[k] = sm->lo_models[l * 9 + k];
+              }
+            }
+          }
+          dyn_max_num_trials = w.nt_table[best_n];
+        }
+        if (trial >= dyn_max_num_trials && trial >= opt.min_num_trials) {
+          abort = true;
+          break;
+        }
+      }
+      if (abort) {
+        t_stop = t;
+        break;  // `trial` stays at the aborting trial
+      }
+    }
+    if (abort) {
+      // loransac.h:129-134: one more loop increment, and +1 inside the loop if it is entered again
+      trial = (trial + 1 < max_num_trials) ? trial + 2 : trial + 1;
+      // rewind the generator to just after the sample of trial t_stop
+      if (t_stop != nb - 1) {
+        wv_sync();
+        for (int i = lane; i < 624; i += 64) sm->mt[i] = sm->mt_bak[i];
+        wv_sync();
+        if (lane == 0) {
+          sm->mti = sm->mti_bak;
+          const uint32_t target = sm->draws_end[t_stop];
+          sm->calls = 0;
+          while (sm->calls < target) (void)mt_next(sm);
+        }
+        wv_sync();
+      }
+    }
+  }
+  rep->num_trials = trial;
+  rep->num_inliers = best_n;
+  rep->residual_sum = best_sum;
+  for (int k = 0; k < 9; ++k) rep->model[k] = best_model[k];
+  if (best_n < (uint32_t)F::K) return;
+  rep->success = true;
+  score_model<FAM>(w, best_model, max_residual, true);  // residuals of the final model -> mask
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------ cameras
+// Camera::ImageToWorld for SIMPLE_PINHOLE / PINHOLE / SIMPLE_RADIAL,
+// /root/reference/src/base/camera_models.h:629-637, 679-689, 733-757, 547-587
+DSM_DEV void image_to_world(const dsm_camera& cam, double x, double y, double* u, double* v) {
+  if (cam.model_id == 0) {
+    const double f = cam.params[0], c1 = cam.params[1], c2 = cam.params[2];
+    *u = (x - c1) / f;
+    *v = (y - c2) / f;
+  } else if (cam.model_id == 1) {
+    const double f1 = cam.params[0], f2 = cam.params[1], c1 = cam.params[2], c2 = cam.params[3];
+    *u = (x - c1) / f1;
+    *v = (y - c2) / f2;
+  } else {
+    const double f = cam.params[0], c1 = cam.params[1], c2 = cam.params[2], k = cam.params[3];
+    const double x0_0 = (x - c1) / f, x0_1 = (y - c2) / f;
+    double x_0 = x0_0, x_1 = x0_1;
+    auto dist = [k](double uu, double vv, double* du, double* dv) {
+      const double u2 = uu * uu, v2 = vv * vv;
+      const double r2 = u2 + v2;
+      const double radial = k * r2;
+      *du = uu * radial;
+      *dv = vv * radial;
+    };
+    for (int it = 0; it < 100; ++it) {
+      const double a0 = fabs(1e-6 * x_0), a1 = fabs(1e-6 * x_1);
+      const double step0 = DBL_EPSILON > a0 ? DBL_EPSILON : a0;
+      const double step1 = DBL_EPSILON > a1 ? DBL_EPSILON : a1;
+      double dx0, dx1, b00, b01, f00, f01, b10, b11, f10, f11;
+      dist(x_0, x_1, &dx0, &dx1);
+      dist(x_0 - step0, x_1, &b00, &b01);
+      dist(x_0 + step0, x_1, &f00, &f01);
+      dist(x_0, x_1 - step1, &b10, &b11);
+      dist(x_0, x_1 + step1, &f10, &f11);
+      const double J00 = 1 + (f00 - b00) / (2 * step0);
+      const double J01 = (f10 - b10) / (2 * step1);
+      const double J10 = (f01 - b01) / (2 * step0);
+      const double J11 = 1 + (f11 - b11) / (2 * step1);
+      const double invdet = 1.0 / (J00 * J11 - J10 * J01);
+      const double i00 = J11 * invdet, i01 = -J01 * invdet, i10 = -J10 * invdet, i11 = J00 * invdet;
+      const double r0 = x_0 + dx0 - x0_0, r1 = x_1 + dx1 - x0_1;
+      const double s0 = i00 * r0 + i01 * r1;
+      const double s1 = i10 * r0 + i11 * r1;
+      x_0 -= s0;
+      x_1 -= s1;
+      if (s0 * s0 + s1 * s1 < 1e-10) break;
+    }
+    *u = x_0;
+    *v = x_1;
+  }
+}
+DSM_DEV double image_to_world_threshold(const dsm_camera& cam, double threshold) {
+  double mean_focal_length = 0;
+  if (cam.model_id == 1) {
+    mean_focal_length += cam.params[0];
+    mean_focal_length += cam.params[1];
+    mean_focal_length /= 2;
+  } else {
+    mean_focal_length += cam.params[0];
+    mean_focal_length /= 1;
+  }
+  return threshold / mean_focal_length;
+}
+
+// ------------------------------------------------------------------------------------ relative pose
+// TriangulatePoint (triangulation.cc:39-52) with P1 = [I | 0] and P2 = [R | t]; returns false never.
+DSM_DEVN void triangulate_point(const double* R, const double* t, double p1x, double p1y, double p2x, double p2y, double* X) {
+  double A[16];
+  const double P1[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  const double P2[12] = {R[0], R[1], R[2], t[0], R[3], R[4], R[5], t[1], R[6], R[7], R[8], t[2]};
+  for (int c = 0; c < 4; ++c) {
+    A[0 * 4 + c] = p1x * P1[8 + c] - P1[0 + c];
+    A[1 * 4 + c] = p1y * P1[8 + c] - P1[4 + c];
+    A[2 * 4 + c] = p2x * P2[8 + c] - P2[0 + c];
+    A[3 * 4 + c] = p2y * P2[8 + c] - P2[4 + c];
+  }
+  double V[16], sv[4];
+  pl_jacobi_svd_square<4, false>(A, nullptr, V, sv);
+  const double w = V[3 * 4 + 3];
+  X[0] = V[3 * 4 + 0] / w;
+  X[1] = V[3 * 4 + 1] / w;
+  X[2] = V[3 * 4 + 2] / w;
+}
+
+// CheckCheirality (pose.cc:225-247): lanes stride over the inlier correspondences; points in front
+// of both cameras are appended, in index order, to pts3d (3 doubles each).  Returns their number.
+DSM_DEV int check_cheirality(const double* R, const double* t, const double* ipts, int n, double* pts3d, int lane) {
+  const double kMinDepth = DBL_EPSILON;
+  double rt[3];
+  for (int i = 0; i < 3; ++i) rt[i] = R[0 * 3 + i] * t[0] + R[1 * 3 + i] * t[1] + R[2 * 3 + i] * t[2];
+  const double max_depth = 1000.0f * sqrt(rt[0] * rt[0] + rt[1] * rt[1] + rt[2] * rt[2]);
+  const double n1 = sqrt(0.0 * 0.0 + 0.0 * 0.0 + 1.0 * 1.0);
+  const double n2 = sqrt(R[2] * R[2] + R[5] * R[5] + R[8] * R[8]);
+  int total = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    bool ok = false;
+    double X[3] = {0, 0, 0};
+    if (i < n) {
+      const double* p = ipts + (size_t)i * 4;
+      triangulate_point(R, t, p[0], p[1], p[2], p[3], X);
+      const double d1 = (0.0 * X[0] + 0.0 * X[1] + 1.0 * X[2] + 0.0 * 1.0) * n1;
+      if (d1 > kMinDepth && d1 < max_depth) {
+        const double d2 = (R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2] * 1.0) * n2;
+        if (d2 > kMinDepth && d2 < max_depth) ok = true;
+      }
+    }
+    const unsigned long long bal = __ballot(ok);
+    if (ok) {
+      double* dst = pts3d + (size_t)(total + __popcll(bal & ((1ull << lane) - 1ull))) * 3;
+      dst[0] = X[0];
+      dst[1] = X[1];
+      dst[2] = X[2];
+    }
+    total += __popcll(bal);
+  }
+  wv_sync();
+  return total;
+}
+
+DSM_DEV void normalized3(const double* a, double* o) {
+  const double n2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+  if (n2 > 0) {
+    const double n = sqrt(n2);
+    for (int i = 0; i < 3; ++i) o[i] = a[i] / n;
+  } else {
+    for (int i = 0; i < 3; ++i) o[i] = a[i];
+  }
+}
+
+// Quaterniond(R) -> (w, x, y, z), Eigen/src/Geometry/Quaternion.h (pose.cc:70-73)
+DSM_DEV void rotation_to_quaternion(const double* R, double* q) {
+  double t = R[0] + R[4] + R[8];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0);
+    q[0] = 0.5 * t;
+    t = 0.5 / t;
+    q[1] = (R[7] - R[5]) * t;
+    q[2] = (R[2] - R[6]) * t;
+    q[3] = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 3 + i]) i = 2;
+    const int j = (i + 1) % 3;
+    const int k = (j + 1) % 3;
+    t = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
+    q[1 + i] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+    q[1 + j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+    q[1 + k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+  }
+}
+
+DSM_DEV double opp_minor(const double* M, int row, int col) {
+  const int col1 = col == 0 ? 1 : 0;
+  const int col2 = col == 2 ? 1 : 2;
+  const int row1 = row == 0 ? 1 : 0;
+  const int row2 = row == 2 ? 1 : 2;
+  return (M[row1 * 3 + col2] * M[row2 * 3 + col1] - M[row1 * 3 + col1] * M[row2 * 3 + col2]);
+}
+DSM_DEV int sign_of(double v) { return (0.0 < v) - (v < 0.0); }
+
+// DecomposeHomographyMatrix, base/homography_matrix.cc:65-165 (uniform; every lane computes it)
+DSM_DEVN int decompose_homography(const double* H, const double* K1, const double* K2, double* Rs, double* ts) {
+  double K2inv[9], T[9], Hn[9];
+  m3_inverse(K2, K2inv);
+  m3_mul(K2inv, H, T);
+  m3_mul(T, K1, Hn);
+  double V[9], sv[3];
+  pl_jacobi_svd_square<3, false>(Hn, nullptr, V, sv);
+  const double s1 = sv[1];
+  for (int i = 0; i < 9; ++i) Hn[i] /= s1;
+  double Hnt[9], S[9];
+  m3_transpose(Hn, Hnt);
+  m3_mul(Hnt, Hn, S);
+  S[0] -= 1; S[4] -= 1; S[8] -= 1;
+  double inf_norm = 0;
+  for (int i = 0; i < 9; ++i) inf_norm = fabs(S[i]) > inf_norm ? fabs(S[i]) : inf_norm;
+  if (inf_norm < 1e-3) {
+    for (int i = 0; i < 9; ++i) Rs[i] = Hn[i];
+    ts[0] = ts[1] = ts[2] = 0;
+    return 1;
+  }
+  const double M00 = opp_minor(S, 0, 0), M11 = opp_minor(S, 1, 1), M22 = opp_minor(S, 2, 2);
+  const double rtM00 = sqrt(M00), rtM11 = sqrt(M11), rtM22 = sqrt(M22);
+  const double M01 = opp_minor(S, 0, 1), M12 = opp_minor(S, 1, 2), M02 = opp_minor(S, 0, 2);
+  const int e12 = sign_of(M12), e02 = sign_of(M02), e01 = sign_of(M01);
+  const double nS[3] = {fabs(S[0]), fabs(S[4]), fabs(S[8])};
+  int idx = 0;
+  if (nS[1] > nS[idx]) idx = 1;
+  if (nS[2] > nS[idx]) idx = 2;
+  double np1[3], np2[3];
+  if (idx == 0) {
+    np1[0] = S[0]; np2[0] = S[0];
+    np1[1] = S[1] + rtM22; np2[1] = S[1] - rtM22;
+    np1[2] = S[2] + e12 * rtM11; np2[2] = S[2] - e12 * rtM11;
+  } else if (idx == 1) {
+    np1[0] = S[1] + rtM22; np2[0] = S[1] - rtM22;
+    np1[1] = S[4]; np2[1] = S[4];
+    np1[2] = S[5] - e02 * rtM00; np2[2] = S[5] + e02 * rtM00;
+  } else {
+    np1[0] = S[2] + e01 * rtM11; np2[0] = S[2] - e01 * rtM11;
+    np1[1] = S[5] + rtM00; np2[1] = S[5] - rtM00;
+    np1[2] = S[8]; np2[2] = S[8];
+  }
+  const double traceS = S[0] + S[4] + S[8];
+  const double v = 2.0 * sqrt(1.0 + traceS - M00 - M11 - M22);
+  const double ESii = sign_of(S[idx * 3 + idx]);
+  const double r_2 = 2 + traceS + v;
+  const double nt_2 = 2 + traceS - v;
+  const double r = sqrt(r_2);
+  const double n_t = sqrt(nt_2);
+  double n1[3], n2[3];
+  normalized3(np1, n1);
+  normalized3(np2, n2);
+  const double half_nt = 0.5 * n_t;
+  const double esii_t_r = ESii * r;
+  double t1_star[3], t2_star[3];
+  for (int i = 0; i < 3; ++i) {
+    t1_star[i] = half_nt * (esii_t_r * n2[i] - n_t * n1[i]);
+    t2_star[i] = half_nt * (esii_t_r * n1[i] - n_t * n2[i]);
+  }
+  double Mx[9], R1[9], R2[9];
+  const double s = 2.0 / v;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Mx[i * 3 + j] = (i == j ? 1.0 : 0.0) - (s * t1_star[i]) * n1[j];
+  m3_mul(Hn, Mx, R1);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Mx[i * 3 + j] = (i == j ? 1.0 : 0.0) - (s * t2_star[i]) * n2[j];
+  m3_mul(Hn, Mx, R2);
+  double t1[3], t2[3];
+  for (int i = 0; i < 3; ++i) {
+    t1[i] = R1[i * 3 + 0] * t1_star[0] + R1[i * 3 + 1] * t1_star[1] + R1[i * 3 + 2] * t1_star[2];
+    t2[i] = R2[i * 3 + 0] * t2_star[0] + R2[i * 3 + 1] * t2_star[1] + R2[i * 3 + 2] * t2_star[2];
+  }
+  for (int i = 0; i < 9; ++i) {
+    Rs[0 * 9 + i] = R1[i];
+    Rs[1 * 9 + i] = R1[i];
+    Rs[2 * 9 + i] = R2[i];
+    Rs[3 * 9 + i] = R2[i];
+  }
+  for (int i = 0; i < 3; ++i) {
+    ts[0 * 3 + i] = t1[i];
+    ts[1 * 3 + i] = -t1[i];
+    ts[2 * 3 + i] = t2[i];
+    ts[3 * 3 + i] = -t2[i];
+  }
+  return 4;
+}
+
+// ------------------------------------------------------------------------------------ kernel
+// Scratch layout per resident workgroup (doubles unless noted), n = n_max of the launch:
+//   pts_px [4n]  pts_norm [4n]  resid [n]  tall [18n + 81]  models [64*10*9]  pts3d_a [3n] pts3d_b [3n]
+//   ipts [4n]  inl (int) [n]
+__host__ __device__ inline size_t verify_scratch_doubles(size_t n) {
+  return 4 * n + 4 * n + n + (18 * n + 96) + (size_t)BATCH * 10 * 9 + 3 * n + 3 * n + 4 * n + (n + 1) / 2 + 8;
+}
+
+__global__ __launch_bounds__(64) void k_verify_pairs(const VerifyParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  VSmem* sm = reinterpret_cast<VSmem*>(smem_raw);
+  uint32_t* sidx = reinterpret_cast<uint32_t*>(smem_raw + ((sizeof(VSmem) + 15) / 16) * 16);
+  const int lane = threadIdx.x;
+  const size_t nmax = p.n_max;
+  double* base = p.scratch + (size_t)blockIdx.x * verify_scratch_doubles(nmax);
+  double* pts_px = base;
+  double* pts_norm = pts_px + 4 * nmax;
+  double* resid = pts_norm + 4 * nmax;
+  double* tall = resid + nmax;
+  double* models = tall + 18 * nmax + 96;
+  double* pts3d_a = models + (size_t)BATCH * 10 * 9;
+  double* pts3d_b = pts3d_a + 3 * nmax;
+  double* ipts = pts3d_b + 3 * nmax;
+  int* inl = reinterpret_cast<int*>(ipts + 4 * nmax);
+
+  for (uint32_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
+    wv_sync();
+    const uint32_t im1 = p.pairs[2 * pi], im2 = p.pairs[2 * pi + 1];
+    const uint64_t moff = p.match_off[pi];
+    const int n = (int)(p.match_off[pi + 1] - moff);
+    const uint32_t* matches = p.matches + 2 * moff;
+    dsm_two_view_geometry* out = p.tvg + pi;
+    uint32_t* out_inl = p.inlier_matches + 2 * moff;
+    const dsm_camera cam1 = p.cams[im1], cam2 = p.cams[im2];
+    const dsm_two_view_options& o = p.opt;
+
+    // result defaults: TwoViewGeometry(), two_view_geometry.h:159-166
+    int config = DSM_CONFIG_UNDEFINED;
+    double Em[9], Fm[9], Hm[9], qvec[4] = {0, 0, 0, 0}, tvec[3] = {0, 0, 0}, tri_angle = 0;
+    for (int k = 0; k < 9; ++k) Em[k] = Fm[k] = Hm[k] = 0.0;
+    uint32_t ntr[4] = {0, 0, 0, 0}, nmo[4] = {0, 0, 0, 0};
+    uint32_t num_inliers = 0;
+    bool have_mask = false;
+
+    const bool calibrated = cam1.has_prior_focal_length && cam2.has_prior_focal_length;
+    if ((uint64_t)n < o.min_num_inliers) {
+      config = DSM_CONFIG_DEGENERATE;  // two_view_geometry.cc:298-301, 433-436
+    } else {
+      // gather matched points (and their normalised versions for the calibrated path)
+      const double* kp1 = p.kp + (size_t)p.img_row0[im1] * 2;
+      const double* kp2 = p.kp + (size_t)p.img_row0[im2] * 2;
+      for (int i = lane; i < n; i += 64) {
+        const uint32_t i1 = matches[2 * i], i2 = matches[2 * i + 1];
+        const double x1 = kp1[2 * (size_t)i1], y1 = kp1[2 * (size_t)i1 + 1];
+        const double x2 = kp2[2 * (size_t)i2], y2 = kp2[2 * (size_t)i2 + 1];
+        pts_px[4 * i + 0] = x1; pts_px[4 * i + 1] = y1; pts_px[4 * i + 2] = x2; pts_px[4 * i + 3] = y2;
+        if (calibrated) {
+          double u1, v1, u2, v2;
+          image_to_world(cam1, x1, y1, &u1, &v1);
+          image_to_world(cam2, x2, y2, &u2, &v2);
+          pts_norm[4 * i + 0] = u1; pts_norm[4 * i + 1] = v1; pts_norm[4 * i + 2] = u2; pts_norm[4 * i + 3] = v2;
+        }
+      }
+      if (lane == 0) mt_seed(sm, p.seeds[pi]);
+      wv_sync();
+
+      PairWork w;
+      w.n = n;
+      w.resid = resid;
+      w.inl = inl;
+      w.tall = tall;
+      w.models = models;
+      w.sm = sm;
+      w.lane = lane;
+      const uint32_t* ntbase = p.nt_table + p.nt_off[n];  // [4][n+1]: E, F, H, T(unused here)
+
+      RansacReport E_rep, F_rep, H_rep;
+      E_rep.success = false;
+      E_rep.num_inliers = 0;
+      E_rep.num_trials = E_rep.num_models = 0;
+      const double max_res_px = o.max_error * o.max_error;
+      // masks: kept as bytes in the tail of `tall`'s neighbour area (ipts region is free until pose)
+      unsigned char* maskE = reinterpret_cast<unsigned char*>(ipts);
+      unsigned char* maskF = maskE + nmax;
+      unsigned char* maskH = maskF + nmax;
+      if (calibrated) {
+        RansacOpt ro;
+        ro.max_error = (image_to_world_threshold(cam1, o.max_error) + image_to_world_threshold(cam2, o.max_error)) / 2;
+        ro.min_num_trials = (uint32_t)o.min_num_trials;
+        ro.max_num_trials = p.max_trials[FAM_E];
+        w.pts = pts_norm;
+        w.nt_table = ntbase + 0 * (size_t)(n + 1);
+        lo_ransac<FAM_E>(w, ro, sidx, &E_rep);
+        const double mr = ro.max_error * ro.max_error;
+        if (E_rep.success)
+          for (int i = lane; i < n; i += 64) maskE[i] = resid[i] <= mr;
+        for (int k = 0; k < 9; ++k) Em[k] = E_rep.model[k];
+        ntr[0] = E_rep.num_trials;
+        nmo[0] = E_rep.num_models;
+        wv_sync();
+      }
+      RansacOpt ro;
+      ro.max_error = o.max_error;
+      ro.min_num_trials = (uint32_t)o.min_num_trials;
+      ro.max_num_trials = p.max_trials[FAM_F];
+      w.pts = pts_px;
+      w.nt_table = ntbase + 1 * (size_t)(n + 1);
+      lo_ransac<FAM_F>(w, ro, sidx, &F_rep);
+      if (F_rep.success)
+        for (int i = lane; i < n; i += 64) maskF[i] = resid[i] <= max_res_px;
+      for (int k = 0; k < 9; ++k) Fm[k] = F_rep.model[k];
+      ntr[1] = F_rep.num_trials;
+      nmo[1] = F_rep.num_models;
+      wv_sync();
+      ro.max_num_trials = p.max_trials[FAM_H];
+      w.nt_table = ntbase + 2 * (size_t)(n + 1);
+      lo_ransac<FAM_H>(w, ro, sidx, &H_rep);
+      if (H_rep.success)
+        for (int i = lane; i < n; i += 64) maskH[i] = resid[i] <= max_res_px;
+      for (int k = 0; k < 9; ++k) Hm[k] = H_rep.model[k];
+      ntr[2] = H_rep.num_trials;
+      nmo[2] = H_rep.num_models;
+      wv_sync();
+
+      const unsigned char* best_mask = nullptr;
+      const uint64_t mni = o.min_num_inliers;
+      if (calibrated) {
+        // EstimateCalibrated decision tree, two_view_geometry.cc:344-413
+        if ((!E_rep.success && !F_rep.success && !H_rep.success) ||
+            (E_rep.num_inliers < mni && F_rep.num_inliers < mni && H_rep.num_inliers < mni)) {
+          config = DSM_CONFIG_DEGENERATE;
+        } else {
+          const double E_F = (double)E_rep.num_inliers / (double)F_rep.num_inliers;
+          const double H_F = (double)H_rep.num_inliers / (double)F_rep.num_inliers;
+          const double H_E = (double)H_rep.num_inliers / (double)E_rep.num_inliers;
+          if (E_rep.success && E_F > o.min_E_F_inlier_ratio && E_rep.num_inliers >= mni) {
+            if (E_rep.num_inliers >= F_rep.num_inliers) {
+              num_inliers = E_rep.num_inliers;
+              best_mask = maskE;
+            } else {
+              num_inliers = F_rep.num_inliers;
+              best_mask = maskF;
+            }
+            if (H_E > o.max_H_inlier_ratio) {
+              config = DSM_CONFIG_PLANAR_OR_PANORAMIC;
+              if (H_rep.num_inliers > num_inliers) {
+                num_inliers = H_rep.num_inliers;
+                best_mask = maskH;
+              }
+            } else {
+              config = DSM_CONFIG_CALIBRATED;
+            }
+          } else if (F_rep.success && F_rep.num_inliers >= mni) {
+            num_inliers = F_rep.num_inliers;
+            best_mask = maskF;
+            if (H_F > o.max_H_inlier_ratio) {
+              config = DSM_CONFIG_PLANAR_OR_PANORAMIC;
+              if (H_rep.num_inliers > num_inliers) {
+                num_inliers = H_rep.num_inliers;
+                best_mask = maskH;
+              }
+            } else {
+              config = DSM_CONFIG_UNCALIBRATED;
+            }
+          } else if (H_rep.success && H_rep.num_inliers >= mni) {
+            num_inliers = H_rep.num_inliers;
+            best_mask = maskH;
+            config = DSM_CONFIG_PLANAR_OR_PANORAMIC;
+          } else {
+            config = DSM_CONFIG_DEGENERATE;
+          }
+        }
+      } else {
+        // EstimateUncalibrated, two_view_geometry.cc:461-488
+        if ((!F_rep.success && !H_rep.success) || (F_rep.num_inliers < mni && H_rep.num_inliers < mni)) {
+          config = DSM_CONFIG_DEGENERATE;
+        } else {
+          const double H_F = (double)H_rep.num_inliers / (double)F_rep.num_inliers;
+          config = (H_F > o.max_H_inlier_ratio) ? DSM_CONFIG_PLANAR_OR_PANORAMIC : DSM_CONFIG_UNCALIBRATED;
+          if (F_rep.success) {
+            num_inliers = F_rep.num_inliers;
+            best_mask = maskF;
+          } else {
+            num_inliers = 0;  // all-false mask
+            for (int i = lane; i < n; i += 64) maskF[i] = 0;
+            best_mask = maskF;
+            wv_sync();
+          }
+        }
+      }
+
+      if (best_mask != nullptr) {
+        have_mask = true;
+        // ExtractInlierMatches (two_view_geometry.cc:53-65): ordered compaction; also inl[] for later
+        int total = 0;
+        for (int b0 = 0; b0 < n; b0 += 64) {
+          const int i = b0 + lane;
+          const bool in = (i < n) && best_mask[i];
+          const unsigned long long bal = __ballot(in);
+          if (in) {
+            const int pos = total + __popcll(bal & ((1ull << lane) - 1ull));
+            out_inl[2 * pos] = matches[2 * i];
+            out_inl[2 * pos + 1] = matches[2 * i + 1];
+            inl[pos] = i;
+          }
+          total += __popcll(bal);
+        }
+        wv_sync();
+        num_inliers = (uint32_t)total;
+
+        // DetectWatermark, two_view_geometry.cc:491-555
+        if (o.detect_watermark && num_inliers > 0) {
+          const double diagonal1 = sqrt((double)(cam1.width * cam1.width + cam1.height * cam1.height));
+          const double diagonal2 = sqrt((double)(cam2.width * cam2.width + cam2.height * cam2.height));
+          const double minx1 = o.watermark_border_size * diagonal1, miny1 = minx1;
+          const double maxx1 = cam1.width - minx1, maxy1 = cam1.height - miny1;
+          const double minx2 = o.watermark_border_size * diagonal2, miny2 = minx2;
+          const double maxx2 = cam2.width - minx2, maxy2 = cam2.height - miny2;
+          int in_border = 0;
+          for (int b0 = 0; b0 < total; b0 += 64) {
+            const int j = b0 + lane;
+            bool hit = false;
+            if (j < total) {
+              const double* q = pts_px + 4 * (size_t)inl[j];
+              const bool in1 = q[0] >= minx1 && q[0] <= maxx1 && q[1] >= miny1 && q[1] <= maxy1;
+              const bool in2 = q[2] >= minx2 && q[2] <= maxx2 && q[3] >= miny2 && q[3] <= maxy2;
+              hit = !in1 && !in2;
+            }
+            in_border += __popcll(__ballot(hit));
+          }
+          const double border_ratio = (double)in_border / (double)num_inliers;
+          if (!(border_ratio < o.watermark_min_inlier_ratio)) {
+            // translation LO-RANSAC over the inlier points (gathered into pts_norm's unused half or ipts)
+            double* tp = pts3d_a;  // 4 * total doubles fit: pts3d_a + pts3d_b are contiguous (6n)
+            for (int j = lane; j < total; j += 64) {
+              const double* q = pts_px + 4 * (size_t)inl[j];
+              tp[4 * j + 0] = q[0]; tp[4 * j + 1] = q[1]; tp[4 * j + 2] = q[2]; tp[4 * j + 3] = q[3];
+            }
+            wv_sync();
+            PairWork wt = w;
+            wt.n = total;
+            wt.pts = tp;
+            wt.nt_table = p.nt_table + p.nt_off_t[total];
+            RansacOpt rt;
+            rt.max_error = o.max_error;
+            rt.min_num_trials = (uint32_t)o.min_num_trials;
+            rt.max_num_trials = p.max_trials[FAM_T];
+            RansacReport T_rep;
+            lo_ransac<FAM_T>(wt, rt, sidx, &T_rep);
+            ntr[3] = T_rep.num_trials;
+            nmo[3] = T_rep.num_models;
+            const double inlier_ratio = (double)T_rep.num_inliers / (double)num_inliers;
+            if (inlier_ratio >= o.watermark_min_inlier_ratio) config = DSM_CONFIG_WATERMARK;
+            // inl[] was reused by the translation RANSAC: rebuild it from the mask
+            int tot2 = 0;
+            for (int b0 = 0; b0 < n; b0 += 64) {
+              const int i = b0 + lane;
+              const bool in = (i < n) && best_mask[i];
+              const unsigned long long bal = __ballot(in);
+              if (in) inl[tot2 + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+              tot2 += __popcll(bal);
+            }
+            wv_sync();
+          }
+        }
+      }
+
+      // EstimateWithRelativePose, two_view_geometry.cc:232-290 (skipped for DEGENERATE: SURVEY.md H8)
+      if (calibrated && have_mask && config != DSM_CONFIG_DEGENERATE && config != DSM_CONFIG_UNDEFINED) {
+        const int ni = (int)num_inliers;
+        for (int j = lane; j < ni; j += 64) {  // inlier_points{1,2}_N, in inlier order
+          const double* q = pts_norm + 4 * (size_t)inl[j];
+          ipts[4 * j + 0] = q[0]; ipts[4 * j + 1] = q[1]; ipts[4 * j + 2] = q[2]; ipts[4 * j + 3] = q[3];
+        }
+        wv_sync();
+        double Rbest[9];
+        for (int k = 0; k < 9; ++k) Rbest[k] = 0.0;
+        int nbest = 0;
+        double* pbest = pts3d_a;
+        double* pcur = pts3d_b;
+        double Rc[4 * 9], tc[4 * 3];
+        int ncmb;
+        if (config == DSM_CONFIG_CALIBRATED || config == DSM_CONFIG_UNCALIBRATED) {
+          // DecomposeEssentialMatrix, base/essential_matrix.cc:41-62
+          double U[9], V[9], sv[3];
+          pl_jacobi_svd_square<3, true>(Em, U, V, sv);
+          double Ur[9], Vt[9];  // row-major U, and V^T (row-major)
+          for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+              Ur[i * 3 + j] = U[j * 3 + i];
+              Vt[i * 3 + j] = V[i * 3 + j];
+            }
+          if (m3_det(Ur) < 0)
+            for (int i = 0; i < 9; ++i) Ur[i] *= -1;
+          if (m3_det(Vt) < 0)
+            for (int i = 0; i < 9; ++i) Vt[i] *= -1;
+          const double W[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
+          double Wt[9], T1[9], R1[9], R2[9];
+          m3_transpose(W, Wt);
+          m3_mul(Ur, W, T1);
+          m3_mul(T1, Vt, R1);
+          m3_mul(Ur, Wt, T1);
+          m3_mul(T1, Vt, R2);
+          const double u2[3] = {Ur[2], Ur[5], Ur[8]};
+          double t0[3];
+          normalized3(u2, t0);
+          for (int k = 0; k < 9; ++k) {
+            Rc[0 * 9 + k] = R1[k];
+            Rc[1 * 9 + k] = R2[k];
+            Rc[2 * 9 + k] = R1[k];
+            Rc[3 * 9 + k] = R2[k];
+          }
+          for (int k = 0; k < 3; ++k) {
+            tc[0 * 3 + k] = t0[k];
+            tc[1 * 3 + k] = t0[k];
+            tc[2 * 3 + k] = -t0[k];
+            tc[3 * 3 + k] = -t0[k];
+            tvec[k] = t0[k];
+          }
+          ncmb = 4;
+        } else {
+          // PoseFromHomographyMatrix, base/homography_matrix.cc:167-192 (K from Camera::CalibrationMatrix)
+          double K1[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, K2[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+          if (cam1.model_id == 1) {
+            K1[0] = cam1.params[0]; K1[4] = cam1.params[1]; K1[2] = cam1.params[2]; K1[5] = cam1.params[3];
+          } else {
+            K1[0] = cam1.params[0]; K1[4] = cam1.params[0]; K1[2] = cam1.params[1]; K1[5] = cam1.params[2];
+          }
+          if (cam2.model_id == 1) {
+            K2[0] = cam2.params[0]; K2[4] = cam2.params[1]; K2[2] = cam2.params[2]; K2[5] = cam2.params[3];
+          } else {
+            K2[0] = cam2.params[0]; K2[4] = cam2.params[0]; K2[2] = cam2.params[1]; K2[5] = cam2.params[2];
+          }
+          ncmb = decompose_homography(Hm, K1, K2, Rc, tc);
+        }
+        for (int c = 0; c < ncmb; ++c) {
+          const int cnt = check_cheirality(Rc + c * 9, tc + c * 3, ipts, ni, pcur, lane);
+          if (cnt >= nbest) {
+            for (int k = 0; k < 9; ++k) Rbest[k] = Rc[c * 9 + k];
+            for (int k = 0; k < 3; ++k) tvec[k] = tc[c * 3 + k];
+            nbest = cnt;
+            double* tsw = pbest;
+            pbest = pcur;
+            pcur = tsw;
+          }
+        }
+        rotation_to_quaternion(Rbest, qvec);
+        if (nbest == 0) {
+          tri_angle = 0;
+        } else {
+          // Median(CalculateTriangulationAnglesWithPM), triangulation.cc:183-218, math.h:211-229
+          double c2[3];
+          for (int i = 0; i < 3; ++i) c2[i] = -(Rbest[0 * 3 + i] * tvec[0] + Rbest[1 * 3 + i] * tvec[1] + Rbest[2 * 3 + i] * tvec[2]);
+          const double c1[3] = {-(1.0 * 0.0 + 0.0 * 0.0 + 0.0 * 0.0), -(0.0 * 0.0 + 1.0 * 0.0 + 0.0 * 0.0), -(0.0 * 0.0 + 0.0 * 0.0 + 1.0 * 0.0)};
+          double baseline2 = 0;
+          for (int i = 0; i < 3; ++i) baseline2 += (c1[i] - c2[i]) * (c1[i] - c2[i]);
+          double* ang = resid;
+          for (int j = lane; j < nbest; j += 64) {
+            const double* X = pbest + 3 * (size_t)j;
+            double r1 = 0, r2 = 0;
+            for (int k = 0; k < 3; ++k) {
+              r1 += (X[k] - c1[k]) * (X[k] - c1[k]);
+              r2 += (X[k] - c2[k]) * (X[k] - c2[k]);
+            }
+            const double ray1 = sqrt(r1), ray2 = sqrt(r2);
+            const double angle = fabs(acos((ray1 * ray1 + ray2 * ray2 - baseline2) / (2 * ray1 * ray2)));
+            ang[j] = isnan(angle) ? 0.0 : (angle < M_PI - angle ? angle : M_PI - angle);
+          }
+          wv_sync();
+          // median by rank counting: element of rank mid (and mid-1 for even sizes)
+          const int mid = nbest / 2;
+          double lo_v = 0.0, hi_v = 0.0;
+          int have = 0;
+          for (int b0 = 0; b0 < nbest; b0 += 64) {
+            const int j = b0 + lane;
+            bool is_mid = false, is_lo = false;
+            double a = 0.0;
+            if (j < nbest) {
+              a = ang[j];
+              int rank = 0;
+              for (int k = 0; k < nbest; ++k) {
+                const double b = ang[k];
+                rank += (b < a) || (b == a && k < j);
+              }
+              is_mid = rank == mid;
+              is_lo = rank == mid - 1;
+            }
+            const unsigned long long bm = __ballot(is_mid), bl = __ballot(is_lo);
+            if (bm) {
+              hi_v = __shfl(a, __ffsll((long long)bm) - 1);
+              have |= 1;
+            }
+            if (bl) {
+              lo_v = __shfl(a, __ffsll((long long)bl) - 1);
+              have |= 2;
+            }
+          }
+          tri_angle = (nbest % 2 == 0) ? (hi_v + lo_v) / 2.0 : hi_v;
+          (void)have;
+        }
+        if (config == DSM_CONFIG_PLANAR_OR_PANORAMIC) {
+          const double tn = sqrt(tvec[0] * tvec[0] + tvec[1] * tvec[1] + tvec[2] * tvec[2]);
+          if (tn == 0) {
+            config = DSM_CONFIG_PANORAMIC;
+            tri_angle = 0;
+          } else {
+            config = DSM_CONFIG_PLANAR;
+          }
+        }
+      }
+    }
+
+    // SiftFeatureMatcher::Match post-filter (matching.cc:824-831) when requested
+    if (p.stage_filter && (uint64_t)num_inliers < o.min_num_inliers) {
+      config = DSM_CONFIG_UNDEFINED;
+      for (int k = 0; k < 9; ++k) Em[k] = Fm[k] = Hm[k] = 0.0;
+      for (int k = 0; k < 4; ++k) qvec[k] = 0.0;
+      for (int k = 0; k < 3; ++k) tvec[k] = 0.0;
+      tri_angle = 0;
+      num_inliers = 0;
+    }
+    if (lane == 0) {
+      out->config = config;
+      out->num_inliers = num_inliers;
+      out->num_matches = (uint32_t)n;
+      out->reserved = 0;
+      for (int k = 0; k < 9; ++k) {
+        out->F[k] = Fm[k];
+        out->E[k] = Em[k];
+        out->H[k] = Hm[k];
+      }
+      for (int k = 0; k < 4; ++k) out->qvec[k] = qvec[k];
+      for (int k = 0; k < 3; ++k) out->tvec[k] = tvec[k];
+      out->tri_angle = tri_angle;
+      p.inl_counts[pi] = num_inliers;
+      for (int k = 0; k < 4; ++k) {
+        out->num_trials[k] = ntr[k];
+        out->num_models[k] = nmo[k];
+      }
+    }
+  }
+}
+
+size_t verify_scratch_bytes_per_block(uint32_t n_max) { return verify_scratch_doubles(n_max) * sizeof(double); }
+size_t verify_smem_bytes(uint32_t n_max) { return ((sizeof(VSmem) + 15) / 16) * 16 + (size_t)(n_max > 0 ? n_max : 1) * 4; }
+
+void launch_verify(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
+  if (p.n_pairs == 0 || n_blocks == 0) return;
+  hipLaunchKernelGGL(k_verify_pairs, dim3(n_blocks), dim3(64), verify_smem_bytes(p.n_max), st, p);
+}
+
+// Compaction of the per-pair inlier matches (stored at the pair's match offset) into list order.
+__global__ __launch_bounds__(64) void k_compact_inliers(const uint64_t* match_off, const uint64_t* inl_off,
+                                                        const uint32_t* inl_counts, const uint32_t* src, uint32_t* dst,
+                                                        uint32_t n_pairs) {
+  for (uint32_t pi = blockIdx.x; pi < n_pairs; pi += gridDim.x) {
+    const uint2* s = reinterpret_cast<const uint2*>(src) + match_off[pi];
+    uint2* d = reinterpret_cast<uint2*>(dst) + inl_off[pi];
+    for (uint32_t i = threadIdx.x; i < inl_counts[pi]; i += 64) d[i] = s[i];
+  }
+}
+void launch_compact_inliers(const uint64_t* match_off, const uint64_t* inl_off, const uint32_t* inl_counts,
+                            const uint32_t* src, uint32_t* dst, uint32_t n_pairs, hipStream_t st) {
+  if (!n_pairs) return;
+  const uint32_t blocks = n_pairs < 8192 ? n_pairs : 8192;
+  hipLaunchKernelGGL(k_compact_inliers, dim3(blocks), dim3(64), 0, st, match_off, inl_off, inl_counts, src, dst, n_pairs);
+}
+
+// ------------------------------------------------------------------------------------ debug hooks
+// Sample sequence of the device sampler (MT19937 + Lemire + partial Fisher-Yates) for parity tests.
+__global__ void k_debug_samples(uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out, uint32_t* idx) {
+  __shared__ VSmem sm;
+  if (threadIdx.x == 0) {
+    mt_seed(&sm, seed);
+    sm.calls = 0;
+    for (uint32_t i = 0; i < total; ++i) idx[i] = i;
+    for (uint32_t d = 0; d < n_draws; ++d) {
+      for (uint32_t i = 0; i < k; ++i) {
+        const uint32_t j = uniform_u32(&sm, i, total - 1);
+        const uint32_t a = idx[i];
+        idx[i] = idx[j];
+        idx[j] = a;
+      }
+      for (uint32_t i = 0; i < k; ++i) out[d * k + i] = idx[i];
+    }
+  }
+}
+void launch_debug_samples(uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out, uint32_t* idx, hipStream_t st) {
+  hipLaunchKernelGGL(k_debug_samples, dim3(1), dim3(64), 0, st, seed, k, total, n_draws, out, idx);
+}

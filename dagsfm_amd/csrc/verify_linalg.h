@@ -1,0 +1,962 @@
+// verify_linalg.h -- device-side FP64 linear algebra of the two-view verification kernels.
+//
+// Two flavours, both with the *same floating-point operation order* as the CPU path they are
+// checked against (reductions accumulate sequentially in index order; -ffp-contract=off):
+//   pl_*  "per lane": each lane owns a small problem in private memory (minimal solvers:
+//         the 9x5 / 9x7 / 9x8 pivoted QR behind the 5-, 7- and 4-point solvers, 3x3 / 4x4 Jacobi
+//         SVD, companion-matrix eigenvalues, 10x10 LU).
+//   wv_*  "per wave": the 64 lanes of a one-wave workgroup cooperate on one problem (the tall
+//         n x 9 systems of the local-optimisation estimators): element-wise updates are spread
+//         over the lanes, every dot product / norm is summed by ONE lane in index order.
+//
+// Algorithms: Eigen 3.3's JacobiSVD with ColPivHouseholderQR preconditioner, RealSchur
+// (Francis double-shift QR), PartialPivLU -- the routines the reference calls at
+//   /root/reference/src/estimators/fundamental_matrix.cc:74,174,181
+//   /root/reference/src/estimators/essential_matrix.cc:71,80,130
+//   /root/reference/src/estimators/homography_matrix.cc:83
+//   /root/reference/src/base/polynomial.cc:250, base/essential_matrix.cc:43, base/triangulation.cc:50
+// For a matrix with more columns than rows the null-space columns of V come straight from the
+// Householder Q of the transposed matrix and are never touched by the Jacobi sweeps, so the
+// minimal solvers run the pivoted QR only.
+#ifndef DAGSFM_AMD_CSRC_VERIFY_LINALG_H_
+#define DAGSFM_AMD_CSRC_VERIFY_LINALG_H_
+
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#define DSM_DEV __device__ __forceinline__
+#define DSM_DEVN __device__ __noinline__
+
+// ====================================================================== per-lane routines
+// Column-major storage with leading dimension ld, like Eigen.
+
+DSM_DEV void pl_make_householder(double* x, int n, double* tau, double* beta) {
+  double tail_sq = 0.0;
+  for (int i = 1; i < n; ++i) tail_sq += x[i] * x[i];
+  const double c0 = x[0];
+  if (tail_sq <= DBL_MIN) {
+    *tau = 0.0;
+    *beta = c0;
+    for (int i = 1; i < n; ++i) x[i] = 0.0;
+  } else {
+    double b = sqrt(c0 * c0 + tail_sq);
+    if (c0 >= 0.0) b = -b;
+    for (int i = 1; i < n; ++i) x[i] = x[i] / (c0 - b);
+    *tau = (b - c0) / b;
+    *beta = b;
+  }
+}
+
+DSM_DEV void pl_apply_householder_left(double* M, int ld, int r0, int c0, int nr, int nc, const double* ess, double tau) {
+  if (nr == 1) {
+    for (int j = 0; j < nc; ++j) M[(c0 + j) * ld + r0] *= (1.0 - tau);
+  } else if (tau != 0.0) {
+    for (int j = 0; j < nc; ++j) {
+      double* col = M + (c0 + j) * ld + r0;
+      double tmp = 0.0;
+      for (int i = 1; i < nr; ++i) tmp += ess[i - 1] * col[i];
+      tmp += col[0];
+      col[0] -= tau * tmp;
+      for (int i = 1; i < nr; ++i) col[i] -= tau * ess[i - 1] * tmp;
+    }
+  }
+}
+
+DSM_DEV void pl_apply_householder_right(double* M, int ld, int r0, int c0, int nr, int nc, const double* ess, double tau) {
+  if (nc == 1) {
+    for (int i = 0; i < nr; ++i) M[c0 * ld + r0 + i] *= (1.0 - tau);
+  } else if (tau != 0.0) {
+    for (int i = 0; i < nr; ++i) {
+      double tmp = 0.0;
+      for (int j = 1; j < nc; ++j) tmp += M[(c0 + j) * ld + r0 + i] * ess[j - 1];
+      tmp += M[c0 * ld + r0 + i];
+      M[c0 * ld + r0 + i] -= tau * tmp;
+      for (int j = 1; j < nc; ++j) M[(c0 + j) * ld + r0 + i] -= tau * tmp * ess[j - 1];
+    }
+  }
+}
+
+// ColPivHouseholderQR::computeInPlace on qr (rows x cols, rows >= cols here), ld = rows.
+DSM_DEV void pl_colpiv_qr(double* qr, int rows, int cols, double* hcoeffs) {
+  const int size = rows < cols ? rows : cols;
+  double norms_updated[9], norms_direct[9];
+  for (int k = 0; k < cols; ++k) {
+    double s = 0.0;
+    for (int i = 0; i < rows; ++i) s += qr[k * rows + i] * qr[k * rows + i];
+    norms_direct[k] = sqrt(s);
+    norms_updated[k] = norms_direct[k];
+  }
+  const double norm_downdate_threshold = sqrt(DBL_EPSILON);
+  for (int k = 0; k < size; ++k) {
+    int biggest = k;
+    double mx = norms_updated[k];
+    for (int j = k + 1; j < cols; ++j)
+      if (norms_updated[j] > mx) {
+        mx = norms_updated[j];
+        biggest = j;
+      }
+    if (k != biggest) {
+      for (int i = 0; i < rows; ++i) {
+        const double t = qr[k * rows + i];
+        qr[k * rows + i] = qr[biggest * rows + i];
+        qr[biggest * rows + i] = t;
+      }
+      double t = norms_updated[k];
+      norms_updated[k] = norms_updated[biggest];
+      norms_updated[biggest] = t;
+      t = norms_direct[k];
+      norms_direct[k] = norms_direct[biggest];
+      norms_direct[biggest] = t;
+    }
+    double tau, beta;
+    pl_make_householder(qr + k * rows + k, rows - k, &tau, &beta);
+    hcoeffs[k] = tau;
+    qr[k * rows + k] = beta;
+    pl_apply_householder_left(qr, rows, k, k + 1, rows - k, cols - k - 1, qr + k * rows + k + 1, tau);
+    for (int j = k + 1; j < cols; ++j) {
+      if (norms_updated[j] != 0.0) {
+        double temp = fabs(qr[j * rows + k]) / norms_updated[j];
+        temp = (1.0 + temp) * (1.0 - temp);
+        temp = temp < 0.0 ? 0.0 : temp;
+        const double ratio = norms_updated[j] / norms_direct[j];
+        const double temp2 = temp * (ratio * ratio);
+        if (temp2 <= norm_downdate_threshold) {
+          double s = 0.0;
+          for (int i = k + 1; i < rows; ++i) s += qr[j * rows + i] * qr[j * rows + i];
+          norms_direct[j] = sqrt(s);
+          norms_updated[j] = norms_direct[j];
+        } else {
+          norms_updated[j] *= sqrt(temp);
+        }
+      }
+    }
+  }
+}
+
+// Column j of householderQ() (rows x rows) of a pivoted QR with `size` reflectors.
+DSM_DEV void pl_householder_q_col(const double* qr, int rows, int size, const double* hcoeffs, int j, double* q) {
+  for (int i = 0; i < rows; ++i) q[i] = (i == j) ? 1.0 : 0.0;
+  for (int k = size - 1; k >= 0; --k) {
+    if (j < k) continue;  // the block starts at column k
+    const int nr = rows - k;
+    const double tau = hcoeffs[k];
+    const double* ess = qr + k * rows + k + 1;
+    if (nr == 1) {
+      q[k] *= (1.0 - tau);
+    } else if (tau != 0.0) {
+      double tmp = 0.0;
+      for (int i = 1; i < nr; ++i) tmp += ess[i - 1] * q[k + i];
+      tmp += q[k];
+      q[k] -= tau * tmp;
+      for (int i = 1; i < nr; ++i) q[k + i] -= tau * ess[i - 1] * tmp;
+    }
+  }
+}
+
+// Null-space columns of V for a `m x 9` system with m < 9 (JacobiSVD "more columns than rows"
+// path): V = householderQ of ColPivQR((A / scale)^T).  At holds A^T (9 x m, column-major, ld 9)
+// and is destroyed.  Writes columns first..8 of V into out[(c - first) * 9 + r].
+DSM_DEV void pl_nullspace_9xm(double* At, int m, int first, double* out) {
+  double scale = 0.0;
+  for (int i = 0; i < 9 * m; ++i) {
+    const double a = fabs(At[i]);
+    if (a > scale) scale = a;
+  }
+  if (scale == 0.0) scale = 1.0;
+  for (int i = 0; i < 9 * m; ++i) At[i] /= scale;
+  double hco[8];
+  pl_colpiv_qr(At, 9, m, hco);
+  for (int c = first; c < 9; ++c) pl_householder_q_col(At, 9, m, hco, c, out + (c - first) * 9);
+}
+
+// makeJacobi(x, y, z)
+DSM_DEV void dsm_make_jacobi(double x, double y, double z, double* c, double* s) {
+  const double deno = 2.0 * fabs(y);
+  if (deno < DBL_MIN) {
+    *c = 1.0;
+    *s = 0.0;
+  } else {
+    const double tau = (x - z) / deno;
+    const double w = sqrt(tau * tau + 1.0);
+    double t;
+    if (tau > 0.0)
+      t = 1.0 / (tau + w);
+    else
+      t = 1.0 / (tau - w);
+    const double sign_t = t > 0.0 ? 1.0 : -1.0;
+    const double n = 1.0 / sqrt(t * t + 1.0);
+    *s = -sign_t * (y / fabs(y)) * fabs(t) * n;
+    *c = n;
+  }
+}
+
+// real_2x2_jacobi_svd: left rotation (lc, ls) and right rotation (rc, rs) for the block
+// [[wpp, wpq], [wqp, wqq]].
+DSM_DEV void dsm_jacobi_2x2(double m00, double m01, double m10, double m11, double* lc, double* ls, double* rc, double* rs) {
+  double r1c, r1s;
+  const double t = m00 + m11;
+  const double d = m10 - m01;
+  if (fabs(d) < DBL_MIN) {
+    r1s = 0.0;
+    r1c = 1.0;
+  } else {
+    const double u = t / d;
+    const double tmp = sqrt(1.0 + u * u);
+    r1s = 1.0 / tmp;
+    r1c = u / tmp;
+  }
+  const double a0 = r1c * m00 + r1s * m10, a1 = r1c * m01 + r1s * m11;
+  const double b1 = -r1s * m01 + r1c * m11;
+  double jc, js;
+  dsm_make_jacobi(a0, a1, b1, &jc, &js);
+  *rc = jc;
+  *rs = js;
+  *lc = r1c * jc - r1s * (-js);
+  *ls = r1c * (-js) + r1s * jc;
+}
+
+// JacobiSVD of a square N x N matrix (no preconditioner).  A is row-major in, W/U/V column-major
+// scratch; outputs singular values (descending), U and V column-major.
+template <int N, bool WANT_U>
+DSM_DEV void pl_jacobi_svd_square(const double* A_rowmajor, double* U, double* V, double* sv) {
+  double W[N * N];
+  double scale = 0.0;
+  for (int i = 0; i < N * N; ++i) {
+    const double a = fabs(A_rowmajor[i]);
+    if (a > scale) scale = a;
+  }
+  if (scale == 0.0) scale = 1.0;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      W[j * N + i] = A_rowmajor[i * N + j] / scale;
+      V[j * N + i] = (i == j) ? 1.0 : 0.0;
+      if (WANT_U) U[j * N + i] = (i == j) ? 1.0 : 0.0;
+    }
+  const double precision = 2.0 * DBL_EPSILON;
+  double max_diag = 0.0;
+  for (int i = 0; i < N; ++i)
+    if (fabs(W[i * N + i]) > max_diag) max_diag = fabs(W[i * N + i]);
+  bool finished = false;
+  while (!finished) {
+    finished = true;
+    for (int p = 1; p < N; ++p) {
+      for (int q = 0; q < p; ++q) {
+        const double thr = DBL_MIN > precision * max_diag ? DBL_MIN : precision * max_diag;
+        if (fabs(W[q * N + p]) > thr || fabs(W[p * N + q]) > thr) {
+          finished = false;
+          double lc, ls, rc, rs;
+          dsm_jacobi_2x2(W[p * N + p], W[q * N + p], W[p * N + q], W[q * N + q], &lc, &ls, &rc, &rs);
+          if (!(lc == 1.0 && ls == 0.0)) {
+            for (int j = 0; j < N; ++j) {  // rows p, q
+              const double xi = W[j * N + p], yi = W[j * N + q];
+              W[j * N + p] = lc * xi + ls * yi;
+              W[j * N + q] = -ls * xi + lc * yi;
+            }
+            if (WANT_U)
+              for (int i = 0; i < N; ++i) {  // columns p, q of U
+                const double xi = U[p * N + i], yi = U[q * N + i];
+                U[p * N + i] = lc * xi + ls * yi;
+                U[q * N + i] = -ls * xi + lc * yi;
+              }
+          }
+          if (!(rc == 1.0 && -rs == 0.0)) {
+            for (int i = 0; i < N; ++i) {  // columns p, q with (rc, -rs)
+              const double xi = W[p * N + i], yi = W[q * N + i];
+              W[p * N + i] = rc * xi + (-rs) * yi;
+              W[q * N + i] = rs * xi + rc * yi;
+            }
+            for (int i = 0; i < N; ++i) {
+              const double xi = V[p * N + i], yi = V[q * N + i];
+              V[p * N + i] = rc * xi + (-rs) * yi;
+              V[q * N + i] = rs * xi + rc * yi;
+            }
+          }
+          const double app = fabs(W[p * N + p]), aqq = fabs(W[q * N + q]);
+          const double mm = app > aqq ? app : aqq;
+          if (mm > max_diag) max_diag = mm;
+        }
+      }
+    }
+  }
+  for (int i = 0; i < N; ++i) {
+    const double a = W[i * N + i];
+    sv[i] = fabs(a);
+    if (WANT_U && a < 0.0)
+      for (int r = 0; r < N; ++r) U[i * N + r] = -U[i * N + r];
+  }
+  for (int i = 0; i < N; ++i) sv[i] *= scale;
+  for (int i = 0; i < N; ++i) {
+    int pos = i;
+    double mx = sv[i];
+    for (int j = i + 1; j < N; ++j)
+      if (sv[j] > mx) {
+        mx = sv[j];
+        pos = j;
+      }
+    if (mx == 0.0) break;
+    if (pos != i) {
+      double t = sv[i];
+      sv[i] = sv[pos];
+      sv[pos] = t;
+      for (int r = 0; r < N; ++r) {
+        if (WANT_U) {
+          t = U[i * N + r];
+          U[i * N + r] = U[pos * N + r];
+          U[pos * N + r] = t;
+        }
+        t = V[i * N + r];
+        V[i * N + r] = V[pos * N + r];
+        V[pos * N + r] = t;
+      }
+    }
+  }
+}
+
+// Eigenvalues of an upper-Hessenberg n x n matrix T (column-major, ld = LD, destroyed):
+// EigenSolver(C, false) for companion matrices (the Hessenberg reduction is the identity on
+// them: every sub-sub-diagonal entry is already zero).  Returns false on non-convergence.
+template <int LD>
+DSM_DEVN bool pl_hessenberg_eigenvalues(double* T, int n, double* re, double* im) {
+#define TT(r, c) T[(c) * LD + (r)]
+  for (int i = 0; i < n; ++i) {
+    re[i] = 0.0;
+    im[i] = 0.0;
+  }
+  if (n == 0) return true;
+  double scale = 0.0;
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) {
+      const double a = fabs(TT(i, j));
+      if (a > scale) scale = a;
+    }
+  if (scale < DBL_MIN) return true;
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) TT(i, j) /= scale;
+  const int max_iters = 40 * n;
+  int iu = n - 1, iter = 0, total_iter = 0;
+  double exshift = 0.0;
+  double norm = 0.0;
+  for (int j = 0; j < n; ++j) {
+    const int lim = (j + 2 < n) ? j + 2 : n;
+    for (int i = 0; i < lim; ++i) norm += fabs(TT(i, j));
+  }
+  if (norm != 0.0) {
+    while (iu >= 0) {
+      int il = iu;
+      while (il > 0) {
+        double s = fabs(TT(il - 1, il - 1)) + fabs(TT(il, il));
+        if (s == 0.0) s = norm;
+        if (fabs(TT(il, il - 1)) < DBL_EPSILON * s) break;
+        il--;
+      }
+      if (il == iu) {
+        TT(iu, iu) = TT(iu, iu) + exshift;
+        if (iu > 0) TT(iu, iu - 1) = 0.0;
+        iu--;
+        iter = 0;
+      } else if (il == iu - 1) {
+        const double p = 0.5 * (TT(iu - 1, iu - 1) - TT(iu, iu));
+        const double q = p * p + TT(iu, iu - 1) * TT(iu - 1, iu);
+        TT(iu, iu) += exshift;
+        TT(iu - 1, iu - 1) += exshift;
+        if (q >= 0.0) {
+          const double z = sqrt(fabs(q));
+          const double gp = (p >= 0.0) ? (p + z) : (p - z);
+          const double gq = TT(iu, iu - 1);
+          double gc, gs;
+          if (gq == 0.0) {
+            gc = gp < 0.0 ? -1.0 : 1.0;
+            gs = 0.0;
+          } else if (gp == 0.0) {
+            gc = 0.0;
+            gs = gq < 0.0 ? 1.0 : -1.0;
+          } else if (fabs(gp) > fabs(gq)) {
+            const double t = gq / gp;
+            double u = sqrt(1.0 + t * t);
+            if (gp < 0.0) u = -u;
+            gc = 1.0 / u;
+            gs = -t * gc;
+          } else {
+            const double t = gp / gq;
+            double u = sqrt(1.0 + t * t);
+            if (gq < 0.0) u = -u;
+            gs = -1.0 / u;
+            gc = -t * gs;
+          }
+          if (!(gc == 1.0 && -gs == 0.0)) {
+            for (int c = iu - 1; c < n; ++c) {  // rows iu-1, iu with (gc, -gs)
+              const double xi = TT(iu - 1, c), yi = TT(iu, c);
+              TT(iu - 1, c) = gc * xi + (-gs) * yi;
+              TT(iu, c) = gs * xi + gc * yi;
+            }
+            for (int r = 0; r <= iu; ++r) {  // columns iu-1, iu with (gc, -gs)
+              const double xi = TT(r, iu - 1), yi = TT(r, iu);
+              TT(r, iu - 1) = gc * xi + (-gs) * yi;
+              TT(r, iu) = gs * xi + gc * yi;
+            }
+          }
+          TT(iu, iu - 1) = 0.0;
+        }
+        if (iu > 1) TT(iu - 1, iu - 2) = 0.0;
+        iu -= 2;
+        iter = 0;
+      } else {
+        double sh0 = TT(iu, iu), sh1 = TT(iu - 1, iu - 1), sh2 = TT(iu, iu - 1) * TT(iu - 1, iu);
+        if (iter == 10) {
+          exshift += sh0;
+          for (int i = 0; i <= iu; ++i) TT(i, i) -= sh0;
+          const double s = fabs(TT(iu, iu - 1)) + fabs(TT(iu - 1, iu - 2));
+          sh0 = 0.75 * s;
+          sh1 = 0.75 * s;
+          sh2 = -0.4375 * s * s;
+        }
+        if (iter == 30) {
+          double s = (sh1 - sh0) / 2.0;
+          s = s * s + sh2;
+          if (s > 0.0) {
+            s = sqrt(s);
+            if (sh1 < sh0) s = -s;
+            s = s + (sh1 - sh0) / 2.0;
+            s = sh0 - sh2 / s;
+            exshift += s;
+            for (int i = 0; i <= iu; ++i) TT(i, i) -= s;
+            sh0 = sh1 = sh2 = 0.964;
+          }
+        }
+        iter = iter + 1;
+        total_iter = total_iter + 1;
+        if (total_iter > max_iters) break;
+        int imm;
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+        for (imm = iu - 2; imm >= il; --imm) {
+          const double Tmm = TT(imm, imm);
+          const double r = sh0 - Tmm;
+          const double s = sh1 - Tmm;
+          v0 = (r * s - sh2) / TT(imm + 1, imm) + TT(imm, imm + 1);
+          v1 = TT(imm + 1, imm + 1) - Tmm - r - s;
+          v2 = TT(imm + 2, imm + 1);
+          if (imm == il) break;
+          const double lhs = TT(imm, imm - 1) * (fabs(v1) + fabs(v2));
+          const double rhs = v0 * (fabs(TT(imm - 1, imm - 1)) + fabs(Tmm) + fabs(TT(imm + 1, imm + 1)));
+          if (fabs(lhs) < DBL_EPSILON * rhs) break;
+        }
+        for (int k = imm; k <= iu - 2; ++k) {
+          const bool first = (k == imm);
+          double v[3];
+          if (first) {
+            v[0] = v0;
+            v[1] = v1;
+            v[2] = v2;
+          } else {
+            v[0] = TT(k, k - 1);
+            v[1] = TT(k + 1, k - 1);
+            v[2] = TT(k + 2, k - 1);
+          }
+          double tau, beta;
+          pl_make_householder(v, 3, &tau, &beta);
+          if (beta != 0.0) {
+            if (first && k > il)
+              TT(k, k - 1) = -TT(k, k - 1);
+            else if (!first)
+              TT(k, k - 1) = beta;
+            pl_apply_householder_left(T, LD, k, k, 3, n - k, &v[1], tau);
+            const int nr = ((iu < k + 3) ? iu : k + 3) + 1;
+            pl_apply_householder_right(T, LD, 0, k, nr, 3, &v[1], tau);
+          }
+        }
+        {
+          double v[2] = {TT(iu - 1, iu - 2), TT(iu, iu - 2)};
+          double tau, beta;
+          pl_make_householder(v, 2, &tau, &beta);
+          if (beta != 0.0) {
+            TT(iu - 1, iu - 2) = beta;
+            pl_apply_householder_left(T, LD, iu - 1, iu - 1, 2, n - iu + 1, &v[1], tau);
+            pl_apply_householder_right(T, LD, 0, iu - 1, iu + 1, 2, &v[1], tau);
+          }
+        }
+        for (int i = imm + 2; i <= iu; ++i) {
+          TT(i, i - 2) = 0.0;
+          if (i > imm + 2) TT(i, i - 3) = 0.0;
+        }
+      }
+    }
+  }
+  if (total_iter > max_iters) return false;
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) TT(i, j) *= scale;
+  int i = 0;
+  while (i < n) {
+    if (i == n - 1 || TT(i + 1, i) == 0.0) {
+      re[i] = TT(i, i);
+      im[i] = 0.0;
+      if (!isfinite(re[i])) return false;
+      ++i;
+    } else {
+      const double p = 0.5 * (TT(i, i) - TT(i + 1, i + 1));
+      double t0 = TT(i + 1, i), t1 = TT(i, i + 1);
+      double maxval = fabs(p);
+      if (fabs(t0) > maxval) maxval = fabs(t0);
+      if (fabs(t1) > maxval) maxval = fabs(t1);
+      t0 /= maxval;
+      t1 /= maxval;
+      const double p0 = p / maxval;
+      const double z = maxval * sqrt(fabs(p0 * p0 + t0 * t1));
+      re[i] = TT(i + 1, i + 1) + p;
+      im[i] = z;
+      re[i + 1] = TT(i + 1, i + 1) + p;
+      im[i + 1] = -z;
+      if (!(isfinite(re[i]) && isfinite(z))) return false;
+      i += 2;
+    }
+  }
+  return true;
+#undef TT
+}
+
+// FindPolynomialRootsCompanionMatrix (/root/reference/src/base/polynomial.cc:208-275) for up to
+// MAXC coefficients (highest degree first).  Returns the number of roots, or -1 on failure.
+template <int MAXC>
+DSM_DEV int pl_poly_roots(const double* coeffs_all, int ncoef, double* real, double* imag) {
+  int lead = 0;
+  for (; lead < ncoef; ++lead)
+    if (coeffs_all[lead] != 0) break;
+  const double* coeffs = coeffs_all + lead;
+  int nc = ncoef - lead;
+  const int degree = nc - 1;
+  if (degree <= 0) return -1;
+  if (degree == 1) {  // FindLinearPolynomialRoots
+    if (coeffs[0] == 0) return -1;
+    real[0] = -coeffs[1] / coeffs[0];
+    imag[0] = 0.0;
+    return 1;
+  }
+  if (degree == 2) {  // FindQuadraticPolynomialRoots (a != 0 here)
+    const double a = coeffs[0], b = coeffs[1], c = coeffs[2];
+    if (b == 0 && c == 0) {
+      real[0] = 0.0;
+      imag[0] = 0.0;
+      return 1;
+    }
+    const double d = b * b - 4 * a * c;
+    if (d >= 0) {
+      const double sqrt_d = sqrt(d);
+      if (b >= 0) {
+        real[0] = (-b - sqrt_d) / (2 * a);
+        real[1] = (2 * c) / (-b - sqrt_d);
+      } else {
+        real[0] = (2 * c) / (-b + sqrt_d);
+        real[1] = (-b + sqrt_d) / (2 * a);
+      }
+      imag[0] = 0.0;
+      imag[1] = 0.0;
+    } else {
+      real[0] = real[1] = -b / (2 * a);
+      imag[0] = sqrt(-d) / (2 * a);
+      imag[1] = -imag[0];
+    }
+    return 2;
+  }
+  int trail = 0;
+  for (; trail < nc; ++trail)
+    if (coeffs[nc - 1 - trail] != 0) break;
+  nc -= trail;
+  if (nc == 1) {
+    real[0] = 0.0;
+    imag[0] = 0.0;
+    return 1;
+  }
+  const int n = nc - 1;
+  constexpr int LD = MAXC - 1;
+  double C[LD * LD];
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) C[j * LD + i] = 0.0;
+  for (int i = 1; i < n; ++i) C[(i - 1) * LD + i] = 1.0;
+  for (int j = 0; j < n; ++j) C[j * LD + 0] = -coeffs[j + 1] / coeffs[0];
+  double re[LD], im[LD];
+  if (!pl_hessenberg_eigenvalues<LD>(C, n, re, im)) return -1;
+  const int effective_degree = n < degree ? n + 1 : n;
+  for (int i = 0; i < effective_degree; ++i) {
+    real[i] = 0.0;
+    imag[i] = 0.0;
+  }
+  for (int i = 0; i < n; ++i) {
+    real[i] = re[i];
+    imag[i] = im[i];
+  }
+  return effective_degree;
+}
+
+// A.partialPivLu().solve(B) for 10 x 10 A and B, column-major in place; the solution overwrites B.
+DSM_DEVN void pl_lu_solve_10(double* A, double* B) {
+  const int n = 10, m = 10;
+  int piv[10];
+  for (int k = 0; k < n; ++k) {
+    int r = k;
+    double best = fabs(A[k * n + k]);
+    for (int i = k + 1; i < n; ++i)
+      if (fabs(A[k * n + i]) > best) {
+        best = fabs(A[k * n + i]);
+        r = i;
+      }
+    piv[k] = r;
+    if (best != 0.0) {
+      if (r != k)
+        for (int j = 0; j < n; ++j) {
+          const double t = A[j * n + k];
+          A[j * n + k] = A[j * n + r];
+          A[j * n + r] = t;
+        }
+      for (int i = k + 1; i < n; ++i) A[k * n + i] /= A[k * n + k];
+    }
+    for (int j = k + 1; j < n; ++j)
+      for (int i = k + 1; i < n; ++i) A[j * n + i] -= A[k * n + i] * A[j * n + k];
+  }
+  for (int k = 0; k < n; ++k)
+    if (piv[k] != k)
+      for (int j = 0; j < m; ++j) {
+        const double t = B[j * n + k];
+        B[j * n + k] = B[j * n + piv[k]];
+        B[j * n + piv[k]] = t;
+      }
+  for (int j = 0; j < m; ++j) {
+    for (int i = 0; i < n; ++i) {
+      double s = B[j * n + i];
+      for (int k = 0; k < i; ++k) s -= A[k * n + i] * B[j * n + k];
+      B[j * n + i] = s;
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double s = B[j * n + i];
+      for (int k = n - 1; k > i; --k) s -= A[k * n + i] * B[j * n + k];
+      B[j * n + i] = s / A[i * n + i];
+    }
+  }
+}
+
+// ---- row-major 3x3 helpers ---------------------------------------------------------------------
+DSM_DEV void m3_mul(const double* A, const double* B, double* C) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3 + 0] * B[0 * 3 + j] + A[i * 3 + 1] * B[1 * 3 + j] + A[i * 3 + 2] * B[2 * 3 + j];
+}
+DSM_DEV void m3_transpose(const double* A, double* T) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) T[i * 3 + j] = A[j * 3 + i];
+}
+DSM_DEV double m3_det(const double* A) {
+  return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+}
+DSM_DEV double m3_cof(const double* M, int i, int j) {
+  const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return M[i1 * 3 + j1] * M[i2 * 3 + j2] - M[i1 * 3 + j2] * M[i2 * 3 + j1];
+}
+DSM_DEV void m3_inverse(const double* M, double* R) {
+  const double c00 = m3_cof(M, 0, 0), c10 = m3_cof(M, 1, 0), c20 = m3_cof(M, 2, 0);
+  const double det = c00 * M[0] + c10 * M[3] + c20 * M[6];
+  const double invdet = 1.0 / det;
+  R[0] = c00 * invdet;
+  R[1] = c10 * invdet;
+  R[2] = c20 * invdet;
+  R[3] = m3_cof(M, 0, 1) * invdet;
+  R[4] = m3_cof(M, 1, 1) * invdet;
+  R[8] = m3_cof(M, 2, 2) * invdet;
+  R[5] = m3_cof(M, 2, 1) * invdet;
+  R[7] = m3_cof(M, 1, 2) * invdet;
+  R[6] = m3_cof(M, 0, 2) * invdet;
+}
+
+// ====================================================================== per-wave routines
+// One-wave workgroups (64 threads): __syncthreads() orders LDS/global traffic between phases.
+
+struct WvSvdShared {
+  double W[81];            // working square matrix, column-major ld = dsz
+  double V[81];            // 9 x 9, column-major ld 9
+  double norms_u[9], norms_d[9];
+  double colbuf[9];        // per-column dot products
+  double hco[9];
+  double scal[4];          // broadcast scalars
+  int perm[9];
+  int iscal[4];
+};
+
+DSM_DEV void wv_sync() { __syncthreads(); }
+
+// Pivoted Householder QR of M (rows x cols, column-major ld = rows, rows >= cols, cols <= 9) in
+// global/LDS memory, by the whole wave.  Leaves R + essential parts in M, hco/perm in sh.
+DSM_DEV void wv_colpiv_qr(double* M, int rows, int cols, WvSvdShared* sh, int lane) {
+  const int size = rows < cols ? rows : cols;
+  if (lane < cols) {
+    double s = 0.0;
+    const double* col = M + (size_t)lane * rows;
+    for (int i = 0; i < rows; ++i) s += col[i] * col[i];
+    sh->norms_d[lane] = sqrt(s);
+    sh->norms_u[lane] = sh->norms_d[lane];
+    sh->perm[lane] = lane;
+  }
+  wv_sync();
+  const double norm_downdate_threshold = sqrt(DBL_EPSILON);
+  for (int k = 0; k < size; ++k) {
+    int biggest = k;
+    double mx = sh->norms_u[k];
+    for (int j = k + 1; j < cols; ++j) {
+      const double v = sh->norms_u[j];
+      if (v > mx) {
+        mx = v;
+        biggest = j;
+      }
+    }
+    wv_sync();
+    if (k != biggest) {
+      double* ck = M + (size_t)k * rows;
+      double* cb = M + (size_t)biggest * rows;
+      for (int i = lane; i < rows; i += 64) {
+        const double t = ck[i];
+        ck[i] = cb[i];
+        cb[i] = t;
+      }
+      if (lane == 0) {
+        double t = sh->norms_u[k];
+        sh->norms_u[k] = sh->norms_u[biggest];
+        sh->norms_u[biggest] = t;
+        t = sh->norms_d[k];
+        sh->norms_d[k] = sh->norms_d[biggest];
+        sh->norms_d[biggest] = t;
+        const int ti = sh->perm[k];
+        sh->perm[k] = sh->perm[biggest];
+        sh->perm[biggest] = ti;
+      }
+    }
+    wv_sync();
+    // makeHouseholder on column k, rows k..rows-1
+    double* x = M + (size_t)k * rows + k;
+    const int n = rows - k;
+    if (lane == 0) {
+      double tail_sq = 0.0;
+      for (int i = 1; i < n; ++i) tail_sq += x[i] * x[i];
+      const double c0 = x[0];
+      if (tail_sq <= DBL_MIN) {
+        sh->scal[0] = 0.0;   // tau
+        sh->scal[1] = c0;    // beta
+        sh->scal[2] = 0.0;   // denominator unused
+        sh->iscal[0] = 1;    // zero the tail
+      } else {
+        double b = sqrt(c0 * c0 + tail_sq);
+        if (c0 >= 0.0) b = -b;
+        sh->scal[0] = (b - c0) / b;
+        sh->scal[1] = b;
+        sh->scal[2] = c0 - b;
+        sh->iscal[0] = 0;
+      }
+    }
+    wv_sync();
+    const double tau = sh->scal[0], beta = sh->scal[1], den = sh->scal[2];
+    const int zero_tail = sh->iscal[0];
+    for (int i = 1 + lane; i < n; i += 64) x[i] = zero_tail ? 0.0 : x[i] / den;
+    if (lane == 0) {
+      x[0] = beta;
+      sh->hco[k] = tau;
+    }
+    wv_sync();
+    // apply to the remaining columns (nr = n rows, nc = cols-k-1 columns)
+    const int nc = cols - k - 1;
+    const double* ess = x + 1;
+    if (nc > 0) {
+      if (n == 1) {
+        if (lane < nc) M[(size_t)(k + 1 + lane) * rows + k] *= (1.0 - tau);
+      } else if (tau != 0.0) {
+        if (lane < nc) {
+          const double* col = M + (size_t)(k + 1 + lane) * rows + k;
+          double tmp = 0.0;
+          for (int i = 1; i < n; ++i) tmp += ess[i - 1] * col[i];
+          tmp += col[0];
+          sh->colbuf[lane] = tmp;
+        }
+        wv_sync();
+        for (int e = lane; e < nc * n; e += 64) {
+          const int j = e / n, i = e - j * n;
+          double* col = M + (size_t)(k + 1 + j) * rows + k;
+          const double tmp = sh->colbuf[j];
+          if (i == 0)
+            col[0] -= tau * tmp;
+          else
+            col[i] -= tau * ess[i - 1] * tmp;
+        }
+      }
+      wv_sync();
+      // norm downdating, one lane per column
+      if (lane < nc) {
+        const int j = k + 1 + lane;
+        if (sh->norms_u[j] != 0.0) {
+          double temp = fabs(M[(size_t)j * rows + k]) / sh->norms_u[j];
+          temp = (1.0 + temp) * (1.0 - temp);
+          temp = temp < 0.0 ? 0.0 : temp;
+          const double ratio = sh->norms_u[j] / sh->norms_d[j];
+          const double temp2 = temp * (ratio * ratio);
+          if (temp2 <= norm_downdate_threshold) {
+            double s = 0.0;
+            const double* col = M + (size_t)j * rows;
+            for (int i = k + 1; i < rows; ++i) s += col[i] * col[i];
+            sh->norms_d[j] = sqrt(s);
+            sh->norms_u[j] = sh->norms_d[j];
+          } else {
+            sh->norms_u[j] *= sqrt(temp);
+          }
+        }
+      }
+    }
+    wv_sync();
+  }
+}
+
+// Two-sided Jacobi sweeps on sh->W (dsz x dsz) accumulating right rotations into sh->V (9 x 9,
+// first dsz columns), then sign/sort.  sv (LDS, >= 9 doubles) receives the singular values.
+DSM_DEV void wv_jacobi_sweeps(WvSvdShared* sh, int dsz, double scale, double* sv, int lane) {
+  double* W = sh->W;
+  double* V = sh->V;
+  const double precision = 2.0 * DBL_EPSILON;
+  double max_diag = 0.0;
+  for (int i = 0; i < dsz; ++i) {
+    const double a = fabs(W[i * dsz + i]);
+    if (a > max_diag) max_diag = a;
+  }
+  bool finished = false;
+  while (!finished) {
+    finished = true;
+    for (int p = 1; p < dsz; ++p) {
+      for (int q = 0; q < p; ++q) {
+        const double thr = DBL_MIN > precision * max_diag ? DBL_MIN : precision * max_diag;
+        const double wpq = W[q * dsz + p], wqp = W[p * dsz + q];
+        if (fabs(wpq) > thr || fabs(wqp) > thr) {
+          finished = false;
+          double lc, ls, rc, rs;
+          dsm_jacobi_2x2(W[p * dsz + p], wpq, wqp, W[q * dsz + q], &lc, &ls, &rc, &rs);
+          wv_sync();
+          if (!(lc == 1.0 && ls == 0.0)) {
+            if (lane < dsz) {  // rows p, q: element (p, lane), (q, lane)
+              const double xi = W[lane * dsz + p], yi = W[lane * dsz + q];
+              W[lane * dsz + p] = lc * xi + ls * yi;
+              W[lane * dsz + q] = -ls * xi + lc * yi;
+            }
+          }
+          wv_sync();
+          if (!(rc == 1.0 && -rs == 0.0)) {
+            if (lane < dsz) {  // columns p, q of W
+              const double xi = W[p * dsz + lane], yi = W[q * dsz + lane];
+              W[p * dsz + lane] = rc * xi + (-rs) * yi;
+              W[q * dsz + lane] = rs * xi + rc * yi;
+            } else if (lane >= 16 && lane < 25) {  // columns p, q of V (9 rows)
+              const int r = lane - 16;
+              const double xi = V[p * 9 + r], yi = V[q * 9 + r];
+              V[p * 9 + r] = rc * xi + (-rs) * yi;
+              V[q * 9 + r] = rs * xi + rc * yi;
+            }
+          }
+          wv_sync();
+          const double app = fabs(W[p * dsz + p]), aqq = fabs(W[q * dsz + q]);
+          const double mm = app > aqq ? app : aqq;
+          if (mm > max_diag) max_diag = mm;
+        }
+      }
+    }
+  }
+  wv_sync();
+  if (lane == 0) {
+    for (int i = 0; i < dsz; ++i) sv[i] = fabs(W[i * dsz + i]) * scale;
+    for (int i = 0; i < dsz; ++i) {
+      int pos = i;
+      double mx = sv[i];
+      for (int j = i + 1; j < dsz; ++j)
+        if (sv[j] > mx) {
+          mx = sv[j];
+          pos = j;
+        }
+      if (mx == 0.0) break;
+      if (pos != i) {
+        double t = sv[i];
+        sv[i] = sv[pos];
+        sv[pos] = t;
+        for (int r = 0; r < 9; ++r) {
+          t = V[i * 9 + r];
+          V[i * 9 + r] = V[pos * 9 + r];
+          V[pos * 9 + r] = t;
+        }
+      }
+    }
+  }
+  wv_sync();
+}
+
+// JacobiSVD<Matrix<double, Dynamic, 9>>(A, ComputeFullV).matrixV() for an m x 9 system, any m >= 1.
+// A (column-major m x 9, ld = m) lives in `A`; `At` is scratch of >= 9*m doubles used when m < 9.
+// Result: sh->V (9 x 9 column-major).  A is destroyed.
+DSM_DEV void wv_svd_V_mx9(double* A, double* At, int m, WvSvdShared* sh, double* sv, int lane) {
+  // scale = max |a_ij| (exact, order independent)
+  double mxl = 0.0;
+  for (int e = lane; e < 9 * m; e += 64) {
+    const double a = fabs(A[e]);
+    if (a > mxl) mxl = a;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double other = __shfl_xor(mxl, o);
+    if (other > mxl) mxl = other;
+  }
+  double scale = mxl;
+  if (scale == 0.0) scale = 1.0;
+  wv_sync();
+  if (m > 9) {
+    for (int e = lane; e < 9 * m; e += 64) A[e] /= scale;
+    wv_sync();
+    wv_colpiv_qr(A, m, 9, sh, lane);
+    for (int e = lane; e < 81; e += 64) {
+      const int i = e % 9, j = e / 9;
+      sh->W[j * 9 + i] = (i <= j) ? A[(size_t)j * m + i] : 0.0;
+      sh->V[e] = 0.0;
+    }
+    wv_sync();
+    if (lane < 9) sh->V[lane * 9 + sh->perm[lane]] = 1.0;
+    wv_sync();
+    wv_jacobi_sweeps(sh, 9, scale, sv, lane);
+  } else if (m < 9) {
+    for (int e = lane; e < 9 * m; e += 64) {
+      const int i = e % m, j = e / m;  // A(i, j)
+      At[(size_t)i * 9 + j] = A[(size_t)j * m + i] / scale;
+    }
+    wv_sync();
+    wv_colpiv_qr(At, 9, m, sh, lane);
+    for (int e = lane; e < m * m; e += 64) {
+      const int j = e % m, i = e / m;  // W(j, i) = R(i, j) for i <= j
+      sh->W[i * m + j] = (i <= j) ? At[(size_t)j * 9 + i] : 0.0;
+    }
+    // V = householderQ (9 x 9): lane c builds column c
+    if (lane < 9) {
+      double q[9];
+      for (int i = 0; i < 9; ++i) q[i] = (i == lane) ? 1.0 : 0.0;
+      for (int k = m - 1; k >= 0; --k) {
+        if (lane < k) continue;
+        const int nr = 9 - k;
+        const double tau = sh->hco[k];
+        const double* ess = At + (size_t)k * 9 + k + 1;
+        if (nr == 1) {
+          q[k] *= (1.0 - tau);
+        } else if (tau != 0.0) {
+          double tmp = 0.0;
+          for (int i = 1; i < nr; ++i) tmp += ess[i - 1] * q[k + i];
+          tmp += q[k];
+          q[k] -= tau * tmp;
+          for (int i = 1; i < nr; ++i) q[k + i] -= tau * ess[i - 1] * tmp;
+        }
+      }
+      for (int i = 0; i < 9; ++i) sh->V[lane * 9 + i] = q[i];
+    }
+    wv_sync();
+    wv_jacobi_sweeps(sh, m, scale, sv, lane);
+  } else {
+    for (int e = lane; e < 81; e += 64) {
+      sh->W[e] = A[e] / scale;
+      sh->V[e] = (e % 9 == e / 9) ? 1.0 : 0.0;
+    }
+    wv_sync();
+    wv_jacobi_sweeps(sh, 9, scale, sv, lane);
+  }
+}
+
+#endif  // DAGSFM_AMD_CSRC_VERIFY_LINALG_H_

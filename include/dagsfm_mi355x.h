@@ -165,6 +165,46 @@ int dsm_match_sift_features(dsm_ctx* ctx, const dsm_match_options* options,
  * launched on: total milliseconds and number of launches. */
 int dsm_get_match_kernel_time(dsm_ctx* ctx, double* total_ms, uint32_t* n_launches);
 
+/* ------------------------------------------------------------------ verification */
+
+/* Per-pair PRNG seed used when dsm_verify_pairs gets no explicit seeds: a 32-bit mix of
+ * Database::ImagePairToPairId(id1, id2) (src/base/database.h:336-347) xor user_seed.  The
+ * reference seeds each verifier thread from the wall clock (src/util/random.cc:40-56) and is
+ * not reproducible; one MT19937 stream per pair, consumed E -> F -> H -> watermark in the order of
+ * src/estimators/two_view_geometry.cc:325-342, 547-549, is the defined schedule here. */
+uint32_t dsm_pair_seed(uint32_t image_id1, uint32_t image_id2, uint32_t user_seed);
+
+/* Geometric verification of every pair of the last dsm_match_pairs on the device.  Replaces
+ * the TwoViewGeometryVerifier stage of SiftFeatureMatcher::Match (src/feature/matching.cc:
+ * 550-608, 749-839) = TwoViewGeometry::Estimate per pair (two_view_geometry.cc:113-126).
+ *   seeds         n_pairs explicit PRNG seeds, or NULL to use dsm_pair_seed(idx1, idx2, user_seed)
+ *   stage_filter  non-zero: pairs with fewer than min_num_inliers inliers get a default
+ *                 TwoViewGeometry(), as Match() writes them (matching.cc:824-831) */
+int dsm_verify_pairs(dsm_ctx* ctx, const dsm_two_view_options* options, const uint32_t* seeds,
+                     uint32_t user_seed, int32_t stage_filter);
+/* Results of the last dsm_verify_pairs: n_pairs fixed-size records ... */
+int dsm_get_two_view_geometries(dsm_ctx* ctx, dsm_two_view_geometry* out);
+/* ... and the inlier_matches of all pairs in list order (same conventions as dsm_get_matches). */
+int dsm_get_inlier_matches(dsm_ctx* ctx, uint64_t* offsets, uint32_t* inlier_matches,
+                           uint64_t capacity);
+/* Device time (HIP events on the launch stream) of the verification kernel of the last call. */
+int dsm_get_verify_kernel_time(dsm_ctx* ctx, double* total_ms);
+
+/* One-shot leaf with the signature shape of TwoViewGeometry::Estimate
+ * (src/estimators/two_view_geometry.h:180-184): host cameras, points (n x 2 doubles, as
+ * FeatureKeypointsToPointsVector makes them) and matches in, TwoViewGeometry out.
+ * `inlier_matches` must hold n_matches x 2 uint32 (may be NULL). */
+int dsm_estimate_two_view_geometry(dsm_ctx* ctx, const dsm_camera* camera1, const double* points1,
+                                   uint32_t n1, const dsm_camera* camera2, const double* points2,
+                                   uint32_t n2, const uint32_t* matches, uint32_t n_matches,
+                                   const dsm_two_view_options* options, uint32_t seed,
+                                   dsm_two_view_geometry* out, uint32_t* inlier_matches);
+
+/* Test hook: the first n_draws samples (k indices each) the device sampler draws from
+ * `total` items with the given seed (RandomSampler, src/optim/random_sampler.cc:43-62). */
+int dsm_debug_sample_sequence(dsm_ctx* ctx, uint32_t seed, uint32_t k, uint32_t total,
+                              uint32_t n_draws, uint32_t* out);
+
 void dsm_default_match_options(dsm_match_options* o);
 void dsm_default_two_view_options(dsm_two_view_options* o);
 

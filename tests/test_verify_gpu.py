@@ -1,0 +1,160 @@
+"""GPU parity of the HIP two-view verification (through the C-ABI) against the CPU oracle:
+bit-exact config / inlier masks / model matrices / trial counts, pose within 1e-6 relative."""
+import numpy as np
+import pytest
+
+from dagsfm_amd import capi, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def tvg_equal(g, r, tag=""):
+    assert g.config == r.config, (tag, g.config, r.config)
+    assert g.num_inliers == r.num_inliers, (tag, g.num_inliers, r.num_inliers)
+    assert g.num_matches == r.num_matches
+    assert list(g.num_trials) == list(r.num_trials), (tag, list(g.num_trials), list(r.num_trials))
+    assert list(g.num_models) == list(r.num_models), (tag, list(g.num_models), list(r.num_models))
+    for name in ("E", "F", "H"):
+        a, b = np.array(getattr(g, name)), np.array(getattr(r, name))
+        assert (a == b).all() or (np.isnan(a) == np.isnan(b)).all() and np.allclose(a, b, rtol=0, atol=0, equal_nan=True), \
+            (tag, name, a, b)
+    assert np.allclose(np.array(g.qvec), np.array(r.qvec), rtol=1e-6, atol=1e-12), (tag, list(g.qvec), list(r.qvec))
+    assert np.allclose(np.array(g.tvec), np.array(r.tvec), rtol=1e-6, atol=1e-12), (tag, list(g.tvec), list(r.tvec))
+    assert abs(g.tri_angle - r.tri_angle) <= 1e-6 * max(abs(r.tri_angle), 1e-9), (tag, g.tri_angle, r.tri_angle)
+
+
+def test_sampler_matches_libstdcxx(dsm, oracle):
+    """Device MT19937 + Lemire + partial Fisher-Yates == std::mt19937 + std::uniform_int_distribution."""
+    for seed, k, total, draws in [(0, 7, 50, 300), (5489, 5, 5, 10), (123456789, 4, 4096, 2000), (42, 1, 1, 5),
+                                  (7, 7, 257, 1000), (4294967295, 4, 3, 0)]:
+        if k > total or draws == 0:
+            continue
+        assert (dsm.debug_sample_sequence(seed, k, total, draws) == oracle.sample_sequence(seed, k, total, draws)).all()
+
+
+def _scene_pair(scene, i, j, oracle):
+    a, b = scene.image(i), scene.image(j)
+    m = oracle.match_sift_features_cpu(a[0], b[0])
+    return a[1].astype(np.float64), b[1].astype(np.float64), m
+
+
+@pytest.mark.parametrize("prior", [0, 1])
+def test_leaf_estimate_general_scene(dsm, oracle, prior):
+    scene = synthetic.Scene(4, 1024, seed=11)
+    cam = capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, prior)
+    opts = capi.default_two_view_options()
+    for (i, j) in [(0, 1), (0, 2), (1, 3)]:
+        p1, p2, m = _scene_pair(scene, i, j, oracle)
+        for seed in (1, 77):
+            ref, ref_inl = oracle.estimate_two_view_geometry(cam, p1, cam, p2, m, opts, seed)
+            got, got_inl = dsm.estimate_two_view_geometry(cam, p1, cam, p2, m, opts, seed)
+            tvg_equal(got, ref, (i, j, seed, prior))
+            assert (got_inl == ref_inl).all()
+            assert ref.num_inliers > 15
+
+
+def test_leaf_estimate_planar_and_degenerate(dsm, oracle):
+    scene = synthetic.Scene(3, 1024, seed=3, planar=True)
+    cam = capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, True)
+    camu = capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, False)
+    opts = capi.default_two_view_options()
+    p1, p2, m = _scene_pair(scene, 0, 1, oracle)
+    for c in (cam, camu):
+        ref, ref_inl = oracle.estimate_two_view_geometry(c, p1, c, p2, m, opts, 5)
+        got, got_inl = dsm.estimate_two_view_geometry(c, p1, c, p2, m, opts, 5)
+        tvg_equal(got, ref, "planar")
+        assert (got_inl == ref_inl).all()
+    # too few matches -> DEGENERATE (two_view_geometry.cc:298-301)
+    ref, _ = oracle.estimate_two_view_geometry(cam, p1, cam, p2, m[:10], opts, 5)
+    got, _ = dsm.estimate_two_view_geometry(cam, p1, cam, p2, m[:10], opts, 5)
+    assert ref.config == 1
+    tvg_equal(got, ref, "few")
+    # pure outliers: random correspondences
+    rng = np.random.default_rng(0)
+    q1 = rng.uniform(0, 1000, (200, 2))
+    q2 = rng.uniform(0, 1000, (200, 2))
+    mm = np.stack([np.arange(200), rng.permutation(200)], axis=1).astype(np.uint32)
+    for c in (cam, camu):
+        ref, ref_inl = oracle.estimate_two_view_geometry(c, q1, c, q2, mm, opts, 9)
+        got, got_inl = dsm.estimate_two_view_geometry(c, q1, c, q2, mm, opts, 9)
+        tvg_equal(got, ref, "outliers")
+        assert (got_inl == ref_inl).all()
+
+
+def test_watermark_configuration(dsm, oracle):
+    """Matches concentrated in the border that follow a pure translation -> WATERMARK (two_view_geometry.cc:491-555)."""
+    rng = np.random.default_rng(1)
+    n = 120
+    p1 = np.c_[rng.uniform(5, 60, n), rng.uniform(5, 700, n)]
+    p2 = p1 + np.array([3.0, -2.0]) + rng.normal(scale=0.2, size=(n, 2))
+    m = np.stack([np.arange(n), np.arange(n)], axis=1).astype(np.uint32)
+    camu = capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, False)
+    opts = capi.default_two_view_options()
+    ref, ref_inl = oracle.estimate_two_view_geometry(camu, p1, camu, p2, m, opts, 3)
+    got, got_inl = dsm.estimate_two_view_geometry(camu, p1, camu, p2, m, opts, 3)
+    assert ref.config == 7
+    tvg_equal(got, ref, "watermark")
+    assert (got_inl == ref_inl).all()
+
+
+@pytest.mark.parametrize("prior", [0, 1])
+def test_stage_match_and_verify_many_pairs(dsm, oracle, prior):
+    """dsm_match_pairs + dsm_verify_pairs over an exhaustive pair list == oracle matcher + oracle verifier
+    with SiftFeatureMatcher::Match's post-filter (matching.cc:824-831)."""
+    n_img = 7
+    scene = synthetic.Scene(n_img, 768, seed=21, n_pool=2048)
+    ims = [scene.image(i) for i in range(n_img)]
+    cams = [capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, prior) for _ in range(n_img)]
+    dsm.set_images([im[0] for im in ims], [im[1] for im in ims], cams)
+    pairs = synthetic.exhaustive_pairs(n_img)
+    dsm.match_pairs(pairs)
+    opts = capi.default_two_view_options()
+    dsm.verify_pairs(opts, user_seed=99, stage_filter=True)
+    offs, m = dsm.matches()
+    tvgs = dsm.two_view_geometries()
+    ioffs, im = dsm.inlier_matches()
+    n_verified = 0
+    for k, (i, j) in enumerate(pairs):
+        mk = m[int(offs[k]):int(offs[k + 1])]
+        ref_m = oracle.match_sift_features_cpu(ims[i][0], ims[j][0])
+        assert (mk == ref_m).all()
+        seed = capi.pair_seed(int(i), int(j), 99)
+        ref, ref_inl = oracle.estimate_two_view_geometry(cams[i], ims[i][1].astype(np.float64), cams[j],
+                                                         ims[j][1].astype(np.float64), ref_m, opts, seed)
+        got = tvgs[k]
+        got_inl = im[int(ioffs[k]):int(ioffs[k + 1])]
+        if ref.num_inliers < opts.min_num_inliers:
+            assert got.config == 0 and got.num_inliers == 0 and len(got_inl) == 0
+        else:
+            tvg_equal(got, ref, (i, j))
+            assert (got_inl == ref_inl).all()
+            n_verified += 1
+    assert n_verified >= 10
+    assert dsm.verify_kernel_time() > 0
+
+
+def test_radial_camera_and_small_lo_systems(dsm, oracle):
+    """SIMPLE_RADIAL cameras (iterative undistortion) and tiny inlier sets (6..9-row LO systems)."""
+    scene = synthetic.Scene(3, 512, seed=8)
+    cam = capi.Camera(model_id=2, has_prior_focal_length=1, width=1000, height=750)
+    cam.params[0], cam.params[1], cam.params[2], cam.params[3] = 800.0, 500.0, 375.0, 0.05
+    opts = capi.default_two_view_options()
+    p1, p2, m = _scene_pair(scene, 0, 1, oracle)
+    ref, ref_inl = oracle.estimate_two_view_geometry(cam, p1, cam, p2, m, opts, 2)
+    got, got_inl = dsm.estimate_two_view_geometry(cam, p1, cam, p2, m, opts, 2)
+    tvg_equal(got, ref, "radial")
+    assert (got_inl == ref_inl).all()
+    # 16..24 matches with only a handful of true correspondences
+    rng = np.random.default_rng(4)
+    camp = capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, True)
+    for n_true, n_tot in [(8, 16), (12, 20), (6, 24)]:
+        mm = m[:n_true]
+        extra = np.stack([rng.choice(len(p1), n_tot - n_true, replace=False),
+                          rng.choice(len(p2), n_tot - n_true, replace=False)], axis=1).astype(np.uint32)
+        mx = np.concatenate([mm, extra])
+        o2 = capi.default_two_view_options(min_num_inliers=6)
+        for seed in (1, 2, 3):
+            ref, ref_inl = oracle.estimate_two_view_geometry(camp, p1, camp, p2, mx, o2, seed)
+            got, got_inl = dsm.estimate_two_view_geometry(camp, p1, camp, p2, mx, o2, seed)
+            tvg_equal(got, ref, ("small", n_true, n_tot, seed))
+            assert (got_inl == ref_inl).all()
