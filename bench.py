@@ -14,6 +14,7 @@ match graph.
 Rank 0 prints ONE JSON line (see README / DESIGN.md "Measurement").
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -36,11 +37,13 @@ def parse_args():
     ap.add_argument("--feats", type=int, default=4096)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-verify", action="store_true", help="matching only (BASELINE config 3 style)")
+    ap.add_argument("--uncalibrated", action="store_true",
+                    help="cameras without focal prior: F + H path (EstimateUncalibrated) instead of E + F + H + pose")
     ap.add_argument("--cpu-pairs", type=int, default=-1, help="pairs in the CPU-baseline sample (-1 = auto, 0 = skip)")
     return ap.parse_args()
 
 
-def cpu_baseline(scene_images, pairs, n_sample, verify):
+def cpu_baseline(scene_images, pairs, n_sample, verify, cams=None, opts=None, user_seed=0):
     """Times the CPU oracle (the reference algorithm restated, oracle/) on a bounded sample of
     the same workload, using all host cores like the reference's matcher/verifier thread pools
     (/root/reference/src/feature/matching.cc:640-674)."""
@@ -50,17 +53,26 @@ def cpu_baseline(scene_images, pairs, n_sample, verify):
     cores = os.cpu_count() or 1
     sample = pairs[np.linspace(0, len(pairs) - 1, n_sample).astype(np.int64)]
 
+    from dagsfm_amd import capi
+    kps = [im[1].astype(np.float64) for im in scene_images]
+
     def one(p):
-        d1, d2 = scene_images[int(p[0])][0], scene_images[int(p[1])][0]
-        m = orc.match_sift_features_cpu(d1, d2)
-        return len(m)
+        i, j = int(p[0]), int(p[1])
+        m = orc.match_sift_features_cpu(scene_images[i][0], scene_images[j][0])
+        nm = 0
+        if verify:
+            tv, _ = orc.estimate_two_view_geometry(cams[i], kps[i], cams[j], kps[j], m, opts, capi.pair_seed(i, j, user_seed))
+            nm = sum(tv.num_models)
+        return nm
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
-        list(ex.map(one, sample))
+        nmodels = sum(ex.map(one, sample))
     dt = time.perf_counter() - t0
     return {"value": len(sample) / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d of %d pairs (%s), %d threads, oracle/ restatement of the reference CPU path, %.1f s"
+            "hypotheses_per_s": nmodels / dt,
+            "sample": "%d of %d pairs (%s), %d threads, oracle/ restatement of the reference CPU path "
+                      "(MatchSiftFeaturesCPU + TwoViewGeometry::Estimate), %.1f s"
                       % (len(sample), len(pairs), "match only" if not verify else "match + verify", cores, dt)}
 
 
@@ -80,7 +92,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    verify = False  # two-view verification is wired in below once available
+    verify = not args.no_verify
+    calibrated = not args.uncalibrated
     scene = synthetic.Scene(args.images, args.feats, seed=args.seed)
     images = [scene.image(i) for i in range(args.images)]
     pairs = synthetic.exhaustive_pairs(args.images)
@@ -89,52 +102,80 @@ def main():
     my_pairs = pairs[bounds[rank]:bounds[rank + 1]]
 
     ctx = capi.Context(local_rank)
-    ctx.set_images([im[0] for im in images], [im[1] for im in images])
+    cams = [capi.simple_pinhole(scene.focal, scene.width / 2.0, scene.height / 2.0, scene.width, scene.height, calibrated)
+            for _ in range(args.images)]
+    ctx.set_images([im[0] for im in images], [im[1] for im in images], cams)
     opts = capi.default_match_options()
+    topts = capi.default_two_view_options()
+    user_seed = 0
+    TVG_BYTES = ctypes.sizeof(capi.TwoViewGeometry)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def gather_results():
-        """All-gather of the per-pair match graph (counts + matches) over RCCL."""
-        counts = torch.empty(len(my_pairs), dtype=torch.int32, device=dev)
-        capi.lib().dsm_get_match_counts(ctx._h, counts.data_ptr())
-        offs = torch.empty(len(my_pairs) + 1, dtype=torch.int64, device=dev)
-        capi.lib().dsm_get_matches(ctx._h, offs.data_ptr(), None, 0)
-        total = int(offs[-1].item())
+    def gather_var(fetch, total):
+        """All-gather of a variable-length [total, 2] int32 array produced by `fetch(ptr, capacity)`."""
         if world == 1:
-            return int(counts.sum().item()), total
+            return total
         sizes = torch.zeros(world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(sizes, torch.tensor([total], dtype=torch.int64, device=dev))
-        mx = int(sizes.max().item())
+        mx = max(int(sizes.max().item()), 1)
         mine = torch.zeros((mx, 2), dtype=torch.int32, device=dev)
         if total:
-            capi.lib().dsm_get_matches(ctx._h, None, mine.data_ptr(), total)
+            fetch(mine.data_ptr(), total)
         allm = torch.empty((world * mx, 2), dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(allm, mine)
-        maxp = int(np.diff(bounds).max())
-        cpad = torch.zeros(maxp, dtype=torch.int32, device=dev)
-        cpad[:len(my_pairs)] = counts
-        allc = torch.empty(world * maxp, dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(allc, cpad)
-        return int(allc.sum().item()), int(sizes.sum().item())
+        return int(sizes.sum().item())
+
+    def gather_results():
+        """All-gather of the per-pair match graph over RCCL: match counts + matches and, when verifying,
+        the TwoViewGeometry records + inlier matches."""
+        L = capi.lib()
+        offs = torch.empty(len(my_pairs) + 1, dtype=torch.int64, device=dev)
+        L.dsm_get_matches(ctx._h, offs.data_ptr(), None, 0)
+        total = int(offs[-1].item())
+        n_matches = gather_var(lambda ptr, cap: L.dsm_get_matches(ctx._h, None, ptr, cap), total)
+        n_inl, n_models, n_ok = 0, 0, 0
+        if verify:
+            maxp = int(np.diff(bounds).max())
+            tv = torch.zeros(maxp * TVG_BYTES, dtype=torch.uint8, device=dev)
+            L.dsm_get_two_view_geometries(ctx._h, tv.data_ptr())
+            if world > 1:
+                alltv = torch.empty(world * maxp * TVG_BYTES, dtype=torch.uint8, device=dev)
+                dist.all_gather_into_tensor(alltv, tv)
+            else:
+                alltv = tv
+            rec = alltv.view(-1, TVG_BYTES)
+            head = rec[:, :16].contiguous().view(torch.int32)        # config, num_inliers, num_matches, reserved
+            tail = rec[:, TVG_BYTES - 16:].contiguous().view(torch.int32)  # num_models[4]
+            n_ok = int((head[:, 0] > 1).sum().item())
+            n_models = int(tail.sum().item())
+            ioffs = torch.empty(len(my_pairs) + 1, dtype=torch.int64, device=dev)
+            L.dsm_get_inlier_matches(ctx._h, ioffs.data_ptr(), None, 0)
+            itotal = int(ioffs[-1].item())
+            n_inl = gather_var(lambda ptr, cap: L.dsm_get_inlier_matches(ctx._h, None, ptr, cap), itotal)
+        return dict(matches=n_matches, inliers=n_inl, models=n_models, verified=n_ok)
 
     def step():
         ctx.match_pairs(my_pairs, opts)
+        if verify:
+            ctx.verify_pairs(topts, user_seed=user_seed, stage_filter=True)
         return gather_results()
 
     for _ in range(args.warmup):
         step()
-    k1_ms, k1_launches = 0.0, 0
+    k1_ms, k1_launches, kv_ms = 0.0, 0, 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        n_matched, n_matches = step()
+        res = step()
         ms, nl = ctx.match_kernel_time()
         k1_ms += ms
         k1_launches += nl
+        if verify:
+            kv_ms += ctx.verify_kernel_time()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -153,14 +194,21 @@ def main():
         pairs_per_launch = len(my_pairs) * args.steps / max(k1_launches, 1)
         achieved = ops_per_pair * pairs_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0
         out = {
-            "metric": "verified image-pairs/sec at 4096 feats/image" if verify else
-                      "matched image-pairs/sec at %d feats/image (verification not in this build)" % args.feats,
+            "metric": ("verified image-pairs/sec (+ RANSAC hypotheses/sec) at %d feats/image" % args.feats) if verify else
+                      "matched image-pairs/sec at %d feats/image (matching only, --no-verify)" % args.feats,
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u8 (int8 MFMA, int32 accumulate)" if not verify else "u8+f64", "data": "synthetic",
+            "dtype": "u8 (int8 MFMA, int32 accumulate)" if not verify else "u8 matching (int8 MFMA) + f64 verification",
+            "data": "synthetic",
             "config": {"workload": "%d images x %d feats exhaustive (%d pairs), %s" % (
-                args.images, args.feats, n_pairs, "match + two-view RANSAC" if verify else "match only"),
-                "pairs": n_pairs, "total_matches": n_matches, "parallelism": "pair-sharded x%d + RCCL all-gather" % world},
+                args.images, args.feats, n_pairs,
+                ("match + two-view LO-RANSAC (%s)" % ("calibrated: E+F+H + relative pose" if calibrated else "uncalibrated: F+H"))
+                if verify else "match only"),
+                "pairs": n_pairs, "total_matches": res["matches"], "total_inlier_matches": res["inliers"],
+                "pairs_with_geometry": res["verified"], "hypotheses_per_step": res["models"],
+                "parallelism": "pair-sharded x%d + RCCL all-gather" % world},
+            "hypotheses_per_s": res["models"] * args.steps / dt if verify else None,
+            "kernel_ms_per_step": {"k1_best_rows": k1_ms / args.steps, "k_verify_pairs": kv_ms / args.steps},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": INT8_MFMA_DENSE_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / INT8_MFMA_DENSE_PEAK, "traffic": None,
                          "kernel": "k1_best_rows", "avg_launch_ms": 1e3 * avg_launch_s, "launches": k1_launches,
@@ -168,9 +216,9 @@ def main():
         }
         n_cpu = args.cpu_pairs
         if n_cpu < 0:
-            n_cpu = 24 if args.feats >= 2048 else 200
+            n_cpu = (os.cpu_count() or 8) * (12 if args.feats >= 2048 else 100)
         if world == 1 and n_cpu > 0:
-            out["cpu_baseline"] = cpu_baseline(images, pairs, min(n_cpu, len(pairs)), verify)
+            out["cpu_baseline"] = cpu_baseline(images, pairs, min(n_cpu, len(pairs)), verify, cams, topts, user_seed)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

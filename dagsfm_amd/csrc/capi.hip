@@ -102,7 +102,7 @@ struct dsm_ctx {
   // last dsm_verify_pairs
   bool verified = false;
   DevBuf d_cams, d_pairs_dev, d_seeds, d_tvg, d_inl, d_inl_counts, d_inl_off, d_inl_compact, d_vscratch, d_inl_total;
-  DevBuf d_nt_table, d_nt_off, d_nt_off_t;
+  DevBuf d_nt_table, d_nt_off, d_nt_off_t, d_pair_state, d_pts_px, d_pts_norm, d_reports, d_masks;
   uint64_t total_inliers = 0;
   double verify_ms = 0.0;
   // cache of the tabulated RANSAC::ComputeNumTrials (host libm), keyed by confidence
@@ -206,7 +206,8 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
                     &ctx->d_dpairs, &ctx->d_doutoff, &ctx->d_pair_dir, &ctx->d_m, &ctx->d_counts,
                     &ctx->d_offsets, &ctx->d_matches, &ctx->d_total, &ctx->d_cams, &ctx->d_pairs_dev, &ctx->d_seeds,
                     &ctx->d_tvg, &ctx->d_inl, &ctx->d_inl_counts, &ctx->d_inl_off, &ctx->d_inl_compact,
-                    &ctx->d_vscratch, &ctx->d_inl_total, &ctx->d_nt_table, &ctx->d_nt_off, &ctx->d_nt_off_t};
+                    &ctx->d_vscratch, &ctx->d_inl_total, &ctx->d_nt_table, &ctx->d_nt_off, &ctx->d_nt_off_t,
+                    &ctx->d_pair_state, &ctx->d_pts_px, &ctx->d_pts_norm, &ctx->d_reports, &ctx->d_masks};
   if (ctx->vev0) (void)hipEventDestroy(ctx->vev0);
   if (ctx->vev1) (void)hipEventDestroy(ctx->vev1);
   for (DevBuf* b : bufs) b->release();
@@ -571,7 +572,19 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
   const uint32_t n_blocks = std::min<uint32_t>(n_pairs, (uint32_t)dev_cus * 8u);
   HIPCHK(ctx, ctx->d_vscratch.reserve(std::max<size_t>(1, (size_t)n_blocks * verify_scratch_bytes_per_block(n_max))));
+  const uint64_t tm = std::max<uint64_t>(total_matches, 1);
+  HIPCHK(ctx, ctx->d_pair_state.reserve(std::max<size_t>(n_pairs, 1) * 640 * 4));
+  HIPCHK(ctx, ctx->d_pts_px.reserve(tm * 32));
+  HIPCHK(ctx, ctx->d_pts_norm.reserve(tm * 32));
+  HIPCHK(ctx, ctx->d_reports.reserve(std::max<size_t>(n_pairs, 1) * 3 * sizeof(RansacReport)));
+  HIPCHK(ctx, ctx->d_masks.reserve(tm * 3));
   VerifyParams vp;
+  vp.pair_state = ctx->d_pair_state.as<uint32_t>();
+  vp.pts_px = ctx->d_pts_px.as<double>();
+  vp.pts_norm = ctx->d_pts_norm.as<double>();
+  vp.reports = ctx->d_reports.as<RansacReport>();
+  vp.masks = ctx->d_masks.as<unsigned char>();
+  vp.mask_stride = tm;
   vp.pairs = d_pairs;
   vp.match_off = d_match_off;
   vp.matches = d_matches;

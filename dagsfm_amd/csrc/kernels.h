@@ -32,6 +32,16 @@ struct K2Params {
   uint32_t* matches;          // [total][2]
 };
 
+// Result of one LO-RANSAC family for one pair (RANSAC<>::Report, /root/reference/src/optim/ransac.h:80-97).
+struct RansacReport {
+  bool success;
+  uint32_t num_trials;
+  uint32_t num_models;
+  uint32_t num_inliers;
+  double residual_sum;
+  double model[9];
+};
+
 // Two-view verification: one 64-lane workgroup per image pair (grid-stride over the pair list).
 struct VerifyParams {
   const uint32_t* pairs;       // [n_pairs][2] image indices
@@ -50,6 +60,13 @@ struct VerifyParams {
   uint32_t* inlier_matches;    // [total][2], pair p at match_off[p]
   uint32_t* inl_counts;        // [n_pairs]
   double* scratch;             // per workgroup work area
+  // per-pair state that travels between the phase kernels
+  uint32_t* pair_state;        // [n_pairs][640]: MT19937 state (624 words) + index
+  double* pts_px;              // [total][4] matched pixel points x1 y1 x2 y2
+  double* pts_norm;            // [total][4] the same through Camera::ImageToWorld (calibrated pairs)
+  RansacReport* reports;       // [n_pairs][3] E, F, H
+  unsigned char* masks;        // [3][mask_stride] inlier masks of the three families
+  uint64_t mask_stride;
   uint32_t n_pairs;
   uint32_t n_max;              // max matches of any pair in this launch
   int32_t stage_filter;        // apply SiftFeatureMatcher::Match's min_num_inliers post-filter

@@ -297,15 +297,6 @@ DSM_DEV int fam_local(const PairWork& w, int ninl) {
 }
 
 // ------------------------------------------------------------------------------------ LO-RANSAC
-struct RansacReport {
-  bool success;
-  uint32_t num_trials;
-  uint32_t num_models;
-  uint32_t num_inliers;
-  double residual_sum;
-  double model[9];
-};
-
 struct RansacOpt {
   double max_error;
   uint32_t min_num_trials;
@@ -711,30 +702,136 @@ DSM_DEVN int decompose_homography(const double* H, const double* K1, const doubl
   return 4;
 }
 
-// ------------------------------------------------------------------------------------ kernel
-// Scratch layout per resident workgroup (doubles unless noted), n = n_max of the launch:
-//   pts_px [4n]  pts_norm [4n]  resid [n]  tall [18n + 81]  models [64*10*9]  pts3d_a [3n] pts3d_b [3n]
-//   ipts [4n]  inl (int) [n]
+// ------------------------------------------------------------------------------------ kernels
+// The verification of a pair list runs as five launches over the same grid-stride pair loop so that
+// each phase gets its own register allocation (the 5-point solver would otherwise pin the whole
+// pipeline at one wave per SIMD):
+//   k_verify_prep      gather matched points (+ ImageToWorld), seed the pair's MT19937
+//   k_ransac<E|F|H>    one LO-RANSAC family each, in the stream order E -> F -> H; the generator
+//                      state travels between the launches through pair_state
+//   k_verify_final     decision tree, inlier extraction, watermark, relative pose, output
+// Per resident workgroup scratch (doubles), n = n_max of the launch:
+//   resid [n]  tall [18n + 96]  models [64*10*9]  pts3d_a [3n]  pts3d_b [3n]  ipts [4n]  inl (int) [n]
 __host__ __device__ inline size_t verify_scratch_doubles(size_t n) {
-  return 4 * n + 4 * n + n + (18 * n + 96) + (size_t)BATCH * 10 * 9 + 3 * n + 3 * n + 4 * n + (n + 1) / 2 + 8;
+  return n + (18 * n + 96) + (size_t)BATCH * 10 * 9 + 3 * n + 3 * n + 4 * n + (n + 1) / 2 + 8;
 }
 
-__global__ __launch_bounds__(64) void k_verify_pairs(const VerifyParams p) {
+struct WgScratch {
+  double *resid, *tall, *models, *pts3d_a, *pts3d_b, *ipts;
+  int* inl;
+};
+DSM_DEV WgScratch wg_scratch(const VerifyParams& p) {
+  const size_t n = p.n_max;
+  WgScratch w;
+  double* base = p.scratch + (size_t)blockIdx.x * verify_scratch_doubles(n);
+  w.resid = base;
+  w.tall = w.resid + n;
+  w.models = w.tall + 18 * n + 96;
+  w.pts3d_a = w.models + (size_t)BATCH * 10 * 9;
+  w.pts3d_b = w.pts3d_a + 3 * n;
+  w.ipts = w.pts3d_b + 3 * n;
+  w.inl = reinterpret_cast<int*>(w.ipts + 4 * n);
+  return w;
+}
+
+__global__ __launch_bounds__(64) void k_verify_prep(const VerifyParams p) {
+  __shared__ VSmem sm;
+  const int lane = threadIdx.x;
+  for (uint32_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
+    const uint32_t im1 = p.pairs[2 * pi], im2 = p.pairs[2 * pi + 1];
+    const uint64_t moff = p.match_off[pi];
+    const int n = (int)(p.match_off[pi + 1] - moff);
+    if ((uint64_t)n < p.opt.min_num_inliers) continue;
+    const uint32_t* matches = p.matches + 2 * moff;
+    const dsm_camera cam1 = p.cams[im1], cam2 = p.cams[im2];
+    const bool calibrated = cam1.has_prior_focal_length && cam2.has_prior_focal_length;
+    const double* kp1 = p.kp + (size_t)p.img_row0[im1] * 2;
+    const double* kp2 = p.kp + (size_t)p.img_row0[im2] * 2;
+    double* pts_px = p.pts_px + 4 * moff;
+    double* pts_norm = p.pts_norm + 4 * moff;
+    for (int i = lane; i < n; i += 64) {
+      const uint32_t i1 = matches[2 * i], i2 = matches[2 * i + 1];
+      const double x1 = kp1[2 * (size_t)i1], y1 = kp1[2 * (size_t)i1 + 1];
+      const double x2 = kp2[2 * (size_t)i2], y2 = kp2[2 * (size_t)i2 + 1];
+      pts_px[4 * i + 0] = x1; pts_px[4 * i + 1] = y1; pts_px[4 * i + 2] = x2; pts_px[4 * i + 3] = y2;
+      if (calibrated) {
+        double u1, v1, u2, v2;
+        image_to_world(cam1, x1, y1, &u1, &v1);
+        image_to_world(cam2, x2, y2, &u2, &v2);
+        pts_norm[4 * i + 0] = u1; pts_norm[4 * i + 1] = v1; pts_norm[4 * i + 2] = u2; pts_norm[4 * i + 3] = v2;
+      }
+    }
+    wv_sync();
+    if (lane == 0) mt_seed(&sm, p.seeds[pi]);
+    wv_sync();
+    uint32_t* st = p.pair_state + (size_t)pi * 640;
+    for (int i = lane; i < 624; i += 64) st[i] = sm.mt[i];
+    if (lane == 0) st[624] = (uint32_t)sm.mti;
+    wv_sync();
+  }
+}
+
+template <int FAM>
+__global__ __launch_bounds__(64) void k_ransac(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   VSmem* sm = reinterpret_cast<VSmem*>(smem_raw);
   uint32_t* sidx = reinterpret_cast<uint32_t*>(smem_raw + ((sizeof(VSmem) + 15) / 16) * 16);
   const int lane = threadIdx.x;
-  const size_t nmax = p.n_max;
-  double* base = p.scratch + (size_t)blockIdx.x * verify_scratch_doubles(nmax);
-  double* pts_px = base;
-  double* pts_norm = pts_px + 4 * nmax;
-  double* resid = pts_norm + 4 * nmax;
-  double* tall = resid + nmax;
-  double* models = tall + 18 * nmax + 96;
-  double* pts3d_a = models + (size_t)BATCH * 10 * 9;
-  double* pts3d_b = pts3d_a + 3 * nmax;
-  double* ipts = pts3d_b + 3 * nmax;
-  int* inl = reinterpret_cast<int*>(ipts + 4 * nmax);
+  const WgScratch ws = wg_scratch(p);
+  for (uint32_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
+    wv_sync();
+    const uint64_t moff = p.match_off[pi];
+    const int n = (int)(p.match_off[pi + 1] - moff);
+    if ((uint64_t)n < p.opt.min_num_inliers) continue;
+    const uint32_t im1 = p.pairs[2 * pi], im2 = p.pairs[2 * pi + 1];
+    const dsm_camera& cam1 = p.cams[im1];
+    const dsm_camera& cam2 = p.cams[im2];
+    const bool calibrated = cam1.has_prior_focal_length && cam2.has_prior_focal_length;
+    if (FAM == FAM_E && !calibrated) continue;
+    uint32_t* st = p.pair_state + (size_t)pi * 640;
+    for (int i = lane; i < 624; i += 64) sm->mt[i] = st[i];
+    if (lane == 0) sm->mti = (int)st[624];
+    wv_sync();
+    PairWork w;
+    w.n = n;
+    w.resid = ws.resid;
+    w.inl = ws.inl;
+    w.tall = ws.tall;
+    w.models = ws.models;
+    w.sm = sm;
+    w.lane = lane;
+    w.pts = (FAM == FAM_E ? p.pts_norm : p.pts_px) + 4 * moff;
+    w.nt_table = p.nt_table + p.nt_off[n] + (size_t)FAM * (size_t)(n + 1);
+    RansacOpt ro;
+    ro.max_error = p.opt.max_error;
+    if (FAM == FAM_E)  // two_view_geometry.cc:319-323
+      ro.max_error = (image_to_world_threshold(cam1, p.opt.max_error) + image_to_world_threshold(cam2, p.opt.max_error)) / 2;
+    ro.min_num_trials = (uint32_t)p.opt.min_num_trials;
+    ro.max_num_trials = p.max_trials[FAM];
+    RansacReport rep;
+    lo_ransac<FAM>(w, ro, sidx, &rep);
+    const double mr = ro.max_error * ro.max_error;
+    unsigned char* mask = p.masks + (size_t)FAM * p.mask_stride + moff;
+    if (rep.success)
+      for (int i = lane; i < n; i += 64) mask[i] = ws.resid[i] <= mr;
+    if (lane == 0) p.reports[(size_t)pi * 3 + FAM] = rep;
+    wv_sync();
+    for (int i = lane; i < 624; i += 64) st[i] = sm->mt[i];
+    if (lane == 0) st[624] = (uint32_t)sm->mti;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_verify_final(const VerifyParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  VSmem* sm = reinterpret_cast<VSmem*>(smem_raw);
+  uint32_t* sidx = reinterpret_cast<uint32_t*>(smem_raw + ((sizeof(VSmem) + 15) / 16) * 16);
+  const int lane = threadIdx.x;
+  const WgScratch ws = wg_scratch(p);
+  double* resid = ws.resid;
+  int* inl = ws.inl;
+  double* ipts = ws.ipts;
+  double* pts3d_a = ws.pts3d_a;
+  double* pts3d_b = ws.pts3d_b;
 
   for (uint32_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
     wv_sync();
@@ -746,6 +843,8 @@ __global__ __launch_bounds__(64) void k_verify_pairs(const VerifyParams p) {
     uint32_t* out_inl = p.inlier_matches + 2 * moff;
     const dsm_camera cam1 = p.cams[im1], cam2 = p.cams[im2];
     const dsm_two_view_options& o = p.opt;
+    const double* pts_px = p.pts_px + 4 * moff;
+    const double* pts_norm = p.pts_norm + 4 * moff;
 
     // result defaults: TwoViewGeometry(), two_view_geometry.h:159-166
     int config = DSM_CONFIG_UNDEFINED;
@@ -759,82 +858,47 @@ __global__ __launch_bounds__(64) void k_verify_pairs(const VerifyParams p) {
     if ((uint64_t)n < o.min_num_inliers) {
       config = DSM_CONFIG_DEGENERATE;  // two_view_geometry.cc:298-301, 433-436
     } else {
-      // gather matched points (and their normalised versions for the calibrated path)
-      const double* kp1 = p.kp + (size_t)p.img_row0[im1] * 2;
-      const double* kp2 = p.kp + (size_t)p.img_row0[im2] * 2;
-      for (int i = lane; i < n; i += 64) {
-        const uint32_t i1 = matches[2 * i], i2 = matches[2 * i + 1];
-        const double x1 = kp1[2 * (size_t)i1], y1 = kp1[2 * (size_t)i1 + 1];
-        const double x2 = kp2[2 * (size_t)i2], y2 = kp2[2 * (size_t)i2 + 1];
-        pts_px[4 * i + 0] = x1; pts_px[4 * i + 1] = y1; pts_px[4 * i + 2] = x2; pts_px[4 * i + 3] = y2;
-        if (calibrated) {
-          double u1, v1, u2, v2;
-          image_to_world(cam1, x1, y1, &u1, &v1);
-          image_to_world(cam2, x2, y2, &u2, &v2);
-          pts_norm[4 * i + 0] = u1; pts_norm[4 * i + 1] = v1; pts_norm[4 * i + 2] = u2; pts_norm[4 * i + 3] = v2;
-        }
+      RansacReport E_rep, F_rep, H_rep;
+      E_rep.success = false;
+      E_rep.num_inliers = 0;
+      E_rep.num_trials = E_rep.num_models = 0;
+      if (calibrated) E_rep = p.reports[(size_t)pi * 3 + FAM_E];
+      F_rep = p.reports[(size_t)pi * 3 + FAM_F];
+      H_rep = p.reports[(size_t)pi * 3 + FAM_H];
+      const unsigned char* maskE = p.masks + (size_t)FAM_E * p.mask_stride + moff;
+      unsigned char* maskF = p.masks + (size_t)FAM_F * p.mask_stride + moff;
+      const unsigned char* maskH = p.masks + (size_t)FAM_H * p.mask_stride + moff;
+      if (calibrated) {
+        for (int k = 0; k < 9; ++k) Em[k] = E_rep.model[k];
+        ntr[0] = E_rep.num_trials;
+        nmo[0] = E_rep.num_models;
       }
-      if (lane == 0) mt_seed(sm, p.seeds[pi]);
-      wv_sync();
+      for (int k = 0; k < 9; ++k) {
+        Fm[k] = F_rep.model[k];
+        Hm[k] = H_rep.model[k];
+      }
+      ntr[1] = F_rep.num_trials;
+      nmo[1] = F_rep.num_models;
+      ntr[2] = H_rep.num_trials;
+      nmo[2] = H_rep.num_models;
+      // the generator continues where the H family stopped (watermark RANSAC, :547-549)
+      {
+        const uint32_t* st = p.pair_state + (size_t)pi * 640;
+        for (int i = lane; i < 624; i += 64) sm->mt[i] = st[i];
+        if (lane == 0) sm->mti = (int)st[624];
+        wv_sync();
+      }
 
       PairWork w;
       w.n = n;
       w.resid = resid;
       w.inl = inl;
-      w.tall = tall;
-      w.models = models;
+      w.tall = ws.tall;
+      w.models = ws.models;
       w.sm = sm;
       w.lane = lane;
-      const uint32_t* ntbase = p.nt_table + p.nt_off[n];  // [4][n+1]: E, F, H, T(unused here)
-
-      RansacReport E_rep, F_rep, H_rep;
-      E_rep.success = false;
-      E_rep.num_inliers = 0;
-      E_rep.num_trials = E_rep.num_models = 0;
-      const double max_res_px = o.max_error * o.max_error;
-      // masks: kept as bytes in the tail of `tall`'s neighbour area (ipts region is free until pose)
-      unsigned char* maskE = reinterpret_cast<unsigned char*>(ipts);
-      unsigned char* maskF = maskE + nmax;
-      unsigned char* maskH = maskF + nmax;
-      if (calibrated) {
-        RansacOpt ro;
-        ro.max_error = (image_to_world_threshold(cam1, o.max_error) + image_to_world_threshold(cam2, o.max_error)) / 2;
-        ro.min_num_trials = (uint32_t)o.min_num_trials;
-        ro.max_num_trials = p.max_trials[FAM_E];
-        w.pts = pts_norm;
-        w.nt_table = ntbase + 0 * (size_t)(n + 1);
-        lo_ransac<FAM_E>(w, ro, sidx, &E_rep);
-        const double mr = ro.max_error * ro.max_error;
-        if (E_rep.success)
-          for (int i = lane; i < n; i += 64) maskE[i] = resid[i] <= mr;
-        for (int k = 0; k < 9; ++k) Em[k] = E_rep.model[k];
-        ntr[0] = E_rep.num_trials;
-        nmo[0] = E_rep.num_models;
-        wv_sync();
-      }
-      RansacOpt ro;
-      ro.max_error = o.max_error;
-      ro.min_num_trials = (uint32_t)o.min_num_trials;
-      ro.max_num_trials = p.max_trials[FAM_F];
       w.pts = pts_px;
-      w.nt_table = ntbase + 1 * (size_t)(n + 1);
-      lo_ransac<FAM_F>(w, ro, sidx, &F_rep);
-      if (F_rep.success)
-        for (int i = lane; i < n; i += 64) maskF[i] = resid[i] <= max_res_px;
-      for (int k = 0; k < 9; ++k) Fm[k] = F_rep.model[k];
-      ntr[1] = F_rep.num_trials;
-      nmo[1] = F_rep.num_models;
-      wv_sync();
-      ro.max_num_trials = p.max_trials[FAM_H];
-      w.nt_table = ntbase + 2 * (size_t)(n + 1);
-      lo_ransac<FAM_H>(w, ro, sidx, &H_rep);
-      if (H_rep.success)
-        for (int i = lane; i < n; i += 64) maskH[i] = resid[i] <= max_res_px;
-      for (int k = 0; k < 9; ++k) Hm[k] = H_rep.model[k];
-      ntr[2] = H_rep.num_trials;
-      nmo[2] = H_rep.num_models;
-      wv_sync();
-
+      w.nt_table = nullptr;
       const unsigned char* best_mask = nullptr;
       const uint64_t mni = o.min_num_inliers;
       if (calibrated) {
@@ -1159,7 +1223,12 @@ size_t verify_smem_bytes(uint32_t n_max) { return ((sizeof(VSmem) + 15) / 16) * 
 
 void launch_verify(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
   if (p.n_pairs == 0 || n_blocks == 0) return;
-  hipLaunchKernelGGL(k_verify_pairs, dim3(n_blocks), dim3(64), verify_smem_bytes(p.n_max), st, p);
+  const size_t smem = verify_smem_bytes(p.n_max);
+  hipLaunchKernelGGL(k_verify_prep, dim3(n_blocks), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(k_ransac<FAM_E>, dim3(n_blocks), dim3(64), smem, st, p);
+  hipLaunchKernelGGL(k_ransac<FAM_F>, dim3(n_blocks), dim3(64), smem, st, p);
+  hipLaunchKernelGGL(k_ransac<FAM_H>, dim3(n_blocks), dim3(64), smem, st, p);
+  hipLaunchKernelGGL(k_verify_final, dim3(n_blocks), dim3(64), smem, st, p);
 }
 
 // Compaction of the per-pair inlier matches (stored at the pair's match offset) into list order.
