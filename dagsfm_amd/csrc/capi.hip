@@ -570,7 +570,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   HIPCHK(ctx, ctx->d_inl_total.reserve(8));
   int dev_cus = 256;
   (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-  const uint32_t n_blocks = std::min<uint32_t>(n_pairs, (uint32_t)dev_cus * 8u);
+  const uint32_t n_blocks = std::min<uint32_t>(n_pairs, (uint32_t)dev_cus * 16u);
   HIPCHK(ctx, ctx->d_vscratch.reserve(std::max<size_t>(1, (size_t)n_blocks * verify_scratch_bytes_per_block(n_max))));
   const uint64_t tm = std::max<uint64_t>(total_matches, 1);
   HIPCHK(ctx, ctx->d_pair_state.reserve(std::max<size_t>(n_pairs, 1) * 640 * 4));

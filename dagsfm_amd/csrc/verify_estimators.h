@@ -179,6 +179,169 @@ DSM_DEVN int homography_four_point(const double* xs, double* models) {
   return 1;
 }
 
+
+// ---------------------------------------------------------------------------------- homography, registers
+// Same arithmetic, operation for operation, as homography_four_point() above, but with every
+// array index a compile-time constant (fully unrolled loops, column pivoting through selects) so
+// that the 9 x 8 system lives in VGPRs instead of scratch memory.  This is the hot minimal solver:
+// the H family runs to its trial cap (1 765 trials per pair with the default options).
+template <int K>
+struct H4Step {
+  // one step of ColPivHouseholderQR::computeInPlace on a[c][r] (column c, row r), rows = 9, cols = 8
+  static DSM_DEV void run(double (&a)[8][9], double (&nu)[8], double (&nd)[8], double (&hco)[8]) {
+    int biggest = K;
+    double mx = nu[K];
+#pragma unroll
+    for (int j = K + 1; j < 8; ++j)
+      if (nu[j] > mx) {
+        mx = nu[j];
+        biggest = j;
+      }
+#pragma unroll
+    for (int j = K + 1; j < 8; ++j) {
+      const bool sw = (biggest == j);
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const double t = a[K][r], u = a[j][r];
+        a[K][r] = sw ? u : t;
+        a[j][r] = sw ? t : u;
+      }
+      const double t1 = nu[K], u1 = nu[j];
+      nu[K] = sw ? u1 : t1;
+      nu[j] = sw ? t1 : u1;
+      const double t2 = nd[K], u2 = nd[j];
+      nd[K] = sw ? u2 : t2;
+      nd[j] = sw ? t2 : u2;
+    }
+    // makeHouseholderInPlace on a[K][K..8]
+    double tail_sq = 0.0;
+#pragma unroll
+    for (int i = K + 1; i < 9; ++i) tail_sq += a[K][i] * a[K][i];
+    const double c0 = a[K][K];
+    double tau, beta;
+    if (tail_sq <= DBL_MIN) {
+      tau = 0.0;
+      beta = c0;
+#pragma unroll
+      for (int i = K + 1; i < 9; ++i) a[K][i] = 0.0;
+    } else {
+      double b = sqrt(c0 * c0 + tail_sq);
+      if (c0 >= 0.0) b = -b;
+#pragma unroll
+      for (int i = K + 1; i < 9; ++i) a[K][i] = a[K][i] / (c0 - b);
+      tau = (b - c0) / b;
+      beta = b;
+    }
+    hco[K] = tau;
+    a[K][K] = beta;
+    // applyHouseholderOnTheLeft to columns K+1..7, rows K..8 (nr = 9 - K >= 2 always)
+    if (tau != 0.0) {
+#pragma unroll
+      for (int j = K + 1; j < 8; ++j) {
+        double tmp = 0.0;
+#pragma unroll
+        for (int i = K + 1; i < 9; ++i) tmp += a[K][i] * a[j][i];
+        tmp += a[j][K];
+        a[j][K] -= tau * tmp;
+#pragma unroll
+        for (int i = K + 1; i < 9; ++i) a[j][i] -= tau * a[K][i] * tmp;
+      }
+    }
+    // norm downdating
+    const double norm_downdate_threshold = sqrt(DBL_EPSILON);
+#pragma unroll
+    for (int j = K + 1; j < 8; ++j) {
+      if (nu[j] != 0.0) {
+        double temp = fabs(a[j][K]) / nu[j];
+        temp = (1.0 + temp) * (1.0 - temp);
+        temp = temp < 0.0 ? 0.0 : temp;
+        const double ratio = nu[j] / nd[j];
+        const double temp2 = temp * (ratio * ratio);
+        if (temp2 <= norm_downdate_threshold) {
+          double ss = 0.0;
+#pragma unroll
+          for (int i = K + 1; i < 9; ++i) ss += a[j][i] * a[j][i];
+          nd[j] = sqrt(ss);
+          nu[j] = nd[j];
+        } else {
+          nu[j] *= sqrt(temp);
+        }
+      }
+    }
+  }
+};
+
+DSM_DEV int homography_four_point_reg(const double* xs, double* models) {
+  double n1[3], n2[3];
+  auto ident = [](int i) { return i; };
+  center_and_normalize(xs, 0, 4, ident, &n1[0], &n1[1], &n1[2]);
+  center_and_normalize(xs, 1, 4, ident, &n2[0], &n2[1], &n2[2]);
+  double a[8][9];  // a[c][r] = At(r, c) = A(c, r): column c of A^T is row c of A
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < 9; ++r) a[c][r] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double s_0, s_1, d_0, d_1;
+    apply_norm(n1[0], n1[1], n1[2], xs[i * 4 + 0], xs[i * 4 + 1], &s_0, &s_1);
+    apply_norm(n2[0], n2[1], n2[2], xs[i * 4 + 2], xs[i * 4 + 3], &d_0, &d_1);
+    a[i][0] = -s_0; a[i][1] = -s_1; a[i][2] = -1;
+    a[i][6] = s_0 * d_0; a[i][7] = s_1 * d_0; a[i][8] = d_0;
+    a[4 + i][3] = -s_0; a[4 + i][4] = -s_1; a[4 + i][5] = -1;
+    a[4 + i][6] = s_0 * d_1; a[4 + i][7] = s_1 * d_1; a[4 + i][8] = d_1;
+  }
+  // pl_nullspace_9xm: scale, pivoted QR, column 8 of householderQ
+  double scale = 0.0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const double v = fabs(a[c][r]);
+      if (v > scale) scale = v;
+    }
+  if (scale == 0.0) scale = 1.0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < 9; ++r) a[c][r] /= scale;
+  double nu[8], nd[8], hco[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    double ss = 0.0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) ss += a[c][r] * a[c][r];
+    nd[c] = sqrt(ss);
+    nu[c] = nd[c];
+  }
+  H4Step<0>::run(a, nu, nd, hco);
+  H4Step<1>::run(a, nu, nd, hco);
+  H4Step<2>::run(a, nu, nd, hco);
+  H4Step<3>::run(a, nu, nd, hco);
+  H4Step<4>::run(a, nu, nd, hco);
+  H4Step<5>::run(a, nu, nd, hco);
+  H4Step<6>::run(a, nu, nd, hco);
+  H4Step<7>::run(a, nu, nd, hco);
+  double q[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) q[i] = (i == 8) ? 1.0 : 0.0;
+#pragma unroll
+  for (int k = 7; k >= 0; --k) {
+    const double tau = hco[k];
+    if (tau != 0.0) {
+      double tmp = 0.0;
+#pragma unroll
+      for (int i = k + 1; i < 9; ++i) tmp += a[k][i] * q[i];
+      tmp += q[k];
+      q[k] -= tau * tmp;
+#pragma unroll
+      for (int i = k + 1; i < 9; ++i) q[i] -= tau * a[k][i] * tmp;
+    }
+  }
+  homography_finish(q, n1, n2, models);
+  return 1;
+}
+
 // ---------------------------------------------------------------------------------- 5-point E
 // Monomial tables of the generic polynomial construction of Nister's 10 x 20 system (see
 // oracle/two_view.cc: the reference's generated essential_matrix_poly.h / _coeffs.h are replaced by
@@ -203,8 +366,16 @@ DSM_DEV void poly_mul(const double* a, int na, const double* b, int nb, double* 
 
 // Steps 3-5 of EssentialMatrixFivePointEstimator::Estimate (/root/reference/src/estimators/essential_matrix.cc:76-147)
 // from the 9 x 4 null-space basis Eb[r*4 + c] = svd.matrixV()(r, 5 + c).  Up to 10 models.
-DSM_DEVN int five_point_finish(const double* Eb, double* models) {
-  double A[200];  // A[r*20 + c]
+// `ws`: optional workspace of FIVEPT_WS doubles (LDS when a single lane runs the local optimisation,
+// so that its long dependent chains wait on LDS instead of scratch memory); nullptr = private arrays.
+#define FIVEPT_WS (200 + 100 + 100 + 100)
+template <bool WS>
+DSM_DEVN int five_point_finish_t(const double* Eb, double* models, double* ws) {
+  double A_loc[WS ? 1 : 200], A1_loc[WS ? 1 : 100], AA_loc[WS ? 1 : 100];
+  double* A = WS ? ws : A_loc;  // A[r*20 + c]
+  double* A1 = WS ? ws + 200 : A1_loc;
+  double* AA = WS ? ws + 300 : AA_loc;
+  double* Cws = WS ? ws + 400 : nullptr;
   for (int i = 0; i < 200; ++i) A[i] = 0.0;
   // lin(r, c) = Eb row (3r + c): 4 coefficients (x, y, z, 1)
 #define LIN(r, c) (Eb + ((r) * 3 + (c)) * 4)
@@ -248,8 +419,7 @@ DSM_DEVN int five_point_finish(const double* Eb, double* models) {
       }
   }
 #undef LIN
-  double A1[100], AA[100];  // column-major 10 x 10
-  for (int r = 0; r < 10; ++r)
+  for (int r = 0; r < 10; ++r)  // A1, AA: column-major 10 x 10
     for (int c = 0; c < 10; ++c) {
       A1[c * 10 + r] = A[r * 20 + c];
       AA[c * 10 + r] = A[r * 20 + 10 + c];
@@ -298,7 +468,7 @@ DSM_DEVN int five_point_finish(const double* Eb, double* models) {
     for (int i = 0; i < 11; ++i) coeffs[i] = det[10 - i];
   }
   double rr[11], ri[11];
-  const int nroots = pl_poly_roots<11>(coeffs, 11, rr, ri);
+  const int nroots = pl_poly_roots<11>(coeffs, 11, rr, ri, Cws);
   if (nroots < 0) return 0;
   int nm = 0;
   for (int i = 0; i < nroots; ++i) {
@@ -328,6 +498,8 @@ DSM_DEVN int five_point_finish(const double* Eb, double* models) {
   }
   return nm;
 }
+
+DSM_DEV int five_point_finish(const double* Eb, double* models) { return five_point_finish_t<false>(Eb, models, nullptr); }
 
 // EssentialMatrixFivePointEstimator::Estimate for the minimal sample, essential_matrix.cc:46-150
 DSM_DEVN int five_point_minimal(const double* xs, double* models) {

@@ -47,6 +47,7 @@ struct VSmem {
   double cur_model[9];
   double bcast[16];
   int ibcast[8];
+  double ws5[FIVEPT_WS];   // LDS workspace of the single-lane 5-point local optimisation
 };
 
 // ------------------------------------------------------------------------------------ MT19937 (lane 0)
@@ -117,7 +118,7 @@ template <int FAM>
 DSM_DEV int fam_minimal(const double* xs, double* models) {
   if (FAM == FAM_E) return five_point_minimal(xs, models);
   if (FAM == FAM_F) return seven_point(xs, models);
-  if (FAM == FAM_H) return homography_four_point(xs, models);
+  if (FAM == FAM_H) return homography_four_point_reg(xs, models);
   // TranslationTransformEstimator<2>::Estimate with one point, translation_transform.h:81-104
   const double sx = (0.0 + xs[0]) / 1, sy = (0.0 + xs[1]) / 1, dx = (0.0 + xs[2]) / 1, dy = (0.0 + xs[3]) / 1;
   models[0] = dx - sx;
@@ -228,7 +229,7 @@ DSM_DEV int fam_local(const PairWork& w, int ninl) {
       double Eb[36];
       for (int r = 0; r < 9; ++r)
         for (int c = 0; c < 4; ++c) Eb[r * 4 + c] = sm->svd.V[(5 + c) * 9 + r];
-      sm->ibcast[0] = five_point_finish(Eb, sm->lo_models);
+      sm->ibcast[0] = five_point_finish_t<true>(Eb, sm->lo_models, sm->ws5);
     }
     wv_sync();
     return sm->ibcast[0];
@@ -772,7 +773,7 @@ __global__ __launch_bounds__(64) void k_verify_prep(const VerifyParams p) {
 }
 
 template <int FAM>
-__global__ __launch_bounds__(64) void k_ransac(const VerifyParams p) {
+__global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_ransac(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   VSmem* sm = reinterpret_cast<VSmem*>(smem_raw);
   uint32_t* sidx = reinterpret_cast<uint32_t*>(smem_raw + ((sizeof(VSmem) + 15) / 16) * 16);
@@ -821,7 +822,7 @@ __global__ __launch_bounds__(64) void k_ransac(const VerifyParams p) {
   }
 }
 
-__global__ __launch_bounds__(64) void k_verify_final(const VerifyParams p) {
+__global__ __launch_bounds__(64, 2) void k_verify_final(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   VSmem* sm = reinterpret_cast<VSmem*>(smem_raw);
   uint32_t* sidx = reinterpret_cast<uint32_t*>(smem_raw + ((sizeof(VSmem) + 15) / 16) * 16);

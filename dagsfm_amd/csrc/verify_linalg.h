@@ -517,7 +517,7 @@ DSM_DEVN bool pl_hessenberg_eigenvalues(double* T, int n, double* re, double* im
 // FindPolynomialRootsCompanionMatrix (/root/reference/src/base/polynomial.cc:208-275) for up to
 // MAXC coefficients (highest degree first).  Returns the number of roots, or -1 on failure.
 template <int MAXC>
-DSM_DEV int pl_poly_roots(const double* coeffs_all, int ncoef, double* real, double* imag) {
+DSM_DEV int pl_poly_roots(const double* coeffs_all, int ncoef, double* real, double* imag, double* ws = nullptr) {
   int lead = 0;
   for (; lead < ncoef; ++lead)
     if (coeffs_all[lead] != 0) break;
@@ -568,7 +568,8 @@ DSM_DEV int pl_poly_roots(const double* coeffs_all, int ncoef, double* real, dou
   }
   const int n = nc - 1;
   constexpr int LD = MAXC - 1;
-  double C[LD * LD];
+  double C_loc[LD * LD];
+  double* C = ws ? ws : C_loc;  // optional caller-provided (LDS) workspace of LD*LD doubles
   for (int j = 0; j < n; ++j)
     for (int i = 0; i < n; ++i) C[j * LD + i] = 0.0;
   for (int i = 1; i < n; ++i) C[(i - 1) * LD + i] = 1.0;
