@@ -435,6 +435,39 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
   return DSM_OK;
 }
 
+int dsm_set_matches(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const uint64_t* offsets, const uint32_t* matches) {
+  if (!ctx || (n_pairs && (!pairs || !offsets))) return DSM_ERR_INVALID_ARGUMENT;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->matched = false;
+  ctx->verified = false;
+  const uint64_t total = n_pairs ? offsets[n_pairs] : 0;
+  if (total && !matches) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "null matches");
+  std::vector<uint32_t> counts(n_pairs);
+  for (uint32_t i = 0; i < n_pairs; ++i) {
+    const uint32_t a = pairs[2 * i], b = pairs[2 * i + 1];
+    if (a >= ctx->n_images || b >= ctx->n_images) return fail(ctx, DSM_ERR_OUT_OF_RANGE, "image index out of range");
+    if (offsets[i + 1] < offsets[i]) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
+    counts[i] = (uint32_t)(offsets[i + 1] - offsets[i]);
+    for (uint64_t k = offsets[i]; k < offsets[i + 1]; ++k)
+      if (matches[2 * k] >= ctx->nfeat[a] || matches[2 * k + 1] >= ctx->nfeat[b])
+        return fail(ctx, DSM_ERR_OUT_OF_RANGE, "match index out of range");
+  }
+  ctx->n_pairs = n_pairs;
+  ctx->pairs.assign(pairs, pairs + (size_t)n_pairs * 2);
+  ctx->total_matches = total;
+  ctx->k1_ms = 0.0;
+  ctx->k1_launches = 0;
+  HIPCHK(ctx, ctx->d_counts.reserve(std::max<uint32_t>(n_pairs, 1) * 4));
+  HIPCHK(ctx, ctx->d_offsets.reserve(((size_t)n_pairs + 1) * 8));
+  HIPCHK(ctx, ctx->d_matches.reserve(std::max<uint64_t>(total, 1) * 8));
+  const uint64_t zero = 0;
+  HIPCHK(ctx, hipMemcpy(ctx->d_offsets.p, n_pairs ? offsets : &zero, ((size_t)n_pairs + 1) * 8, hipMemcpyHostToDevice));
+  if (n_pairs) HIPCHK(ctx, hipMemcpy(ctx->d_counts.p, counts.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice));
+  if (total) HIPCHK(ctx, hipMemcpy(ctx->d_matches.p, matches, total * 8, hipMemcpyHostToDevice));
+  ctx->matched = true;
+  return DSM_OK;
+}
+
 int dsm_get_match_counts(dsm_ctx* ctx, uint32_t* counts) {
   if (!ctx || !counts) return DSM_ERR_INVALID_ARGUMENT;
   if (!ctx->matched) return fail(ctx, DSM_ERR_NOT_READY, "dsm_match_pairs has not run");

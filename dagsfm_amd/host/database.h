@@ -1,0 +1,75 @@
+// database.h -- COLMAP/DAGSfM database.db access for the matching path (system sqlite3).
+// Mirrors the parts of /root/reference/src/base/database.{h,cc} this path touches: schema
+// (:1165-1262), pair ids (database.h:336-364), blob formats (:90-110), matches /
+// two_view_geometries rows incl. DAGSfM's use of the F column for qvec and the E column for tvec
+// (:681-751, :493-533).
+#ifndef DAGSFM_AMD_HOST_DATABASE_H_
+#define DAGSFM_AMD_HOST_DATABASE_H_
+
+#include <string>
+#include <vector>
+
+#include "types.h"
+
+struct sqlite3;
+struct sqlite3_stmt;
+
+namespace dagsfm_amd {
+
+class Database {
+ public:
+  const static int kSchemaVersion = 1;
+  const static size_t kMaxNumImages = static_cast<size_t>(std::numeric_limits<int32_t>::max());
+
+  Database();
+  explicit Database(const std::string& path);
+  ~Database();
+  void Open(const std::string& path);
+  void Close();
+
+  static image_pair_t ImagePairToPairId(image_t image_id1, image_t image_id2);
+  static void PairIdToImagePair(image_pair_t pair_id, image_t* image_id1, image_t* image_id2);
+  static bool SwapImagePair(image_t image_id1, image_t image_id2);
+
+  bool ExistsMatches(image_t image_id1, image_t image_id2) const;
+  bool ExistsInlierMatches(image_t image_id1, image_t image_id2) const;
+  size_t NumMatchedImagePairs() const;
+  size_t NumVerifiedImagePairs() const;
+
+  std::vector<Camera> ReadAllCameras() const;
+  std::vector<Image> ReadAllImages() const;
+  FeatureKeypoints ReadKeypoints(image_t image_id) const;
+  FeatureDescriptors ReadDescriptors(image_t image_id) const;
+  FeatureMatches ReadMatches(image_t image_id1, image_t image_id2) const;
+  TwoViewGeometry ReadTwoViewGeometry(image_t image_id1, image_t image_id2) const;
+
+  camera_t WriteCamera(const Camera& camera) const;
+  image_t WriteImage(const Image& image) const;
+  void WriteKeypoints(image_t image_id, const FeatureKeypoints& keypoints) const;
+  void WriteDescriptors(image_t image_id, const FeatureDescriptors& descriptors) const;
+  void WriteMatches(image_t image_id1, image_t image_id2, const FeatureMatches& matches) const;
+  void WriteTwoViewGeometry(image_t image_id1, image_t image_id2, const TwoViewGeometry& two_view_geometry) const;
+  void DeleteMatches(image_t image_id1, image_t image_id2) const;
+  void DeleteInlierMatches(image_t image_id1, image_t image_id2) const;
+
+  void BeginTransaction() const;
+  void EndTransaction() const;
+
+ private:
+  void CreateTables() const;
+  void Exec(const char* sql) const;
+  sqlite3* database_ = nullptr;
+};
+
+// RAII transaction like DatabaseTransaction, database.h:306-318
+class DatabaseTransaction {
+ public:
+  explicit DatabaseTransaction(Database* database) : database_(database) { database_->BeginTransaction(); }
+  ~DatabaseTransaction() { database_->EndTransaction(); }
+
+ private:
+  Database* database_;
+};
+
+}  // namespace dagsfm_amd
+#endif

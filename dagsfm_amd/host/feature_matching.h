@@ -1,0 +1,103 @@
+// feature_matching.h -- drop-in host side of the matching + verification stage, above the C-ABI.
+//
+// Same surface as the reference so that the two call sites compile unchanged
+// (/root/reference/src/controllers/distributed_mapper_controller.cpp:506-520,
+//  /root/reference/src/controllers/incremental_mapper_controller.cc:450-471):
+//     FeatureMatcherCache cache(5 * num_images, &database);
+//     SiftFeatureMatcher matcher(options, &database, &cache);
+//     matcher.Setup();  cache.Setup();  matcher.Match(image_pairs);
+// Classes mirrored: FeatureMatcherCache (src/feature/matching.h:180-212, matching.cc:215-316),
+// SiftFeatureMatcher (matching.h:320-391, matching.cc:610-839), ExhaustiveFeatureMatcher
+// (matching.h:393-414, matching.cc:841-915).  The reference's thread pipeline (matcher threads,
+// verifier threads, JobQueues) is replaced by one pass of the HIP kernels over the pair list.
+#ifndef DAGSFM_AMD_HOST_FEATURE_MATCHING_H_
+#define DAGSFM_AMD_HOST_FEATURE_MATCHING_H_
+
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "database.h"
+#include "types.h"
+
+namespace dagsfm_amd {
+
+struct ExhaustiveMatchingOptions {  // matching.h:52-60
+  int block_size = 50;
+  bool Check() const { return block_size > 1; }
+};
+
+// All cameras / images resident; keypoints and descriptors of every image are bulk-loaded once and
+// stay resident in HBM (the reference keeps an LRU of 5 * block_size images in host RAM).
+class FeatureMatcherCache {
+ public:
+  FeatureMatcherCache(size_t cache_size, const Database* database);
+  void Setup();
+
+  const Camera& GetCamera(camera_t camera_id) const { return cameras_cache_.at(camera_id); }
+  const Image& GetImage(image_t image_id) const { return images_cache_.at(image_id); }
+  std::vector<image_t> GetImageIds() const;
+  const FeatureKeypoints& GetKeypoints(image_t image_id);
+  const FeatureDescriptors& GetDescriptors(image_t image_id);
+  FeatureMatches GetMatches(image_t a, image_t b) const { return database_->ReadMatches(a, b); }
+  bool ExistsMatches(image_t a, image_t b) const { return database_->ExistsMatches(a, b); }
+  bool ExistsInlierMatches(image_t a, image_t b) const { return database_->ExistsInlierMatches(a, b); }
+  void WriteMatches(image_t a, image_t b, const FeatureMatches& m) const { database_->WriteMatches(a, b, m); }
+  void WriteTwoViewGeometry(image_t a, image_t b, const TwoViewGeometry& t) const { database_->WriteTwoViewGeometry(a, b, t); }
+  void DeleteMatches(image_t a, image_t b) const { database_->DeleteMatches(a, b); }
+  void DeleteInlierMatches(image_t a, image_t b) const { database_->DeleteInlierMatches(a, b); }
+
+ private:
+  const size_t cache_size_;
+  const Database* database_;
+  std::unordered_map<camera_t, Camera> cameras_cache_;
+  std::unordered_map<image_t, Image> images_cache_;
+  std::unordered_map<image_t, FeatureKeypoints> keypoints_cache_;
+  std::unordered_map<image_t, FeatureDescriptors> descriptors_cache_;
+};
+
+class SiftFeatureMatcher {
+ public:
+  SiftFeatureMatcher(const SiftMatchingOptions& options, Database* database, FeatureMatcherCache* cache);
+  ~SiftFeatureMatcher();
+
+  // Creates the device context; false when no usable GPU is present (matching.cc:732-742).
+  bool Setup();
+  // Matches + verifies the pairs and writes `matches` / `two_view_geometries` rows, with the
+  // reference's dedupe / skip / partial-recompute / post-filter semantics (matching.cc:749-839).
+  void Match(const std::vector<std::pair<image_t, image_t>>& image_pairs);
+
+  const std::string& LastError() const { return last_error_; }
+
+ private:
+  bool UploadImages();
+  SiftMatchingOptions options_;
+  Database* database_;
+  FeatureMatcherCache* cache_;
+  bool is_setup_ = false;
+  bool images_uploaded_ = false;
+  dsm_ctx* ctx_ = nullptr;
+  std::vector<image_t> image_ids_;                    // device image index -> image_id
+  std::unordered_map<image_t, uint32_t> image_index_;  // image_id -> device image index
+  std::string last_error_;
+};
+
+// ExhaustiveFeatureMatcher::Run, matching.cc:853-915: blocks of block_size x block_size images,
+// one transaction + one Match() per block.
+class ExhaustiveFeatureMatcher {
+ public:
+  ExhaustiveFeatureMatcher(const ExhaustiveMatchingOptions& options, const SiftMatchingOptions& match_options,
+                           const std::string& database_path);
+  bool Run();
+
+ private:
+  ExhaustiveMatchingOptions options_;
+  SiftMatchingOptions match_options_;
+  Database database_;
+  FeatureMatcherCache cache_;
+  SiftFeatureMatcher matcher_;
+};
+
+}  // namespace dagsfm_amd
+#endif

@@ -1,0 +1,91 @@
+// types.h -- host-side data types of the matching + verification path, mirroring the reference:
+//   util/types.h:48-77 (id typedefs), feature/types.h:44-104 (FeatureKeypoint/Match/Descriptors),
+//   feature/sift.h:116-165 (SiftMatchingOptions), estimators/two_view_geometry.h:79-306 (TwoViewGeometry),
+//   base/camera.h / base/image.h (only the members this path reads).
+#ifndef DAGSFM_AMD_HOST_TYPES_H_
+#define DAGSFM_AMD_HOST_TYPES_H_
+
+#include <cstdint>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/dagsfm_mi355x.h"
+
+namespace dagsfm_amd {
+
+typedef uint32_t camera_t;
+typedef uint32_t image_t;
+typedef uint64_t image_pair_t;
+typedef uint32_t point2D_t;
+const image_t kInvalidImageId = std::numeric_limits<image_t>::max();
+const point2D_t kInvalidPoint2DIdx = std::numeric_limits<point2D_t>::max();
+
+struct FeatureKeypoint {  // feature/types.h:44-81
+  float x = 0, y = 0, a11 = 1, a12 = 0, a21 = 0, a22 = 1;
+};
+typedef std::vector<FeatureKeypoint> FeatureKeypoints;
+
+struct FeatureDescriptors {  // row-major uint8 [rows][cols], feature/types.h:102-103
+  size_t rows = 0, cols = 128;
+  std::vector<uint8_t> data;
+};
+
+struct FeatureMatch {  // feature/types.h:86-99
+  point2D_t point2D_idx1 = kInvalidPoint2DIdx;
+  point2D_t point2D_idx2 = kInvalidPoint2DIdx;
+  FeatureMatch() {}
+  FeatureMatch(point2D_t a, point2D_t b) : point2D_idx1(a), point2D_idx2(b) {}
+};
+typedef std::vector<FeatureMatch> FeatureMatches;
+
+struct Camera {  // base/camera.h (subset)
+  camera_t camera_id = 0;
+  int model_id = 0;
+  size_t width = 0, height = 0;
+  std::vector<double> params;
+  bool prior_focal_length = false;
+  bool HasPriorFocalLength() const { return prior_focal_length; }
+};
+
+struct Image {  // base/image.h (subset)
+  image_t image_id = 0;
+  std::string name;
+  camera_t camera_id = 0;
+};
+
+struct TwoViewGeometry {  // estimators/two_view_geometry.h:79-306
+  int config = DSM_CONFIG_UNDEFINED;
+  double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // row-major
+  double F[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double qvec[4] = {0, 0, 0, 0};
+  double tvec[3] = {0, 0, 0};
+  FeatureMatches inlier_matches;
+  double tri_angle = 0;
+  void Invert();  // two_view_geometry.cc:98-111
+};
+
+struct SiftMatchingOptions {  // feature/sift.h:116-165, same names and defaults
+  int num_threads = -1;
+  bool use_gpu = true;
+  std::string gpu_index = "-1";
+  double max_ratio = 0.8;
+  double max_distance = 0.7;
+  bool cross_check = true;
+  int max_num_matches = 32768;
+  double max_error = 4.0;
+  double confidence = 0.999;
+  int min_num_trials = 30;
+  int max_num_trials = 10000;
+  double min_inlier_ratio = 0.25;
+  int min_num_inliers = 15;
+  bool multiple_models = false;
+  bool guided_matching = false;
+  // not in the reference: seed of the per-pair PRNG schedule (the reference seeds from the clock)
+  uint32_t random_seed = 0;
+  bool Check() const;  // feature/sift.cc:236-250
+};
+
+}  // namespace dagsfm_amd
+#endif

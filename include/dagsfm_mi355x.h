@@ -140,6 +140,13 @@ int dsm_set_images(dsm_ctx* ctx, uint32_t n_images, const uint32_t* n_feats,
 int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs,
                     const dsm_match_options* options);
 
+/* Installs caller-provided matches (host pointers) as if dsm_match_pairs had produced them, so
+ * that dsm_verify_pairs can verify them.  Used for SiftFeatureMatcher::Match's resume path: a
+ * pair whose `matches` row exists but whose `two_view_geometries` row does not is only
+ * re-verified (src/feature/matching.cc:782-812).  offsets has n_pairs+1 entries. */
+int dsm_set_matches(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const uint64_t* offsets,
+                    const uint32_t* matches);
+
 /* Per-pair number of matches of the last dsm_match_pairs; `counts` has n_pairs
  * entries (host or device pointer). */
 int dsm_get_match_counts(dsm_ctx* ctx, uint32_t* counts);

@@ -1,0 +1,153 @@
+"""Host-side C++ shim (dagsfm_amd/host): Database blob/pair-id semantics on CPU, and the full
+SiftFeatureMatcher::Match / ExhaustiveFeatureMatcher::Run drop-in on the GPU against the oracle."""
+import ctypes
+import os
+import sqlite3
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import dbutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_LIB = os.path.join(ROOT, "dagsfm_amd", "libdagsfm_host.so")
+CLI = os.path.join(ROOT, "dagsfm_amd", "dsm_exhaustive_matcher")
+u32p = ctypes.POINTER(ctypes.c_uint32)
+f64p = ctypes.POINTER(ctypes.c_double)
+
+
+def host():
+    assert os.path.exists(HOST_LIB), "run __graft_entry__.build() first"
+    L = ctypes.CDLL(HOST_LIB)
+    L.dsm_host_image_pair_to_pair_id.restype = ctypes.c_uint64
+    L.dsm_host_image_pair_to_pair_id.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    L.dsm_host_db_write_pair.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, u32p, ctypes.c_uint32, ctypes.c_int,
+                                         f64p, f64p, u32p, ctypes.c_uint32]
+    L.dsm_host_db_read_pair.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, u32p, u32p,
+                                        ctypes.POINTER(ctypes.c_int), f64p, f64p, u32p, u32p, ctypes.c_uint32]
+    L.dsm_host_exhaustive_matcher.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_double,
+                                              ctypes.c_double, ctypes.c_int, ctypes.c_int]
+    return L
+
+
+def test_pair_id(tmp_path):
+    # Database::ImagePairToPairId, /root/reference/src/base/database.h:336-347
+    L = host()
+    assert L.dsm_host_image_pair_to_pair_id(1, 2) == 2147483647 * 1 + 2
+    assert L.dsm_host_image_pair_to_pair_id(2, 1) == 2147483647 * 1 + 2
+    assert L.dsm_host_image_pair_to_pair_id(7, 7) == 2147483647 * 7 + 7
+    assert L.dsm_host_image_pair_to_pair_id(100, 3) == dbutil.pair_id(3, 100)
+
+
+def _write(L, path, a, b, m, config, q, t, inl):
+    m = np.ascontiguousarray(m, np.uint32).reshape(-1, 2)
+    inl = np.ascontiguousarray(inl, np.uint32).reshape(-1, 2)
+    q, t = np.asarray(q, np.float64), np.asarray(t, np.float64)
+    rc = L.dsm_host_db_write_pair(path.encode(), a, b, m.ctypes.data_as(u32p), len(m), config, q.ctypes.data_as(f64p),
+                                  t.ctypes.data_as(f64p), inl.ctypes.data_as(u32p), len(inl))
+    assert rc == 0
+
+
+def _read(L, path, a, b):
+    m, inl = np.zeros((256, 2), np.uint32), np.zeros((256, 2), np.uint32)
+    nm, ni, cfg = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_int(0)
+    q, t = np.zeros(4), np.zeros(3)
+    rc = L.dsm_host_db_read_pair(path.encode(), a, b, m.ctypes.data_as(u32p), ctypes.byref(nm), ctypes.byref(cfg),
+                                 q.ctypes.data_as(f64p), t.ctypes.data_as(f64p), inl.ctypes.data_as(u32p), ctypes.byref(ni), 256)
+    assert rc == 0
+    return m[:nm.value].copy(), cfg.value, q, t, inl[:ni.value].copy()
+
+
+def test_database_round_trip_and_dagsfm_columns(tmp_path):
+    """base/database_test.cc:283-360 patterns + DAGSfM's F:=qvec / E:=tvec / H:=NULL columns (database.cc:733-747)."""
+    L = host()
+    path = str(tmp_path / "db.db")
+    m = [[0, 1], [2, 3], [5, 4]]
+    inl = [[0, 1], [5, 4]]
+    q = [0.5, 0.5, -0.5, 0.5]
+    t = [1.0, 2.0, 3.0]
+    _write(L, path, 1, 2, m, 2, q, t, inl)
+    rm, cfg, rq, rt, ri = _read(L, path, 1, 2)
+    assert rm.tolist() == m and ri.tolist() == inl and cfg == 2 and rq.tolist() == q and rt.tolist() == t
+    # reading in swapped order swaps the match columns and inverts the pose (database.cc:527-529, pose.cc:192-196)
+    rm2, cfg2, rq2, rt2, ri2 = _read(L, path, 2, 1)
+    assert rm2.tolist() == [[1, 0], [3, 2], [4, 5]] and ri2.tolist() == [[1, 0], [4, 5]]
+    assert rq2.tolist() == [0.5, -0.5, 0.5, -0.5]
+    w, x, y, z = 0.5, -0.5, 0.5, -0.5
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    assert np.allclose(rt2, -R @ np.array(t), atol=1e-12)
+    # raw rows
+    con = sqlite3.connect(path)
+    row = con.execute("SELECT pair_id, rows, cols, data, config, F, E, H FROM two_view_geometries").fetchone()
+    assert row[0] == dbutil.pair_id(1, 2) and row[1] == 2 and row[2] == 2 and row[4] == 2
+    assert np.frombuffer(row[5], np.float64).tolist() == q and np.frombuffer(row[6], np.float64).tolist() == t
+    assert row[7] is None
+    mrow = con.execute("SELECT rows, cols, data FROM matches").fetchone()
+    assert mrow[0] == 3 and mrow[1] == 2 and np.frombuffer(mrow[2], np.uint32).reshape(3, 2).tolist() == m
+    con.close()
+    # writing with id1 > id2 stores the swapped matches under the same pair id convention
+    _write(L, path, 9, 4, [[7, 8]], 3, q, t, [[7, 8]])
+    con = sqlite3.connect(path)
+    data = con.execute("SELECT data FROM matches WHERE pair_id = ?", (dbutil.pair_id(4, 9),)).fetchone()[0]
+    assert np.frombuffer(data, np.uint32).tolist() == [8, 7]
+    con.close()
+    # no inliers -> zero-length F/E blobs (database.cc:739-747)
+    _write(L, path, 5, 6, [], 0, [0, 0, 0, 0], [0, 0, 0], [])
+    con = sqlite3.connect(path)
+    row = con.execute("SELECT rows, data, config, F, E FROM two_view_geometries WHERE pair_id = ?", (dbutil.pair_id(5, 6),)).fetchone()
+    assert row[0] == 0 and row[2] == 0 and len(row[3] or b"") == 0 and len(row[4] or b"") == 0
+    assert con.execute("PRAGMA user_version").fetchone()[0] == 3600
+    con.close()
+
+
+@pytest.mark.gpu
+def test_exhaustive_matcher_drop_in(tmp_path, oracle):
+    """colmap exhaustive_matcher equivalent over a synthetic database.db == oracle, incl. resume semantics."""
+    from dagsfm_amd import capi, synthetic
+    n_img = 6
+    scene = synthetic.Scene(n_img, 640, seed=33, n_pool=1800)
+    ims = [scene.image(i) for i in range(n_img)]
+    path = str(tmp_path / "database.db")
+    dbutil.create(path, [(im[0], im[1]) for im in ims], prior=True)
+    assert os.path.exists(CLI)
+    subprocess.check_call([CLI, "--database_path", path, "--ExhaustiveMatching.block_size", "4", "--random_seed", "5"])
+    matches, tvgs = dbutil.read_results(path)
+    assert len(matches) == n_img * (n_img - 1) // 2 == len(tvgs)
+    cam = capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, True)
+    opts = capi.default_two_view_options()
+    n_geo = 0
+    for i in range(n_img):
+        for j in range(i + 1, n_img):
+            pid = dbutil.pair_id(i + 1, j + 1)
+            ref_m = oracle.match_sift_features_cpu(ims[i][0], ims[j][0])
+            ref, ref_inl = oracle.estimate_two_view_geometry(cam, ims[i][1].astype(np.float64), cam, ims[j][1].astype(np.float64),
+                                                             ref_m, opts, capi.pair_seed(i + 1, j + 1, 5))
+            exp_m = ref_m if len(ref_m) >= 15 else np.zeros((0, 2), np.uint32)
+            assert (matches[pid] == exp_m).all()
+            t = tvgs[pid]
+            if ref.num_inliers >= 15:
+                n_geo += 1
+                assert t["config"] == ref.config and (t["inliers"] == ref_inl).all()
+                assert np.allclose(np.frombuffer(t["F"], np.float64), list(ref.qvec), rtol=1e-6, atol=1e-12)
+                assert np.allclose(np.frombuffer(t["E"], np.float64), list(ref.tvec), rtol=1e-6, atol=1e-12)
+                assert t["H"] is None
+            else:
+                assert t["config"] == 0 and len(t["inliers"]) == 0
+    assert n_geo >= 8
+    # resume: (1) nothing to do; (2) a deleted two_view_geometries row is re-verified from the stored matches
+    before = dbutil.read_results(path)
+    subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5"])
+    after = dbutil.read_results(path)
+    assert all((before[0][k] == after[0][k]).all() for k in before[0])
+    con = sqlite3.connect(path)
+    pid = dbutil.pair_id(1, 2)
+    con.execute("DELETE FROM two_view_geometries WHERE pair_id = ?", (pid,))
+    con.commit()
+    con.close()
+    subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5"])
+    again = dbutil.read_results(path)
+    assert (again[1][pid]["inliers"] == before[1][pid]["inliers"]).all() and again[1][pid]["config"] == before[1][pid]["config"]
+    assert again[1][pid]["F"] == before[1][pid]["F"]
