@@ -56,6 +56,9 @@ def cpu_baseline(scene_images, pairs, budget_s, verify, cams=None, opts=None, us
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    # each worker holds an N1 x N2 int32 distance matrix (64 MiB at 4096 features) like the reference does;
+    # beyond ~64 threads the host's memory system, not its cores, limits this path
+    cores = min(cores, 64)
     kps = [im[1].astype(np.float64) for im in scene_images]
     order = np.linspace(0, len(pairs) - 1, min(len(pairs), 65536)).astype(np.int64)
     lock = threading.Lock()

@@ -113,7 +113,7 @@ def test_exhaustive_matcher_drop_in(tmp_path, oracle):
     path = str(tmp_path / "database.db")
     dbutil.create(path, [(im[0], im[1]) for im in ims], prior=True)
     assert os.path.exists(CLI)
-    subprocess.check_call([CLI, "--database_path", path, "--ExhaustiveMatching.block_size", "4", "--random_seed", "5"])
+    subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5"])  # one block: pairs visited as (i, j), i < j
     matches, tvgs = dbutil.read_results(path)
     assert len(matches) == n_img * (n_img - 1) // 2 == len(tvgs)
     cam = capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, True)
@@ -151,3 +151,63 @@ def test_exhaustive_matcher_drop_in(tmp_path, oracle):
     again = dbutil.read_results(path)
     assert (again[1][pid]["inliers"] == before[1][pid]["inliers"]).all() and again[1][pid]["config"] == before[1][pid]["config"]
     assert again[1][pid]["F"] == before[1][pid]["F"]
+
+
+def _visit_order(n, block_size):
+    """ExhaustiveFeatureMatcher::Run's block loop, /root/reference/src/feature/matching.cc:870-905 (0-based indices)."""
+    out = []
+    for s1 in range(0, n, block_size):
+        e1 = min(n, s1 + block_size) - 1
+        for s2 in range(0, n, block_size):
+            e2 = min(n, s2 + block_size) - 1
+            for i1 in range(s1, e1 + 1):
+                for i2 in range(s2, e2 + 1):
+                    b1, b2 = i1 % block_size, i2 % block_size
+                    if (i1 > i2 and b1 <= b2) or (i1 < i2 and b1 < b2):
+                        out.append((i1, i2))
+    return out
+
+
+@pytest.mark.gpu
+def test_exhaustive_matcher_blocks_and_swapped_pairs(tmp_path, oracle):
+    """block_size < #images: some pairs are visited as (larger id, smaller id); the rows are stored swapped /
+    inverted exactly as Database::WriteMatches / WriteTwoViewGeometry do (database.cc:681-751)."""
+    from dagsfm_amd import capi, synthetic
+    n_img = 6
+    scene = synthetic.Scene(n_img, 512, seed=34, n_pool=1400)
+    ims = [scene.image(i) for i in range(n_img)]
+    path = str(tmp_path / "database.db")
+    dbutil.create(path, [(im[0], im[1]) for im in ims], prior=True)
+    subprocess.check_call([CLI, "--database_path", path, "--ExhaustiveMatching.block_size", "4", "--random_seed", "9"])
+    matches, tvgs = dbutil.read_results(path)
+    order = _visit_order(n_img, 4)
+    assert len({frozenset(p) for p in order}) == len(order) == n_img * (n_img - 1) // 2 == len(matches)
+    assert any(a > b for a, b in order)
+    cam = capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, True)
+    opts = capi.default_two_view_options()
+    n_swapped_geo = 0
+    for a, b in order:
+        pid = dbutil.pair_id(a + 1, b + 1)
+        ref_m = oracle.match_sift_features_cpu(ims[a][0], ims[b][0])
+        ref, ref_inl = oracle.estimate_two_view_geometry(cam, ims[a][1].astype(np.float64), cam, ims[b][1].astype(np.float64),
+                                                         ref_m, opts, capi.pair_seed(a + 1, b + 1, 9))
+        swap = a > b
+        exp_m = ref_m[:, ::-1] if swap else ref_m
+        assert (matches[pid] == exp_m).all()
+        t = tvgs[pid]
+        if ref.num_inliers >= 15:
+            assert t["config"] == ref.config
+            assert (t["inliers"] == (ref_inl[:, ::-1] if swap else ref_inl)).all()
+            q = np.frombuffer(t["F"], np.float64)
+            tv = np.frombuffer(t["E"], np.float64)
+            rq, rt = np.array(list(ref.qvec)), np.array(list(ref.tvec))
+            if swap:
+                n_swapped_geo += 1
+                w, x, y, z = rq[0], -rq[1], -rq[2], -rq[3]
+                R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                              [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                              [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+                assert np.allclose(q, [w, x, y, z], rtol=1e-6, atol=1e-12) and np.allclose(tv, -R @ rt, rtol=1e-6, atol=1e-9)
+            else:
+                assert np.allclose(q, rq, rtol=1e-6, atol=1e-12) and np.allclose(tv, rt, rtol=1e-6, atol=1e-12)
+    assert n_swapped_geo >= 1
