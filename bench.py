@@ -204,6 +204,13 @@ def main():
         avg_launch_s = 1e-3 * k1_ms / max(k1_launches, 1)
         pairs_per_launch = len(my_pairs) * args.steps / max(k1_launches, 1)
         achieved = ops_per_pair * pairs_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0
+        traffic = None
+        try:  # HBM bytes per K1 launch from the committed PMC collection (tools/collect_pmc.py), same workload only
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_k1_pmc.json")))
+            if pmc.get("images") == args.images and pmc.get("feats") == args.feats and world == 1:
+                traffic = pmc.get("k1_traffic_bytes_per_launch")
+        except Exception:
+            traffic = None
         out = {
             "metric": ("verified image-pairs/sec (+ RANSAC hypotheses/sec) at %d feats/image" % args.feats) if verify else
                       "matched image-pairs/sec at %d feats/image (matching only, --no-verify)" % args.feats,
@@ -221,7 +228,9 @@ def main():
             "hypotheses_per_s": res["models"] * args.steps / dt if verify else None,
             "kernel_ms_per_step": {"k1_best_rows": k1_ms / args.steps, "k_verify_pairs": kv_ms / args.steps},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": INT8_MFMA_DENSE_PEAK / 1e12,
-                         "unit": "TFLOP/s", "frac": achieved / INT8_MFMA_DENSE_PEAK, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / INT8_MFMA_DENSE_PEAK, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) + "
+                                         "WRITE_SIZE in separate passes (profiles/r01_k1_pmc.json); null when not collected for this workload",
                          "kernel": "k1_best_rows", "avg_launch_ms": 1e3 * avg_launch_s, "launches": k1_launches,
                          "note": "int8 ops (2 per MAC) counted as flops; algorithmic 2*128*N^2 per pair"},
         }
