@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -103,6 +105,8 @@ struct dsm_ctx {
   bool verified = false;
   DevBuf d_cams, d_pairs_dev, d_seeds, d_tvg, d_inl, d_inl_counts, d_inl_off, d_inl_compact, d_vscratch, d_inl_total;
   DevBuf d_nt_table, d_nt_off, d_nt_off_t, d_pair_state, d_pts_px, d_pts_norm, d_reports, d_masks;
+  DevBuf d_fam_state, d_samples, d_draws_end, d_nmodels, d_vcounts, d_models, d_sidx, d_active;
+  uint32_t verify_rounds[3] = {0, 0, 0};
   uint64_t total_inliers = 0;
   double verify_ms = 0.0;
   // cache of the tabulated RANSAC::ComputeNumTrials (host libm), keyed by confidence
@@ -207,7 +211,9 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
                     &ctx->d_offsets, &ctx->d_matches, &ctx->d_total, &ctx->d_cams, &ctx->d_pairs_dev, &ctx->d_seeds,
                     &ctx->d_tvg, &ctx->d_inl, &ctx->d_inl_counts, &ctx->d_inl_off, &ctx->d_inl_compact,
                     &ctx->d_vscratch, &ctx->d_inl_total, &ctx->d_nt_table, &ctx->d_nt_off, &ctx->d_nt_off_t,
-                    &ctx->d_pair_state, &ctx->d_pts_px, &ctx->d_pts_norm, &ctx->d_reports, &ctx->d_masks};
+                    &ctx->d_pair_state, &ctx->d_pts_px, &ctx->d_pts_norm, &ctx->d_reports, &ctx->d_masks,
+                    &ctx->d_fam_state, &ctx->d_samples, &ctx->d_draws_end, &ctx->d_nmodels, &ctx->d_vcounts, &ctx->d_models,
+                    &ctx->d_sidx, &ctx->d_active};
   if (ctx->vev0) (void)hipEventDestroy(ctx->vev0);
   if (ctx->vev1) (void)hipEventDestroy(ctx->vev1);
   for (DevBuf* b : bufs) b->release();
@@ -311,8 +317,6 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
     if (a >= ctx->n_images || b >= ctx->n_images) return fail(ctx, DSM_ERR_OUT_OF_RANGE, "image index out of range");
     if ((int64_t)ctx->nfeat[a] > options->max_num_matches || (int64_t)ctx->nfeat[b] > options->max_num_matches)
       return fail(ctx, DSM_ERR_OUT_OF_RANGE, "image has more features than max_num_matches");
-    if (ctx->rows[a] > 8192 || ctx->rows[b] > 8192)
-      return fail(ctx, DSM_ERR_OUT_OF_RANGE, "more than 8192 features per image not supported by this build");
   }
   HIPCHK(ctx, ctx->d_counts.reserve(std::max<uint32_t>(n_pairs, 1) * 4));
   HIPCHK(ctx, ctx->d_offsets.reserve(((size_t)n_pairs + 1) * 8));
@@ -606,7 +610,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   const uint32_t n_blocks = std::min<uint32_t>(n_pairs, (uint32_t)dev_cus * 16u);
   HIPCHK(ctx, ctx->d_vscratch.reserve(std::max<size_t>(1, (size_t)n_blocks * verify_scratch_bytes_per_block(n_max))));
   const uint64_t tm = std::max<uint64_t>(total_matches, 1);
-  HIPCHK(ctx, ctx->d_pair_state.reserve(std::max<size_t>(n_pairs, 1) * 640 * 4));
+  HIPCHK(ctx, ctx->d_pair_state.reserve(std::max<size_t>(n_pairs, 1) * 1280 * 4));
   HIPCHK(ctx, ctx->d_pts_px.reserve(tm * 32));
   HIPCHK(ctx, ctx->d_pts_norm.reserve(tm * 32));
   HIPCHK(ctx, ctx->d_reports.reserve(std::max<size_t>(n_pairs, 1) * 3 * sizeof(RansacReport)));
@@ -644,10 +648,97 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     HIPCHK(ctx, hipEventCreate(&ctx->vev0));
     HIPCHK(ctx, hipEventCreate(&ctx->vev1));
   }
-  HIPCHK(ctx, hipEventRecord(ctx->vev0, st));
-  launch_verify(vp, n_blocks, st);
-  HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipEventRecord(ctx->vev1, st));
+  vp.pair0 = 0;
+  vp.n_chunk = n_pairs;
+  vp.batch = 0;
+  vp.fam_state = nullptr;
+  vp.samples = nullptr;
+  vp.draws_end = nullptr;
+  vp.nmodels = nullptr;
+  vp.counts = nullptr;
+  vp.models = nullptr;
+  vp.sidx_g = nullptr;
+  vp.active_count = nullptr;
+  const bool legacy = getenv("DSM_VERIFY_LEGACY") != nullptr;  // single-kernel-per-family schedule (debug)
+  if (legacy) {
+    HIPCHK(ctx, hipEventRecord(ctx->vev0, st));
+    launch_verify(vp, n_blocks, st);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->vev1, st));
+  } else {
+    // phase-split pipeline: per family, rounds of sample -> solve+score -> replay until no pair is active
+    uint32_t batch[3], bmax = 0;
+    uint64_t bm_max = 0;
+    for (int f = 0; f < 3; ++f) {
+      batch[f] = vp_batch(f, vp.max_trials[f]);
+      bmax = std::max(bmax, batch[f]);
+      bm_max = std::max<uint64_t>(bm_max, (uint64_t)batch[f] * vp_maxm(f));
+    }
+    const uint64_t per_pair = (uint64_t)bmax * (7 * 4 + 4 + 4) + bm_max * (4 + 72);
+    const uint64_t budget = 16ull << 30;
+    const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_pairs, budget / per_pair));
+    HIPCHK(ctx, ctx->d_fam_state.reserve(std::max<size_t>(n_pairs, 1) * 3 * sizeof(FamState)));
+    HIPCHK(ctx, ctx->d_sidx.reserve(tm * 4));
+    HIPCHK(ctx, ctx->d_active.reserve(128));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_active.p, 0, 128, st));
+    HIPCHK(ctx, ctx->d_samples.reserve((size_t)chunk * bmax * 7 * 4));
+    HIPCHK(ctx, ctx->d_draws_end.reserve((size_t)chunk * bmax * 4));
+    HIPCHK(ctx, ctx->d_nmodels.reserve((size_t)chunk * bmax * 4));
+    HIPCHK(ctx, ctx->d_vcounts.reserve((size_t)chunk * bm_max * 4));
+    HIPCHK(ctx, ctx->d_models.reserve((size_t)chunk * bm_max * 72));
+    vp.fam_state = ctx->d_fam_state.as<FamState>();
+    vp.samples = ctx->d_samples.as<uint32_t>();
+    vp.draws_end = ctx->d_draws_end.as<uint32_t>();
+    vp.nmodels = ctx->d_nmodels.as<int32_t>();
+    vp.counts = ctx->d_vcounts.as<int32_t>();
+    vp.models = ctx->d_models.as<double>();
+    vp.sidx_g = ctx->d_sidx.as<uint32_t>();
+    vp.active_count = ctx->d_active.as<uint32_t>();
+    ctx->verify_rounds[0] = ctx->verify_rounds[1] = ctx->verify_rounds[2] = 0;
+    HIPCHK(ctx, hipEventRecord(ctx->vev0, st));
+    for (uint32_t c0 = 0; c0 < n_pairs; c0 += chunk) {
+      vp.pair0 = c0;
+      vp.n_chunk = std::min<uint32_t>(chunk, n_pairs - c0);
+      const uint32_t nb_light = std::min<uint32_t>(vp.n_chunk, (uint32_t)dev_cus * 32u);
+      const uint32_t nb_heavy = std::min<uint32_t>(vp.n_chunk, (uint32_t)dev_cus * 16u);
+      vp.batch = 0;
+      launch_vp_prep(vp, nb_light, st);
+      HIPCHK(ctx, hipGetLastError());
+      for (int f = 0; f < 3; ++f) {
+        vp.batch = batch[f];
+        for (uint32_t round = 0; round < 100000; ++round) {
+          HIPCHK(ctx, hipMemsetAsync(ctx->d_active.p, 0, 4, st));
+          launch_vp_sample(vp, f, nb_light, st);
+          launch_vp_solve_score(vp, f, st);
+          launch_vp_replay(vp, f, nb_heavy, st);
+          HIPCHK(ctx, hipGetLastError());
+          uint32_t active = 0;
+          HIPCHK(ctx, hipMemcpyAsync(&active, ctx->d_active.p, 4, hipMemcpyDeviceToHost, st));
+          HIPCHK(ctx, hipStreamSynchronize(st));
+          ctx->verify_rounds[f]++;
+          if (active == 0) break;
+        }
+      }
+      launch_vp_final(vp, nb_heavy, st);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->vev1, st));
+    if (getenv("DSM_VERIFY_DEBUG")) {
+      uint32_t dbg[32];
+      HIPCHK(ctx, hipMemcpy(dbg, ctx->d_active.p, 128, hipMemcpyDeviceToHost));
+      const unsigned long long* cyc = reinterpret_cast<const unsigned long long*>(dbg + 8);
+      fprintf(stderr, "[dsm verify] replay cycles (all families): candidates %llu  local-opt %llu  whole-pair loop %llu\n", cyc[0], cyc[1], cyc[2]);
+#ifdef DSM_PROFILE_SECTIONS
+      {
+        unsigned long long prof[16];
+        debug_read_prof(prof);
+        fprintf(stderr, "[dsm verify] LO sections (cycles): qr %llu  jacobi %llu  finish8pt %llu  finish5pt %llu\n", prof[4], prof[5], prof[6], prof[7]);
+      }
+#endif
+      fprintf(stderr, "[dsm verify] pairs %u rounds E/F/H %u/%u/%u candidates E/F/H %u/%u/%u LO calls E/F/H %u/%u/%u\n", n_pairs,
+              ctx->verify_rounds[0], ctx->verify_rounds[1], ctx->verify_rounds[2], dbg[1], dbg[3], dbg[5], dbg[2], dbg[4], dbg[6]);
+    }
+  }
   // compact inlier matches in list order
   HIPCHK(ctx, hipMemsetAsync(ctx->d_inl_total.p, 0, 8, st));
   launch_scan(ctx->d_inl_counts.as<uint32_t>(), ctx->d_inl_off.as<uint64_t>(), n_pairs, ctx->d_inl_total.as<uint64_t>(), st);

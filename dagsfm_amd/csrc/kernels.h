@@ -42,6 +42,15 @@ struct RansacReport {
   double model[9];
 };
 
+// Progress of one LO-RANSAC family for one pair between the rounds of the phase-split pipeline.
+struct FamState {
+  RansacReport rep;     // best support so far; rep.num_trials = trials consumed so far
+  uint32_t dyn_max;     // dyn_max_num_trials
+  uint32_t active;      // 1 while more trials are needed
+  uint32_t rounds;      // sampling rounds done
+  uint32_t nb;          // trials sampled in the current round
+};
+
 // Two-view verification: one 64-lane workgroup per image pair (grid-stride over the pair list).
 struct VerifyParams {
   const uint32_t* pairs;       // [n_pairs][2] image indices
@@ -67,6 +76,17 @@ struct VerifyParams {
   RansacReport* reports;       // [n_pairs][3] E, F, H
   unsigned char* masks;        // [3][mask_stride] inlier masks of the three families
   uint64_t mask_stride;
+  // phase-split pipeline (sample -> solve+score -> replay), one chunk of pairs [pair0, pair0 + n_chunk)
+  struct FamState* fam_state;  // [n_pairs][3]
+  uint32_t* samples;           // [n_chunk][batch][7] minimal-sample indices
+  uint32_t* draws_end;         // [n_chunk][batch] generator calls consumed up to the end of each trial's sample
+  int32_t* nmodels;            // [n_chunk][batch]
+  int32_t* counts;             // [n_chunk][batch][maxm]
+  double* models;              // [n_chunk][batch][maxm][9]
+  uint32_t* sidx_g;            // [total] RandomSampler's persistent index array of every pair (at match offsets)
+  uint32_t* active_count;      // pairs that still need trials after a replay round
+  uint32_t pair0, n_chunk;     // chunk of the pair list handled by this launch
+  uint32_t batch;              // trials speculated per round for the family being launched
   uint32_t n_pairs;
   uint32_t n_max;              // max matches of any pair in this launch
   int32_t stage_filter;        // apply SiftFeatureMatcher::Match's min_num_inliers post-filter
@@ -75,6 +95,15 @@ struct VerifyParams {
 size_t verify_scratch_bytes_per_block(uint32_t n_max);
 size_t verify_smem_bytes(uint32_t n_max);
 void launch_verify(const VerifyParams& p, uint32_t n_blocks, hipStream_t st);
+// phase-split pipeline launches (fam: 0 = E, 1 = F, 2 = H)
+void launch_vp_prep(const VerifyParams& p, uint32_t n_blocks, hipStream_t st);
+void launch_vp_sample(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st);
+void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st);
+void launch_vp_replay(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st);
+void launch_vp_final(const VerifyParams& p, uint32_t n_blocks, hipStream_t st);
+uint32_t vp_batch(int fam, uint32_t max_trials);
+uint32_t vp_maxm(int fam);
+void debug_read_prof(unsigned long long* out16);
 void launch_debug_samples(uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out, uint32_t* idx, hipStream_t st);
 void launch_compact_inliers(const uint64_t* match_off, const uint64_t* inl_off, const uint32_t* inl_counts,
                             const uint32_t* src, uint32_t* dst, uint32_t n_pairs, hipStream_t st);

@@ -19,10 +19,14 @@
 //   dot = S + rterm(i) + rterm(j) + 2^21,  S = sum a'b',  rterm(x) = 128 * sum x'
 // all in int32 (|dot| <= 128*255^2 < 2^23).  Per row the comparison value is
 //   v' = dot - rterm(i) - 2^22 = S + rterm(j) - 2^21   in (-2^23, 2^23)
-// so (v' << 8) + (255 - tile) is an order-preserving int32 key: larger dot wins, equal dots
-// resolve to the lower tile; the 32 columns of a tile live in different lanes and are merged
-// at the end with a 64-bit (v', ~column) key, which resolves equal dots to the lowest column
-// index exactly like the reference's ascending strict-`>` scan.  Top-2 of *distinct* keys
+// so key = ((v' + 2^23) << 7) + (127 - tile) is an order-preserving key: larger dot wins, equal
+// dots resolve to the lower tile.  The key is a positive int32 below 0x7F800000 with a non-zero
+// exponent field, i.e. also a finite normal float with the SAME ordering, so the top-2 update runs
+// on the full-rate float pipe (v_max_f32 / v_med3_f32); only the key build is an integer op.
+// A tile index has 7 bits => columns are swept in segments of 128 tiles (4 096 columns) whose
+// results are merged in ascending order; the 32 columns of a tile live in different lanes and
+// are merged per segment with a (key, lane) butterfly, which resolves equal dots to the lowest
+// column index exactly like the reference's ascending strict-`>` scan.  Top-2 of *distinct* keys
 // reproduces the reference's second-best semantics (a duplicate of the best value is the
 // second best, sift.cc:126-132).  Zero padding rows/columns have dot == 0 and can never
 // beat the initial best_dist = second_best_dist = 0 (sift.cc:122-123).
@@ -62,9 +66,15 @@ __global__ __launch_bounds__(256) void k0_prepare(const uint8_t* __restrict__ in
 }
 
 // ------------------------------------------------------------------------------------ K1
-__device__ __forceinline__ int med3_i32(int a, int b, int c) {
+// keys are positive normal floats bit-wise (see above): float max / med3 order them like integers
+__device__ __forceinline__ int key_med3(int a, int b, int c) {
   int d;
-  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  asm("v_med3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ int key_max(int a, int b) {
+  int d;
+  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
 
@@ -104,120 +114,181 @@ __global__ __launch_bounds__(256, 2) void k1_best_rows(const K1Params p) {
     for (int ks = 0; ks < 4; ++ks)
       afrag[rt][ks] = *reinterpret_cast<const v4i*>(arow + (rt * 32 + l31) * 128 + ks * 32 + half * 16);
 
-  // Running top-2 keys; initial value = "dot 0" (best_dist = second_best_dist = 0).
-  int best[2][16], second[2][16];
+  const int8_t* bimg = p.desc + (size_t)b_row0 * 128;
+  const int32_t* rt_bimg = p.rterm + b_row0;
   const int32_t* rt_a = p.rterm + a_row0 + wave * 64;
+  int key0[2][16];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int key0 = (int)((uint32_t)(-rt_a[row] - (1 << 22)) << 8);
-      best[rt][r] = key0;
-      second[rt][r] = key0;
+      key0[rt][r] = (int)((uint32_t)((1 << 22) - rt_a[row]) << 7);  // dot 0: v' + 2^23 = 2^22 - rterm(i)
     }
+  // running result of this lane's row over the column segments (best_dist = second_best_dist = 0 initially)
+  int run_b = 0, run_s = 0;
+  uint32_t run_j = 0;
 
-  const int8_t* bbase = p.desc + (size_t)b_row0 * 128;
-  const int32_t* rt_b = p.rterm + b_row0;
-  const uint32_t nsteps = b_cols >> 6;
-
-  v4i stage[2];
-  int colterm[2];
-  // prologue: tile 0
-#pragma unroll
-  for (int u = 0; u < 2; ++u) stage[u] = *reinterpret_cast<const v4i*>(bbase + (size_t)(tid + 256 * u) * 16);
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) colterm[ct] = rt_b[ct * 32 + l31];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int q = tid + 256 * u;
-    *reinterpret_cast<v4i*>(&sB[0][lds_off(q >> 3, q & 7)]) = stage[u];
+#define K1_MFMA4(ACC, RT, BF)                                                              \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                         \
+      ACC = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[RT][ks], BF[ks], ACC, 0, 0, 0)
+#define K1_EPILOGUE(ACC, RT, KT)                                                           \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
+    const int key = (int)((uint32_t)ACC[r] << 7) + KT;                                     \
+    second[RT][r] = key_med3(best[RT][r], second[RT][r], key);                             \
+    best[RT][r] = key_max(best[RT][r], key);                                               \
   }
-  __syncthreads();
+// one MFMA followed by 12 VALU of the previous tile's epilogue, four times
+#define K1_INTERLEAVE()                                                                    \
+  _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                          \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+    __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                                    \
+  }
 
-  for (uint32_t s = 0; s < nsteps; ++s) {
-    const int cur = s & 1;
-    const bool more = (s + 1) < nsteps;
-    int colterm_next[2] = {0, 0};
-    if (more) {
-      const int8_t* src = bbase + (size_t)(s + 1) * 64 * 128;
+  for (uint32_t seg0 = 0; seg0 < b_cols; seg0 += 4096) {
+    const uint32_t seg_cols = (b_cols - seg0) < 4096u ? (b_cols - seg0) : 4096u;
+    const uint32_t nsteps = seg_cols >> 6;
+    const int8_t* bbase = bimg + (size_t)seg0 * 128;
+    const int32_t* rt_b = rt_bimg + seg0;
+    int best[2][16], second[2][16];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) stage[u] = *reinterpret_cast<const v4i*>(src + (size_t)(tid + 256 * u) * 16);
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) colterm_next[ct] = rt_b[(s + 1) * 64 + ct * 32 + l31];
-    }
-
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const int col = ct * 32 + l31;
-      const int kterm = (int)((uint32_t)(colterm[ct] - (1 << 21)) << 8) + (255 - (int)(2 * s + ct));
-      v4i bfrag[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        bfrag[ks] = *reinterpret_cast<const v4i*>(&sB[cur][lds_off(col, ks * 2 + half)]);
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][ks], bfrag[ks], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = (int)((uint32_t)acc[r] << 8) + kterm;
-          second[rt][r] = med3_i32(best[rt][r], second[rt][r], key);
-          best[rt][r] = max(best[rt][r], key);
-        }
+      for (int r = 0; r < 16; ++r) {
+        best[rt][r] = key0[rt][r];
+        second[rt][r] = key0[rt][r];
       }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
-    if (more) {
+    v4i stage[2];
+    int colterm[2];
+    // prologue: tile 0 of the segment
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int q = tid + 256 * u;
-        *reinterpret_cast<v4i*>(&sB[cur ^ 1][lds_off(q >> 3, q & 7)]) = stage[u];
-      }
-      colterm[0] = colterm_next[0];
-      colterm[1] = colterm_next[1];
+    for (int u = 0; u < 2; ++u) stage[u] = *reinterpret_cast<const v4i*>(bbase + (size_t)(tid + 256 * u) * 16);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) colterm[ct] = rt_b[ct * 32 + l31];
+    __syncthreads();  // the previous segment's last tile is no longer being read
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = tid + 256 * u;
+      *reinterpret_cast<v4i*>(&sB[0][lds_off(q >> 3, q & 7)]) = stage[u];
     }
     __syncthreads();
-  }
+    // make sure nothing issued before the loop is still pending at its head: hipcc's waitcnt pass would
+    // otherwise keep a conservative vmcnt wait at the top of every iteration (right behind the prefetch)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // Merge the 32 lanes of each half (they hold the 32 columns of every tile) and let the
-  // lane with l31 == rt*16 + r finish row (rt, r, half).
-  // 32-bit butterfly: (key, source lane) for the best, key only for the second best.  Equal
-  // keys from two lanes are two distinct columns of the same tile: the lower lane (= lower
-  // column) keeps "best", the other one becomes the second best -- exactly sift.cc:126-132.
-  int myB = 0, myS = 0, myL = 0;
+    for (uint32_t s = 0; s < nsteps; ++s) {
+      const int cur = s & 1;
+      const bool more = (s + 1) < nsteps;
+      // keys of this step's two column tiles from the already-resident column terms
+      int kterm0 = (int)((uint32_t)(colterm[0] + (1 << 23) - (1 << 21)) << 7) + (127 - (int)(2 * s));
+      int kterm1 = (int)((uint32_t)(colterm[1] + (1 << 23) - (1 << 21)) << 7) + (127 - (int)(2 * s + 1));
+      // keep each kterm one opaque VGPR: otherwise the compiler re-associates (acc << 7) + a + b into
+      // v_lshlrev + v_add3 (2 VALU per element) instead of one v_lshl_add_u32
+      asm volatile("" : "+v"(kterm0));
+      asm volatile("" : "+v"(kterm1));
+      // prefetch of the next B tile (global -> registers); consumed at the end of the step
+      int colterm_next[2] = {0, 0};
+      if (more) {
+        const int8_t* src = bbase + (size_t)(s + 1) * 64 * 128;
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+        for (int u = 0; u < 2; ++u) stage[u] = *reinterpret_cast<const v4i*>(src + (size_t)(tid + 256 * u) * 16);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int B = best[rt][r], S = second[rt][r], L = l31;
-#pragma unroll
-      for (int m = 1; m < 32; m <<= 1) {
-        const int oB = __shfl_xor(B, m);
-        const int oS = __shfl_xor(S, m);
-        const int oL = __shfl_xor(L, m);
-        const bool take = (oB > B) || (oB == B && oL < L);
-        const int lo = min(B, oB);
-        S = max(lo, max(S, oS));
-        B = take ? oB : B;
-        L = take ? oL : L;
+        for (int ct = 0; ct < 2; ++ct) colterm_next[ct] = rt_b[(s + 1) * 64 + ct * 32 + l31];
       }
-      if (l31 == rt * 16 + r) {
-        myB = B;
-        myS = S;
-        myL = L;
+      v4i bf0[4], bf1[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf0[ks] = *reinterpret_cast<const v4i*>(&sB[cur][lds_off(l31, ks * 2 + half)]);
+        bf1[ks] = *reinterpret_cast<const v4i*>(&sB[cur][lds_off(32 + l31, ks * 2 + half)]);
       }
+      const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      v16i accA = zero16, accB = zero16;
+      // software pipeline over the four 32x32 tiles of the step: the MFMAs of tile i+1 run in the matrix
+      // pipe while the VALU does the top-2 epilogue of tile i
+      K1_MFMA4(accA, 0, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+      K1_MFMA4(accB, 1, bf0);
+      K1_EPILOGUE(accA, 0, kterm0);
+      K1_INTERLEAVE();
+      __builtin_amdgcn_sched_barrier(0);
+      accA = zero16;
+      K1_MFMA4(accA, 0, bf1);
+      K1_EPILOGUE(accB, 1, kterm0);
+      K1_INTERLEAVE();
+      __builtin_amdgcn_sched_barrier(0);
+      accB = zero16;
+      K1_MFMA4(accB, 1, bf1);
+      K1_EPILOGUE(accA, 0, kterm1);
+      K1_INTERLEAVE();
+      __builtin_amdgcn_sched_barrier(0);
+      K1_EPILOGUE(accB, 1, kterm1);
+      __builtin_amdgcn_sched_barrier(0);
+
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int q = tid + 256 * u;
+          *reinterpret_cast<v4i*>(&sB[cur ^ 1][lds_off(q >> 3, q & 7)]) = stage[u];
+        }
+        colterm[0] = colterm_next[0];
+        colterm[1] = colterm_next[1];
+      }
+      __syncthreads();
     }
+
+    // (key, source lane) butterfly over the 32 lanes that hold the 32 columns of every tile.  Equal keys
+    // from two lanes are two distinct columns of the same tile: the lower lane (= lower column) keeps
+    // "best", the other one becomes the second best -- exactly sift.cc:126-132.
+    int myB = 0, myS = 0, myL = 0;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int B = best[rt][r], S = second[rt][r], L = l31;
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) {
+          const int oB = __shfl_xor(B, m);
+          const int oS = __shfl_xor(S, m);
+          const int oL = __shfl_xor(L, m);
+          const bool take = (oB > B) || (oB == B && oL < L);
+          const int lo = min(B, oB);
+          S = max(lo, max(S, oS));
+          B = take ? oB : B;
+          L = take ? oL : L;
+        }
+        if (l31 == rt * 16 + r) {
+          myB = B;
+          myS = S;
+          myL = L;
+        }
+      }
+    {
+      const int rt = l31 >> 4, r = l31 & 15;
+      const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int rti = rt_a[row];
+      const int seg_b = (myB >> 7) - (1 << 23) + rti + (1 << 22);
+      const int seg_s = (myS >> 7) - (1 << 23) + rti + (1 << 22);
+      const uint32_t seg_j = seg0 + (uint32_t)(127 - (myB & 127)) * 32u + (uint32_t)myL;
+      // merge with the earlier segments: earlier columns win ties (ascending strict-`>` scan)
+      const int lo = min(run_b, seg_b);
+      const int new_s = max(lo, max(run_s, seg_s));
+      if (seg_b > run_b) {
+        run_b = seg_b;
+        run_j = seg_j;
+      }
+      run_s = new_s;
+    }
+  }
+#undef K1_MFMA4
+#undef K1_EPILOGUE
+#undef K1_INTERLEAVE
+
   {
     const int rt = l31 >> 4, r = l31 & 15;
     const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    const int rti = rt_a[row];
-    const int best_dot = (myB >> 8) + rti + (1 << 22);
-    const int second_dot = (myS >> 8) + rti + (1 << 22);
-    const uint32_t j = (uint32_t)(255 - (myB & 255)) * 32u + (uint32_t)myL;
+    const int best_dot = run_b;
+    const int second_dot = run_s;
+    const uint32_t j = run_j;
     int res = -1;
     if (best_dot > 0) {  // best_i2 != -1, sift.cc:136
       const float bn = p.lut[min(best_dot, 262144)];

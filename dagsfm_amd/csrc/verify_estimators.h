@@ -62,6 +62,25 @@ DSM_DEV void center_and_normalize(const double* pts, int which, int n, IdxFn idx
   *m02 = -norm_factor * cx;
   *m12 = -norm_factor * cy;
 }
+// Same, by the whole wave (in-order sums through wv_seq_sum); every lane gets the same result.
+template <typename IdxFn>
+DSM_DEV void wv_center_and_normalize(const double* pts, int which, int n, IdxFn idx, int lane, double* nf, double* m02,
+                                     double* m12) {
+  double cx = wv_seq_sum(0.0, n, lane, [pts, which, idx](int i) { return pts[(size_t)idx(i) * 4 + which * 2]; });
+  double cy = wv_seq_sum(0.0, n, lane, [pts, which, idx](int i) { return pts[(size_t)idx(i) * 4 + which * 2 + 1]; });
+  cx /= n;
+  cy /= n;
+  double rms = wv_seq_sum(0.0, n, lane, [pts, which, idx, cx, cy](int i) {
+    const double* p = pts + (size_t)idx(i) * 4 + which * 2;
+    const double dx = p[0] - cx, dy = p[1] - cy;
+    return dx * dx + dy * dy;
+  });
+  rms = sqrt(rms / n);
+  const double norm_factor = sqrt(2.0) / rms;
+  *nf = norm_factor;
+  *m02 = -norm_factor * cx;
+  *m12 = -norm_factor * cy;
+}
 // applies M = [[nf,0,m02],[0,nf,m12],[0,0,1]] exactly like utils.cc:66-84
 DSM_DEV void apply_norm(double nf, double m02, double m12, double p_0, double p_1, double* o0, double* o1) {
   const double np_0 = nf * p_0 + 0.0 * p_1 + m02;

@@ -23,6 +23,7 @@
 // host with the host libm per (num_samples, min_samples, confidence) and looked up here, the
 // same construction as the acos LUT of the matcher.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/dagsfm_mi355x.h"
@@ -32,31 +33,38 @@
 #define BATCH 64
 
 // ------------------------------------------------------------------------------------ shared state
-struct VSmem {
+struct MtState {
   uint32_t mt[624];
-  uint32_t mt_bak[624];
-  int mti, mti_bak;
-  uint32_t calls;          // raw generator calls since the backup
+  int mti;
+  uint32_t calls;  // raw generator calls since the last reset
+};
+
+// LDS of one verification workgroup.  The replay kernels only allocate the prefix up to `gen`, the
+// final kernel up to `mt_bak`; the tail is used by the in-kernel LO-RANSAC (lo_ransac) only.
+struct VSmem {
   WvSvdShared svd;
   double sv[9];
-  int sample[BATCH * 7];
-  uint32_t draws_end[BATCH];
-  int nmodels[BATCH];
-  int counts[BATCH * 10];
   double lo_models[90];
   double cur_model[9];
   double bcast[16];
   int ibcast[8];
   double ws5[FIVEPT_WS];   // LDS workspace of the single-lane 5-point local optimisation
+  MtState gen;
+  uint32_t mt_bak[624];
+  int mti_bak;
+  int sample[BATCH * 7];
+  uint32_t draws_end[BATCH];
+  int nmodels[BATCH];
+  int counts[BATCH * 10];
 };
 
 // ------------------------------------------------------------------------------------ MT19937 (lane 0)
-DSM_DEV void mt_seed(VSmem* s, uint32_t seed) {
+DSM_DEV void mt_seed(MtState* s, uint32_t seed) {
   s->mt[0] = seed;
   for (int i = 1; i < 624; ++i) s->mt[i] = 1812433253u * (s->mt[i - 1] ^ (s->mt[i - 1] >> 30)) + (uint32_t)i;
   s->mti = 624;
 }
-DSM_DEV uint32_t mt_next(VSmem* s) {
+DSM_DEV uint32_t mt_next(MtState* s) {
   if (s->mti >= 624) {
     uint32_t* mt = s->mt;
     int kk;
@@ -82,7 +90,7 @@ DSM_DEV uint32_t mt_next(VSmem* s) {
 }
 // std::uniform_int_distribution<uint32_t>(a, b)(mt19937) of libstdc++ (GCC 11,
 // bits/uniform_int_dist.h:246-317): Lemire's nearly divisionless method on 32-bit draws.
-DSM_DEV uint32_t uniform_u32(VSmem* s, uint32_t a, uint32_t b) {
+DSM_DEV uint32_t uniform_u32(MtState* s, uint32_t a, uint32_t b) {
   const uint64_t urange = (uint64_t)b - (uint64_t)a;
   if (urange == 0xffffffffull) return mt_next(s) + a;
   const uint32_t range = (uint32_t)(urange + 1);
@@ -96,6 +104,36 @@ DSM_DEV uint32_t uniform_u32(VSmem* s, uint32_t a, uint32_t b) {
     }
   }
   return (uint32_t)(product >> 32) + a;
+}
+
+// Per-pair generator record in global memory: [0..623] state, [624] index at the end of the last sampling;
+// [640..1263] + [1264] the snapshot taken before the last sampling round; [1265] draws to skip from the
+// snapshot, [1266] != 0: the next consumer must resume from the snapshot + skip (an early stop left the
+// "current" state ahead of the sequential stream position).
+#define PAIR_STATE_WORDS 1280
+#define PS_SNAP 640
+#define PS_SKIP 1265
+#define PS_USE_SNAP 1266
+
+DSM_DEV void generator_load(MtState* sm, uint32_t* st, int lane) {
+  const bool use_snap = st[PS_USE_SNAP] != 0;
+  const uint32_t* src = use_snap ? st + PS_SNAP : st;
+  for (int i = lane; i < 624; i += 64) sm->mt[i] = src[i];
+  wv_sync();
+  if (lane == 0) {
+    sm->mti = (int)src[624];
+    if (use_snap) {
+      const uint32_t target = st[PS_SKIP];
+      sm->calls = 0;
+      while (sm->calls < target) (void)mt_next(sm);
+      st[PS_USE_SNAP] = 0;
+    }
+  }
+  wv_sync();
+}
+DSM_DEV void generator_store(const MtState* sm, uint32_t* dst, int lane) {
+  for (int i = lane; i < 624; i += 64) dst[i] = sm->mt[i];
+  if (lane == 0) dst[624] = (uint32_t)sm->mti;
 }
 
 // ------------------------------------------------------------------------------------ families
@@ -160,16 +198,17 @@ DSM_DEV int score_model(const PairWork& w, const double* M, double max_residual,
 // InlierSupportMeasurer::Evaluate's residual_sum (support_measurement.cc:43-48): in index order.
 DSM_DEV double ordered_residual_sum(const PairWork& w, double max_residual) {
   wv_sync();
-  if (w.lane == 0) {
-    double s = 0;
-    for (int i = 0; i < w.n; ++i) {
-      const double r = w.resid[i];
+  double s = 0;
+  for (int base = 0; base < w.n; base += 64) {
+    const int i = base + w.lane;
+    const double v = (i < w.n) ? w.resid[i] : 0.0;
+    const int cnt = (w.n - base) < 64 ? (w.n - base) : 64;
+    for (int k = 0; k < cnt; ++k) {
+      const double r = wv_readlane_f64(v, k);
       if (r <= max_residual) s += r;
     }
-    w.sm->bcast[0] = s;
   }
-  wv_sync();
-  return w.sm->bcast[0];
+  return s;
 }
 
 // ordered compaction of the inliers of resid[] into inl[]; returns the count
@@ -196,15 +235,14 @@ DSM_DEV int fam_local(const PairWork& w, int ninl) {
   auto idx = [inl](int i) { return inl[i]; };
   if (FAM == FAM_T) {
     // TranslationTransformEstimator<2>::Estimate, translation_transform.h:81-104
+    const double* tpts = w.pts;
+    double sx = wv_seq_sum(0.0, ninl, lane, [tpts, inl](int i) { return tpts[(size_t)inl[i] * 4 + 0]; });
+    double sy = wv_seq_sum(0.0, ninl, lane, [tpts, inl](int i) { return tpts[(size_t)inl[i] * 4 + 1]; });
+    double dx = wv_seq_sum(0.0, ninl, lane, [tpts, inl](int i) { return tpts[(size_t)inl[i] * 4 + 2]; });
+    double dy = wv_seq_sum(0.0, ninl, lane, [tpts, inl](int i) { return tpts[(size_t)inl[i] * 4 + 3]; });
+    sx /= ninl; sy /= ninl;
+    dx /= ninl; dy /= ninl;
     if (lane == 0) {
-      double sx = 0, sy = 0, dx = 0, dy = 0;
-      for (int i = 0; i < ninl; ++i) {
-        const double* p = w.pts + (size_t)inl[i] * 4;
-        sx += p[0]; sy += p[1];
-        dx += p[2]; dy += p[3];
-      }
-      sx /= ninl; sy /= ninl;
-      dx /= ninl; dy /= ninl;
       sm->lo_models[0] = dx - sx;
       sm->lo_models[1] = dy - sy;
       for (int k = 2; k < 9; ++k) sm->lo_models[k] = 0.0;
@@ -229,19 +267,17 @@ DSM_DEV int fam_local(const PairWork& w, int ninl) {
       double Eb[36];
       for (int r = 0; r < 9; ++r)
         for (int c = 0; c < 4; ++c) Eb[r * 4 + c] = sm->svd.V[(5 + c) * 9 + r];
+      LSEC_BEGIN();
       sm->ibcast[0] = five_point_finish_t<true>(Eb, sm->lo_models, sm->ws5);
+      LSEC_END(7);
     }
     wv_sync();
     return sm->ibcast[0];
   }
   // F (8-point) and H share the normalisation prologue.
-  if (lane == 0) {
-    center_and_normalize(w.pts, 0, ninl, idx, &sm->bcast[0], &sm->bcast[1], &sm->bcast[2]);
-    center_and_normalize(w.pts, 1, ninl, idx, &sm->bcast[3], &sm->bcast[4], &sm->bcast[5]);
-  }
-  wv_sync();
-  double n1[3] = {sm->bcast[0], sm->bcast[1], sm->bcast[2]};
-  double n2[3] = {sm->bcast[3], sm->bcast[4], sm->bcast[5]};
+  double n1[3], n2[3];
+  wv_center_and_normalize(w.pts, 0, ninl, idx, lane, &n1[0], &n1[1], &n1[2]);
+  wv_center_and_normalize(w.pts, 1, ninl, idx, lane, &n2[0], &n2[1], &n2[2]);
   if (FAM == FAM_F) {
     // FundamentalMatrixEightPointEstimator::Estimate, fundamental_matrix.cc:150-192
     const int m = ninl;
@@ -261,9 +297,11 @@ DSM_DEV int fam_local(const PairWork& w, int ninl) {
     wv_sync();
     wv_svd_V_mx9(C, C + (size_t)9 * m, m, &sm->svd, sm->sv, lane);
     if (lane == 0) {
+      LSEC_BEGIN();
       double nv[9];
       for (int k = 0; k < 9; ++k) nv[k] = sm->svd.V[8 * 9 + k];
       eight_point_finish(nv, n1, n2, sm->lo_models);
+      LSEC_END(6);
     }
     wv_sync();
     return 1;
@@ -335,20 +373,20 @@ DSM_DEV void lo_ransac(const PairWork& w, const RansacOpt& opt, uint32_t* sidx, 
   while (trial < max_num_trials && !abort) {
     const int nb = (int)((max_num_trials - trial) < (uint32_t)BATCH ? (max_num_trials - trial) : (uint32_t)BATCH);
     // ---- backup of the generator, then nb samples by lane 0 (RandomSampler::Sample)
-    for (int i = lane; i < 624; i += 64) sm->mt_bak[i] = sm->mt[i];
+    for (int i = lane; i < 624; i += 64) sm->mt_bak[i] = sm->gen.mt[i];
     if (lane == 0) {
-      sm->mti_bak = sm->mti;
-      sm->calls = 0;
+      sm->mti_bak = sm->gen.mti;
+      sm->gen.calls = 0;
       const uint32_t last_idx = (uint32_t)(n - 1);
       for (int t = 0; t < nb; ++t) {
         for (uint32_t i = 0; i < (uint32_t)F::K; ++i) {
-          const uint32_t j = uniform_u32(sm, i, last_idx);
+          const uint32_t j = uniform_u32(&sm->gen, i, last_idx);
           const uint32_t a = sidx[i];
           sidx[i] = sidx[j];
           sidx[j] = a;
         }
         for (int i = 0; i < F::K; ++i) sm->sample[t * 7 + i] = (int)sidx[i];
-        sm->draws_end[t] = sm->calls;
+        sm->draws_end[t] = sm->gen.calls;
       }
     }
     wv_sync();
@@ -430,13 +468,13 @@ DSM_DEV void lo_ransac(const PairWork& w, const RansacOpt& opt, uint32_t* sidx, 
       // rewind the generator to just after the sample of trial t_stop
       if (t_stop != nb - 1) {
         wv_sync();
-        for (int i = lane; i < 624; i += 64) sm->mt[i] = sm->mt_bak[i];
+        for (int i = lane; i < 624; i += 64) sm->gen.mt[i] = sm->mt_bak[i];
         wv_sync();
         if (lane == 0) {
-          sm->mti = sm->mti_bak;
+          sm->gen.mti = sm->mti_bak;
           const uint32_t target = sm->draws_end[t_stop];
-          sm->calls = 0;
-          while (sm->calls < target) (void)mt_next(sm);
+          sm->gen.calls = 0;
+          while (sm->gen.calls < target) (void)mt_next(&sm->gen);
         }
         wv_sync();
       }
@@ -736,9 +774,10 @@ DSM_DEV WgScratch wg_scratch(const VerifyParams& p) {
 }
 
 __global__ __launch_bounds__(64) void k_verify_prep(const VerifyParams p) {
-  __shared__ VSmem sm;
+  __shared__ MtState sm;
   const int lane = threadIdx.x;
-  for (uint32_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
+  for (uint32_t pl = blockIdx.x; pl < p.n_chunk; pl += gridDim.x) {
+    const uint32_t pi = p.pair0 + pl;
     const uint32_t im1 = p.pairs[2 * pi], im2 = p.pairs[2 * pi + 1];
     const uint64_t moff = p.match_off[pi];
     const int n = (int)(p.match_off[pi + 1] - moff);
@@ -765,9 +804,27 @@ __global__ __launch_bounds__(64) void k_verify_prep(const VerifyParams p) {
     wv_sync();
     if (lane == 0) mt_seed(&sm, p.seeds[pi]);
     wv_sync();
-    uint32_t* st = p.pair_state + (size_t)pi * 640;
-    for (int i = lane; i < 624; i += 64) st[i] = sm.mt[i];
-    if (lane == 0) st[624] = (uint32_t)sm.mti;
+    uint32_t* st = p.pair_state + (size_t)pi * PAIR_STATE_WORDS;
+    generator_store(&sm, st, lane);
+    if (lane == 0) {
+      st[PS_USE_SNAP] = 0;
+      st[PS_SKIP] = 0;
+    }
+    if (p.fam_state != nullptr && lane < 3) {  // phase-split pipeline: initial family states
+      const int K[3] = {5, 7, 4};
+      FamState fs;
+      fs.rep.success = false;
+      fs.rep.num_trials = 0;
+      fs.rep.num_models = 0;
+      fs.rep.num_inliers = 0;
+      fs.rep.residual_sum = DBL_MAX;
+      for (int k = 0; k < 9; ++k) fs.rep.model[k] = 0.0;
+      fs.dyn_max = p.max_trials[lane];
+      fs.active = (n >= K[lane] && (lane != FAM_E || calibrated) && p.max_trials[lane] > 0) ? 1u : 0u;
+      fs.rounds = 0;
+      fs.nb = 0;
+      p.fam_state[(size_t)pi * 3 + lane] = fs;
+    }
     wv_sync();
   }
 }
@@ -779,7 +836,8 @@ __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_ransac(const Ver
   uint32_t* sidx = reinterpret_cast<uint32_t*>(smem_raw + ((sizeof(VSmem) + 15) / 16) * 16);
   const int lane = threadIdx.x;
   const WgScratch ws = wg_scratch(p);
-  for (uint32_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
+  for (uint32_t pl = blockIdx.x; pl < p.n_chunk; pl += gridDim.x) {
+    const uint32_t pi = p.pair0 + pl;
     wv_sync();
     const uint64_t moff = p.match_off[pi];
     const int n = (int)(p.match_off[pi + 1] - moff);
@@ -789,10 +847,8 @@ __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_ransac(const Ver
     const dsm_camera& cam2 = p.cams[im2];
     const bool calibrated = cam1.has_prior_focal_length && cam2.has_prior_focal_length;
     if (FAM == FAM_E && !calibrated) continue;
-    uint32_t* st = p.pair_state + (size_t)pi * 640;
-    for (int i = lane; i < 624; i += 64) sm->mt[i] = st[i];
-    if (lane == 0) sm->mti = (int)st[624];
-    wv_sync();
+    uint32_t* st = p.pair_state + (size_t)pi * PAIR_STATE_WORDS;
+    generator_load(&sm->gen, st, lane);
     PairWork w;
     w.n = n;
     w.resid = ws.resid;
@@ -817,8 +873,7 @@ __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_ransac(const Ver
       for (int i = lane; i < n; i += 64) mask[i] = ws.resid[i] <= mr;
     if (lane == 0) p.reports[(size_t)pi * 3 + FAM] = rep;
     wv_sync();
-    for (int i = lane; i < 624; i += 64) st[i] = sm->mt[i];
-    if (lane == 0) st[624] = (uint32_t)sm->mti;
+    generator_store(&sm->gen, st, lane);
   }
 }
 
@@ -834,7 +889,8 @@ __global__ __launch_bounds__(64, 2) void k_verify_final(const VerifyParams p) {
   double* pts3d_a = ws.pts3d_a;
   double* pts3d_b = ws.pts3d_b;
 
-  for (uint32_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
+  for (uint32_t pl = blockIdx.x; pl < p.n_chunk; pl += gridDim.x) {
+    const uint32_t pi = p.pair0 + pl;
     wv_sync();
     const uint32_t im1 = p.pairs[2 * pi], im2 = p.pairs[2 * pi + 1];
     const uint64_t moff = p.match_off[pi];
@@ -883,12 +939,7 @@ __global__ __launch_bounds__(64, 2) void k_verify_final(const VerifyParams p) {
       ntr[2] = H_rep.num_trials;
       nmo[2] = H_rep.num_models;
       // the generator continues where the H family stopped (watermark RANSAC, :547-549)
-      {
-        const uint32_t* st = p.pair_state + (size_t)pi * 640;
-        for (int i = lane; i < 624; i += 64) sm->mt[i] = st[i];
-        if (lane == 0) sm->mti = (int)st[624];
-        wv_sync();
-      }
+      generator_load(&sm->gen, p.pair_state + (size_t)pi * PAIR_STATE_WORDS, lane);
 
       PairWork w;
       w.n = n;
@@ -1232,6 +1283,365 @@ void launch_verify(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
   hipLaunchKernelGGL(k_verify_final, dim3(n_blocks), dim3(64), smem, st, p);
 }
 
+// ------------------------------------------------------------------------------------ phase-split pipeline
+// Same LO-RANSAC, different schedule: the sequential part of loransac.h:91-233 is only (a) drawing the
+// samples and (b) comparing supports in trial order; solving and scoring the speculated trials is flat
+// data-parallel work.  Per family and round:
+//   k_sample        wave per pair, lane 0 draws `batch` minimal samples (light kernel, high occupancy)
+//   k_solve_score   lane per hypothesis over ALL pairs x trials: minimal solve + inlier count of its models
+//   k_replay        wave per pair: scans the counts in trial order (ballot-skipping the trials that can change
+//                   nothing), re-scores candidates with the in-order residual_sum, runs the local
+//                   optimisation, applies the dynamic stop, rewinds the generator on an early stop
+// The host repeats the round while any pair is still active (active_count).
+uint32_t vp_batch(int fam, uint32_t max_trials) {
+  if (fam == FAM_E) return 64;
+  if (fam == FAM_F) return 128;
+  const uint32_t b = ((max_trials + 63u) / 64u) * 64u;  // H runs to its cap on non-planar scenes
+  return b < 64u ? 64u : (b > 2048u ? 2048u : b);
+}
+uint32_t vp_maxm(int fam) { return fam == FAM_E ? 10u : (fam == FAM_F ? 3u : 1u); }
+
+#define SAMPLER_PREFIX (((sizeof(MtState) + 15) / 16) * 16)
+
+template <int FAM>
+__global__ __launch_bounds__(64) void k_sample(const VerifyParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  MtState* gen = reinterpret_cast<MtState*>(smem_raw);
+  uint32_t* sidx = reinterpret_cast<uint32_t*>(smem_raw + SAMPLER_PREFIX);
+  typedef Fam<FAM> F;
+  const int lane = threadIdx.x;
+  for (uint32_t pl = blockIdx.x; pl < p.n_chunk; pl += gridDim.x) {
+    const uint32_t pi = p.pair0 + pl;
+    FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
+    wv_sync();
+    if (!fs->active) continue;
+    const uint64_t moff = p.match_off[pi];
+    const int n = (int)(p.match_off[pi + 1] - moff);
+    uint32_t* st = p.pair_state + (size_t)pi * PAIR_STATE_WORDS;
+    generator_load(gen, st, lane);
+    uint32_t* sg = p.sidx_g + moff;
+    if (fs->rounds == 0) {
+      for (int i = lane; i < n; i += 64) sidx[i] = (uint32_t)i;  // sampler.Initialize
+    } else {
+      for (int i = lane; i < n; i += 64) sidx[i] = sg[i];
+    }
+    const uint32_t remaining = p.max_trials[FAM] - fs->rep.num_trials;
+    const int nb = (int)(remaining < p.batch ? remaining : p.batch);
+    generator_store(gen, st + PS_SNAP, lane);  // snapshot before this round's draws
+    wv_sync();
+    if (lane == 0) {
+      gen->calls = 0;
+      const uint32_t last_idx = (uint32_t)(n - 1);
+      uint32_t* smp = p.samples + ((size_t)pl * p.batch) * 7;
+      uint32_t* de = p.draws_end + (size_t)pl * p.batch;
+      for (int t = 0; t < nb; ++t) {
+        for (uint32_t i = 0; i < (uint32_t)F::K; ++i) {
+          const uint32_t j = uniform_u32(gen, i, last_idx);
+          const uint32_t a = sidx[i];
+          sidx[i] = sidx[j];
+          sidx[j] = a;
+        }
+        for (int i = 0; i < F::K; ++i) smp[t * 7 + i] = sidx[i];
+        de[t] = gen->calls;
+      }
+      fs->nb = (uint32_t)nb;
+    }
+    wv_sync();
+    generator_store(gen, st, lane);
+    for (int i = lane; i < n; i += 64) sg[i] = sidx[i];
+  }
+}
+
+// lane per hypothesis: block = 64 consecutive trials of one pair; the pair's correspondences are staged in
+// LDS when they fit (VP_LDS_PTS), every lane then scores its own models over all of them (broadcast reads).
+#define VP_LDS_PTS 1536
+template <int FAM>
+__global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_solve_score(const VerifyParams p) {
+  typedef Fam<FAM> F;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* spts = reinterpret_cast<double*>(smem_raw);  // min(n_max, VP_LDS_PTS) x 4 doubles
+  const uint32_t pl = blockIdx.x;
+  const uint32_t pi = p.pair0 + pl;
+  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
+  if (!fs->active) return;
+  const int lane = threadIdx.x;
+  const int t = blockIdx.y * 64 + lane;
+  const int nb = (int)fs->nb;
+  if ((int)(blockIdx.y * 64) >= nb) return;
+  const uint64_t moff = p.match_off[pi];
+  const int n = (int)(p.match_off[pi + 1] - moff);
+  const double* gpts = (FAM == FAM_E ? p.pts_norm : p.pts_px) + 4 * moff;
+  const bool in_lds = n <= VP_LDS_PTS;
+  if (in_lds) {
+    for (int e = lane; e < 4 * n; e += 64) spts[e] = gpts[e];
+    __syncthreads();
+  }
+  const double* pts = in_lds ? spts : gpts;
+  double max_error = p.opt.max_error;
+  if (FAM == FAM_E) {
+    const dsm_camera& cam1 = p.cams[p.pairs[2 * pi]];
+    const dsm_camera& cam2 = p.cams[p.pairs[2 * pi + 1]];
+    max_error = (image_to_world_threshold(cam1, p.opt.max_error) + image_to_world_threshold(cam2, p.opt.max_error)) / 2;
+  }
+  const double max_residual = max_error * max_error;
+  int nm = 0;
+  double mloc[F::MAXM * 9];
+  if (t < nb) {
+    const uint32_t* smp = p.samples + ((size_t)pl * p.batch + t) * 7;
+    double xs[F::K * 4];
+    for (int i = 0; i < F::K; ++i) {
+      const double* q = pts + (size_t)smp[i] * 4;
+      xs[i * 4 + 0] = q[0]; xs[i * 4 + 1] = q[1]; xs[i * 4 + 2] = q[2]; xs[i * 4 + 3] = q[3];
+    }
+    nm = fam_minimal<FAM>(xs, mloc);
+    p.nmodels[(size_t)pl * p.batch + t] = nm;
+  }
+  double* gm = p.models + ((size_t)pl * p.batch + (size_t)(t < nb ? t : 0)) * F::MAXM * 9;
+  int32_t* gc = p.counts + ((size_t)pl * p.batch + (size_t)(t < nb ? t : 0)) * F::MAXM;
+  for (int m = 0; m < nm; ++m) {
+    const double* M = mloc + m * 9;
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) cnt += (fam_residual<FAM>(M, pts + (size_t)i * 4) <= max_residual) ? 1 : 0;
+    gc[m] = cnt;
+    for (int k = 0; k < 9; ++k) gm[m * 9 + k] = M[k];
+  }
+}
+
+#ifdef DSM_PROFILE_SECTIONS
+#define TSEC_BEGIN() const long long t__0 = clock64()
+#define TSEC_END(sec) do { if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(p_dbg) + (sec), (unsigned long long)(clock64() - t__0)); } while (0)
+#else
+#define TSEC_BEGIN() do {} while (0)
+#define TSEC_END(sec) do {} while (0)
+#endif
+
+template <int FAM>
+__global__ __launch_bounds__(64, 4) void k_replay(const VerifyParams p) {
+  uint32_t* p_dbg = p.active_count + 8;
+  (void)p_dbg;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  VSmem* sm = reinterpret_cast<VSmem*>(smem_raw);
+  typedef Fam<FAM> F;
+  const int lane = threadIdx.x;
+  const WgScratch ws = wg_scratch(p);
+  for (uint32_t pl = blockIdx.x; pl < p.n_chunk; pl += gridDim.x) {
+    const uint32_t pi = p.pair0 + pl;
+    FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
+    wv_sync();
+    if (!fs->active) continue;
+    const uint64_t moff = p.match_off[pi];
+    const int n = (int)(p.match_off[pi + 1] - moff);
+    const dsm_camera& cam1 = p.cams[p.pairs[2 * pi]];
+    const dsm_camera& cam2 = p.cams[p.pairs[2 * pi + 1]];
+    PairWork w;
+    w.n = n;
+    w.resid = ws.resid;
+    w.inl = ws.inl;
+    w.tall = ws.tall;
+    w.models = nullptr;
+    w.sm = sm;
+    w.lane = lane;
+    w.pts = (FAM == FAM_E ? p.pts_norm : p.pts_px) + 4 * moff;
+    w.nt_table = p.nt_table + p.nt_off[n] + (size_t)FAM * (size_t)(n + 1);
+    double max_error = p.opt.max_error;
+    if (FAM == FAM_E)
+      max_error = (image_to_world_threshold(cam1, p.opt.max_error) + image_to_world_threshold(cam2, p.opt.max_error)) / 2;
+    const double max_residual = max_error * max_error;
+    const uint32_t min_trials = (uint32_t)p.opt.min_num_trials;
+    const uint32_t max_num_trials = p.max_trials[FAM];
+
+    uint32_t best_n = fs->rep.num_inliers;
+    double best_sum = fs->rep.residual_sum;
+    double best_model[9];
+    for (int k = 0; k < 9; ++k) best_model[k] = fs->rep.model[k];
+    uint32_t dyn_max = fs->dyn_max;
+    uint32_t num_models = fs->rep.num_models;
+    const uint32_t T0 = fs->rep.num_trials;
+    const int nb = (int)fs->nb;
+    const int32_t* nmod = p.nmodels + (size_t)pl * p.batch;
+    const int32_t* cnts = p.counts + (size_t)pl * p.batch * F::MAXM;
+    const double* mods = p.models + (size_t)pl * p.batch * F::MAXM * 9;
+
+    bool abort = false;
+    int t = 0;
+    int t_stop = nb - 1;
+    uint32_t trial_abs = T0;
+    const long long t_pair0 = clock64();
+    (void)t_pair0;
+    while (t < nb) {
+      // ---- skip ahead to the next trial that can change anything
+      const int tt = t + lane;
+      int nm_l = 0;
+      bool ev = false;
+      if (tt < nb) {
+        nm_l = nmod[tt];
+        int mx = -1;
+        for (int m = 0; m < nm_l; ++m) {
+          const int c = cnts[(size_t)tt * F::MAXM + m];
+          mx = c > mx ? c : mx;
+        }
+        const uint32_t thr = dyn_max > min_trials ? dyn_max : min_trials;
+        ev = nm_l > 0 && ((uint32_t)mx >= best_n || (T0 + (uint32_t)tt) >= thr);
+      }
+      const unsigned long long bal = __ballot(ev);
+      const int f = bal ? (__ffsll((long long)bal) - 1) : 64;
+      // models of the skipped trials are still "scored" models (bookkeeping only)
+      int skipped = (lane < f) ? nm_l : 0;
+      for (int o = 32; o > 0; o >>= 1) skipped += __shfl_xor(skipped, o);
+      num_models += (uint32_t)skipped;
+      if (!bal) {
+        t += 64;
+        continue;
+      }
+      t += f;
+      trial_abs = T0 + (uint32_t)t;
+      // ---- exact sequential processing of trial t (loransac.h:142-198)
+      const int nm = nmod[t];
+      for (int m = 0; m < nm; ++m) {
+        num_models += 1;
+        const uint32_t cnt = (uint32_t)cnts[(size_t)t * F::MAXM + m];
+        const double* M = mods + ((size_t)t * F::MAXM + m) * 9;
+        if (cnt >= best_n) {
+          if (lane == 0) atomicAdd(p.active_count + 1 + FAM * 2, 1u);
+          double sum;
+          {
+            TSEC_BEGIN();
+            score_model<FAM>(w, M, max_residual, true);
+            sum = ordered_residual_sum(w, max_residual);
+            TSEC_END(0);
+          }
+          if (cnt > best_n || (cnt == best_n && sum < best_sum)) {
+            best_n = cnt;
+            best_sum = sum;
+            for (int k = 0; k < 9; ++k) best_model[k] = M[k];
+            if (cnt > (uint32_t)F::K && cnt >= (uint32_t)F::LO_MIN) {
+              if (lane == 0) atomicAdd(p.active_count + 2 + FAM * 2, 1u);
+              int ninl, nlo;
+              {
+                TSEC_BEGIN();
+                ninl = compact_inliers(w, max_residual);
+                nlo = fam_local<FAM>(w, ninl);
+                TSEC_END(1);
+              }
+              for (int l = 0; l < nlo; ++l) {
+                num_models += 1;
+                const uint32_t lc = (uint32_t)score_model<FAM>(w, sm->lo_models + l * 9, max_residual, true);
+                const double lsum = ordered_residual_sum(w, max_residual);
+                if (lc > best_n || (lc == best_n && lsum < best_sum)) {
+                  best_n = lc;
+                  best_sum = lsum;
+                  for (int k = 0; k < 9; ++k) best_model[k] = sm->lo_models[l * 9 + k];
+                }
+              }
+            }
+            dyn_max = w.nt_table[best_n];
+          }
+        }
+        if (trial_abs >= dyn_max && trial_abs >= min_trials) {
+          abort = true;
+          break;
+        }
+      }
+      if (abort) {
+        t_stop = t;
+        break;
+      }
+      t += 1;
+    }
+
+#ifdef DSM_PROFILE_SECTIONS
+    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(p_dbg) + 2, (unsigned long long)(clock64() - t_pair0));
+#endif
+    uint32_t trials_done;
+    bool finished;
+    uint32_t* st = p.pair_state + (size_t)pi * PAIR_STATE_WORDS;
+    if (abort) {
+      trials_done = (trial_abs + 1 < max_num_trials) ? trial_abs + 2 : trial_abs + 1;  // loransac.h:129-134
+      finished = true;
+      if (lane == 0) {
+        if (t_stop != nb - 1) {  // later samples of this round were speculation: resume from the snapshot
+          st[PS_SKIP] = p.draws_end[(size_t)pl * p.batch + t_stop];
+          st[PS_USE_SNAP] = 1;
+        }
+      }
+    } else {
+      trials_done = T0 + (uint32_t)nb;
+      finished = trials_done >= max_num_trials;
+    }
+    if (lane == 0) {
+      fs->rep.num_trials = trials_done;
+      fs->rep.num_models = num_models;
+      fs->rep.num_inliers = best_n;
+      fs->rep.residual_sum = best_sum;
+      for (int k = 0; k < 9; ++k) fs->rep.model[k] = best_model[k];
+      fs->dyn_max = dyn_max;
+      fs->rounds += 1;
+      fs->active = finished ? 0u : 1u;
+      if (!finished) atomicAdd(p.active_count, 1u);
+    }
+    if (finished) {
+      const bool success = best_n >= (uint32_t)F::K;
+      if (success) {
+        score_model<FAM>(w, best_model, max_residual, true);
+        wv_sync();
+        unsigned char* mask = p.masks + (size_t)FAM * p.mask_stride + moff;
+        for (int i = lane; i < n; i += 64) mask[i] = ws.resid[i] <= max_residual;
+      }
+      if (lane == 0) {
+        RansacReport rep = fs->rep;
+        rep.success = success;
+        rep.num_trials = trials_done;
+        rep.num_models = num_models;
+        rep.num_inliers = best_n;
+        rep.residual_sum = best_sum;
+        for (int k = 0; k < 9; ++k) rep.model[k] = best_model[k];
+        p.reports[(size_t)pi * 3 + FAM] = rep;
+      }
+    }
+  }
+}
+
+void launch_vp_prep(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
+  if (!p.n_pairs || !n_blocks) return;
+  hipLaunchKernelGGL(k_verify_prep, dim3(n_blocks), dim3(64), 0, st, p);
+}
+void launch_vp_sample(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st) {
+  if (!p.n_chunk || !n_blocks) return;
+  const size_t smem = SAMPLER_PREFIX + (size_t)(p.n_max > 0 ? p.n_max : 1) * 4;
+  if (fam == FAM_E) hipLaunchKernelGGL(k_sample<FAM_E>, dim3(n_blocks), dim3(64), smem, st, p);
+  if (fam == FAM_F) hipLaunchKernelGGL(k_sample<FAM_F>, dim3(n_blocks), dim3(64), smem, st, p);
+  if (fam == FAM_H) hipLaunchKernelGGL(k_sample<FAM_H>, dim3(n_blocks), dim3(64), smem, st, p);
+}
+void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
+  if (!p.n_chunk) return;
+  const dim3 grid(p.n_chunk, (p.batch + 63) / 64);
+  const size_t smem = (size_t)(p.n_max < VP_LDS_PTS ? (p.n_max > 0 ? p.n_max : 1) : VP_LDS_PTS) * 32;
+  if (fam == FAM_E) hipLaunchKernelGGL(k_solve_score<FAM_E>, grid, dim3(64), smem, st, p);
+  if (fam == FAM_F) hipLaunchKernelGGL(k_solve_score<FAM_F>, grid, dim3(64), smem, st, p);
+  if (fam == FAM_H) hipLaunchKernelGGL(k_solve_score<FAM_H>, grid, dim3(64), smem, st, p);
+}
+void launch_vp_replay(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st) {
+  if (!p.n_chunk || !n_blocks) return;
+  const size_t smem = ((offsetof(VSmem, gen) + 15) / 16) * 16;  // the replay needs no generator / sampler state
+  if (fam == FAM_E) hipLaunchKernelGGL(k_replay<FAM_E>, dim3(n_blocks), dim3(64), smem, st, p);
+  if (fam == FAM_F) hipLaunchKernelGGL(k_replay<FAM_F>, dim3(n_blocks), dim3(64), smem, st, p);
+  if (fam == FAM_H) hipLaunchKernelGGL(k_replay<FAM_H>, dim3(n_blocks), dim3(64), smem, st, p);
+}
+void launch_vp_final(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
+  if (!p.n_pairs || !n_blocks) return;
+  hipLaunchKernelGGL(k_verify_final, dim3(n_blocks), dim3(64), verify_smem_bytes(p.n_max), st, p);
+}
+
+void debug_read_prof(unsigned long long* out16) {
+#ifdef DSM_PROFILE_SECTIONS
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dsm_prof), 16 * sizeof(unsigned long long));
+  unsigned long long zero[16] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dsm_prof), zero, sizeof(zero));
+#else
+  for (int i = 0; i < 16; ++i) out16[i] = 0;
+#endif
+}
+
 // Compaction of the per-pair inlier matches (stored at the pair's match offset) into list order.
 __global__ __launch_bounds__(64) void k_compact_inliers(const uint64_t* match_off, const uint64_t* inl_off,
                                                         const uint32_t* inl_counts, const uint32_t* src, uint32_t* dst,
@@ -1252,7 +1662,7 @@ void launch_compact_inliers(const uint64_t* match_off, const uint64_t* inl_off, 
 // ------------------------------------------------------------------------------------ debug hooks
 // Sample sequence of the device sampler (MT19937 + Lemire + partial Fisher-Yates) for parity tests.
 __global__ void k_debug_samples(uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out, uint32_t* idx) {
-  __shared__ VSmem sm;
+  __shared__ MtState sm;
   if (threadIdx.x == 0) {
     mt_seed(&sm, seed);
     sm.calls = 0;

@@ -668,6 +668,31 @@ DSM_DEV void m3_inverse(const double* M, double* R) {
 // ====================================================================== per-wave routines
 // One-wave workgroups (64 threads): __syncthreads() orders LDS/global traffic between phases.
 
+
+// ---- exact in-order reductions by the whole wave ------------------------------------------------
+// The sum must be accumulated in index order (one rounding per addition, like the sequential CPU
+// loop).  The 64 lanes fetch 64 consecutive operands with ONE coalesced load, then every lane walks
+// them in order through v_readlane (wave-uniform, a few cycles each) -- no serial chain of memory
+// round trips.  All lanes end with the same bit-identical sum.
+DSM_DEV double wv_readlane_f64(double v, int i) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffull), i);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), i);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// s = (((init + f(0)) + f(1)) + ...), f(i) supplied per lane for index base+lane by `load(i)`.
+template <typename LoadFn>
+DSM_DEV double wv_seq_sum(double init, int n, int lane, LoadFn load) {
+  double s = init;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const double v = (i < n) ? load(i) : 0.0;
+    const int cnt = (n - base) < 64 ? (n - base) : 64;
+    for (int k = 0; k < cnt; ++k) s += wv_readlane_f64(v, k);
+  }
+  return s;
+}
+
 struct WvSvdShared {
   double W[81];            // working square matrix, column-major ld = dsz
   double V[81];            // 9 x 9, column-major ld 9
@@ -685,13 +710,14 @@ DSM_DEV void wv_sync() { __syncthreads(); }
 // global/LDS memory, by the whole wave.  Leaves R + essential parts in M, hco/perm in sh.
 DSM_DEV void wv_colpiv_qr(double* M, int rows, int cols, WvSvdShared* sh, int lane) {
   const int size = rows < cols ? rows : cols;
-  if (lane < cols) {
-    double s = 0.0;
-    const double* col = M + (size_t)lane * rows;
-    for (int i = 0; i < rows; ++i) s += col[i] * col[i];
-    sh->norms_d[lane] = sqrt(s);
-    sh->norms_u[lane] = sh->norms_d[lane];
-    sh->perm[lane] = lane;
+  for (int c = 0; c < cols; ++c) {
+    const double* col = M + (size_t)c * rows;
+    const double s = wv_seq_sum(0.0, rows, lane, [col](int i) { return col[i] * col[i]; });
+    if (lane == 0) {
+      sh->norms_d[c] = sqrt(s);
+      sh->norms_u[c] = sh->norms_d[c];
+      sh->perm[c] = c;
+    }
   }
   wv_sync();
   const double norm_downdate_threshold = sqrt(DBL_EPSILON);
@@ -730,9 +756,8 @@ DSM_DEV void wv_colpiv_qr(double* M, int rows, int cols, WvSvdShared* sh, int la
     // makeHouseholder on column k, rows k..rows-1
     double* x = M + (size_t)k * rows + k;
     const int n = rows - k;
+    const double tail_sq = wv_seq_sum(0.0, n - 1, lane, [x](int i) { return x[i + 1] * x[i + 1]; });
     if (lane == 0) {
-      double tail_sq = 0.0;
-      for (int i = 1; i < n; ++i) tail_sq += x[i] * x[i];
       const double c0 = x[0];
       if (tail_sq <= DBL_MIN) {
         sh->scal[0] = 0.0;   // tau
@@ -764,12 +789,11 @@ DSM_DEV void wv_colpiv_qr(double* M, int rows, int cols, WvSvdShared* sh, int la
       if (n == 1) {
         if (lane < nc) M[(size_t)(k + 1 + lane) * rows + k] *= (1.0 - tau);
       } else if (tau != 0.0) {
-        if (lane < nc) {
-          const double* col = M + (size_t)(k + 1 + lane) * rows + k;
-          double tmp = 0.0;
-          for (int i = 1; i < n; ++i) tmp += ess[i - 1] * col[i];
+        for (int c = 0; c < nc; ++c) {
+          const double* col = M + (size_t)(k + 1 + c) * rows + k;
+          double tmp = wv_seq_sum(0.0, n - 1, lane, [ess, col](int i) { return ess[i] * col[i + 1]; });
           tmp += col[0];
-          sh->colbuf[lane] = tmp;
+          if (lane == 0) sh->colbuf[c] = tmp;
         }
         wv_sync();
         for (int e = lane; e < nc * n; e += 64) {
@@ -783,23 +807,26 @@ DSM_DEV void wv_colpiv_qr(double* M, int rows, int cols, WvSvdShared* sh, int la
         }
       }
       wv_sync();
-      // norm downdating, one lane per column
-      if (lane < nc) {
-        const int j = k + 1 + lane;
-        if (sh->norms_u[j] != 0.0) {
-          double temp = fabs(M[(size_t)j * rows + k]) / sh->norms_u[j];
+      // norm downdating (uniform over the wave; the rare re-computation is an in-order wave sum)
+      for (int c = 0; c < nc; ++c) {
+        const int j = k + 1 + c;
+        const double nu = sh->norms_u[j];
+        if (nu != 0.0) {
+          double temp = fabs(M[(size_t)j * rows + k]) / nu;
           temp = (1.0 + temp) * (1.0 - temp);
           temp = temp < 0.0 ? 0.0 : temp;
-          const double ratio = sh->norms_u[j] / sh->norms_d[j];
+          const double ratio = nu / sh->norms_d[j];
           const double temp2 = temp * (ratio * ratio);
+          wv_sync();
           if (temp2 <= norm_downdate_threshold) {
-            double s = 0.0;
-            const double* col = M + (size_t)j * rows;
-            for (int i = k + 1; i < rows; ++i) s += col[i] * col[i];
-            sh->norms_d[j] = sqrt(s);
-            sh->norms_u[j] = sh->norms_d[j];
-          } else {
-            sh->norms_u[j] *= sqrt(temp);
+            const double* col = M + (size_t)j * rows + (k + 1);
+            const double ss = wv_seq_sum(0.0, rows - k - 1, lane, [col](int i) { return col[i] * col[i]; });
+            if (lane == 0) {
+              sh->norms_d[j] = sqrt(ss);
+              sh->norms_u[j] = sh->norms_d[j];
+            }
+          } else if (lane == 0) {
+            sh->norms_u[j] = nu * sqrt(temp);
           }
         }
       }
@@ -889,6 +916,14 @@ DSM_DEV void wv_jacobi_sweeps(WvSvdShared* sh, int dsz, double scale, double* sv
 // JacobiSVD<Matrix<double, Dynamic, 9>>(A, ComputeFullV).matrixV() for an m x 9 system, any m >= 1.
 // A (column-major m x 9, ld = m) lives in `A`; `At` is scratch of >= 9*m doubles used when m < 9.
 // Result: sh->V (9 x 9 column-major).  A is destroyed.
+#ifdef DSM_PROFILE_SECTIONS
+__device__ unsigned long long g_dsm_prof[16];
+#define LSEC_BEGIN() const long long lt__0 = clock64()
+#define LSEC_END(sec) do { if (threadIdx.x == 0) atomicAdd(&g_dsm_prof[sec], (unsigned long long)(clock64() - lt__0)); } while (0)
+#else
+#define LSEC_BEGIN() do {} while (0)
+#define LSEC_END(sec) do {} while (0)
+#endif
 DSM_DEV void wv_svd_V_mx9(double* A, double* At, int m, WvSvdShared* sh, double* sv, int lane) {
   // scale = max |a_ij| (exact, order independent)
   double mxl = 0.0;
@@ -906,7 +941,11 @@ DSM_DEV void wv_svd_V_mx9(double* A, double* At, int m, WvSvdShared* sh, double*
   if (m > 9) {
     for (int e = lane; e < 9 * m; e += 64) A[e] /= scale;
     wv_sync();
-    wv_colpiv_qr(A, m, 9, sh, lane);
+    {
+      LSEC_BEGIN();
+      wv_colpiv_qr(A, m, 9, sh, lane);
+      LSEC_END(4);
+    }
     for (int e = lane; e < 81; e += 64) {
       const int i = e % 9, j = e / 9;
       sh->W[j * 9 + i] = (i <= j) ? A[(size_t)j * m + i] : 0.0;
@@ -915,7 +954,11 @@ DSM_DEV void wv_svd_V_mx9(double* A, double* At, int m, WvSvdShared* sh, double*
     wv_sync();
     if (lane < 9) sh->V[lane * 9 + sh->perm[lane]] = 1.0;
     wv_sync();
-    wv_jacobi_sweeps(sh, 9, scale, sv, lane);
+    {
+      LSEC_BEGIN();
+      wv_jacobi_sweeps(sh, 9, scale, sv, lane);
+      LSEC_END(5);
+    }
   } else if (m < 9) {
     for (int e = lane; e < 9 * m; e += 64) {
       const int i = e % m, j = e / m;  // A(i, j)

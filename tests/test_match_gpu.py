@@ -172,3 +172,22 @@ def test_4096_features_bit_exact_and_properties(dsm, oracle):
         b = get(k + 1)[:, ::-1]
         b = b[np.argsort(b[:, 0], kind="stable")]
         check_equal(a, b)
+
+
+def test_more_than_one_column_segment(dsm, oracle):
+    """> 4 096 and > 8 192 features: K1 sweeps the columns in segments of 128 tiles and merges them in order;
+    ties across segments must still resolve to the lowest index."""
+    rng = np.random.default_rng(99)
+    d1 = rand_sift(rng, 4500)
+    d2 = rand_sift(rng, 9000)
+    perm = rng.permutation(4500)
+    d2[perm[:3000] * 2] = np.clip(d1[perm[:3000]].astype(np.int32) + rng.integers(-4, 5, (3000, 128)), 0, 255).astype(np.uint8)
+    d2[8999] = d2[10]     # duplicate columns in different segments
+    d2[4100] = d2[4097]
+    d1[7] = d2[10]
+    for cross in (1, 0):
+        o = capi.default_match_options(cross_check=cross)
+        check_equal(dsm.match_sift_features(d1, d2, o), oracle.match_sift_features_cpu(d1, d2, 0.8, 0.7, bool(cross)))
+        check_equal(dsm.match_sift_features(d2, d1, o), oracle.match_sift_features_cpu(d2, d1, 0.8, 0.7, bool(cross)))
+    o = capi.default_match_options(max_ratio=2.0, max_distance=3.0, cross_check=0)
+    check_equal(dsm.match_sift_features(d1, d2, o), oracle.match_sift_features_cpu(d1, d2, 2.0, 3.0, False))
