@@ -29,6 +29,7 @@
 #include "../../include/dagsfm_mi355x.h"
 #include "kernels.h"
 #include "verify_estimators.h"
+#include "verify_fivept_coop.h"
 
 #define BATCH 64
 
@@ -48,7 +49,7 @@ struct VSmem {
   double cur_model[9];
   double bcast[16];
   int ibcast[8];
-  double ws5[FIVEPT_WS];   // LDS workspace of the single-lane 5-point local optimisation
+  G5Ws g5;                 // LDS workspace of the group-cooperative 5-point solver (local optimisation)
   MtState gen;
   uint32_t mt_bak[624];
   int mti_bak;
@@ -263,12 +264,15 @@ DSM_DEV int fam_local(const PairWork& w, int ninl) {
     }
     wv_sync();
     wv_svd_V_mx9(Q, Q + (size_t)9 * m, m, &sm->svd, sm->sv, lane);
-    if (lane == 0) {
-      double Eb[36];
-      for (int r = 0; r < 9; ++r)
-        for (int c = 0; c < 4; ++c) Eb[r * 4 + c] = sm->svd.V[(5 + c) * 9 + r];
+    {
       LSEC_BEGIN();
-      sm->ibcast[0] = five_point_finish_t<true>(Eb, sm->lo_models, sm->ws5);
+      if (lane < 36) sm->g5.Eb[lane] = sm->svd.V[(5 + (lane & 3)) * 9 + (lane >> 2)];  // Eb[r*4 + c] = V(r, 5 + c)
+      wv_sync();
+      if (lane < 16) {
+        const int nm = g5_five_point_finish(&sm->g5, lane, 0);
+        for (int e = lane; e < nm * 9; e += 16) sm->lo_models[e] = sm->g5.models[e];
+        if (lane == 0) sm->ibcast[0] = nm;
+      }
       LSEC_END(7);
     }
     wv_sync();
@@ -1414,6 +1418,7 @@ __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_solve_score(cons
 #define TSEC_BEGIN() do {} while (0)
 #define TSEC_END(sec) do {} while (0)
 #endif
+
 
 template <int FAM>
 __global__ __launch_bounds__(64, 4) void k_replay(const VerifyParams p) {
