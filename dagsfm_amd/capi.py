@@ -72,6 +72,7 @@ def lib():
         L.dsm_match_sift_features.argtypes = [vp, ctypes.POINTER(MatchOptions), u8p, ctypes.c_uint32, u8p,
                                               ctypes.c_uint32, u32p, u32p]
         L.dsm_get_match_kernel_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double), u32p]
+        L.dsm_get_match_resolve_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
         L.dsm_pair_seed.argtypes = [ctypes.c_uint32] * 3
         L.dsm_pair_seed.restype = ctypes.c_uint32
         L.dsm_verify_pairs.argtypes = [vp, ctypes.POINTER(TwoViewOptions), u32p, ctypes.c_uint32, ctypes.c_int32]
@@ -253,3 +254,8 @@ class Context:
         n = ctypes.c_uint32(0)
         self._chk(lib().dsm_get_match_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+    def match_resolve_time(self):
+        ms = ctypes.c_double(0)
+        self._chk(lib().dsm_get_match_resolve_time(self._h, ctypes.byref(ms)))
+        return ms.value

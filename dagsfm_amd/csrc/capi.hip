@@ -98,6 +98,7 @@ struct dsm_ctx {
   DevBuf d_dpairs, d_doutoff, d_pair_dir, d_m, d_counts, d_offsets, d_matches, d_total;
   uint64_t total_matches = 0;
   double k1_ms = 0.0;
+  double k1b_ms = 0.0;  // k1_resolve_index
   uint32_t k1_launches = 0;
   std::vector<hipEvent_t> ev;
 
@@ -309,6 +310,7 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
   ctx->n_pairs = n_pairs;
   ctx->pairs.assign(pairs, pairs + (size_t)n_pairs * 2);
   ctx->k1_ms = 0.0;
+  ctx->k1b_ms = 0.0;
   ctx->k1_launches = 0;
   ctx->total_matches = 0;
   const bool cross = options->cross_check != 0;
@@ -393,7 +395,7 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
     k1.max_ratio = (float)options->max_ratio;        // narrowed as at sift.cc:164-166
     k1.max_distance = (float)options->max_distance;
     k1.out = ctx->d_m.as<int32_t>();
-    while (ctx->ev.size() < ev_used + 2) {
+    while (ctx->ev.size() < ev_used + 3) {
       hipEvent_t e;
       HIPCHK(ctx, hipEventCreate(&e));
       ctx->ev.push_back(e);
@@ -402,7 +404,10 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
     launch_k1(k1, nd, max_rb, st);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 1], st));
-    ev_used += 2;
+    launch_k1_resolve(k1, nd, max_rb, st);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 2], st));
+    ev_used += 3;
     if (max_rb) ctx->k1_launches++;
 
     K2Params k2;
@@ -430,10 +435,12 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
     c0 = c1;
   }
   HIPCHK(ctx, hipStreamSynchronize(st));
-  for (size_t k = 0; k + 1 < ev_used; k += 2) {
+  for (size_t k = 0; k + 2 < ev_used; k += 3) {
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[k], ctx->ev[k + 1]));
     ctx->k1_ms += ms;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[k + 1], ctx->ev[k + 2]));
+    ctx->k1b_ms += ms;
   }
   ctx->matched = true;
   return DSM_OK;
@@ -460,6 +467,7 @@ int dsm_set_matches(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
   ctx->pairs.assign(pairs, pairs + (size_t)n_pairs * 2);
   ctx->total_matches = total;
   ctx->k1_ms = 0.0;
+  ctx->k1b_ms = 0.0;
   ctx->k1_launches = 0;
   HIPCHK(ctx, ctx->d_counts.reserve(std::max<uint32_t>(n_pairs, 1) * 4));
   HIPCHK(ctx, ctx->d_offsets.reserve(((size_t)n_pairs + 1) * 8));
@@ -918,6 +926,13 @@ int dsm_get_match_kernel_time(dsm_ctx* ctx, double* total_ms, uint32_t* n_launch
   if (!ctx->matched) return fail(ctx, DSM_ERR_NOT_READY, "dsm_match_pairs has not run");
   if (total_ms) *total_ms = ctx->k1_ms;
   if (n_launches) *n_launches = ctx->k1_launches;
+  return DSM_OK;
+}
+
+int dsm_get_match_resolve_time(dsm_ctx* ctx, double* total_ms) {
+  if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
+  if (!ctx->matched) return fail(ctx, DSM_ERR_NOT_READY, "dsm_match_pairs has not run");
+  if (total_ms) *total_ms = ctx->k1b_ms;
   return DSM_OK;
 }
 

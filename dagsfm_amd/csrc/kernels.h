@@ -13,12 +13,12 @@ struct K1Params {
   const int32_t* rterm;       // 128 * sum(s8 row)
   const uint2* dpairs;        // directed pairs {image a, image b}
   const uint32_t* img_row0;   // first padded row of every image
-  const uint32_t* img_rows;   // padded row count of every image (multiple of 256, <= 8192)
+  const uint32_t* img_rows;   // padded row count of every image (multiple of 256)
   const uint64_t* d_out_off;  // per directed pair: offset (in rows) into `out`
   const float* lut;           // acosf(min(d / 2^18, 1)), d = 0..262144, built on the host
   float max_ratio;
   float max_distance;
-  int32_t* out;               // per row: matched column index or -1
+  int32_t* out;               // per row: matched column index or -1 (between K1 and K1b: the 32-column tile)
 };
 
 // K2: mutual check + ordered compaction, one workgroup per undirected pair.
@@ -110,6 +110,7 @@ void launch_compact_inliers(const uint64_t* match_off, const uint64_t* inl_off, 
 
 void launch_k0(const uint8_t* in_u8, int8_t* out_s8, int32_t* rterm, uint64_t n_rows, hipStream_t st);
 void launch_k1(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st);
+void launch_k1_resolve(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st);
 void launch_k2(const K2Params& p, uint32_t n_pairs, bool write, hipStream_t st);
 void launch_scan(const uint32_t* counts, uint64_t* offsets, uint32_t n, uint64_t* running_total, hipStream_t st);
 

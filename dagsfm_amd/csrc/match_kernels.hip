@@ -7,36 +7,52 @@
 // without ever materialising the N1 x N2 int32 matrix.
 //
 // K0  k0_prepare        u8 -> s8 (x ^ 0x80) + per-row bias term, once per image upload.
-// K1  k1_best_rows      one *directed* pass (image a rows vs image b columns):
-//                       int8 MFMA 32x32x32 distance tiles, top-2 per row fused in the
-//                       epilogue as packed (value<<8 | tile) keys (v_lshl_add, v_med3, v_max),
+// K1  k1_best_rows      one *directed* pass (image a rows vs image b columns): int8 MFMA 32x32x32
+//                       distance tiles whose accumulators start at the column bias, top-2 VALUES
+//                       per row fused in the epilogue (3 VALU per 2 elements: v_med3, v_max3,
+//                       v_max) plus the 32-column tile in which the best value was reached;
 //                       thresholds (acos LUT, ratio) applied before the single int32 store.
 //                       Cross-check uses the second directed pass (b rows vs a columns),
 //                       which is exactly FindBestMatchesOneWay(dists.transpose()).
+// K1b k1_resolve_index  for the rows that passed the thresholds only: the lowest column of that
+//                       tile that attains the best value (32 dot products per row, v_dot4).
 // K2  k2_cross_compact  mutual check + ordered compaction (ascending idx1) per pair.
 //
 // Exactness of the signed-MFMA trick: a = a' + 128, b = b' + 128,
 //   dot = S + rterm(i) + rterm(j) + 2^21,  S = sum a'b',  rterm(x) = 128 * sum x'
-// all in int32 (|dot| <= 128*255^2 < 2^23).  Per row the comparison value is
-//   v' = dot - rterm(i) - 2^22 = S + rterm(j) - 2^21   in (-2^23, 2^23)
-// so key = ((v' + 2^23) << 7) + (127 - tile) is an order-preserving key: larger dot wins, equal
-// dots resolve to the lower tile.  The key is a positive int32 below 0x7F800000 with a non-zero
-// exponent field, i.e. also a finite normal float with the SAME ordering, so the top-2 update runs
-// on the full-rate float pipe (v_max_f32 / v_med3_f32); only the key build is an integer op.
-// A tile index has 7 bits => columns are swept in segments of 128 tiles (4 096 columns) whose
-// results are merged in ascending order; the 32 columns of a tile live in different lanes and
-// are merged per segment with a (key, lane) butterfly, which resolves equal dots to the lowest
-// column index exactly like the reference's ascending strict-`>` scan.  Top-2 of *distinct* keys
-// reproduces the reference's second-best semantics (a duplicate of the best value is the
-// second best, sift.cc:126-132).  Zero padding rows/columns have dot == 0 and can never
-// beat the initial best_dist = second_best_dist = 0 (sift.cc:122-123).
+// all in int32 (|dot| <= 128*255^2 < 2^23).  Within a row only  v = S + rterm(j) + 2^21  matters
+// (dot = v + rterm(i)); the MFMA chain of a tile starts from C = rterm(j) + 2^21, so the finished
+// accumulator IS v and needs no further arithmetic before the comparisons.
+//
+// The tile is computed transposed (descriptor columns of image b as the MFMA A operand): a lane
+// owns ONE row of image a and its 16 accumulator registers are 16 different columns, so the
+// running (best, second) of a row are two registers and two new values x, y update them with
+//   second = max(second, med3(best, x, y));  best = max3(best, x, y)
+// (the second largest of {best, second, x, y} given second <= best).  That is the reference's
+// second-best semantics on values: a duplicate of the best value is the second best
+// (sift.cc:126-132).  The reference's best_i2 is the LOWEST column that attains the maximum
+// (ascending strict-`>` scan): K1 remembers the first tile in which the final best value was
+// reached (a strict increase of the running best), K1b finds the first column inside that tile.
+// Zero padding rows/columns have dot == 0 and can never beat the initial
+// best_dist = second_best_dist = 0 (sift.cc:122-123).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "kernels.h"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>());
+    static_for<B + 1, E>(f);
+  }
+}
 
 // ------------------------------------------------------------------------------------ K0
 // 8 lanes per descriptor row, 16 bytes per lane.
@@ -66,18 +82,50 @@ __global__ __launch_bounds__(256) void k0_prepare(const uint8_t* __restrict__ in
 }
 
 // ------------------------------------------------------------------------------------ K1
-// keys are positive normal floats bit-wise (see above): float max / med3 order them like integers
-__device__ __forceinline__ int key_med3(int a, int b, int c) {
-  int d;
-  asm("v_med3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
+// One quarter (4 of the 16 accumulator registers = 4 columns) of a tile's top-2 update for the lane's
+// row, as ONE asm block so that it can be placed between two MFMAs as a unit:
+//   second = max(second, med3(best, x, y));  best = max3(best, x, y)      for two pairs (x, y)
+// Quarter 0 leaves the tile's incoming best in `ob`; quarter 3 records the tile index when the best
+// strictly increased during the tile.
+template <int Q>
+__device__ __forceinline__ void k1_epilogue_quarter(const v16i& a, int& best, int& second, int& ob, int& btile,
+                                                    int tile) {
+  int t0, t1;
+  if constexpr (Q == 0) {
+    int nb;
+    asm volatile(
+        "v_med3_i32 %[t0], %[b], %[a0], %[a1]\n\t"
+        "v_max3_i32 %[nb], %[b], %[a0], %[a1]\n\t"
+        "v_med3_i32 %[t1], %[nb], %[a2], %[a3]\n\t"
+        "v_max3_i32 %[nb], %[nb], %[a2], %[a3]\n\t"
+        "v_max3_i32 %[s], %[s], %[t0], %[t1]"
+        : [nb] "=&v"(nb), [s] "+v"(second), [t0] "=&v"(t0), [t1] "=&v"(t1)
+        : [b] "v"(best), [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]));
+    ob = best;
+    best = nb;
+  } else if constexpr (Q == 3) {
+    asm volatile(
+        "v_med3_i32 %[t0], %[b], %[a0], %[a1]\n\t"
+        "v_max3_i32 %[b], %[b], %[a0], %[a1]\n\t"
+        "v_med3_i32 %[t1], %[b], %[a2], %[a3]\n\t"
+        "v_max3_i32 %[b], %[b], %[a2], %[a3]\n\t"
+        "v_max3_i32 %[s], %[s], %[t0], %[t1]\n\t"
+        "v_cmp_gt_i32 vcc, %[b], %[ob]\n\t"
+        "v_cndmask_b32 %[bt], %[bt], %[tile], vcc"
+        : [b] "+v"(best), [s] "+v"(second), [bt] "+v"(btile), [t0] "=&v"(t0), [t1] "=&v"(t1)
+        : [ob] "v"(ob), [tile] "v"(tile), [a0] "v"(a[12]), [a1] "v"(a[13]), [a2] "v"(a[14]), [a3] "v"(a[15])
+        : "vcc");
+  } else {
+    asm volatile(
+        "v_med3_i32 %[t0], %[b], %[a0], %[a1]\n\t"
+        "v_max3_i32 %[b], %[b], %[a0], %[a1]\n\t"
+        "v_med3_i32 %[t1], %[b], %[a2], %[a3]\n\t"
+        "v_max3_i32 %[b], %[b], %[a2], %[a3]\n\t"
+        "v_max3_i32 %[s], %[s], %[t0], %[t1]"
+        : [b] "+v"(best), [s] "+v"(second), [t0] "=&v"(t0), [t1] "=&v"(t1)
+        : [a0] "v"(a[4 * Q]), [a1] "v"(a[4 * Q + 1]), [a2] "v"(a[4 * Q + 2]), [a3] "v"(a[4 * Q + 3]));
+  }
 }
-__device__ __forceinline__ int key_max(int a, int b) {
-  int d;
-  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-
 
 // LDS image of a 64-column B tile: column c occupies 128 B; its eight 16-B chunks are
 // XOR-swizzled with (c>>1)&7 so that the 16-lane ds_read_b128 groups are conflict free.
@@ -85,14 +133,16 @@ __device__ __forceinline__ int lds_off(int col, int chunk) {
   return col * 128 + ((chunk ^ ((col >> 1) & 7)) << 4);
 }
 
+// Workgroup = 4 waves x 128 rows of image a (4 resident 32-row fragments per wave); the columns of
+// image b stream through LDS in 64-column steps (double buffered) together with their bias terms.
 __global__ __launch_bounds__(256, 2) void k1_best_rows(const K1Params p) {
   const uint32_t d = blockIdx.x;
   const uint32_t rb = blockIdx.y;
   const uint2 ab = p.dpairs[d];
   const uint32_t a_rows = p.img_rows[ab.x];
-  if (rb * 256u >= a_rows) return;
+  if (rb * 512u >= a_rows) return;
   const uint32_t b_cols = p.img_rows[ab.y];
-  const uint32_t a_row0 = p.img_row0[ab.x] + rb * 256u;
+  const uint32_t a_row0 = p.img_row0[ab.x] + rb * 512u;
   const uint32_t b_row0 = p.img_row0[ab.y];
 
   const int tid = threadIdx.x;
@@ -100,205 +150,203 @@ __global__ __launch_bounds__(256, 2) void k1_best_rows(const K1Params p) {
   const int wave = tid >> 6;
   const int l31 = lane & 31;
   const int half = lane >> 5;
+  // images are padded to 256 rows: the upper two waves of the last workgroup may have no rows at all
+  const bool active = rb * 512u + (uint32_t)wave * 128u < a_rows;
 
   __shared__ __attribute__((aligned(16))) int8_t sB[2][64 * 128];
+  __shared__ __attribute__((aligned(16))) int sC[2][64];
 
-  int32_t* out = p.out + p.d_out_off[d] + rb * 256u + wave * 64;
-
-  // Resident A fragments: 64 rows x 128 B per wave.
-  const int8_t* arow = p.desc + (size_t)(a_row0 + wave * 64) * 128;
-  v4i afrag[2][4];
+  // Resident fragments of this wave's 128 rows (MFMA B operand: lane = row, 16 B of k per half).
+  v4i afrag[4][4];
+  int rterm_i[4];
+  {
+    const int8_t* arow = p.desc + (size_t)(a_row0 + wave * 128) * 128;
+    const int32_t* rt_a = p.rterm + a_row0 + wave * 128;
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < 4; ++rt) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      afrag[rt][ks] = *reinterpret_cast<const v4i*>(arow + (rt * 32 + l31) * 128 + ks * 32 + half * 16);
+      for (int ks = 0; ks < 4; ++ks) {
+        const v4i z = {0, 0, 0, 0};
+        afrag[rt][ks] =
+            active ? *reinterpret_cast<const v4i*>(arow + (rt * 32 + l31) * 128 + ks * 32 + half * 16) : z;
+      }
+      rterm_i[rt] = active ? rt_a[rt * 32 + l31] : 0;
+    }
+  }
+  // dot == 0  <=>  v == -rterm(i): best_dist = second_best_dist = 0 initially (sift.cc:122-123)
+  int best[4], second[4], btile[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    best[rt] = -rterm_i[rt];
+    second[rt] = -rterm_i[rt];
+    btile[rt] = 0;
+  }
 
   const int8_t* bimg = p.desc + (size_t)b_row0 * 128;
-  const int32_t* rt_bimg = p.rterm + b_row0;
-  const int32_t* rt_a = p.rterm + a_row0 + wave * 64;
-  int key0[2][16];
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      key0[rt][r] = (int)((uint32_t)((1 << 22) - rt_a[row]) << 7);  // dot 0: v' + 2^23 = 2^22 - rterm(i)
-    }
-  // running result of this lane's row over the column segments (best_dist = second_best_dist = 0 initially)
-  int run_b = 0, run_s = 0;
-  uint32_t run_j = 0;
+  const int32_t* rt_b = p.rterm + b_row0;
+  const uint32_t nsteps = b_cols >> 6;
 
-#define K1_MFMA4(ACC, RT, BF)                                                              \
-  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                         \
-      ACC = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[RT][ks], BF[ks], ACC, 0, 0, 0)
-#define K1_EPILOGUE(ACC, RT, KT)                                                           \
-  _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
-    const int key = (int)((uint32_t)ACC[r] << 7) + KT;                                     \
-    second[RT][r] = key_med3(best[RT][r], second[RT][r], key);                             \
-    best[RT][r] = key_max(best[RT][r], key);                                               \
+  v4i stage[2];
+  int cstage = 0;
+  // prologue: step 0
+#pragma unroll
+  for (int u = 0; u < 2; ++u) stage[u] = *reinterpret_cast<const v4i*>(bimg + (size_t)(tid + 256 * u) * 16);
+  cstage = rt_b[tid & 63];  // every wave loads it: no divergent branch around a global load
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int q = tid + 256 * u;
+    *reinterpret_cast<v4i*>(&sB[0][lds_off(q >> 3, q & 7)]) = stage[u];
   }
-// one MFMA followed by 12 VALU of the previous tile's epilogue, four times
-#define K1_INTERLEAVE()                                                                    \
-  _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                          \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
-    __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                                    \
-  }
+  if (tid < 64) sC[0][tid] = cstage + (1 << 21);
+  __syncthreads();
+  // make sure nothing issued before the loop is still pending at its head: hipcc's waitcnt pass would
+  // otherwise keep a conservative vmcnt wait at the top of every iteration (right behind the prefetch)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  for (uint32_t seg0 = 0; seg0 < b_cols; seg0 += 4096) {
-    const uint32_t seg_cols = (b_cols - seg0) < 4096u ? (b_cols - seg0) : 4096u;
-    const uint32_t nsteps = seg_cols >> 6;
-    const int8_t* bbase = bimg + (size_t)seg0 * 128;
-    const int32_t* rt_b = rt_bimg + seg0;
-    int best[2][16], second[2][16];
+  for (uint32_t s = 0; s < nsteps; ++s) {
+    const int cur = s & 1;
+    const bool more = (s + 1) < nsteps;
+    // prefetch of the next B step (global -> registers); consumed at the end of the step
+    if (more) {
+      const int8_t* src = bimg + (size_t)(s + 1) * 64 * 128;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        best[rt][r] = key0[rt][r];
-        second[rt][r] = key0[rt][r];
-      }
-    v4i stage[2];
-    int colterm[2];
-    // prologue: tile 0 of the segment
-#pragma unroll
-    for (int u = 0; u < 2; ++u) stage[u] = *reinterpret_cast<const v4i*>(bbase + (size_t)(tid + 256 * u) * 16);
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) colterm[ct] = rt_b[ct * 32 + l31];
-    __syncthreads();  // the previous segment's last tile is no longer being read
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int q = tid + 256 * u;
-      *reinterpret_cast<v4i*>(&sB[0][lds_off(q >> 3, q & 7)]) = stage[u];
+      for (int u = 0; u < 2; ++u) stage[u] = *reinterpret_cast<const v4i*>(src + (size_t)(tid + 256 * u) * 16);
+      cstage = rt_b[(s + 1) * 64 + (tid & 63)];
     }
-    __syncthreads();
-    // make sure nothing issued before the loop is still pending at its head: hipcc's waitcnt pass would
-    // otherwise keep a conservative vmcnt wait at the top of every iteration (right behind the prefetch)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    for (uint32_t s = 0; s < nsteps; ++s) {
-      const int cur = s & 1;
-      const bool more = (s + 1) < nsteps;
-      // keys of this step's two column tiles from the already-resident column terms
-      int kterm0 = (int)((uint32_t)(colterm[0] + (1 << 23) - (1 << 21)) << 7) + (127 - (int)(2 * s));
-      int kterm1 = (int)((uint32_t)(colterm[1] + (1 << 23) - (1 << 21)) << 7) + (127 - (int)(2 * s + 1));
-      // keep each kterm one opaque VGPR: otherwise the compiler re-associates (acc << 7) + a + b into
-      // v_lshlrev + v_add3 (2 VALU per element) instead of one v_lshl_add_u32
-      asm volatile("" : "+v"(kterm0));
-      asm volatile("" : "+v"(kterm1));
-      // prefetch of the next B tile (global -> registers); consumed at the end of the step
-      int colterm_next[2] = {0, 0};
-      if (more) {
-        const int8_t* src = bbase + (size_t)(s + 1) * 64 * 128;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) stage[u] = *reinterpret_cast<const v4i*>(src + (size_t)(tid + 256 * u) * 16);
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) colterm_next[ct] = rt_b[(s + 1) * 64 + ct * 32 + l31];
-      }
+    if (active) {
+      // MFMA A operand: lane = column of the tile; C input: register r <-> column 8*(r>>2) + 4*half + (r&3)
       v4i bf0[4], bf1[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         bf0[ks] = *reinterpret_cast<const v4i*>(&sB[cur][lds_off(l31, ks * 2 + half)]);
         bf1[ks] = *reinterpret_cast<const v4i*>(&sB[cur][lds_off(32 + l31, ks * 2 + half)]);
       }
-      const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      v16i accA = zero16, accB = zero16;
-      // software pipeline over the four 32x32 tiles of the step: the MFMAs of tile i+1 run in the matrix
-      // pipe while the VALU does the top-2 epilogue of tile i
-      K1_MFMA4(accA, 0, bf0);
-      __builtin_amdgcn_sched_barrier(0);
-      K1_MFMA4(accB, 1, bf0);
-      K1_EPILOGUE(accA, 0, kterm0);
-      K1_INTERLEAVE();
-      __builtin_amdgcn_sched_barrier(0);
-      accA = zero16;
-      K1_MFMA4(accA, 0, bf1);
-      K1_EPILOGUE(accB, 1, kterm0);
-      K1_INTERLEAVE();
-      __builtin_amdgcn_sched_barrier(0);
-      accB = zero16;
-      K1_MFMA4(accB, 1, bf1);
-      K1_EPILOGUE(accA, 0, kterm1);
-      K1_INTERLEAVE();
-      __builtin_amdgcn_sched_barrier(0);
-      K1_EPILOGUE(accB, 1, kterm1);
-      __builtin_amdgcn_sched_barrier(0);
-
-      if (more) {
+      v16i ci0, ci1;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int q = tid + 256 * u;
-          *reinterpret_cast<v4i*>(&sB[cur ^ 1][lds_off(q >> 3, q & 7)]) = stage[u];
-        }
-        colterm[0] = colterm_next[0];
-        colterm[1] = colterm_next[1];
-      }
-      __syncthreads();
-    }
-
-    // (key, source lane) butterfly over the 32 lanes that hold the 32 columns of every tile.  Equal keys
-    // from two lanes are two distinct columns of the same tile: the lower lane (= lower column) keeps
-    // "best", the other one becomes the second best -- exactly sift.cc:126-132.
-    int myB = 0, myS = 0, myL = 0;
+      for (int q = 0; q < 4; ++q) {
+        const v4i c0 = *reinterpret_cast<const v4i*>(&sC[cur][8 * q + 4 * half]);
+        const v4i c1 = *reinterpret_cast<const v4i*>(&sC[cur][32 + 8 * q + 4 * half]);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int B = best[rt][r], S = second[rt][r], L = l31;
-#pragma unroll
-        for (int m = 1; m < 32; m <<= 1) {
-          const int oB = __shfl_xor(B, m);
-          const int oS = __shfl_xor(S, m);
-          const int oL = __shfl_xor(L, m);
-          const bool take = (oB > B) || (oB == B && oL < L);
-          const int lo = min(B, oB);
-          S = max(lo, max(S, oS));
-          B = take ? oB : B;
-          L = take ? oL : L;
-        }
-        if (l31 == rt * 16 + r) {
-          myB = B;
-          myS = S;
-          myL = L;
+        for (int e = 0; e < 4; ++e) {
+          ci0[4 * q + e] = c0[e];
+          ci1[4 * q + e] = c1[e];
         }
       }
-    {
-      const int rt = l31 >> 4, r = l31 & 15;
-      const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int rti = rt_a[row];
-      const int seg_b = (myB >> 7) - (1 << 23) + rti + (1 << 22);
-      const int seg_s = (myS >> 7) - (1 << 23) + rti + (1 << 22);
-      const uint32_t seg_j = seg0 + (uint32_t)(127 - (myB & 127)) * 32u + (uint32_t)myL;
-      // merge with the earlier segments: earlier columns win ties (ascending strict-`>` scan)
-      const int lo = min(run_b, seg_b);
-      const int new_s = max(lo, max(run_s, seg_s));
-      if (seg_b > run_b) {
-        run_b = seg_b;
-        run_j = seg_j;
-      }
-      run_s = new_s;
-    }
+      // Software pipeline over the eight 32x32 tiles of the step (tile k = column tile k>>2, row
+      // fragment k&3, accumulator set k%3).  Slot j issues one MFMA of tile (j>>2)+1 and, one slot behind,
+      // one epilogue quarter of tile j>>2: the VALU works on finished accumulators while the matrix pipe
+      // runs the next chain, and no epilogue reads an accumulator right behind the MFMA that writes it.
+      v16i acc[3];
+      int ob[4];
+      int tile_v[2];  // the step's two tile indices, one VGPR each (v_cndmask takes no second SGPR)
+      asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(tile_v[0]), "=v"(tile_v[1]) : "s"(2 * s), "s"(2 * s + 1));
+#define K1_MFMA(K, KS)                                                                                 \
+  acc[(K) % 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(((K) >> 2) ? bf1[KS] : bf0[KS], afrag[(K)&3][KS], \
+                                                       (KS) == 0 ? (((K) >> 2) ? ci1 : ci0) : acc[(K) % 3], 0, 0, 0)
+#define K1_EPI(E)                                                                                        \
+  {                                                                                                      \
+    constexpr int ek = (E) >> 2, eq = (E)&3, ert = ek & 3;                                               \
+    k1_epilogue_quarter<eq>(acc[ek % 3], best[ert], second[ert], ob[ert], btile[ert], tile_v[ek >> 2]);      \
   }
-#undef K1_MFMA4
-#undef K1_EPILOGUE
-#undef K1_INTERLEAVE
+      static_for<0, 4>([&](auto KS) { K1_MFMA(0, KS.value); });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, 28>([&](auto J) {
+        constexpr int j = J.value;
+        K1_MFMA((j >> 2) + 1, j & 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (j >= 1) {
+          K1_EPI(j - 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      static_for<27, 32>([&](auto E) { K1_EPI(E.value); });
+      __builtin_amdgcn_sched_barrier(0);
+#undef K1_MFMA
+#undef K1_EPI
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = tid + 256 * u;
+        *reinterpret_cast<v4i*>(&sB[cur ^ 1][lds_off(q >> 3, q & 7)]) = stage[u];
+      }
+      if (tid < 64) sC[cur ^ 1][tid] = cstage + (1 << 21);
+    }
+    __syncthreads();
+  }
 
-  {
-    const int rt = l31 >> 4, r = l31 & 15;
-    const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    const int best_dot = run_b;
-    const int second_dot = run_s;
-    const uint32_t j = run_j;
+  if (!active) return;
+  int32_t* out = p.out + p.d_out_off[d] + rb * 512u + wave * 128;
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    // the two halves of the wave hold disjoint columns of the same row
+    const int oB = __shfl_xor(best[rt], 32);
+    const int oS = __shfl_xor(second[rt], 32);
+    const int oT = __shfl_xor(btile[rt], 32);
+    const int B = max(best[rt], oB);
+    const int S = max(min(best[rt], oB), max(second[rt], oS));
+    const bool take = (oB > best[rt]) || (oB == best[rt] && oT < btile[rt]);
+    const int T = take ? oT : btile[rt];
+    const int best_dot = B + rterm_i[rt];
+    const int second_dot = S + rterm_i[rt];
     int res = -1;
     if (best_dot > 0) {  // best_i2 != -1, sift.cc:136
       const float bn = p.lut[min(best_dot, 262144)];
       if (!(bn > p.max_distance)) {  // sift.cc:144
         const float sn = p.lut[min(second_dot, 262144)];
         const float rhs = __fmul_rn(p.max_ratio, sn);
-        if (!(bn >= rhs)) res = (int)j;  // sift.cc:153
+        if (!(bn >= rhs)) res = T;  // sift.cc:153; K1b turns the tile into the column
       }
     }
-    out[row] = res;
+    if (half == (rt & 1)) out[rt * 32 + l31] = res;
+  }
+}
+
+// ------------------------------------------------------------------------------------ K1b
+// out[row] holds a tile index for the rows that passed the thresholds: replace it by the lowest
+// column of that tile with the largest dot product (= the row's best value, reached in this tile).
+// A wave owns 64 rows and resolves its flagged rows two at a time, 32 lanes = the 32 columns of a tile.
+__global__ __launch_bounds__(256) void k1_resolve_index(const K1Params p) {
+  const uint32_t d = blockIdx.x;
+  const uint32_t rb = blockIdx.y;
+  const uint2 ab = p.dpairs[d];
+  const uint32_t a_rows = p.img_rows[ab.x];
+  if (rb * 256u >= a_rows) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const uint32_t row_w = rb * 256u + wave * 64u;  // first row of this wave inside image a
+  int32_t* out = p.out + p.d_out_off[d] + row_w;
+  const int8_t* arow = p.desc + (size_t)(p.img_row0[ab.x] + row_w) * 128;
+  const uint32_t b_row0 = p.img_row0[ab.y];
+  const int8_t* bimg = p.desc + (size_t)b_row0 * 128;
+  const int32_t* rt_b = p.rterm + b_row0;
+
+  const int t = out[lane];
+  unsigned long long mask = __ballot(t >= 0);
+  while (mask) {
+    const int r0 = __ffsll((long long)mask) - 1;
+    mask &= mask - 1;
+    int r1 = r0;
+    if (mask) {
+      r1 = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+    }
+    const int myr = half ? r1 : r0;
+    const int tile = __shfl(t, myr);
+    const uint32_t col = (uint32_t)tile * 32u + (uint32_t)l31;
+    const v4i* rp = reinterpret_cast<const v4i*>(arow + (size_t)myr * 128);
+    const v4i* cp = reinterpret_cast<const v4i*>(bimg + (size_t)col * 128);
+    int acc = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const v4i x = rp[c], y = cp[c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_sdot4(x[e], y[e], acc, false);
+    }
+    int key = (int)((uint32_t)(acc + rt_b[col]) << 5) | (31 - l31);  // |S + rterm(j)| <= 2^22
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) key = max(key, __shfl_xor(key, m));
+    if (l31 == 0 && (half == 0 || r1 != r0)) out[myr] = tile * 32 + (31 - (key & 31));
   }
 }
 
@@ -390,9 +438,14 @@ void launch_k0(const uint8_t* in_u8, int8_t* out_s8, int32_t* rterm, uint64_t n_
   hipLaunchKernelGGL(k0_prepare, dim3(blocks), dim3(256), 0, st, in_u8, out_s8, rterm, n_rows);
 }
 
+// max_row_blocks = largest padded row count of an `a` image / 256
 void launch_k1(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st) {
   if (n_directed == 0 || max_row_blocks == 0) return;
-  hipLaunchKernelGGL(k1_best_rows, dim3(n_directed, max_row_blocks), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(k1_best_rows, dim3(n_directed, (max_row_blocks + 1) / 2), dim3(256), 0, st, p);
+}
+void launch_k1_resolve(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st) {
+  if (n_directed == 0 || max_row_blocks == 0) return;
+  hipLaunchKernelGGL(k1_resolve_index, dim3(n_directed, max_row_blocks), dim3(256), 0, st, p);
 }
 
 void launch_k2(const K2Params& p, uint32_t n_pairs, bool write, hipStream_t st) {

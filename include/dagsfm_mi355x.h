@@ -171,6 +171,9 @@ int dsm_match_sift_features(dsm_ctx* ctx, const dsm_match_options* options,
  * last dsm_match_pairs, measured with HIP events on the stream the kernel was
  * launched on: total milliseconds and number of launches. */
 int dsm_get_match_kernel_time(dsm_ctx* ctx, double* total_ms, uint32_t* n_launches);
+/* Same for the small follow-up kernel that turns the best tile of every accepted row into
+ * the exact column index (k1_resolve_index). */
+int dsm_get_match_resolve_time(dsm_ctx* ctx, double* total_ms);
 
 /* ------------------------------------------------------------------ verification */
 
