@@ -305,48 +305,55 @@ __global__ __launch_bounds__(256, 2) void k1_best_rows(const K1Params p) {
 // ------------------------------------------------------------------------------------ K1b
 // out[row] holds a tile index for the rows that passed the thresholds: replace it by the lowest
 // column of that tile with the largest dot product (= the row's best value, reached in this tile).
-// A wave owns 64 rows and resolves its flagged rows two at a time, 32 lanes = the 32 columns of a tile.
+// One workgroup per directed pair (the 32-column tiles it reads all belong to ONE image b, which stays
+// in L2); a wave takes 64 rows at a time and resolves its flagged rows one after the other.
 __global__ __launch_bounds__(256) void k1_resolve_index(const K1Params p) {
   const uint32_t d = blockIdx.x;
-  const uint32_t rb = blockIdx.y;
   const uint2 ab = p.dpairs[d];
   const uint32_t a_rows = p.img_rows[ab.x];
-  if (rb * 256u >= a_rows) return;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
-  const uint32_t row_w = rb * 256u + wave * 64u;  // first row of this wave inside image a
-  int32_t* out = p.out + p.d_out_off[d] + row_w;
-  const int8_t* arow = p.desc + (size_t)(p.img_row0[ab.x] + row_w) * 128;
+  const int lane = tid & 63, wave = tid >> 6;
   const uint32_t b_row0 = p.img_row0[ab.y];
   const int8_t* bimg = p.desc + (size_t)b_row0 * 128;
   const int32_t* rt_b = p.rterm + b_row0;
-
-  const int t = out[lane];
-  unsigned long long mask = __ballot(t >= 0);
-  while (mask) {
-    const int r0 = __ffsll((long long)mask) - 1;
-    mask &= mask - 1;
-    int r1 = r0;
-    if (mask) {
-      r1 = __ffsll((long long)mask) - 1;
+  for (uint32_t row_w = wave * 64u; row_w < a_rows; row_w += 256u) {  // first row of this wave's chunk
+    int32_t* out = p.out + p.d_out_off[d] + row_w;
+    const int8_t* arow = p.desc + (size_t)(p.img_row0[ab.x] + row_w) * 128;
+    const int t = out[lane];
+    unsigned long long mask = __ballot(t >= 0);
+    while (mask) {
+      const int r = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
+      const int tile = __builtin_amdgcn_readlane(t, r);
+      // the tile's 32 columns are 4 KB of contiguous memory: four fully coalesced 1-KB loads, lane =
+      // (column i*8 + (lane>>3), 16-byte chunk lane&7) -- eight lanes share one dot product
+      const v4i x = *reinterpret_cast<const v4i*>(arow + (size_t)r * 128 + (lane & 7) * 16);
+      const int8_t* tbase = bimg + (size_t)tile * 4096 + lane * 16;
+      const int32_t* tterm = rt_b + tile * 32 + (lane >> 3);
+      v4i y[4];
+      int ct[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        y[i] = *reinterpret_cast<const v4i*>(tbase + i * 1024);
+        ct[i] = tterm[i * 8];
+      }
+      int key = INT32_MIN;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int acc = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_sdot4(x[e], y[i][e], acc, false);
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        acc += __shfl_xor(acc, 4);
+        const int col = i * 8 + (lane >> 3);
+        key = max(key, (int)((uint32_t)(acc + ct[i]) << 5) | (31 - col));  // |S + rterm(j)| <= 2^22
+      }
+      key = max(key, __shfl_xor(key, 8));
+      key = max(key, __shfl_xor(key, 16));
+      key = max(key, __shfl_xor(key, 32));
+      if (lane == 0) out[r] = tile * 32 + (31 - (key & 31));
     }
-    const int myr = half ? r1 : r0;
-    const int tile = __shfl(t, myr);
-    const uint32_t col = (uint32_t)tile * 32u + (uint32_t)l31;
-    const v4i* rp = reinterpret_cast<const v4i*>(arow + (size_t)myr * 128);
-    const v4i* cp = reinterpret_cast<const v4i*>(bimg + (size_t)col * 128);
-    int acc = 0;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const v4i x = rp[c], y = cp[c];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_sdot4(x[e], y[e], acc, false);
-    }
-    int key = (int)((uint32_t)(acc + rt_b[col]) << 5) | (31 - l31);  // |S + rterm(j)| <= 2^22
-#pragma unroll
-    for (int m = 1; m < 32; m <<= 1) key = max(key, __shfl_xor(key, m));
-    if (l31 == 0 && (half == 0 || r1 != r0)) out[myr] = tile * 32 + (31 - (key & 31));
   }
 }
 
@@ -445,7 +452,7 @@ void launch_k1(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, 
 }
 void launch_k1_resolve(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st) {
   if (n_directed == 0 || max_row_blocks == 0) return;
-  hipLaunchKernelGGL(k1_resolve_index, dim3(n_directed, max_row_blocks), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(k1_resolve_index, dim3(n_directed), dim3(256), 0, st, p);
 }
 
 void launch_k2(const K2Params& p, uint32_t n_pairs, bool write, hipStream_t st) {
