@@ -741,6 +741,8 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
         unsigned long long prof[16];
         debug_read_prof(prof);
         fprintf(stderr, "[dsm verify] LO sections (cycles): qr %llu  jacobi %llu  finish8pt %llu  finish5pt %llu\n", prof[4], prof[5], prof[6], prof[7]);
+        fprintf(stderr, "[dsm verify] 5pt per-lane sections (Mcycles): build %llu  lu %llu  det %llu  roots %llu  models %llu | score E %llu  score F/H %llu\n",
+                prof[8] >> 20, prof[9] >> 20, prof[10] >> 20, prof[11] >> 20, prof[12] >> 20, prof[13] >> 20, prof[14] >> 20);
       }
 #endif
       fprintf(stderr, "[dsm verify] pairs %u rounds E/F/H %u/%u/%u candidates E/F/H %u/%u/%u LO calls E/F/H %u/%u/%u\n", n_pairs,

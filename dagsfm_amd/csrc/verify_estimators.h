@@ -388,13 +388,14 @@ DSM_DEV void poly_mul(const double* a, int na, const double* b, int nb, double* 
 // `ws`: optional workspace of FIVEPT_WS doubles (LDS when a single lane runs the local optimisation,
 // so that its long dependent chains wait on LDS instead of scratch memory); nullptr = private arrays.
 #define FIVEPT_WS (200 + 100 + 100 + 100)
+// Steps 3-4a: the 10 x 20 constraint matrix, its elimination, B(z) and the determinant polynomial.
 template <bool WS>
-DSM_DEVN int five_point_finish_t(const double* Eb, double* models, double* ws) {
+DSM_DEV void five_point_poly_t(const double* Eb, double* B, double* coeffs, double* ws) {
   double A_loc[WS ? 1 : 200], A1_loc[WS ? 1 : 100], AA_loc[WS ? 1 : 100];
   double* A = WS ? ws : A_loc;  // A[r*20 + c]
   double* A1 = WS ? ws + 200 : A1_loc;
   double* AA = WS ? ws + 300 : AA_loc;
-  double* Cws = WS ? ws + 400 : nullptr;
+  LSEC_BEGIN();
   for (int i = 0; i < 200; ++i) A[i] = 0.0;
   // lin(r, c) = Eb row (3r + c): 4 coefficients (x, y, z, 1)
 #define LIN(r, c) (Eb + ((r) * 3 + (c)) * 4)
@@ -438,14 +439,18 @@ DSM_DEVN int five_point_finish_t(const double* Eb, double* models, double* ws) {
       }
   }
 #undef LIN
+  LSEC_END(8);
+  LSEC_BEGIN2();
   for (int r = 0; r < 10; ++r)  // A1, AA: column-major 10 x 10
     for (int c = 0; c < 10; ++c) {
       A1[c * 10 + r] = A[r * 20 + c];
       AA[c * 10 + r] = A[r * 20 + 10 + c];
     }
   pl_lu_solve_10(A1, AA);
+  LSEC_END2(9);
+  LSEC_BEGIN3();
 #define AAe(r, c) AA[(c) * 10 + (r)]
-  double B[39];  // B[row*3 + col]
+  // B[row*3 + col], 39 entries
   for (int i = 0; i < 3; ++i) {
     B[0 * 3 + i] = 0; B[4 * 3 + i] = 0; B[8 * 3 + i] = 0;
     for (int k = 0; k < 3; ++k) {
@@ -461,7 +466,6 @@ DSM_DEVN int five_point_finish_t(const double* Eb, double* models, double* ws) {
   }
 #undef AAe
   // determinant polynomial of B(z), highest degree first
-  double coeffs[11];
   {
     double b[45];  // b[(j*3 + c)*5 + deg], lowest degree first
     for (int j = 0; j < 3; ++j) {
@@ -486,9 +490,13 @@ DSM_DEVN int five_point_finish_t(const double* Eb, double* models, double* ws) {
     }
     for (int i = 0; i < 11; ++i) coeffs[i] = det[10 - i];
   }
-  double rr[11], ri[11];
-  const int nroots = pl_poly_roots<11>(coeffs, 11, rr, ri, Cws);
-  if (nroots < 0) return 0;
+  LSEC_END3(10);
+}
+
+// Step 5: one essential matrix per real root of the determinant polynomial (essential_matrix.cc:124-147).
+DSM_DEV int five_point_models(const double* Eb, const double* B, const double* rr, const double* ri, int nroots,
+                              double* models) {
+  LSEC_BEGIN5();
   int nm = 0;
   for (int i = 0; i < nroots; ++i) {
     if (fabs(ri[i]) > 1e-10) continue;
@@ -515,13 +523,27 @@ DSM_DEVN int five_point_finish_t(const double* Eb, double* models, double* ws) {
     for (int k = 0; k < 9; ++k) models[nm * 9 + k] = ev[k] / norm;
     ++nm;
   }
+  LSEC_END5(12);
   return nm;
+}
+
+template <bool WS>
+DSM_DEVN int five_point_finish_t(const double* Eb, double* models, double* ws) {
+  double B[39], coeffs[11];
+  five_point_poly_t<WS>(Eb, B, coeffs, ws);
+  double rr[11], ri[11];
+  LSEC_BEGIN4();
+  const int nroots = pl_poly_roots<11>(coeffs, 11, rr, ri, WS ? ws + 400 : nullptr);
+  LSEC_END4(11);
+  if (nroots < 0) return 0;
+  return five_point_models(Eb, B, rr, ri, nroots, models);
 }
 
 DSM_DEV int five_point_finish(const double* Eb, double* models) { return five_point_finish_t<false>(Eb, models, nullptr); }
 
 // EssentialMatrixFivePointEstimator::Estimate for the minimal sample, essential_matrix.cc:46-150
-DSM_DEVN int five_point_minimal(const double* xs, double* models) {
+// Steps 1-2 for the minimal sample: the basis of the null space of Q (essential_matrix.cc:52-74)
+DSM_DEV void five_point_basis(const double* xs, double* Eb) {
   double At[45];  // Q^T, 9 x 5
   for (int i = 0; i < 5; ++i) {
     const double x1_0 = xs[i * 4 + 0], x1_1 = xs[i * 4 + 1], x2_0 = xs[i * 4 + 2], x2_1 = xs[i * 4 + 3];
@@ -532,9 +554,12 @@ DSM_DEVN int five_point_minimal(const double* xs, double* models) {
   }
   double nv[36];  // columns 5..8 of V, nv[c*9 + r]
   pl_nullspace_9xm(At, 5, 5, nv);
-  double Eb[36];
   for (int r = 0; r < 9; ++r)
     for (int c = 0; c < 4; ++c) Eb[r * 4 + c] = nv[c * 9 + r];
+}
+DSM_DEVN int five_point_minimal(const double* xs, double* models) {
+  double Eb[36];
+  five_point_basis(xs, Eb);
   return five_point_finish(Eb, models);
 }
 

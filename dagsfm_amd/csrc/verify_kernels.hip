@@ -1400,6 +1400,7 @@ __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_solve_score(cons
     nm = fam_minimal<FAM>(xs, mloc);
     p.nmodels[(size_t)pl * p.batch + t] = nm;
   }
+  LSEC_BEGIN();
   double* gm = p.models + ((size_t)pl * p.batch + (size_t)(t < nb ? t : 0)) * F::MAXM * 9;
   int32_t* gc = p.counts + ((size_t)pl * p.batch + (size_t)(t < nb ? t : 0)) * F::MAXM;
   for (int m = 0; m < nm; ++m) {
@@ -1409,6 +1410,87 @@ __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_solve_score(cons
     gc[m] = cnt;
     for (int k = 0; k < 9; ++k) gm[m * 9 + k] = M[k];
   }
+  LSEC_END(13 + (FAM == FAM_E ? 0 : 1));
+}
+
+// E family: the minimal solve is split in two kernels.  One lane per hypothesis keeps ~5 KB of matrices in
+// scratch memory, and with thousands of resident waves that scratch lives in HBM; two thirds of the time
+// went into the companion-matrix eigenvalue iteration alone.  k_solve_e_poly stops at the determinant
+// polynomial and parks (Eb, B, coefficients) in the hypothesis' model slot; k_roots_score_e runs the
+// eigenvalue iteration on a lane-interleaved 10 x 10 matrix in LDS (element e of lane l at T[e * 64 + l]:
+// conflict-free, no memory traffic), then builds and scores the models.  Same operations, same order.
+#define EPOLY_EB 0
+#define EPOLY_B 36
+#define EPOLY_COEFFS 75
+__global__ __launch_bounds__(64, 4) void k_solve_e_poly(const VerifyParams p) {
+  const uint32_t pl = blockIdx.x;
+  const uint32_t pi = p.pair0 + pl;
+  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
+  if (!fs->active) return;
+  const int t = blockIdx.y * 64 + threadIdx.x;
+  if (t >= (int)fs->nb) return;
+  const double* pts = p.pts_norm + 4 * p.match_off[pi];
+  const uint32_t* smp = p.samples + ((size_t)pl * p.batch + t) * 7;
+  double xs[20];
+  for (int i = 0; i < 5; ++i) {
+    const double* q = pts + (size_t)smp[i] * 4;
+    xs[i * 4 + 0] = q[0]; xs[i * 4 + 1] = q[1]; xs[i * 4 + 2] = q[2]; xs[i * 4 + 3] = q[3];
+  }
+  double Eb[36], B[39], coeffs[11];
+  five_point_basis(xs, Eb);
+  five_point_poly_t<false>(Eb, B, coeffs, nullptr);
+  double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
+  for (int k = 0; k < 36; ++k) slot[EPOLY_EB + k] = Eb[k];
+  for (int k = 0; k < 39; ++k) slot[EPOLY_B + k] = B[k];
+  for (int k = 0; k < 11; ++k) slot[EPOLY_COEFFS + k] = coeffs[k];
+}
+
+__global__ __launch_bounds__(64) void k_roots_score_e(const VerifyParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* Tl = reinterpret_cast<double*>(smem_raw) + threadIdx.x;  // this lane's companion matrix, stride 64
+  const uint32_t pl = blockIdx.x;
+  const uint32_t pi = p.pair0 + pl;
+  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
+  if (!fs->active) return;
+  const int lane = threadIdx.x;
+  const int t = blockIdx.y * 64 + lane;
+  const int nb = (int)fs->nb;
+  if ((int)(blockIdx.y * 64) >= nb) return;
+  const uint64_t moff = p.match_off[pi];
+  const int n = (int)(p.match_off[pi + 1] - moff);
+  const double* pts = p.pts_norm + 4 * moff;
+  const dsm_camera& cam1 = p.cams[p.pairs[2 * pi]];
+  const dsm_camera& cam2 = p.cams[p.pairs[2 * pi + 1]];
+  const double max_error =
+      (image_to_world_threshold(cam1, p.opt.max_error) + image_to_world_threshold(cam2, p.opt.max_error)) / 2;
+  const double max_residual = max_error * max_error;
+  int nm = 0;
+  double mloc[90];
+  double* slot = p.models + ((size_t)pl * p.batch + (size_t)(t < nb ? t : 0)) * 90;
+  if (t < nb) {
+    double coeffs[11], rr[11], ri[11];
+    for (int k = 0; k < 11; ++k) coeffs[k] = slot[EPOLY_COEFFS + k];
+    LSEC_BEGIN4();
+    const int nroots = pl_poly_roots<11, 64>(coeffs, 11, rr, ri, Tl);
+    LSEC_END4(11);
+    if (nroots >= 0) {
+      double Eb[36], B[39];
+      for (int k = 0; k < 36; ++k) Eb[k] = slot[EPOLY_EB + k];
+      for (int k = 0; k < 39; ++k) B[k] = slot[EPOLY_B + k];
+      nm = five_point_models(Eb, B, rr, ri, nroots, mloc);
+    }
+    p.nmodels[(size_t)pl * p.batch + t] = nm;
+  }
+  LSEC_BEGIN();
+  int32_t* gc = p.counts + ((size_t)pl * p.batch + (size_t)(t < nb ? t : 0)) * 10;
+  for (int m = 0; m < nm; ++m) {
+    const double* M = mloc + m * 9;
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) cnt += (fam_residual<FAM_E>(M, pts + (size_t)i * 4) <= max_residual) ? 1 : 0;
+    gc[m] = cnt;
+    for (int k = 0; k < 9; ++k) slot[m * 9 + k] = M[k];
+  }
+  LSEC_END(13);
 }
 
 #ifdef DSM_PROFILE_SECTIONS
@@ -1621,7 +1703,17 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
   if (!p.n_chunk) return;
   const dim3 grid(p.n_chunk, (p.batch + 63) / 64);
   const size_t smem = (size_t)(p.n_max < VP_LDS_PTS ? (p.n_max > 0 ? p.n_max : 1) : VP_LDS_PTS) * 32;
-  if (fam == FAM_E) hipLaunchKernelGGL(k_solve_score<FAM_E>, grid, dim3(64), smem, st, p);
+  if (fam == FAM_E) {
+    hipLaunchKernelGGL(k_solve_e_poly, grid, dim3(64), 0, st, p);
+    hipLaunchKernelGGL(k_roots_score_e, grid, dim3(64), 100 * 64 * sizeof(double), st, p);
+    if (getenv("DSM_VERIFY_DEBUG")) {
+      int nb1 = -1, nb2 = -1, nb3 = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, k_roots_score_e, 64, 100 * 64 * sizeof(double));
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, k_roots_score_e, 64, 30000);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3, k_solve_e_poly, 64, 0);
+      fprintf(stderr, "[dsm verify] occupancy blocks/CU: roots(51200 B) %d  roots(30000 B) %d  poly %d\n", nb1, nb2, nb3);
+    }
+  }
   if (fam == FAM_F) hipLaunchKernelGGL(k_solve_score<FAM_F>, grid, dim3(64), smem, st, p);
   if (fam == FAM_H) hipLaunchKernelGGL(k_solve_score<FAM_H>, grid, dim3(64), smem, st, p);
 }

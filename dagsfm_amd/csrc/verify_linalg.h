@@ -48,31 +48,35 @@ DSM_DEV void pl_make_householder(double* x, int n, double* tau, double* beta) {
   }
 }
 
+// ES = element stride: 1 for a private matrix, 64 for a matrix whose elements are interleaved over the
+// lanes of a wave in LDS (element e of lane l at base[e * 64 + l], M = base + l)
+template <int ES = 1>
 DSM_DEV void pl_apply_householder_left(double* M, int ld, int r0, int c0, int nr, int nc, const double* ess, double tau) {
   if (nr == 1) {
-    for (int j = 0; j < nc; ++j) M[(c0 + j) * ld + r0] *= (1.0 - tau);
+    for (int j = 0; j < nc; ++j) M[((c0 + j) * ld + r0) * ES] *= (1.0 - tau);
   } else if (tau != 0.0) {
     for (int j = 0; j < nc; ++j) {
-      double* col = M + (c0 + j) * ld + r0;
+      double* col = M + ((c0 + j) * ld + r0) * ES;
       double tmp = 0.0;
-      for (int i = 1; i < nr; ++i) tmp += ess[i - 1] * col[i];
+      for (int i = 1; i < nr; ++i) tmp += ess[i - 1] * col[i * ES];
       tmp += col[0];
       col[0] -= tau * tmp;
-      for (int i = 1; i < nr; ++i) col[i] -= tau * ess[i - 1] * tmp;
+      for (int i = 1; i < nr; ++i) col[i * ES] -= tau * ess[i - 1] * tmp;
     }
   }
 }
 
+template <int ES = 1>
 DSM_DEV void pl_apply_householder_right(double* M, int ld, int r0, int c0, int nr, int nc, const double* ess, double tau) {
   if (nc == 1) {
-    for (int i = 0; i < nr; ++i) M[c0 * ld + r0 + i] *= (1.0 - tau);
+    for (int i = 0; i < nr; ++i) M[(c0 * ld + r0 + i) * ES] *= (1.0 - tau);
   } else if (tau != 0.0) {
     for (int i = 0; i < nr; ++i) {
       double tmp = 0.0;
-      for (int j = 1; j < nc; ++j) tmp += M[(c0 + j) * ld + r0 + i] * ess[j - 1];
-      tmp += M[c0 * ld + r0 + i];
-      M[c0 * ld + r0 + i] -= tau * tmp;
-      for (int j = 1; j < nc; ++j) M[(c0 + j) * ld + r0 + i] -= tau * tmp * ess[j - 1];
+      for (int j = 1; j < nc; ++j) tmp += M[((c0 + j) * ld + r0 + i) * ES] * ess[j - 1];
+      tmp += M[(c0 * ld + r0 + i) * ES];
+      M[(c0 * ld + r0 + i) * ES] -= tau * tmp;
+      for (int j = 1; j < nc; ++j) M[((c0 + j) * ld + r0 + i) * ES] -= tau * tmp * ess[j - 1];
     }
   }
 }
@@ -316,9 +320,9 @@ DSM_DEV void pl_jacobi_svd_square(const double* A_rowmajor, double* U, double* V
 // Eigenvalues of an upper-Hessenberg n x n matrix T (column-major, ld = LD, destroyed):
 // EigenSolver(C, false) for companion matrices (the Hessenberg reduction is the identity on
 // them: every sub-sub-diagonal entry is already zero).  Returns false on non-convergence.
-template <int LD>
-DSM_DEVN bool pl_hessenberg_eigenvalues(double* T, int n, double* re, double* im) {
-#define TT(r, c) T[(c) * LD + (r)]
+template <int LD, int ES>
+DSM_DEV bool pl_hessenberg_eigenvalues_impl(double* T, int n, double* re, double* im) {
+#define TT(r, c) T[((c) * LD + (r)) * ES]
   for (int i = 0; i < n; ++i) {
     re[i] = 0.0;
     im[i] = 0.0;
@@ -460,9 +464,9 @@ DSM_DEVN bool pl_hessenberg_eigenvalues(double* T, int n, double* re, double* im
               TT(k, k - 1) = -TT(k, k - 1);
             else if (!first)
               TT(k, k - 1) = beta;
-            pl_apply_householder_left(T, LD, k, k, 3, n - k, &v[1], tau);
+            pl_apply_householder_left<ES>(T, LD, k, k, 3, n - k, &v[1], tau);
             const int nr = ((iu < k + 3) ? iu : k + 3) + 1;
-            pl_apply_householder_right(T, LD, 0, k, nr, 3, &v[1], tau);
+            pl_apply_householder_right<ES>(T, LD, 0, k, nr, 3, &v[1], tau);
           }
         }
         {
@@ -471,8 +475,8 @@ DSM_DEVN bool pl_hessenberg_eigenvalues(double* T, int n, double* re, double* im
           pl_make_householder(v, 2, &tau, &beta);
           if (beta != 0.0) {
             TT(iu - 1, iu - 2) = beta;
-            pl_apply_householder_left(T, LD, iu - 1, iu - 1, 2, n - iu + 1, &v[1], tau);
-            pl_apply_householder_right(T, LD, 0, iu - 1, iu + 1, 2, &v[1], tau);
+            pl_apply_householder_left<ES>(T, LD, iu - 1, iu - 1, 2, n - iu + 1, &v[1], tau);
+            pl_apply_householder_right<ES>(T, LD, 0, iu - 1, iu + 1, 2, &v[1], tau);
           }
         }
         for (int i = imm + 2; i <= iu; ++i) {
@@ -513,10 +517,16 @@ DSM_DEVN bool pl_hessenberg_eigenvalues(double* T, int n, double* re, double* im
   return true;
 #undef TT
 }
+template <int LD>
+DSM_DEVN bool pl_hessenberg_eigenvalues(double* T, int n, double* re, double* im) {
+  return pl_hessenberg_eigenvalues_impl<LD, 1>(T, n, re, im);
+}
 
 // FindPolynomialRootsCompanionMatrix (/root/reference/src/base/polynomial.cc:208-275) for up to
 // MAXC coefficients (highest degree first).  Returns the number of roots, or -1 on failure.
-template <int MAXC>
+// ES > 1: the companion matrix lives in `ws` with element stride ES (lane-interleaved LDS) and the
+// eigenvalue iteration is inlined into the caller, so that its accesses compile to LDS instructions.
+template <int MAXC, int ES = 1>
 DSM_DEV int pl_poly_roots(const double* coeffs_all, int ncoef, double* real, double* imag, double* ws = nullptr) {
   int lead = 0;
   for (; lead < ncoef; ++lead)
@@ -568,14 +578,19 @@ DSM_DEV int pl_poly_roots(const double* coeffs_all, int ncoef, double* real, dou
   }
   const int n = nc - 1;
   constexpr int LD = MAXC - 1;
-  double C_loc[LD * LD];
-  double* C = ws ? ws : C_loc;  // optional caller-provided (LDS) workspace of LD*LD doubles
+  double C_loc[ES == 1 ? LD * LD : 1];
+  double* C;  // optional caller-provided (LDS) workspace of LD*LD doubles
+  if constexpr (ES == 1) C = ws ? ws : C_loc; else C = ws;
   for (int j = 0; j < n; ++j)
-    for (int i = 0; i < n; ++i) C[j * LD + i] = 0.0;
-  for (int i = 1; i < n; ++i) C[(i - 1) * LD + i] = 1.0;
-  for (int j = 0; j < n; ++j) C[j * LD + 0] = -coeffs[j + 1] / coeffs[0];
+    for (int i = 0; i < n; ++i) C[(j * LD + i) * ES] = 0.0;
+  for (int i = 1; i < n; ++i) C[((i - 1) * LD + i) * ES] = 1.0;
+  for (int j = 0; j < n; ++j) C[(j * LD + 0) * ES] = -coeffs[j + 1] / coeffs[0];
   double re[LD], im[LD];
-  if (!pl_hessenberg_eigenvalues<LD>(C, n, re, im)) return -1;
+  if (ES == 1) {
+    if (!pl_hessenberg_eigenvalues<LD>(C, n, re, im)) return -1;
+  } else {
+    if (!pl_hessenberg_eigenvalues_impl<LD, ES>(C, n, re, im)) return -1;
+  }
   const int effective_degree = n < degree ? n + 1 : n;
   for (int i = 0; i < effective_degree; ++i) {
     real[i] = 0.0;
@@ -693,6 +708,36 @@ DSM_DEV double wv_seq_sum(double init, int n, int lane, LoadFn load) {
   return s;
 }
 
+// The reductions INSIDE the pivoted QR of a tall matrix (rows > 9) have no order fixed by the reference
+// (Eigen's depends on its packet width): oracle/linalg.h wide_sum() defines them as 64 interleaved partial
+// sums -- lane l accumulates f(l), f(l + 64), ... -- combined by the xor butterfly 32, 16, ..., 1
+// (s_l + s_(l^o) is commutative, so every lane ends with the same bits as the oracle's tree).
+template <typename LoadFn>
+DSM_DEV double wv_tree_sum(int n, int lane, LoadFn load) {
+  double s = 0.0;
+  for (int i = lane; i < n; i += 64) s += load(i);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  return s;
+}
+// up to NC such sums at once (independent butterflies overlap their latency): out[c] = sum_i load(c, i)
+template <int NC, typename LoadFn>
+DSM_DEV void wv_tree_sums(int nc, int n, int lane, double* out, LoadFn load) {
+  double acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+  for (int i = lane; i < n; i += 64) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      if (c < nc) acc[c] += load(c, i);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] += __shfl_xor(acc[c], o);
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) out[c] = acc[c];
+}
+
 struct WvSvdShared {
   double W[81];            // working square matrix, column-major ld = dsz
   double V[81];            // 9 x 9, column-major ld 9
@@ -710,13 +755,29 @@ DSM_DEV void wv_sync() { __syncthreads(); }
 // global/LDS memory, by the whole wave.  Leaves R + essential parts in M, hco/perm in sh.
 DSM_DEV void wv_colpiv_qr(double* M, int rows, int cols, WvSvdShared* sh, int lane) {
   const int size = rows < cols ? rows : cols;
-  for (int c = 0; c < cols; ++c) {
-    const double* col = M + (size_t)c * rows;
-    const double s = wv_seq_sum(0.0, rows, lane, [col](int i) { return col[i] * col[i]; });
-    if (lane == 0) {
-      sh->norms_d[c] = sqrt(s);
-      sh->norms_u[c] = sh->norms_d[c];
-      sh->perm[c] = c;
+  const bool wide = rows > 9;  // reduction order: wide_sum() tree for tall matrices, sequential otherwise
+  if (wide) {
+    double s[9];
+    wv_tree_sums<9>(cols, rows, lane, s, [M, rows](int c, int i) {
+      const double v = M[(size_t)c * rows + i];
+      return v * v;
+    });
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+      if (lane == 0 && c < cols) {
+        sh->norms_d[c] = sqrt(s[c]);
+        sh->norms_u[c] = sh->norms_d[c];
+        sh->perm[c] = c;
+      }
+  } else {
+    for (int c = 0; c < cols; ++c) {
+      const double* col = M + (size_t)c * rows;
+      const double s = wv_seq_sum(0.0, rows, lane, [col](int i) { return col[i] * col[i]; });
+      if (lane == 0) {
+        sh->norms_d[c] = sqrt(s);
+        sh->norms_u[c] = sh->norms_d[c];
+        sh->perm[c] = c;
+      }
     }
   }
   wv_sync();
@@ -756,7 +817,8 @@ DSM_DEV void wv_colpiv_qr(double* M, int rows, int cols, WvSvdShared* sh, int la
     // makeHouseholder on column k, rows k..rows-1
     double* x = M + (size_t)k * rows + k;
     const int n = rows - k;
-    const double tail_sq = wv_seq_sum(0.0, n - 1, lane, [x](int i) { return x[i + 1] * x[i + 1]; });
+    const double tail_sq = wide ? wv_tree_sum(n - 1, lane, [x](int i) { return x[i + 1] * x[i + 1]; })
+                                : wv_seq_sum(0.0, n - 1, lane, [x](int i) { return x[i + 1] * x[i + 1]; });
     if (lane == 0) {
       const double c0 = x[0];
       if (tail_sq <= DBL_MIN) {
@@ -789,11 +851,20 @@ DSM_DEV void wv_colpiv_qr(double* M, int rows, int cols, WvSvdShared* sh, int la
       if (n == 1) {
         if (lane < nc) M[(size_t)(k + 1 + lane) * rows + k] *= (1.0 - tau);
       } else if (tau != 0.0) {
-        for (int c = 0; c < nc; ++c) {
-          const double* col = M + (size_t)(k + 1 + c) * rows + k;
-          double tmp = wv_seq_sum(0.0, n - 1, lane, [ess, col](int i) { return ess[i] * col[i + 1]; });
-          tmp += col[0];
-          if (lane == 0) sh->colbuf[c] = tmp;
+        if (wide) {
+          double tmp[8];
+          const double* col0 = M + (size_t)(k + 1) * rows + k;
+          wv_tree_sums<8>(nc, n - 1, lane, tmp, [ess, col0, rows](int c, int i) { return ess[i] * col0[(size_t)c * rows + i + 1]; });
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+            if (lane == 0 && c < nc) sh->colbuf[c] = tmp[c] + col0[(size_t)c * rows];
+        } else {
+          for (int c = 0; c < nc; ++c) {
+            const double* col = M + (size_t)(k + 1 + c) * rows + k;
+            double tmp = wv_seq_sum(0.0, n - 1, lane, [ess, col](int i) { return ess[i] * col[i + 1]; });
+            tmp += col[0];
+            if (lane == 0) sh->colbuf[c] = tmp;
+          }
         }
         wv_sync();
         for (int e = lane; e < nc * n; e += 64) {
@@ -820,7 +891,8 @@ DSM_DEV void wv_colpiv_qr(double* M, int rows, int cols, WvSvdShared* sh, int la
           wv_sync();
           if (temp2 <= norm_downdate_threshold) {
             const double* col = M + (size_t)j * rows + (k + 1);
-            const double ss = wv_seq_sum(0.0, rows - k - 1, lane, [col](int i) { return col[i] * col[i]; });
+            const double ss = wide ? wv_tree_sum(rows - k - 1, lane, [col](int i) { return col[i] * col[i]; })
+                                   : wv_seq_sum(0.0, rows - k - 1, lane, [col](int i) { return col[i] * col[i]; });
             if (lane == 0) {
               sh->norms_d[j] = sqrt(ss);
               sh->norms_u[j] = sh->norms_d[j];
@@ -920,9 +992,25 @@ DSM_DEV void wv_jacobi_sweeps(WvSvdShared* sh, int dsz, double scale, double* sv
 __device__ unsigned long long g_dsm_prof[16];
 #define LSEC_BEGIN() const long long lt__0 = clock64()
 #define LSEC_END(sec) do { if (threadIdx.x == 0) atomicAdd(&g_dsm_prof[sec], (unsigned long long)(clock64() - lt__0)); } while (0)
+#define LSEC_BEGIN2() const long long lt__2 = clock64()
+#define LSEC_END2(sec) do { if (threadIdx.x == 0) atomicAdd(&g_dsm_prof[sec], (unsigned long long)(clock64() - lt__2)); } while (0)
+#define LSEC_BEGIN3() const long long lt__3 = clock64()
+#define LSEC_END3(sec) do { if (threadIdx.x == 0) atomicAdd(&g_dsm_prof[sec], (unsigned long long)(clock64() - lt__3)); } while (0)
+#define LSEC_BEGIN4() const long long lt__4 = clock64()
+#define LSEC_END4(sec) do { if (threadIdx.x == 0) atomicAdd(&g_dsm_prof[sec], (unsigned long long)(clock64() - lt__4)); } while (0)
+#define LSEC_BEGIN5() const long long lt__5 = clock64()
+#define LSEC_END5(sec) do { if (threadIdx.x == 0) atomicAdd(&g_dsm_prof[sec], (unsigned long long)(clock64() - lt__5)); } while (0)
 #else
 #define LSEC_BEGIN() do {} while (0)
 #define LSEC_END(sec) do {} while (0)
+#define LSEC_BEGIN2() do {} while (0)
+#define LSEC_END2(sec) do {} while (0)
+#define LSEC_BEGIN3() do {} while (0)
+#define LSEC_END3(sec) do {} while (0)
+#define LSEC_BEGIN4() do {} while (0)
+#define LSEC_END4(sec) do {} while (0)
+#define LSEC_BEGIN5() do {} while (0)
+#define LSEC_END5(sec) do {} while (0)
 #endif
 DSM_DEV void wv_svd_V_mx9(double* A, double* At, int m, WvSvdShared* sh, double* sv, int lane) {
   // scale = max |a_ij| (exact, order independent)

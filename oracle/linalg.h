@@ -8,10 +8,17 @@
 //   ColPivHouseholderQR (LAPACK-style norm downdating)  HouseholderSequence::evalTo
 //   EigenSolver/RealSchur (Hessenberg + Francis double-shift QR, eigenvalues only)
 //   PartialPivLU::solve, Matrix3d::inverse (cofactors), Quaterniond(Matrix3d)
-// Reductions (dot products, norms) are accumulated sequentially left to right; Eigen's
-// vectorised association order is not reproducible here, so oracle == Eigen only to rounding
-// (checked against numpy and the reference's known-answer tests in tests/), while
-// GPU == oracle is bit-exact because the device code uses the same operation order.
+// Reductions (dot products, norms) inside these Eigen routines have no order the reference fixes:
+// Eigen's own association order depends on its packet width and unrolling (SSE2 here, AVX
+// elsewhere), so oracle == Eigen only to rounding (checked against numpy and the reference's
+// known-answer tests in tests/).  The oracle therefore picks one definite order and the device
+// code uses exactly the same one, which makes GPU == oracle bit-exact:
+//   * short vectors (every routine on matrices with <= 9 rows): sequential, left to right;
+//   * the pivoted QR of a tall matrix (rows > 9: the local-optimisation / final least-squares
+//     systems with one or two rows per correspondence): wide_sum() below -- 64 interleaved partial
+//     sums combined by a fixed binary tree, the natural order of a 64-lane wavefront.
+// Sums the reference itself writes as a sequential loop (centroids, residual_sum, ...) are NOT
+// Eigen reductions and stay sequential everywhere (two_view.cc).
 #ifndef ORACLE_LINALG_H_
 #define ORACLE_LINALG_H_
 
@@ -32,11 +39,27 @@ struct Mat {
   double operator()(int r, int c) const { return a[static_cast<size_t>(c) * rows + r]; }
 };
 
+// sum_{i < n} f(i) in the "wide" order: partial[i % 64] accumulates f(i) in increasing i, then
+// partial[l] += partial[l + o] for o = 32, 16, 8, 4, 2, 1.
+template <typename F>
+inline double wide_sum(int n, F f) {
+  double part[64];
+  for (int l = 0; l < 64; ++l) part[l] = 0.0;
+  for (int i = 0; i < n; ++i) part[i & 63] += f(i);
+  for (int o = 32; o > 0; o >>= 1)
+    for (int l = 0; l < o; ++l) part[l] += part[l + o];
+  return part[0];
+}
+
 // ---- Householder (Eigen/src/Householder/Householder.h) -------------------------------------
 // makeHouseholder on x[0..n): returns tau, beta; essential part = x[1..n) / (x0 - beta).
-inline void make_householder(double* x, int n, double* tau, double* beta) {
+inline void make_householder(double* x, int n, double* tau, double* beta, bool wide = false) {
   double tail_sq = 0.0;
-  for (int i = 1; i < n; ++i) tail_sq += x[i] * x[i];
+  if (wide) {
+    tail_sq = wide_sum(n - 1, [x](int i) { return x[i + 1] * x[i + 1]; });
+  } else {
+    for (int i = 1; i < n; ++i) tail_sq += x[i] * x[i];
+  }
   const double c0 = x[0];
   const double tol = DBL_MIN;
   if (tail_sq <= tol) {
@@ -53,13 +76,19 @@ inline void make_householder(double* x, int n, double* tau, double* beta) {
 }
 
 // M.block(r0,c0,nr,nc).applyHouseholderOnTheLeft(essential, tau)
-inline void apply_householder_left(Mat& M, int r0, int c0, int nr, int nc, const double* ess, double tau) {
+inline void apply_householder_left(Mat& M, int r0, int c0, int nr, int nc, const double* ess, double tau,
+                                   bool wide = false) {
   if (nr == 1) {
     for (int j = 0; j < nc; ++j) M(r0, c0 + j) *= (1.0 - tau);
   } else if (tau != 0.0) {
     for (int j = 0; j < nc; ++j) {
       double tmp = 0.0;
-      for (int i = 1; i < nr; ++i) tmp += ess[i - 1] * M(r0 + i, c0 + j);
+      if (wide) {
+        const Mat& Mc = M;
+        tmp = wide_sum(nr - 1, [&](int i) { return ess[i] * Mc(r0 + i + 1, c0 + j); });
+      } else {
+        for (int i = 1; i < nr; ++i) tmp += ess[i - 1] * M(r0 + i, c0 + j);
+      }
       tmp += M(r0, c0 + j);
       M(r0, c0 + j) -= tau * tmp;
       for (int i = 1; i < nr; ++i) M(r0 + i, c0 + j) -= tau * ess[i - 1] * tmp;
@@ -94,9 +123,15 @@ struct ColPivQR {
     hcoeffs.assign(size, 0.0);
     std::vector<int> transp(cols);
     std::vector<double> norms_updated(cols), norms_direct(cols);
+    const bool wide = rows > 9;  // reduction order, see the header of this file
+    const Mat& cq = qr;
     for (int k = 0; k < cols; ++k) {
       double s = 0.0;
-      for (int i = 0; i < rows; ++i) s += qr(i, k) * qr(i, k);
+      if (wide) {
+        s = wide_sum(rows, [&](int i) { return cq(i, k) * cq(i, k); });
+      } else {
+        for (int i = 0; i < rows; ++i) s += qr(i, k) * qr(i, k);
+      }
       norms_direct[k] = std::sqrt(s);
       norms_updated[k] = norms_direct[k];
     }
@@ -120,10 +155,11 @@ struct ColPivQR {
         std::swap(norms_direct[k], norms_direct[biggest]);
       }
       double tau, beta;
-      make_householder(&qr(k, k), rows - k, &tau, &beta);
+      make_householder(&qr(k, k), rows - k, &tau, &beta, wide);
       hcoeffs[k] = tau;
       qr(k, k) = beta;
-      apply_householder_left(qr, k, k + 1, rows - k, cols - k - 1, &qr.a[static_cast<size_t>(k) * rows + k + 1], tau);
+      apply_householder_left(qr, k, k + 1, rows - k, cols - k - 1, &qr.a[static_cast<size_t>(k) * rows + k + 1], tau,
+                             wide);
       for (int j = k + 1; j < cols; ++j) {
         if (norms_updated[j] != 0.0) {
           double temp = std::fabs(qr(k, j)) / norms_updated[j];
@@ -133,7 +169,11 @@ struct ColPivQR {
           const double temp2 = temp * (ratio * ratio);
           if (temp2 <= norm_downdate_threshold) {
             double s = 0.0;
-            for (int i = k + 1; i < rows; ++i) s += qr(i, j) * qr(i, j);
+            if (wide) {
+              s = wide_sum(rows - k - 1, [&](int i) { return cq(k + 1 + i, j) * cq(k + 1 + i, j); });
+            } else {
+              for (int i = k + 1; i < rows; ++i) s += qr(i, j) * qr(i, j);
+            }
             norms_direct[j] = std::sqrt(s);
             norms_updated[j] = norms_direct[j];
           } else {
