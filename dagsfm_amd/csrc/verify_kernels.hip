@@ -1416,9 +1416,10 @@ __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_solve_score(cons
 // E family: the minimal solve is split in two kernels.  One lane per hypothesis keeps ~5 KB of matrices in
 // scratch memory, and with thousands of resident waves that scratch lives in HBM; two thirds of the time
 // went into the companion-matrix eigenvalue iteration alone.  k_solve_e_poly stops at the determinant
-// polynomial and parks (Eb, B, coefficients) in the hypothesis' model slot; k_roots_score_e runs the
-// eigenvalue iteration on a lane-interleaved 10 x 10 matrix in LDS (element e of lane l at T[e * 64 + l]:
-// conflict-free, no memory traffic), then builds and scores the models.  Same operations, same order.
+// polynomial and parks (Eb, B, coefficients) in the hypothesis' model slot; k_roots_e runs the eigenvalue
+// iteration on a lane-interleaved 10 x 10 matrix in LDS (element e of lane l at T[e * 64 + l]: conflict-free,
+// no memory traffic; 51 KB per wave, so it is kept free of everything else); k_models_score_e builds and
+// scores the models at full occupancy.  Same operations, same order.
 #define EPOLY_EB 0
 #define EPOLY_B 36
 #define EPOLY_COEFFS 75
@@ -1445,50 +1446,95 @@ __global__ __launch_bounds__(64, 4) void k_solve_e_poly(const VerifyParams p) {
   for (int k = 0; k < 11; ++k) slot[EPOLY_COEFFS + k] = coeffs[k];
 }
 
-__global__ __launch_bounds__(64) void k_roots_score_e(const VerifyParams p) {
+// roots of the determinant polynomial: slot coefficients -> slot roots (real parts) + nmodels = root count /
+// real-root mask for k_models_score_e
+__global__ __launch_bounds__(64) void k_roots_e(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* Tl = reinterpret_cast<double*>(smem_raw) + threadIdx.x;  // this lane's companion matrix, stride 64
   const uint32_t pl = blockIdx.x;
   const uint32_t pi = p.pair0 + pl;
   const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
   if (!fs->active) return;
+  const int t = blockIdx.y * 64 + threadIdx.x;
+  if (t >= (int)fs->nb) return;
+  double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
+  double coeffs[11], rr[11], ri[11];
+  for (int k = 0; k < 11; ++k) coeffs[k] = slot[EPOLY_COEFFS + k];
+  LSEC_BEGIN4();
+  const int nroots = pl_poly_roots<11, 64>(coeffs, 11, rr, ri, Tl);
+  LSEC_END4(11);
+  int code = 0;  // bits 0..9: root i is real (essential_matrix.cc:126), bits 16..: number of roots
+  if (nroots > 0) {
+    for (int i = 0; i < nroots; ++i) {
+      if (!(fabs(ri[i]) > 1e-10)) code |= 1 << i;
+      slot[EPOLY_COEFFS + i] = rr[i];
+    }
+    code |= nroots << 16;
+  }
+  p.nmodels[(size_t)pl * p.batch + t] = code;
+}
+
+// models of every hypothesis (one lane each), then the inlier counts of ALL models of the block's 64
+// hypotheses with the lanes spread over the correspondences (a hypothesis has 0..10 models: scoring them
+// lane-per-hypothesis would run every lane as long as the one with the most models).
+__global__ __launch_bounds__(64, 4) void k_models_score_e(const VerifyParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* spts = reinterpret_cast<double*>(smem_raw);  // min(n_max, VP_LDS_PTS) x 4 doubles
+  const uint32_t pl = blockIdx.x;
+  const uint32_t pi = p.pair0 + pl;
+  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
+  if (!fs->active) return;
   const int lane = threadIdx.x;
-  const int t = blockIdx.y * 64 + lane;
+  const int t0 = blockIdx.y * 64;
+  const int t = t0 + lane;
   const int nb = (int)fs->nb;
-  if ((int)(blockIdx.y * 64) >= nb) return;
+  if (t0 >= nb) return;
   const uint64_t moff = p.match_off[pi];
   const int n = (int)(p.match_off[pi + 1] - moff);
-  const double* pts = p.pts_norm + 4 * moff;
+  const double* gpts = p.pts_norm + 4 * moff;
+  const bool in_lds = n <= VP_LDS_PTS;
+  if (in_lds)
+    for (int e = lane; e < 4 * n; e += 64) spts[e] = gpts[e];
+  const double* pts = in_lds ? spts : gpts;
   const dsm_camera& cam1 = p.cams[p.pairs[2 * pi]];
   const dsm_camera& cam2 = p.cams[p.pairs[2 * pi + 1]];
   const double max_error =
       (image_to_world_threshold(cam1, p.opt.max_error) + image_to_world_threshold(cam2, p.opt.max_error)) / 2;
   const double max_residual = max_error * max_error;
   int nm = 0;
-  double mloc[90];
-  double* slot = p.models + ((size_t)pl * p.batch + (size_t)(t < nb ? t : 0)) * 90;
+  double* slots = p.models + ((size_t)pl * p.batch + t0) * 90;
   if (t < nb) {
-    double coeffs[11], rr[11], ri[11];
-    for (int k = 0; k < 11; ++k) coeffs[k] = slot[EPOLY_COEFFS + k];
-    LSEC_BEGIN4();
-    const int nroots = pl_poly_roots<11, 64>(coeffs, 11, rr, ri, Tl);
-    LSEC_END4(11);
-    if (nroots >= 0) {
-      double Eb[36], B[39];
+    double* slot = slots + (size_t)lane * 90;
+    const int code = p.nmodels[(size_t)pl * p.batch + t];
+    const int nroots = code >> 16;
+    if (nroots > 0) {
+      double Eb[36], B[39], rr[11], ri[11], mloc[90];
       for (int k = 0; k < 36; ++k) Eb[k] = slot[EPOLY_EB + k];
       for (int k = 0; k < 39; ++k) B[k] = slot[EPOLY_B + k];
+      for (int i = 0; i < nroots; ++i) {
+        rr[i] = slot[EPOLY_COEFFS + i];
+        ri[i] = ((code >> i) & 1) ? 0.0 : 1.0;  // five_point_models only tests |imag| > 1e-10
+      }
       nm = five_point_models(Eb, B, rr, ri, nroots, mloc);
+      for (int k = 0; k < nm * 9; ++k) slot[k] = mloc[k];
     }
     p.nmodels[(size_t)pl * p.batch + t] = nm;
   }
+  __syncthreads();  // models (global) and points (LDS) visible to the whole wave
   LSEC_BEGIN();
-  int32_t* gc = p.counts + ((size_t)pl * p.batch + (size_t)(t < nb ? t : 0)) * 10;
-  for (int m = 0; m < nm; ++m) {
-    const double* M = mloc + m * 9;
-    int cnt = 0;
-    for (int i = 0; i < n; ++i) cnt += (fam_residual<FAM_E>(M, pts + (size_t)i * 4) <= max_residual) ? 1 : 0;
-    gc[m] = cnt;
-    for (int k = 0; k < 9; ++k) slot[m * 9 + k] = M[k];
+  int32_t* counts = p.counts + ((size_t)pl * p.batch + t0) * 10;
+  const int ntr = (nb - t0) < 64 ? (nb - t0) : 64;
+  for (int tt = 0; tt < ntr; ++tt) {
+    const int nmt = __builtin_amdgcn_readlane(nm, tt);
+    for (int m = 0; m < nmt; ++m) {
+      const double* Mg = slots + (size_t)tt * 90 + m * 9;
+      double M[9];
+      for (int k = 0; k < 9; ++k) M[k] = Mg[k];
+      int cnt = 0;
+      for (int i = lane; i < n; i += 64) cnt += (fam_residual<FAM_E>(M, pts + (size_t)i * 4) <= max_residual) ? 1 : 0;
+      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+      if (lane == 0) counts[tt * 10 + m] = cnt;
+    }
   }
   LSEC_END(13);
 }
@@ -1705,14 +1751,8 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
   const size_t smem = (size_t)(p.n_max < VP_LDS_PTS ? (p.n_max > 0 ? p.n_max : 1) : VP_LDS_PTS) * 32;
   if (fam == FAM_E) {
     hipLaunchKernelGGL(k_solve_e_poly, grid, dim3(64), 0, st, p);
-    hipLaunchKernelGGL(k_roots_score_e, grid, dim3(64), 100 * 64 * sizeof(double), st, p);
-    if (getenv("DSM_VERIFY_DEBUG")) {
-      int nb1 = -1, nb2 = -1, nb3 = -1;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, k_roots_score_e, 64, 100 * 64 * sizeof(double));
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, k_roots_score_e, 64, 30000);
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3, k_solve_e_poly, 64, 0);
-      fprintf(stderr, "[dsm verify] occupancy blocks/CU: roots(51200 B) %d  roots(30000 B) %d  poly %d\n", nb1, nb2, nb3);
-    }
+    hipLaunchKernelGGL(k_roots_e, grid, dim3(64), 100 * 64 * sizeof(double), st, p);
+    hipLaunchKernelGGL(k_models_score_e, grid, dim3(64), smem, st, p);
   }
   if (fam == FAM_F) hipLaunchKernelGGL(k_solve_score<FAM_F>, grid, dim3(64), smem, st, p);
   if (fam == FAM_H) hipLaunchKernelGGL(k_solve_score<FAM_H>, grid, dim3(64), smem, st, p);
