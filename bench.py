@@ -177,7 +177,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    k1_ms, k1_launches, kv_ms = 0.0, 0, 0.0
+    k1_ms, k1_launches, kv_ms, k1b_ms = 0.0, 0, 0.0, 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -185,6 +185,7 @@ def main():
         ms, nl = ctx.match_kernel_time()
         k1_ms += ms
         k1_launches += nl
+        k1b_ms += ctx.match_resolve_time()
         if verify:
             kv_ms += ctx.verify_kernel_time()
     barrier()
@@ -226,13 +227,17 @@ def main():
                 "pairs_with_geometry": res["verified"], "hypotheses_per_step": res["models"],
                 "parallelism": "pair-sharded x%d + RCCL all-gather" % world},
             "hypotheses_per_s": res["models"] * args.steps / dt if verify else None,
-            "kernel_ms_per_step": {"k1_best_rows": k1_ms / args.steps, "k_verify_pairs": kv_ms / args.steps},
+            "kernel_ms_per_step": {"k1_best_rows": k1_ms / args.steps, "k1_resolve_index": k1b_ms / args.steps,
+                                   "k_verify_pairs": kv_ms / args.steps},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": INT8_MFMA_DENSE_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / INT8_MFMA_DENSE_PEAK, "traffic": traffic,
                          "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) + "
                                          "WRITE_SIZE in separate passes (profiles/r01_k1_pmc.json); null when not collected for this workload",
                          "kernel": "k1_best_rows", "avg_launch_ms": 1e3 * avg_launch_s, "launches": k1_launches,
-                         "note": "int8 ops (2 per MAC) counted as flops; algorithmic 2*128*N^2 per pair"},
+                         "executed_frac": 2.0 * achieved / INT8_MFMA_DENSE_PEAK,
+                         "note": "int8 ops (2 per MAC) counted as flops; algorithmic = ONE 2*128*N1*N2 distance matrix per pair "
+                                 "(SURVEY.md 8d).  The kernel issues twice that (one directed pass per direction of the "
+                                 "cross-check, each with its own fused top-2): executed_frac is the matrix-pipe view"},
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(images, pairs, args.cpu_seconds, verify, cams, topts, user_seed)
