@@ -652,6 +652,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.n_pairs = n_pairs;
   vp.n_max = n_max;
   vp.stage_filter = stage_filter;
+  vp.sampler_serial = getenv("DSM_SAMPLER_SERIAL") ? 1 : 0;
   if (!ctx->vev0) {
     HIPCHK(ctx, hipEventCreate(&ctx->vev0));
     HIPCHK(ctx, hipEventCreate(&ctx->vev1));
@@ -911,15 +912,21 @@ int dsm_estimate_two_view_geometry(dsm_ctx* ctx, const dsm_camera* camera1, cons
 int dsm_debug_sample_sequence(dsm_ctx* ctx, uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out) {
   if (!ctx || !out || k == 0 || k > total) return DSM_ERR_INVALID_ARGUMENT;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  DevBuf o, idx;
+  DevBuf o, idx, tmp7;
   HIPCHK(ctx, o.reserve((size_t)k * n_draws * 4 + 4));
   HIPCHK(ctx, idx.reserve((size_t)total * 4));
-  launch_debug_samples(seed, k, total, n_draws, o.as<uint32_t>(), idx.as<uint32_t>(), ctx->stream);
+  HIPCHK(ctx, tmp7.reserve((size_t)n_draws * 7 * 4 + 4));
+  // 1 (default): the wave sampler of the product path; 0: lane-0 reference loop; 2: the sampler's serial replay path
+  const char* mode_env = getenv("DSM_DEBUG_SAMPLER_MODE");
+  int mode = mode_env ? atoi(mode_env) : 1;
+  if (!(k == 1 || k == 4 || k == 5 || k == 7)) mode = 0;
+  launch_debug_samples(seed, k, total, n_draws, o.as<uint32_t>(), idx.as<uint32_t>(), tmp7.as<uint32_t>(), mode, ctx->stream);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipMemcpy(out, o.p, (size_t)k * n_draws * 4, hipMemcpyDeviceToHost));
   o.release();
   idx.release();
+  tmp7.release();
   return DSM_OK;
 }
 

@@ -90,6 +90,7 @@ struct VerifyParams {
   uint32_t n_pairs;
   uint32_t n_max;              // max matches of any pair in this launch
   int32_t stage_filter;        // apply SiftFeatureMatcher::Match's min_num_inliers post-filter
+  int32_t sampler_serial;      // test hook (DSM_SAMPLER_SERIAL): force the sampler's serial replay path
 };
 
 size_t verify_scratch_bytes_per_block(uint32_t n_max);
@@ -104,7 +105,8 @@ void launch_vp_final(const VerifyParams& p, uint32_t n_blocks, hipStream_t st);
 uint32_t vp_batch(int fam, uint32_t max_trials);
 uint32_t vp_maxm(int fam);
 void debug_read_prof(unsigned long long* out16);
-void launch_debug_samples(uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out, uint32_t* idx, hipStream_t st);
+void launch_debug_samples(uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out, uint32_t* idx, uint32_t* tmp7,
+                          int mode, hipStream_t st);
 void launch_compact_inliers(const uint64_t* match_off, const uint64_t* inl_off, const uint32_t* inl_counts,
                             const uint32_t* src, uint32_t* dst, uint32_t n_pairs, hipStream_t st);
 

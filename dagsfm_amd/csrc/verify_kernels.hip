@@ -107,6 +107,159 @@ DSM_DEV uint32_t uniform_u32(MtState* s, uint32_t a, uint32_t b) {
   return (uint32_t)(product >> 32) + a;
 }
 
+// ---- the same generator driven by the whole wave ---------------------------------------------------
+DSM_DEV uint32_t mt_temper(uint32_t y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+DSM_DEV uint32_t mt_mix(uint32_t hi, uint32_t lo) {
+  const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+  return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+// The state regeneration of mt_next by 64 lanes: element k needs the OLD mt[k], mt[k+1] and mt[k+397] (old
+// for k < 227, already regenerated for k >= 227), so chunks of 64 consecutive k in ascending order are
+// independent inside a chunk (every lane reads before any lane of the chunk writes).
+DSM_DEV void mt_twist_wave(uint32_t* mt, int lane) {
+  for (int k0 = 0; k0 < 623; k0 += 64) {
+    const int k = k0 + lane;
+    uint32_t v = 0;
+    if (k < 623) v = mt[k < 227 ? k + 397 : k - 227] ^ mt_mix(mt[k], mt[k + 1]);
+    wv_sync();
+    if (k < 623) mt[k] = v;
+    wv_sync();
+  }
+  if (lane == 0) mt[623] = mt[396] ^ mt_mix(mt[623], mt[0]);
+  wv_sync();
+}
+// state after `target` further mt_next calls, without producing them (uniform over the wave)
+DSM_DEV void mt_skip_wave(MtState* s, uint32_t target, int lane) {
+  uint32_t pos = (uint32_t)s->mti + target;
+  wv_sync();
+  while (pos > 624u) {  // a call that finds mti >= 624 regenerates first
+    mt_twist_wave(s->mt, lane);
+    pos -= 624u;
+  }
+  if (lane == 0) s->mti = (int)pos;
+  wv_sync();
+}
+
+// LDS work area of wv_draw_samples
+struct WvSampler {
+  uint32_t raw[640];  // tempered outputs not yet consumed (<= 6 left over + one regenerated block)
+  uint32_t jb[640];   // swap partners of the draws of one block
+};
+
+// RandomSampler::Sample x nb (src/optim/random_sampler.cc:43-62) for K-element samples out of n, by the wave:
+// draw d of a trial picks j = uniform_int_distribution(i, n-1) and swaps sidx[i] <-> sidx[j].  The generator
+// outputs of a whole block are tempered and mapped through Lemire's multiply-shift by all lanes; only the
+// swaps -- a true sequential chain through the index array -- are left to lane 0.  A draw that Lemire's
+// method would reject (probability (2^32 mod range) / 2^32, ~6e-8 at 256 matches) shifts every later draw:
+// the first block that contains one, and everything after it, is replayed serially with the same
+// semantics as uniform_u32 above.  smp: [nb][7] samples; de (optional): generator calls after each trial.
+template <int K_>
+DSM_DEV void wv_draw_samples(MtState* gen, WvSampler* ws, uint32_t* sidx, uint32_t n, int nb, uint32_t* smp, uint32_t* de,
+                             int lane, bool force_serial) {
+  const int mti0 = gen->mti;
+  int have = 624 - mti0;
+  if (have < 0) have = 0;
+  for (int e = lane; e < have; e += 64) ws->raw[e] = mt_temper(gen->mt[mti0 + e]);
+  int pos = 0;
+  uint32_t calls = 0;
+  int t = 0;
+  bool serial = force_serial;
+  wv_sync();
+  while (t < nb && !serial) {
+    if (have < K_) {  // move the left-over to the front, regenerate, temper the new block behind it
+      const uint32_t keep = (lane < have) ? ws->raw[pos + lane] : 0u;
+      wv_sync();
+      if (lane < have) ws->raw[lane] = keep;
+      mt_twist_wave(gen->mt, lane);
+      for (int e = lane; e < 624; e += 64) ws->raw[have + e] = mt_temper(gen->mt[e]);
+      pos = 0;
+      have += 624;
+      wv_sync();
+    }
+    int nt = have / K_;
+    if (nt > nb - t) nt = nb - t;
+    const int nd = nt * K_;
+    bool rej = false;
+    for (int e = lane; e < nd; e += 64) {
+      const uint32_t i = (uint32_t)(e % K_);  // a block starts at a trial boundary
+      const uint32_t range = n - i;
+      const uint64_t product = (uint64_t)ws->raw[pos + e] * (uint64_t)range;
+      const uint32_t low = (uint32_t)product;
+      if (low < range) {
+        const uint32_t threshold = (0u - range) % range;
+        if (low < threshold) rej = true;
+      }
+      ws->jb[e] = (uint32_t)(product >> 32) + i;
+    }
+    wv_sync();
+    if (__ballot(rej) != 0ull) {
+      serial = true;
+      break;
+    }
+    if (lane == 0) {
+      for (int tt = 0; tt < nt; ++tt) {
+        for (int i = 0; i < K_; ++i) {
+          const uint32_t j = ws->jb[tt * K_ + i];
+          const uint32_t a = sidx[i];
+          sidx[i] = sidx[j];
+          sidx[j] = a;
+        }
+        for (int i = 0; i < K_; ++i) smp[(size_t)(t + tt) * 7 + i] = sidx[i];
+        if (de) de[t + tt] = calls + (uint32_t)(tt + 1) * K_;
+      }
+    }
+    pos += nd;
+    have -= nd;
+    calls += (uint32_t)nd;
+    t += nt;
+    wv_sync();
+  }
+  if (lane == 0) {
+    if (serial && t < nb) {
+      gen->mti = 624;  // every output of the current block is in raw[]; mt_next regenerates when raw[] runs dry
+      auto next = [&]() -> uint32_t {
+        ++calls;
+        if (have > 0) {
+          --have;
+          return ws->raw[pos++];
+        }
+        return mt_next(gen);
+      };
+      for (; t < nb; ++t) {
+        for (uint32_t i = 0; i < (uint32_t)K_; ++i) {
+          const uint32_t range = n - i;
+          uint64_t product = (uint64_t)next() * (uint64_t)range;
+          uint32_t low = (uint32_t)product;
+          if (low < range) {
+            const uint32_t threshold = (0u - range) % range;
+            while (low < threshold) {
+              product = (uint64_t)next() * (uint64_t)range;
+              low = (uint32_t)product;
+            }
+          }
+          const uint32_t j = (uint32_t)(product >> 32) + i;
+          const uint32_t a = sidx[i];
+          sidx[i] = sidx[j];
+          sidx[j] = a;
+        }
+        for (int i = 0; i < K_; ++i) smp[(size_t)t * 7 + i] = sidx[i];
+        if (de) de[t] = calls;
+      }
+      if (have > 0) gen->mti = 624 - have;
+    } else {
+      gen->mti = 624 - have;
+    }
+    gen->calls = calls;
+  }
+  wv_sync();
+}
+
 // Per-pair generator record in global memory: [0..623] state, [624] index at the end of the last sampling;
 // [640..1263] + [1264] the snapshot taken before the last sampling round; [1265] draws to skip from the
 // snapshot, [1266] != 0: the next consumer must resume from the snapshot + skip (an early stop left the
@@ -121,14 +274,11 @@ DSM_DEV void generator_load(MtState* sm, uint32_t* st, int lane) {
   const uint32_t* src = use_snap ? st + PS_SNAP : st;
   for (int i = lane; i < 624; i += 64) sm->mt[i] = src[i];
   wv_sync();
-  if (lane == 0) {
-    sm->mti = (int)src[624];
-    if (use_snap) {
-      const uint32_t target = st[PS_SKIP];
-      sm->calls = 0;
-      while (sm->calls < target) (void)mt_next(sm);
-      st[PS_USE_SNAP] = 0;
-    }
+  if (lane == 0) sm->mti = (int)src[624];
+  wv_sync();
+  if (use_snap) {
+    mt_skip_wave(sm, st[PS_SKIP], lane);
+    if (lane == 0) st[PS_USE_SNAP] = 0;
   }
   wv_sync();
 }
@@ -1305,12 +1455,13 @@ uint32_t vp_batch(int fam, uint32_t max_trials) {
 }
 uint32_t vp_maxm(int fam) { return fam == FAM_E ? 10u : (fam == FAM_F ? 3u : 1u); }
 
-#define SAMPLER_PREFIX (((sizeof(MtState) + 15) / 16) * 16)
+#define SAMPLER_PREFIX (((sizeof(MtState) + sizeof(WvSampler) + 15) / 16) * 16)
 
 template <int FAM>
 __global__ __launch_bounds__(64) void k_sample(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   MtState* gen = reinterpret_cast<MtState*>(smem_raw);
+  WvSampler* ws = reinterpret_cast<WvSampler*>(smem_raw + sizeof(MtState));
   uint32_t* sidx = reinterpret_cast<uint32_t*>(smem_raw + SAMPLER_PREFIX);
   typedef Fam<FAM> F;
   const int lane = threadIdx.x;
@@ -1333,23 +1484,9 @@ __global__ __launch_bounds__(64) void k_sample(const VerifyParams p) {
     const int nb = (int)(remaining < p.batch ? remaining : p.batch);
     generator_store(gen, st + PS_SNAP, lane);  // snapshot before this round's draws
     wv_sync();
-    if (lane == 0) {
-      gen->calls = 0;
-      const uint32_t last_idx = (uint32_t)(n - 1);
-      uint32_t* smp = p.samples + ((size_t)pl * p.batch) * 7;
-      uint32_t* de = p.draws_end + (size_t)pl * p.batch;
-      for (int t = 0; t < nb; ++t) {
-        for (uint32_t i = 0; i < (uint32_t)F::K; ++i) {
-          const uint32_t j = uniform_u32(gen, i, last_idx);
-          const uint32_t a = sidx[i];
-          sidx[i] = sidx[j];
-          sidx[j] = a;
-        }
-        for (int i = 0; i < F::K; ++i) smp[t * 7 + i] = sidx[i];
-        de[t] = gen->calls;
-      }
-      fs->nb = (uint32_t)nb;
-    }
+    wv_draw_samples<F::K>(gen, ws, sidx, (uint32_t)n, nb, p.samples + ((size_t)pl * p.batch) * 7,
+                          p.draws_end + (size_t)pl * p.batch, lane, p.sampler_serial != 0);
+    if (lane == 0) fs->nb = (uint32_t)nb;
     wv_sync();
     generator_store(gen, st, lane);
     for (int i = lane; i < n; i += 64) sg[i] = sidx[i];
@@ -1798,23 +1935,46 @@ void launch_compact_inliers(const uint64_t* match_off, const uint64_t* inl_off, 
 
 // ------------------------------------------------------------------------------------ debug hooks
 // Sample sequence of the device sampler (MT19937 + Lemire + partial Fisher-Yates) for parity tests.
-__global__ void k_debug_samples(uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out, uint32_t* idx) {
+__global__ void k_debug_samples(uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out, uint32_t* idx,
+                                uint32_t* tmp7, int mode) {
   __shared__ MtState sm;
-  if (threadIdx.x == 0) {
+  __shared__ WvSampler ws;
+  const int lane = threadIdx.x;
+  if (lane == 0) {
     mt_seed(&sm, seed);
     sm.calls = 0;
     for (uint32_t i = 0; i < total; ++i) idx[i] = i;
-    for (uint32_t d = 0; d < n_draws; ++d) {
-      for (uint32_t i = 0; i < k; ++i) {
-        const uint32_t j = uniform_u32(&sm, i, total - 1);
-        const uint32_t a = idx[i];
-        idx[i] = idx[j];
-        idx[j] = a;
+  }
+  __syncthreads();
+  if (mode == 0) {  // lane 0 alone, uniform_u32
+    if (lane == 0) {
+      for (uint32_t d = 0; d < n_draws; ++d) {
+        for (uint32_t i = 0; i < k; ++i) {
+          const uint32_t j = uniform_u32(&sm, i, total - 1);
+          const uint32_t a = idx[i];
+          idx[i] = idx[j];
+          idx[j] = a;
+        }
+        for (uint32_t i = 0; i < k; ++i) out[d * k + i] = idx[i];
       }
-      for (uint32_t i = 0; i < k; ++i) out[d * k + i] = idx[i];
     }
+    return;
+  }
+  // wave sampler (mode 1) / its serial replay path from the first block on (mode 2); two calls back to back so
+  // that the hand-over of the generator position between rounds is covered too
+  const int n1 = (int)(n_draws / 2), n2 = (int)n_draws - n1;
+  for (int part = 0; part < 2; ++part) {
+    const int nb = part ? n2 : n1;
+    if (k == 1) wv_draw_samples<1>(&sm, &ws, idx, total, nb, tmp7, nullptr, lane, mode == 2);
+    if (k == 4) wv_draw_samples<4>(&sm, &ws, idx, total, nb, tmp7, nullptr, lane, mode == 2);
+    if (k == 5) wv_draw_samples<5>(&sm, &ws, idx, total, nb, tmp7, nullptr, lane, mode == 2);
+    if (k == 7) wv_draw_samples<7>(&sm, &ws, idx, total, nb, tmp7, nullptr, lane, mode == 2);
+    __syncthreads();
+    for (int e = lane; e < nb * (int)k; e += 64) out[(size_t)(part ? n1 : 0) * k + e] = tmp7[(e / k) * 7 + (e % k)];
+    __syncthreads();
   }
 }
-void launch_debug_samples(uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out, uint32_t* idx, hipStream_t st) {
-  hipLaunchKernelGGL(k_debug_samples, dim3(1), dim3(64), 0, st, seed, k, total, n_draws, out, idx);
+void launch_debug_samples(uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out, uint32_t* idx, uint32_t* tmp7,
+                          int mode, hipStream_t st) {
+  hipLaunchKernelGGL(k_debug_samples, dim3(1), dim3(64), 0, st, seed, k, total, n_draws, out, idx, tmp7, mode);
 }

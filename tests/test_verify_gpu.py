@@ -1,5 +1,7 @@
 """GPU parity of the HIP two-view verification (through the C-ABI) against the CPU oracle:
 bit-exact config / inlier masks / model matrices / trial counts, pose within 1e-6 relative."""
+import os
+
 import numpy as np
 import pytest
 
@@ -29,7 +31,15 @@ def test_sampler_matches_libstdcxx(dsm, oracle):
                                   (7, 7, 257, 1000), (4294967295, 4, 3, 0)]:
         if k > total or draws == 0:
             continue
-        assert (dsm.debug_sample_sequence(seed, k, total, draws) == oracle.sample_sequence(seed, k, total, draws)).all()
+        ref = oracle.sample_sequence(seed, k, total, draws)
+        # 1 = the wave sampler of the product path (parallel regeneration / tempering / Lemire, serial swaps),
+        # 0 = plain lane-0 loop, 2 = the wave sampler's serial replay path (taken after a Lemire rejection)
+        for mode in ("1", "0", "2"):
+            os.environ["DSM_DEBUG_SAMPLER_MODE"] = mode
+            try:
+                assert (dsm.debug_sample_sequence(seed, k, total, draws) == ref).all(), (seed, k, total, draws, mode)
+            finally:
+                del os.environ["DSM_DEBUG_SAMPLER_MODE"]
 
 
 def _scene_pair(scene, i, j, oracle):
@@ -97,10 +107,13 @@ def test_watermark_configuration(dsm, oracle):
     assert (got_inl == ref_inl).all()
 
 
-@pytest.mark.parametrize("prior", [0, 1])
-def test_stage_match_and_verify_many_pairs(dsm, oracle, prior):
+@pytest.mark.parametrize("prior,sampler_serial", [(0, False), (1, False), (1, True)])
+def test_stage_match_and_verify_many_pairs(dsm, oracle, prior, sampler_serial, monkeypatch):
     """dsm_match_pairs + dsm_verify_pairs over an exhaustive pair list == oracle matcher + oracle verifier
-    with SiftFeatureMatcher::Match's post-filter (matching.cc:824-831)."""
+    with SiftFeatureMatcher::Match's post-filter (matching.cc:824-831).  sampler_serial forces the sampler's
+    rarely taken serial replay path (a Lemire rejection) for every round."""
+    if sampler_serial:
+        monkeypatch.setenv("DSM_SAMPLER_SERIAL", "1")
     n_img = 7
     scene = synthetic.Scene(n_img, 768, seed=21, n_pool=2048)
     ims = [scene.image(i) for i in range(n_img)]
