@@ -30,7 +30,8 @@ class TwoViewOptions(ctypes.Structure):
                 ("watermark_border_size", ctypes.c_double), ("detect_watermark", ctypes.c_int32),
                 ("multiple_models", ctypes.c_int32), ("max_error", ctypes.c_double),
                 ("min_inlier_ratio", ctypes.c_double), ("confidence", ctypes.c_double),
-                ("min_num_trials", ctypes.c_uint64), ("max_num_trials", ctypes.c_uint64)]
+                ("min_num_trials", ctypes.c_uint64), ("max_num_trials", ctypes.c_uint64),
+                ("multiple_ignore_watermark", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class Camera(ctypes.Structure):

@@ -107,6 +107,7 @@ struct dsm_ctx {
   DevBuf d_cams, d_pairs_dev, d_seeds, d_tvg, d_inl, d_inl_counts, d_inl_off, d_inl_compact, d_vscratch, d_inl_total;
   DevBuf d_nt_table, d_nt_off, d_nt_off_t, d_pair_state, d_pts_px, d_pts_norm, d_reports, d_masks;
   DevBuf d_fam_state, d_samples, d_draws_end, d_nmodels, d_vcounts, d_models, d_sidx, d_active;
+  DevBuf d_mm_matches[2], d_mm_off[2], d_mm_counts, d_mm_state, d_mm_first, d_mm_acc, d_mm_keep, d_mm_total;  // EstimateMultiple
   uint32_t verify_rounds[3] = {0, 0, 0};
   uint64_t total_inliers = 0;
   double verify_ms = 0.0;
@@ -153,6 +154,8 @@ void dsm_default_two_view_options(dsm_two_view_options* o) {
   o->watermark_border_size = 0.1;       // :127
   o->detect_watermark = 1;              // :130
   o->multiple_models = 0;               // sift.h:159
+  o->multiple_ignore_watermark = 1;     // two_view_geometry.h:140
+  o->reserved = 0;
   o->max_error = 4.0;                   // sift.h:141
   o->min_inlier_ratio = 0.25;           // sift.h:152
   o->confidence = 0.999;                // sift.h:144
@@ -214,7 +217,9 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
                     &ctx->d_vscratch, &ctx->d_inl_total, &ctx->d_nt_table, &ctx->d_nt_off, &ctx->d_nt_off_t,
                     &ctx->d_pair_state, &ctx->d_pts_px, &ctx->d_pts_norm, &ctx->d_reports, &ctx->d_masks,
                     &ctx->d_fam_state, &ctx->d_samples, &ctx->d_draws_end, &ctx->d_nmodels, &ctx->d_vcounts, &ctx->d_models,
-                    &ctx->d_sidx, &ctx->d_active};
+                    &ctx->d_sidx, &ctx->d_active, &ctx->d_mm_matches[0], &ctx->d_mm_matches[1], &ctx->d_mm_off[0],
+                    &ctx->d_mm_off[1], &ctx->d_mm_counts, &ctx->d_mm_state, &ctx->d_mm_first, &ctx->d_mm_acc, &ctx->d_mm_keep,
+                    &ctx->d_mm_total};
   if (ctx->vev0) (void)hipEventDestroy(ctx->vev0);
   if (ctx->vev1) (void)hipEventDestroy(ctx->vev1);
   for (DevBuf* b : bufs) b->release();
@@ -602,7 +607,8 @@ static int ensure_nt_tables(dsm_ctx* ctx, const dsm_two_view_options* o, const s
 static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, const uint64_t* d_match_off,
                        const uint32_t* d_matches, uint64_t total_matches, const std::vector<uint32_t>& counts,
                        const double* d_kp, const uint32_t* d_img_row0, const dsm_camera* d_cams,
-                       const dsm_two_view_options* o, const uint32_t* d_seeds, int stage_filter) {
+                       const dsm_two_view_options* o, const uint32_t* d_seeds, int stage_filter, bool reseed = true,
+                       bool keep_generator = false, bool accumulate_time = false) {
   hipStream_t st = ctx->stream;
   uint32_t n_max = 1;
   for (uint32_t c : counts) n_max = std::max(n_max, c);
@@ -653,6 +659,8 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.n_max = n_max;
   vp.stage_filter = stage_filter;
   vp.sampler_serial = getenv("DSM_SAMPLER_SERIAL") ? 1 : 0;
+  vp.reseed = reseed ? 1 : 0;
+  vp.keep_generator = keep_generator ? 1 : 0;
   if (!ctx->vev0) {
     HIPCHK(ctx, hipEventCreate(&ctx->vev0));
     HIPCHK(ctx, hipEventCreate(&ctx->vev1));
@@ -765,7 +773,105 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   HIPCHK(ctx, hipStreamSynchronize(st));
   float ms = 0.f;
   HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->vev0, ctx->vev1));
-  ctx->verify_ms = ms;
+  ctx->verify_ms = accumulate_time ? ctx->verify_ms + ms : ms;
+  return DSM_OK;
+}
+
+static int verify_core_plain(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, const uint64_t* d_match_off,
+                             const uint32_t* d_matches, uint64_t total_matches, const std::vector<uint32_t>& counts,
+                             const double* d_kp, const uint32_t* d_img_row0, const dsm_camera* d_cams,
+                             const dsm_two_view_options* o, const uint32_t* d_seeds, int stage_filter) {
+  return verify_core(ctx, n_pairs, d_pairs, d_match_off, d_matches, total_matches, counts, d_kp, d_img_row0, d_cams, o, d_seeds,
+                     stage_filter);
+}
+
+// TwoViewGeometry::EstimateMultiple (/root/reference/src/estimators/two_view_geometry.cc:128-167) for all pairs:
+// repeated passes of verify_core over the matches that are not inliers of the geometries found so far (a
+// finished pair carries zero matches and costs nothing), the pair's generator stream continuing from pass to
+// pass.  Results land where verify_core leaves them (d_tvg, d_inl_off, d_inl_compact).
+static int verify_multiple(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, const uint64_t* d_match_off,
+                           const uint32_t* d_matches, uint64_t total_matches, const std::vector<uint32_t>& counts,
+                           const double* d_kp, const uint32_t* d_img_row0, const dsm_camera* d_cams,
+                           const dsm_two_view_options* o, const uint32_t* d_seeds, int stage_filter) {
+  hipStream_t st = ctx->stream;
+  const uint64_t tm = std::max<uint64_t>(total_matches, 1);
+  const size_t np1 = std::max<uint32_t>(n_pairs, 1);
+  HIPCHK(ctx, ctx->d_mm_matches[0].reserve(tm * 8));
+  HIPCHK(ctx, ctx->d_mm_matches[1].reserve(tm * 8));
+  HIPCHK(ctx, ctx->d_mm_off[0].reserve((np1 + 1) * 8));
+  HIPCHK(ctx, ctx->d_mm_off[1].reserve((np1 + 1) * 8));
+  HIPCHK(ctx, ctx->d_mm_counts.reserve(np1 * 4));
+  HIPCHK(ctx, ctx->d_mm_state.reserve(np1 * sizeof(MultiState)));
+  HIPCHK(ctx, ctx->d_mm_first.reserve(np1 * sizeof(dsm_two_view_geometry)));
+  HIPCHK(ctx, ctx->d_mm_acc.reserve(tm * 8));
+  HIPCHK(ctx, ctx->d_mm_keep.reserve(tm));
+  HIPCHK(ctx, ctx->d_mm_total.reserve(16));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_mm_state.p, 0, np1 * sizeof(MultiState), st));
+  dsm_two_view_options pass_opt = *o;
+  pass_opt.multiple_models = 0;
+  const uint64_t* cur_off = d_match_off;
+  const uint32_t* cur_matches = d_matches;
+  std::vector<uint32_t> cur_counts = counts;
+  uint64_t cur_total = total_matches;
+  MultiParams mp;
+  mp.orig_off = d_match_off;
+  mp.state = ctx->d_mm_state.as<MultiState>();
+  mp.first = ctx->d_mm_first.as<dsm_two_view_geometry>();
+  mp.acc = ctx->d_mm_acc.as<uint32_t>();
+  mp.keep = ctx->d_mm_keep.as<unsigned char>();
+  mp.next_count = ctx->d_mm_counts.as<uint32_t>();
+  mp.active = ctx->d_mm_total.as<uint32_t>() + 2;
+  mp.ignore_watermark = o->multiple_ignore_watermark ? 1 : 0;
+  mp.stage_filter = stage_filter;
+  mp.min_num_inliers = o->min_num_inliers;
+  mp.n_pairs = n_pairs;
+  double ms_total = 0.0;
+  for (uint32_t pass = 0;; ++pass) {
+    int rc = verify_core(ctx, n_pairs, d_pairs, cur_off, cur_matches, cur_total, cur_counts, d_kp, d_img_row0, d_cams,
+                         &pass_opt, d_seeds, /*stage_filter=*/0, /*reseed=*/pass == 0, /*keep_generator=*/true);
+    if (rc != DSM_OK) return rc;
+    ms_total += ctx->verify_ms;
+    const int nxt = (int)(pass & 1u);
+    mp.cur_off = cur_off;
+    mp.cur_matches = cur_matches;
+    mp.tvg = ctx->d_tvg.as<dsm_two_view_geometry>();
+    mp.inl = ctx->d_inl.as<uint32_t>();
+    mp.inl_counts = ctx->d_inl_counts.as<uint32_t>();
+    mp.next_off = ctx->d_mm_off[nxt].as<uint64_t>();
+    mp.next_matches = ctx->d_mm_matches[nxt].as<uint32_t>();
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_mm_total.p, 0, 16, st));
+    launch_multi_accumulate(mp, st);
+    HIPCHK(ctx, hipGetLastError());
+    launch_scan(mp.next_count, ctx->d_mm_off[nxt].as<uint64_t>(), n_pairs, ctx->d_mm_total.as<uint64_t>(), st);
+    launch_multi_scatter(mp, st);
+    HIPCHK(ctx, hipGetLastError());
+    uint32_t tot[4] = {0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(tot, ctx->d_mm_total.p, 16, hipMemcpyDeviceToHost, st));
+    if (n_pairs) HIPCHK(ctx, hipMemcpyAsync(cur_counts.data(), ctx->d_mm_counts.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (tot[2] == 0) break;  // every pair has returned DEGENERATE
+    cur_off = ctx->d_mm_off[nxt].as<uint64_t>();
+    cur_matches = ctx->d_mm_matches[nxt].as<uint32_t>();
+    cur_total = (uint64_t)tot[0] | ((uint64_t)tot[1] << 32);
+  }
+  // final records + inlier matches (accumulated at the original offsets) in list order
+  mp.out_tvg = ctx->d_tvg.as<dsm_two_view_geometry>();
+  mp.out_inl_counts = ctx->d_inl_counts.as<uint32_t>();
+  launch_multi_finalize(mp, st);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_inl_total.p, 0, 8, st));
+  launch_scan(ctx->d_inl_counts.as<uint32_t>(), ctx->d_inl_off.as<uint64_t>(), n_pairs, ctx->d_inl_total.as<uint64_t>(), st);
+  HIPCHK(ctx, hipGetLastError());
+  uint64_t total = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&total, ctx->d_inl_total.p, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  ctx->total_inliers = total;
+  HIPCHK(ctx, ctx->d_inl_compact.reserve(std::max<uint64_t>(total, 1) * 8));
+  launch_compact_inliers(d_match_off, ctx->d_inl_off.as<uint64_t>(), ctx->d_inl_counts.as<uint32_t>(), ctx->d_mm_acc.as<uint32_t>(),
+                         ctx->d_inl_compact.as<uint32_t>(), n_pairs, st);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  ctx->verify_ms = ms_total;
   return DSM_OK;
 }
 
@@ -792,7 +898,6 @@ int dsm_verify_pairs(dsm_ctx* ctx, const dsm_two_view_options* options, const ui
   if (!(options->max_error > 0) || options->min_inlier_ratio < 0 || options->min_inlier_ratio > 1 ||
       options->confidence < 0 || options->confidence > 1 || options->min_num_trials > options->max_num_trials)
     return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "invalid RANSAC options");
-  if (options->multiple_models) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "multiple_models is not supported");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->verified = false;
   const uint32_t np = ctx->n_pairs;
@@ -809,9 +914,10 @@ int dsm_verify_pairs(dsm_ctx* ctx, const dsm_two_view_options* options, const ui
     HIPCHK(ctx, hipMemcpy(ctx->d_pairs_dev.p, ctx->pairs.data(), (size_t)np * 8, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->d_seeds.p, sd.data(), (size_t)np * 4, hipMemcpyHostToDevice));
   }
-  int rc = verify_core(ctx, np, ctx->d_pairs_dev.as<uint32_t>(), ctx->d_offsets.as<uint64_t>(), ctx->d_matches.as<uint32_t>(),
-                       ctx->total_matches, counts, ctx->d_kp.as<double>(), ctx->d_img_row0.as<uint32_t>(),
-                       ctx->d_cams.as<dsm_camera>(), options, ctx->d_seeds.as<uint32_t>(), stage_filter);
+  int rc = (options->multiple_models ? verify_multiple : verify_core_plain)(
+      ctx, np, ctx->d_pairs_dev.as<uint32_t>(), ctx->d_offsets.as<uint64_t>(), ctx->d_matches.as<uint32_t>(), ctx->total_matches,
+      counts, ctx->d_kp.as<double>(), ctx->d_img_row0.as<uint32_t>(), ctx->d_cams.as<dsm_camera>(), options,
+      ctx->d_seeds.as<uint32_t>(), stage_filter);
   if (rc != DSM_OK) return rc;
   ctx->verified = true;
   return DSM_OK;
@@ -894,8 +1000,9 @@ int dsm_estimate_two_view_geometry(dsm_ctx* ctx, const dsm_camera* camera1, cons
   if (rc == DSM_OK) {
     std::vector<uint32_t> counts(1, n_matches);
     lf->n_pairs = 1;
-    rc = verify_core(lf, 1, pr.as<uint32_t>(), off.as<uint64_t>(), mt.as<uint32_t>(), n_matches, counts, kp.as<double>(),
-                     row0.as<uint32_t>(), cams.as<dsm_camera>(), options, sd.as<uint32_t>(), 0);
+    rc = (options->multiple_models ? verify_multiple : verify_core_plain)(
+        lf, 1, pr.as<uint32_t>(), off.as<uint64_t>(), mt.as<uint32_t>(), n_matches, counts, kp.as<double>(),
+        row0.as<uint32_t>(), cams.as<dsm_camera>(), options, sd.as<uint32_t>(), 0);
     if (rc != DSM_OK) ctx->err = lf->err;
   }
   if (rc == DSM_OK) {

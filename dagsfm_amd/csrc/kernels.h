@@ -91,6 +91,8 @@ struct VerifyParams {
   uint32_t n_max;              // max matches of any pair in this launch
   int32_t stage_filter;        // apply SiftFeatureMatcher::Match's min_num_inliers post-filter
   int32_t sampler_serial;      // test hook (DSM_SAMPLER_SERIAL): force the sampler's serial replay path
+  int32_t reseed;              // 1: k_verify_prep seeds the pair's generator; 0: it continues (EstimateMultiple passes)
+  int32_t keep_generator;      // 1: k_verify_final stores the generator state for a following pass
 };
 
 size_t verify_scratch_bytes_per_block(uint32_t n_max);
@@ -115,5 +117,40 @@ void launch_k1(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, 
 void launch_k1_resolve(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st);
 void launch_k2(const K2Params& p, uint32_t n_pairs, bool write, hipStream_t st);
 void launch_scan(const uint32_t* counts, uint64_t* offsets, uint32_t n, uint64_t* running_total, hipStream_t st);
+
+// EstimateMultiple (two_view_geometry.cc:128-167): per-pair bookkeeping across the passes
+struct MultiState {
+  uint32_t ngeo;      // geometries collected so far
+  uint32_t done;      // a pass returned DEGENERATE
+  uint32_t acc_inl;   // inlier matches accumulated (stored at the pair's ORIGINAL match offset)
+  uint32_t pad;
+  uint32_t trials[4], models[4];  // counters summed over the passes
+};
+struct MultiParams {
+  const uint64_t* cur_off;       // match offsets of this pass
+  const uint32_t* cur_matches;
+  const uint64_t* orig_off;      // match offsets of the first pass
+  const dsm_two_view_geometry* tvg;  // results of this pass
+  const uint32_t* inl;           // inlier matches of this pass (at cur offsets)
+  const uint32_t* inl_counts;
+  MultiState* state;
+  dsm_two_view_geometry* first;  // first collected geometry of every pair
+  uint32_t* acc;                 // accumulated inlier matches (at orig offsets)
+  unsigned char* keep;           // per match of this pass: stays in the remaining set
+  uint32_t* next_count;
+  const uint64_t* next_off;
+  uint32_t* next_matches;
+  uint32_t* active;
+  int32_t ignore_watermark;
+  int32_t stage_filter;
+  uint64_t min_num_inliers;
+  uint32_t n_pairs;
+  // finalize
+  dsm_two_view_geometry* out_tvg;
+  uint32_t* out_inl_counts;
+};
+void launch_multi_accumulate(const MultiParams& p, hipStream_t st);
+void launch_multi_scatter(const MultiParams& p, hipStream_t st);
+void launch_multi_finalize(const MultiParams& p, hipStream_t st);
 
 #endif

@@ -956,13 +956,15 @@ __global__ __launch_bounds__(64) void k_verify_prep(const VerifyParams p) {
       }
     }
     wv_sync();
-    if (lane == 0) mt_seed(&sm, p.seeds[pi]);
-    wv_sync();
     uint32_t* st = p.pair_state + (size_t)pi * PAIR_STATE_WORDS;
-    generator_store(&sm, st, lane);
-    if (lane == 0) {
-      st[PS_USE_SNAP] = 0;
-      st[PS_SKIP] = 0;
+    if (p.reseed) {  // a later pass of EstimateMultiple continues the pair's stream instead
+      if (lane == 0) mt_seed(&sm, p.seeds[pi]);
+      wv_sync();
+      generator_store(&sm, st, lane);
+      if (lane == 0) {
+        st[PS_USE_SNAP] = 0;
+        st[PS_SKIP] = 0;
+      }
     }
     if (p.fam_state != nullptr && lane < 3) {  // phase-split pipeline: initial family states
       const int K[3] = {5, 7, 4};
@@ -1064,6 +1066,7 @@ __global__ __launch_bounds__(64, 2) void k_verify_final(const VerifyParams p) {
     uint32_t ntr[4] = {0, 0, 0, 0}, nmo[4] = {0, 0, 0, 0};
     uint32_t num_inliers = 0;
     bool have_mask = false;
+    bool gen_loaded = false;
 
     const bool calibrated = cam1.has_prior_focal_length && cam2.has_prior_focal_length;
     if ((uint64_t)n < o.min_num_inliers) {
@@ -1094,6 +1097,7 @@ __global__ __launch_bounds__(64, 2) void k_verify_final(const VerifyParams p) {
       nmo[2] = H_rep.num_models;
       // the generator continues where the H family stopped (watermark RANSAC, :547-549)
       generator_load(&sm->gen, p.pair_state + (size_t)pi * PAIR_STATE_WORDS, lane);
+      gen_loaded = true;
 
       PairWork w;
       w.n = n;
@@ -1393,6 +1397,10 @@ __global__ __launch_bounds__(64, 2) void k_verify_final(const VerifyParams p) {
       }
     }
 
+    if (p.keep_generator && gen_loaded) {  // EstimateMultiple: the next pass continues this stream
+      wv_sync();
+      generator_store(&sm->gen, p.pair_state + (size_t)pi * PAIR_STATE_WORDS, lane);
+    }
     // SiftFeatureMatcher::Match post-filter (matching.cc:824-831) when requested
     if (p.stage_filter && (uint64_t)num_inliers < o.min_num_inliers) {
       config = DSM_CONFIG_UNDEFINED;
@@ -1931,6 +1939,161 @@ void launch_compact_inliers(const uint64_t* match_off, const uint64_t* inl_off, 
   if (!n_pairs) return;
   const uint32_t blocks = n_pairs < 8192 ? n_pairs : 8192;
   hipLaunchKernelGGL(k_compact_inliers, dim3(blocks), dim3(64), 0, st, match_off, inl_off, inl_counts, src, dst, n_pairs);
+}
+
+// ------------------------------------------------------------------------------------ EstimateMultiple
+// TwoViewGeometry::EstimateMultiple (two_view_geometry.cc:128-167) is a loop of Estimate() over the matches
+// that are not inliers of the geometries found so far; the host repeats the whole verification pipeline over
+// all pairs (finished pairs carry zero matches) and these kernels do the per-pair bookkeeping between passes.
+__global__ __launch_bounds__(64) void k_multi_accumulate(const MultiParams p) {
+  const int lane = threadIdx.x;
+  for (uint32_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
+    MultiState* ms = p.state + pi;
+    const uint64_t off = p.cur_off[pi];
+    const int n = (int)(p.cur_off[pi + 1] - off);
+    __syncthreads();
+    if (ms->done) {
+      if (lane == 0) p.next_count[pi] = 0;
+      continue;
+    }
+    const dsm_two_view_geometry* t = p.tvg + pi;
+    const int config = t->config;
+    if (lane < 4) {
+      ms->trials[lane] += t->num_trials[lane];
+      ms->models[lane] += t->num_models[lane];
+    }
+    if (config == DSM_CONFIG_DEGENERATE) {  // :136-138
+      if (lane == 0) {
+        ms->done = 1;
+        p.next_count[pi] = 0;
+      }
+      continue;
+    }
+    const uint32_t ninl = p.inl_counts[pi];
+    const uint2* inl = reinterpret_cast<const uint2*>(p.inl) + off;
+    const bool accept = !(p.ignore_watermark && config == DSM_CONFIG_WATERMARK);  // :140-146
+    const uint32_t acc0 = ms->acc_inl, ngeo0 = ms->ngeo;
+    __syncthreads();
+    if (accept) {
+      uint2* acc = reinterpret_cast<uint2*>(p.acc) + p.orig_off[pi] + acc0;
+      for (uint32_t i = lane; i < ninl; i += 64) acc[i] = inl[i];
+      if (ngeo0 == 0) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(t);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(p.first + pi);
+        for (uint32_t i = lane; i < sizeof(dsm_two_view_geometry) / 4; i += 64) dst[i] = src[i];
+      }
+      if (lane == 0) {
+        ms->acc_inl = acc0 + ninl;
+        ms->ngeo = ngeo0 + 1;
+      }
+    }
+    // ExtractOutlierMatches (:67-88): a match stays unless the same (idx1, idx2) pair is an inlier match.  The
+    // inlier list is an ordered subsequence of the matches; when idx1 is strictly ascending (every list the
+    // matcher produces) a binary search finds it, otherwise every inlier is compared.
+    const uint2* m = reinterpret_cast<const uint2*>(p.cur_matches) + off;
+    bool asc = true;
+    for (int i = lane; i + 1 < n; i += 64) asc = asc && (m[i].x < m[i + 1].x);
+    const bool sorted = __ballot(!asc) == 0ull;
+    uint32_t cnt = 0;
+    for (int b0 = 0; b0 < n; b0 += 64) {
+      const int i = b0 + lane;
+      bool keep = false;
+      if (i < n) {
+        const uint2 q = m[i];
+        bool found = false;
+        if (sorted) {
+          uint32_t lo = 0, hi = ninl;
+          while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (inl[mid].x < q.x) lo = mid + 1; else hi = mid;
+          }
+          found = lo < ninl && inl[lo].x == q.x && inl[lo].y == q.y;
+        } else {
+          for (uint32_t k = 0; k < ninl && !found; ++k) found = inl[k].x == q.x && inl[k].y == q.y;
+        }
+        keep = !found;
+        p.keep[off + i] = keep ? 1 : 0;
+      }
+      cnt += (uint32_t)__popcll(__ballot(keep));
+    }
+    if (lane == 0) {
+      p.next_count[pi] = cnt;
+      atomicAdd(p.active, 1u);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_multi_scatter(const MultiParams p) {
+  const int lane = threadIdx.x;
+  for (uint32_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
+    const uint32_t cnt = p.next_count[pi];
+    if (cnt == 0) continue;
+    const uint64_t off = p.cur_off[pi];
+    const int n = (int)(p.cur_off[pi + 1] - off);
+    const uint2* m = reinterpret_cast<const uint2*>(p.cur_matches) + off;
+    uint2* dst = reinterpret_cast<uint2*>(p.next_matches) + p.next_off[pi];
+    uint32_t total = 0;
+    for (int b0 = 0; b0 < n; b0 += 64) {
+      const int i = b0 + lane;
+      const bool keep = i < n && p.keep[off + i] != 0;
+      const unsigned long long bal = __ballot(keep);
+      if (keep) dst[total + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = m[i];
+      total += (uint32_t)__popcll(bal);
+    }
+  }
+}
+
+// :154-166 -- no geometry: DEGENERATE; one: that geometry; several: config MULTIPLE with the inlier matches of
+// all of them, everything else as in a fresh TwoViewGeometry().  Then SiftFeatureMatcher::Match's post-filter.
+__global__ __launch_bounds__(64) void k_multi_finalize(const MultiParams p) {
+  const int lane = threadIdx.x;
+  for (uint32_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
+    const MultiState ms = p.state[pi];
+    dsm_two_view_geometry* out = p.out_tvg + pi;
+    uint32_t* o32 = reinterpret_cast<uint32_t*>(out);
+    const uint32_t n_orig = (uint32_t)(p.orig_off[pi + 1] - p.orig_off[pi]);
+    if (ms.ngeo == 1) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(p.first + pi);
+      for (uint32_t i = lane; i < sizeof(dsm_two_view_geometry) / 4; i += 64) o32[i] = src[i];
+    } else {
+      for (uint32_t i = lane; i < sizeof(dsm_two_view_geometry) / 4; i += 64) o32[i] = 0;
+    }
+    __syncthreads();
+    uint32_t ninl = ms.acc_inl;
+    if (lane == 0) {
+      if (ms.ngeo == 0) out->config = DSM_CONFIG_DEGENERATE;
+      if (ms.ngeo > 1) out->config = DSM_CONFIG_MULTIPLE;
+      out->num_matches = n_orig;
+      out->num_inliers = ninl;
+      for (int k = 0; k < 4; ++k) {
+        out->num_trials[k] = ms.trials[k];
+        out->num_models[k] = ms.models[k];
+      }
+      if (p.stage_filter && (uint64_t)ninl < p.min_num_inliers) {  // matching.cc:824-831
+        const dsm_two_view_geometry keepc = *out;
+        uint32_t* z = reinterpret_cast<uint32_t*>(out);
+        for (uint32_t i = 0; i < sizeof(dsm_two_view_geometry) / 4; ++i) z[i] = 0;
+        out->num_matches = keepc.num_matches;
+        for (int k = 0; k < 4; ++k) {
+          out->num_trials[k] = keepc.num_trials[k];
+          out->num_models[k] = keepc.num_models[k];
+        }
+        ninl = 0;
+      }
+      p.out_inl_counts[pi] = ninl;
+    }
+    __syncthreads();
+  }
+}
+static uint32_t multi_blocks(uint32_t n) { return n < 16384u ? (n ? n : 1u) : 16384u; }
+void launch_multi_accumulate(const MultiParams& p, hipStream_t st) {
+  hipLaunchKernelGGL(k_multi_accumulate, dim3(multi_blocks(p.n_pairs)), dim3(64), 0, st, p);
+}
+void launch_multi_scatter(const MultiParams& p, hipStream_t st) {
+  hipLaunchKernelGGL(k_multi_scatter, dim3(multi_blocks(p.n_pairs)), dim3(64), 0, st, p);
+}
+void launch_multi_finalize(const MultiParams& p, hipStream_t st) {
+  hipLaunchKernelGGL(k_multi_finalize, dim3(multi_blocks(p.n_pairs)), dim3(64), 0, st, p);
 }
 
 // ------------------------------------------------------------------------------------ debug hooks

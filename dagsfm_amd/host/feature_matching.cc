@@ -48,6 +48,10 @@ SiftFeatureMatcher::~SiftFeatureMatcher() {
 }
 
 bool SiftFeatureMatcher::Setup() {
+  if (options_.guided_matching) {  // matching.cc:429-548 is not part of this build
+    last_error_ = "guided_matching is not supported by the MI355X matcher";
+    return false;
+  }
   int device = 0;
   if (options_.gpu_index != "-1" && !options_.gpu_index.empty()) device = std::atoi(options_.gpu_index.c_str());
   const int rc = dsm_ctx_create(device, &ctx_);
@@ -141,7 +145,7 @@ void SiftFeatureMatcher::Match(const std::vector<std::pair<image_t, image_t>>& i
   to.min_num_trials = static_cast<uint64_t>(options_.min_num_trials);
   to.max_num_trials = static_cast<uint64_t>(options_.max_num_trials);
   to.min_inlier_ratio = options_.min_inlier_ratio;
-  to.multiple_models = options_.multiple_models ? 1 : 0;
+  to.multiple_models = options_.multiple_models ? 1 : 0;  // TwoViewGeometry::Options::multiple_ignore_watermark stays at its default (true)
 
   auto run = [&](const std::vector<std::pair<image_t, image_t>>& prs, const std::vector<FeatureMatches>* given) {
     if (prs.empty()) return;

@@ -53,13 +53,15 @@ typedef struct dsm_two_view_options {
   double watermark_min_inlier_ratio; /* 0.7  */
   double watermark_border_size;      /* 0.1  */
   int32_t detect_watermark;          /* 1    */
-  int32_t multiple_models;           /* 0 (EstimateMultiple is a "next" row) */
+  int32_t multiple_models;           /* 0; != 0: TwoViewGeometry::EstimateMultiple (two_view_geometry.cc:128-167) */
   /* RANSACOptions */
   double max_error;        /* 4.0   */
   double min_inlier_ratio; /* 0.25  */
   double confidence;       /* 0.999 */
   uint64_t min_num_trials; /* 30    */
   uint64_t max_num_trials; /* 10000 */
+  int32_t multiple_ignore_watermark; /* 1 (two_view_geometry.h:140); only read when multiple_models != 0 */
+  int32_t reserved;
 } dsm_two_view_options;
 
 /* Camera as used by the verification path (src/base/camera.h; models

@@ -39,6 +39,8 @@
 #include <limits>
 #include <numeric>
 #include <random>
+#include <set>
+#include <utility>
 #include <vector>
 
 #include "../include/dagsfm_mi355x.h"
@@ -1316,10 +1318,54 @@ void oracle_estimate_two_view_geometry(const dsm_camera* camera1, const double* 
   const std::vector<Vec2> p1 = ToVec2(points1, n1), p2 = ToVec2(points2, n2);
   PRNG prng(seed);
   TwoView tv;
-  if (camera1->has_prior_focal_length && camera2->has_prior_focal_length)
-    EstimateWithRelativePose(*camera1, p1, *camera2, p2, matches, n_matches, *options, &prng, &tv);
-  else
-    EstimateUncalibrated(*camera1, p1, *camera2, p2, matches, n_matches, *options, &prng, &tv);
+  auto estimate = [&](const uint32_t* m, size_t nm, TwoView* t) {  // TwoViewGeometry::Estimate, :113-126
+    if (camera1->has_prior_focal_length && camera2->has_prior_focal_length)
+      EstimateWithRelativePose(*camera1, p1, *camera2, p2, m, nm, *options, &prng, t);
+    else
+      EstimateUncalibrated(*camera1, p1, *camera2, p2, m, nm, *options, &prng, t);
+  };
+  if (!options->multiple_models) {
+    estimate(matches, n_matches, &tv);
+  } else {
+    // TwoViewGeometry::EstimateMultiple, two_view_geometry.cc:128-167.  The reference's PRNG is one thread-local
+    // stream, so every pass continues the stream of the previous one.  num_trials / num_models (our own
+    // counters) are summed over all passes.
+    std::vector<uint32_t> remaining(matches, matches + 2 * static_cast<size_t>(n_matches));
+    std::vector<TwoView> found;
+    uint32_t trials[4] = {0, 0, 0, 0}, models[4] = {0, 0, 0, 0};
+    while (true) {
+      TwoView t;
+      estimate(remaining.data(), remaining.size() / 2, &t);
+      for (int k = 0; k < 4; ++k) {
+        trials[k] += t.num_trials[k];
+        models[k] += t.num_models[k];
+      }
+      if (t.config == DSM_CONFIG_DEGENERATE) break;
+      if (!(options->multiple_ignore_watermark && t.config == DSM_CONFIG_WATERMARK)) found.push_back(t);
+      // ExtractOutlierMatches, :67-88
+      std::set<std::pair<uint32_t, uint32_t>> inl;
+      for (size_t i = 0; i + 1 < t.inlier_matches.size(); i += 2) inl.emplace(t.inlier_matches[i], t.inlier_matches[i + 1]);
+      std::vector<uint32_t> next;
+      for (size_t i = 0; i + 1 < remaining.size(); i += 2)
+        if (inl.count(std::make_pair(remaining[i], remaining[i + 1])) == 0) {
+          next.push_back(remaining[i]);
+          next.push_back(remaining[i + 1]);
+        }
+      remaining.swap(next);
+    }
+    if (found.empty()) {
+      tv.config = DSM_CONFIG_DEGENERATE;
+    } else if (found.size() == 1) {
+      tv = found[0];
+    } else {
+      tv.config = DSM_CONFIG_MULTIPLE;
+      for (const TwoView& t : found) tv.inlier_matches.insert(tv.inlier_matches.end(), t.inlier_matches.begin(), t.inlier_matches.end());
+    }
+    for (int k = 0; k < 4; ++k) {
+      tv.num_trials[k] = trials[k];
+      tv.num_models[k] = models[k];
+    }
+  }
   std::memset(out, 0, sizeof(*out));
   out->config = tv.config;
   out->num_inliers = static_cast<uint32_t>(tv.inlier_matches.size() / 2);

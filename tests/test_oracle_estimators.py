@@ -258,3 +258,35 @@ def test_sample_sequence_is_partial_fisher_yates(oracle):
         assert len(set(row.tolist())) == 7
     assert (oracle.sample_sequence(7, 7, 50, 200) == s).all()
     assert not (oracle.sample_sequence(8, 7, 50, 200) == s).all()
+
+
+def test_estimate_multiple_two_motions(oracle):
+    """EstimateMultiple (two_view_geometry.cc:128-167) on the correspondences of two independently moving
+    structures: MULTIPLE, the inlier matches are those of the single passes one after the other (disjoint, and
+    each group a subset of the matches); with one structure it degenerates to Estimate plus a DEGENERATE pass."""
+    from dagsfm_amd import capi, synthetic
+
+    def pair(seed):
+        sc = synthetic.Scene(2, 640, seed=seed, n_pool=900)
+        a, b = sc.image(0), sc.image(1)
+        return a[1].astype(np.float64), b[1].astype(np.float64), oracle.match_sift_features_cpu(a[0], b[0])
+
+    a1, a2, ma = pair(101)
+    b1, b2, mb = pair(202)
+    p1, p2 = np.concatenate([a1, b1]), np.concatenate([a2, b2])
+    m = np.concatenate([ma, mb + np.array([len(a1), len(a2)], dtype=np.uint32)]).astype(np.uint32)
+    cam = capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, 1)
+    opts = capi.default_two_view_options()
+    single, inl_single = oracle.estimate_two_view_geometry(cam, p1, cam, p2, m, opts, 4)
+    opts.multiple_models = 1
+    multi, inl = oracle.estimate_two_view_geometry(cam, p1, cam, p2, m, opts, 4)
+    assert multi.config == 8 and single.config in (2, 3, 4, 5, 6)
+    assert multi.num_inliers > single.num_inliers
+    # the first group is exactly the single-pass result (same stream position at the start)
+    assert (inl[:single.num_inliers] == inl_single).all()
+    as_set = {tuple(r) for r in inl.tolist()}
+    assert len(as_set) == len(inl) and as_set <= {tuple(r) for r in m.tolist()}
+    assert np.array(multi.E).any() == False and np.array(multi.qvec).any() == False  # fresh TwoViewGeometry()
+    # both structures contribute
+    first = inl[:, 0] < len(a1)
+    assert first.sum() >= 15 and (~first).sum() >= 15

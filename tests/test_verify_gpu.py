@@ -171,3 +171,78 @@ def test_radial_camera_and_small_lo_systems(dsm, oracle):
             got, got_inl = dsm.estimate_two_view_geometry(camp, p1, camp, p2, mx, o2, seed)
             tvg_equal(got, ref, ("small", n_true, n_tot, seed))
             assert (got_inl == ref_inl).all()
+
+
+def _two_motion_problem(oracle):
+    """Correspondences of two independently moving structures: the matches of two different scene pairs put side
+    by side (indices of the second set shifted), so that a second Estimate pass over the outliers of the first
+    finds another geometry."""
+    sa = synthetic.Scene(2, 640, seed=101, n_pool=900)
+    sb = synthetic.Scene(2, 640, seed=202, n_pool=900)
+    a1, a2, ma = _scene_pair(sa, 0, 1, oracle)
+    b1, b2, mb = _scene_pair(sb, 0, 1, oracle)
+    p1 = np.concatenate([a1, b1])
+    p2 = np.concatenate([a2, b2])
+    m = np.concatenate([ma, mb + np.array([len(a1), len(a2)], dtype=np.uint32)]).astype(np.uint32)
+    return p1, p2, m, len(ma), len(mb)
+
+
+@pytest.mark.parametrize("prior", [0, 1])
+def test_estimate_multiple_leaf(dsm, oracle, prior):
+    """TwoViewGeometry::EstimateMultiple (two_view_geometry.cc:128-167): repeated passes over the remaining
+    matches on one generator stream; one geometry -> that geometry, several -> MULTIPLE + all inlier matches."""
+    cam = capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, prior)
+    opts = capi.default_two_view_options()
+    opts.multiple_models = 1
+    p1, p2, m, na, nb = _two_motion_problem(oracle)
+    assert na > 60 and nb > 60
+    for seed in (4, 19):
+        ref, ref_inl = oracle.estimate_two_view_geometry(cam, p1, cam, p2, m, opts, seed)
+        got, got_inl = dsm.estimate_two_view_geometry(cam, p1, cam, p2, m, opts, seed)
+        assert ref.config == 8, ref.config  # MULTIPLE
+        tvg_equal(got, ref, ("multiple", prior, seed))
+        assert (got_inl == ref_inl).all()
+    # a single rigid scene: the second pass is DEGENERATE -> the first geometry, trial counters of both passes
+    scene = synthetic.Scene(2, 1024, seed=11)
+    q1, q2, mm = _scene_pair(scene, 0, 1, oracle)
+    single = capi.default_two_view_options()
+    ref1, _ = oracle.estimate_two_view_geometry(cam, q1, cam, q2, mm, single, 7)
+    ref, ref_inl = oracle.estimate_two_view_geometry(cam, q1, cam, q2, mm, opts, 7)
+    got, got_inl = dsm.estimate_two_view_geometry(cam, q1, cam, q2, mm, opts, 7)
+    assert ref.config == ref1.config and ref.num_inliers == ref1.num_inliers
+    assert sum(ref.num_trials) > sum(ref1.num_trials)
+    tvg_equal(got, ref, ("single", prior))
+    assert (got_inl == ref_inl).all()
+
+
+def test_estimate_multiple_stage(dsm, oracle):
+    """multiple_models through dsm_verify_pairs over a pair list (pairs finish after different numbers of passes)."""
+    n_img = 5
+    scene = synthetic.Scene(n_img, 768, seed=33, n_pool=2048)
+    ims = [scene.image(i) for i in range(n_img)]
+    cams = [capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, 1) for _ in range(n_img)]
+    dsm.set_images([im[0] for im in ims], [im[1] for im in ims], cams)
+    pairs = synthetic.exhaustive_pairs(n_img)
+    dsm.match_pairs(pairs)
+    opts = capi.default_two_view_options()
+    opts.multiple_models = 1
+    opts.min_num_inliers = 8  # lets second passes find small structures among the leftovers
+    dsm.verify_pairs(opts, user_seed=5, stage_filter=True)
+    offs, m = dsm.matches()
+    tvgs = dsm.two_view_geometries()
+    ioffs, im = dsm.inlier_matches()
+    configs = set()
+    for k, (i, j) in enumerate(pairs):
+        mk = m[int(offs[k]):int(offs[k + 1])]
+        seed = capi.pair_seed(int(i), int(j), 5)
+        ref, ref_inl = oracle.estimate_two_view_geometry(cams[i], ims[i][1].astype(np.float64), cams[j],
+                                                         ims[j][1].astype(np.float64), mk, opts, seed)
+        got = tvgs[k]
+        got_inl = im[int(ioffs[k]):int(ioffs[k + 1])]
+        if ref.num_inliers < opts.min_num_inliers:
+            assert got.config == 0 and got.num_inliers == 0 and len(got_inl) == 0
+        else:
+            tvg_equal(got, ref, (i, j))
+            assert (got_inl == ref_inl).all()
+        configs.add(ref.config)
+    assert len(configs) >= 1
