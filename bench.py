@@ -92,7 +92,7 @@ def cpu_baseline(scene_images, pairs, budget_s, verify, cams=None, opts=None, us
     return {"value": state["pairs"] / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
             "hypotheses_per_s": state["models"] / dt,
             "sample": "%d of %d pairs (%s) in %.1f s on %d threads; oracle/ = the reference CPU path restated "
-                      "(MatchSiftFeaturesCPU + TwoViewGeometry::Estimate), built -O2 without -march like the reference"
+                      "(MatchSiftFeaturesCPU + TwoViewGeometry::Estimate), built -O3 without -march (CMake Release, like the reference)"
                       % (state["pairs"], len(pairs), "match only" if not verify else "match + verify", dt, cores)}
 
 
@@ -153,7 +153,7 @@ def main():
         L.dsm_get_matches(ctx._h, offs.data_ptr(), None, 0)
         total = int(offs[-1].item())
         n_matches = gather_var(lambda ptr, cap: L.dsm_get_matches(ctx._h, None, ptr, cap), total)
-        n_inl, n_models, n_ok = 0, 0, 0
+        n_inl, n_models, n_ok, score_flops = 0, 0, 0, 0.0
         if verify:
             maxp = int(np.diff(bounds).max())
             tv = torch.zeros((len(my_pairs), TVG_BYTES), dtype=torch.uint8, device=dev)
@@ -163,11 +163,15 @@ def main():
             tail = rec[:, TVG_BYTES - 16:].contiguous().view(torch.int32)  # num_models[4]
             n_ok = int((head[:, 0] > 1).sum().item())
             n_models = int(tail.sum().item())
+            # algorithmic FP64 flops of the inlier scoring: per (model, correspondence)
+            # 33 Sampson (E, F), 20 transfer (H), 5 translation (watermark)
+            w = torch.tensor([33.0, 33.0, 20.0, 5.0], dtype=torch.float64, device=dev)
+            score_flops = float((tail.to(torch.float64) @ w * head[:, 2].to(torch.float64)).sum().item())
             ioffs = torch.empty(len(my_pairs) + 1, dtype=torch.int64, device=dev)
             L.dsm_get_inlier_matches(ctx._h, ioffs.data_ptr(), None, 0)
             itotal = int(ioffs[-1].item())
             n_inl = gather_var(lambda ptr, cap: L.dsm_get_inlier_matches(ctx._h, None, ptr, cap), itotal)
-        return dict(matches=n_matches, inliers=n_inl, models=n_models, verified=n_ok)
+        return dict(matches=n_matches, inliers=n_inl, models=n_models, verified=n_ok, score_flops=score_flops)
 
     def step():
         ctx.match_pairs(my_pairs, opts)
@@ -239,6 +243,15 @@ def main():
                                  "(SURVEY.md 8d).  The kernel issues twice that (one directed pass per direction of the "
                                  "cross-check, each with its own fused top-2): executed_frac is the matrix-pipe view"},
         }
+        if verify and kv_ms > 0:
+            # second roofline, verification: algorithmic scoring flops of the step / device time of the verification
+            # kernels (solvers, local optimisation and the sequential replay are extra work on top of it)
+            fp64_peak = 78.6e12  # MI355X vector FP64 (MI355X_MICROARCH.md)
+            ach = res["score_flops"] / (1e-3 * kv_ms / args.steps) / max(world, 1)
+            out["roofline_verify"] = {"bound": "fp64-valu", "achieved": ach / 1e12, "peak": fp64_peak / 1e12, "unit": "TFLOP/s",
+                                      "frac": ach / fp64_peak, "traffic": None,
+                                      "note": "algorithmic inlier-scoring flops only (33 / 20 / 5 per model x correspondence), "
+                                              "per GPU, over the HIP-event time of all verification kernels"}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(images, pairs, args.cpu_seconds, verify, cams, topts, user_seed)
         print(json.dumps(out), flush=True)

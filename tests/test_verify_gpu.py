@@ -246,3 +246,51 @@ def test_estimate_multiple_stage(dsm, oracle):
             assert (got_inl == ref_inl).all()
         configs.add(ref.config)
     assert len(configs) >= 1
+
+
+def test_baseline_config1_size(dsm, oracle):
+    """BASELINE.json configs[0] shape: 50 images x 1 024 features, exhaustive (1 225 pairs), cameras without focal
+    prior (F + H path).  Matching is compared with the oracle on every 5th pair, verification on every 25th;
+    over ALL pairs the size-independent properties: ascending unique idx1, unique idx2, inlier matches an ordered
+    subsequence of the matches, config / inlier-count consistency."""
+    n_img = 50
+    scene = synthetic.Scene(n_img, 1024, seed=42)
+    ims = [scene.image(i) for i in range(n_img)]
+    cams = [capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, 0) for _ in range(n_img)]
+    dsm.set_images([im[0] for im in ims], [im[1] for im in ims], cams)
+    pairs = synthetic.exhaustive_pairs(n_img)
+    assert len(pairs) == 1225
+    dsm.match_pairs(pairs)
+    opts = capi.default_two_view_options()
+    dsm.verify_pairs(opts, user_seed=1, stage_filter=True)
+    offs, m = dsm.matches()
+    tvgs = dsm.two_view_geometries()
+    ioffs, im = dsm.inlier_matches()
+    n_geo = 0
+    for k, (i, j) in enumerate(pairs):
+        mk = m[int(offs[k]):int(offs[k + 1])]
+        ik = im[int(ioffs[k]):int(ioffs[k + 1])]
+        if len(mk) > 1:
+            assert (np.diff(mk[:, 0].astype(np.int64)) > 0).all()
+        assert len(np.unique(mk[:, 1])) == len(mk)
+        assert tvgs[k].num_inliers == len(ik) and tvgs[k].num_matches == len(mk)
+        if len(ik):
+            pos = np.searchsorted(mk[:, 0], ik[:, 0])
+            assert (mk[pos] == ik).all() and (np.diff(pos) > 0).all()
+            assert tvgs[k].config in (3, 4, 5, 6, 7) and len(ik) >= opts.min_num_inliers
+            n_geo += 1
+        else:
+            assert tvgs[k].config == 0
+        if k % 5 == 0:
+            ref_m = oracle.match_sift_features_cpu(ims[i][0], ims[j][0])
+            assert (mk == ref_m).all(), (i, j)
+            if k % 25 == 0:
+                ref, ref_inl = oracle.estimate_two_view_geometry(cams[i], ims[i][1].astype(np.float64), cams[j],
+                                                                 ims[j][1].astype(np.float64), ref_m, opts,
+                                                                 capi.pair_seed(int(i), int(j), 1))
+                if ref.num_inliers < opts.min_num_inliers:
+                    assert tvgs[k].config == 0
+                else:
+                    tvg_equal(tvgs[k], ref, (i, j))
+                    assert (ik == ref_inl).all()
+    assert n_geo > 100
