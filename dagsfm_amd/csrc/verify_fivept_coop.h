@@ -425,6 +425,7 @@ DSM_DEV int g5_poly_roots(G5Ws* ws, int gl) {
 DSM_DEV int g5_five_point_finish(G5Ws* ws, int gl, int group_shift) {
   g5v Eb = ws->Eb;
   g5v A = ws->A;
+  LSEC_BEGIN();
 #define LIN(r, c) (Eb + ((r) * 3 + (c)) * 4)
   for (int e = gl; e < 200; e += 16) A[e] = 0.0;
   // E E^T entries, one per lane
@@ -468,6 +469,8 @@ DSM_DEV int g5_five_point_finish(G5Ws* ws, int gl, int group_shift) {
     g5_quad_lin_mul_acc(ws->ht, LIN(i, j), -1.0, row);
   }
 #undef LIN
+  LSEC_END(8);
+  LSEC_BEGIN2();
   // ---- A[:, :10].partialPivLu().solve(A[:, 10:]) on the augmented 10 x 20 matrix
 #define AE(r, c) A[(r) * 20 + (c)]
   for (int k = 0; k < 10; ++k) {
@@ -526,6 +529,8 @@ DSM_DEV int g5_five_point_finish(G5Ws* ws, int gl, int group_shift) {
   }
 #undef AAe
 #undef AE
+  LSEC_END2(9);
+  LSEC_BEGIN3();
   // ---- determinant polynomial of B(z)
   if (gl < 3) {
     const int j = gl;
@@ -565,8 +570,12 @@ DSM_DEV int g5_five_point_finish(G5Ws* ws, int gl, int group_shift) {
       ws->coeffs[10 - i] = d;
     }
   }
+  LSEC_END3(10);
+  LSEC_BEGIN4();
   const int nroots = g5_poly_roots(ws, gl);
+  LSEC_END4(11);
   if (nroots < 0) return 0;
+  LSEC_BEGIN5();
   // ---- one root per lane
   bool valid = false;
   double model[9];
@@ -605,6 +614,7 @@ DSM_DEV int g5_five_point_finish(G5Ws* ws, int gl, int group_shift) {
   const int pos = __popc(gm & ((1u << gl) - 1u));
   if (valid)
     for (int k = 0; k < 9; ++k) ws->models[pos * 9 + k] = model[k];
+  LSEC_END5(12);
   return __popc(gm);
 }
 

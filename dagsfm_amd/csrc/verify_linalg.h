@@ -23,6 +23,8 @@
 
 #include <hip/hip_runtime.h>
 #include <float.h>
+
+#include <type_traits>
 #include <stdint.h>
 
 #define DSM_DEV __device__ __forceinline__
@@ -867,38 +869,60 @@ DSM_DEV void wv_colpiv_qr(double* M, int rows, int cols, WvSvdShared* sh, int la
           }
         }
         wv_sync();
-        for (int e = lane; e < nc * n; e += 64) {
-          const int j = e / n, i = e - j * n;
-          double* col = M + (size_t)(k + 1 + j) * rows + k;
-          const double tmp = sh->colbuf[j];
-          if (i == 0)
-            col[0] -= tau * tmp;
-          else
-            col[i] -= tau * ess[i - 1] * tmp;
+        if (n >= 64) {  // tall: one column after the other, lanes over the rows (no index division)
+          for (int j = 0; j < nc; ++j) {
+            double* col = M + (size_t)(k + 1 + j) * rows + k;
+            const double tmp = sh->colbuf[j];
+            for (int i = lane; i < n; i += 64) {
+              if (i == 0)
+                col[0] -= tau * tmp;
+              else
+                col[i] -= tau * ess[i - 1] * tmp;
+            }
+          }
+        } else {
+          for (int e = lane; e < nc * n; e += 64) {
+            const int j = e / n, i = e - j * n;
+            double* col = M + (size_t)(k + 1 + j) * rows + k;
+            const double tmp = sh->colbuf[j];
+            if (i == 0)
+              col[0] -= tau * tmp;
+            else
+              col[i] -= tau * ess[i - 1] * tmp;
+          }
         }
       }
       wv_sync();
-      // norm downdating (uniform over the wave; the rare re-computation is an in-order wave sum)
-      for (int c = 0; c < nc; ++c) {
-        const int j = k + 1 + c;
-        const double nu = sh->norms_u[j];
-        if (nu != 0.0) {
-          double temp = fabs(M[(size_t)j * rows + k]) / nu;
-          temp = (1.0 + temp) * (1.0 - temp);
-          temp = temp < 0.0 ? 0.0 : temp;
-          const double ratio = nu / sh->norms_d[j];
-          const double temp2 = temp * (ratio * ratio);
-          wv_sync();
-          if (temp2 <= norm_downdate_threshold) {
-            const double* col = M + (size_t)j * rows + (k + 1);
-            const double ss = wide ? wv_tree_sum(rows - k - 1, lane, [col](int i) { return col[i] * col[i]; })
-                                   : wv_seq_sum(0.0, rows - k - 1, lane, [col](int i) { return col[i] * col[i]; });
-            if (lane == 0) {
-              sh->norms_d[j] = sqrt(ss);
-              sh->norms_u[j] = sh->norms_d[j];
-            }
-          } else if (lane == 0) {
-            sh->norms_u[j] = nu * sqrt(temp);
+      // norm downdating: lane c owns column k+1+c (independent scalar work); the rare re-computation of a
+      // column norm is a wave-wide sum, done column by column for the flagged ones
+      {
+        bool recompute = false;
+        if (lane < nc) {
+          const int j = k + 1 + lane;
+          const double nu = sh->norms_u[j];
+          if (nu != 0.0) {
+            double temp = fabs(M[(size_t)j * rows + k]) / nu;
+            temp = (1.0 + temp) * (1.0 - temp);
+            temp = temp < 0.0 ? 0.0 : temp;
+            const double ratio = nu / sh->norms_d[j];
+            const double temp2 = temp * (ratio * ratio);
+            if (temp2 <= norm_downdate_threshold)
+              recompute = true;
+            else
+              sh->norms_u[j] = nu * sqrt(temp);
+          }
+        }
+        unsigned long long todo = __ballot(recompute);
+        while (todo) {
+          const int c = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          const int j = k + 1 + c;
+          const double* col = M + (size_t)j * rows + (k + 1);
+          const double ss = wide ? wv_tree_sum(rows - k - 1, lane, [col](int i) { return col[i] * col[i]; })
+                                 : wv_seq_sum(0.0, rows - k - 1, lane, [col](int i) { return col[i] * col[i]; });
+          if (lane == 0) {
+            sh->norms_d[j] = sqrt(ss);
+            sh->norms_u[j] = sh->norms_d[j];
           }
         }
       }
