@@ -107,6 +107,7 @@ struct dsm_ctx {
   DevBuf d_cams, d_pairs_dev, d_seeds, d_tvg, d_inl, d_inl_counts, d_inl_off, d_inl_compact, d_vscratch, d_inl_total;
   DevBuf d_nt_table, d_nt_off, d_nt_off_t, d_pair_state, d_pts_px, d_pts_norm, d_reports, d_masks;
   DevBuf d_fam_state, d_samples, d_draws_end, d_nmodels, d_vcounts, d_models, d_sidx, d_active;
+  DevBuf d_ework;
   DevBuf d_mm_matches[2], d_mm_off[2], d_mm_counts, d_mm_state, d_mm_first, d_mm_acc, d_mm_keep, d_mm_total;  // EstimateMultiple
   uint32_t verify_rounds[3] = {0, 0, 0};
   uint64_t total_inliers = 0;
@@ -217,7 +218,7 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
                     &ctx->d_vscratch, &ctx->d_inl_total, &ctx->d_nt_table, &ctx->d_nt_off, &ctx->d_nt_off_t,
                     &ctx->d_pair_state, &ctx->d_pts_px, &ctx->d_pts_norm, &ctx->d_reports, &ctx->d_masks,
                     &ctx->d_fam_state, &ctx->d_samples, &ctx->d_draws_end, &ctx->d_nmodels, &ctx->d_vcounts, &ctx->d_models,
-                    &ctx->d_sidx, &ctx->d_active, &ctx->d_mm_matches[0], &ctx->d_mm_matches[1], &ctx->d_mm_off[0],
+                    &ctx->d_sidx, &ctx->d_active, &ctx->d_ework, &ctx->d_mm_matches[0], &ctx->d_mm_matches[1], &ctx->d_mm_off[0],
                     &ctx->d_mm_off[1], &ctx->d_mm_counts, &ctx->d_mm_state, &ctx->d_mm_first, &ctx->d_mm_acc, &ctx->d_mm_keep,
                     &ctx->d_mm_total};
   if (ctx->vev0) (void)hipEventDestroy(ctx->vev0);
@@ -674,6 +675,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.nmodels = nullptr;
   vp.counts = nullptr;
   vp.models = nullptr;
+  vp.e_work = nullptr;
   vp.sidx_g = nullptr;
   vp.active_count = nullptr;
   const bool legacy = getenv("DSM_VERIFY_LEGACY") != nullptr;  // single-kernel-per-family schedule (debug)
@@ -691,7 +693,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
       bmax = std::max(bmax, batch[f]);
       bm_max = std::max<uint64_t>(bm_max, (uint64_t)batch[f] * vp_maxm(f));
     }
-    const uint64_t per_pair = (uint64_t)bmax * (7 * 4 + 4 + 4) + bm_max * (4 + 72);
+    const uint64_t per_pair = (uint64_t)bmax * (7 * 4 + 4 + 4) + bm_max * (4 + 72) + (uint64_t)batch[0] * 200 * 8;
     const uint64_t budget = 16ull << 30;
     const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_pairs, budget / per_pair));
     HIPCHK(ctx, ctx->d_fam_state.reserve(std::max<size_t>(n_pairs, 1) * 3 * sizeof(FamState)));
@@ -703,12 +705,14 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     HIPCHK(ctx, ctx->d_nmodels.reserve((size_t)chunk * bmax * 4));
     HIPCHK(ctx, ctx->d_vcounts.reserve((size_t)chunk * bm_max * 4));
     HIPCHK(ctx, ctx->d_models.reserve((size_t)chunk * bm_max * 72));
+    HIPCHK(ctx, ctx->d_ework.reserve((size_t)chunk * batch[0] * 200 * 8));
     vp.fam_state = ctx->d_fam_state.as<FamState>();
     vp.samples = ctx->d_samples.as<uint32_t>();
     vp.draws_end = ctx->d_draws_end.as<uint32_t>();
     vp.nmodels = ctx->d_nmodels.as<int32_t>();
     vp.counts = ctx->d_vcounts.as<int32_t>();
     vp.models = ctx->d_models.as<double>();
+    vp.e_work = ctx->d_ework.as<double>();
     vp.sidx_g = ctx->d_sidx.as<uint32_t>();
     vp.active_count = ctx->d_active.as<uint32_t>();
     ctx->verify_rounds[0] = ctx->verify_rounds[1] = ctx->verify_rounds[2] = 0;

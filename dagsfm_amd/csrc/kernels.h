@@ -90,6 +90,7 @@ struct VerifyParams {
   uint32_t n_pairs;
   uint32_t n_max;              // max matches of any pair in this launch
   int32_t stage_filter;        // apply SiftFeatureMatcher::Match's min_num_inliers post-filter
+  double* e_work;              // 5-point solver: the 10 x 20 constraint matrix of every hypothesis of the E batch
   int32_t sampler_serial;      // test hook (DSM_SAMPLER_SERIAL): force the sampler's serial replay path
   int32_t reseed;              // 1: k_verify_prep seeds the pair's generator; 0: it continues (EstimateMultiple passes)
   int32_t keep_generator;      // 1: k_verify_final stores the generator state for a following pass

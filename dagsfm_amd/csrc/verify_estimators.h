@@ -388,13 +388,8 @@ DSM_DEV void poly_mul(const double* a, int na, const double* b, int nb, double* 
 // `ws`: optional workspace of FIVEPT_WS doubles (LDS when a single lane runs the local optimisation,
 // so that its long dependent chains wait on LDS instead of scratch memory); nullptr = private arrays.
 #define FIVEPT_WS (200 + 100 + 100 + 100)
-// Steps 3-4a: the 10 x 20 constraint matrix, its elimination, B(z) and the determinant polynomial.
-template <bool WS>
-DSM_DEV void five_point_poly_t(const double* Eb, double* B, double* coeffs, double* ws) {
-  double A_loc[WS ? 1 : 200], A1_loc[WS ? 1 : 100], AA_loc[WS ? 1 : 100];
-  double* A = WS ? ws : A_loc;  // A[r*20 + c]
-  double* A1 = WS ? ws + 200 : A1_loc;
-  double* AA = WS ? ws + 300 : AA_loc;
+// Step 3: the 10 x 20 constraint matrix A[r*20 + c] (essential_matrix_poly.h restated by polynomial arithmetic).
+DSM_DEV void five_point_build_A(const double* Eb, double* A) {
   LSEC_BEGIN();
   for (int i = 0; i < 200; ++i) A[i] = 0.0;
   // lin(r, c) = Eb row (3r + c): 4 coefficients (x, y, z, 1)
@@ -440,16 +435,13 @@ DSM_DEV void five_point_poly_t(const double* Eb, double* B, double* coeffs, doub
   }
 #undef LIN
   LSEC_END(8);
-  LSEC_BEGIN2();
-  for (int r = 0; r < 10; ++r)  // A1, AA: column-major 10 x 10
-    for (int c = 0; c < 10; ++c) {
-      A1[c * 10 + r] = A[r * 20 + c];
-      AA[c * 10 + r] = A[r * 20 + 10 + c];
-    }
-  pl_lu_solve_10(A1, AA);
-  LSEC_END2(9);
+}
+
+// Steps 4a: B(z) from rows 4..9 of the eliminated system (S[(r-4)*10 + c] = AA(r, c)) and the determinant
+// polynomial (essential_matrix_coeffs.h restated), highest degree first.
+DSM_DEV void five_point_B_det(const double* S, double* B, double* coeffs) {
   LSEC_BEGIN3();
-#define AAe(r, c) AA[(c) * 10 + (r)]
+#define AAe(r, c) S[((r)-4) * 10 + (c)]
   // B[row*3 + col], 39 entries
   for (int i = 0; i < 3; ++i) {
     B[0 * 3 + i] = 0; B[4 * 3 + i] = 0; B[8 * 3 + i] = 0;
@@ -491,6 +483,28 @@ DSM_DEV void five_point_poly_t(const double* Eb, double* B, double* coeffs, doub
     for (int i = 0; i < 11; ++i) coeffs[i] = det[10 - i];
   }
   LSEC_END3(10);
+}
+
+// Steps 3-4a for one lane with private (or caller-provided) storage.
+template <bool WS>
+DSM_DEV void five_point_poly_t(const double* Eb, double* B, double* coeffs, double* ws) {
+  double A_loc[WS ? 1 : 200], A1_loc[WS ? 1 : 100], AA_loc[WS ? 1 : 100];
+  double* A = WS ? ws : A_loc;  // A[r*20 + c]
+  double* A1 = WS ? ws + 200 : A1_loc;
+  double* AA = WS ? ws + 300 : AA_loc;
+  five_point_build_A(Eb, A);
+  LSEC_BEGIN2();
+  for (int r = 0; r < 10; ++r)  // A1, AA: column-major 10 x 10
+    for (int c = 0; c < 10; ++c) {
+      A1[c * 10 + r] = A[r * 20 + c];
+      AA[c * 10 + r] = A[r * 20 + 10 + c];
+    }
+  pl_lu_solve_10(A1, AA);
+  LSEC_END2(9);
+  double S[60];
+  for (int r = 4; r < 10; ++r)
+    for (int c = 0; c < 10; ++c) S[(r - 4) * 10 + c] = AA[c * 10 + r];
+  five_point_B_det(S, B, coeffs);
 }
 
 // Step 5: one essential matrix per real root of the determinant polynomial (essential_matrix.cc:124-147).

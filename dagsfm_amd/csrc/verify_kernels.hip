@@ -1560,15 +1560,16 @@ __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_solve_score(cons
 
 // E family: the minimal solve is split in two kernels.  One lane per hypothesis keeps ~5 KB of matrices in
 // scratch memory, and with thousands of resident waves that scratch lives in HBM; two thirds of the time
-// went into the companion-matrix eigenvalue iteration alone.  k_solve_e_poly stops at the determinant
-// polynomial and parks (Eb, B, coefficients) in the hypothesis' model slot; k_roots_e runs the eigenvalue
+// went into the companion-matrix eigenvalue iteration alone.  k_solve_e_build (null space + constraint matrix,
+// to global memory) and k_solve_e_lu (pivoted elimination in LDS, determinant polynomial) park (Eb, B,
+// coefficients) in the hypothesis' model slot; k_roots_e runs the eigenvalue
 // iteration on a lane-interleaved 10 x 10 matrix in LDS (element e of lane l at T[e * 64 + l]: conflict-free,
 // no memory traffic; 51 KB per wave, so it is kept free of everything else); k_models_score_e builds and
 // scores the models at full occupancy.  Same operations, same order.
 #define EPOLY_EB 0
 #define EPOLY_B 36
 #define EPOLY_COEFFS 75
-__global__ __launch_bounds__(64, 4) void k_solve_e_poly(const VerifyParams p) {
+__global__ __launch_bounds__(64, 4) void k_solve_e_build(const VerifyParams p) {
   const uint32_t pl = blockIdx.x;
   const uint32_t pi = p.pair0 + pl;
   const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
@@ -1582,11 +1583,94 @@ __global__ __launch_bounds__(64, 4) void k_solve_e_poly(const VerifyParams p) {
     const double* q = pts + (size_t)smp[i] * 4;
     xs[i * 4 + 0] = q[0]; xs[i * 4 + 1] = q[1]; xs[i * 4 + 2] = q[2]; xs[i * 4 + 3] = q[3];
   }
-  double Eb[36], B[39], coeffs[11];
+  double Eb[36], A[200];
   five_point_basis(xs, Eb);
-  five_point_poly_t<false>(Eb, B, coeffs, nullptr);
+  five_point_build_A(Eb, A);
   double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
   for (int k = 0; k < 36; ++k) slot[EPOLY_EB + k] = Eb[k];
+  double* Ag = p.e_work + ((size_t)pl * p.batch + t) * 200;
+  for (int k = 0; k < 200; ++k) Ag[k] = A[k];
+}
+
+// A[:, :10].partialPivLu().solve(A[:, 10:]) (essential_matrix.cc:80) with the 10 x 10 factor in lane-interleaved
+// LDS (element (i, k) of lane l at Al[(k*10 + i)*64 + l]; the pivoted row swaps index it dynamically, which
+// would otherwise force it into scratch memory), the right-hand sides one column at a time in registers.
+// Only rows 4..9 of the solution enter B(z), so the back substitution stops there.  Same operations in the
+// same order as pl_lu_solve_10.
+#define ELU_SMEM (100 * 64 * 8 + 10 * 64)
+__global__ __launch_bounds__(64) void k_solve_e_lu(const VerifyParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* Al = reinterpret_cast<double*>(smem_raw) + threadIdx.x;
+  unsigned char* idx = smem_raw + 100 * 64 * 8 + threadIdx.x;  // idx[i*64]: original row now in row i
+  const uint32_t pl = blockIdx.x;
+  const uint32_t pi = p.pair0 + pl;
+  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
+  if (!fs->active) return;
+  const int t = blockIdx.y * 64 + threadIdx.x;
+  if (t >= (int)fs->nb) return;
+  const double* Ag = p.e_work + ((size_t)pl * p.batch + t) * 200;  // A[r*20 + c]
+#define LA(i, k) Al[((k) * 10 + (i)) * 64]
+  LSEC_BEGIN2();
+  for (int r = 0; r < 10; ++r)
+    for (int c = 0; c < 10; ++c) LA(r, c) = Ag[r * 20 + c];
+  for (int i = 0; i < 10; ++i) idx[i * 64] = (unsigned char)i;
+  for (int k = 0; k < 10; ++k) {
+    int r = k;
+    double best = fabs(LA(k, k));
+    for (int i = k + 1; i < 10; ++i) {
+      const double a = fabs(LA(i, k));
+      if (a > best) {
+        best = a;
+        r = i;
+      }
+    }
+    if (best != 0.0) {
+      if (r != k) {
+        for (int j = 0; j < 10; ++j) {
+          const double tmp = LA(k, j);
+          LA(k, j) = LA(r, j);
+          LA(r, j) = tmp;
+        }
+        const unsigned char ti = idx[k * 64];
+        idx[k * 64] = idx[r * 64];
+        idx[r * 64] = ti;
+      }
+      const double piv = LA(k, k);
+      for (int i = k + 1; i < 10; ++i) LA(i, k) /= piv;
+    }
+    for (int j = k + 1; j < 10; ++j) {
+      const double akj = LA(k, j);
+      for (int i = k + 1; i < 10; ++i) LA(i, j) -= LA(i, k) * akj;
+    }
+  }
+  double S[60];  // S[(r-4)*10 + c] = solution(r, c), rows 4..9
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    double b[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) b[i] = Ag[(int)idx[i * 64] * 20 + 10 + j];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      double s = b[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) s -= LA(i, k) * b[k];
+      b[i] = s;
+    }
+#pragma unroll
+    for (int i = 9; i >= 4; --i) {
+      double s = b[i];
+#pragma unroll
+      for (int k = 9; k > i; --k) s -= LA(i, k) * b[k];
+      b[i] = s / LA(i, i);
+    }
+#pragma unroll
+    for (int i = 4; i < 10; ++i) S[(i - 4) * 10 + j] = b[i];
+  }
+  LSEC_END2(9);
+#undef LA
+  double B[39], coeffs[11];
+  five_point_B_det(S, B, coeffs);
+  double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
   for (int k = 0; k < 39; ++k) slot[EPOLY_B + k] = B[k];
   for (int k = 0; k < 11; ++k) slot[EPOLY_COEFFS + k] = coeffs[k];
 }
@@ -1895,7 +1979,8 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
   const dim3 grid(p.n_chunk, (p.batch + 63) / 64);
   const size_t smem = (size_t)(p.n_max < VP_LDS_PTS ? (p.n_max > 0 ? p.n_max : 1) : VP_LDS_PTS) * 32;
   if (fam == FAM_E) {
-    hipLaunchKernelGGL(k_solve_e_poly, grid, dim3(64), 0, st, p);
+    hipLaunchKernelGGL(k_solve_e_build, grid, dim3(64), 0, st, p);
+    hipLaunchKernelGGL(k_solve_e_lu, grid, dim3(64), ELU_SMEM, st, p);
     hipLaunchKernelGGL(k_roots_e, grid, dim3(64), 100 * 64 * sizeof(double), st, p);
     hipLaunchKernelGGL(k_models_score_e, grid, dim3(64), smem, st, p);
   }

@@ -107,13 +107,16 @@ def test_watermark_configuration(dsm, oracle):
     assert (got_inl == ref_inl).all()
 
 
-@pytest.mark.parametrize("prior,sampler_serial", [(0, False), (1, False), (1, True)])
-def test_stage_match_and_verify_many_pairs(dsm, oracle, prior, sampler_serial, monkeypatch):
+@pytest.mark.parametrize("prior,sampler_serial,legacy", [(0, False, False), (1, False, False), (1, True, False), (1, False, True)])
+def test_stage_match_and_verify_many_pairs(dsm, oracle, prior, sampler_serial, legacy, monkeypatch):
     """dsm_match_pairs + dsm_verify_pairs over an exhaustive pair list == oracle matcher + oracle verifier
     with SiftFeatureMatcher::Match's post-filter (matching.cc:824-831).  sampler_serial forces the sampler's
-    rarely taken serial replay path (a Lemire rejection) for every round."""
+    rarely taken serial replay path (a Lemire rejection) for every round; legacy runs the single-kernel-per-family
+    schedule (DSM_VERIFY_LEGACY)."""
     if sampler_serial:
         monkeypatch.setenv("DSM_SAMPLER_SERIAL", "1")
+    if legacy:  # the first schedule of this round: one k_ransac kernel per family, wave per pair
+        monkeypatch.setenv("DSM_VERIFY_LEGACY", "1")
     n_img = 7
     scene = synthetic.Scene(n_img, 768, seed=21, n_pool=2048)
     ims = [scene.image(i) for i in range(n_img)]
