@@ -437,6 +437,105 @@ DSM_DEV void five_point_build_A(const double* Eb, double* A) {
   LSEC_END(8);
 }
 
+// Step 3 again, row by row with every index a compile-time constant, so that the accumulators live in
+// registers instead of a 200-double private array (the batch kernel k_solve_e_build): row r is written to
+// out[r*20 .. r*20+20) as soon as it is complete.  E E^T entries are recomputed per row (three of them, 144
+// multiply-adds) rather than kept (90 doubles).  Operation order per output element as in five_point_build_A.
+constexpr int cLL[4][4] = {{0, 3, 4, 6}, {3, 1, 5, 7}, {4, 5, 2, 8}, {6, 7, 8, 9}};
+constexpr int cQL[10][4] = {{0, 2, 4, 5},   {3, 1, 6, 7},   {10, 13, 16, 17}, {2, 3, 8, 9},    {4, 8, 10, 11},
+                            {8, 6, 13, 14}, {5, 9, 11, 12}, {9, 7, 14, 15},   {11, 14, 17, 18}, {12, 15, 18, 19}};
+template <int RA, int CA, int RB, int CB>
+DSM_DEV void c_lin_mul_acc(const double (&Eb)[36], double (&quad)[10]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) quad[cLL[i][j]] += Eb[(RA * 3 + CA) * 4 + i] * Eb[(RB * 3 + CB) * 4 + j];
+}
+template <int RL, int CL>
+DSM_DEV void c_quad_lin_mul_acc(const double (&q)[10], const double (&Eb)[36], double sign, double (&cubic)[20]) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cubic[cQL[i][j]] += sign * (q[i] * Eb[(RL * 3 + CL) * 4 + j]);
+}
+template <int I, int K>
+DSM_DEV void c_EEt(const double (&Eb)[36], double (&e)[10]) {  // (E E^T)(I, K) = sum_m lin(I, m) * lin(K, m)
+#pragma unroll
+  for (int q = 0; q < 10; ++q) e[q] = 0.0;
+  c_lin_mul_acc<I, 0, K, 0>(Eb, e);
+  c_lin_mul_acc<I, 1, K, 1>(Eb, e);
+  c_lin_mul_acc<I, 2, K, 2>(Eb, e);
+}
+template <int I, int J>
+DSM_DEV void c_trace_row(const double (&Eb)[36], const double (&ht)[10], double* out) {
+  double row[20];
+#pragma unroll
+  for (int q = 0; q < 20; ++q) row[q] = 0.0;
+  double e[10];
+  c_EEt<I, 0>(Eb, e);
+  c_quad_lin_mul_acc<0, J>(e, Eb, 1.0, row);
+  c_EEt<I, 1>(Eb, e);
+  c_quad_lin_mul_acc<1, J>(e, Eb, 1.0, row);
+  c_EEt<I, 2>(Eb, e);
+  c_quad_lin_mul_acc<2, J>(e, Eb, 1.0, row);
+  c_quad_lin_mul_acc<I, J>(ht, Eb, -1.0, row);
+#pragma unroll
+  for (int q = 0; q < 20; ++q) out[(1 + I * 3 + J) * 20 + q] = row[q];
+}
+DSM_DEV void five_point_build_A_rows(const double* Eb_in, double* out) {
+  double Eb[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) Eb[k] = Eb_in[k];
+  {  // determinant row
+    double m0[10], m1[10], m2[10], tmp[10], row[20];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) m0[i] = m1[i] = m2[i] = tmp[i] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 20; ++q) row[q] = 0.0;
+    c_lin_mul_acc<1, 1, 2, 2>(Eb, m0);
+    c_lin_mul_acc<1, 2, 2, 1>(Eb, tmp);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      m0[i] -= tmp[i];
+      tmp[i] = 0.0;
+    }
+    c_lin_mul_acc<1, 0, 2, 2>(Eb, m1);
+    c_lin_mul_acc<1, 2, 2, 0>(Eb, tmp);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      m1[i] -= tmp[i];
+      tmp[i] = 0.0;
+    }
+    c_lin_mul_acc<1, 0, 2, 1>(Eb, m2);
+    c_lin_mul_acc<1, 1, 2, 0>(Eb, tmp);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) m2[i] -= tmp[i];
+    c_quad_lin_mul_acc<0, 0>(m0, Eb, 1.0, row);
+    c_quad_lin_mul_acc<0, 1>(m1, Eb, -1.0, row);
+    c_quad_lin_mul_acc<0, 2>(m2, Eb, 1.0, row);
+#pragma unroll
+    for (int q = 0; q < 20; ++q) out[q] = row[q];
+  }
+  double ht[10];
+  {
+    double e0[10], e1[10], e2[10];
+    c_EEt<0, 0>(Eb, e0);
+    c_EEt<1, 1>(Eb, e1);
+    c_EEt<2, 2>(Eb, e2);
+#pragma unroll
+    for (int q = 0; q < 10; ++q) ht[q] = 0.5 * (e0[q] + e1[q] + e2[q]);
+  }
+  c_trace_row<0, 0>(Eb, ht, out);
+  c_trace_row<0, 1>(Eb, ht, out);
+  c_trace_row<0, 2>(Eb, ht, out);
+  c_trace_row<1, 0>(Eb, ht, out);
+  c_trace_row<1, 1>(Eb, ht, out);
+  c_trace_row<1, 2>(Eb, ht, out);
+  c_trace_row<2, 0>(Eb, ht, out);
+  c_trace_row<2, 1>(Eb, ht, out);
+  c_trace_row<2, 2>(Eb, ht, out);
+}
+
 // Steps 4a: B(z) from rows 4..9 of the eliminated system (S[(r-4)*10 + c] = AA(r, c)) and the determinant
 // polynomial (essential_matrix_coeffs.h restated), highest degree first.
 DSM_DEV void five_point_B_det(const double* S, double* B, double* coeffs) {

@@ -1569,7 +1569,7 @@ __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_solve_score(cons
 #define EPOLY_EB 0
 #define EPOLY_B 36
 #define EPOLY_COEFFS 75
-__global__ __launch_bounds__(64, 4) void k_solve_e_build(const VerifyParams p) {
+__global__ __launch_bounds__(64, 2) void k_solve_e_build(const VerifyParams p) {
   const uint32_t pl = blockIdx.x;
   const uint32_t pi = p.pair0 + pl;
   const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
@@ -1583,13 +1583,11 @@ __global__ __launch_bounds__(64, 4) void k_solve_e_build(const VerifyParams p) {
     const double* q = pts + (size_t)smp[i] * 4;
     xs[i * 4 + 0] = q[0]; xs[i * 4 + 1] = q[1]; xs[i * 4 + 2] = q[2]; xs[i * 4 + 3] = q[3];
   }
-  double Eb[36], A[200];
+  double Eb[36];
   five_point_basis(xs, Eb);
-  five_point_build_A(Eb, A);
   double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
   for (int k = 0; k < 36; ++k) slot[EPOLY_EB + k] = Eb[k];
-  double* Ag = p.e_work + ((size_t)pl * p.batch + t) * 200;
-  for (int k = 0; k < 200; ++k) Ag[k] = A[k];
+  five_point_build_A_rows(Eb, p.e_work + ((size_t)pl * p.batch + t) * 200);
 }
 
 // A[:, :10].partialPivLu().solve(A[:, 10:]) (essential_matrix.cc:80) with the 10 x 10 factor in lane-interleaved
