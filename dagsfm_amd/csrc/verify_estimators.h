@@ -94,17 +94,22 @@ DSM_DEV void apply_norm(double nf, double m02, double m12, double p_0, double p_
 // ---------------------------------------------------------------------------------- 7-point F
 // FundamentalMatrixSevenPointEstimator::Estimate, /root/reference/src/estimators/fundamental_matrix.cc:47-142
 // xs: 7 correspondences (x1 y1 x2 y2).  Returns the number of models written to models[k*9].
-DSM_DEVN int seven_point(const double* xs, double* models) {
-  double At[63];  // A^T, 9 x 7 column-major: At[i*9 + c] = A(i, c)
+// ES > 1: the 9 x 7 working matrix lives in `At_ext` with element stride ES (lane-interleaved LDS of the batch
+// kernel: its pivoted QR indexes it dynamically, which would otherwise put it in scratch memory).
+template <int ES>
+DSM_DEV int seven_point_t(const double* xs, double* models, double* At_ext) {
+  double At_loc[ES == 1 ? 63 : 1];  // A^T, 9 x 7 column-major: At[i*9 + c] = A(i, c)
+  double* At;
+  if constexpr (ES == 1) At = At_loc; else At = At_ext;
   for (int i = 0; i < 7; ++i) {
     const double x0 = xs[i * 4 + 0], y0 = xs[i * 4 + 1], x1 = xs[i * 4 + 2], y1 = xs[i * 4 + 3];
-    double* r = At + i * 9;
-    r[0] = x1 * x0; r[1] = x1 * y0; r[2] = x1;
-    r[3] = y1 * x0; r[4] = y1 * y0; r[5] = y1;
-    r[6] = x0; r[7] = y0; r[8] = 1;
+    double* r = At + i * 9 * ES;
+    r[0 * ES] = x1 * x0; r[1 * ES] = x1 * y0; r[2 * ES] = x1;
+    r[3 * ES] = y1 * x0; r[4 * ES] = y1 * y0; r[5 * ES] = y1;
+    r[6 * ES] = x0; r[7 * ES] = y0; r[8 * ES] = 1;
   }
   double nv[18];
-  pl_nullspace_9xm(At, 7, 7, nv);
+  pl_nullspace_9xm<ES>(At, 7, 7, nv);
   double* f1 = nv;
   double* f2 = nv + 9;
   for (int k = 0; k < 9; ++k) f1[k] -= f2[k];
@@ -142,6 +147,7 @@ DSM_DEVN int seven_point(const double* xs, double* models) {
   }
   return nm;
 }
+DSM_DEVN int seven_point(const double* xs, double* models) { return seven_point_t<1>(xs, models, nullptr); }
 
 // Rank-2 projection + de-normalisation of the 8-point estimator (fundamental_matrix.cc:172-191);
 // nullvec = cmatrix_svd.matrixV().col(8); N1/N2 given as (nf, m02, m12).

@@ -1450,7 +1450,7 @@ void launch_verify(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
 // samples and (b) comparing supports in trial order; solving and scoring the speculated trials is flat
 // data-parallel work.  Per family and round:
 //   k_sample        wave per pair, lane 0 draws `batch` minimal samples (light kernel, high occupancy)
-//   k_solve_score   lane per hypothesis over ALL pairs x trials: minimal solve + inlier count of its models
+//   k_solve/k_score lane per hypothesis (per model) over ALL pairs x trials: minimal solve, inlier counts
 //   k_replay        wave per pair: scans the counts in trial order (ballot-skipping the trials that can change
 //                   nothing), re-scores candidates with the in-order residual_sum, runs the local
 //                   optimisation, applies the dynamic stop, rewinds the generator on an early stop
@@ -1501,11 +1501,43 @@ __global__ __launch_bounds__(64) void k_sample(const VerifyParams p) {
   }
 }
 
-// lane per hypothesis: block = 64 consecutive trials of one pair; the pair's correspondences are staged in
-// LDS when they fit (VP_LDS_PTS), every lane then scores its own models over all of them (broadcast reads).
+// the pair's correspondences are staged in LDS when they fit
 #define VP_LDS_PTS 1536
+// F and H: solver and inlier counting as two kernels.  k_solve keeps the solver's working set (F: the 9 x 7
+// matrix in lane-interleaved LDS; H: ~220 VGPRs) away from the counting loop, which is pure FP64 VALU work
+// with a 9-double model per lane and wants many resident waves; k_score gives every (trial, model) slot its
+// own lane, so a 7-point sample with three roots costs three lanes instead of three passes of its lane.
 template <int FAM>
-__global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_solve_score(const VerifyParams p) {
+__global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_solve(const VerifyParams p) {
+  typedef Fam<FAM> F;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* At_l = reinterpret_cast<double*>(smem_raw) + threadIdx.x;  // F only: 63 x 64 doubles
+  const uint32_t pl = blockIdx.x;
+  const uint32_t pi = p.pair0 + pl;
+  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
+  if (!fs->active) return;
+  const int t = blockIdx.y * 64 + threadIdx.x;
+  if (t >= (int)fs->nb) return;
+  const double* pts = p.pts_px + 4 * p.match_off[pi];
+  const uint32_t* smp = p.samples + ((size_t)pl * p.batch + t) * 7;
+  double xs[F::K * 4];
+  for (int i = 0; i < F::K; ++i) {
+    const double* q = pts + (size_t)smp[i] * 4;
+    xs[i * 4 + 0] = q[0]; xs[i * 4 + 1] = q[1]; xs[i * 4 + 2] = q[2]; xs[i * 4 + 3] = q[3];
+  }
+  double mloc[F::MAXM * 9];
+  int nm;
+  if constexpr (FAM == FAM_F)
+    nm = seven_point_t<64>(xs, mloc, At_l);
+  else
+    nm = fam_minimal<FAM>(xs, mloc);
+  p.nmodels[(size_t)pl * p.batch + t] = nm;
+  double* gm = p.models + ((size_t)pl * p.batch + t) * F::MAXM * 9;
+  for (int k = 0; k < nm * 9; ++k) gm[k] = mloc[k];
+}
+
+template <int FAM>
+__global__ __launch_bounds__(64, 8) void k_score(const VerifyParams p) {
   typedef Fam<FAM> F;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* spts = reinterpret_cast<double*>(smem_raw);  // min(n_max, VP_LDS_PTS) x 4 doubles
@@ -1514,48 +1546,27 @@ __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_solve_score(cons
   const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
   if (!fs->active) return;
   const int lane = threadIdx.x;
-  const int t = blockIdx.y * 64 + lane;
   const int nb = (int)fs->nb;
-  if ((int)(blockIdx.y * 64) >= nb) return;
+  const int slot = blockIdx.y * 64 + lane;  // (trial, model) = (slot / MAXM, slot % MAXM)
+  if ((int)(blockIdx.y * 64) / F::MAXM >= nb) return;
+  const int t = slot / F::MAXM, m = slot - t * F::MAXM;
   const uint64_t moff = p.match_off[pi];
   const int n = (int)(p.match_off[pi + 1] - moff);
-  const double* gpts = (FAM == FAM_E ? p.pts_norm : p.pts_px) + 4 * moff;
+  const double* gpts = p.pts_px + 4 * moff;
   const bool in_lds = n <= VP_LDS_PTS;
   if (in_lds) {
     for (int e = lane; e < 4 * n; e += 64) spts[e] = gpts[e];
     __syncthreads();
   }
   const double* pts = in_lds ? spts : gpts;
-  double max_error = p.opt.max_error;
-  if (FAM == FAM_E) {
-    const dsm_camera& cam1 = p.cams[p.pairs[2 * pi]];
-    const dsm_camera& cam2 = p.cams[p.pairs[2 * pi + 1]];
-    max_error = (image_to_world_threshold(cam1, p.opt.max_error) + image_to_world_threshold(cam2, p.opt.max_error)) / 2;
-  }
-  const double max_residual = max_error * max_error;
-  int nm = 0;
-  double mloc[F::MAXM * 9];
-  if (t < nb) {
-    const uint32_t* smp = p.samples + ((size_t)pl * p.batch + t) * 7;
-    double xs[F::K * 4];
-    for (int i = 0; i < F::K; ++i) {
-      const double* q = pts + (size_t)smp[i] * 4;
-      xs[i * 4 + 0] = q[0]; xs[i * 4 + 1] = q[1]; xs[i * 4 + 2] = q[2]; xs[i * 4 + 3] = q[3];
-    }
-    nm = fam_minimal<FAM>(xs, mloc);
-    p.nmodels[(size_t)pl * p.batch + t] = nm;
-  }
-  LSEC_BEGIN();
-  double* gm = p.models + ((size_t)pl * p.batch + (size_t)(t < nb ? t : 0)) * F::MAXM * 9;
-  int32_t* gc = p.counts + ((size_t)pl * p.batch + (size_t)(t < nb ? t : 0)) * F::MAXM;
-  for (int m = 0; m < nm; ++m) {
-    const double* M = mloc + m * 9;
-    int cnt = 0;
-    for (int i = 0; i < n; ++i) cnt += (fam_residual<FAM>(M, pts + (size_t)i * 4) <= max_residual) ? 1 : 0;
-    gc[m] = cnt;
-    for (int k = 0; k < 9; ++k) gm[m * 9 + k] = M[k];
-  }
-  LSEC_END(13 + (FAM == FAM_E ? 0 : 1));
+  const double max_residual = p.opt.max_error * p.opt.max_error;
+  if (t >= nb || m >= p.nmodels[(size_t)pl * p.batch + t]) return;
+  const double* gm = p.models + ((size_t)pl * p.batch + t) * F::MAXM * 9 + m * 9;
+  double M[9];
+  for (int k = 0; k < 9; ++k) M[k] = gm[k];
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) cnt += (fam_residual<FAM>(M, pts + (size_t)i * 4) <= max_residual) ? 1 : 0;
+  p.counts[((size_t)pl * p.batch + t) * F::MAXM + m] = cnt;
 }
 
 // E family: the minimal solve is split in two kernels.  One lane per hypothesis keeps ~5 KB of matrices in
@@ -1982,8 +1993,14 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
     hipLaunchKernelGGL(k_roots_e, grid, dim3(64), 100 * 64 * sizeof(double), st, p);
     hipLaunchKernelGGL(k_models_score_e, grid, dim3(64), smem, st, p);
   }
-  if (fam == FAM_F) hipLaunchKernelGGL(k_solve_score<FAM_F>, grid, dim3(64), smem, st, p);
-  if (fam == FAM_H) hipLaunchKernelGGL(k_solve_score<FAM_H>, grid, dim3(64), smem, st, p);
+  if (fam == FAM_F) {
+    hipLaunchKernelGGL(k_solve<FAM_F>, grid, dim3(64), 63 * 64 * sizeof(double), st, p);
+    hipLaunchKernelGGL(k_score<FAM_F>, dim3(p.n_chunk, (p.batch * 3 + 63) / 64), dim3(64), smem, st, p);
+  }
+  if (fam == FAM_H) {
+    hipLaunchKernelGGL(k_solve<FAM_H>, grid, dim3(64), 0, st, p);
+    hipLaunchKernelGGL(k_score<FAM_H>, grid, dim3(64), smem, st, p);
+  }
 }
 void launch_vp_replay(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st) {
   if (!p.n_chunk || !n_blocks) return;

@@ -33,18 +33,20 @@
 // ====================================================================== per-lane routines
 // Column-major storage with leading dimension ld, like Eigen.
 
+// ES = element stride of x (see pl_apply_householder_left)
+template <int ES = 1>
 DSM_DEV void pl_make_householder(double* x, int n, double* tau, double* beta) {
   double tail_sq = 0.0;
-  for (int i = 1; i < n; ++i) tail_sq += x[i] * x[i];
+  for (int i = 1; i < n; ++i) tail_sq += x[i * ES] * x[i * ES];
   const double c0 = x[0];
   if (tail_sq <= DBL_MIN) {
     *tau = 0.0;
     *beta = c0;
-    for (int i = 1; i < n; ++i) x[i] = 0.0;
+    for (int i = 1; i < n; ++i) x[i * ES] = 0.0;
   } else {
     double b = sqrt(c0 * c0 + tail_sq);
     if (c0 >= 0.0) b = -b;
-    for (int i = 1; i < n; ++i) x[i] = x[i] / (c0 - b);
+    for (int i = 1; i < n; ++i) x[i * ES] = x[i * ES] / (c0 - b);
     *tau = (b - c0) / b;
     *beta = b;
   }
@@ -52,7 +54,8 @@ DSM_DEV void pl_make_householder(double* x, int n, double* tau, double* beta) {
 
 // ES = element stride: 1 for a private matrix, 64 for a matrix whose elements are interleaved over the
 // lanes of a wave in LDS (element e of lane l at base[e * 64 + l], M = base + l)
-template <int ES = 1>
+// ESS = element stride of the essential part (it may live inside the strided matrix itself)
+template <int ES = 1, int ESS = 1>
 DSM_DEV void pl_apply_householder_left(double* M, int ld, int r0, int c0, int nr, int nc, const double* ess, double tau) {
   if (nr == 1) {
     for (int j = 0; j < nc; ++j) M[((c0 + j) * ld + r0) * ES] *= (1.0 - tau);
@@ -60,10 +63,10 @@ DSM_DEV void pl_apply_householder_left(double* M, int ld, int r0, int c0, int nr
     for (int j = 0; j < nc; ++j) {
       double* col = M + ((c0 + j) * ld + r0) * ES;
       double tmp = 0.0;
-      for (int i = 1; i < nr; ++i) tmp += ess[i - 1] * col[i * ES];
+      for (int i = 1; i < nr; ++i) tmp += ess[(i - 1) * ESS] * col[i * ES];
       tmp += col[0];
       col[0] -= tau * tmp;
-      for (int i = 1; i < nr; ++i) col[i * ES] -= tau * ess[i - 1] * tmp;
+      for (int i = 1; i < nr; ++i) col[i * ES] -= tau * ess[(i - 1) * ESS] * tmp;
     }
   }
 }
@@ -84,12 +87,14 @@ DSM_DEV void pl_apply_householder_right(double* M, int ld, int r0, int c0, int n
 }
 
 // ColPivHouseholderQR::computeInPlace on qr (rows x cols, rows >= cols here), ld = rows.
+template <int ES = 1>
 DSM_DEV void pl_colpiv_qr(double* qr, int rows, int cols, double* hcoeffs) {
+#define QR(i) qr[(i) * ES]
   const int size = rows < cols ? rows : cols;
   double norms_updated[9], norms_direct[9];
   for (int k = 0; k < cols; ++k) {
     double s = 0.0;
-    for (int i = 0; i < rows; ++i) s += qr[k * rows + i] * qr[k * rows + i];
+    for (int i = 0; i < rows; ++i) s += QR(k * rows + i) * QR(k * rows + i);
     norms_direct[k] = sqrt(s);
     norms_updated[k] = norms_direct[k];
   }
@@ -104,9 +109,9 @@ DSM_DEV void pl_colpiv_qr(double* qr, int rows, int cols, double* hcoeffs) {
       }
     if (k != biggest) {
       for (int i = 0; i < rows; ++i) {
-        const double t = qr[k * rows + i];
-        qr[k * rows + i] = qr[biggest * rows + i];
-        qr[biggest * rows + i] = t;
+        const double t = QR(k * rows + i);
+        QR(k * rows + i) = QR(biggest * rows + i);
+        QR(biggest * rows + i) = t;
       }
       double t = norms_updated[k];
       norms_updated[k] = norms_updated[biggest];
@@ -116,20 +121,20 @@ DSM_DEV void pl_colpiv_qr(double* qr, int rows, int cols, double* hcoeffs) {
       norms_direct[biggest] = t;
     }
     double tau, beta;
-    pl_make_householder(qr + k * rows + k, rows - k, &tau, &beta);
+    pl_make_householder<ES>(qr + (k * rows + k) * ES, rows - k, &tau, &beta);
     hcoeffs[k] = tau;
-    qr[k * rows + k] = beta;
-    pl_apply_householder_left(qr, rows, k, k + 1, rows - k, cols - k - 1, qr + k * rows + k + 1, tau);
+    QR(k * rows + k) = beta;
+    pl_apply_householder_left<ES, ES>(qr, rows, k, k + 1, rows - k, cols - k - 1, qr + (k * rows + k + 1) * ES, tau);
     for (int j = k + 1; j < cols; ++j) {
       if (norms_updated[j] != 0.0) {
-        double temp = fabs(qr[j * rows + k]) / norms_updated[j];
+        double temp = fabs(QR(j * rows + k)) / norms_updated[j];
         temp = (1.0 + temp) * (1.0 - temp);
         temp = temp < 0.0 ? 0.0 : temp;
         const double ratio = norms_updated[j] / norms_direct[j];
         const double temp2 = temp * (ratio * ratio);
         if (temp2 <= norm_downdate_threshold) {
           double s = 0.0;
-          for (int i = k + 1; i < rows; ++i) s += qr[j * rows + i] * qr[j * rows + i];
+          for (int i = k + 1; i < rows; ++i) s += QR(j * rows + i) * QR(j * rows + i);
           norms_direct[j] = sqrt(s);
           norms_updated[j] = norms_direct[j];
         } else {
@@ -138,24 +143,26 @@ DSM_DEV void pl_colpiv_qr(double* qr, int rows, int cols, double* hcoeffs) {
       }
     }
   }
+#undef QR
 }
 
 // Column j of householderQ() (rows x rows) of a pivoted QR with `size` reflectors.
+template <int ES = 1>
 DSM_DEV void pl_householder_q_col(const double* qr, int rows, int size, const double* hcoeffs, int j, double* q) {
   for (int i = 0; i < rows; ++i) q[i] = (i == j) ? 1.0 : 0.0;
   for (int k = size - 1; k >= 0; --k) {
     if (j < k) continue;  // the block starts at column k
     const int nr = rows - k;
     const double tau = hcoeffs[k];
-    const double* ess = qr + k * rows + k + 1;
+    const double* ess = qr + (k * rows + k + 1) * ES;
     if (nr == 1) {
       q[k] *= (1.0 - tau);
     } else if (tau != 0.0) {
       double tmp = 0.0;
-      for (int i = 1; i < nr; ++i) tmp += ess[i - 1] * q[k + i];
+      for (int i = 1; i < nr; ++i) tmp += ess[(i - 1) * ES] * q[k + i];
       tmp += q[k];
       q[k] -= tau * tmp;
-      for (int i = 1; i < nr; ++i) q[k + i] -= tau * ess[i - 1] * tmp;
+      for (int i = 1; i < nr; ++i) q[k + i] -= tau * ess[(i - 1) * ES] * tmp;
     }
   }
 }
@@ -163,17 +170,19 @@ DSM_DEV void pl_householder_q_col(const double* qr, int rows, int size, const do
 // Null-space columns of V for a `m x 9` system with m < 9 (JacobiSVD "more columns than rows"
 // path): V = householderQ of ColPivQR((A / scale)^T).  At holds A^T (9 x m, column-major, ld 9)
 // and is destroyed.  Writes columns first..8 of V into out[(c - first) * 9 + r].
+// ES: element stride of At (1 = private array, 64 = lane-interleaved LDS).
+template <int ES = 1>
 DSM_DEV void pl_nullspace_9xm(double* At, int m, int first, double* out) {
   double scale = 0.0;
   for (int i = 0; i < 9 * m; ++i) {
-    const double a = fabs(At[i]);
+    const double a = fabs(At[i * ES]);
     if (a > scale) scale = a;
   }
   if (scale == 0.0) scale = 1.0;
-  for (int i = 0; i < 9 * m; ++i) At[i] /= scale;
+  for (int i = 0; i < 9 * m; ++i) At[i * ES] /= scale;
   double hco[8];
-  pl_colpiv_qr(At, 9, m, hco);
-  for (int c = first; c < 9; ++c) pl_householder_q_col(At, 9, m, hco, c, out + (c - first) * 9);
+  pl_colpiv_qr<ES>(At, 9, m, hco);
+  for (int c = first; c < 9; ++c) pl_householder_q_col<ES>(At, 9, m, hco, c, out + (c - first) * 9);
 }
 
 // makeJacobi(x, y, z)
@@ -322,7 +331,10 @@ DSM_DEV void pl_jacobi_svd_square(const double* A_rowmajor, double* U, double* V
 // Eigenvalues of an upper-Hessenberg n x n matrix T (column-major, ld = LD, destroyed):
 // EigenSolver(C, false) for companion matrices (the Hessenberg reduction is the identity on
 // them: every sub-sub-diagonal entry is already zero).  Returns false on non-convergence.
-template <int LD, int ES>
+// VALUES_ONLY: the reflectors are not applied to the columns right of the active block (c > iu).  Those columns
+// are deflated for good (iu only decreases) and their entries above the diagonal blocks never feed back into a
+// diagonal block, so the eigenvalues keep their bits (LAPACK's job = 'E'); Eigen itself updates them.
+template <int LD, int ES, bool VALUES_ONLY = false>
 DSM_DEV bool pl_hessenberg_eigenvalues_impl(double* T, int n, double* re, double* im) {
 #define TT(r, c) T[((c) * LD + (r)) * ES]
   for (int i = 0; i < n; ++i) {
@@ -391,7 +403,7 @@ DSM_DEV bool pl_hessenberg_eigenvalues_impl(double* T, int n, double* re, double
             gc = -t * gs;
           }
           if (!(gc == 1.0 && -gs == 0.0)) {
-            for (int c = iu - 1; c < n; ++c) {  // rows iu-1, iu with (gc, -gs)
+            for (int c = iu - 1; c < (VALUES_ONLY ? iu + 1 : n); ++c) {  // rows iu-1, iu with (gc, -gs)
               const double xi = TT(iu - 1, c), yi = TT(iu, c);
               TT(iu - 1, c) = gc * xi + (-gs) * yi;
               TT(iu, c) = gs * xi + gc * yi;
@@ -466,7 +478,7 @@ DSM_DEV bool pl_hessenberg_eigenvalues_impl(double* T, int n, double* re, double
               TT(k, k - 1) = -TT(k, k - 1);
             else if (!first)
               TT(k, k - 1) = beta;
-            pl_apply_householder_left<ES>(T, LD, k, k, 3, n - k, &v[1], tau);
+            pl_apply_householder_left<ES>(T, LD, k, k, 3, (VALUES_ONLY ? iu + 1 : n) - k, &v[1], tau);
             const int nr = ((iu < k + 3) ? iu : k + 3) + 1;
             pl_apply_householder_right<ES>(T, LD, 0, k, nr, 3, &v[1], tau);
           }
@@ -477,7 +489,7 @@ DSM_DEV bool pl_hessenberg_eigenvalues_impl(double* T, int n, double* re, double
           pl_make_householder(v, 2, &tau, &beta);
           if (beta != 0.0) {
             TT(iu - 1, iu - 2) = beta;
-            pl_apply_householder_left<ES>(T, LD, iu - 1, iu - 1, 2, n - iu + 1, &v[1], tau);
+            pl_apply_householder_left<ES>(T, LD, iu - 1, iu - 1, 2, (VALUES_ONLY ? iu + 1 : n) - iu + 1, &v[1], tau);
             pl_apply_householder_right<ES>(T, LD, 0, iu - 1, iu + 1, 2, &v[1], tau);
           }
         }
@@ -591,7 +603,7 @@ DSM_DEV int pl_poly_roots(const double* coeffs_all, int ncoef, double* real, dou
   if (ES == 1) {
     if (!pl_hessenberg_eigenvalues<LD>(C, n, re, im)) return -1;
   } else {
-    if (!pl_hessenberg_eigenvalues_impl<LD, ES>(C, n, re, im)) return -1;
+    if (!pl_hessenberg_eigenvalues_impl<LD, ES, true>(C, n, re, im)) return -1;
   }
   const int effective_degree = n < degree ? n + 1 : n;
   for (int i = 0; i < effective_degree; ++i) {
