@@ -729,8 +729,10 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
         vp.batch = batch[f];
         for (uint32_t round = 0; round < 100000; ++round) {
           HIPCHK(ctx, hipMemsetAsync(ctx->d_active.p, 0, 4, st));
+          HIPCHK(ctx, hipMemsetAsync(static_cast<char*>(ctx->d_active.p) + 72, 0, 4, st));  // k_sample's work counter
           launch_vp_sample(vp, f, nb_light, st);
           launch_vp_solve_score(vp, f, st);
+          HIPCHK(ctx, hipMemsetAsync(static_cast<char*>(ctx->d_active.p) + 64, 0, 4, st));  // k_replay's work counter
           launch_vp_replay(vp, f, nb_heavy, st);
           HIPCHK(ctx, hipGetLastError());
           uint32_t active = 0;
@@ -740,6 +742,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
           if (active == 0) break;
         }
       }
+      HIPCHK(ctx, hipMemsetAsync(static_cast<char*>(ctx->d_active.p) + 68, 0, 4, st));  // k_verify_final's work counter
       launch_vp_final(vp, nb_heavy, st);
       HIPCHK(ctx, hipGetLastError());
     }

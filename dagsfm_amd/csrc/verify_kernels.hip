@@ -1045,9 +1045,21 @@ __global__ __launch_bounds__(64, 2) void k_verify_final(const VerifyParams p) {
   double* pts3d_a = ws.pts3d_a;
   double* pts3d_b = ws.pts3d_b;
 
-  for (uint32_t pl = blockIdx.x; pl < p.n_chunk; pl += gridDim.x) {
-    const uint32_t pi = p.pair0 + pl;
+  __shared__ uint32_t s_next;
+  uint32_t pl_static = blockIdx.x;
+  for (;;) {
     wv_sync();
+    uint32_t pl;
+    if (p.active_count != nullptr) {  // pipeline: pairs handed out dynamically (work counter [17])
+      if (threadIdx.x == 0) s_next = atomicAdd(p.active_count + 17, 1u);
+      wv_sync();
+      pl = s_next;
+    } else {
+      pl = pl_static;
+      pl_static += gridDim.x;
+    }
+    if (pl >= p.n_chunk) break;
+    const uint32_t pi = p.pair0 + pl;
     const uint32_t im1 = p.pairs[2 * pi], im2 = p.pairs[2 * pi + 1];
     const uint64_t moff = p.match_off[pi];
     const int n = (int)(p.match_off[pi + 1] - moff);
@@ -1473,10 +1485,15 @@ __global__ __launch_bounds__(64) void k_sample(const VerifyParams p) {
   uint32_t* sidx = reinterpret_cast<uint32_t*>(smem_raw + SAMPLER_PREFIX);
   typedef Fam<FAM> F;
   const int lane = threadIdx.x;
-  for (uint32_t pl = blockIdx.x; pl < p.n_chunk; pl += gridDim.x) {
+  __shared__ uint32_t s_next;
+  for (;;) {
+    wv_sync();
+    if (lane == 0) s_next = atomicAdd(p.active_count + 18, 1u);  // dynamic hand-out, as in k_replay
+    wv_sync();
+    const uint32_t pl = s_next;
+    if (pl >= p.n_chunk) break;
     const uint32_t pi = p.pair0 + pl;
     FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
-    wv_sync();
     if (!fs->active) continue;
     const uint64_t moff = p.match_off[pi];
     const int n = (int)(p.match_off[pi + 1] - moff);
@@ -1795,10 +1812,17 @@ __global__ __launch_bounds__(64, 4) void k_replay(const VerifyParams p) {
   typedef Fam<FAM> F;
   const int lane = threadIdx.x;
   const WgScratch ws = wg_scratch(p);
-  for (uint32_t pl = blockIdx.x; pl < p.n_chunk; pl += gridDim.x) {
+  // pairs are handed out dynamically (their cost varies with the number of local optimisations, and from the
+  // second round on most of them are inactive): p.active_count[16] is the next pair of this launch
+  __shared__ uint32_t s_next;
+  for (;;) {
+    wv_sync();
+    if (lane == 0) s_next = atomicAdd(p.active_count + 16, 1u);
+    wv_sync();
+    const uint32_t pl = s_next;
+    if (pl >= p.n_chunk) break;
     const uint32_t pi = p.pair0 + pl;
     FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
-    wv_sync();
     if (!fs->active) continue;
     const uint64_t moff = p.match_off[pi];
     const int n = (int)(p.match_off[pi + 1] - moff);
