@@ -191,7 +191,12 @@ uint32_t dsm_pair_seed(uint32_t image_id1, uint32_t image_id2, uint32_t user_see
  * 550-608, 749-839) = TwoViewGeometry::Estimate per pair (two_view_geometry.cc:113-126).
  *   seeds         n_pairs explicit PRNG seeds, or NULL to use dsm_pair_seed(idx1, idx2, user_seed)
  *   stage_filter  non-zero: pairs with fewer than min_num_inliers inliers get a default
- *                 TwoViewGeometry(), as Match() writes them (matching.cc:824-831) */
+ *                 TwoViewGeometry(), as Match() writes them (matching.cc:824-831)
+ * options->multiple_models != 0 runs TwoViewGeometry::EstimateMultiple (two_view_geometry.cc:128-167)
+ * instead, as the verifier does (matching.cc:596-599): repeated Estimate passes over the matches that are
+ * not inliers yet, on ONE generator stream per pair; several geometries -> config MULTIPLE with the inlier
+ * matches of all of them (other fields as in a fresh TwoViewGeometry()); num_trials / num_models are summed
+ * over the passes. */
 int dsm_verify_pairs(dsm_ctx* ctx, const dsm_two_view_options* options, const uint32_t* seeds,
                      uint32_t user_seed, int32_t stage_filter);
 /* Results of the last dsm_verify_pairs: n_pairs fixed-size records ... */
