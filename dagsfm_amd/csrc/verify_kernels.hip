@@ -1486,11 +1486,18 @@ __global__ __launch_bounds__(64) void k_sample(const VerifyParams p) {
   typedef Fam<FAM> F;
   const int lane = threadIdx.x;
   __shared__ uint32_t s_next;
+  uint32_t pl_static = blockIdx.x;
   for (;;) {
     wv_sync();
-    if (lane == 0) s_next = atomicAdd(p.active_count + 18, 1u);  // dynamic hand-out, as in k_replay
-    wv_sync();
-    const uint32_t pl = s_next;
+    uint32_t pl;
+    if (FAM == FAM_H) {  // thousands of draws per pair: dynamic hand-out as in k_replay; E / F rounds are too short for it
+      if (lane == 0) s_next = atomicAdd(p.active_count + 18, 1u);
+      wv_sync();
+      pl = s_next;
+    } else {
+      pl = pl_static;
+      pl_static += gridDim.x;
+    }
     if (pl >= p.n_chunk) break;
     const uint32_t pi = p.pair0 + pl;
     FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
