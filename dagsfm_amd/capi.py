@@ -77,6 +77,7 @@ def lib():
         L.dsm_pair_seed.argtypes = [ctypes.c_uint32] * 3
         L.dsm_pair_seed.restype = ctypes.c_uint32
         L.dsm_verify_pairs.argtypes = [vp, ctypes.POINTER(TwoViewOptions), u32p, ctypes.c_uint32, ctypes.c_int32]
+        L.dsm_guided_match_pairs.argtypes = [vp, ctypes.POINTER(MatchOptions), ctypes.POINTER(TwoViewOptions), ctypes.c_int32]
         L.dsm_get_two_view_geometries.argtypes = [vp, vp]
         L.dsm_get_inlier_matches.argtypes = [vp, vp, vp, ctypes.c_uint64]
         L.dsm_get_verify_kernel_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
@@ -255,6 +256,12 @@ class Context:
         n = ctypes.c_uint32(0)
         self._chk(lib().dsm_get_match_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+    def guided_match_pairs(self, match_options=None, options=None, stage_filter=False):
+        """dsm_guided_match_pairs: replaces the inlier matches of the verified pairs by guided matches."""
+        mo = match_options if match_options is not None else default_match_options()
+        to = options if options is not None else default_two_view_options()
+        self._chk(lib().dsm_guided_match_pairs(self._h, ctypes.byref(mo), ctypes.byref(to), 1 if stage_filter else 0))
 
     def match_resolve_time(self):
         ms = ctypes.c_double(0)

@@ -108,6 +108,8 @@ struct dsm_ctx {
   DevBuf d_nt_table, d_nt_off, d_nt_off_t, d_pair_state, d_pts_px, d_pts_norm, d_reports, d_masks;
   DevBuf d_fam_state, d_samples, d_draws_end, d_nmodels, d_vcounts, d_models, d_sidx, d_active;
   DevBuf d_ework;
+  DevBuf d_g_nfeat, d_g_dpairs, d_g_doff, d_g_pdir, d_g_params, d_g_m, d_g_counts, d_g_offsets, d_g_total, d_g_matches,
+      d_g_plan, d_g_inl, d_g_inl_off;  // guided matching
   DevBuf d_mm_matches[2], d_mm_off[2], d_mm_counts, d_mm_state, d_mm_first, d_mm_acc, d_mm_keep, d_mm_total;  // EstimateMultiple
   uint32_t verify_rounds[3] = {0, 0, 0};
   uint64_t total_inliers = 0;
@@ -218,7 +220,9 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
                     &ctx->d_vscratch, &ctx->d_inl_total, &ctx->d_nt_table, &ctx->d_nt_off, &ctx->d_nt_off_t,
                     &ctx->d_pair_state, &ctx->d_pts_px, &ctx->d_pts_norm, &ctx->d_reports, &ctx->d_masks,
                     &ctx->d_fam_state, &ctx->d_samples, &ctx->d_draws_end, &ctx->d_nmodels, &ctx->d_vcounts, &ctx->d_models,
-                    &ctx->d_sidx, &ctx->d_active, &ctx->d_ework, &ctx->d_mm_matches[0], &ctx->d_mm_matches[1], &ctx->d_mm_off[0],
+                    &ctx->d_sidx, &ctx->d_active, &ctx->d_ework, &ctx->d_g_nfeat, &ctx->d_g_dpairs, &ctx->d_g_doff, &ctx->d_g_pdir,
+                    &ctx->d_g_params, &ctx->d_g_m, &ctx->d_g_counts, &ctx->d_g_offsets, &ctx->d_g_total, &ctx->d_g_matches, &ctx->d_g_plan,
+                    &ctx->d_g_inl, &ctx->d_g_inl_off, &ctx->d_mm_matches[0], &ctx->d_mm_matches[1], &ctx->d_mm_off[0],
                     &ctx->d_mm_off[1], &ctx->d_mm_counts, &ctx->d_mm_state, &ctx->d_mm_first, &ctx->d_mm_acc, &ctx->d_mm_keep,
                     &ctx->d_mm_total};
   if (ctx->vev0) (void)hipEventDestroy(ctx->vev0);
@@ -927,6 +931,177 @@ int dsm_verify_pairs(dsm_ctx* ctx, const dsm_two_view_options* options, const ui
       ctx->d_seeds.as<uint32_t>(), stage_filter);
   if (rc != DSM_OK) return rc;
   ctx->verified = true;
+  return DSM_OK;
+}
+
+// Guided matching over the pairs of the last dsm_verify_pairs: GuidedSiftCPUFeatureMatcher::Run
+// (/root/reference/src/feature/matching.cc:441-470) + MatchGuidedSiftFeaturesCPU (src/feature/sift.cc:824-875).
+int dsm_guided_match_pairs(dsm_ctx* ctx, const dsm_match_options* mo, const dsm_two_view_options* to, int32_t stage_filter) {
+  if (!ctx || !mo || !to) return DSM_ERR_INVALID_ARGUMENT;
+  if (!ctx->verified) return fail(ctx, DSM_ERR_NOT_READY, "dsm_verify_pairs has not run");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const uint32_t np = ctx->n_pairs;
+  std::vector<dsm_two_view_geometry> tv(np);
+  std::vector<uint64_t> old_off((size_t)np + 1, 0);
+  if (np) {
+    HIPCHK(ctx, hipMemcpy(tv.data(), ctx->d_tvg.p, (size_t)np * sizeof(dsm_two_view_geometry), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(old_off.data(), ctx->d_inl_off.p, ((size_t)np + 1) * 8, hipMemcpyDeviceToHost));
+  }
+  // which pairs are re-matched, and against which matrix (sift.cc:838-863)
+  std::vector<uint32_t> G;
+  std::vector<int> mode(np, 0);
+  for (uint32_t i = 0; i < np; ++i) {
+    if ((uint64_t)tv[i].num_inliers < to->min_num_inliers) continue;  // matching.cc:449-453
+    const int c = tv[i].config;
+    if (c == DSM_CONFIG_CALIBRATED || c == DSM_CONFIG_UNCALIBRATED) mode[i] = 1;
+    else if (c == DSM_CONFIG_PLANAR || c == DSM_CONFIG_PANORAMIC || c == DSM_CONFIG_PLANAR_OR_PANORAMIC) mode[i] = 2;
+    if (mode[i]) G.push_back(i);
+  }
+  const bool cross = mo->cross_check != 0;
+  const uint32_t ng = (uint32_t)G.size();
+  std::vector<uint32_t> gcount(ng, 0);
+  std::vector<uint64_t> goff((size_t)ng + 1, 0);
+  HIPCHK(ctx, ctx->d_g_nfeat.reserve(std::max<uint32_t>(ctx->n_images, 1) * 4));
+  if (ctx->n_images) HIPCHK(ctx, hipMemcpyAsync(ctx->d_g_nfeat.p, ctx->nfeat.data(), ctx->n_images * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(ctx, ctx->d_g_counts.reserve(std::max<uint32_t>(ng, 1) * 4));
+  HIPCHK(ctx, ctx->d_g_offsets.reserve(((size_t)ng + 1) * 8));
+  HIPCHK(ctx, ctx->d_g_total.reserve(8));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_g_total.p, 0, 8, st));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_g_offsets.p, 0, 8, st));
+  uint64_t g_total = 0;
+  const uint64_t budget_rows = (6ull << 30) / 4;
+  std::vector<uint2> dpairs;
+  std::vector<uint64_t> doff;
+  std::vector<uint4> pdir;
+  std::vector<float> gpar;
+  const float max_residual = (float)(to->max_error * to->max_error);  // sift.cc:833
+  uint32_t c0 = 0;
+  while (c0 < ng) {
+    uint64_t rows_acc = 0;
+    uint32_t c1 = c0;
+    while (c1 < ng) {
+      const uint32_t a = ctx->pairs[2 * G[c1]], b = ctx->pairs[2 * G[c1] + 1];
+      const uint64_t r = (uint64_t)ctx->rows[a] + (cross ? ctx->rows[b] : 0);
+      if (c1 > c0 && rows_acc + r > budget_rows) break;
+      rows_acc += r;
+      ++c1;
+    }
+    const uint32_t nc = c1 - c0, nd = cross ? 2 * nc : nc;
+    dpairs.resize(nd);
+    doff.resize(nd);
+    pdir.resize(nc);
+    gpar.assign((size_t)nd * 12, 0.0f);
+    uint64_t off = 0;
+    uint32_t max_rb = 0;
+    for (uint32_t k = 0; k < nc; ++k) {
+      const uint32_t pi = G[c0 + k];
+      const uint32_t a = ctx->pairs[2 * pi], b = ctx->pairs[2 * pi + 1];
+      const double* Md = mode[pi] == 1 ? tv[pi].F : tv[pi].H;
+      const uint32_t dab = cross ? 2 * k : k, dba = 2 * k + 1;
+      for (int dir = 0; dir < (cross ? 2 : 1); ++dir) {
+        const uint32_t dd = dir ? dba : dab;
+        dpairs[dd] = dir ? make_uint2(b, a) : make_uint2(a, b);
+        doff[dd] = off;
+        off += ctx->rows[dir ? b : a];
+        max_rb = std::max(max_rb, ctx->rows[dir ? b : a] / 256);
+        float* g = gpar.data() + (size_t)dd * 12;
+        for (int e = 0; e < 9; ++e) g[e] = (float)Md[e];  // F.cast<float>() / H.cast<float>(), sift.cc:835-836
+        g[9] = (float)mode[pi];
+        g[10] = dir ? 1.0f : 0.0f;
+      }
+      pdir[k] = make_uint4(dab, cross ? dba : 0, ctx->nfeat[a], ctx->nfeat[b]);
+    }
+    HIPCHK(ctx, ctx->d_g_dpairs.reserve(std::max<uint32_t>(nd, 1) * sizeof(uint2)));
+    HIPCHK(ctx, ctx->d_g_doff.reserve(std::max<uint32_t>(nd, 1) * 8));
+    HIPCHK(ctx, ctx->d_g_pdir.reserve(std::max<uint32_t>(nc, 1) * sizeof(uint4)));
+    HIPCHK(ctx, ctx->d_g_params.reserve(std::max<size_t>(gpar.size(), 1) * 4));
+    HIPCHK(ctx, ctx->d_g_m.reserve(std::max<uint64_t>(off, 1) * 4));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_g_dpairs.p, dpairs.data(), nd * sizeof(uint2), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_g_doff.p, doff.data(), nd * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_g_pdir.p, pdir.data(), nc * sizeof(uint4), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_g_params.p, gpar.data(), gpar.size() * 4, hipMemcpyHostToDevice, st));
+    KgParams kg;
+    kg.desc = ctx->d_desc.as<int8_t>();
+    kg.rterm = ctx->d_rterm.as<int32_t>();
+    kg.kp = ctx->d_kp.as<double>();
+    kg.dpairs = ctx->d_g_dpairs.as<uint2>();
+    kg.img_row0 = ctx->d_img_row0.as<uint32_t>();
+    kg.img_rows = ctx->d_img_rows.as<uint32_t>();
+    kg.img_nfeat = ctx->d_g_nfeat.as<uint32_t>();
+    kg.d_out_off = ctx->d_g_doff.as<uint64_t>();
+    kg.lut = ctx->d_lut.as<float>();
+    kg.max_ratio = (float)mo->max_ratio;
+    kg.max_distance = (float)mo->max_distance;
+    kg.max_residual = max_residual;
+    kg.gparams = ctx->d_g_params.as<float>();
+    kg.out = ctx->d_g_m.as<int32_t>();
+    launch_kg(kg, nd, max_rb, st);
+    HIPCHK(ctx, hipGetLastError());
+    K2Params k2;
+    k2.pair_dir = ctx->d_g_pdir.as<uint4>();
+    k2.d_out_off = ctx->d_g_doff.as<uint64_t>();
+    k2.m = ctx->d_g_m.as<int32_t>();
+    k2.cross_check = cross ? 1 : 0;
+    k2.counts = ctx->d_g_counts.as<uint32_t>() + c0;
+    k2.offsets = ctx->d_g_offsets.as<uint64_t>() + c0;
+    k2.matches = nullptr;
+    launch_k2(k2, nc, false, st);
+    launch_scan(ctx->d_g_counts.as<uint32_t>() + c0, ctx->d_g_offsets.as<uint64_t>() + c0, nc, ctx->d_g_total.as<uint64_t>(), st);
+    HIPCHK(ctx, hipGetLastError());
+    uint64_t total = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&total, ctx->d_g_total.p, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, ctx->d_g_matches.grow(std::max<uint64_t>(total, 1) * 8, g_total * 8, st));
+    k2.matches = ctx->d_g_matches.as<uint32_t>();
+    launch_k2(k2, nc, true, st);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    g_total = total;
+    c0 = c1;
+  }
+  if (ng) {
+    HIPCHK(ctx, hipMemcpy(gcount.data(), ctx->d_g_counts.p, (size_t)ng * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(goff.data(), ctx->d_g_offsets.p, ((size_t)ng + 1) * 8, hipMemcpyDeviceToHost));
+  }
+  // final inlier lists: guided pairs take the new matches, the others keep theirs; then Match()'s post-filter
+  struct Plan { uint64_t src_off; uint64_t dst_off; uint32_t count; uint32_t from_guided; };
+  std::vector<Plan> plan(np);
+  std::vector<uint64_t> new_off((size_t)np + 1, 0);
+  std::vector<int> gslot(np, -1);
+  for (uint32_t k = 0; k < ng; ++k) gslot[G[k]] = (int)k;
+  uint64_t acc = 0;
+  for (uint32_t i = 0; i < np; ++i) {
+    uint32_t cnt = gslot[i] >= 0 ? gcount[gslot[i]] : tv[i].num_inliers;
+    const uint64_t src = gslot[i] >= 0 ? goff[gslot[i]] : old_off[i];
+    if (stage_filter && (uint64_t)cnt < to->min_num_inliers) {  // matching.cc:824-831
+      const dsm_two_view_geometry keep = tv[i];
+      memset(&tv[i], 0, sizeof(tv[i]));
+      tv[i].num_matches = keep.num_matches;
+      for (int e = 0; e < 4; ++e) {
+        tv[i].num_trials[e] = keep.num_trials[e];
+        tv[i].num_models[e] = keep.num_models[e];
+      }
+      cnt = 0;
+    }
+    tv[i].num_inliers = cnt;
+    plan[i] = Plan{src, acc, cnt, gslot[i] >= 0 ? 1u : 0u};
+    new_off[i] = acc;
+    acc += cnt;
+  }
+  new_off[np] = acc;
+  HIPCHK(ctx, ctx->d_g_plan.reserve(std::max<size_t>(np, 1) * sizeof(Plan)));
+  HIPCHK(ctx, ctx->d_g_inl.reserve(std::max<uint64_t>(acc, 1) * 8));
+  if (np) HIPCHK(ctx, hipMemcpyAsync(ctx->d_g_plan.p, plan.data(), (size_t)np * sizeof(Plan), hipMemcpyHostToDevice, st));
+  launch_guided_assemble(ctx->d_g_plan.p, ctx->d_inl_compact.as<uint32_t>(), ctx->d_g_matches.as<uint32_t>(),
+                         ctx->d_g_inl.as<uint32_t>(), np, st);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  std::swap(ctx->d_inl_compact, ctx->d_g_inl);
+  HIPCHK(ctx, ctx->d_inl_off.reserve(((size_t)np + 1) * 8));
+  HIPCHK(ctx, hipMemcpy(ctx->d_inl_off.p, new_off.data(), ((size_t)np + 1) * 8, hipMemcpyHostToDevice));
+  if (np) HIPCHK(ctx, hipMemcpy(ctx->d_tvg.p, tv.data(), (size_t)np * sizeof(dsm_two_view_geometry), hipMemcpyHostToDevice));
+  ctx->total_inliers = acc;
   return DSM_OK;
 }
 

@@ -32,6 +32,26 @@ struct K2Params {
   uint32_t* matches;          // [total][2]
 };
 
+// Guided matching (MatchGuidedSiftFeaturesCPU, sift.cc:824-875): one directed pass with the geometric filter.
+struct KgParams {
+  const int8_t* desc;         // as K1Params
+  const int32_t* rterm;
+  const double* kp;           // keypoints (x, y) of all images, exact float values widened to double
+  const uint2* dpairs;        // directed pairs {row image, column image}
+  const uint32_t* img_row0;
+  const uint32_t* img_rows;   // padded row counts
+  const uint32_t* img_nfeat;  // true feature counts
+  const uint64_t* d_out_off;
+  const float* lut;
+  float max_ratio, max_distance, max_residual;
+  const float* gparams;       // per directed pair: 9 x float matrix (row-major), mode (1 F / 2 H), swap (row image is image 2), pad
+  int32_t* out;               // per row: matched column or -1
+};
+void launch_kg(const KgParams& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st);
+// plan: per pair {uint64 src_off, uint64 dst_off, uint32 count, uint32 from_guided}: copies the pair's final inlier matches
+void launch_guided_assemble(const void* plan, const uint32_t* old_inl, const uint32_t* guided, uint32_t* dst, uint32_t n_pairs,
+                            hipStream_t st);
+
 // Result of one LO-RANSAC family for one pair (RANSAC<>::Report, /root/reference/src/optim/ransac.h:80-97).
 struct RansacReport {
   bool success;

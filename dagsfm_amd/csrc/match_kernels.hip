@@ -357,6 +357,115 @@ __global__ __launch_bounds__(256) void k1_resolve_index(const K1Params p) {
   }
 }
 
+// ------------------------------------------------------------------------------------ KG (guided matching)
+// The guided filters of MatchGuidedSiftFeaturesCPU (sift.cc:838-866) in float, same operation order as
+// oracle_guided_filter (oracle/sift_match.c): true = the keypoint pair violates the geometry.
+__device__ __forceinline__ bool guided_filter(int mode, const float* M, float x1, float y1, float x2, float y2,
+                                              float max_residual) {
+  if (mode == 1) {
+    const float Fx1_0 = (M[0] * x1 + M[1] * y1) + M[2];
+    const float Fx1_1 = (M[3] * x1 + M[4] * y1) + M[5];
+    const float Fx1_2 = (M[6] * x1 + M[7] * y1) + M[8];
+    const float Ftx2_0 = (M[0] * x2 + M[3] * y2) + M[6];
+    const float Ftx2_1 = (M[1] * x2 + M[4] * y2) + M[7];
+    const float x2tFx1 = (x2 * Fx1_0 + y2 * Fx1_1) + Fx1_2;
+    return x2tFx1 * x2tFx1 / (((Fx1_0 * Fx1_0 + Fx1_1 * Fx1_1) + Ftx2_0 * Ftx2_0) + Ftx2_1 * Ftx2_1) > max_residual;
+  }
+  const float Hp_0 = (M[0] * x1 + M[1] * y1) + M[2];
+  const float Hp_1 = (M[3] * x1 + M[4] * y1) + M[5];
+  const float Hp_2 = (M[6] * x1 + M[7] * y1) + M[8];
+  const float d0 = Hp_0 / Hp_2 - x2, d1 = Hp_1 / Hp_2 - y2;
+  return d0 * d0 + d1 * d1 > max_residual;
+}
+
+// One directed pass with the filter: thread = one row of image a, all columns of image b in ascending order
+// (64-column tiles of descriptors + bias + keypoints through LDS, every lane reads the same column: broadcast),
+// dists(i1, i2) = filtered ? 0 : dot -- the scan of FindBestMatchesOneWay itself (strict >, lowest index wins).
+// An optional mode, per element ~70 instructions (32 v_dot4 + the float filter): no MFMA here, the filter
+// dominates.
+__global__ __launch_bounds__(256) void kg_best_rows(const KgParams p) {
+  const uint32_t d = blockIdx.x;
+  const uint32_t rb = blockIdx.y;
+  const uint2 ab = p.dpairs[d];
+  const uint32_t a_rows = p.img_rows[ab.x];
+  if (rb * 256u >= a_rows) return;
+  const uint32_t b_cols = p.img_rows[ab.y];
+  const uint32_t a_feat = p.img_nfeat[ab.x], b_feat = p.img_nfeat[ab.y];
+  const uint32_t a_row0 = p.img_row0[ab.x], b_row0 = p.img_row0[ab.y];
+  const int tid = threadIdx.x;
+  const uint32_t row = rb * 256u + tid;
+
+  __shared__ __attribute__((aligned(16))) int8_t sB[64 * 128];
+  __shared__ int sR[64];
+  __shared__ float sX[64], sY[64];
+
+  const float* gp = p.gparams + (size_t)d * 12;
+  float M[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) M[k] = gp[k];
+  const int mode = (int)gp[9];
+  const bool swap = gp[10] != 0.0f;  // rows are image 2 of the pair
+
+  v4i a[8];
+  const int8_t* arow = p.desc + (size_t)(a_row0 + row) * 128;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const v4i*>(arow + c * 16);
+  const int rterm_i = p.rterm[a_row0 + row];
+  float xr = 0.0f, yr = 0.0f;
+  if (row < a_feat) {
+    xr = (float)p.kp[(size_t)(a_row0 + row) * 2];
+    yr = (float)p.kp[(size_t)(a_row0 + row) * 2 + 1];
+  }
+  int best = 0, second = 0, best_j = -1;
+  for (uint32_t j0 = 0; j0 < b_cols; j0 += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = tid + 256 * u;
+      *reinterpret_cast<v4i*>(&sB[q * 16]) = *reinterpret_cast<const v4i*>(p.desc + (size_t)(b_row0 + j0) * 128 + (size_t)q * 16);
+    }
+    if (tid < 64) {
+      const uint32_t col = j0 + tid;
+      sR[tid] = p.rterm[b_row0 + col];
+      const bool real = col < b_feat;
+      sX[tid] = real ? (float)p.kp[(size_t)(b_row0 + col) * 2] : 0.0f;
+      sY[tid] = real ? (float)p.kp[(size_t)(b_row0 + col) * 2 + 1] : 0.0f;
+    }
+    __syncthreads();
+    for (int j = 0; j < 64; ++j) {
+      int acc = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const v4i b = *reinterpret_cast<const v4i*>(&sB[j * 128 + c * 16]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_sdot4(a[c][e], b[e], acc, false);
+      }
+      int dist = acc + rterm_i + sR[j] + (1 << 21);
+      const float xc = sX[j], yc = sY[j];
+      const bool filtered = swap ? guided_filter(mode, M, xc, yc, xr, yr, p.max_residual)
+                                 : guided_filter(mode, M, xr, yr, xc, yc, p.max_residual);
+      if (filtered) dist = 0;
+      if (dist > best) {  // sift.cc:126-132
+        second = best;
+        best = dist;
+        best_j = (int)(j0 + j);
+      } else if (dist > second) {
+        second = dist;
+      }
+    }
+  }
+  int res = -1;
+  if (best_j >= 0) {
+    const float bn = p.lut[min(best, 262144)];
+    if (!(bn > p.max_distance)) {
+      const float sn = p.lut[min(second, 262144)];
+      const float rhs = __fmul_rn(p.max_ratio, sn);
+      if (!(bn >= rhs)) res = best_j;
+    }
+  }
+  if (row < a_rows) p.out[p.d_out_off[d] + row] = res;
+}
+
 // ------------------------------------------------------------------------------------ K2
 // One workgroup per undirected pair: mutual check + ordered compaction (sift.cc:171-197).
 template <bool WRITE>
@@ -453,6 +562,31 @@ void launch_k1(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, 
 void launch_k1_resolve(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st) {
   if (n_directed == 0 || max_row_blocks == 0) return;
   hipLaunchKernelGGL(k1_resolve_index, dim3(n_directed), dim3(256), 0, st, p);
+}
+
+void launch_kg(const KgParams& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st) {
+  if (n_directed == 0 || max_row_blocks == 0) return;
+  hipLaunchKernelGGL(kg_best_rows, dim3(n_directed, max_row_blocks), dim3(256), 0, st, p);
+}
+
+struct GuidedPlan {
+  uint64_t src_off, dst_off;
+  uint32_t count, from_guided;
+};
+__global__ __launch_bounds__(64) void k_guided_assemble(const GuidedPlan* plan, const uint32_t* old_inl, const uint32_t* guided,
+                                                        uint32_t* dst, uint32_t n_pairs) {
+  for (uint32_t pi = blockIdx.x; pi < n_pairs; pi += gridDim.x) {
+    const GuidedPlan pl = plan[pi];
+    const uint2* s = reinterpret_cast<const uint2*>(pl.from_guided ? guided : old_inl) + pl.src_off;
+    uint2* d = reinterpret_cast<uint2*>(dst) + pl.dst_off;
+    for (uint32_t i = threadIdx.x; i < pl.count; i += 64) d[i] = s[i];
+  }
+}
+void launch_guided_assemble(const void* plan, const uint32_t* old_inl, const uint32_t* guided, uint32_t* dst, uint32_t n_pairs,
+                            hipStream_t st) {
+  if (!n_pairs) return;
+  hipLaunchKernelGGL(k_guided_assemble, dim3(n_pairs < 8192 ? n_pairs : 8192), dim3(64), 0, st,
+                     static_cast<const GuidedPlan*>(plan), old_inl, guided, dst, n_pairs);
 }
 
 void launch_k2(const K2Params& p, uint32_t n_pairs, bool write, hipStream_t st) {

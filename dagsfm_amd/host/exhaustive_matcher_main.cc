@@ -4,23 +4,27 @@
 #include <iostream>
 #include <string>
 
-extern "C" int dsm_host_exhaustive_matcher(const char* database_path, int block_size, int use_prior_defaults,
-                                           unsigned random_seed, double max_ratio, double max_distance, int cross_check,
-                                           int min_num_inliers);
+extern "C" int dsm_host_exhaustive_matcher_ex(const char* database_path, int block_size, int use_prior_defaults,
+                                              unsigned random_seed, double max_ratio, double max_distance, int cross_check,
+                                              int min_num_inliers, int guided_matching, int multiple_models);
 
 int main(int argc, char** argv) {
   std::string db;
   int block = 50;
   unsigned seed = 0;
+  int guided = 0, multiple = 0;
   for (int i = 1; i + 1 < argc; i += 2) {
     const std::string k = argv[i];
     if (k == "--database_path") db = argv[i + 1];
     else if (k == "--ExhaustiveMatching.block_size") block = std::atoi(argv[i + 1]);
     else if (k == "--random_seed") seed = static_cast<unsigned>(std::strtoul(argv[i + 1], nullptr, 10));
+    else if (k == "--SiftMatching.guided_matching") guided = std::atoi(argv[i + 1]);
+    else if (k == "--SiftMatching.multiple_models") multiple = std::atoi(argv[i + 1]);
   }
   if (db.empty()) {
-    std::cerr << "usage: dsm_exhaustive_matcher --database_path database.db [--ExhaustiveMatching.block_size 50] [--random_seed 0]\n";
+    std::cerr << "usage: dsm_exhaustive_matcher --database_path database.db [--ExhaustiveMatching.block_size 50] [--random_seed 0]"
+                 " [--SiftMatching.guided_matching 0] [--SiftMatching.multiple_models 0]\n";
     return 64;
   }
-  return dsm_host_exhaustive_matcher(db.c_str(), block, 1, seed, 0, 0, 1, 15);
+  return dsm_host_exhaustive_matcher_ex(db.c_str(), block, 1, seed, 0, 0, 1, 15, guided, multiple);
 }

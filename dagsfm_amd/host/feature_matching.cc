@@ -48,10 +48,6 @@ SiftFeatureMatcher::~SiftFeatureMatcher() {
 }
 
 bool SiftFeatureMatcher::Setup() {
-  if (options_.guided_matching) {  // matching.cc:429-548 is not part of this build
-    last_error_ = "guided_matching is not supported by the MI355X matcher";
-    return false;
-  }
   int device = 0;
   if (options_.gpu_index != "-1" && !options_.gpu_index.empty()) device = std::atoi(options_.gpu_index.c_str());
   const int rc = dsm_ctx_create(device, &ctx_);
@@ -170,7 +166,9 @@ void SiftFeatureMatcher::Match(const std::vector<std::pair<image_t, image_t>>& i
     } else {
       rc = dsm_match_pairs(ctx_, np, idx.data(), &mo);
     }
-    if (rc == DSM_OK) rc = dsm_verify_pairs(ctx_, &to, seeds.data(), 0, 1);
+    // guided_matching (matching.cc:647-667): verifier -> guided matcher -> output; the post-filter then sees the guided counts
+    if (rc == DSM_OK) rc = dsm_verify_pairs(ctx_, &to, seeds.data(), 0, options_.guided_matching ? 0 : 1);
+    if (rc == DSM_OK && options_.guided_matching) rc = dsm_guided_match_pairs(ctx_, &mo, &to, 1);
     if (rc != DSM_OK) throw std::runtime_error(std::string("device matching failed: ") + dsm_last_error(ctx_));
     std::vector<uint64_t> moff(np + 1), ioff(np + 1);
     rc = dsm_get_matches(ctx_, moff.data(), nullptr, 0);
@@ -259,8 +257,9 @@ using namespace dagsfm_amd;
 extern "C" {
 
 // Runs ExhaustiveFeatureMatcher over database_path.  Returns 0 on success.
-int dsm_host_exhaustive_matcher(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,
-                                double max_ratio, double max_distance, int cross_check, int min_num_inliers) {
+int dsm_host_exhaustive_matcher_ex(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,
+                                   double max_ratio, double max_distance, int cross_check, int min_num_inliers,
+                                   int guided_matching, int multiple_models) {
   try {
     ExhaustiveMatchingOptions eo;
     eo.block_size = block_size;
@@ -271,6 +270,8 @@ int dsm_host_exhaustive_matcher(const char* database_path, int block_size, int u
       mo.cross_check = cross_check != 0;
       mo.min_num_inliers = min_num_inliers;
     }
+    mo.guided_matching = guided_matching != 0;
+    mo.multiple_models = multiple_models != 0;
     mo.random_seed = random_seed;
     ExhaustiveFeatureMatcher m(eo, mo, database_path);
     return m.Run() ? 0 : 2;
@@ -278,6 +279,12 @@ int dsm_host_exhaustive_matcher(const char* database_path, int block_size, int u
     std::cerr << "ERROR: " << e.what() << std::endl;
     return 1;
   }
+}
+
+int dsm_host_exhaustive_matcher(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,
+                                double max_ratio, double max_distance, int cross_check, int min_num_inliers) {
+  return dsm_host_exhaustive_matcher_ex(database_path, block_size, use_prior_defaults, random_seed, max_ratio, max_distance,
+                                        cross_check, min_num_inliers, 0, 0);
 }
 
 // Database round trip used by the CPU-only tests (mirrors base/database_test.cc:283-360).

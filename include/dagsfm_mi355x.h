@@ -200,6 +200,17 @@ uint32_t dsm_pair_seed(uint32_t image_id1, uint32_t image_id2, uint32_t user_see
 int dsm_verify_pairs(dsm_ctx* ctx, const dsm_two_view_options* options, const uint32_t* seeds,
                      uint32_t user_seed, int32_t stage_filter);
 /* Results of the last dsm_verify_pairs: n_pairs fixed-size records ... */
+/* Guided matching (SiftMatchingOptions::guided_matching, src/feature/sift.h:162) over the pairs of the last
+ * dsm_verify_pairs: every pair with at least min_num_inliers inlier matches (matching.cc:449-453) and an F-type
+ * (CALIBRATED, UNCALIBRATED) or H-type (PLANAR, PANORAMIC, PLANAR_OR_PANORAMIC) configuration is matched again
+ * with the descriptor distance of keypoint pairs that violate F / H (float Sampson / transfer error above
+ * max_error^2) set to zero, and the result REPLACES its inlier matches -- MatchGuidedSiftFeaturesCPU
+ * (src/feature/sift.cc:824-875), GuidedSiftCPUFeatureMatcher::Run (matching.cc:441-470); config, E, F, H and
+ * the pose stay.  Call dsm_verify_pairs with stage_filter = 0 first; stage_filter here is Match()'s
+ * post-filter (matching.cc:824-831) on the final inlier counts. */
+int dsm_guided_match_pairs(dsm_ctx* ctx, const dsm_match_options* match_options,
+                           const dsm_two_view_options* options, int32_t stage_filter);
+
 int dsm_get_two_view_geometries(dsm_ctx* ctx, dsm_two_view_geometry* out);
 /* ... and the inlier_matches of all pairs in list order (same conventions as dsm_get_matches). */
 int dsm_get_inlier_matches(dsm_ctx* ctx, uint64_t* offsets, uint32_t* inlier_matches,

@@ -112,6 +112,26 @@ class Oracle:
                                                    ctypes.c_uint32(seed), ctypes.byref(out), inl.ctypes.data_as(u32p))
         return out, inl[:out.num_inliers].copy()
 
+    def match_guided_sift_features_cpu(self, kp1, kp2, desc1, desc2, tvg, max_error=4.0, max_ratio=0.8, max_distance=0.7,
+                                       cross_check=True):
+        """MatchGuidedSiftFeaturesCPU (sift.cc:824-875): None when the configuration has no guided filter."""
+        k1 = np.ascontiguousarray(kp1, dtype=np.float32).reshape(-1, 2)
+        k2 = np.ascontiguousarray(kp2, dtype=np.float32).reshape(-1, 2)
+        d1 = np.ascontiguousarray(desc1, dtype=np.uint8).reshape(-1, 128)
+        d2 = np.ascontiguousarray(desc2, dtype=np.uint8).reshape(-1, 128)
+        mode = 1 if tvg.config in (2, 3) else (2 if tvg.config in (4, 5, 6) else 0)
+        M = np.array(tvg.F if mode == 1 else tvg.H, dtype=np.float64)
+        out = np.zeros((max(len(d1), 1), 2), dtype=np.uint32)
+        f32p = ctypes.POINTER(ctypes.c_float)
+        self.lib.oracle_match_guided_sift_features_cpu.restype = ctypes.c_int
+        n = self.lib.oracle_match_guided_sift_features_cpu(
+            ctypes.c_double(max_ratio), ctypes.c_double(max_distance), ctypes.c_int(1 if cross_check else 0),
+            ctypes.c_double(max_error), k1.ctypes.data_as(f32p), k2.ctypes.data_as(f32p),
+            d1.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.c_int(len(d1)),
+            d2.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.c_int(len(d2)), ctypes.c_int(mode),
+            M.ctypes.data_as(f64p), out.ctypes.data_as(u32p))
+        return None if n < 0 else out[:n].copy()
+
     def compute_num_trials(self, num_inliers, num_samples, confidence, min_samples):
         return int(self.lib.oracle_compute_num_trials(num_inliers, num_samples, confidence, min_samples))
 

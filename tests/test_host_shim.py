@@ -211,3 +211,36 @@ def test_exhaustive_matcher_blocks_and_swapped_pairs(tmp_path, oracle):
             else:
                 assert np.allclose(q, rq, rtol=1e-6, atol=1e-12) and np.allclose(tv, rt, rtol=1e-6, atol=1e-12)
     assert n_swapped_geo >= 1
+
+
+@pytest.mark.gpu
+def test_exhaustive_matcher_guided_matching(tmp_path, oracle):
+    """--SiftMatching.guided_matching 1: the two_view_geometries rows hold the guided matches (matching.cc:647-667)."""
+    from dagsfm_amd import capi, synthetic
+    n_img = 4
+    scene = synthetic.Scene(n_img, 512, seed=35, n_pool=1200)
+    ims = [scene.image(i) for i in range(n_img)]
+    path = str(tmp_path / "database.db")
+    dbutil.create(path, [(im[0], im[1]) for im in ims], prior=True)
+    subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5", "--SiftMatching.guided_matching", "1"])
+    matches, tvgs = dbutil.read_results(path)
+    cam = capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, True)
+    opts = capi.default_two_view_options()
+    n_guided = 0
+    for i in range(n_img):
+        for j in range(i + 1, n_img):
+            pid = dbutil.pair_id(i + 1, j + 1)
+            ref_m = oracle.match_sift_features_cpu(ims[i][0], ims[j][0])
+            ref, ref_inl = oracle.estimate_two_view_geometry(cam, ims[i][1].astype(np.float64), cam, ims[j][1].astype(np.float64),
+                                                             ref_m, opts, capi.pair_seed(i + 1, j + 1, 5))
+            exp = ref_inl
+            if ref.num_inliers >= 15:
+                g = oracle.match_guided_sift_features_cpu(ims[i][1], ims[j][1], ims[i][0], ims[j][0], ref)
+                if g is not None:
+                    exp, n_guided = g, n_guided + 1
+            t = tvgs[pid]
+            if len(exp) >= 15:
+                assert t["config"] == ref.config and (t["inliers"] == exp).all()
+            else:
+                assert t["config"] == 0 and len(t["inliers"]) == 0
+    assert n_guided >= 3

@@ -55,3 +55,30 @@ def test_second_best_duplicate_rejected(oracle):
     m = oracle.match_sift_features_cpu(d1, d2, cross_check=False)
     assert 0 not in m[:, 0].tolist()
     assert sorted(m[:, 0].tolist()) == [1, 2, 3]
+
+
+def test_guided_matching_filters_by_geometry(oracle):
+    """MatchGuidedSiftFeaturesCPU (sift.cc:824-875): with the true fundamental matrix of a synthetic pair, keypoint
+    pairs off the epipolar geometry get distance 0 -- geometric outliers whose descriptors match disappear and
+    no surviving match violates the filter; a configuration without filter leaves the matches alone."""
+    from dagsfm_amd import capi, synthetic
+    sc = synthetic.Scene(2, 512, seed=5, n_pool=700)
+    a, b = sc.image(0), sc.image(1)
+    plain = oracle.match_sift_features_cpu(a[0], b[0])
+    cam = capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, 0)
+    opts = capi.default_two_view_options()
+    tv, inl = oracle.estimate_two_view_geometry(cam, a[1].astype(np.float64), cam, b[1].astype(np.float64), plain, opts, 3)
+    assert tv.config == 3
+    g = oracle.match_guided_sift_features_cpu(a[1], b[1], a[0], b[0], tv)
+    assert g is not None and len(g) >= len(inl) - 5 and len(g) <= len(plain)
+    F = np.array(tv.F, dtype=np.float32).reshape(3, 3)
+    x1 = np.c_[a[1][g[:, 0]], np.ones(len(g), dtype=np.float32)]
+    x2 = np.c_[b[1][g[:, 1]], np.ones(len(g), dtype=np.float32)]
+    Fx1, Ftx2 = x1 @ F.T, x2 @ F
+    samp = (np.sum(x2 * Fx1, axis=1) ** 2) / (Fx1[:, 0] ** 2 + Fx1[:, 1] ** 2 + Ftx2[:, 0] ** 2 + Ftx2[:, 1] ** 2)
+    assert (samp <= 16.0 * 1.001).all()
+    # every guided match is mutual-best under the mask, so plain matches that satisfy the geometry survive
+    plain_set = {tuple(r) for r in plain.tolist()}
+    assert len(plain_set & {tuple(r) for r in g.tolist()}) >= len(inl) - 5
+    tv.config = 1  # DEGENERATE: no filter (sift.cc:861-863)
+    assert oracle.match_guided_sift_features_cpu(a[1], b[1], a[0], b[0], tv) is None

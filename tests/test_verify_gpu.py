@@ -297,3 +297,50 @@ def test_baseline_config1_size(dsm, oracle):
                     tvg_equal(tvgs[k], ref, (i, j))
                     assert (ik == ref_inl).all()
     assert n_geo > 100
+
+
+@pytest.mark.parametrize("prior,planar,cross", [(1, False, True), (0, False, True), (1, True, True), (1, False, False)])
+def test_guided_matching_stage(dsm, oracle, prior, planar, cross):
+    """SiftMatchingOptions::guided_matching: verify, then MatchGuidedSiftFeaturesCPU (sift.cc:824-875) for every pair
+    with enough inliers and an F- or H-type configuration replaces the inlier matches (matching.cc:441-470), then
+    Match()'s post-filter.  Compared with the oracle pair by pair."""
+    n_img = 5
+    scene = synthetic.Scene(n_img, 640, seed=51 + prior, n_pool=1500, planar=planar)
+    ims = [scene.image(i) for i in range(n_img)]
+    cams = [capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, prior) for _ in range(n_img)]
+    dsm.set_images([im[0] for im in ims], [im[1] for im in ims], cams)
+    pairs = synthetic.exhaustive_pairs(n_img)
+    mo = capi.default_match_options()
+    mo.cross_check = 1 if cross else 0
+    dsm.match_pairs(pairs, mo)
+    opts = capi.default_two_view_options()
+    dsm.verify_pairs(opts, user_seed=8, stage_filter=False)
+    pre = dsm.two_view_geometries()
+    pre_cfg = [t.config for t in pre]
+    dsm.guided_match_pairs(mo, opts, stage_filter=True)
+    offs, m = dsm.matches()
+    tvgs = dsm.two_view_geometries()
+    ioffs, im = dsm.inlier_matches()
+    n_guided = 0
+    for k, (i, j) in enumerate(pairs):
+        mk = m[int(offs[k]):int(offs[k + 1])]
+        ref, ref_inl = oracle.estimate_two_view_geometry(cams[i], ims[i][1].astype(np.float64), cams[j],
+                                                         ims[j][1].astype(np.float64), mk, opts, capi.pair_seed(int(i), int(j), 8))
+        assert ref.config == pre_cfg[k]
+        exp = ref_inl
+        if ref.num_inliers >= opts.min_num_inliers:
+            g = oracle.match_guided_sift_features_cpu(ims[i][1], ims[j][1], ims[i][0], ims[j][0], ref, max_error=opts.max_error,
+                                                      cross_check=cross)
+            if g is not None:
+                exp = g
+                n_guided += 1
+        got = tvgs[k]
+        got_inl = im[int(ioffs[k]):int(ioffs[k + 1])]
+        if len(exp) < opts.min_num_inliers:
+            assert got.config == 0 and got.num_inliers == 0 and len(got_inl) == 0
+        else:
+            assert got.config == ref.config and got.num_inliers == len(exp)
+            assert (got_inl == exp).all(), (i, j)
+            for name in ("E", "F", "H"):
+                assert (np.array(getattr(got, name)) == np.array(getattr(ref, name))).all()
+    assert n_guided >= 5
