@@ -2,6 +2,8 @@
 // SQLITE3_CALL / glog FATAL, /root/reference/src/util/sqlite3_utils.h).
 #include "database.h"
 
+#include <unordered_map>
+
 #include <sqlite3.h>
 
 #include <cmath>
@@ -9,6 +11,12 @@
 #include <stdexcept>
 
 namespace dagsfm_amd {
+// A prepared statement that is compiled once per connection and re-used (the reference prepares all of its
+// statements in Database::PrepareSQLStatements, database.cc:1121-1131): the per-pair Exists / Write calls of
+// SiftFeatureMatcher::Match otherwise spend more time in sqlite3_prepare_v2 than in the insert itself.
+struct StmtCache {
+  std::unordered_map<const char*, sqlite3_stmt*> map;  // keyed by the address of the SQL literal
+};
 namespace {
 
 void Check(int rc, sqlite3* db, const char* what) {
@@ -19,8 +27,29 @@ void Check(int rc, sqlite3* db, const char* what) {
 struct Stmt {
   sqlite3* db;
   sqlite3_stmt* s = nullptr;
-  Stmt(sqlite3* d, const char* sql) : db(d) { Check(sqlite3_prepare_v2(db, sql, -1, &s, nullptr), db, sql); }
-  ~Stmt() { sqlite3_finalize(s); }
+  bool cached = false;
+  Stmt(sqlite3* d, const char* sql, StmtCache* cache = nullptr) : db(d) {
+    if (cache) {
+      auto it = cache->map.find(sql);
+      if (it != cache->map.end()) {
+        s = it->second;
+      } else {
+        Check(sqlite3_prepare_v2(db, sql, -1, &s, nullptr), db, sql);
+        cache->map.emplace(sql, s);
+      }
+      cached = true;
+    } else {
+      Check(sqlite3_prepare_v2(db, sql, -1, &s, nullptr), db, sql);
+    }
+  }
+  ~Stmt() {
+    if (cached) {
+      sqlite3_reset(s);
+      sqlite3_clear_bindings(s);
+    } else {
+      sqlite3_finalize(s);
+    }
+  }
   int Step() {
     const int rc = sqlite3_step(s);
     Check(rc, db, "step");
@@ -108,10 +137,16 @@ void Database::Open(const std::string& path) {
   Exec("PRAGMA temp_store=MEMORY;");
   Exec("PRAGMA foreign_keys=ON;");
   CreateTables();
+  stmts_ = new StmtCache();
   Exec("PRAGMA user_version = 3600;");  // COLMAP_VERSION_NUMBER, /root/reference/CMakeLists.txt:37
 }
 
 void Database::Close() {
+  if (stmts_) {
+    for (auto& kv : stmts_->map) sqlite3_finalize(kv.second);
+    delete stmts_;
+    stmts_ = nullptr;
+  }
   if (database_) sqlite3_close_v2(database_);
   database_ = nullptr;
 }
@@ -144,21 +179,29 @@ void Database::PairIdToImagePair(image_pair_t pair_id, image_t* image_id1, image
 }
 bool Database::SwapImagePair(image_t image_id1, image_t image_id2) { return image_id1 > image_id2; }
 
-static bool ExistsRow(sqlite3* db, const char* sql, image_pair_t pair_id) {
-  Stmt st(db, sql);
+static bool ExistsRow(sqlite3* db, StmtCache* cache, const char* sql, image_pair_t pair_id) {
+  Stmt st(db, sql, cache);
   sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(pair_id));
   return st.Step() == SQLITE_ROW;
 }
 bool Database::ExistsMatches(image_t a, image_t b) const {
-  return ExistsRow(database_, "SELECT 1 FROM matches WHERE pair_id = ?;", ImagePairToPairId(a, b));
+  static const char* const kSql = "SELECT 1 FROM matches WHERE pair_id = ?;";
+  return ExistsRow(database_, stmts_, kSql, ImagePairToPairId(a, b));
 }
 bool Database::ExistsInlierMatches(image_t a, image_t b) const {
-  return ExistsRow(database_, "SELECT 1 FROM two_view_geometries WHERE pair_id = ?;", ImagePairToPairId(a, b));
+  static const char* const kSql = "SELECT 1 FROM two_view_geometries WHERE pair_id = ?;";
+  return ExistsRow(database_, stmts_, kSql, ImagePairToPairId(a, b));
 }
 static size_t CountRows(sqlite3* db, const char* sql) {
   Stmt st(db, sql);
   st.Step();
   return static_cast<size_t>(sqlite3_column_int64(st.s, 0));
+}
+std::vector<image_pair_t> Database::ReadPairIds(bool inliers) const {
+  Stmt st(database_, inliers ? "SELECT pair_id FROM two_view_geometries;" : "SELECT pair_id FROM matches;");
+  std::vector<image_pair_t> ids;
+  while (st.Step() == SQLITE_ROW) ids.push_back(static_cast<image_pair_t>(sqlite3_column_int64(st.s, 0)));
+  return ids;
 }
 size_t Database::NumMatchedImagePairs() const { return CountRows(database_, "SELECT COUNT(*) FROM matches WHERE rows > 0;"); }
 size_t Database::NumVerifiedImagePairs() const {
@@ -198,7 +241,8 @@ std::vector<Image> Database::ReadAllImages() const {
 
 FeatureKeypoints Database::ReadKeypoints(image_t image_id) const {
   // FeatureKeypointsFromBlob, database.cc:60-88: 2, 4 or 6 float columns
-  Stmt st(database_, "SELECT rows, cols, data FROM keypoints WHERE image_id = ?;");
+  static const char* const kSql = "SELECT rows, cols, data FROM keypoints WHERE image_id = ?;";
+  Stmt st(database_, kSql, stmts_);
   sqlite3_bind_int64(st.s, 1, image_id);
   FeatureKeypoints kps;
   if (st.Step() != SQLITE_ROW) return kps;
@@ -229,7 +273,8 @@ FeatureKeypoints Database::ReadKeypoints(image_t image_id) const {
 }
 
 FeatureDescriptors Database::ReadDescriptors(image_t image_id) const {
-  Stmt st(database_, "SELECT rows, cols, data FROM descriptors WHERE image_id = ?;");
+  static const char* const kSql = "SELECT rows, cols, data FROM descriptors WHERE image_id = ?;";
+  Stmt st(database_, kSql, stmts_);
   sqlite3_bind_int64(st.s, 1, image_id);
   FeatureDescriptors d;
   if (st.Step() != SQLITE_ROW) return d;
@@ -253,7 +298,8 @@ static FeatureMatches MatchesFromBlob(sqlite3_stmt* s, int col_rows, int col_dat
 }
 
 FeatureMatches Database::ReadMatches(image_t a, image_t b) const {
-  Stmt st(database_, "SELECT rows, cols, data FROM matches WHERE pair_id = ?;");
+  static const char* const kSql = "SELECT rows, cols, data FROM matches WHERE pair_id = ?;";
+  Stmt st(database_, kSql, stmts_);
   sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(a, b)));
   FeatureMatches m;
   if (st.Step() != SQLITE_ROW) return m;
@@ -265,7 +311,8 @@ FeatureMatches Database::ReadMatches(image_t a, image_t b) const {
 
 TwoViewGeometry Database::ReadTwoViewGeometry(image_t a, image_t b) const {
   // database.cc:493-533: qvec comes back from the F column, tvec from the E column
-  Stmt st(database_, "SELECT rows, cols, data, config, F, E, H FROM two_view_geometries WHERE pair_id = ?;");
+  static const char* const kSql = "SELECT rows, cols, data, config, F, E, H FROM two_view_geometries WHERE pair_id = ?;";
+  Stmt st(database_, kSql, stmts_);
   sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(a, b)));
   TwoViewGeometry t;
   if (st.Step() != SQLITE_ROW) return t;
@@ -338,7 +385,8 @@ static std::vector<uint32_t> MatchesToBlob(const FeatureMatches& m, bool swap) {
 
 void Database::WriteMatches(image_t a, image_t b, const FeatureMatches& matches) const {
   const std::vector<uint32_t> blob = MatchesToBlob(matches, SwapImagePair(a, b));
-  Stmt st(database_, "INSERT INTO matches(pair_id, rows, cols, data) VALUES(?, ?, ?, ?);");
+  static const char* const kSql = "INSERT INTO matches(pair_id, rows, cols, data) VALUES(?, ?, ?, ?);";
+  Stmt st(database_, kSql, stmts_);
   sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(a, b)));
   sqlite3_bind_int64(st.s, 2, static_cast<sqlite3_int64>(matches.size()));
   sqlite3_bind_int64(st.s, 3, 2);
@@ -355,7 +403,8 @@ void Database::WriteTwoViewGeometry(image_t a, image_t b, const TwoViewGeometry&
     t = &swapped;
   }
   const std::vector<uint32_t> blob = MatchesToBlob(t->inlier_matches, false);
-  Stmt st(database_, "INSERT INTO two_view_geometries(pair_id, rows, cols, data, config, F, E, H) VALUES(?, ?, ?, ?, ?, ?, ?, ?);");
+  static const char* const kSql = "INSERT INTO two_view_geometries(pair_id, rows, cols, data, config, F, E, H) VALUES(?, ?, ?, ?, ?, ?, ?, ?);";
+  Stmt st(database_, kSql, stmts_);
   sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(ImagePairToPairId(a, b)));
   sqlite3_bind_int64(st.s, 2, static_cast<sqlite3_int64>(t->inlier_matches.size()));
   sqlite3_bind_int64(st.s, 3, 2);
@@ -374,16 +423,18 @@ void Database::WriteTwoViewGeometry(image_t a, image_t b, const TwoViewGeometry&
   st.Step();
 }
 
-static void DeleteRow(sqlite3* db, const char* sql, image_pair_t pair_id) {
-  Stmt st(db, sql);
+static void DeleteRow(sqlite3* db, StmtCache* cache, const char* sql, image_pair_t pair_id) {
+  Stmt st(db, sql, cache);
   sqlite3_bind_int64(st.s, 1, static_cast<sqlite3_int64>(pair_id));
   st.Step();
 }
 void Database::DeleteMatches(image_t a, image_t b) const {
-  DeleteRow(database_, "DELETE FROM matches WHERE pair_id = ?;", ImagePairToPairId(a, b));
+  static const char* const kSql = "DELETE FROM matches WHERE pair_id = ?;";
+  DeleteRow(database_, stmts_, kSql, ImagePairToPairId(a, b));
 }
 void Database::DeleteInlierMatches(image_t a, image_t b) const {
-  DeleteRow(database_, "DELETE FROM two_view_geometries WHERE pair_id = ?;", ImagePairToPairId(a, b));
+  static const char* const kSql = "DELETE FROM two_view_geometries WHERE pair_id = ?;";
+  DeleteRow(database_, stmts_, kSql, ImagePairToPairId(a, b));
 }
 
 void Database::BeginTransaction() const { Exec("BEGIN TRANSACTION;"); }

@@ -15,6 +15,10 @@ struct sqlite3;
 struct sqlite3_stmt;
 
 namespace dagsfm_amd {
+struct StmtCache;
+}
+
+namespace dagsfm_amd {
 
 class Database {
  public:
@@ -33,6 +37,8 @@ class Database {
 
   bool ExistsMatches(image_t image_id1, image_t image_id2) const;
   bool ExistsInlierMatches(image_t image_id1, image_t image_id2) const;
+  // all pair ids of `matches` (inliers == false) or `two_view_geometries` (true), one query
+  std::vector<image_pair_t> ReadPairIds(bool inliers) const;
   size_t NumMatchedImagePairs() const;
   size_t NumVerifiedImagePairs() const;
 
@@ -59,6 +65,7 @@ class Database {
   void CreateTables() const;
   void Exec(const char* sql) const;
   sqlite3* database_ = nullptr;
+  StmtCache* stmts_ = nullptr;  // prepared statements of the per-pair calls, compiled once
 };
 
 // RAII transaction like DatabaseTransaction, database.h:306-318

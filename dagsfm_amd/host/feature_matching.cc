@@ -1,6 +1,8 @@
 // feature_matching.cc -- see feature_matching.h.
 #include "feature_matching.h"
 
+#include <chrono>
+
 #include <algorithm>
 #include <cstring>
 #include <iostream>
@@ -17,6 +19,10 @@ FeatureMatcherCache::FeatureMatcherCache(size_t cache_size, const Database* data
 void FeatureMatcherCache::Setup() {  // matching.cc:221-243
   for (const Camera& c : database_->ReadAllCameras()) cameras_cache_.emplace(c.camera_id, c);
   for (const Image& im : database_->ReadAllImages()) images_cache_.emplace(im.image_id, im);
+  have_matches_.clear();
+  have_inliers_.clear();
+  for (image_pair_t id : database_->ReadPairIds(false)) have_matches_.insert(id);
+  for (image_pair_t id : database_->ReadPairIds(true)) have_inliers_.insert(id);
 }
 
 std::vector<image_t> FeatureMatcherCache::GetImageIds() const {
@@ -285,6 +291,38 @@ int dsm_host_exhaustive_matcher(const char* database_path, int block_size, int u
                                 double max_ratio, double max_distance, int cross_check, int min_num_inliers) {
   return dsm_host_exhaustive_matcher_ex(database_path, block_size, use_prior_defaults, random_seed, max_ratio, max_distance,
                                         cross_check, min_num_inliers, 0, 0);
+}
+
+// Write-back micro-benchmark: n_pairs synthetic matches + two_view_geometries rows in ONE
+// transaction through the same Database calls SiftFeatureMatcher::Match uses.  Returns pairs per second.
+double dsm_host_db_bulk_write_bench(const char* database_path, uint32_t n_pairs, uint32_t n_matches, uint32_t n_inliers) {
+  try {
+    Database db(database_path);
+    FeatureMatches m(n_matches), inl(n_inliers);
+    for (uint32_t i = 0; i < n_matches; ++i) m[i] = FeatureMatch(i, n_matches - 1 - i);
+    for (uint32_t i = 0; i < n_inliers; ++i) inl[i] = m[i];
+    TwoViewGeometry t;
+    t.config = 2;
+    t.qvec[0] = 1;
+    t.inlier_matches = inl;
+    FeatureMatcherCache cache(100, &db);
+    cache.Setup();
+    const auto t0 = std::chrono::steady_clock::now();
+    {
+      DatabaseTransaction tr(&db);
+      for (uint32_t k = 0; k < n_pairs; ++k) {
+        const image_t a = 1 + k / 1000, b = 2000 + k % 1000;
+        if (cache.ExistsMatches(a, b) || cache.ExistsInlierMatches(a, b)) continue;
+        cache.WriteMatches(a, b, m);
+        cache.WriteTwoViewGeometry(a, b, t);
+      }
+    }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return n_pairs / dt;
+  } catch (const std::exception& e) {
+    std::cerr << "ERROR: " << e.what() << std::endl;
+    return -1.0;
+  }
 }
 
 // Database round trip used by the CPU-only tests (mirrors base/database_test.cc:283-360).

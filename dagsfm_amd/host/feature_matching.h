@@ -15,6 +15,7 @@
 
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -41,12 +42,26 @@ class FeatureMatcherCache {
   const FeatureKeypoints& GetKeypoints(image_t image_id);
   const FeatureDescriptors& GetDescriptors(image_t image_id);
   FeatureMatches GetMatches(image_t a, image_t b) const { return database_->ReadMatches(a, b); }
-  bool ExistsMatches(image_t a, image_t b) const { return database_->ExistsMatches(a, b); }
-  bool ExistsInlierMatches(image_t a, image_t b) const { return database_->ExistsInlierMatches(a, b); }
-  void WriteMatches(image_t a, image_t b, const FeatureMatches& m) const { database_->WriteMatches(a, b, m); }
-  void WriteTwoViewGeometry(image_t a, image_t b, const TwoViewGeometry& t) const { database_->WriteTwoViewGeometry(a, b, t); }
-  void DeleteMatches(image_t a, image_t b) const { database_->DeleteMatches(a, b); }
-  void DeleteInlierMatches(image_t a, image_t b) const { database_->DeleteInlierMatches(a, b); }
+  // The pair ids of both result tables are read in bulk by Setup() and kept current here, so the two existence
+  // checks Match() makes for every pair (matching.cc:782-812) cost a hash lookup instead of a SELECT each.
+  bool ExistsMatches(image_t a, image_t b) const { return have_matches_.count(Database::ImagePairToPairId(a, b)) != 0; }
+  bool ExistsInlierMatches(image_t a, image_t b) const { return have_inliers_.count(Database::ImagePairToPairId(a, b)) != 0; }
+  void WriteMatches(image_t a, image_t b, const FeatureMatches& m) {
+    database_->WriteMatches(a, b, m);
+    have_matches_.insert(Database::ImagePairToPairId(a, b));
+  }
+  void WriteTwoViewGeometry(image_t a, image_t b, const TwoViewGeometry& t) {
+    database_->WriteTwoViewGeometry(a, b, t);
+    have_inliers_.insert(Database::ImagePairToPairId(a, b));
+  }
+  void DeleteMatches(image_t a, image_t b) {
+    database_->DeleteMatches(a, b);
+    have_matches_.erase(Database::ImagePairToPairId(a, b));
+  }
+  void DeleteInlierMatches(image_t a, image_t b) {
+    database_->DeleteInlierMatches(a, b);
+    have_inliers_.erase(Database::ImagePairToPairId(a, b));
+  }
 
  private:
   const size_t cache_size_;
@@ -55,6 +70,7 @@ class FeatureMatcherCache {
   std::unordered_map<image_t, Image> images_cache_;
   std::unordered_map<image_t, FeatureKeypoints> keypoints_cache_;
   std::unordered_map<image_t, FeatureDescriptors> descriptors_cache_;
+  std::unordered_set<image_pair_t> have_matches_, have_inliers_;
 };
 
 class SiftFeatureMatcher {

@@ -213,6 +213,22 @@ def test_exhaustive_matcher_blocks_and_swapped_pairs(tmp_path, oracle):
     assert n_swapped_geo >= 1
 
 
+def test_database_bulk_write_rate(tmp_path):
+    """Write-back of SiftFeatureMatcher::Match (Exists x2 + WriteMatches + WriteTwoViewGeometry per pair, one
+    transaction, statements prepared once): must stay far above the GPU's ~1e5 pairs/s only in the sense of not being
+    orders of magnitude below it -- the rate is printed and recorded in DESIGN.md."""
+    L = host()
+    L.dsm_host_db_bulk_write_bench.restype = ctypes.c_double
+    L.dsm_host_db_bulk_write_bench.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    rate = L.dsm_host_db_bulk_write_bench(str(tmp_path / "bulk.db").encode(), 20000, 256, 160)
+    print("db write-back: %.0f pairs/s" % rate)
+    assert rate > 20000
+    con = sqlite3.connect(str(tmp_path / "bulk.db"))
+    assert con.execute("SELECT COUNT(*) FROM matches").fetchone()[0] == 20000
+    assert con.execute("SELECT COUNT(*) FROM two_view_geometries WHERE rows = 160").fetchone()[0] == 20000
+    con.close()
+
+
 @pytest.mark.gpu
 def test_exhaustive_matcher_guided_matching(tmp_path, oracle):
     """--SiftMatching.guided_matching 1: the two_view_geometries rows hold the guided matches (matching.cc:647-667)."""
