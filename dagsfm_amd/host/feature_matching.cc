@@ -2,6 +2,7 @@
 #include "feature_matching.h"
 
 #include <chrono>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstring>
@@ -34,11 +35,13 @@ std::vector<image_t> FeatureMatcherCache::GetImageIds() const {
 }
 
 const FeatureKeypoints& FeatureMatcherCache::GetKeypoints(image_t image_id) {
+  std::lock_guard<std::mutex> lock(mutex_);
   auto it = keypoints_cache_.find(image_id);
   if (it == keypoints_cache_.end()) it = keypoints_cache_.emplace(image_id, database_->ReadKeypoints(image_id)).first;
   return it->second;
 }
 const FeatureDescriptors& FeatureMatcherCache::GetDescriptors(image_t image_id) {
+  std::lock_guard<std::mutex> lock(mutex_);
   auto it = descriptors_cache_.find(image_id);
   if (it == descriptors_cache_.end()) it = descriptors_cache_.emplace(image_id, database_->ReadDescriptors(image_id)).first;
   return it->second;
@@ -50,7 +53,17 @@ SiftFeatureMatcher::SiftFeatureMatcher(const SiftMatchingOptions& options, Datab
 }
 
 SiftFeatureMatcher::~SiftFeatureMatcher() {
+  if (writer_.joinable()) writer_.join();  // errors of a never-flushed write-back are lost with the object
   if (ctx_) dsm_ctx_destroy(ctx_);
+}
+
+void SiftFeatureMatcher::Flush() {
+  if (writer_.joinable()) writer_.join();
+  if (writer_error_) {
+    std::exception_ptr e = writer_error_;
+    writer_error_ = nullptr;
+    std::rethrow_exception(e);
+  }
 }
 
 bool SiftFeatureMatcher::Setup() {
@@ -116,23 +129,26 @@ void SiftFeatureMatcher::Match(const std::vector<std::pair<image_t, image_t>>& i
   std::unordered_set<image_pair_t> seen;
   std::vector<std::pair<image_t, image_t>> to_match, to_verify_only;
   std::vector<FeatureMatches> existing;
-  for (const auto& pr : image_pairs) {
-    if (pr.first == pr.second) continue;
-    const image_pair_t pair_id = Database::ImagePairToPairId(pr.first, pr.second);
-    if (!seen.insert(pair_id).second) continue;
-    const bool exists_matches = cache_->ExistsMatches(pr.first, pr.second);
-    const bool exists_inlier_matches = cache_->ExistsInlierMatches(pr.first, pr.second);
-    if (exists_matches && exists_inlier_matches) continue;
-    if (exists_inlier_matches) cache_->DeleteInlierMatches(pr.first, pr.second);
-    if (exists_matches) {
-      existing.push_back(cache_->GetMatches(pr.first, pr.second));
-      cache_->DeleteMatches(pr.first, pr.second);
-      to_verify_only.push_back(pr);
-    } else {
-      to_match.push_back(pr);
+  {
+    const auto lock = cache_->Lock();  // one acquisition for the whole list (the write-back thread may be running)
+    for (const auto& pr : image_pairs) {
+      if (pr.first == pr.second) continue;
+      const image_pair_t pair_id = Database::ImagePairToPairId(pr.first, pr.second);
+      if (!seen.insert(pair_id).second) continue;
+      const bool exists_matches = cache_->ExistsMatchesUnlocked(pr.first, pr.second);
+      const bool exists_inlier_matches = cache_->ExistsInlierMatchesUnlocked(pr.first, pr.second);
+      if (exists_matches && exists_inlier_matches) continue;
+      if (exists_inlier_matches) cache_->DeleteInlierMatchesUnlocked(pr.first, pr.second);
+      if (exists_matches) {
+        existing.push_back(cache_->GetMatchesUnlocked(pr.first, pr.second));
+        cache_->DeleteMatchesUnlocked(pr.first, pr.second);
+        to_verify_only.push_back(pr);
+      } else {
+        to_match.push_back(pr);
+      }
+      if (options_.async_write_back) cache_->MarkPendingUnlocked(pr.first, pr.second);
     }
   }
-
   dsm_match_options mo;
   dsm_default_match_options(&mo);
   mo.max_ratio = options_.max_ratio;
@@ -186,26 +202,45 @@ void SiftFeatureMatcher::Match(const std::vector<std::pair<image_t, image_t>>& i
     std::vector<uint32_t> im(2 * std::max<uint64_t>(ioff[np], 1));
     if (rc == DSM_OK) rc = dsm_get_inlier_matches(ctx_, nullptr, im.data(), ioff[np]);
     if (rc != DSM_OK) throw std::runtime_error(std::string("result fetch failed: ") + dsm_last_error(ctx_));
-    // ---- write results (matching.cc:819-836)
-    for (uint32_t i = 0; i < np; ++i) {
-      FeatureMatches matches(moff[i + 1] - moff[i]);
-      for (size_t k = 0; k < matches.size(); ++k) matches[k] = FeatureMatch(m[2 * (moff[i] + k)], m[2 * (moff[i] + k) + 1]);
-      if (matches.size() < static_cast<size_t>(options_.min_num_inliers)) matches.clear();
-      TwoViewGeometry t;  // stays TwoViewGeometry() when the device post-filter zeroed the pair
-      if (tv[i].num_inliers >= static_cast<uint32_t>(options_.min_num_inliers) && tv[i].num_inliers > 0) {
-        t.config = tv[i].config;
-        std::memcpy(t.E, tv[i].E, sizeof(t.E));
-        std::memcpy(t.F, tv[i].F, sizeof(t.F));
-        std::memcpy(t.H, tv[i].H, sizeof(t.H));
-        std::memcpy(t.qvec, tv[i].qvec, sizeof(t.qvec));
-        std::memcpy(t.tvec, tv[i].tvec, sizeof(t.tvec));
-        t.tri_angle = tv[i].tri_angle;
-        t.inlier_matches.resize(ioff[i + 1] - ioff[i]);
-        for (size_t k = 0; k < t.inlier_matches.size(); ++k)
-          t.inlier_matches[k] = FeatureMatch(im[2 * (ioff[i] + k)], im[2 * (ioff[i] + k) + 1]);
+    // ---- write results (matching.cc:819-836), on this thread or handed to the write-back thread
+    const int min_num_inliers = options_.min_num_inliers;
+    FeatureMatcherCache* cache = cache_;
+    auto write = [cache, min_num_inliers, np, prs, moff = std::move(moff), m = std::move(m), tv = std::move(tv),
+                  ioff = std::move(ioff), im = std::move(im)]() {
+      for (uint32_t i = 0; i < np; ++i) {
+        FeatureMatches matches(moff[i + 1] - moff[i]);
+        for (size_t k = 0; k < matches.size(); ++k) matches[k] = FeatureMatch(m[2 * (moff[i] + k)], m[2 * (moff[i] + k) + 1]);
+        if (matches.size() < static_cast<size_t>(min_num_inliers)) matches.clear();
+        TwoViewGeometry t;  // stays TwoViewGeometry() when the device post-filter zeroed the pair
+        if (tv[i].num_inliers >= static_cast<uint32_t>(min_num_inliers) && tv[i].num_inliers > 0) {
+          t.config = tv[i].config;
+          std::memcpy(t.E, tv[i].E, sizeof(t.E));
+          std::memcpy(t.F, tv[i].F, sizeof(t.F));
+          std::memcpy(t.H, tv[i].H, sizeof(t.H));
+          std::memcpy(t.qvec, tv[i].qvec, sizeof(t.qvec));
+          std::memcpy(t.tvec, tv[i].tvec, sizeof(t.tvec));
+          t.tri_angle = tv[i].tri_angle;
+          t.inlier_matches.resize(ioff[i + 1] - ioff[i]);
+          for (size_t k = 0; k < t.inlier_matches.size(); ++k)
+            t.inlier_matches[k] = FeatureMatch(im[2 * (ioff[i] + k)], im[2 * (ioff[i] + k) + 1]);
+        }
+        cache->WriteMatches(prs[i].first, prs[i].second, matches);
+        cache->WriteTwoViewGeometry(prs[i].first, prs[i].second, t);
       }
-      cache_->WriteMatches(prs[i].first, prs[i].second, matches);
-      cache_->WriteTwoViewGeometry(prs[i].first, prs[i].second, t);
+    };
+    if (!options_.async_write_back) {
+      write();
+    } else {
+      Flush();  // one write-back in flight
+      writer_ = std::thread([this, cache, write = std::move(write)]() {
+        try {
+          cache->BeginTransaction();
+          write();
+          cache->EndTransaction();
+        } catch (...) {
+          writer_error_ = std::current_exception();
+        }
+      });
     }
   };
   run(to_match, nullptr);
@@ -247,10 +282,15 @@ bool ExhaustiveFeatureMatcher::Run() {
           }
         }
       }
-      DatabaseTransaction database_transaction(&database_);
-      matcher_.Match(image_pairs);
+      if (match_options_.async_write_back) {  // the write-back thread owns the transaction of its rows
+        matcher_.Match(image_pairs);
+      } else {
+        DatabaseTransaction database_transaction(&database_);
+        matcher_.Match(image_pairs);
+      }
     }
   }
+  matcher_.Flush();
   return true;
 }
 
@@ -278,6 +318,7 @@ int dsm_host_exhaustive_matcher_ex(const char* database_path, int block_size, in
     }
     mo.guided_matching = guided_matching != 0;
     mo.multiple_models = multiple_models != 0;
+    mo.async_write_back = std::getenv("DSM_ASYNC_WRITE_BACK") != nullptr;  // CLI / tests: overlap SQLite with the device
     mo.random_seed = random_seed;
     ExhaustiveFeatureMatcher m(eo, mo, database_path);
     return m.Run() ? 0 : 2;

@@ -14,6 +14,9 @@
 #define DAGSFM_AMD_HOST_FEATURE_MATCHING_H_
 
 #include <string>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <utility>
@@ -41,26 +44,73 @@ class FeatureMatcherCache {
   std::vector<image_t> GetImageIds() const;
   const FeatureKeypoints& GetKeypoints(image_t image_id);
   const FeatureDescriptors& GetDescriptors(image_t image_id);
-  FeatureMatches GetMatches(image_t a, image_t b) const { return database_->ReadMatches(a, b); }
+  FeatureMatches GetMatches(image_t a, image_t b) const {
+    std::lock_guard<std::mutex> lock(mutex_);
+    return database_->ReadMatches(a, b);
+  }
   // The pair ids of both result tables are read in bulk by Setup() and kept current here, so the two existence
   // checks Match() makes for every pair (matching.cc:782-812) cost a hash lookup instead of a SELECT each.
-  bool ExistsMatches(image_t a, image_t b) const { return have_matches_.count(Database::ImagePairToPairId(a, b)) != 0; }
-  bool ExistsInlierMatches(image_t a, image_t b) const { return have_inliers_.count(Database::ImagePairToPairId(a, b)) != 0; }
+  // One mutex serialises every touch of the (single, NOMUTEX) connection and of the id sets, like the reference's
+  // database_mutex_ (matching.h:208): the asynchronous write-back thread and the caller may both be here.
+  bool ExistsMatches(image_t a, image_t b) const {
+    std::lock_guard<std::mutex> lock(mutex_);
+    return have_matches_.count(Database::ImagePairToPairId(a, b)) != 0;
+  }
+  bool ExistsInlierMatches(image_t a, image_t b) const {
+    std::lock_guard<std::mutex> lock(mutex_);
+    return have_inliers_.count(Database::ImagePairToPairId(a, b)) != 0;
+  }
+  // Holds the mutex for a whole batch of the calls below (the *Unlocked variants), so that a batch is not
+  // interleaved lock by lock with the write-back thread.
+  std::unique_lock<std::mutex> Lock() const { return std::unique_lock<std::mutex>(mutex_); }
+  bool ExistsMatchesUnlocked(image_t a, image_t b) const { return have_matches_.count(Database::ImagePairToPairId(a, b)) != 0; }
+  bool ExistsInlierMatchesUnlocked(image_t a, image_t b) const { return have_inliers_.count(Database::ImagePairToPairId(a, b)) != 0; }
+  FeatureMatches GetMatchesUnlocked(image_t a, image_t b) const { return database_->ReadMatches(a, b); }
+  void DeleteMatchesUnlocked(image_t a, image_t b) {
+    database_->DeleteMatches(a, b);
+    have_matches_.erase(Database::ImagePairToPairId(a, b));
+  }
+  void DeleteInlierMatchesUnlocked(image_t a, image_t b) {
+    database_->DeleteInlierMatches(a, b);
+    have_inliers_.erase(Database::ImagePairToPairId(a, b));
+  }
+  void MarkPendingUnlocked(image_t a, image_t b) {
+    have_matches_.insert(Database::ImagePairToPairId(a, b));
+    have_inliers_.insert(Database::ImagePairToPairId(a, b));
+  }
+  // the rows of this pair are on their way (asynchronous write-back): later Match() calls must skip it
+  void MarkPending(image_t a, image_t b) {
+    std::lock_guard<std::mutex> lock(mutex_);
+    have_matches_.insert(Database::ImagePairToPairId(a, b));
+    have_inliers_.insert(Database::ImagePairToPairId(a, b));
+  }
   void WriteMatches(image_t a, image_t b, const FeatureMatches& m) {
+    std::lock_guard<std::mutex> lock(mutex_);
     database_->WriteMatches(a, b, m);
     have_matches_.insert(Database::ImagePairToPairId(a, b));
   }
   void WriteTwoViewGeometry(image_t a, image_t b, const TwoViewGeometry& t) {
+    std::lock_guard<std::mutex> lock(mutex_);
     database_->WriteTwoViewGeometry(a, b, t);
     have_inliers_.insert(Database::ImagePairToPairId(a, b));
   }
   void DeleteMatches(image_t a, image_t b) {
+    std::lock_guard<std::mutex> lock(mutex_);
     database_->DeleteMatches(a, b);
     have_matches_.erase(Database::ImagePairToPairId(a, b));
   }
   void DeleteInlierMatches(image_t a, image_t b) {
+    std::lock_guard<std::mutex> lock(mutex_);
     database_->DeleteInlierMatches(a, b);
     have_inliers_.erase(Database::ImagePairToPairId(a, b));
+  }
+  void BeginTransaction() const {
+    std::lock_guard<std::mutex> lock(mutex_);
+    database_->BeginTransaction();
+  }
+  void EndTransaction() const {
+    std::lock_guard<std::mutex> lock(mutex_);
+    database_->EndTransaction();
   }
 
  private:
@@ -71,6 +121,7 @@ class FeatureMatcherCache {
   std::unordered_map<image_t, FeatureKeypoints> keypoints_cache_;
   std::unordered_map<image_t, FeatureDescriptors> descriptors_cache_;
   std::unordered_set<image_pair_t> have_matches_, have_inliers_;
+  mutable std::mutex mutex_;
 };
 
 class SiftFeatureMatcher {
@@ -83,6 +134,9 @@ class SiftFeatureMatcher {
   // Matches + verifies the pairs and writes `matches` / `two_view_geometries` rows, with the
   // reference's dedupe / skip / partial-recompute / post-filter semantics (matching.cc:749-839).
   void Match(const std::vector<std::pair<image_t, image_t>>& image_pairs);
+
+  // Waits for an asynchronous write-back (SiftMatchingOptions::async_write_back) and rethrows its error, if any.
+  void Flush();
 
   const std::string& LastError() const { return last_error_; }
 
@@ -97,6 +151,8 @@ class SiftFeatureMatcher {
   std::vector<image_t> image_ids_;                    // device image index -> image_id
   std::unordered_map<image_t, uint32_t> image_index_;  // image_id -> device image index
   std::string last_error_;
+  std::thread writer_;                // at most one write-back in flight
+  std::exception_ptr writer_error_;
 };
 
 // ExhaustiveFeatureMatcher::Run, matching.cc:853-915: blocks of block_size x block_size images,

@@ -82,6 +82,10 @@ struct SiftMatchingOptions {  // feature/sift.h:116-165, same names and defaults
   int min_num_inliers = 15;
   bool multiple_models = false;
   bool guided_matching = false;
+  // extension (not a reference option): SiftFeatureMatcher::Match returns once the device results are on the host
+  // and the rows are written by a background thread, overlapping SQLite with the next block's device work; the
+  // writer owns the transaction, so the caller must not hold one; Flush() / the destructor waits for it.
+  bool async_write_back = false;
   // not in the reference: seed of the per-pair PRNG schedule (the reference seeds from the clock)
   uint32_t random_seed = 0;
   bool Check() const;  // feature/sift.cc:236-250

@@ -104,8 +104,12 @@ def test_database_round_trip_and_dagsfm_columns(tmp_path):
 
 
 @pytest.mark.gpu
-def test_exhaustive_matcher_drop_in(tmp_path, oracle):
-    """colmap exhaustive_matcher equivalent over a synthetic database.db == oracle, incl. resume semantics."""
+@pytest.mark.parametrize("async_write", [False, True])
+def test_exhaustive_matcher_drop_in(tmp_path, oracle, async_write, monkeypatch):
+    """colmap exhaustive_matcher equivalent over a synthetic database.db == oracle, incl. resume semantics; also with
+    the write-back on a background thread (SiftMatchingOptions::async_write_back, DSM_ASYNC_WRITE_BACK)."""
+    if async_write:
+        monkeypatch.setenv("DSM_ASYNC_WRITE_BACK", "1")
     from dagsfm_amd import capi, synthetic
     n_img = 6
     scene = synthetic.Scene(n_img, 640, seed=33, n_pool=1800)
@@ -169,9 +173,12 @@ def _visit_order(n, block_size):
 
 
 @pytest.mark.gpu
-def test_exhaustive_matcher_blocks_and_swapped_pairs(tmp_path, oracle):
+@pytest.mark.parametrize("async_write", [False, True])
+def test_exhaustive_matcher_blocks_and_swapped_pairs(tmp_path, oracle, async_write, monkeypatch):
     """block_size < #images: some pairs are visited as (larger id, smaller id); the rows are stored swapped /
     inverted exactly as Database::WriteMatches / WriteTwoViewGeometry do (database.cc:681-751)."""
+    if async_write:  # several Match() calls: the write-back of one block overlaps the device work of the next
+        monkeypatch.setenv("DSM_ASYNC_WRITE_BACK", "1")
     from dagsfm_amd import capi, synthetic
     n_img = 6
     scene = synthetic.Scene(n_img, 512, seed=34, n_pool=1400)

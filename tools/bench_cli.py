@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the drop-in CLI (dsm_exhaustive_matcher = colmap exhaustive_matcher on the MI355X path) over a
+synthetic database.db, SQLite included: blocking write-back vs SiftMatchingOptions::async_write_back
+(DSM_ASYNC_WRITE_BACK=1).    python tools/bench_cli.py [--images 400] [--feats 1024]"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dagsfm_amd import synthetic  # noqa: E402
+from tests import dbutil  # noqa: E402
+
+CLI = os.path.join(ROOT, "dagsfm_amd", "dsm_exhaustive_matcher")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=400)
+    ap.add_argument("--feats", type=int, default=1024)
+    ap.add_argument("--block_size", type=int, default=50, help="ExhaustiveMatching.block_size (reference default 50)")
+    a = ap.parse_args()
+    scene = synthetic.Scene(a.images, a.feats, seed=1)
+    ims = [scene.image(i) for i in range(a.images)]
+    d = tempfile.mkdtemp()
+    base = os.path.join(d, "base.db")
+    dbutil.create(base, [(im[0], im[1]) for im in ims], prior=True)
+    n_pairs = a.images * (a.images - 1) // 2
+    for mode in ("blocking", "async"):
+        path = os.path.join(d, mode + ".db")
+        shutil.copy(base, path)
+        env = dict(os.environ)
+        if mode == "async":
+            env["DSM_ASYNC_WRITE_BACK"] = "1"
+        t0 = time.perf_counter()
+        subprocess.check_call([CLI, "--database_path", path, "--random_seed", "1", "--ExhaustiveMatching.block_size",
+                               str(a.block_size)], env=env)
+        dt = time.perf_counter() - t0
+        print("block_size %d  %-9s %d pairs in %.2f s  (%.0f pairs/s incl. process start, image upload and SQLite)" % (a.block_size, mode, n_pairs, dt, n_pairs / dt), flush=True)
+    shutil.rmtree(d)
+
+
+if __name__ == "__main__":
+    main()
