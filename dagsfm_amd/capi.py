@@ -87,6 +87,8 @@ def lib():
                                                      ctypes.POINTER(TwoViewOptions), ctypes.c_uint32,
                                                      ctypes.POINTER(TwoViewGeometry), u32p]
         L.dsm_debug_sample_sequence.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, u32p]
+        L.dsm_debug_image_to_world.argtypes = [vp, ctypes.POINTER(Camera), ctypes.c_uint32, ctypes.POINTER(ctypes.c_double),
+                                               ctypes.POINTER(ctypes.c_double)]
         L.dsm_default_match_options.argtypes = [ctypes.POINTER(MatchOptions)]
         L.dsm_default_match_options.restype = None
         L.dsm_default_two_view_options.argtypes = [ctypes.POINTER(TwoViewOptions)]
@@ -102,6 +104,17 @@ def pair_seed(id1, id2, user_seed=0):
 def simple_pinhole(f, cx, cy, width, height, prior=True):
     c = Camera(model_id=0, has_prior_focal_length=int(bool(prior)), width=width, height=height)
     c.params[0], c.params[1], c.params[2] = f, cx, cy
+    return c
+
+
+CAMERA_MODEL_NUM_PARAMS = (3, 4, 4, 5, 8, 8, 12, 5, 4, 5, 12)  # camera_models.h:187-349, ids 0..10
+
+
+def camera(model_id, params, width, height, prior=True):
+    """dsm_camera of any of the reference's camera models (params in the reference's order)."""
+    c = Camera(model_id=model_id, has_prior_focal_length=int(bool(prior)), width=width, height=height)
+    for k, v in enumerate(params):
+        c.params[k] = float(v)
     return c
 
 
@@ -249,6 +262,13 @@ class Context:
     def debug_sample_sequence(self, seed, k, total, n_draws):
         out = np.zeros((n_draws, k), dtype=np.uint32)
         self._chk(lib().dsm_debug_sample_sequence(self._h, seed, k, total, n_draws, out.ctypes.data_as(u32p)))
+        return out
+
+    def debug_image_to_world(self, cam, xy):
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        out = np.zeros_like(xy)
+        dp = ctypes.POINTER(ctypes.c_double)
+        self._chk(lib().dsm_debug_image_to_world(self._h, ctypes.byref(cam), len(xy), xy.ctypes.data_as(dp), out.ctypes.data_as(dp)))
         return out
 
     def match_kernel_time(self):

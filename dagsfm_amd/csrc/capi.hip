@@ -25,6 +25,7 @@
 
 #include "../../include/dagsfm_mi355x.h"
 #include "kernels.h"
+#include "verify_camera.h"
 
 namespace {
 
@@ -246,6 +247,9 @@ int dsm_set_images(dsm_ctx* ctx, uint32_t n_images, const uint32_t* n_feats, con
   if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
   if (n_images && (!n_feats || !desc)) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "null image arrays");
   if (kp_xy && kp_stride < 2) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "kp_stride must be >= 2");
+  if (cameras)  // Camera::SetModelId CHECKs ExistsCameraModelWithId (camera.cc:52); never a silent default
+    for (uint32_t i = 0; i < n_images; ++i)
+      if (!cam_model_exists(cameras[i].model_id)) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "camera model id does not exist (0..10)");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->matched = false;
   ctx->verified = false;
@@ -327,8 +331,8 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
   for (uint32_t i = 0; i < n_pairs; ++i) {
     const uint32_t a = pairs[2 * i], b = pairs[2 * i + 1];
     if (a >= ctx->n_images || b >= ctx->n_images) return fail(ctx, DSM_ERR_OUT_OF_RANGE, "image index out of range");
-    if ((int64_t)ctx->nfeat[a] > options->max_num_matches || (int64_t)ctx->nfeat[b] > options->max_num_matches)
-      return fail(ctx, DSM_ERR_OUT_OF_RANGE, "image has more features than max_num_matches");
+    // max_num_matches is not consulted: MatchSiftFeaturesCPU (sift.cc:810-822), the path this library reproduces,
+    // ignores it (only the SiftGPU matcher clamps, sift.cc:200-209); an image of any size is matched in full
   }
   HIPCHK(ctx, ctx->d_counts.reserve(std::max<uint32_t>(n_pairs, 1) * 4));
   HIPCHK(ctx, ctx->d_offsets.reserve(((size_t)n_pairs + 1) * 8));
@@ -1140,6 +1144,8 @@ int dsm_estimate_two_view_geometry(dsm_ctx* ctx, const dsm_camera* camera1, cons
                                    uint32_t seed, dsm_two_view_geometry* out, uint32_t* inlier_matches) {
   if (!ctx || !camera1 || !camera2 || !options || !out || (n_matches && (!matches || !points1 || !points2)))
     return DSM_ERR_INVALID_ARGUMENT;
+  if (!cam_model_exists(camera1->model_id) || !cam_model_exists(camera2->model_id))
+    return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "camera model id does not exist (0..10)");
   for (uint32_t i = 0; i < n_matches; ++i)
     if (matches[2 * i] >= n1 || matches[2 * i + 1] >= n2) return fail(ctx, DSM_ERR_OUT_OF_RANGE, "match index out of range");
   if (!ctx->leaf) {
@@ -1216,6 +1222,24 @@ int dsm_debug_sample_sequence(dsm_ctx* ctx, uint32_t seed, uint32_t k, uint32_t 
   o.release();
   idx.release();
   tmp7.release();
+  return DSM_OK;
+}
+
+int dsm_debug_image_to_world(dsm_ctx* ctx, const dsm_camera* camera, uint32_t n, const double* xy, double* out_uv) {
+  if (!ctx || !camera || (n && (!xy || !out_uv))) return DSM_ERR_INVALID_ARGUMENT;
+  if (!cam_model_exists(camera->model_id)) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "camera model id does not exist (0..10)");
+  if (!n) return DSM_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  DevBuf in, out;
+  HIPCHK(ctx, in.reserve((size_t)n * 16));
+  HIPCHK(ctx, out.reserve((size_t)n * 16));
+  HIPCHK(ctx, hipMemcpy(in.p, xy, (size_t)n * 16, hipMemcpyHostToDevice));
+  launch_debug_image_to_world(*camera, n, in.as<double>(), out.as<double>(), ctx->stream);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpy(out_uv, out.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+  in.release();
+  out.release();
   return DSM_OK;
 }
 

@@ -130,6 +130,7 @@ uint32_t vp_maxm(int fam);
 void debug_read_prof(unsigned long long* out16);
 void launch_debug_samples(uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out, uint32_t* idx, uint32_t* tmp7,
                           int mode, hipStream_t st);
+void launch_debug_image_to_world(const dsm_camera& cam, uint32_t n, const double* xy, double* uv, hipStream_t st);
 void launch_compact_inliers(const uint64_t* match_off, const uint64_t* inl_off, const uint32_t* inl_counts,
                             const uint32_t* src, uint32_t* dst, uint32_t n_pairs, hipStream_t st);
 

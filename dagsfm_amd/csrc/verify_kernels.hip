@@ -29,6 +29,7 @@
 #include "../../include/dagsfm_mi355x.h"
 #include "kernels.h"
 #include "verify_estimators.h"
+#include "verify_camera.h"
 #include "verify_fivept_coop.h"
 
 #define BATCH 64
@@ -645,67 +646,7 @@ DSM_DEV void lo_ransac(const PairWork& w, const RansacOpt& opt, uint32_t* sidx, 
 }
 
 // ------------------------------------------------------------------------------------ cameras
-// Camera::ImageToWorld for SIMPLE_PINHOLE / PINHOLE / SIMPLE_RADIAL,
-// /root/reference/src/base/camera_models.h:629-637, 679-689, 733-757, 547-587
-DSM_DEV void image_to_world(const dsm_camera& cam, double x, double y, double* u, double* v) {
-  if (cam.model_id == 0) {
-    const double f = cam.params[0], c1 = cam.params[1], c2 = cam.params[2];
-    *u = (x - c1) / f;
-    *v = (y - c2) / f;
-  } else if (cam.model_id == 1) {
-    const double f1 = cam.params[0], f2 = cam.params[1], c1 = cam.params[2], c2 = cam.params[3];
-    *u = (x - c1) / f1;
-    *v = (y - c2) / f2;
-  } else {
-    const double f = cam.params[0], c1 = cam.params[1], c2 = cam.params[2], k = cam.params[3];
-    const double x0_0 = (x - c1) / f, x0_1 = (y - c2) / f;
-    double x_0 = x0_0, x_1 = x0_1;
-    auto dist = [k](double uu, double vv, double* du, double* dv) {
-      const double u2 = uu * uu, v2 = vv * vv;
-      const double r2 = u2 + v2;
-      const double radial = k * r2;
-      *du = uu * radial;
-      *dv = vv * radial;
-    };
-    for (int it = 0; it < 100; ++it) {
-      const double a0 = fabs(1e-6 * x_0), a1 = fabs(1e-6 * x_1);
-      const double step0 = DBL_EPSILON > a0 ? DBL_EPSILON : a0;
-      const double step1 = DBL_EPSILON > a1 ? DBL_EPSILON : a1;
-      double dx0, dx1, b00, b01, f00, f01, b10, b11, f10, f11;
-      dist(x_0, x_1, &dx0, &dx1);
-      dist(x_0 - step0, x_1, &b00, &b01);
-      dist(x_0 + step0, x_1, &f00, &f01);
-      dist(x_0, x_1 - step1, &b10, &b11);
-      dist(x_0, x_1 + step1, &f10, &f11);
-      const double J00 = 1 + (f00 - b00) / (2 * step0);
-      const double J01 = (f10 - b10) / (2 * step1);
-      const double J10 = (f01 - b01) / (2 * step0);
-      const double J11 = 1 + (f11 - b11) / (2 * step1);
-      const double invdet = 1.0 / (J00 * J11 - J10 * J01);
-      const double i00 = J11 * invdet, i01 = -J01 * invdet, i10 = -J10 * invdet, i11 = J00 * invdet;
-      const double r0 = x_0 + dx0 - x0_0, r1 = x_1 + dx1 - x0_1;
-      const double s0 = i00 * r0 + i01 * r1;
-      const double s1 = i10 * r0 + i11 * r1;
-      x_0 -= s0;
-      x_1 -= s1;
-      if (s0 * s0 + s1 * s1 < 1e-10) break;
-    }
-    *u = x_0;
-    *v = x_1;
-  }
-}
-DSM_DEV double image_to_world_threshold(const dsm_camera& cam, double threshold) {
-  double mean_focal_length = 0;
-  if (cam.model_id == 1) {
-    mean_focal_length += cam.params[0];
-    mean_focal_length += cam.params[1];
-    mean_focal_length /= 2;
-  } else {
-    mean_focal_length += cam.params[0];
-    mean_focal_length /= 1;
-  }
-  return threshold / mean_focal_length;
-}
+// Camera::ImageToWorld / ImageToWorldThreshold / CalibrationMatrix for all eleven models: verify_camera.h
 
 // ------------------------------------------------------------------------------------ relative pose
 // TriangulatePoint (triangulation.cc:39-52) with P1 = [I | 0] and P2 = [R | t]; returns false never.
@@ -1319,17 +1260,9 @@ __global__ __launch_bounds__(64, 2) void k_verify_final(const VerifyParams p) {
           ncmb = 4;
         } else {
           // PoseFromHomographyMatrix, base/homography_matrix.cc:167-192 (K from Camera::CalibrationMatrix)
-          double K1[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, K2[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-          if (cam1.model_id == 1) {
-            K1[0] = cam1.params[0]; K1[4] = cam1.params[1]; K1[2] = cam1.params[2]; K1[5] = cam1.params[3];
-          } else {
-            K1[0] = cam1.params[0]; K1[4] = cam1.params[0]; K1[2] = cam1.params[1]; K1[5] = cam1.params[2];
-          }
-          if (cam2.model_id == 1) {
-            K2[0] = cam2.params[0]; K2[4] = cam2.params[1]; K2[2] = cam2.params[2]; K2[5] = cam2.params[3];
-          } else {
-            K2[0] = cam2.params[0]; K2[4] = cam2.params[0]; K2[2] = cam2.params[1]; K2[5] = cam2.params[2];
-          }
+          double K1[9], K2[9];
+          calibration_matrix(cam1, K1);
+          calibration_matrix(cam2, K2);
           ncmb = decompose_homography(Hm, K1, K2, Rc, tc);
         }
         for (int c = 0; c < ncmb; ++c) {
@@ -2268,6 +2201,18 @@ __global__ void k_debug_samples(uint32_t seed, uint32_t k, uint32_t total, uint3
     __syncthreads();
   }
 }
+__global__ void k_debug_image_to_world(const dsm_camera cam, uint32_t n, const double* xy, double* uv) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double u, v;
+  image_to_world(cam, xy[2 * i], xy[2 * i + 1], &u, &v);
+  uv[2 * i] = u;
+  uv[2 * i + 1] = v;
+}
+void launch_debug_image_to_world(const dsm_camera& cam, uint32_t n, const double* xy, double* uv, hipStream_t st) {
+  hipLaunchKernelGGL(k_debug_image_to_world, dim3((n + 63) / 64), dim3(64), 0, st, cam, n, xy, uv);
+}
+
 void launch_debug_samples(uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out, uint32_t* idx, uint32_t* tmp7,
                           int mode, hipStream_t st) {
   hipLaunchKernelGGL(k_debug_samples, dim3(1), dim3(64), 0, st, seed, k, total, n_draws, out, idx, tmp7, mode);

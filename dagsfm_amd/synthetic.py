@@ -34,9 +34,81 @@ def _look_at(cam_pos, target, up):
     return R, t
 
 
+def world_to_image(model_id, params, u, v):
+    """<Model>::WorldToImage of /root/reference/src/base/camera_models.h for the eleven camera models (numpy, arrays):
+    normalised camera coordinates -> pixels.  Only the test / bench scenes use it (to make keypoints that are
+    consistent with a distorted camera); the product path only ever needs the inverse (ImageToWorld)."""
+    p = [float(x) for x in params]
+    two_focal = model_id in (1, 4, 5, 6, 7, 10)
+    if two_focal:
+        f1, f2, c1, c2, e = p[0], p[1], p[2], p[3], p[4:]
+    else:
+        f1, f2, c1, c2, e = p[0], p[0], p[1], p[2], p[3:]
+    u = np.asarray(u, dtype=np.float64)
+    v = np.asarray(v, dtype=np.float64)
+    if model_id == 10:  # THIN_PRISM_FISHEYE lifts to the equidistant sphere first
+        r = np.sqrt(u * u + v * v)
+        sc = np.where(r > np.finfo(np.float64).eps, np.arctan(r) / np.where(r > 0, r, 1.0), 1.0)
+        u, v = u * sc, v * sc
+    u2, v2, uv = u * u, v * v, u * v
+    r2 = u2 + v2
+    if model_id in (0, 1):
+        du, dv = 0.0 * u, 0.0 * v
+    elif model_id == 2:
+        du, dv = u * (e[0] * r2), v * (e[0] * r2)
+    elif model_id == 3:
+        rad = e[0] * r2 + e[1] * r2 * r2
+        du, dv = u * rad, v * rad
+    elif model_id == 4:
+        rad = e[0] * r2 + e[1] * r2 * r2
+        du = u * rad + 2 * e[2] * uv + e[3] * (r2 + 2 * u2)
+        dv = v * rad + 2 * e[3] * uv + e[2] * (r2 + 2 * v2)
+    elif model_id == 6:
+        r4, r6 = r2 * r2, r2 * r2 * r2
+        rad = (1 + e[0] * r2 + e[1] * r4 + e[4] * r6) / (1 + e[5] * r2 + e[6] * r4 + e[7] * r6)
+        du = u * rad + 2 * e[2] * uv + e[3] * (r2 + 2 * u2) - u
+        dv = v * rad + 2 * e[3] * uv + e[2] * (r2 + 2 * v2) - v
+    elif model_id in (5, 8, 9):
+        k = (list(e) + [0.0, 0.0, 0.0])[:4] if model_id != 5 else list(e[:4])
+        r = np.sqrt(r2)
+        th = np.arctan(r)
+        th2 = th * th
+        thd = th * (1 + k[0] * th2 + k[1] * th2 ** 2 + k[2] * th2 ** 3 + k[3] * th2 ** 4)
+        ok = r > np.finfo(np.float64).eps
+        rs = np.where(ok, r, 1.0)
+        du = np.where(ok, u * thd / rs - u, 0.0)
+        dv = np.where(ok, v * thd / rs - v, 0.0)
+    elif model_id == 7:
+        om = e[0]
+        rad = np.sqrt(r2)
+        if om * om < 1e-4:
+            fac = (om * om * r2) / 3 - om * om / 12 + 1
+        else:
+            small = r2 < 1e-4
+            th = np.tan(om / 2)
+            f_small = (-2 * th * (4 * r2 * th * th - 3)) / (3 * om)
+            f_big = np.arctan(np.where(small, 1.0, rad) * 2 * th) / (np.where(small, 1.0, rad) * om)
+            fac = np.where(small, f_small, f_big)
+        du, dv = u * fac - u, v * fac - v
+    elif model_id == 10:
+        r4, r6, r8 = r2 * r2, r2 ** 3, r2 ** 4
+        rad = e[0] * r2 + e[1] * r4 + e[4] * r6 + e[5] * r8
+        du = u * rad + 2 * e[2] * uv + e[3] * (r2 + 2 * u2) + e[6] * r2
+        dv = v * rad + 2 * e[3] * uv + e[2] * (r2 + 2 * v2) + e[7] * r2
+    else:
+        raise ValueError("camera model %d does not exist" % model_id)
+    return f1 * (u + du) + c1, f2 * (v + dv) + c2
+
+
 class Scene:
     def __init__(self, n_images, n_feats, seed=0, n_obs=None, n_pool=None, focal=800.0, width=1000, height=750,
-                 kp_sigma=0.5, desc_sigma=0.012, planar=False, outlier_frac=0.2):
+                 kp_sigma=0.5, desc_sigma=0.012, planar=False, outlier_frac=0.2, planar_depth=0.05, panoramic=False,
+                 camera=None):
+        """planar: the point pool is flattened to z in +-5 * planar_depth (0.0 = an exact plane); panoramic: every camera
+        sits at the same centre (pure rotation between the images); camera = (model_id, params): keypoints are
+        projected through that camera model's WorldToImage instead of the SIMPLE_PINHOLE default."""
+        self.panoramic = panoramic
+        self.camera = camera
         self.n_images, self.n_feats, self.seed = n_images, n_feats, seed
         self.n_obs = n_obs if n_obs is not None else n_feats // 2
         self.n_pool = n_pool if n_pool is not None else max(4 * n_feats, self.n_obs)
@@ -46,7 +118,7 @@ class Scene:
         rng = np.random.default_rng([seed, 0xD5F])
         self.points = rng.uniform(-5.0, 5.0, (self.n_pool, 3))
         if planar:
-            self.points[:, 2] = 0.05 * self.points[:, 2]
+            self.points[:, 2] = planar_depth * self.points[:, 2]
         self.base = _sift_like(rng, self.n_pool)
 
     def image(self, i):
@@ -59,14 +131,21 @@ class Scene:
         d[2] = -abs(d[2]) - 0.6  # keep cameras on one side so that planar scenes stay visible
         d /= np.linalg.norm(d)
         pos = d * rng.uniform(14.0, 20.0)
-        R, t = _look_at(pos, rng.uniform(-1.0, 1.0, 3), np.array([0.0, 1.0, 0.0]) + 0.2 * rng.normal(size=3))
+        target = rng.uniform(-1.0, 1.0, 3)
+        if self.panoramic:  # one shared centre, the viewing direction is what differs
+            pos = np.array([0.0, 0.0, -17.0])
+            target = 3.0 * target
+        R, t = _look_at(pos, target, np.array([0.0, 1.0, 0.0]) + 0.2 * rng.normal(size=3))
         ids = np.full(n, -1, dtype=np.int64)
         obs = rng.choice(self.n_pool, size=k, replace=False)
         desc = np.empty((n, 128), dtype=np.float32)
         kp = np.empty((n, 2), dtype=np.float64)
         pc = self.points[obs] @ R.T + t
-        kp[:k, 0] = self.focal * pc[:, 0] / pc[:, 2] + self.width / 2.0
-        kp[:k, 1] = self.focal * pc[:, 1] / pc[:, 2] + self.height / 2.0
+        if self.camera is None:
+            kp[:k, 0] = self.focal * pc[:, 0] / pc[:, 2] + self.width / 2.0
+            kp[:k, 1] = self.focal * pc[:, 1] / pc[:, 2] + self.height / 2.0
+        else:
+            kp[:k, 0], kp[:k, 1] = world_to_image(self.camera[0], self.camera[1], pc[:, 0] / pc[:, 2], pc[:, 1] / pc[:, 2])
         kp[:k] += rng.normal(scale=self.kp_sigma, size=(k, 2))
         # geometric outliers: the descriptor still matches but the keypoint is somewhere else
         bad = rng.random(k) < self.outlier_frac

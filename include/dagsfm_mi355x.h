@@ -39,7 +39,8 @@ typedef struct dsm_match_options {
   double max_ratio;        /* default 0.8  */
   double max_distance;     /* default 0.7  */
   int32_t cross_check;     /* default 1    */
-  int32_t max_num_matches; /* default 32768; features per image beyond this are an error */
+  int32_t max_num_matches; /* default 32768; carried for ABI parity only: MatchSiftFeaturesCPU (sift.cc:810-822)
+                              ignores it (the SiftGPU matcher alone clamps, sift.cc:200-209), and so does this library */
 } dsm_match_options;
 
 /* Mirrors TwoViewGeometry::Options (src/estimators/two_view_geometry.h:105-157)
@@ -65,8 +66,14 @@ typedef struct dsm_two_view_options {
 } dsm_two_view_options;
 
 /* Camera as used by the verification path (src/base/camera.h; models
- * src/base/camera_models.h).  model_id follows the reference's numbering:
- * 0 SIMPLE_PINHOLE (f,cx,cy), 1 PINHOLE (fx,fy,cx,cy), 2 SIMPLE_RADIAL (f,cx,cy,k). */
+ * src/base/camera_models.h:187-349).  model_id and the parameter order follow the reference:
+ *   0 SIMPLE_PINHOLE f,cx,cy            1 PINHOLE fx,fy,cx,cy              2 SIMPLE_RADIAL f,cx,cy,k
+ *   3 RADIAL f,cx,cy,k1,k2              4 OPENCV fx,fy,cx,cy,k1,k2,p1,p2   5 OPENCV_FISHEYE fx,fy,cx,cy,k1..k4
+ *   6 FULL_OPENCV fx,fy,cx,cy,k1,k2,p1,p2,k3..k6   7 FOV fx,fy,cx,cy,omega
+ *   8 SIMPLE_RADIAL_FISHEYE f,cx,cy,k   9 RADIAL_FISHEYE f,cx,cy,k1,k2
+ *  10 THIN_PRISM_FISHEYE fx,fy,cx,cy,k1,k2,p1,p2,k3,k4,sx1,sy1
+ * Any other model_id is rejected with DSM_ERR_INVALID_ARGUMENT (the reference CHECKs ExistsCameraModelWithId,
+ * camera.cc:52).  Models 5, 7, 8, 9, 10 evaluate atan/tan/sin/cos with the device's math library. */
 typedef struct dsm_camera {
   int32_t model_id;
   int32_t has_prior_focal_length; /* Camera::HasPriorFocalLength, camera.h:191 */
@@ -232,6 +239,9 @@ int dsm_estimate_two_view_geometry(dsm_ctx* ctx, const dsm_camera* camera1, cons
  * `total` items with the given seed (RandomSampler, src/optim/random_sampler.cc:43-62). */
 int dsm_debug_sample_sequence(dsm_ctx* ctx, uint32_t seed, uint32_t k, uint32_t total,
                               uint32_t n_draws, uint32_t* out);
+
+/* Test hook: Camera::ImageToWorld (src/base/camera.cc:210-214) of n pixel points (x, y) on the device. */
+int dsm_debug_image_to_world(dsm_ctx* ctx, const dsm_camera* camera, uint32_t n, const double* xy, double* out_uv);
 
 void dsm_default_match_options(dsm_match_options* o);
 void dsm_default_two_view_options(dsm_two_view_options* o);

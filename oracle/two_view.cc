@@ -35,6 +35,8 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -720,17 +722,127 @@ static Report<Estimator> LoRansac(RansacOptions options, PRNG* prng, const std::
 }
 
 // ------------------------------------------------------------------------------------ camera
-// Distortion of SIMPLE_RADIAL, camera_models.h:747-757
-static void SimpleRadialDistortion(const double* extra, double u, double v, double* du, double* dv) {
-  const double k = extra[0];
-  const double u2 = u * u, v2 = v * v;
-  const double r2 = u2 + v2;
-  const double radial = k * r2;
-  *du = u * radial;
-  *dv = v * radial;
+// All eleven camera models of /root/reference/src/base/camera_models.h:187-349.  kTwoFocal = focal_length_idxs has
+// two entries (fx, fy, cx, cy, extra from 4); otherwise (f, cx, cy, extra from 3).
+static bool CameraModelExists(int id) { return id >= 0 && id <= 10; }
+static bool TwoFocal(int id) { return id == 1 || id == 4 || id == 5 || id == 6 || id == 7 || id == 10; }
+static void CheckModel(const dsm_camera& cam) {  // ExistsCameraModelWithId is a CHECK in the reference (camera.cc:52)
+  if (!CameraModelExists(cam.model_id)) {
+    std::fprintf(stderr, "oracle: camera model %d does not exist\n", cam.model_id);
+    std::abort();
+  }
+}
+
+// <Model>::Distortion(extra_params, u, v, &du, &dv)
+static void Distortion(int id, const double* e, double u, double v, double* du, double* dv) {
+  const double eps = std::numeric_limits<double>::epsilon();
+  switch (id) {
+    case 2: {  // SimpleRadialCameraModel::Distortion, camera_models.h:747-757
+      const double k = e[0];
+      const double u2 = u * u, v2 = v * v;
+      const double r2 = u2 + v2;
+      const double radial = k * r2;
+      *du = u * radial;
+      *dv = v * radial;
+      break;
+    }
+    case 3: {  // RadialCameraModel::Distortion, :810-822
+      const double k1 = e[0], k2 = e[1];
+      const double u2 = u * u, v2 = v * v;
+      const double r2 = u2 + v2;
+      const double radial = k1 * r2 + k2 * r2 * r2;
+      *du = u * radial;
+      *dv = v * radial;
+      break;
+    }
+    case 4: {  // OpenCVCameraModel::Distortion, :881-897
+      const double k1 = e[0], k2 = e[1], p1 = e[2], p2 = e[3];
+      const double u2 = u * u, uv = u * v, v2 = v * v;
+      const double r2 = u2 + v2;
+      const double radial = k1 * r2 + k2 * r2 * r2;
+      *du = u * radial + 2.0 * p1 * uv + p2 * (r2 + 2.0 * u2);
+      *dv = v * radial + 2.0 * p2 * uv + p1 * (r2 + 2.0 * v2);
+      break;
+    }
+    case 5: {  // OpenCVFisheyeCameraModel::Distortion, :957-982
+      const double k1 = e[0], k2 = e[1], k3 = e[2], k4 = e[3];
+      const double r = std::sqrt(u * u + v * v);
+      if (r > eps) {
+        const double theta = std::atan(r);
+        const double theta2 = theta * theta;
+        const double theta4 = theta2 * theta2;
+        const double theta6 = theta4 * theta2;
+        const double theta8 = theta4 * theta4;
+        const double thetad = theta * (1.0 + k1 * theta2 + k2 * theta4 + k3 * theta6 + k4 * theta8);
+        *du = u * thetad / r - u;
+        *dv = v * thetad / r - v;
+      } else {
+        *du = 0;
+        *dv = 0;
+      }
+      break;
+    }
+    case 6: {  // FullOpenCVCameraModel::Distortion, :1053-1077
+      const double k1 = e[0], k2 = e[1], p1 = e[2], p2 = e[3], k3 = e[4], k4 = e[5], k5 = e[6], k6 = e[7];
+      const double u2 = u * u, uv = u * v, v2 = v * v;
+      const double r2 = u2 + v2;
+      const double r4 = r2 * r2;
+      const double r6 = r4 * r2;
+      const double radial = (1.0 + k1 * r2 + k2 * r4 + k3 * r6) / (1.0 + k4 * r2 + k5 * r4 + k6 * r6);
+      *du = u * radial + 2.0 * p1 * uv + p2 * (r2 + 2.0 * u2) - u;
+      *dv = v * radial + 2.0 * p2 * uv + p1 * (r2 + 2.0 * v2) - v;
+      break;
+    }
+    case 8: {  // SimpleRadialFisheyeCameraModel::Distortion, :1278-1297
+      const double k = e[0];
+      const double r = std::sqrt(u * u + v * v);
+      if (r > eps) {
+        const double theta = std::atan(r);
+        const double theta2 = theta * theta;
+        const double thetad = theta * (1.0 + k * theta2);
+        *du = u * thetad / r - u;
+        *dv = v * thetad / r - v;
+      } else {
+        *du = 0;
+        *dv = 0;
+      }
+      break;
+    }
+    case 9: {  // RadialFisheyeCameraModel::Distortion, :1358-1380
+      const double k1 = e[0], k2 = e[1];
+      const double r = std::sqrt(u * u + v * v);
+      if (r > eps) {
+        const double theta = std::atan(r);
+        const double theta2 = theta * theta;
+        const double theta4 = theta2 * theta2;
+        const double thetad = theta * (1.0 + k1 * theta2 + k2 * theta4);
+        *du = u * thetad / r - u;
+        *dv = v * thetad / r - v;
+      } else {
+        *du = 0;
+        *dv = 0;
+      }
+      break;
+    }
+    case 10: {  // ThinPrismFisheyeCameraModel::Distortion, :1459-1481
+      const double k1 = e[0], k2 = e[1], p1 = e[2], p2 = e[3], k3 = e[4], k4 = e[5], sx1 = e[6], sy1 = e[7];
+      const double u2 = u * u, uv = u * v, v2 = v * v;
+      const double r2 = u2 + v2;
+      const double r4 = r2 * r2;
+      const double r6 = r4 * r2;
+      const double r8 = r6 * r2;
+      const double radial = k1 * r2 + k2 * r4 + k3 * r6 + k4 * r8;
+      *du = u * radial + 2.0 * p1 * uv + p2 * (r2 + 2.0 * u2) + sx1 * r2;
+      *dv = v * radial + 2.0 * p2 * uv + p1 * (r2 + 2.0 * v2) + sy1 * r2;
+      break;
+    }
+    default:
+      *du = 0;
+      *dv = 0;
+  }
 }
 // BaseCameraModel::IterativeUndistortion, camera_models.h:547-587
-static void IterativeUndistortionSimpleRadial(const double* params, double* u, double* v) {
+static void IterativeUndistortion(int id, const double* params, double* u, double* v) {
   const size_t kNumIterations = 100;
   const double kMaxStepNorm = 1e-10;
   const double kRelStepSize = 1e-6;
@@ -740,11 +852,11 @@ static void IterativeUndistortionSimpleRadial(const double* params, double* u, d
     const double step0 = std::max(std::numeric_limits<double>::epsilon(), std::abs(kRelStepSize * x_0));
     const double step1 = std::max(std::numeric_limits<double>::epsilon(), std::abs(kRelStepSize * x_1));
     double dx0, dx1, b00, b01, f00, f01, b10, b11, f10, f11;
-    SimpleRadialDistortion(params, x_0, x_1, &dx0, &dx1);
-    SimpleRadialDistortion(params, x_0 - step0, x_1, &b00, &b01);
-    SimpleRadialDistortion(params, x_0 + step0, x_1, &f00, &f01);
-    SimpleRadialDistortion(params, x_0, x_1 - step1, &b10, &b11);
-    SimpleRadialDistortion(params, x_0, x_1 + step1, &f10, &f11);
+    Distortion(id, params, x_0, x_1, &dx0, &dx1);
+    Distortion(id, params, x_0 - step0, x_1, &b00, &b01);
+    Distortion(id, params, x_0 + step0, x_1, &f00, &f01);
+    Distortion(id, params, x_0, x_1 - step1, &b10, &b11);
+    Distortion(id, params, x_0, x_1 + step1, &f10, &f11);
     const double J00 = 1 + (f00 - b00) / (2 * step0);
     const double J01 = (f10 - b10) / (2 * step1);
     const double J10 = (f01 - b01) / (2 * step0);
@@ -762,35 +874,65 @@ static void IterativeUndistortionSimpleRadial(const double* params, double* u, d
   *u = x_0;
   *v = x_1;
 }
-
-static Vec2 ImageToWorld(const dsm_camera& cam, const Vec2& p) {
-  Vec2 w;
-  switch (cam.model_id) {
-    case 0: {  // SIMPLE_PINHOLE, camera_models.h:629-637
-      const double f = cam.params[0], c1 = cam.params[1], c2 = cam.params[2];
-      w.x = (p.x - c1) / f;
-      w.y = (p.y - c2) / f;
-      break;
-    }
-    case 1: {  // PINHOLE, :679-689
-      const double f1 = cam.params[0], f2 = cam.params[1], c1 = cam.params[2], c2 = cam.params[3];
-      w.x = (p.x - c1) / f1;
-      w.y = (p.y - c2) / f2;
-      break;
-    }
-    default: {  // SIMPLE_RADIAL, :733-744
-      const double f = cam.params[0], c1 = cam.params[1], c2 = cam.params[2];
-      w.x = (p.x - c1) / f;
-      w.y = (p.y - c2) / f;
-      IterativeUndistortionSimpleRadial(&cam.params[3], &w.x, &w.y);
-      break;
-    }
+// FOVCameraModel::Undistortion, camera_models.h:1179-1218
+static void FOVUndistortion(const double* e, double u, double v, double* du, double* dv) {
+  const double omega = e[0];
+  const double kEpsilon = 1e-4;
+  const double radius2 = u * u + v * v;
+  const double omega2 = omega * omega;
+  double factor;
+  if (omega2 < kEpsilon) {
+    factor = (omega2 * radius2) / 3.0 - omega2 / 12.0 + 1.0;
+  } else if (radius2 < kEpsilon) {
+    factor = (omega * (omega * omega * radius2 + 3.0)) / (6.0 * std::tan(omega / 2.0));
+  } else {
+    const double radius = std::sqrt(radius2);
+    const double numerator = std::tan(radius * omega);
+    factor = numerator / (radius * 2.0 * std::tan(omega / 2.0));
   }
+  *du = u * factor;
+  *dv = v * factor;
+}
+
+// Camera::ImageToWorld -> <Model>::ImageToWorld
+static Vec2 ImageToWorld(const dsm_camera& cam, const Vec2& p) {
+  CheckModel(cam);
+  Vec2 w;
+  const int id = cam.model_id;
+  if (TwoFocal(id)) {
+    const double f1 = cam.params[0], f2 = cam.params[1], c1 = cam.params[2], c2 = cam.params[3];
+    if (id == 7) {  // FOVCameraModel::ImageToWorld, :1126-1141
+      const double uu = (p.x - c1) / f1;
+      const double vv = (p.y - c2) / f2;
+      FOVUndistortion(&cam.params[4], uu, vv, &w.x, &w.y);
+      return w;
+    }
+    w.x = (p.x - c1) / f1;
+    w.y = (p.y - c2) / f2;
+    if (id == 1) return w;  // PINHOLE, :679-689
+    IterativeUndistortion(id, &cam.params[4], &w.x, &w.y);
+    if (id == 10) {  // ThinPrismFisheyeCameraModel::ImageToWorld, :1434-1456
+      const double theta = std::sqrt(w.x * w.x + w.y * w.y);
+      const double theta_cos_theta = theta * std::cos(theta);
+      if (theta_cos_theta > std::numeric_limits<double>::epsilon()) {
+        const double scale = std::sin(theta) / theta_cos_theta;
+        w.x *= scale;
+        w.y *= scale;
+      }
+    }
+    return w;
+  }
+  const double f = cam.params[0], c1 = cam.params[1], c2 = cam.params[2];
+  w.x = (p.x - c1) / f;
+  w.y = (p.y - c2) / f;
+  if (id == 0) return w;  // SIMPLE_PINHOLE, :629-637
+  IterativeUndistortion(id, &cam.params[3], &w.x, &w.y);
   return w;
 }
 static double ImageToWorldThreshold(const dsm_camera& cam, double threshold) {  // camera_models.h:535-543
+  CheckModel(cam);
   double mean_focal_length = 0;
-  if (cam.model_id == 1) {
+  if (TwoFocal(cam.model_id)) {
     mean_focal_length += cam.params[0];
     mean_focal_length += cam.params[1];
     mean_focal_length /= 2;
@@ -801,10 +943,11 @@ static double ImageToWorldThreshold(const dsm_camera& cam, double threshold) {  
   return threshold / mean_focal_length;
 }
 static Mat3 CalibrationMatrix(const dsm_camera& cam) {  // camera.cc:75-93
+  CheckModel(cam);
   Mat3 K;
   for (int i = 0; i < 9; ++i) K.m[i] = 0;
   K(0, 0) = K(1, 1) = K(2, 2) = 1;
-  if (cam.model_id == 1) {
+  if (TwoFocal(cam.model_id)) {
     K(0, 0) = cam.params[0]; K(1, 1) = cam.params[1];
     K(0, 2) = cam.params[2]; K(1, 2) = cam.params[3];
   } else {
@@ -1541,6 +1684,7 @@ void oracle_image_to_world(const dsm_camera* cam, const double* p, double* w) {
   w[0] = r.x;
   w[1] = r.y;
 }
+double oracle_image_to_world_threshold(const dsm_camera* cam, double threshold) { return ImageToWorldThreshold(*cam, threshold); }
 // Sample sequence of RandomSampler for tests of the device MT19937 + Lemire mapping.
 void oracle_sample_sequence(uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out) {
   PRNG prng(seed);
