@@ -56,3 +56,43 @@ def test_device_reproduces_golden(dsm):
         m = dsm.match_sift_features(g[name + "/desc1"], g[name + "/desc2"])
         tv, inl = dsm.estimate_two_view_geometry(cam, g[name + "/kp1"], cam, g[name + "/kp2"], m, opts, seed)
         _check(g, name, m, tv, inl, 1e-6)
+
+
+# ---- pairs_v2.npz (round 2): PLANAR / PANORAMIC configurations, distorted camera models, one benchmark-size pair
+GOLDEN2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pairs_v2.npz")
+
+
+def _cam_from_array(a):
+    return capi.camera(int(a[0]), list(a[4:]), int(a[2]), int(a[3]), bool(a[1]))
+
+
+def _setup2(g, name):
+    seed, multiple, mni = [int(v) for v in g[name + "/params"]]
+    opts = capi.default_two_view_options(multiple_models=multiple, min_num_inliers=mni)
+    return _cam_from_array(g[name + "/cam1"]), _cam_from_array(g[name + "/cam2"]), opts, seed
+
+
+def test_oracle_reproduces_golden_v2(oracle):
+    g = np.load(GOLDEN2)
+    cases = [str(c) for c in g["cases"]]
+    assert {"planar", "panoramic", "radial", "opencv", "full_opencv", "bench_pair_4096"} <= set(cases)
+    assert int(g["planar/tvg_config"]) == 4 and int(g["panoramic/tvg_config"]) == 5
+    for name in cases:
+        cam1, cam2, opts, seed = _setup2(g, name)
+        m = g[name + "/matches"]
+        if name + "/desc1" in g:
+            m = oracle.match_sift_features_cpu(g[name + "/desc1"], g[name + "/desc2"])
+        tv, inl = oracle.estimate_two_view_geometry(cam1, g[name + "/kp1"], cam2, g[name + "/kp2"], m, opts, seed)
+        _check(g, name, m, tv, inl, 1e-9)
+
+
+@pytest.mark.gpu
+def test_device_reproduces_golden_v2(dsm):
+    g = np.load(GOLDEN2)
+    for name in [str(c) for c in g["cases"]]:
+        cam1, cam2, opts, seed = _setup2(g, name)
+        m = g[name + "/matches"]
+        if name + "/desc1" in g:
+            m = dsm.match_sift_features(g[name + "/desc1"], g[name + "/desc2"])
+        tv, inl = dsm.estimate_two_view_geometry(cam1, g[name + "/kp1"], cam2, g[name + "/kp2"], m, opts, seed)
+        _check(g, name, m, tv, inl, 1e-6)
