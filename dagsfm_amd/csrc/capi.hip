@@ -100,6 +100,8 @@ struct dsm_ctx {
   uint64_t total_matches = 0;
   double k1_ms = 0.0;
   double k1b_ms = 0.0;  // k1_resolve_index
+  double k1g_ms = 0.0;  // k1_best_rows<GATHER> (pass 2 of the cross-check)
+  DevBuf d_order, d_dpairs2, d_ecnt, d_eoff, d_etotal, d_entries, d_out2;
   uint32_t k1_launches = 0;
   std::vector<hipEvent_t> ev;
 
@@ -225,7 +227,8 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
                     &ctx->d_g_params, &ctx->d_g_m, &ctx->d_g_counts, &ctx->d_g_offsets, &ctx->d_g_total, &ctx->d_g_matches, &ctx->d_g_plan,
                     &ctx->d_g_inl, &ctx->d_g_inl_off, &ctx->d_mm_matches[0], &ctx->d_mm_matches[1], &ctx->d_mm_off[0],
                     &ctx->d_mm_off[1], &ctx->d_mm_counts, &ctx->d_mm_state, &ctx->d_mm_first, &ctx->d_mm_acc, &ctx->d_mm_keep,
-                    &ctx->d_mm_total};
+                    &ctx->d_mm_total, &ctx->d_order, &ctx->d_dpairs2, &ctx->d_ecnt, &ctx->d_eoff, &ctx->d_etotal, &ctx->d_entries,
+                    &ctx->d_out2};
   if (ctx->vev0) (void)hipEventDestroy(ctx->vev0);
   if (ctx->vev1) (void)hipEventDestroy(ctx->vev1);
   for (DevBuf* b : bufs) b->release();
@@ -325,6 +328,7 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
   ctx->pairs.assign(pairs, pairs + (size_t)n_pairs * 2);
   ctx->k1_ms = 0.0;
   ctx->k1b_ms = 0.0;
+  ctx->k1g_ms = 0.0;
   ctx->k1_launches = 0;
   ctx->total_matches = 0;
   const bool cross = options->cross_check != 0;
@@ -341,10 +345,10 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
 
   // Chunk the pair list so that the K1 output scratch stays below a fixed budget.
   const uint64_t budget_rows = (6ull << 30) / 4;
-  std::vector<uint2> dpairs;
+  std::vector<uint2> dpairs, dpairs2;
   std::vector<uint64_t> doff;
   std::vector<uint4> pdir;
-  std::vector<uint32_t> cnt_b(ctx->n_images + 1);
+  std::vector<uint32_t> order, cnt_b(ctx->n_images + 1);
   size_t ev_used = 0;
   uint32_t c0 = 0;
   while (c0 < n_pairs) {
@@ -352,50 +356,43 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
     uint64_t rows_acc = 0;
     uint32_t c1 = c0;
     while (c1 < n_pairs) {
-      const uint32_t a = pairs[2 * c1], b = pairs[2 * c1 + 1];
-      const uint64_t r = (uint64_t)ctx->rows[a] + (cross ? ctx->rows[b] : 0);
+      const uint64_t r = ctx->rows[pairs[2 * c1]];
       if (c1 > c0 && rows_acc + r > budget_rows) break;
       rows_acc += r;
       ++c1;
     }
     const uint32_t nc = c1 - c0;
-    const uint32_t nd = cross ? 2 * nc : nc;
-    // directed list, counting-sorted by column image b so that workgroups running at the
-    // same time stream the same B image out of L2.
-    std::fill(cnt_b.begin(), cnt_b.end(), 0u);
-    for (uint32_t i = c0; i < c1; ++i) {
-      const uint32_t a = pairs[2 * i], b = pairs[2 * i + 1];
-      cnt_b[b + 1]++;
-      if (cross) cnt_b[a + 1]++;
-    }
-    for (uint32_t k = 0; k < ctx->n_images; ++k) cnt_b[k + 1] += cnt_b[k];
-    dpairs.resize(nd);
+    // Pass 1, image a rows vs image b columns: pair k of the chunk IS directed pair k (its K1 output lives at
+    // doff[k]); the launch order is counting-sorted by the column image b so that workgroups running at the same
+    // time stream the same B image out of L2.
+    dpairs.resize(nc);
+    dpairs2.resize(nc);
     pdir.resize(nc);
-    for (uint32_t i = c0; i < c1; ++i) {
-      const uint32_t a = pairs[2 * i], b = pairs[2 * i + 1];
-      const uint32_t dab = cnt_b[b]++;
-      dpairs[dab] = make_uint2(a, b);
-      uint32_t dba = 0;
-      if (cross) {
-        dba = cnt_b[a]++;
-        dpairs[dba] = make_uint2(b, a);
-      }
-      pdir[i - c0] = make_uint4(dab, dba, ctx->nfeat[a], ctx->nfeat[b]);
-    }
-    doff.resize(nd);
+    doff.resize(nc);
+    order.resize(nc);
+    std::fill(cnt_b.begin(), cnt_b.end(), 0u);
     uint64_t off = 0;
     uint32_t max_rb = 0;
-    for (uint32_t k = 0; k < nd; ++k) {
+    for (uint32_t k = 0; k < nc; ++k) {
+      const uint32_t a = pairs[2 * (c0 + k)], b = pairs[2 * (c0 + k) + 1];
+      dpairs[k] = make_uint2(a, b);
+      dpairs2[k] = make_uint2(b, a);  // pass 2: gathered rows of image b vs the columns of image a
+      pdir[k] = make_uint4(k, 0, ctx->nfeat[a], ctx->nfeat[b]);
       doff[k] = off;
-      off += ctx->rows[dpairs[k].x];
-      max_rb = std::max(max_rb, ctx->rows[dpairs[k].x] / 256);
+      off += ctx->rows[a];
+      max_rb = std::max(max_rb, ctx->rows[a] / 256);
+      cnt_b[b + 1]++;
     }
-    HIPCHK(ctx, ctx->d_dpairs.reserve(std::max<uint32_t>(nd, 1) * sizeof(uint2)));
-    HIPCHK(ctx, ctx->d_doutoff.reserve(std::max<uint32_t>(nd, 1) * 8));
+    for (uint32_t k = 0; k < ctx->n_images; ++k) cnt_b[k + 1] += cnt_b[k];
+    for (uint32_t k = 0; k < nc; ++k) order[cnt_b[dpairs[k].y]++] = k;
+    HIPCHK(ctx, ctx->d_dpairs.reserve(std::max<uint32_t>(nc, 1) * sizeof(uint2)));
+    HIPCHK(ctx, ctx->d_order.reserve(std::max<uint32_t>(nc, 1) * 4));
+    HIPCHK(ctx, ctx->d_doutoff.reserve(std::max<uint32_t>(nc, 1) * 8));
     HIPCHK(ctx, ctx->d_pair_dir.reserve(std::max<uint32_t>(nc, 1) * sizeof(uint4)));
     HIPCHK(ctx, ctx->d_m.reserve(std::max<uint64_t>(off, 1) * 4));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_dpairs.p, dpairs.data(), nd * sizeof(uint2), hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_doutoff.p, doff.data(), nd * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_dpairs.p, dpairs.data(), nc * sizeof(uint2), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_order.p, order.data(), nc * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_doutoff.p, doff.data(), nc * 8, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_pair_dir.p, pdir.data(), nc * sizeof(uint4), hipMemcpyHostToDevice, st));
 
     K1Params k1;
@@ -409,52 +406,121 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
     k1.max_ratio = (float)options->max_ratio;        // narrowed as at sift.cc:164-166
     k1.max_distance = (float)options->max_distance;
     k1.out = ctx->d_m.as<int32_t>();
-    while (ctx->ev.size() < ev_used + 3) {
+    k1.order = ctx->d_order.as<uint32_t>();
+    k1.entries = nullptr;
+    k1.e_off = nullptr;
+    k1.e_cnt = nullptr;
+    while (ctx->ev.size() < ev_used + 5) {
       hipEvent_t e;
       HIPCHK(ctx, hipEventCreate(&e));
       ctx->ev.push_back(e);
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used], st));
-    launch_k1(k1, nd, max_rb, st);
+    launch_k1(k1, nc, max_rb, st);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 1], st));
-    launch_k1_resolve(k1, nd, max_rb, st);
+    launch_k1_resolve(k1, nc, max_rb, st);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 2], st));
-    ev_used += 3;
     if (max_rb) ctx->k1_launches++;
 
+    // one-way matches (i1, matches12[i1]) of every pair, compact and in ascending i1: without the cross-check they
+    // are the result (sift.cc:188-196), with it they are the entry list of pass 2
     K2Params k2;
     k2.pair_dir = ctx->d_pair_dir.as<uint4>();
     k2.d_out_off = ctx->d_doutoff.as<uint64_t>();
     k2.m = ctx->d_m.as<int32_t>();
-    k2.cross_check = cross ? 1 : 0;
-    k2.counts = ctx->d_counts.as<uint32_t>() + c0;
-    k2.offsets = ctx->d_offsets.as<uint64_t>() + c0;
+    k2.cross_check = 0;
     k2.matches = nullptr;
-    launch_k2(k2, nc, false, st);
-    HIPCHK(ctx, hipGetLastError());
-    launch_scan(ctx->d_counts.as<uint32_t>() + c0, ctx->d_offsets.as<uint64_t>() + c0, nc, ctx->d_total.as<uint64_t>(), st);
-    HIPCHK(ctx, hipGetLastError());
     uint64_t total = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&total, ctx->d_total.p, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    HIPCHK(ctx, ctx->d_matches.grow(std::max<uint64_t>(total, 1) * 8, ctx->total_matches * 8, st));
-    k2.matches = ctx->d_matches.as<uint32_t>();
-    launch_k2(k2, nc, true, st);
-    HIPCHK(ctx, hipGetLastError());
+    if (!cross) {
+      k2.counts = ctx->d_counts.as<uint32_t>() + c0;
+      k2.offsets = ctx->d_offsets.as<uint64_t>() + c0;
+      launch_k2(k2, nc, false, st);
+      HIPCHK(ctx, hipGetLastError());
+      launch_scan(ctx->d_counts.as<uint32_t>() + c0, ctx->d_offsets.as<uint64_t>() + c0, nc, ctx->d_total.as<uint64_t>(), st);
+      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipMemcpyAsync(&total, ctx->d_total.p, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      HIPCHK(ctx, ctx->d_matches.grow(std::max<uint64_t>(total, 1) * 8, ctx->total_matches * 8, st));
+      k2.matches = ctx->d_matches.as<uint32_t>();
+      launch_k2(k2, nc, true, st);
+      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 3], st));
+      HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 4], st));
+    } else {
+      HIPCHK(ctx, ctx->d_ecnt.reserve(std::max<uint32_t>(nc, 1) * 4));
+      HIPCHK(ctx, ctx->d_eoff.reserve(((size_t)nc + 1) * 8));
+      HIPCHK(ctx, ctx->d_etotal.reserve(8));
+      HIPCHK(ctx, hipMemsetAsync(ctx->d_etotal.p, 0, 8, st));
+      k2.counts = ctx->d_ecnt.as<uint32_t>();
+      k2.offsets = ctx->d_eoff.as<uint64_t>();
+      launch_k2(k2, nc, false, st);
+      HIPCHK(ctx, hipGetLastError());
+      launch_scan(ctx->d_ecnt.as<uint32_t>(), ctx->d_eoff.as<uint64_t>(), nc, ctx->d_etotal.as<uint64_t>(), st);
+      HIPCHK(ctx, hipGetLastError());
+      uint64_t etotal = 0;
+      HIPCHK(ctx, hipMemcpyAsync(&etotal, ctx->d_etotal.p, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      HIPCHK(ctx, ctx->d_entries.reserve(std::max<uint64_t>(etotal, 1) * 8));
+      HIPCHK(ctx, ctx->d_out2.reserve(std::max<uint64_t>(etotal, 1) * 4));
+      k2.matches = ctx->d_entries.as<uint32_t>();
+      launch_k2(k2, nc, true, st);
+      HIPCHK(ctx, hipGetLastError());
+      // Pass 2: FindBestMatchesOneWay(dists.transpose()) (sift.cc:175-176) for the rows matches12 points at
+      HIPCHK(ctx, ctx->d_dpairs2.reserve(std::max<uint32_t>(nc, 1) * sizeof(uint2)));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->d_dpairs2.p, dpairs2.data(), nc * sizeof(uint2), hipMemcpyHostToDevice, st));
+      K1Params g = k1;
+      g.dpairs = ctx->d_dpairs2.as<uint2>();
+      g.order = nullptr;  // list order: the column image a of consecutive pairs rarely changes in the lists the callers build
+      g.entries = ctx->d_entries.as<uint2>();
+      g.e_off = ctx->d_eoff.as<uint64_t>();
+      g.e_cnt = ctx->d_ecnt.as<uint32_t>();
+      g.out = ctx->d_out2.as<int32_t>();
+      HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 3], st));
+      if (etotal) {
+        launch_k1(g, nc, max_rb, st);  // a pair has at most rows(a) entries
+        HIPCHK(ctx, hipGetLastError());
+      }
+      HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 4], st));
+      if (etotal) {
+        launch_k1_resolve(g, nc, max_rb, st);
+        HIPCHK(ctx, hipGetLastError());
+      }
+      K2eParams ke;
+      ke.entries = g.entries;
+      ke.e_off = g.e_off;
+      ke.e_cnt = g.e_cnt;
+      ke.out2 = ctx->d_out2.as<int32_t>();
+      ke.counts = ctx->d_counts.as<uint32_t>() + c0;
+      ke.offsets = ctx->d_offsets.as<uint64_t>() + c0;
+      ke.matches = nullptr;
+      launch_k2_entries(ke, nc, false, st);
+      HIPCHK(ctx, hipGetLastError());
+      launch_scan(ctx->d_counts.as<uint32_t>() + c0, ctx->d_offsets.as<uint64_t>() + c0, nc, ctx->d_total.as<uint64_t>(), st);
+      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipMemcpyAsync(&total, ctx->d_total.p, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      HIPCHK(ctx, ctx->d_matches.grow(std::max<uint64_t>(total, 1) * 8, ctx->total_matches * 8, st));
+      ke.matches = ctx->d_matches.as<uint32_t>();
+      launch_k2_entries(ke, nc, true, st);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    ev_used += 5;
     ctx->total_matches = total;
     // the scratch of this chunk is reused by the next one
     HIPCHK(ctx, hipStreamSynchronize(st));
     c0 = c1;
   }
   HIPCHK(ctx, hipStreamSynchronize(st));
-  for (size_t k = 0; k + 2 < ev_used; k += 3) {
+  for (size_t k = 0; k + 4 < ev_used; k += 5) {
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[k], ctx->ev[k + 1]));
     ctx->k1_ms += ms;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[k + 1], ctx->ev[k + 2]));
     ctx->k1b_ms += ms;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[k + 3], ctx->ev[k + 4]));
+    ctx->k1g_ms += ms;
   }
   ctx->matched = true;
   return DSM_OK;
@@ -1248,6 +1314,13 @@ int dsm_get_match_kernel_time(dsm_ctx* ctx, double* total_ms, uint32_t* n_launch
   if (!ctx->matched) return fail(ctx, DSM_ERR_NOT_READY, "dsm_match_pairs has not run");
   if (total_ms) *total_ms = ctx->k1_ms;
   if (n_launches) *n_launches = ctx->k1_launches;
+  return DSM_OK;
+}
+
+int dsm_get_match_gather_time(dsm_ctx* ctx, double* total_ms) {
+  if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
+  if (!ctx->matched) return fail(ctx, DSM_ERR_NOT_READY, "dsm_match_pairs has not run");
+  if (total_ms) *total_ms = ctx->k1g_ms;
   return DSM_OK;
 }
 

@@ -19,6 +19,22 @@ struct K1Params {
   float max_ratio;
   float max_distance;
   int32_t* out;               // per row: matched column index or -1 (between K1 and K1b: the 32-column tile)
+  // gathered pass (pass 2 of the cross-check); entries == nullptr: plain pass over an image's rows
+  const uint32_t* order;      // optional: blockIdx.x -> directed pair (launch order, sorted by column image)
+  const uint2* entries;       // one-way matches (i1, i2) of all pairs; entry k of pair d = row i2 of image dpairs[d].x
+  const uint64_t* e_off;      // [n_pairs] first entry of every pair (also the pair's offset into `out`)
+  const uint32_t* e_cnt;      // [n_pairs] entries of every pair
+};
+
+// Cross-check on the gathered pass' result: keep entry (i1, i2) when out2 == i1.
+struct K2eParams {
+  const uint2* entries;
+  const uint64_t* e_off;
+  const uint32_t* e_cnt;
+  const int32_t* out2;        // per entry: matches21[i2] (column of image a) or -1
+  uint32_t* counts;           // [n_pairs] (count pass)
+  const uint64_t* offsets;    // [n_pairs] absolute offsets into matches (write pass)
+  uint32_t* matches;          // [total][2]
 };
 
 // K2: mutual check + ordered compaction, one workgroup per undirected pair.
@@ -138,6 +154,7 @@ void launch_k0(const uint8_t* in_u8, int8_t* out_s8, int32_t* rterm, uint64_t n_
 void launch_k1(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st);
 void launch_k1_resolve(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st);
 void launch_k2(const K2Params& p, uint32_t n_pairs, bool write, hipStream_t st);
+void launch_k2_entries(const K2eParams& p, uint32_t n_pairs, bool write, hipStream_t st);
 void launch_scan(const uint32_t* counts, uint64_t* offsets, uint32_t n, uint64_t* running_total, hipStream_t st);
 
 // EstimateMultiple (two_view_geometry.cc:128-167): per-pair bookkeeping across the passes

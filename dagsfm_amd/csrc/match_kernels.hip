@@ -12,8 +12,11 @@
 //                       per row fused in the epilogue (3 VALU per 2 elements: v_med3, v_max3,
 //                       v_max) plus the 32-column tile in which the best value was reached;
 //                       thresholds (acos LUT, ratio) applied before the single int32 store.
-//                       Cross-check uses the second directed pass (b rows vs a columns),
-//                       which is exactly FindBestMatchesOneWay(dists.transpose()).
+//                       Cross-check: FindBestMatches only ever reads matches21[matches12[i1]]
+//                       (sift.cc:178-186), so the second pass (GATHER) computes
+//                       FindBestMatchesOneWay(dists.transpose()) for exactly those rows of image b --
+//                       the one-way matches of pass 1, gathered through an entry list -- against
+//                       all columns of image a: ~N/14 rows instead of N at the benchmark shape.
 // K1b k1_resolve_index  for the rows that passed the thresholds only: the lowest column of that
 //                       tile that attains the best value (32 dot products per row, v_dot4).
 // K2  k2_cross_compact  mutual check + ordered compaction (ascending idx1) per pair.
@@ -135,14 +138,17 @@ __device__ __forceinline__ int lds_off(int col, int chunk) {
 
 // Workgroup = 4 waves x 128 rows of image a (4 resident 32-row fragments per wave); the columns of
 // image b stream through LDS in 64-column steps (double buffered) together with their bias terms.
+// GATHER: the rows are not an image's rows but the entries [e_off[d], e_off[d] + e_cnt[d]) of the entry list, entry
+// k standing for row entries[k].y of image ab.x (pass 2 of the cross-check); out is indexed like the entry list.
+template <bool GATHER>
 __global__ __launch_bounds__(256, 2) void k1_best_rows(const K1Params p) {
-  const uint32_t d = blockIdx.x;
+  const uint32_t d = p.order ? p.order[blockIdx.x] : blockIdx.x;
   const uint32_t rb = blockIdx.y;
   const uint2 ab = p.dpairs[d];
-  const uint32_t a_rows = p.img_rows[ab.x];
+  const uint32_t a_rows = GATHER ? p.e_cnt[d] : p.img_rows[ab.x];
   if (rb * 512u >= a_rows) return;
   const uint32_t b_cols = p.img_rows[ab.y];
-  const uint32_t a_row0 = p.img_row0[ab.x] + rb * 512u;
+  const uint32_t a_row0 = (GATHER ? 0u : p.img_row0[ab.x]) + rb * 512u;  // GATHER: first entry of this block
   const uint32_t b_row0 = p.img_row0[ab.y];
 
   const int tid = threadIdx.x;
@@ -159,18 +165,23 @@ __global__ __launch_bounds__(256, 2) void k1_best_rows(const K1Params p) {
   // Resident fragments of this wave's 128 rows (MFMA B operand: lane = row, 16 B of k per half).
   v4i afrag[4][4];
   int rterm_i[4];
+  bool valid[4];  // GATHER: this lane's row of fragment rt is an entry (the last fragments of a pair are ragged)
   {
-    const int8_t* arow = p.desc + (size_t)(a_row0 + wave * 128) * 128;
-    const int32_t* rt_a = p.rterm + a_row0 + wave * 128;
+    const uint2* ent = GATHER ? p.entries + p.e_off[d] : nullptr;
+    const uint32_t img0 = GATHER ? p.img_row0[ab.x] : 0u;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
+      const uint32_t r = a_row0 + wave * 128 + rt * 32 + l31;  // row of the image / entry of the pair
+      valid[rt] = GATHER ? (r < a_rows) : active;
+      uint32_t grow = r;
+      if (GATHER) grow = valid[rt] ? img0 + ent[r].y : 0u;
+      const int8_t* arow = p.desc + (size_t)grow * 128;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const v4i z = {0, 0, 0, 0};
-        afrag[rt][ks] =
-            active ? *reinterpret_cast<const v4i*>(arow + (rt * 32 + l31) * 128 + ks * 32 + half * 16) : z;
+        afrag[rt][ks] = valid[rt] ? *reinterpret_cast<const v4i*>(arow + ks * 32 + half * 16) : z;
       }
-      rterm_i[rt] = active ? rt_a[rt * 32 + l31] : 0;
+      rterm_i[rt] = valid[rt] ? p.rterm[grow] : 0;
     }
   }
   // dot == 0  <=>  v == -rterm(i): best_dist = second_best_dist = 0 initially (sift.cc:122-123)
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void k1_best_rows(const K1Params p) {
   }
 
   if (!active) return;
-  int32_t* out = p.out + p.d_out_off[d] + rb * 512u + wave * 128;
+  int32_t* out = p.out + (GATHER ? p.e_off[d] : p.d_out_off[d]) + rb * 512u + wave * 128;
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
     // the two halves of the wave hold disjoint columns of the same row
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void k1_best_rows(const K1Params p) {
         if (!(bn >= rhs)) res = T;  // sift.cc:153; K1b turns the tile into the column
       }
     }
-    if (half == (rt & 1)) out[rt * 32 + l31] = res;
+    if (half == (rt & 1) && valid[rt]) out[rt * 32 + l31] = res;
   }
 }
 
@@ -307,27 +318,32 @@ __global__ __launch_bounds__(256, 2) void k1_best_rows(const K1Params p) {
 // column of that tile with the largest dot product (= the row's best value, reached in this tile).
 // One workgroup per directed pair (the 32-column tiles it reads all belong to ONE image b, which stays
 // in L2); a wave takes 64 rows at a time and resolves its flagged rows one after the other.
+template <bool GATHER>
 __global__ __launch_bounds__(256) void k1_resolve_index(const K1Params p) {
   const uint32_t d = blockIdx.x;
   const uint2 ab = p.dpairs[d];
-  const uint32_t a_rows = p.img_rows[ab.x];
+  const uint32_t a_rows = GATHER ? p.e_cnt[d] : p.img_rows[ab.x];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const uint32_t b_row0 = p.img_row0[ab.y];
   const int8_t* bimg = p.desc + (size_t)b_row0 * 128;
   const int32_t* rt_b = p.rterm + b_row0;
+  const uint2* ent = GATHER ? p.entries + p.e_off[d] : nullptr;
   for (uint32_t row_w = wave * 64u; row_w < a_rows; row_w += 256u) {  // first row of this wave's chunk
-    int32_t* out = p.out + p.d_out_off[d] + row_w;
-    const int8_t* arow = p.desc + (size_t)(p.img_row0[ab.x] + row_w) * 128;
-    const int t = out[lane];
+    int32_t* out = p.out + (GATHER ? p.e_off[d] : p.d_out_off[d]) + row_w;
+    const int8_t* arow = p.desc + (size_t)(p.img_row0[ab.x] + (GATHER ? 0u : row_w)) * 128;
+    const bool in_range = !GATHER || row_w + (uint32_t)lane < a_rows;
+    const int t = in_range ? out[lane] : -1;
+    const uint32_t my_row = GATHER ? (in_range ? ent[row_w + lane].y : 0u) : (uint32_t)lane;  // row inside the image (relative to arow)
     unsigned long long mask = __ballot(t >= 0);
     while (mask) {
       const int r = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
       const int tile = __builtin_amdgcn_readlane(t, r);
+      const uint32_t rr = GATHER ? (uint32_t)__builtin_amdgcn_readlane((int)my_row, r) : (uint32_t)r;
       // the tile's 32 columns are 4 KB of contiguous memory: four fully coalesced 1-KB loads, lane =
       // (column i*8 + (lane>>3), 16-byte chunk lane&7) -- eight lanes share one dot product
-      const v4i x = *reinterpret_cast<const v4i*>(arow + (size_t)r * 128 + (lane & 7) * 16);
+      const v4i x = *reinterpret_cast<const v4i*>(arow + (size_t)rr * 128 + (lane & 7) * 16);
       const int8_t* tbase = bimg + (size_t)tile * 4096 + lane * 16;
       const int32_t* tterm = rt_b + tile * 32 + (lane >> 3);
       v4i y[4];
@@ -508,6 +524,46 @@ __global__ __launch_bounds__(256) void k2_cross_compact(const K2Params p) {
   if (!WRITE && tid == 0) p.counts[pi] = running;
 }
 
+// Cross-check after the gathered pass: entry k of pair pi is (i1, i2 = matches12[i1]); out2[k] = matches21[i2].
+// Keep it when matches21[i2] == i1 (sift.cc:183-186), in entry order = ascending i1.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k2_entries_compact(const K2eParams p) {
+  const uint32_t pi = blockIdx.x;
+  const uint32_t n = p.e_cnt[pi];
+  const uint2* ent = p.entries + p.e_off[pi];
+  const int32_t* m21 = p.out2 + p.e_off[pi];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  __shared__ uint32_t wsum[4];
+  uint32_t running = 0;
+  uint2* dst = nullptr;
+  if (WRITE) dst = reinterpret_cast<uint2*>(p.matches) + p.offsets[pi];
+  for (uint32_t base = 0; base < n; base += 256) {
+    const uint32_t k = base + tid;
+    uint2 e = make_uint2(0, 0);
+    bool ok = false;
+    if (k < n) {
+      e = ent[k];
+      ok = m21[k] == (int32_t)e.x;
+    }
+    const unsigned long long bal = __ballot(ok);
+    const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t c = wsum[w];
+      if (w < wave) wbase += c;
+      total += c;
+    }
+    if (WRITE && ok) dst[running + wbase + before] = e;
+    running += total;
+    __syncthreads();
+  }
+  if (!WRITE && tid == 0) p.counts[pi] = running;
+}
+
 // Single-workgroup exclusive scan of per-pair counts into 64-bit offsets:
 // offsets[i] = base + sum_{k<i} counts[k], offsets[n] = total; *running_total updated.
 __global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* __restrict__ counts,
@@ -557,11 +613,24 @@ void launch_k0(const uint8_t* in_u8, int8_t* out_s8, int32_t* rterm, uint64_t n_
 // max_row_blocks = largest padded row count of an `a` image / 256
 void launch_k1(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st) {
   if (n_directed == 0 || max_row_blocks == 0) return;
-  hipLaunchKernelGGL(k1_best_rows, dim3(n_directed, (max_row_blocks + 1) / 2), dim3(256), 0, st, p);
+  if (p.entries)
+    hipLaunchKernelGGL(k1_best_rows<true>, dim3(n_directed, (max_row_blocks + 1) / 2), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(k1_best_rows<false>, dim3(n_directed, (max_row_blocks + 1) / 2), dim3(256), 0, st, p);
 }
 void launch_k1_resolve(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st) {
   if (n_directed == 0 || max_row_blocks == 0) return;
-  hipLaunchKernelGGL(k1_resolve_index, dim3(n_directed), dim3(256), 0, st, p);
+  if (p.entries)
+    hipLaunchKernelGGL(k1_resolve_index<true>, dim3(n_directed), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(k1_resolve_index<false>, dim3(n_directed), dim3(256), 0, st, p);
+}
+void launch_k2_entries(const K2eParams& p, uint32_t n_pairs, bool write, hipStream_t st) {
+  if (n_pairs == 0) return;
+  if (write)
+    hipLaunchKernelGGL(k2_entries_compact<true>, dim3(n_pairs), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(k2_entries_compact<false>, dim3(n_pairs), dim3(256), 0, st, p);
 }
 
 void launch_kg(const KgParams& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st) {

@@ -47,3 +47,108 @@ def assemble_ragged(sizes, gathered):
     import torch
     mx = gathered.shape[0] // len(sizes)
     return torch.cat([gathered[r * mx:r * mx + int(sizes[r])] for r in range(len(sizes))], dim=0)
+
+
+class MatchGraph:
+    """The assembled result of a pair list: what SiftFeatureMatcher::Match leaves in `matches` +
+    `two_view_geometries` (/root/reference/src/feature/matching.cc:814-836), for ALL pairs in list order."""
+
+    def __init__(self, match_counts, matches, tvg=None, inlier_counts=None, inlier_matches=None):
+        self.match_counts = match_counts      # [P] int64
+        self.matches = matches                # [sum, 2] int32
+        self.tvg = tvg                        # [P, record bytes] uint8 or None (matching only)
+        self.inlier_counts = inlier_counts    # [P] int64 or None
+        self.inlier_matches = inlier_matches  # [sum, 2] int32 or None
+
+
+def gather_match_graph(dist, source, rank, world_size, bounds, verify):
+    """Assembles the match graph of the whole pair list on every rank from the per-rank shards.
+
+    `source` is this rank's result holder (bench.py / the CLI wrap a dsm_ctx in it; the CPU test uses a stub) with
+      match_offsets() -> [n+1] int64        matches(total) -> [total, 2] int32
+      two_view_geometries() -> [n, K] uint8
+      inlier_offsets() -> [n+1] int64       inlier_matches(total) -> [total, 2] int32
+    all torch tensors on the device the process group communicates from.  Fixed-size per-pair records (counts,
+    TwoViewGeometry) go through one max-padded all-gather; the variable-length arrays through the two-phase
+    (sizes, then payload) all-gather.  With world_size 1 nothing is communicated.  `bounds` = shard_bounds()."""
+    import torch
+    n_mine = int(bounds[rank + 1] - bounds[rank])
+    maxp = int(np.diff(bounds).max()) if world_size > 0 else n_mine
+
+    def counts_of(offs):
+        return (offs[1:] - offs[:-1]).reshape(-1, 1)
+
+    def gather_counts(offs):
+        c = counts_of(offs)
+        if world_size == 1:
+            return c.reshape(-1)
+        allc = all_gather_fixed(dist, c, maxp, world_size)
+        return torch.cat([allc[r * maxp:r * maxp + int(bounds[r + 1] - bounds[r])] for r in range(world_size)]).reshape(-1)
+
+    def gather_rows(rows):
+        if world_size == 1:
+            return rows
+        sizes, allr = all_gather_ragged(dist, rows, world_size)
+        return assemble_ragged(sizes, allr)
+
+    offs = source.match_offsets()
+    assert offs.shape[0] == n_mine + 1
+    g = MatchGraph(gather_counts(offs), gather_rows(source.matches(int(offs[-1].item()))))
+    if verify:
+        tv = source.two_view_geometries()
+        if world_size > 1:
+            allt = all_gather_fixed(dist, tv, maxp, world_size)
+            tv = torch.cat([allt[r * maxp:r * maxp + int(bounds[r + 1] - bounds[r])] for r in range(world_size)])
+        g.tvg = tv
+        ioffs = source.inlier_offsets()
+        g.inlier_counts = gather_counts(ioffs)
+        g.inlier_matches = gather_rows(source.inlier_matches(int(ioffs[-1].item())))
+    return g
+
+
+class CtxSource:
+    """gather_match_graph source over a dsm_ctx: results are fetched device-to-device into torch tensors
+    (the C-ABI getters accept device pointers), so nothing crosses PCIe on the way into RCCL."""
+
+    def __init__(self, ctx, n_pairs, device):
+        import ctypes
+        from . import capi
+        self.ctx, self.n, self.dev = ctx, n_pairs, device
+        self.L = capi.lib()
+        self.tvg_bytes = ctypes.sizeof(capi.TwoViewGeometry)
+
+    def _chk(self, rc):
+        self.ctx._chk(rc)
+
+    def match_offsets(self):
+        import torch
+        o = torch.empty(self.n + 1, dtype=torch.int64, device=self.dev)
+        self._chk(self.L.dsm_get_matches(self.ctx._h, o.data_ptr(), None, 0))
+        return o
+
+    def matches(self, total):
+        import torch
+        m = torch.empty((total, 2), dtype=torch.int32, device=self.dev)
+        if total:
+            self._chk(self.L.dsm_get_matches(self.ctx._h, None, m.data_ptr(), total))
+        return m
+
+    def two_view_geometries(self):
+        import torch
+        t = torch.empty((self.n, self.tvg_bytes), dtype=torch.uint8, device=self.dev)
+        if self.n:
+            self._chk(self.L.dsm_get_two_view_geometries(self.ctx._h, t.data_ptr()))
+        return t
+
+    def inlier_offsets(self):
+        import torch
+        o = torch.empty(self.n + 1, dtype=torch.int64, device=self.dev)
+        self._chk(self.L.dsm_get_inlier_matches(self.ctx._h, o.data_ptr(), None, 0))
+        return o
+
+    def inlier_matches(self, total):
+        import torch
+        m = torch.empty((total, 2), dtype=torch.int32, device=self.dev)
+        if total:
+            self._chk(self.L.dsm_get_inlier_matches(self.ctx._h, None, m.data_ptr(), total))
+        return m

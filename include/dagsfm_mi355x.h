@@ -183,6 +183,8 @@ int dsm_get_match_kernel_time(dsm_ctx* ctx, double* total_ms, uint32_t* n_launch
 /* Same for the small follow-up kernel that turns the best tile of every accepted row into
  * the exact column index (k1_resolve_index). */
 int dsm_get_match_resolve_time(dsm_ctx* ctx, double* total_ms);
+/* Same for the gathered second pass of the cross-check (k1_best_rows over the rows matches12 points at). */
+int dsm_get_match_gather_time(dsm_ctx* ctx, double* total_ms);
 
 /* ------------------------------------------------------------------ verification */
 

@@ -125,10 +125,19 @@ VERIFY_CAMERAS = [
 @pytest.mark.parametrize("model_id,params", VERIFY_CAMERAS)
 def test_verified_pair_per_camera_model(dsm, oracle, model_id, params):
     """One calibrated pair per model (keypoints projected through the model's own WorldToImage, so the E path
-    really depends on the undistortion) + a mixed pair (this model vs SIMPLE_PINHOLE).  The trigonometric models are
-    compared with the same bit-exact bar: an ulp of ocml-vs-glibc difference in the normalised points has never moved
-    a decision in these cases (it could in principle; DESIGN.md lists it as the one libm dependency of the path)."""
-    from tests.test_verify_gpu import tvg_equal
+    really depends on the undistortion) + a mixed pair (this model vs SIMPLE_PINHOLE).  Models 0-4 and 6 are held to
+    the bit-exact bar.  For the trigonometric models an ulp of ocml-vs-glibc difference in the normalised points
+    reaches the last bits of E: decisions (config, inlier set, trial and model counts) must still be identical,
+    the matrices agree to 1e-6 relative, the north_star tolerance for camera parameters (DESIGN.md lists this as the one libm dependency of the path)."""
+    from tests.test_verify_gpu import tvg_equal as tvg_exact
+
+    def tvg_equal(g, r, tag):
+        if model_id in EXACT_MODELS:
+            return tvg_exact(g, r, tag)
+        assert (g.config, g.num_inliers, g.num_matches) == (r.config, r.num_inliers, r.num_matches), tag
+        assert list(g.num_trials) == list(r.num_trials) and list(g.num_models) == list(r.num_models), tag
+        for name in ("E", "F", "H", "qvec", "tvec"):
+            assert np.allclose(np.array(getattr(g, name)), np.array(getattr(r, name)), rtol=1e-6, atol=1e-9), (tag, name)
     scene = synthetic.Scene(3, 1024, seed=60 + model_id, camera=(model_id, params))
     ims = [scene.image(i) for i in range(3)]
     cam = capi.camera(model_id, params, 1000, 750, True)

@@ -74,3 +74,78 @@ def test_shard_bounds_cover_uneven():
         for w in (1, 2, 4, 8):
             b = sharding.shard_bounds(n, w)
             assert b[0] == 0 and b[-1] == n and (np.diff(b) >= 0).all() and np.diff(b).max() - np.diff(b).min() <= 1
+
+
+# ---- the real assembly code (sharding.gather_match_graph, the function bench.py times) over a stub result holder
+
+class _StubSource:
+    """Stands in for a dsm_ctx: serves the results of this rank's shard as CPU tensors.  The per-pair results are a
+    deterministic function of the pair, so that any rank layout must assemble to the same graph."""
+
+    def __init__(self, pairs, verify):
+        self.pairs = pairs
+        c, self.rows = _fake_results(pairs)
+        self.offs = np.concatenate([[0], np.cumsum(c)]).astype(np.int64)
+        ic = (c // 2).astype(np.int64)
+        self.ioffs = np.concatenate([[0], np.cumsum(ic)]).astype(np.int64)
+        self.irows = np.concatenate([self.rows[self.offs[k]:self.offs[k] + ic[k]] for k in range(len(pairs))] or
+                                    [np.zeros((0, 2), np.int32)]).astype(np.int32).reshape(-1, 2)
+        rec = np.zeros((len(pairs), 328), dtype=np.uint8)  # sizeof(dsm_two_view_geometry)
+        rec[:, 0] = (pairs[:, 0] + pairs[:, 1]) % 9
+        rec[:, 4] = ic % 256
+        rec[:, 327] = pairs[:, 1] % 251
+        self.rec = rec
+
+    def match_offsets(self):
+        return torch.from_numpy(self.offs)
+
+    def matches(self, total):
+        assert total == len(self.rows)
+        return torch.from_numpy(self.rows)
+
+    def two_view_geometries(self):
+        return torch.from_numpy(self.rec)
+
+    def inlier_offsets(self):
+        return torch.from_numpy(self.ioffs)
+
+    def inlier_matches(self, total):
+        assert total == len(self.irows)
+        return torch.from_numpy(self.irows)
+
+
+def _graph_to_numpy(g):
+    return [None if t is None else t.numpy().copy() for t in (g.match_counts, g.matches, g.tvg, g.inlier_counts, g.inlier_matches)]
+
+
+def _graph_worker(rank, world, port, n_images, q):
+    from dagsfm_amd import sharding, synthetic
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    pairs = synthetic.exhaustive_pairs(n_images).astype(np.int64)
+    bounds = sharding.shard_bounds(len(pairs), world)
+    src = _StubSource(sharding.shard(pairs, rank, world), True)
+    g = sharding.gather_match_graph(dist, src, rank, world, bounds, True)
+    q.put((rank, _graph_to_numpy(g)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_match_graph_two_ranks_equals_single_process():
+    from dagsfm_amd import sharding, synthetic
+    for n_images in (9, 4):  # 36 pairs (even split) and 6 pairs
+        pairs = synthetic.exhaustive_pairs(n_images).astype(np.int64)
+        ref = _graph_to_numpy(sharding.gather_match_graph(None, _StubSource(pairs, True), 0, 1, sharding.shard_bounds(len(pairs), 1), True))
+        assert ref[0].sum() == len(ref[1]) and ref[3].sum() == len(ref[4]) and ref[2].shape == (len(pairs), 328)
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_graph_worker, args=(r, 2, port, n_images, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=120) for _ in range(2)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        for rank, got in res:
+            for a, b in zip(got, ref):
+                assert a.shape == b.shape and (a == b).all(), rank
