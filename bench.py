@@ -1,22 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json metric on MI355X: verified image-pairs/s at 4 096 feats/image.
+"""bench.py -- BASELINE.json metric on MI355X: verified image-pairs/s (+ RANSAC hypotheses/s) at 4 096 feats/image.
 
-One "step" = one pass of the hot path (brute-force matching + two-view verification) over the
-whole exhaustive pair list of the workload (BASELINE.json configs[1]: 500 images x 4 096
-features => 124 750 pairs), inputs already resident in HBM.  With N GPUs the pair list is
-block-partitioned over the ranks (strong scaling), every rank runs the same kernels on its
-share, and the per-pair results are all-gathered with RCCL so that every rank holds the full
-match graph.
+One "step" = one pass of the hot path (brute-force matching + two-view verification + assembly of the match
+graph) over the whole pair list of the workload, inputs already resident in HBM.  Default workload = BASELINE.json
+configs[1]: 500 images x 4 096 features, exhaustive => 124 750 pairs, calibrated (E + F + H + relative pose).
+With N GPUs the pair list is block-partitioned over the ranks (strong scaling: the workload is fixed), every rank
+runs the same kernels on its share, and the per-pair results are all-gathered with RCCL so that every rank holds
+the full match graph (dagsfm_amd/sharding.py).
 
-  python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W          # N > 1: re-launches itself under torch.distributed.run
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (see README / DESIGN.md "Measurement").
+Other workloads of BASELINE.json (parity-test / profile cases, not the default line):
+  --images 50 --feats 1024 --uncalibrated                          configs[0] shape on the GPU
+  --images 2000 --no-verify                                         configs[2]
+  --images 10000 --pairs knn:200 --shard-of 8                       configs[3], one GPU's shard of the 8
+  --images 10000 --feats 8192 --pairs knn:200 --fixed-trials 4096 --shard-of 8 --max-pairs N    configs[4], shard
+
+Rank 0 prints ONE JSON line (README / DESIGN.md "Measurement").
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,7 +33,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-INT8_MFMA_DENSE_PEAK = 5.0e15  # ops/s, MI355X dense (MI355X_MICROARCH.md: ~5 PF dense 8-bit; 4.40 P measured)
+# Sanity bounds from /opt/skills/guides/MI355X_MICROARCH.md (the peaks themselves are derived from hipDeviceProp).
+GUIDE_INT8_DENSE = 5.0e15   # ops/s: "I8 ~2x bf16 rate", bf16 dense ~2.5 PF
+GUIDE_FP64_VECTOR = 78.6e12
+GUIDE_HBM = 8.0e12
 
 
 def parse_args():
@@ -36,30 +47,76 @@ def parse_args():
     ap.add_argument("--images", type=int, default=500)
     ap.add_argument("--feats", type=int, default=4096)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--no-verify", action="store_true", help="matching only (BASELINE config 3 style)")
+    ap.add_argument("--pairs", default="exhaustive", help="exhaustive | knn:K (K pseudo-neighbours per image from a seeded "
+                                                          "kNN over the camera centres, id1<id2 dedupe; SURVEY 8d config 4)")
+    ap.add_argument("--shard-of", type=int, default=1, help="run only the first 1/S of the pair list: one GPU's shard of an S-GPU config")
+    ap.add_argument("--max-pairs", type=int, default=0, help="truncate the (sharded) pair list (bounded runs of the big configs)")
+    ap.add_argument("--fixed-trials", type=int, default=0,
+                    help="T > 0: min_num_trials = max_num_trials = T, confidence 0.999999, min_inlier_ratio 0.01 -- exactly T "
+                         "trials per family and pair (SURVEY 8d config 5)")
+    ap.add_argument("--no-verify", action="store_true", help="matching only (BASELINE configs[2])")
     ap.add_argument("--uncalibrated", action="store_true",
                     help="cameras without focal prior: F + H path (EstimateUncalibrated) instead of E + F + H + pose")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU-baseline samples (0 = skip)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="debug: all ranks on device 0 over gloo (exercises the multi-rank path on a 1-GPU box)")
     return ap.parse_args()
 
 
-def cpu_baseline(scene_images, pairs, budget_s, verify, cams=None, opts=None, user_seed=0):
-    """Times the CPU oracle (the reference algorithm restated, oracle/) on a bounded sample of the same
-    workload: worker threads pull evenly spaced pairs of the list until `budget_s` seconds have passed,
-    one thread per usable host core like the reference's matcher/verifier thread pools
-    (/root/reference/src/feature/matching.cc:640-674)."""
-    import threading
-    from tests import oracle_lib
-    from dagsfm_amd import capi
-    orc = oracle_lib.load()
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def relaunch_multi_rank(args):
+    """`python bench.py --gpus N` without a launcher: become the launcher (one process per GPU, RCCL)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def host_cores():
     try:
-        cores = len(os.sched_getaffinity(0))
+        return len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    # each worker holds an N1 x N2 int32 distance matrix (64 MiB at 4096 features) like the reference does;
-    # beyond ~64 threads the host's memory system, not its cores, limits this path
-    cores = min(cores, 64)
-    kps = [im[1].astype(np.float64) for im in scene_images]
+        return os.cpu_count() or 1
+
+
+def knn_pairs(scene, n_images, k, seed):
+    """Candidate-pair graph standing in for the vocabulary-tree retrieval of configs[3]: the K
+    nearest images of every image by camera-centre distance (seeded scene => deterministic), deduplicated to id1 < id2
+    and sorted -- the order VocabTreeFeatureMatcher hands its pairs to Match() in (by query image)."""
+    centres = np.empty((n_images, 3))
+    for i in range(n_images):
+        R, t = scene.pose(i)
+        centres[i] = -R.T @ t
+    k = min(k, n_images - 1)
+    pairs = set()
+    blk = 1024
+    for s in range(0, n_images, blk):
+        d = ((centres[s:s + blk, None, :] - centres[None, :, :]) ** 2).sum(-1)
+        d[np.arange(d.shape[0]), np.arange(s, s + d.shape[0])] = np.inf
+        nn = np.argpartition(d, k - 1, axis=1)[:, :k]
+        for r in range(nn.shape[0]):
+            i = s + r
+            for j in nn[r]:
+                pairs.add((min(i, int(j)), max(i, int(j))))
+    out = np.array(sorted(pairs), dtype=np.uint32).reshape(-1, 2)
+    return out
+
+
+def cpu_baseline(orc, label, build, scene_images, pairs, budget_s, verify, cams, opts, user_seed, cores):
+    """Times a CPU oracle build (the reference algorithm restated, oracle/) on a bounded sample of the same
+    workload: worker threads pull evenly spaced pairs of the list until `budget_s` seconds have passed, one thread
+    per host core like the reference's matcher/verifier thread pools (/root/reference/src/feature/matching.cc:640-674)."""
+    import threading
+    from dagsfm_amd import capi
+    kps = [None if im is None else im[1].astype(np.float64) for im in scene_images]
     order = np.linspace(0, len(pairs) - 1, min(len(pairs), 65536)).astype(np.int64)
     lock = threading.Lock()
     state = {"next": 0, "pairs": 0, "models": 0}
@@ -89,15 +146,17 @@ def cpu_baseline(scene_images, pairs, budget_s, verify, cams=None, opts=None, us
     for t in threads:
         t.join()
     dt = time.perf_counter() - t0
-    return {"value": state["pairs"] / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+    return {"value": state["pairs"] / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "build": build,
             "hypotheses_per_s": state["models"] / dt,
-            "sample": "%d of %d pairs (%s) in %.1f s on %d threads; oracle/ = the reference CPU path restated "
-                      "(MatchSiftFeaturesCPU + TwoViewGeometry::Estimate), built -O3 without -march (CMake Release, like the reference)"
-                      % (state["pairs"], len(pairs), "match only" if not verify else "match + verify", dt, cores)}
+            "sample": "%d of %d pairs (%s) in %.1f s on %d threads (host has %d usable cores); oracle/ = the reference CPU "
+                      "path restated (MatchSiftFeaturesCPU + TwoViewGeometry::Estimate), %s"
+                      % (state["pairs"], len(pairs), "match only" if not verify else "match + verify", dt, cores, host_cores(), label)}
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_multi_rank(args)
     import torch
     import torch.distributed as dist
     from dagsfm_amd import capi, sharding, synthetic
@@ -105,117 +164,157 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = 0 if args.oversubscribe else local_rank
+    if dev_index >= n_dev:
+        raise SystemExit("bench.py: rank %d wants GPU %d but only %d are visible" % (rank, dev_index, n_dev))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    comm_dev = dev
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.oversubscribe:  # several ranks on one GPU: RCCL refuses that, gloo moves host copies
+            dist.init_process_group("gloo")
+            comm_dev = torch.device("cpu")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == world
 
     verify = not args.no_verify
     calibrated = not args.uncalibrated
     scene = synthetic.Scene(args.images, args.feats, seed=args.seed)
-    images = [scene.image(i) for i in range(args.images)]
-    pairs = synthetic.exhaustive_pairs(args.images)
-    # strong scaling: contiguous block of the pair list per rank
+    if args.pairs == "exhaustive":
+        pairs = synthetic.exhaustive_pairs(args.images)
+        pairs_desc = "exhaustive"
+    elif args.pairs.startswith("knn:"):
+        pairs = knn_pairs(scene, args.images, int(args.pairs[4:]), args.seed)
+        pairs_desc = "kNN candidate graph, %s neighbours/image, id1<id2" % args.pairs[4:]
+    else:
+        raise SystemExit("--pairs must be exhaustive or knn:K")
+    n_full = len(pairs)
+    if args.shard_of > 1:
+        pairs = sharding.shard(pairs, 0, args.shard_of)
+    if args.max_pairs and len(pairs) > args.max_pairs:
+        pairs = pairs[:args.max_pairs]
+    # only the images the (sharded / truncated) list touches are generated and made resident
+    used = np.unique(pairs) if (args.shard_of > 1 or args.max_pairs) else np.arange(args.images)
+    remap = np.full(args.images, -1, dtype=np.int64)
+    remap[used] = np.arange(len(used))
+    images = [scene.image(int(i)) for i in used]
+    pairs = remap[pairs.astype(np.int64)].astype(np.uint32)
     bounds = sharding.shard_bounds(len(pairs), world)
     my_pairs = sharding.shard(pairs, rank, world)
 
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(dev_index)
+    info = ctx.device_info()
     cams = [capi.simple_pinhole(scene.focal, scene.width / 2.0, scene.height / 2.0, scene.width, scene.height, calibrated)
-            for _ in range(args.images)]
+            for _ in range(len(images))]
     ctx.set_images([im[0] for im in images], [im[1] for im in images], cams)
     opts = capi.default_match_options()
     topts = capi.default_two_view_options()
+    if args.fixed_trials:
+        topts = capi.default_two_view_options(min_num_trials=args.fixed_trials, max_num_trials=args.fixed_trials,
+                                              confidence=0.999999, min_inlier_ratio=0.01)
     user_seed = 0
-    TVG_BYTES = ctypes.sizeof(capi.TwoViewGeometry)
+    source = sharding.CtxSource(ctx, len(my_pairs), dev)
+    if comm_dev.type == "cpu":
+        class HostSource:  # gloo debug path: the same fetches, staged through the host
+            def __getattr__(self, name):
+                f = getattr(source, name)
+                return lambda *a: f(*a).cpu()
+        gsource = HostSource()
+    else:
+        gsource = source
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def gather_var(fetch, total):
-        """All-gather of a variable-length [total, 2] int32 array produced by `fetch(ptr, capacity)`."""
-        if world == 1:
-            return total
-        mine = torch.zeros((max(total, 1), 2), dtype=torch.int32, device=dev)
-        if total:
-            fetch(mine.data_ptr(), total)
-        sizes, _ = sharding.all_gather_ragged(dist, mine[:total], world)
-        return int(sizes.sum())
-
-    def gather_results():
-        """All-gather of the per-pair match graph over RCCL: matches and, when verifying, the
-        TwoViewGeometry records + inlier matches."""
-        L = capi.lib()
-        offs = torch.empty(len(my_pairs) + 1, dtype=torch.int64, device=dev)
-        L.dsm_get_matches(ctx._h, offs.data_ptr(), None, 0)
-        total = int(offs[-1].item())
-        n_matches = gather_var(lambda ptr, cap: L.dsm_get_matches(ctx._h, None, ptr, cap), total)
-        n_inl, n_models, n_ok, score_flops = 0, 0, 0, 0.0
-        if verify:
-            maxp = int(np.diff(bounds).max())
-            tv = torch.zeros((len(my_pairs), TVG_BYTES), dtype=torch.uint8, device=dev)
-            L.dsm_get_two_view_geometries(ctx._h, tv.data_ptr())
-            rec = sharding.all_gather_fixed(dist, tv, maxp, world) if world > 1 else tv
-            head = rec[:, :16].contiguous().view(torch.int32)              # config, num_inliers, num_matches, reserved
-            tail = rec[:, TVG_BYTES - 16:].contiguous().view(torch.int32)  # num_models[4]
-            n_ok = int((head[:, 0] > 1).sum().item())
-            n_models = int(tail.sum().item())
-            # algorithmic FP64 flops of the inlier scoring (SURVEY.md 8d): per (model, correspondence)
-            # 33 Sampson (E, F), 20 transfer (H), 5 translation (watermark)
-            w = torch.tensor([33.0, 33.0, 20.0, 5.0], dtype=torch.float64, device=dev)
-            score_flops = float((tail.to(torch.float64) @ w * head[:, 2].to(torch.float64)).sum().item())
-            ioffs = torch.empty(len(my_pairs) + 1, dtype=torch.int64, device=dev)
-            L.dsm_get_inlier_matches(ctx._h, ioffs.data_ptr(), None, 0)
-            itotal = int(ioffs[-1].item())
-            n_inl = gather_var(lambda ptr, cap: L.dsm_get_inlier_matches(ctx._h, None, ptr, cap), itotal)
-        return dict(matches=n_matches, inliers=n_inl, models=n_models, verified=n_ok, score_flops=score_flops)
-
     def step():
         ctx.match_pairs(my_pairs, opts)
         if verify:
             ctx.verify_pairs(topts, user_seed=user_seed, stage_filter=True)
-        return gather_results()
+        return sharding.gather_match_graph(dist, gsource, rank, world, bounds, verify)
 
     for _ in range(args.warmup):
         step()
-    k1_ms, k1_launches, kv_ms, k1b_ms = 0.0, 0, 0.0, 0.0
+    k1_ms, k1_launches, kv_ms, k1b_ms, k1g_ms = 0.0, 0, 0.0, 0.0, 0.0
+    graph = None
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step()
-        ms, nl = ctx.match_kernel_time()
+        graph = step()
+        ms, nl = ctx.match_kernel_time()  # host-side reads of HIP-event times already taken inside the library
         k1_ms += ms
         k1_launches += nl
         k1b_ms += ctx.match_resolve_time()
+        k1g_ms += ctx.match_gather_time()
         if verify:
             kv_ms += ctx.verify_kernel_time()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # ---- statistics of the assembled graph (outside the timed region)
+    n_pairs = len(pairs)
+    assert graph.match_counts.shape[0] == n_pairs, "the assembled match graph must cover the whole pair list"
+    res = dict(matches=int(graph.matches.shape[0]), inliers=0, models=0, verified=0, score_flops=0.0)
+    if verify:
+        tvb = ctypes.sizeof(capi.TwoViewGeometry)
+        rec = graph.tvg
+        head = rec[:, :16].contiguous().view(torch.int32)           # config, num_inliers, num_matches, reserved
+        tail = rec[:, tvb - 16:].contiguous().view(torch.int32)     # num_models[4]
+        res["verified"] = int((head[:, 0] > 1).sum().item())
+        res["models"] = int(tail.sum().item())
+        # algorithmic FP64 flops of the inlier scoring: per (model, correspondence) 33 Sampson (E, F),
+        # 20 transfer (H), 5 translation (watermark)
+        w = torch.tensor([33.0, 33.0, 20.0, 5.0], dtype=torch.float64, device=rec.device)
+        res["score_flops"] = float(((tail.to(torch.float64) * w).sum(dim=1) * head[:, 2].to(torch.float64)).sum().item())
+        res["inliers"] = int(graph.inlier_matches.shape[0])
+
     if rank == 0:
-        n_pairs = len(pairs)
         ms_per_step = 1e3 * dt / args.steps
         value = n_pairs * args.steps / dt
-        # roofline of the dominant kernel (k1_best_rows) on this rank:
+        # ---- peaks from what the device reports (hipDeviceProp_t), the guide's figures as a sanity bound
+        cus, clk = info.compute_units, info.clock_khz * 1e3
+        int8_peak = cus * clk * 4 * 2048.0   # per CU and clock: 4 SIMDs x (32x32x32 i8 MFMA = 65 536 ops / 32 cycles)
+        fp64_peak = cus * clk * 4 * 32.0     # 4 SIMD-32 x 16 lanes-equivalent of f64 FMA x 2 flops = 128 flop/clk/CU
+        hbm_peak = info.memory_clock_khz * 1e3 * 2.0 * info.memory_bus_bits / 8.0
+        peaks_note = "from hipDeviceProp: %d CUs x %.0f MHz; HBM %d-bit x %.0f MHz DDR" % (
+            cus, clk / 1e6, info.memory_bus_bits, info.memory_clock_khz / 1e3)
+        if not (0.5 * GUIDE_INT8_DENSE <= int8_peak <= 1.2 * GUIDE_INT8_DENSE):
+            peaks_note += "; derived int8 peak %.3g outside the guide's range -> guide value used" % int8_peak
+            int8_peak, fp64_peak = GUIDE_INT8_DENSE, GUIDE_FP64_VECTOR
+        if not (0.5 * GUIDE_HBM <= hbm_peak <= 1.2 * GUIDE_HBM):
+            hbm_peak = GUIDE_HBM
+        # ---- roofline of the dominant kernel (k1_best_rows, both passes) on this rank:
         # algorithmic ops = 2*128*N1*N2 per pair (SURVEY.md 8d) x pairs per launch
         ops_per_pair = 2.0 * 128.0 * args.feats * args.feats
-        avg_launch_s = 1e-3 * k1_ms / max(k1_launches, 1)
-        pairs_per_launch = len(my_pairs) * args.steps / max(k1_launches, 1)
-        achieved = ops_per_pair * pairs_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0
+        launches = max(k1_launches, 1)
+        pass1_s = 1e-3 * k1_ms / launches
+        pass2_s = 1e-3 * k1g_ms / launches
+        pairs_per_launch = len(my_pairs) * args.steps / launches
+        achieved = ops_per_pair * pairs_per_launch / (pass1_s + pass2_s) if pass1_s > 0 else 0.0
         traffic = None
         try:  # HBM bytes per K1 launch from the committed PMC collection (tools/collect_pmc.py), same workload only
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_k1_pmc.json")))
-            if pmc.get("images") == args.images and pmc.get("feats") == args.feats and world == 1:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_k1_pmc.json")))
+            if pmc.get("images") == args.images and pmc.get("feats") == args.feats and pmc.get("pairs") == n_pairs and world == 1:
                 traffic = pmc.get("k1_traffic_bytes_per_launch")
         except Exception:
             traffic = None
+        fam = ("calibrated: E+F+H + relative pose" if calibrated else "uncalibrated: F+H")
+        if args.fixed_trials:
+            fam += ", fixed %d trials/family" % args.fixed_trials
+        shard_note = ""
+        if args.shard_of > 1 or args.max_pairs:
+            shard_note = " [shard 1/%d of %d pairs%s]" % (args.shard_of, n_full, ", truncated" if args.max_pairs else "")
         out = {
             "metric": ("verified image-pairs/sec (+ RANSAC hypotheses/sec) at %d feats/image" % args.feats) if verify else
                       "matched image-pairs/sec at %d feats/image (matching only, --no-verify)" % args.feats,
@@ -223,39 +322,54 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8 (int8 MFMA, int32 accumulate)" if not verify else "u8 matching (int8 MFMA) + f64 verification",
             "data": "synthetic",
-            "config": {"workload": "%d images x %d feats exhaustive (%d pairs), %s" % (
-                args.images, args.feats, n_pairs,
-                ("match + two-view LO-RANSAC (%s)" % ("calibrated: E+F+H + relative pose" if calibrated else "uncalibrated: F+H"))
-                if verify else "match only"),
-                "pairs": n_pairs, "total_matches": res["matches"], "total_inlier_matches": res["inliers"],
-                "pairs_with_geometry": res["verified"], "hypotheses_per_step": res["models"],
-                "parallelism": "pair-sharded x%d + RCCL all-gather" % world},
+            "config": {"workload": "%d images x %d feats, %s (%d pairs)%s, %s" % (
+                args.images, args.feats, pairs_desc, n_pairs, shard_note,
+                ("match + two-view LO-RANSAC (%s)" % fam) if verify else "match only"),
+                "pairs": n_pairs, "images_resident": len(images), "total_matches": res["matches"],
+                "total_inlier_matches": res["inliers"], "pairs_with_geometry": res["verified"],
+                "hypotheses_per_step": res["models"],
+                "parallelism": "pair-sharded x%d + %s all-gather of the match graph" % (world, "gloo (debug, oversubscribed)" if args.oversubscribe else "RCCL")},
             "hypotheses_per_s": res["models"] * args.steps / dt if verify else None,
-            "kernel_ms_per_step": {"k1_best_rows": k1_ms / args.steps, "k1_resolve_index": k1b_ms / args.steps,
-                                   "k_verify_pairs": kv_ms / args.steps},
-            "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": INT8_MFMA_DENSE_PEAK / 1e12,
-                         "unit": "TFLOP/s", "frac": achieved / INT8_MFMA_DENSE_PEAK, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) + "
-                                         "WRITE_SIZE in separate passes (profiles/r01_k1_pmc.json); null when not collected for this workload",
-                         "kernel": "k1_best_rows", "avg_launch_ms": 1e3 * avg_launch_s, "launches": k1_launches,
-                         "executed_frac": 2.0 * achieved / INT8_MFMA_DENSE_PEAK,
+            "device": {"name": info.name.decode(), "arch": info.arch.decode(), "compute_units": cus, "clock_mhz": clk / 1e6,
+                       "hbm_gb": info.total_memory / 2 ** 30, "ranks_seen_by_process_group": world},
+            "kernel_ms_per_step": {"k1_best_rows<pass 1>": k1_ms / args.steps, "k1_best_rows<gathered pass 2>": k1g_ms / args.steps,
+                                   "k1_resolve_index": k1b_ms / args.steps, "k_verify_pairs": kv_ms / args.steps},
+            "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": int8_peak / 1e12,
+                         "unit": "TFLOP/s", "frac": achieved / int8_peak, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch of both passes, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read "
+                                         "correction) + WRITE_SIZE in separate passes (profiles/r02_k1_pmc.json); null when not "
+                                         "collected for this workload",
+                         "kernel": "k1_best_rows (pass 1 over all rows + gathered pass 2 of the cross-check)",
+                         "avg_launch_ms": 1e3 * (pass1_s + pass2_s), "avg_launch_ms_pass1": 1e3 * pass1_s,
+                         "avg_launch_ms_pass2": 1e3 * pass2_s, "launches": k1_launches, "peak_source": peaks_note,
+                         "executed_frac": None,
                          "note": "int8 ops (2 per MAC) counted as flops; algorithmic = ONE 2*128*N1*N2 distance matrix per pair "
-                                 "(SURVEY.md 8d).  The kernel issues twice that (one directed pass per direction of the "
-                                 "cross-check, each with its own fused top-2): executed_frac is the matrix-pipe view"},
+                                 "(SURVEY.md 8d) over the HIP-event time of BOTH k1_best_rows launches; pass 2 recomputes only "
+                                 "the rows matches12 points at (~7 % of the matrix at this shape)"},
         }
+        if pass1_s > 0 and res["matches"] >= 0:
+            # what the matrix pipe executed: pass 1 = the whole matrix; pass 2 = gathered rows in 128-row wave units
+            out["roofline"]["frac_pass1_only"] = ops_per_pair * pairs_per_launch / pass1_s / int8_peak
         if verify and kv_ms > 0:
-            # second roofline, verification: algorithmic scoring flops of the step / device time of the verification
-            # kernels (solvers, local optimisation and the sequential replay are extra work on top of it)
-            fp64_peak = 78.6e12  # MI355X vector FP64 (MI355X_MICROARCH.md)
             ach = res["score_flops"] / (1e-3 * kv_ms / args.steps) / max(world, 1)
             out["roofline_verify"] = {"bound": "fp64-valu", "achieved": ach / 1e12, "peak": fp64_peak / 1e12, "unit": "TFLOP/s",
                                       "frac": ach / fp64_peak, "traffic": None,
                                       "note": "algorithmic inlier-scoring flops only (33 / 20 / 5 per model x correspondence), "
                                               "per GPU, over the HIP-event time of all verification kernels"}
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(images, pairs, args.cpu_seconds, verify, cams, topts, user_seed)
+            from tests import oracle_lib
+            cores = min(host_cores(), 256)
+            share = args.cpu_seconds * 0.6
+            out["cpu_baseline"] = cpu_baseline(oracle_lib.load(), "built -O3 without -march (CMake Release, like the reference)",
+                                               "-O3", images, pairs, share, verify, cams, topts, user_seed, cores)
+            native = oracle_lib.load_native()
+            if native is not None:
+                out["cpu_baseline_native"] = cpu_baseline(native, "built -O3 -march=native on this host (labelled second baseline, SURVEY 8d)",
+                                                          "-O3 -march=native", images, pairs, args.cpu_seconds - share, verify, cams,
+                                                          topts, user_seed, cores)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -47,6 +47,12 @@ class TwoViewGeometry(ctypes.Structure):
                 ("num_models", ctypes.c_uint32 * 4)]
 
 
+class DeviceInfo(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 128), ("arch", ctypes.c_char * 64), ("compute_units", ctypes.c_int32),
+                ("clock_khz", ctypes.c_int32), ("memory_clock_khz", ctypes.c_int32), ("memory_bus_bits", ctypes.c_int32),
+                ("total_memory", ctypes.c_uint64), ("l2_bytes", ctypes.c_int32), ("lds_per_cu", ctypes.c_int32)]
+
+
 _lib = None
 
 
@@ -87,6 +93,8 @@ def lib():
                                                      ctypes.POINTER(TwoViewOptions), ctypes.c_uint32,
                                                      ctypes.POINTER(TwoViewGeometry), u32p]
         L.dsm_debug_sample_sequence.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, u32p]
+        L.dsm_get_device_info.argtypes = [vp, ctypes.POINTER(DeviceInfo)]
+        L.dsm_get_match_gather_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
         L.dsm_debug_image_to_world.argtypes = [vp, ctypes.POINTER(Camera), ctypes.c_uint32, ctypes.POINTER(ctypes.c_double),
                                                ctypes.POINTER(ctypes.c_double)]
         L.dsm_default_match_options.argtypes = [ctypes.POINTER(MatchOptions)]
@@ -282,6 +290,16 @@ class Context:
         mo = match_options if match_options is not None else default_match_options()
         to = options if options is not None else default_two_view_options()
         self._chk(lib().dsm_guided_match_pairs(self._h, ctypes.byref(mo), ctypes.byref(to), 1 if stage_filter else 0))
+
+    def device_info(self):
+        d = DeviceInfo()
+        self._chk(lib().dsm_get_device_info(self._h, ctypes.byref(d)))
+        return d
+
+    def match_gather_time(self):
+        ms = ctypes.c_double(0)
+        self._chk(lib().dsm_get_match_gather_time(self._h, ctypes.byref(ms)))
+        return ms.value
 
     def match_resolve_time(self):
         ms = ctypes.c_double(0)

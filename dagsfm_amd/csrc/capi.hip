@@ -238,6 +238,23 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
 
 const char* dsm_last_error(const dsm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+int dsm_get_device_info(dsm_ctx* ctx, dsm_device_info* out) {
+  if (!ctx || !out) return DSM_ERR_INVALID_ARGUMENT;
+  hipDeviceProp_t pr;
+  HIPCHK(ctx, hipGetDeviceProperties(&pr, ctx->device));
+  memset(out, 0, sizeof(*out));
+  snprintf(out->name, sizeof(out->name), "%s", pr.name);
+  snprintf(out->arch, sizeof(out->arch), "%s", pr.gcnArchName);
+  out->compute_units = pr.multiProcessorCount;
+  out->clock_khz = pr.clockRate;
+  out->memory_clock_khz = pr.memoryClockRate;
+  out->memory_bus_bits = pr.memoryBusWidth;
+  out->total_memory = pr.totalGlobalMem;
+  out->l2_bytes = pr.l2CacheSize;
+  out->lds_per_cu = (int32_t)pr.maxSharedMemoryPerMultiProcessor;
+  return DSM_OK;
+}
+
 int dsm_sync(dsm_ctx* ctx) {
   if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
   HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -121,10 +121,7 @@ class Scene:
             self.points[:, 2] = planar_depth * self.points[:, 2]
         self.base = _sift_like(rng, self.n_pool)
 
-    def image(self, i):
-        """Returns (descriptors u8 [n,128], keypoints f32 [n,2], (R,t), observed pool ids [n] (-1 = clutter))."""
-        rng = np.random.default_rng([self.seed, 1 + i])
-        n, k = self.n_feats, min(self.n_obs, self.n_feats)
+    def _pose(self, rng):
         # camera on a shell around the scene, looking at a jittered centre
         d = rng.normal(size=3)
         d /= np.linalg.norm(d)
@@ -135,7 +132,17 @@ class Scene:
         if self.panoramic:  # one shared centre, the viewing direction is what differs
             pos = np.array([0.0, 0.0, -17.0])
             target = 3.0 * target
-        R, t = _look_at(pos, target, np.array([0.0, 1.0, 0.0]) + 0.2 * rng.normal(size=3))
+        return _look_at(pos, target, np.array([0.0, 1.0, 0.0]) + 0.2 * rng.normal(size=3))
+
+    def pose(self, i):
+        """(R, t) world -> camera of image i without generating its features."""
+        return self._pose(np.random.default_rng([self.seed, 1 + i]))
+
+    def image(self, i):
+        """Returns (descriptors u8 [n,128], keypoints f32 [n,2], (R,t), observed pool ids [n] (-1 = clutter))."""
+        rng = np.random.default_rng([self.seed, 1 + i])
+        n, k = self.n_feats, min(self.n_obs, self.n_feats)
+        R, t = self._pose(rng)
         ids = np.full(n, -1, dtype=np.int64)
         obs = rng.choice(self.n_pool, size=k, replace=False)
         desc = np.empty((n, 128), dtype=np.float32)

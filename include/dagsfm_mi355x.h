@@ -127,6 +127,21 @@ const char* dsm_last_error(const dsm_ctx* ctx);
 /* Blocks until all work queued by this context has finished. */
 int dsm_sync(dsm_ctx* ctx);
 
+/* What the device reports about itself (hipDeviceProp_t): used by bench.py to derive the roofline peaks from
+ * the hardware instead of hard-coding them. */
+typedef struct dsm_device_info {
+  char name[128];
+  char arch[64];            /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+  int32_t compute_units;    /* multiProcessorCount */
+  int32_t clock_khz;        /* clockRate: peak engine clock */
+  int32_t memory_clock_khz; /* memoryClockRate */
+  int32_t memory_bus_bits;  /* memoryBusWidth */
+  uint64_t total_memory;    /* totalGlobalMem, bytes */
+  int32_t l2_bytes;         /* l2CacheSize (one XCD's L2) */
+  int32_t lds_per_cu;       /* maxSharedMemoryPerMultiProcessor */
+} dsm_device_info;
+int dsm_get_device_info(dsm_ctx* ctx, dsm_device_info* out);
+
 /* Makes `n_images` images resident in HBM.  Replaces FeatureMatcherCache::Setup /
  * GetDescriptors / GetKeypoints (src/feature/matching.cc:221-316) and
  * SiftMatchGPU::SetDescriptors (lib/SiftGPU/SiftGPU.h:303-336).

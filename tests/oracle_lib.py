@@ -249,3 +249,15 @@ def load():
             build()
         _LIB = Oracle(ctypes.CDLL(path))
     return _LIB
+
+
+def load_native(build_dir=None):
+    """The same sources built -O3 -march=native ON THIS HOST (oracle/Makefile `native`): a second, labelled CPU
+    baseline for bench.py; returns None when it cannot be built here.  Never used as the parity checker."""
+    import tempfile
+    d = build_dir or os.path.join(tempfile.gettempdir(), "dagsfm_oracle_native_%d" % os.getuid())
+    try:
+        subprocess.check_call(["make", "-s", "-C", _DIR, "native", "NDIR=" + d], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return Oracle(ctypes.CDLL(os.path.join(d, "liboracle_native.so")))
+    except Exception:
+        return None
