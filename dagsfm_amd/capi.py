@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdagsfm_mi355x.so")
+# DSM_LIB_PATH: developer override (e.g. the -DDSM_PROFILE_SECTIONS build under dagsfm_amd/prof/)
+LIB_PATH = os.environ.get("DSM_LIB_PATH") or os.path.join(_HERE, "libdagsfm_mi355x.so")
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 u32p = ctypes.POINTER(ctypes.c_uint32)
