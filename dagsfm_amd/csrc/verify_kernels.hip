@@ -1446,7 +1446,20 @@ __global__ __launch_bounds__(64) void k_sample(const VerifyParams p) {
       for (int i = lane; i < n; i += 64) sidx[i] = sg[i];
     }
     const uint32_t remaining = p.max_trials[FAM] - fs->rep.num_trials;
-    const int nb = (int)(remaining < p.batch ? remaining : p.batch);
+    // Speculation is only useful up to the dynamic stop: the loop aborts at the first trial >= max(dyn_max_num_trials,
+    // min_num_trials) that yields a model (loransac.h:190-194), and dyn_max_num_trials never grows (the best inlier
+    // count never shrinks).  After the first round, draw just that many trials plus a margin for samples without a
+    // model; if the margin was too small the pair simply stays active for another round.
+    uint32_t want = p.batch;
+    if (fs->rounds > 0) {
+      const uint32_t mt = (uint32_t)p.opt.min_num_trials;
+      const uint32_t thr = fs->dyn_max > mt ? fs->dyn_max : mt;
+      const uint32_t T0 = fs->rep.num_trials;
+      const uint32_t margin = FAM == FAM_E ? 8u : 4u;
+      const uint32_t need = (thr > T0 ? thr - T0 : 0u) + margin;
+      if (need < want) want = need;
+    }
+    const int nb = (int)(remaining < want ? remaining : want);
     generator_store(gen, st + PS_SNAP, lane);  // snapshot before this round's draws
     wv_sync();
     wv_draw_samples<F::K>(gen, ws, sidx, (uint32_t)n, nb, p.samples + ((size_t)pl * p.batch) * 7,
