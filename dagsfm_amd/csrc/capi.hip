@@ -111,6 +111,8 @@ struct dsm_ctx {
   DevBuf d_nt_table, d_nt_off, d_nt_off_t, d_pair_state, d_pts_px, d_pts_norm, d_reports, d_masks;
   DevBuf d_fam_state, d_samples, d_draws_end, d_nmodels, d_vcounts, d_models, d_sidx, d_active;
   DevBuf d_ework;
+  DevBuf d_lo_inl, d_lo_queue, d_lo_work, d_lo_models, d_lo_slots, d_lo_ework;  // batched local optimisation
+  uint32_t verify_lo_iters[3] = {0, 0, 0};
   DevBuf d_g_nfeat, d_g_dpairs, d_g_doff, d_g_pdir, d_g_params, d_g_m, d_g_counts, d_g_offsets, d_g_total, d_g_matches,
       d_g_plan, d_g_inl, d_g_inl_off;  // guided matching
   DevBuf d_mm_matches[2], d_mm_off[2], d_mm_counts, d_mm_state, d_mm_first, d_mm_acc, d_mm_keep, d_mm_total;  // EstimateMultiple
@@ -228,7 +230,8 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
                     &ctx->d_g_inl, &ctx->d_g_inl_off, &ctx->d_mm_matches[0], &ctx->d_mm_matches[1], &ctx->d_mm_off[0],
                     &ctx->d_mm_off[1], &ctx->d_mm_counts, &ctx->d_mm_state, &ctx->d_mm_first, &ctx->d_mm_acc, &ctx->d_mm_keep,
                     &ctx->d_mm_total, &ctx->d_order, &ctx->d_dpairs2, &ctx->d_ecnt, &ctx->d_eoff, &ctx->d_etotal, &ctx->d_entries,
-                    &ctx->d_out2};
+                    &ctx->d_out2, &ctx->d_lo_inl, &ctx->d_lo_queue, &ctx->d_lo_work, &ctx->d_lo_models, &ctx->d_lo_slots,
+                    &ctx->d_lo_ework};
   if (ctx->vev0) (void)hipEventDestroy(ctx->vev0);
   if (ctx->vev1) (void)hipEventDestroy(ctx->vev1);
   for (DevBuf* b : bufs) b->release();
@@ -769,6 +772,12 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.e_work = nullptr;
   vp.sidx_g = nullptr;
   vp.active_count = nullptr;
+  vp.lo_inl = nullptr;
+  vp.worklist = nullptr;
+  vp.n_work = 0;
+  vp.lo_queue = nullptr;
+  vp.lo_count = nullptr;
+  vp.lo_work = vp.lo_models = vp.lo_slots = vp.lo_ework = nullptr;
   const bool legacy = getenv("DSM_VERIFY_LEGACY") != nullptr;  // single-kernel-per-family schedule (debug)
   if (legacy) {
     HIPCHK(ctx, hipEventRecord(ctx->vev0, st));
@@ -784,7 +793,8 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
       bmax = std::max(bmax, batch[f]);
       bm_max = std::max<uint64_t>(bm_max, (uint64_t)batch[f] * vp_maxm(f));
     }
-    const uint64_t per_pair = (uint64_t)bmax * (7 * 4 + 4 + 4) + bm_max * (4 + 72) + (uint64_t)batch[0] * 200 * 8;
+    const uint64_t per_pair = (uint64_t)bmax * (7 * 4 + 4 + 4) + bm_max * (4 + 72) + (uint64_t)batch[0] * 200 * 8 +
+                              (LO_WORK_DOUBLES + 90 + 90 + 200) * 8 + 8;
     const uint64_t budget = 16ull << 30;
     const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_pairs, budget / per_pair));
     HIPCHK(ctx, ctx->d_fam_state.reserve(std::max<size_t>(n_pairs, 1) * 3 * sizeof(FamState)));
@@ -797,6 +807,19 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     HIPCHK(ctx, ctx->d_vcounts.reserve((size_t)chunk * bm_max * 4));
     HIPCHK(ctx, ctx->d_models.reserve((size_t)chunk * bm_max * 72));
     HIPCHK(ctx, ctx->d_ework.reserve((size_t)chunk * batch[0] * 200 * 8));
+    const bool inline_lo = getenv("DSM_VERIFY_INLINE_LO") != nullptr;  // reference schedule: k_replay with the LO inline
+    HIPCHK(ctx, ctx->d_lo_inl.reserve(tm * 4));
+    HIPCHK(ctx, ctx->d_lo_queue.reserve((size_t)chunk * 2 * 4));
+    HIPCHK(ctx, ctx->d_lo_work.reserve((size_t)chunk * LO_WORK_DOUBLES * 8));
+    HIPCHK(ctx, ctx->d_lo_models.reserve((size_t)chunk * 90 * 8));
+    HIPCHK(ctx, ctx->d_lo_slots.reserve((size_t)chunk * 90 * 8));
+    HIPCHK(ctx, ctx->d_lo_ework.reserve((size_t)chunk * 200 * 8));
+    vp.lo_inl = ctx->d_lo_inl.as<uint32_t>();
+    vp.lo_work = ctx->d_lo_work.as<double>();
+    vp.lo_models = ctx->d_lo_models.as<double>();
+    vp.lo_slots = ctx->d_lo_slots.as<double>();
+    vp.lo_ework = ctx->d_lo_ework.as<double>();
+    ctx->verify_lo_iters[0] = ctx->verify_lo_iters[1] = ctx->verify_lo_iters[2] = 0;
     vp.fam_state = ctx->d_fam_state.as<FamState>();
     vp.samples = ctx->d_samples.as<uint32_t>();
     vp.draws_end = ctx->d_draws_end.as<uint32_t>();
@@ -823,12 +846,42 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
           HIPCHK(ctx, hipMemsetAsync(static_cast<char*>(ctx->d_active.p) + 72, 0, 4, st));  // k_sample's work counter
           launch_vp_sample(vp, f, nb_light, st);
           launch_vp_solve_score(vp, f, st);
-          HIPCHK(ctx, hipMemsetAsync(static_cast<char*>(ctx->d_active.p) + 64, 0, 4, st));  // k_replay's work counter
-          launch_vp_replay(vp, f, nb_heavy, st);
-          HIPCHK(ctx, hipGetLastError());
           uint32_t active = 0;
-          HIPCHK(ctx, hipMemcpyAsync(&active, ctx->d_active.p, 4, hipMemcpyDeviceToHost, st));
-          HIPCHK(ctx, hipStreamSynchronize(st));
+          if (inline_lo) {
+            HIPCHK(ctx, hipMemsetAsync(static_cast<char*>(ctx->d_active.p) + 64, 0, 4, st));  // k_replay's work counter
+            launch_vp_replay(vp, f, nb_heavy, st);
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipMemcpyAsync(&active, ctx->d_active.p, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+          } else {
+            // replay until every pair of the chunk has either consumed the batch or stopped; a pair that reaches a
+            // local optimisation is suspended onto the queue, the optimisation runs for the whole queue, and the
+            // next replay launch works through exactly that queue
+            uint32_t* queues = ctx->d_lo_queue.as<uint32_t>();
+            vp.worklist = nullptr;
+            vp.n_work = vp.n_chunk;
+            for (uint32_t cur = 0;; cur ^= 1u) {
+              uint32_t* cnt_dev = ctx->d_active.as<uint32_t>() + 20 + cur;
+              HIPCHK(ctx, hipMemsetAsync(cnt_dev, 0, 4, st));
+              HIPCHK(ctx, hipMemsetAsync(static_cast<char*>(ctx->d_active.p) + 64, 0, 4, st));  // work counter [16]
+              vp.lo_queue = queues + (size_t)cur * chunk;
+              vp.lo_count = cnt_dev;
+              launch_vp_replay_lo(vp, f, nb_heavy, st);
+              HIPCHK(ctx, hipGetLastError());
+              uint32_t host_ctr[32];
+              HIPCHK(ctx, hipMemcpyAsync(host_ctr, ctx->d_active.p, 128, hipMemcpyDeviceToHost, st));
+              HIPCHK(ctx, hipStreamSynchronize(st));
+              active = host_ctr[0];
+              const uint32_t nq = host_ctr[20 + cur];
+              if (nq == 0) break;
+              ctx->verify_lo_iters[f]++;
+              vp.worklist = vp.lo_queue;
+              vp.n_work = nq;
+              HIPCHK(ctx, hipMemsetAsync(static_cast<char*>(ctx->d_active.p) + 76, 0, 4, st));  // k_lo_prepare's work counter [19]
+              launch_vp_local_opt(vp, f, nb_heavy, st);
+              HIPCHK(ctx, hipGetLastError());
+            }
+          }
           ctx->verify_rounds[f]++;
           if (active == 0) break;
         }
@@ -852,6 +905,8 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
                 prof[8] >> 20, prof[9] >> 20, prof[10] >> 20, prof[11] >> 20, prof[12] >> 20, prof[13] >> 20, prof[14] >> 20);
       }
 #endif
+      fprintf(stderr, "[dsm verify] local-optimisation iterations E/F/H %u/%u/%u\n", ctx->verify_lo_iters[0], ctx->verify_lo_iters[1],
+              ctx->verify_lo_iters[2]);
       fprintf(stderr, "[dsm verify] pairs %u rounds E/F/H %u/%u/%u candidates E/F/H %u/%u/%u LO calls E/F/H %u/%u/%u\n", n_pairs,
               ctx->verify_rounds[0], ctx->verify_rounds[1], ctx->verify_rounds[2], dbg[1], dbg[3], dbg[5], dbg[2], dbg[4], dbg[6]);
     }

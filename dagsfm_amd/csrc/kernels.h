@@ -85,7 +85,15 @@ struct FamState {
   uint32_t active;      // 1 while more trials are needed
   uint32_t rounds;      // sampling rounds done
   uint32_t nb;          // trials sampled in the current round
+  // suspended replay (local optimisation as its own batched kernels): where k_replay_lo resumes
+  uint32_t t_pos;       // trial of the current batch to look at next
+  uint32_t m_pos;       // model of that trial to look at next
+  uint32_t lo_wait;     // 1: the pair waits for the models of a local optimisation (triggered by model m_pos - 1)
+  uint32_t lo_ninl;     // inliers handed to that local optimisation
+  uint32_t lo_nm;       // models it produced
+  uint32_t pad;
 };
+#define LO_WORK_DOUBLES 176  // per pair: W[81] V[81] n1[3] n2[3] scale dsz, padded
 
 // Two-view verification: one 64-lane workgroup per image pair (grid-stride over the pair list).
 struct VerifyParams {
@@ -130,6 +138,17 @@ struct VerifyParams {
   int32_t sampler_serial;      // test hook (DSM_SAMPLER_SERIAL): force the sampler's serial replay path
   int32_t reseed;              // 1: k_verify_prep seeds the pair's generator; 0: it continues (EstimateMultiple passes)
   int32_t keep_generator;      // 1: k_verify_final stores the generator state for a following pass
+  // local optimisation as batched kernels: k_replay_lo suspends a pair at every LO, the LO runs for all suspended
+  // pairs at once (k_lo_prepare: wave per pair; k_lo_jacobi: 16-lane group per pair; E: the flat 5-point kernels)
+  uint32_t* lo_inl;            // [total] ordered inlier indices of the pair's pending LO (at match offsets)
+  const uint32_t* worklist;    // k_replay_lo / LO kernels: chunk-local pair indices to process (nullptr: all pairs)
+  uint32_t n_work;
+  uint32_t* lo_queue;          // out: pairs that k_replay_lo suspended
+  uint32_t* lo_count;          // out: their number
+  double* lo_work;             // [n_chunk][LO_WORK_DOUBLES]
+  double* lo_models;           // [n_chunk][10][9]
+  double* lo_slots;            // E: [n_chunk][90] (null-space basis, B(z), determinant polynomial / roots)
+  double* lo_ework;            // E: [n_chunk][200] constraint matrix
 };
 
 size_t verify_scratch_bytes_per_block(uint32_t n_max);
@@ -141,6 +160,8 @@ void launch_vp_sample(const VerifyParams& p, int fam, uint32_t n_blocks, hipStre
 void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st);
 void launch_vp_replay(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st);
 void launch_vp_final(const VerifyParams& p, uint32_t n_blocks, hipStream_t st);
+void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st);
+void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st);  // over p.worklist / p.n_work
 uint32_t vp_batch(int fam, uint32_t max_trials);
 uint32_t vp_maxm(int fam);
 void debug_read_prof(unsigned long long* out16);

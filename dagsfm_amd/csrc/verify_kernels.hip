@@ -920,6 +920,7 @@ __global__ __launch_bounds__(64) void k_verify_prep(const VerifyParams p) {
       fs.active = (n >= K[lane] && (lane != FAM_E || calibrated) && p.max_trials[lane] > 0) ? 1u : 0u;
       fs.rounds = 0;
       fs.nb = 0;
+      fs.t_pos = fs.m_pos = fs.lo_wait = fs.lo_ninl = fs.lo_nm = fs.pad = 0;
       p.fam_state[(size_t)pi * 3 + lane] = fs;
     }
     wv_sync();
@@ -1464,7 +1465,12 @@ __global__ __launch_bounds__(64) void k_sample(const VerifyParams p) {
     wv_sync();
     wv_draw_samples<F::K>(gen, ws, sidx, (uint32_t)n, nb, p.samples + ((size_t)pl * p.batch) * 7,
                           p.draws_end + (size_t)pl * p.batch, lane, p.sampler_serial != 0);
-    if (lane == 0) fs->nb = (uint32_t)nb;
+    if (lane == 0) {
+      fs->nb = (uint32_t)nb;
+      fs->t_pos = 0;
+      fs->m_pos = 0;
+      fs->lo_wait = 0;
+    }
     wv_sync();
     generator_store(gen, st, lane);
     for (int i = lane; i < n; i += 64) sg[i] = sidx[i];
@@ -1577,17 +1583,9 @@ __global__ __launch_bounds__(64, 2) void k_solve_e_build(const VerifyParams p) {
 // Only rows 4..9 of the solution enter B(z), so the back substitution stops there.  Same operations in the
 // same order as pl_lu_solve_10.
 #define ELU_SMEM (100 * 64 * 8 + 10 * 64)
-__global__ __launch_bounds__(64) void k_solve_e_lu(const VerifyParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  double* Al = reinterpret_cast<double*>(smem_raw) + threadIdx.x;
-  unsigned char* idx = smem_raw + 100 * 64 * 8 + threadIdx.x;  // idx[i*64]: original row now in row i
-  const uint32_t pl = blockIdx.x;
-  const uint32_t pi = p.pair0 + pl;
-  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
-  if (!fs->active) return;
-  const int t = blockIdx.y * 64 + threadIdx.x;
-  if (t >= (int)fs->nb) return;
-  const double* Ag = p.e_work + ((size_t)pl * p.batch + t) * 200;  // A[r*20 + c]
+// Ag: the hypothesis' 10 x 20 constraint matrix A[r*20 + c]; slot: its 90-double record (B(z) and the determinant
+// polynomial are written to it); Al / idx: this lane's column of the lane-interleaved LDS work area.
+DSM_DEV void e_lu_body(const double* Ag, double* slot, double* Al, unsigned char* idx) {
 #define LA(i, k) Al[((k) * 10 + (i)) * 64]
   LSEC_BEGIN2();
   for (int r = 0; r < 10; ++r)
@@ -1649,9 +1647,52 @@ __global__ __launch_bounds__(64) void k_solve_e_lu(const VerifyParams p) {
 #undef LA
   double B[39], coeffs[11];
   five_point_B_det(S, B, coeffs);
-  double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
   for (int k = 0; k < 39; ++k) slot[EPOLY_B + k] = B[k];
   for (int k = 0; k < 11; ++k) slot[EPOLY_COEFFS + k] = coeffs[k];
+}
+__global__ __launch_bounds__(64) void k_solve_e_lu(const VerifyParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* Al = reinterpret_cast<double*>(smem_raw) + threadIdx.x;
+  unsigned char* idx = smem_raw + 100 * 64 * 8 + threadIdx.x;  // idx[i*64]: original row now in row i
+  const uint32_t pl = blockIdx.x;
+  const uint32_t pi = p.pair0 + pl;
+  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
+  if (!fs->active) return;
+  const int t = blockIdx.y * 64 + threadIdx.x;
+  if (t >= (int)fs->nb) return;
+  e_lu_body(p.e_work + ((size_t)pl * p.batch + t) * 200, p.models + ((size_t)pl * p.batch + t) * 90, Al, idx);
+}
+
+// slot coefficients -> slot roots (real parts); returns the code for nmodels: bits 0..9 root i is real
+// (essential_matrix.cc:126), bits 16..: number of roots
+DSM_DEV int e_roots_body(double* slot, double* Tl) {
+  double coeffs[11], rr[11], ri[11];
+  for (int k = 0; k < 11; ++k) coeffs[k] = slot[EPOLY_COEFFS + k];
+  LSEC_BEGIN4();
+  const int nroots = pl_poly_roots<11, 64>(coeffs, 11, rr, ri, Tl);
+  LSEC_END4(11);
+  int code = 0;
+  if (nroots > 0) {
+    for (int i = 0; i < nroots; ++i) {
+      if (!(fabs(ri[i]) > 1e-10)) code |= 1 << i;
+      slot[EPOLY_COEFFS + i] = rr[i];
+    }
+    code |= nroots << 16;
+  }
+  return code;
+}
+// slot (Eb, B, roots) + code -> models; returns their number
+DSM_DEV int e_models_body(const double* slot, int code, double* models_out) {
+  const int nroots = code >> 16;
+  if (nroots <= 0) return 0;
+  double Eb[36], B[39], rr[11], ri[11];
+  for (int k = 0; k < 36; ++k) Eb[k] = slot[EPOLY_EB + k];
+  for (int k = 0; k < 39; ++k) B[k] = slot[EPOLY_B + k];
+  for (int i = 0; i < nroots; ++i) {
+    rr[i] = slot[EPOLY_COEFFS + i];
+    ri[i] = ((code >> i) & 1) ? 0.0 : 1.0;  // five_point_models only tests |imag| > 1e-10
+  }
+  return five_point_models(Eb, B, rr, ri, nroots, models_out);
 }
 
 // roots of the determinant polynomial: slot coefficients -> slot roots (real parts) + nmodels = root count /
@@ -1665,21 +1706,7 @@ __global__ __launch_bounds__(64) void k_roots_e(const VerifyParams p) {
   if (!fs->active) return;
   const int t = blockIdx.y * 64 + threadIdx.x;
   if (t >= (int)fs->nb) return;
-  double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
-  double coeffs[11], rr[11], ri[11];
-  for (int k = 0; k < 11; ++k) coeffs[k] = slot[EPOLY_COEFFS + k];
-  LSEC_BEGIN4();
-  const int nroots = pl_poly_roots<11, 64>(coeffs, 11, rr, ri, Tl);
-  LSEC_END4(11);
-  int code = 0;  // bits 0..9: root i is real (essential_matrix.cc:126), bits 16..: number of roots
-  if (nroots > 0) {
-    for (int i = 0; i < nroots; ++i) {
-      if (!(fabs(ri[i]) > 1e-10)) code |= 1 << i;
-      slot[EPOLY_COEFFS + i] = rr[i];
-    }
-    code |= nroots << 16;
-  }
-  p.nmodels[(size_t)pl * p.batch + t] = code;
+  p.nmodels[(size_t)pl * p.batch + t] = e_roots_body(p.models + ((size_t)pl * p.batch + t) * 90, Tl);
 }
 
 // models of every hypothesis (one lane each), then the inlier counts of ALL models of the block's 64
@@ -1713,19 +1740,9 @@ __global__ __launch_bounds__(64, 4) void k_models_score_e(const VerifyParams p) 
   double* slots = p.models + ((size_t)pl * p.batch + t0) * 90;
   if (t < nb) {
     double* slot = slots + (size_t)lane * 90;
-    const int code = p.nmodels[(size_t)pl * p.batch + t];
-    const int nroots = code >> 16;
-    if (nroots > 0) {
-      double Eb[36], B[39], rr[11], ri[11], mloc[90];
-      for (int k = 0; k < 36; ++k) Eb[k] = slot[EPOLY_EB + k];
-      for (int k = 0; k < 39; ++k) B[k] = slot[EPOLY_B + k];
-      for (int i = 0; i < nroots; ++i) {
-        rr[i] = slot[EPOLY_COEFFS + i];
-        ri[i] = ((code >> i) & 1) ? 0.0 : 1.0;  // five_point_models only tests |imag| > 1e-10
-      }
-      nm = five_point_models(Eb, B, rr, ri, nroots, mloc);
-      for (int k = 0; k < nm * 9; ++k) slot[k] = mloc[k];
-    }
+    double mloc[90];
+    nm = e_models_body(slot, p.nmodels[(size_t)pl * p.batch + t], mloc);
+    for (int k = 0; k < nm * 9; ++k) slot[k] = mloc[k];
     p.nmodels[(size_t)pl * p.batch + t] = nm;
   }
   __syncthreads();  // models (global) and points (LDS) visible to the whole wave
@@ -1946,6 +1963,430 @@ __global__ __launch_bounds__(64, 4) void k_replay(const VerifyParams p) {
         p.reports[(size_t)pi * 3 + FAM] = rep;
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------ replay with batched local optimisation
+// k_replay runs a pair's local optimisations inline: ONE problem on a 64-lane wave, most of it scalar chains
+// (2 x 2 rotations of the 9 x 9 Jacobi, the 5-point finish) that every lane executes redundantly -- 72 % of its
+// wave cycles.  Here the replay SUSPENDS at every local optimisation: k_replay_lo records the pair's state, hands
+// the ordered inlier list to lo_inl and puts the pair on a queue; the optimisation then runs for all queued pairs
+// at once (k_lo_prepare: wave per pair, matrix + pivoted QR; k_lo_jacobi: a 16-lane group per pair for the 9 x 9
+// sweeps and the 8-point / DLT finish; the essential family re-uses the flat 5-point kernels, lane per problem);
+// the next k_replay_lo launch (work list = that queue) scores the returned models and scans on.  Same operations
+// in the same order as k_replay, which stays as the reference schedule (DSM_VERIFY_INLINE_LO=1).
+template <int FAM>
+__global__ __launch_bounds__(64, 4) void k_replay_lo(const VerifyParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  VSmem* sm = reinterpret_cast<VSmem*>(smem_raw);
+  typedef Fam<FAM> F;
+  const int lane = threadIdx.x;
+  const WgScratch ws = wg_scratch(p);
+  __shared__ uint32_t s_next;
+  for (;;) {
+    wv_sync();
+    if (lane == 0) s_next = atomicAdd(p.active_count + 16, 1u);
+    wv_sync();
+    const uint32_t widx = s_next;
+    if (widx >= p.n_work) break;
+    const uint32_t pl = p.worklist ? p.worklist[widx] : widx;
+    const uint32_t pi = p.pair0 + pl;
+    FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
+    if (!fs->active) continue;
+    const uint64_t moff = p.match_off[pi];
+    const int n = (int)(p.match_off[pi + 1] - moff);
+    const dsm_camera& cam1 = p.cams[p.pairs[2 * pi]];
+    const dsm_camera& cam2 = p.cams[p.pairs[2 * pi + 1]];
+    PairWork w;
+    w.n = n;
+    w.resid = ws.resid;
+    w.inl = reinterpret_cast<int*>(p.lo_inl + moff);  // the compaction's output IS the hand-over to the LO kernels
+    w.tall = ws.tall;
+    w.models = nullptr;
+    w.sm = sm;
+    w.lane = lane;
+    w.pts = (FAM == FAM_E ? p.pts_norm : p.pts_px) + 4 * moff;
+    w.nt_table = p.nt_table + p.nt_off[n] + (size_t)FAM * (size_t)(n + 1);
+    double max_error = p.opt.max_error;
+    if (FAM == FAM_E)
+      max_error = (image_to_world_threshold(cam1, p.opt.max_error) + image_to_world_threshold(cam2, p.opt.max_error)) / 2;
+    const double max_residual = max_error * max_error;
+    const uint32_t min_trials = (uint32_t)p.opt.min_num_trials;
+    const uint32_t max_num_trials = p.max_trials[FAM];
+
+    uint32_t best_n = fs->rep.num_inliers;
+    double best_sum = fs->rep.residual_sum;
+    double best_model[9];
+    for (int k = 0; k < 9; ++k) best_model[k] = fs->rep.model[k];
+    uint32_t dyn_max = fs->dyn_max;
+    uint32_t num_models = fs->rep.num_models;
+    const uint32_t T0 = fs->rep.num_trials;
+    const int nb = (int)fs->nb;
+    const int32_t* nmod = p.nmodels + (size_t)pl * p.batch;
+    const int32_t* cnts = p.counts + (size_t)pl * p.batch * F::MAXM;
+    const double* mods = p.models + (size_t)pl * p.batch * F::MAXM * 9;
+
+    bool abort = false, suspended = false;
+    int t = (int)fs->t_pos;
+    int m_start = (int)fs->m_pos;
+    int t_stop = nb - 1;
+    uint32_t trial_abs = T0 + (uint32_t)t;
+    bool in_trial = false;  // resume inside trial t at model m_start
+    if (fs->lo_wait) {
+      // the local optimisation of (trial t, model m_start - 1) has returned: loransac.h:160-178
+      const int nlo = (int)fs->lo_nm;
+      const double* lom = p.lo_models + (size_t)pl * 90;
+      for (int l = 0; l < nlo; ++l) {
+        num_models += 1;
+        double M[9];
+        for (int k = 0; k < 9; ++k) M[k] = lom[l * 9 + k];
+        const uint32_t lc = (uint32_t)score_model<FAM>(w, M, max_residual, true);
+        const double lsum = ordered_residual_sum(w, max_residual);
+        if (lc > best_n || (lc == best_n && lsum < best_sum)) {
+          best_n = lc;
+          best_sum = lsum;
+          for (int k = 0; k < 9; ++k) best_model[k] = M[k];
+        }
+      }
+      dyn_max = w.nt_table[best_n];
+      if (trial_abs >= dyn_max && trial_abs >= min_trials) {
+        abort = true;
+        t_stop = t;
+      }
+      in_trial = true;
+    }
+    while (!abort && t < nb) {
+      if (!in_trial) {
+        // ---- skip ahead to the next trial that can change anything
+        const int tt = t + lane;
+        int nm_l = 0;
+        bool ev = false;
+        if (tt < nb) {
+          nm_l = nmod[tt];
+          int mx = -1;
+          for (int m = 0; m < nm_l; ++m) {
+            const int c = cnts[(size_t)tt * F::MAXM + m];
+            mx = c > mx ? c : mx;
+          }
+          const uint32_t thr = dyn_max > min_trials ? dyn_max : min_trials;
+          ev = nm_l > 0 && ((uint32_t)mx >= best_n || (T0 + (uint32_t)tt) >= thr);
+        }
+        const unsigned long long bal = __ballot(ev);
+        const int f = bal ? (__ffsll((long long)bal) - 1) : 64;
+        int skipped = (lane < f) ? nm_l : 0;
+        for (int o = 32; o > 0; o >>= 1) skipped += __shfl_xor(skipped, o);
+        num_models += (uint32_t)skipped;
+        if (!bal) {
+          t += 64;
+          continue;
+        }
+        t += f;
+        m_start = 0;
+      }
+      in_trial = false;
+      trial_abs = T0 + (uint32_t)t;
+      // ---- exact sequential processing of trial t (loransac.h:142-198)
+      const int nm = nmod[t];
+      for (int m = m_start; m < nm; ++m) {
+        num_models += 1;
+        const uint32_t cnt = (uint32_t)cnts[(size_t)t * F::MAXM + m];
+        const double* M = mods + ((size_t)t * F::MAXM + m) * 9;
+        if (cnt >= best_n) {
+          if (lane == 0) atomicAdd(p.active_count + 1 + FAM * 2, 1u);
+          score_model<FAM>(w, M, max_residual, true);
+          const double sum = ordered_residual_sum(w, max_residual);
+          if (cnt > best_n || (cnt == best_n && sum < best_sum)) {
+            best_n = cnt;
+            best_sum = sum;
+            for (int k = 0; k < 9; ++k) best_model[k] = M[k];
+            if (cnt > (uint32_t)F::K && cnt >= (uint32_t)F::LO_MIN) {
+              if (lane == 0) atomicAdd(p.active_count + 2 + FAM * 2, 1u);
+              const int ninl = compact_inliers(w, max_residual);  // -> lo_inl
+              if (lane == 0) {
+                fs->t_pos = (uint32_t)t;
+                fs->m_pos = (uint32_t)(m + 1);
+                fs->lo_wait = 1;
+                fs->lo_ninl = (uint32_t)ninl;
+                p.lo_queue[atomicAdd(p.lo_count, 1u)] = pl;
+              }
+              suspended = true;
+              break;
+            }
+            dyn_max = w.nt_table[best_n];
+          }
+        }
+        if (trial_abs >= dyn_max && trial_abs >= min_trials) {
+          abort = true;
+          break;
+        }
+      }
+      if (suspended) break;
+      if (abort) {
+        t_stop = t;
+        break;
+      }
+      t += 1;
+    }
+    if (suspended) {
+      if (lane == 0) {
+        fs->rep.num_models = num_models;
+        fs->rep.num_inliers = best_n;
+        fs->rep.residual_sum = best_sum;
+        for (int k = 0; k < 9; ++k) fs->rep.model[k] = best_model[k];
+        fs->dyn_max = dyn_max;
+      }
+      continue;
+    }
+
+    uint32_t trials_done;
+    bool finished;
+    uint32_t* st = p.pair_state + (size_t)pi * PAIR_STATE_WORDS;
+    if (abort) {
+      trials_done = (trial_abs + 1 < max_num_trials) ? trial_abs + 2 : trial_abs + 1;  // loransac.h:129-134
+      finished = true;
+      if (lane == 0) {
+        if (t_stop != nb - 1) {  // later samples of this round were speculation: resume from the snapshot
+          st[PS_SKIP] = p.draws_end[(size_t)pl * p.batch + t_stop];
+          st[PS_USE_SNAP] = 1;
+        }
+      }
+    } else {
+      trials_done = T0 + (uint32_t)nb;
+      finished = trials_done >= max_num_trials;
+    }
+    if (lane == 0) {
+      fs->rep.num_trials = trials_done;
+      fs->rep.num_models = num_models;
+      fs->rep.num_inliers = best_n;
+      fs->rep.residual_sum = best_sum;
+      for (int k = 0; k < 9; ++k) fs->rep.model[k] = best_model[k];
+      fs->dyn_max = dyn_max;
+      fs->rounds += 1;
+      fs->lo_wait = 0;
+      fs->active = finished ? 0u : 1u;
+      if (!finished) atomicAdd(p.active_count, 1u);
+    }
+    if (finished) {
+      const bool success = best_n >= (uint32_t)F::K;
+      if (success) {
+        score_model<FAM>(w, best_model, max_residual, true);
+        wv_sync();
+        unsigned char* mask = p.masks + (size_t)FAM * p.mask_stride + moff;
+        for (int i = lane; i < n; i += 64) mask[i] = ws.resid[i] <= max_residual;
+      }
+      if (lane == 0) {
+        RansacReport rep;
+        rep.success = success;
+        rep.num_trials = trials_done;
+        rep.num_models = num_models;
+        rep.num_inliers = best_n;
+        rep.residual_sum = best_sum;
+        for (int k = 0; k < 9; ++k) rep.model[k] = best_model[k];
+        p.reports[(size_t)pi * 3 + FAM] = rep;
+      }
+    }
+  }
+}
+
+// LO step 1, wave per queued pair: the local estimator's constraint matrix over the pair's inlier list and its
+// reduction to the square problem -- fam_local up to (not including) the Jacobi sweeps.
+template <int FAM>
+__global__ __launch_bounds__(64, 4) void k_lo_prepare(const VerifyParams p) {
+  __shared__ WvSvdShared svd;
+  const int lane = threadIdx.x;
+  const WgScratch ws = wg_scratch(p);
+  __shared__ uint32_t s_next;
+  for (;;) {
+    wv_sync();
+    if (lane == 0) s_next = atomicAdd(p.active_count + 19, 1u);
+    wv_sync();
+    const uint32_t widx = s_next;
+    if (widx >= p.n_work) break;
+    const uint32_t pl = p.worklist[widx];
+    const uint32_t pi = p.pair0 + pl;
+    const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
+    const uint64_t moff = p.match_off[pi];
+    const double* pts = (FAM == FAM_E ? p.pts_norm : p.pts_px) + 4 * moff;
+    const int* inl = reinterpret_cast<const int*>(p.lo_inl + moff);
+    const int ninl = (int)fs->lo_ninl;
+    double* out = p.lo_work + (size_t)pl * LO_WORK_DOUBLES;
+    double n1[3] = {0, 0, 0}, n2[3] = {0, 0, 0};
+    auto idx = [inl](int i) { return inl[i]; };
+    int m;
+    double* A = ws.tall;
+    if (FAM == FAM_E) {
+      // EssentialMatrixFivePointEstimator::Estimate with all inliers, essential_matrix.cc:52-66
+      m = ninl;
+      for (int i = lane; i < m; i += 64) {
+        const double* q = pts + (size_t)inl[i] * 4;
+        const double x1_0 = q[0], x1_1 = q[1], x2_0 = q[2], x2_1 = q[3];
+        A[(size_t)0 * m + i] = x1_0 * x2_0; A[(size_t)1 * m + i] = x1_1 * x2_0; A[(size_t)2 * m + i] = x2_0;
+        A[(size_t)3 * m + i] = x1_0 * x2_1; A[(size_t)4 * m + i] = x1_1 * x2_1; A[(size_t)5 * m + i] = x2_1;
+        A[(size_t)6 * m + i] = x1_0; A[(size_t)7 * m + i] = x1_1; A[(size_t)8 * m + i] = 1;
+      }
+    } else {
+      wv_center_and_normalize(pts, 0, ninl, idx, lane, &n1[0], &n1[1], &n1[2]);
+      wv_center_and_normalize(pts, 1, ninl, idx, lane, &n2[0], &n2[1], &n2[2]);
+      if (FAM == FAM_F) {
+        // FundamentalMatrixEightPointEstimator::Estimate, fundamental_matrix.cc:150-171
+        m = ninl;
+        for (int i = lane; i < m; i += 64) {
+          const double* q = pts + (size_t)inl[i] * 4;
+          double a0, a1, b0, b1;
+          apply_norm(n1[0], n1[1], n1[2], q[0], q[1], &a0, &a1);
+          apply_norm(n2[0], n2[1], n2[2], q[2], q[3], &b0, &b1);
+          const double h[3] = {a0, a1, 1.0};
+          for (int k = 0; k < 3; ++k) {
+            A[(size_t)k * m + i] = h[k] * b0;
+            A[(size_t)(3 + k) * m + i] = h[k] * b1;
+            A[(size_t)(6 + k) * m + i] = h[k];
+          }
+        }
+      } else {
+        // HomographyMatrixEstimator::Estimate, homography_matrix.cc:44-82
+        const int N = ninl;
+        m = 2 * ninl;
+        for (int e = lane; e < 9 * m; e += 64) A[e] = 0.0;
+        wv_sync();
+        for (int i = lane; i < N; i += 64) {
+          const double* q = pts + (size_t)inl[i] * 4;
+          double s_0, s_1, d_0, d_1;
+          apply_norm(n1[0], n1[1], n1[2], q[0], q[1], &s_0, &s_1);
+          apply_norm(n2[0], n2[1], n2[2], q[2], q[3], &d_0, &d_1);
+          const int j = N + i;
+          A[(size_t)0 * m + i] = -s_0; A[(size_t)1 * m + i] = -s_1; A[(size_t)2 * m + i] = -1;
+          A[(size_t)6 * m + i] = s_0 * d_0; A[(size_t)7 * m + i] = s_1 * d_0; A[(size_t)8 * m + i] = d_0;
+          A[(size_t)3 * m + j] = -s_0; A[(size_t)4 * m + j] = -s_1; A[(size_t)5 * m + j] = -1;
+          A[(size_t)6 * m + j] = s_0 * d_1; A[(size_t)7 * m + j] = s_1 * d_1; A[(size_t)8 * m + j] = d_1;
+        }
+      }
+    }
+    wv_sync();
+    double scale;
+    const int dsz = wv_svd_prepare_mx9(A, A + (size_t)9 * m, m, &svd, &scale, lane);
+    for (int e = lane; e < 81; e += 64) {
+      out[e] = svd.W[e];
+      out[81 + e] = svd.V[e];
+    }
+    if (lane == 0) {
+      for (int k = 0; k < 3; ++k) {
+        out[162 + k] = n1[k];
+        out[165 + k] = n2[k];
+      }
+      out[168] = scale;
+      out[169] = (double)dsz;
+    }
+  }
+}
+
+// LO step 2, a 16-lane group per queued pair (four per wave): the Jacobi sweeps of JacobiSVD on the 9 x 9 (or
+// smaller) problem, then the family's finish by the group's first lane: rank-2 projection + de-normalisation
+// (8-point F), de-normalisation (H), or the null-space basis handed to the flat 5-point kernels (E).
+#define LOJ_GROUP_DOUBLES (81 + 81 + 9)
+template <int FAM>
+__global__ __launch_bounds__(64) void k_lo_jacobi(const VerifyParams p) {
+  __shared__ double lds[4 * LOJ_GROUP_DOUBLES];
+  const int lane = threadIdx.x;
+  const int g = lane >> 4, gl = lane & 15;
+  const uint32_t widx = blockIdx.x * 4u + (uint32_t)g;
+  if (widx >= p.n_work) return;
+  const uint32_t pl = p.worklist[widx];
+  const uint32_t pi = p.pair0 + pl;
+  FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
+  const double* in = p.lo_work + (size_t)pl * LO_WORK_DOUBLES;
+  grp_vd W = lds + g * LOJ_GROUP_DOUBLES;
+  grp_vd V = W + 81;
+  grp_vd sv = V + 81;
+  for (int e = gl; e < 81; e += 16) {
+    W[e] = in[e];
+    V[e] = in[81 + e];
+  }
+  const double scale = in[168];
+  const int dsz = (int)in[169];
+  grp_jacobi_sweeps(W, V, dsz, scale, sv, gl);
+  if (gl != 0) return;
+  if (FAM == FAM_E) {
+    double* slot = p.lo_slots + (size_t)pl * 90;
+    for (int r = 0; r < 9; ++r)
+      for (int c = 0; c < 4; ++c) slot[EPOLY_EB + r * 4 + c] = V[(5 + c) * 9 + r];  // Eb[r*4 + c] = V(r, 5 + c)
+    return;
+  }
+  double nv[9], n1[3], n2[3], model[9];
+  for (int k = 0; k < 9; ++k) nv[k] = V[8 * 9 + k];
+  for (int k = 0; k < 3; ++k) {
+    n1[k] = in[162 + k];
+    n2[k] = in[165 + k];
+  }
+  if (FAM == FAM_F)
+    eight_point_finish(nv, n1, n2, model);
+  else
+    homography_finish(nv, n1, n2, model);
+  double* om = p.lo_models + (size_t)pl * 90;
+  for (int k = 0; k < 9; ++k) om[k] = model[k];
+  fs->lo_nm = 1;
+}
+
+// LO step 3 (E only), lane per queued pair: the 5-point solver from the null-space basis on, the same device
+// functions as the minimal-sample kernels (k_solve_e_build / _lu / k_roots_e / k_models_score_e).
+__global__ __launch_bounds__(64, 2) void k_lo_e_build(const VerifyParams p) {
+  const uint32_t widx = blockIdx.x * 64u + threadIdx.x;
+  if (widx >= p.n_work) return;
+  const uint32_t pl = p.worklist[widx];
+  double Eb[36];
+  const double* slot = p.lo_slots + (size_t)pl * 90;
+  for (int k = 0; k < 36; ++k) Eb[k] = slot[EPOLY_EB + k];
+  five_point_build_A_rows(Eb, p.lo_ework + (size_t)pl * 200);
+}
+__global__ __launch_bounds__(64) void k_lo_e_lu(const VerifyParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* Al = reinterpret_cast<double*>(smem_raw) + threadIdx.x;
+  unsigned char* idx = smem_raw + 100 * 64 * 8 + threadIdx.x;
+  const uint32_t widx = blockIdx.x * 64u + threadIdx.x;
+  if (widx >= p.n_work) return;
+  const uint32_t pl = p.worklist[widx];
+  e_lu_body(p.lo_ework + (size_t)pl * 200, p.lo_slots + (size_t)pl * 90, Al, idx);
+}
+__global__ __launch_bounds__(64) void k_lo_e_roots_models(const VerifyParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* Tl = reinterpret_cast<double*>(smem_raw) + threadIdx.x;
+  const uint32_t widx = blockIdx.x * 64u + threadIdx.x;
+  if (widx >= p.n_work) return;
+  const uint32_t pl = p.worklist[widx];
+  const uint32_t pi = p.pair0 + pl;
+  double* slot = p.lo_slots + (size_t)pl * 90;
+  const int code = e_roots_body(slot, Tl);
+  double mloc[90];
+  const int nm = e_models_body(slot, code, mloc);
+  double* om = p.lo_models + (size_t)pl * 90;
+  for (int k = 0; k < nm * 9; ++k) om[k] = mloc[k];
+  p.fam_state[(size_t)pi * 3 + FAM_E].lo_nm = (uint32_t)nm;
+}
+
+void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st) {
+  if (!p.n_work || !n_blocks) return;
+  const size_t smem = ((offsetof(VSmem, gen) + 15) / 16) * 16;
+  if (fam == FAM_E) hipLaunchKernelGGL(k_replay_lo<FAM_E>, dim3(n_blocks), dim3(64), smem, st, p);
+  if (fam == FAM_F) hipLaunchKernelGGL(k_replay_lo<FAM_F>, dim3(n_blocks), dim3(64), smem, st, p);
+  if (fam == FAM_H) hipLaunchKernelGGL(k_replay_lo<FAM_H>, dim3(n_blocks), dim3(64), smem, st, p);
+}
+void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st) {
+  if (!p.n_work || !n_blocks) return;
+  const uint32_t nb_prep = p.n_work < n_blocks ? p.n_work : n_blocks;  // one scratch area per workgroup (wg_scratch)
+  const dim3 g4((p.n_work + 3) / 4), g64((p.n_work + 63) / 64);
+  if (fam == FAM_E) {
+    hipLaunchKernelGGL(k_lo_prepare<FAM_E>, dim3(nb_prep), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(k_lo_jacobi<FAM_E>, g4, dim3(64), 0, st, p);
+    hipLaunchKernelGGL(k_lo_e_build, g64, dim3(64), 0, st, p);
+    hipLaunchKernelGGL(k_lo_e_lu, g64, dim3(64), ELU_SMEM, st, p);
+    hipLaunchKernelGGL(k_lo_e_roots_models, g64, dim3(64), 100 * 64 * sizeof(double), st, p);
+  }
+  if (fam == FAM_F) {
+    hipLaunchKernelGGL(k_lo_prepare<FAM_F>, dim3(nb_prep), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(k_lo_jacobi<FAM_F>, g4, dim3(64), 0, st, p);
+  }
+  if (fam == FAM_H) {
+    hipLaunchKernelGGL(k_lo_prepare<FAM_H>, dim3(nb_prep), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(k_lo_jacobi<FAM_H>, g4, dim3(64), 0, st, p);
   }
 }
 

@@ -1048,7 +1048,9 @@ __device__ unsigned long long g_dsm_prof[16];
 #define LSEC_BEGIN5() do {} while (0)
 #define LSEC_END5(sec) do {} while (0)
 #endif
-DSM_DEV void wv_svd_V_mx9(double* A, double* At, int m, WvSvdShared* sh, double* sv, int lane) {
+// First half: everything up to the Jacobi sweeps -- leaves the square working matrix in sh->W (dsz x dsz, column-major
+// ld = dsz) and the accumulated right factor in sh->V; returns dsz, *scale_out = the scaling factor.
+DSM_DEV int wv_svd_prepare_mx9(double* A, double* At, int m, WvSvdShared* sh, double* scale_out, int lane) {
   // scale = max |a_ij| (exact, order independent)
   double mxl = 0.0;
   for (int e = lane; e < 9 * m; e += 64) {
@@ -1061,6 +1063,7 @@ DSM_DEV void wv_svd_V_mx9(double* A, double* At, int m, WvSvdShared* sh, double*
   }
   double scale = mxl;
   if (scale == 0.0) scale = 1.0;
+  *scale_out = scale;
   wv_sync();
   if (m > 9) {
     for (int e = lane; e < 9 * m; e += 64) A[e] /= scale;
@@ -1078,11 +1081,7 @@ DSM_DEV void wv_svd_V_mx9(double* A, double* At, int m, WvSvdShared* sh, double*
     wv_sync();
     if (lane < 9) sh->V[lane * 9 + sh->perm[lane]] = 1.0;
     wv_sync();
-    {
-      LSEC_BEGIN();
-      wv_jacobi_sweeps(sh, 9, scale, sv, lane);
-      LSEC_END(5);
-    }
+    return 9;
   } else if (m < 9) {
     for (int e = lane; e < 9 * m; e += 64) {
       const int i = e % m, j = e / m;  // A(i, j)
@@ -1116,14 +1115,96 @@ DSM_DEV void wv_svd_V_mx9(double* A, double* At, int m, WvSvdShared* sh, double*
       for (int i = 0; i < 9; ++i) sh->V[lane * 9 + i] = q[i];
     }
     wv_sync();
-    wv_jacobi_sweeps(sh, m, scale, sv, lane);
-  } else {
-    for (int e = lane; e < 81; e += 64) {
-      sh->W[e] = A[e] / scale;
-      sh->V[e] = (e % 9 == e / 9) ? 1.0 : 0.0;
+    return m;
+  }
+  for (int e = lane; e < 81; e += 64) {
+    sh->W[e] = A[e] / scale;
+    sh->V[e] = (e % 9 == e / 9) ? 1.0 : 0.0;
+  }
+  wv_sync();
+  return 9;
+}
+
+DSM_DEV void wv_svd_V_mx9(double* A, double* At, int m, WvSvdShared* sh, double* sv, int lane) {
+  double scale;
+  const int dsz = wv_svd_prepare_mx9(A, At, m, sh, &scale, lane);
+  LSEC_BEGIN();
+  wv_jacobi_sweeps(sh, dsz, scale, sv, lane);
+  LSEC_END(5);
+}
+
+// The same sweeps (same rotations, same order, same arithmetic as wv_jacobi_sweeps) by a GROUP of 16 lanes that
+// owns one problem in LDS -- four problems per wave.  gl = lane within the group.  All lanes of a group read the
+// same LDS words and take the same branches; different groups of a wave diverge.  W, V, sv are the group's LDS
+// areas, accessed through volatile pointers: the instruction order of the wave is the only synchronisation that
+// the lanes of a group need (as in verify_fivept_coop.h).
+typedef volatile double* grp_vd;
+DSM_DEV void grp_jacobi_sweeps(grp_vd W, grp_vd V, int dsz, double scale, grp_vd sv, int gl) {
+  const double precision = 2.0 * DBL_EPSILON;
+  double max_diag = 0.0;
+  for (int i = 0; i < dsz; ++i) {
+    const double a = fabs(W[i * dsz + i]);
+    if (a > max_diag) max_diag = a;
+  }
+  bool finished = false;
+  while (!finished) {
+    finished = true;
+    for (int p = 1; p < dsz; ++p) {
+      for (int q = 0; q < p; ++q) {
+        const double thr = DBL_MIN > precision * max_diag ? DBL_MIN : precision * max_diag;
+        const double wpq = W[q * dsz + p], wqp = W[p * dsz + q];
+        if (fabs(wpq) > thr || fabs(wqp) > thr) {
+          finished = false;
+          double lc, ls, rc, rs;
+          dsm_jacobi_2x2(W[p * dsz + p], wpq, wqp, W[q * dsz + q], &lc, &ls, &rc, &rs);
+          if (!(lc == 1.0 && ls == 0.0)) {
+            if (gl < dsz) {  // rows p, q: element (p, gl), (q, gl)
+              const double xi = W[gl * dsz + p], yi = W[gl * dsz + q];
+              W[gl * dsz + p] = lc * xi + ls * yi;
+              W[gl * dsz + q] = -ls * xi + lc * yi;
+            }
+          }
+          if (!(rc == 1.0 && -rs == 0.0)) {
+            if (gl < dsz) {  // columns p, q of W
+              const double xi = W[p * dsz + gl], yi = W[q * dsz + gl];
+              W[p * dsz + gl] = rc * xi + (-rs) * yi;
+              W[q * dsz + gl] = rs * xi + rc * yi;
+            }
+            if (gl < 9) {  // columns p, q of V (9 rows)
+              const double xi = V[p * 9 + gl], yi = V[q * 9 + gl];
+              V[p * 9 + gl] = rc * xi + (-rs) * yi;
+              V[q * 9 + gl] = rs * xi + rc * yi;
+            }
+          }
+          const double app = fabs(W[p * dsz + p]), aqq = fabs(W[q * dsz + q]);
+          const double mm = app > aqq ? app : aqq;
+          if (mm > max_diag) max_diag = mm;
+        }
+      }
     }
-    wv_sync();
-    wv_jacobi_sweeps(sh, 9, scale, sv, lane);
+  }
+  if (gl == 0) {
+    for (int i = 0; i < dsz; ++i) sv[i] = fabs(W[i * dsz + i]) * scale;
+    for (int i = 0; i < dsz; ++i) {
+      int pos = i;
+      double mx = sv[i];
+      for (int j = i + 1; j < dsz; ++j)
+        if (sv[j] > mx) {
+          mx = sv[j];
+          pos = j;
+        }
+      if (mx == 0.0) break;
+      if (pos != i) {
+        double t = sv[i];
+        sv[i] = sv[pos];
+        sv[pos] = t;
+        for (int r = 0; r < 9; ++r) {
+          t = V[i * 9 + r];
+          V[i * 9 + r] = V[pos * 9 + r];
+          V[pos * 9 + r] = t;
+        }
+      }
+    }
   }
 }
 
