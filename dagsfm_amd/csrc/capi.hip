@@ -795,8 +795,23 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     }
     const uint64_t per_pair = (uint64_t)bmax * (7 * 4 + 4 + 4) + bm_max * (4 + 72) + (uint64_t)batch[0] * 200 * 8 +
                               (LO_WORK_DOUBLES + 90 + 90 + 200) * 8 + 8;
-    const uint64_t budget = 16ull << 30;
-    const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_pairs, budget / per_pair));
+    // Scratch of the speculated trials: as much of the pair list per chunk as memory allows (every chunk pays the
+    // latency tail of its sequential rounds, so fewer chunks are faster): up to 40 % of what is free now, at
+    // least 4 GiB, at most 96 GiB (config 2 needs 38 GiB for one chunk; an MI355X has 288 GB).
+    uint64_t budget = 16ull << 30;
+    {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        uint64_t have = 0;  // buffers of an earlier call are reused, not allocated again
+        for (DevBuf* b : {&ctx->d_samples, &ctx->d_draws_end, &ctx->d_nmodels, &ctx->d_vcounts, &ctx->d_models, &ctx->d_ework,
+                          &ctx->d_lo_work, &ctx->d_lo_models, &ctx->d_lo_slots, &ctx->d_lo_ework})
+          have += b->cap;
+        budget = std::min<uint64_t>(96ull << 30, std::max<uint64_t>(4ull << 30, (uint64_t)((free_b + have) * 0.4)));
+      }
+    }
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_pairs, budget / per_pair));
+    if (const char* cp = getenv("DSM_VERIFY_CHUNK_PAIRS"))  // test hook: force several chunks on a small pair list
+      chunk = std::max<uint32_t>(1, std::min<uint32_t>(chunk, (uint32_t)atoi(cp)));
     HIPCHK(ctx, ctx->d_fam_state.reserve(std::max<size_t>(n_pairs, 1) * 3 * sizeof(FamState)));
     HIPCHK(ctx, ctx->d_sidx.reserve(tm * 4));
     HIPCHK(ctx, ctx->d_active.reserve(128));

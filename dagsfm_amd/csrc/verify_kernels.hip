@@ -363,6 +363,35 @@ DSM_DEV double ordered_residual_sum(const PairWork& w, double max_residual) {
   return s;
 }
 
+// score_model(store) + ordered_residual_sum in one pass: the residuals stay in registers, and the in-order sum walks
+// only the inliers of every 64-chunk (ascending lane order = index order; the same additions in the same order as
+// the loop over all elements that skips the outliers).  resid[] is still written for the compaction / final mask.
+template <int FAM>
+DSM_DEV double score_and_sum(const PairWork& w, const double* M, double max_residual, uint32_t* count_out) {
+  double s = 0;
+  uint32_t count = 0;
+  for (int base = 0; base < w.n; base += 64) {
+    const int i = base + w.lane;
+    bool in = false;
+    double r = 0.0;
+    if (i < w.n) {
+      r = fam_residual<FAM>(M, w.pts + (size_t)i * 4);
+      w.resid[i] = r;
+      in = r <= max_residual;
+    }
+    unsigned long long mask = __ballot(in);
+    count += (uint32_t)__popcll(mask);
+    while (mask) {
+      const int k = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      s += wv_readlane_f64(r, k);
+    }
+  }
+  wv_sync();
+  *count_out = count;
+  return s;
+}
+
 // ordered compaction of the inliers of resid[] into inl[]; returns the count
 DSM_DEV int compact_inliers(const PairWork& w, double max_residual) {
   int total = 0;
@@ -2040,8 +2069,8 @@ __global__ __launch_bounds__(64, 4) void k_replay_lo(const VerifyParams p) {
         num_models += 1;
         double M[9];
         for (int k = 0; k < 9; ++k) M[k] = lom[l * 9 + k];
-        const uint32_t lc = (uint32_t)score_model<FAM>(w, M, max_residual, true);
-        const double lsum = ordered_residual_sum(w, max_residual);
+        uint32_t lc;
+        const double lsum = score_and_sum<FAM>(w, M, max_residual, &lc);
         if (lc > best_n || (lc == best_n && lsum < best_sum)) {
           best_n = lc;
           best_sum = lsum;
@@ -2093,8 +2122,8 @@ __global__ __launch_bounds__(64, 4) void k_replay_lo(const VerifyParams p) {
         const double* M = mods + ((size_t)t * F::MAXM + m) * 9;
         if (cnt >= best_n) {
           if (lane == 0) atomicAdd(p.active_count + 1 + FAM * 2, 1u);
-          score_model<FAM>(w, M, max_residual, true);
-          const double sum = ordered_residual_sum(w, max_residual);
+          uint32_t cnt_again;
+          const double sum = score_and_sum<FAM>(w, M, max_residual, &cnt_again);
           if (cnt > best_n || (cnt == best_n && sum < best_sum)) {
             best_n = cnt;
             best_sum = sum;

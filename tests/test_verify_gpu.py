@@ -107,7 +107,8 @@ def test_watermark_configuration(dsm, oracle):
     assert (got_inl == ref_inl).all()
 
 
-@pytest.mark.parametrize("prior,sampler_serial,legacy", [(0, False, False), (1, False, False), (1, True, False), (1, False, True)])
+@pytest.mark.parametrize("prior,sampler_serial,legacy", [(0, False, False), (1, False, False), (1, True, False), (1, False, True),
+                                                         (1, False, "inline_lo"), (0, False, "inline_lo"), (1, False, "chunks")])
 def test_stage_match_and_verify_many_pairs(dsm, oracle, prior, sampler_serial, legacy, monkeypatch):
     """dsm_match_pairs + dsm_verify_pairs over an exhaustive pair list == oracle matcher + oracle verifier
     with SiftFeatureMatcher::Match's post-filter (matching.cc:824-831).  sampler_serial forces the sampler's
@@ -115,7 +116,11 @@ def test_stage_match_and_verify_many_pairs(dsm, oracle, prior, sampler_serial, l
     schedule (DSM_VERIFY_LEGACY)."""
     if sampler_serial:
         monkeypatch.setenv("DSM_SAMPLER_SERIAL", "1")
-    if legacy:  # the first schedule of this round: one k_ransac kernel per family, wave per pair
+    if legacy == "chunks":  # several chunks of the pair list (one chunk is the rule on a 288 GB device)
+        monkeypatch.setenv("DSM_VERIFY_CHUNK_PAIRS", "5")
+    elif legacy == "inline_lo":  # phase-split pipeline with the local optimisation inline in the replay (round-1 schedule)
+        monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "1")
+    elif legacy:  # the first schedule of round 1: one k_ransac kernel per family, wave per pair
         monkeypatch.setenv("DSM_VERIFY_LEGACY", "1")
     n_img = 7
     scene = synthetic.Scene(n_img, 768, seed=21, n_pool=2048)
