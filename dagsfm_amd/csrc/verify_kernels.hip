@@ -2309,8 +2309,7 @@ __global__ __launch_bounds__(64, 4) void k_lo_prepare(const VerifyParams p) {
 }
 
 // LO step 2, a 16-lane group per queued pair (four per wave): the Jacobi sweeps of JacobiSVD on the 9 x 9 (or
-// smaller) problem, then the family's finish by the group's first lane: rank-2 projection + de-normalisation
-// (8-point F), de-normalisation (H), or the null-space basis handed to the flat 5-point kernels (E).
+// smaller) problem; the sorted right factor V goes back to the pair's record.
 #define LOJ_GROUP_DOUBLES (81 + 81 + 9)
 template <int FAM>
 __global__ __launch_bounds__(64) void k_lo_jacobi(const VerifyParams p) {
@@ -2320,8 +2319,6 @@ __global__ __launch_bounds__(64) void k_lo_jacobi(const VerifyParams p) {
   const uint32_t widx = blockIdx.x * 4u + (uint32_t)g;
   if (widx >= p.n_work) return;
   const uint32_t pl = p.worklist[widx];
-  const uint32_t pi = p.pair0 + pl;
-  FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
   const double* in = p.lo_work + (size_t)pl * LO_WORK_DOUBLES;
   grp_vd W = lds + g * LOJ_GROUP_DOUBLES;
   grp_vd V = W + 81;
@@ -2333,15 +2330,21 @@ __global__ __launch_bounds__(64) void k_lo_jacobi(const VerifyParams p) {
   const double scale = in[168];
   const int dsz = (int)in[169];
   grp_jacobi_sweeps(W, V, dsz, scale, sv, gl);
-  if (gl != 0) return;
-  if (FAM == FAM_E) {
-    double* slot = p.lo_slots + (size_t)pl * 90;
-    for (int r = 0; r < 9; ++r)
-      for (int c = 0; c < 4; ++c) slot[EPOLY_EB + r * 4 + c] = V[(5 + c) * 9 + r];  // Eb[r*4 + c] = V(r, 5 + c)
-    return;
-  }
+  double* outV = p.lo_work + (size_t)pl * LO_WORK_DOUBLES + 81;  // sorted right factor back to the pair's record
+  for (int e = gl; e < 81; e += 16) outV[e] = V[e];
+}
+
+// LO step 2b (F, H), lane per queued pair: the family's finish on the null vector V(:, 8) -- rank-2 projection +
+// de-normalisation (8-point F, fundamental_matrix.cc:172-191) or de-normalisation (H, homography_matrix.cc:86-91).
+template <int FAM>
+__global__ __launch_bounds__(64) void k_lo_finish(const VerifyParams p) {
+  const uint32_t widx = blockIdx.x * 64u + threadIdx.x;
+  if (widx >= p.n_work) return;
+  const uint32_t pl = p.worklist[widx];
+  const uint32_t pi = p.pair0 + pl;
+  const double* in = p.lo_work + (size_t)pl * LO_WORK_DOUBLES;
   double nv[9], n1[3], n2[3], model[9];
-  for (int k = 0; k < 9; ++k) nv[k] = V[8 * 9 + k];
+  for (int k = 0; k < 9; ++k) nv[k] = in[81 + 8 * 9 + k];
   for (int k = 0; k < 3; ++k) {
     n1[k] = in[162 + k];
     n2[k] = in[165 + k];
@@ -2352,7 +2355,7 @@ __global__ __launch_bounds__(64) void k_lo_jacobi(const VerifyParams p) {
     homography_finish(nv, n1, n2, model);
   double* om = p.lo_models + (size_t)pl * 90;
   for (int k = 0; k < 9; ++k) om[k] = model[k];
-  fs->lo_nm = 1;
+  p.fam_state[(size_t)pi * 3 + FAM].lo_nm = 1;
 }
 
 // LO step 3 (E only), lane per queued pair: the 5-point solver from the null-space basis on, the same device
@@ -2362,8 +2365,11 @@ __global__ __launch_bounds__(64, 2) void k_lo_e_build(const VerifyParams p) {
   if (widx >= p.n_work) return;
   const uint32_t pl = p.worklist[widx];
   double Eb[36];
-  const double* slot = p.lo_slots + (size_t)pl * 90;
-  for (int k = 0; k < 36; ++k) Eb[k] = slot[EPOLY_EB + k];
+  const double* V = p.lo_work + (size_t)pl * LO_WORK_DOUBLES + 81;
+  double* slot = p.lo_slots + (size_t)pl * 90;
+  for (int r = 0; r < 9; ++r)
+    for (int c = 0; c < 4; ++c) Eb[r * 4 + c] = V[(5 + c) * 9 + r];  // Eb[r*4 + c] = V(r, 5 + c), essential_matrix.cc:72-74
+  for (int k = 0; k < 36; ++k) slot[EPOLY_EB + k] = Eb[k];
   five_point_build_A_rows(Eb, p.lo_ework + (size_t)pl * 200);
 }
 __global__ __launch_bounds__(64) void k_lo_e_lu(const VerifyParams p) {
@@ -2412,10 +2418,12 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, hipS
   if (fam == FAM_F) {
     hipLaunchKernelGGL(k_lo_prepare<FAM_F>, dim3(nb_prep), dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_lo_jacobi<FAM_F>, g4, dim3(64), 0, st, p);
+    hipLaunchKernelGGL(k_lo_finish<FAM_F>, g64, dim3(64), 0, st, p);
   }
   if (fam == FAM_H) {
     hipLaunchKernelGGL(k_lo_prepare<FAM_H>, dim3(nb_prep), dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_lo_jacobi<FAM_H>, g4, dim3(64), 0, st, p);
+    hipLaunchKernelGGL(k_lo_finish<FAM_H>, g64, dim3(64), 0, st, p);
   }
 }
 
