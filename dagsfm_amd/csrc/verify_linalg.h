@@ -86,68 +86,6 @@ DSM_DEV void pl_apply_householder_right(double* M, int ld, int r0, int c0, int n
   }
 }
 
-// The two reflector applications of a Francis step for a matrix in lane-interleaved LDS (ES > 1): NR (left) / NC
-// (right) is 2 or 3, the other extent is dynamic but at most LD.  Every element is read before any is written and
-// the loops are unrolled with a per-lane guard, so the compiler issues the (up to 3 * LD) LDS reads back to back
-// and waits once instead of once per column -- the kernel that runs these is bound by exactly that latency.
-// Per element the operations and their order are those of pl_apply_householder_left / _right.
-template <int LD, int ES, int NR>
-DSM_DEV void pl_hh_left_batched(double* M, int r0, int c0, int nc, const double* ess, double tau) {
-  if (tau == 0.0) return;
-  double x[NR][LD];
-#pragma unroll
-  for (int j = 0; j < LD; ++j)
-    if (j < nc) {
-#pragma unroll
-      for (int i = 0; i < NR; ++i) x[i][j] = M[((c0 + j) * LD + r0 + i) * ES];
-    }
-#pragma unroll
-  for (int j = 0; j < LD; ++j)
-    if (j < nc) {
-      double tmp = 0.0;
-#pragma unroll
-      for (int i = 1; i < NR; ++i) tmp += ess[i - 1] * x[i][j];
-      tmp += x[0][j];
-      x[0][j] -= tau * tmp;
-#pragma unroll
-      for (int i = 1; i < NR; ++i) x[i][j] -= tau * ess[i - 1] * tmp;
-    }
-#pragma unroll
-  for (int j = 0; j < LD; ++j)
-    if (j < nc) {
-#pragma unroll
-      for (int i = 0; i < NR; ++i) M[((c0 + j) * LD + r0 + i) * ES] = x[i][j];
-    }
-}
-template <int LD, int ES, int NC>
-DSM_DEV void pl_hh_right_batched(double* M, int r0, int c0, int nr, const double* ess, double tau) {
-  if (tau == 0.0) return;
-  double x[LD][NC];
-#pragma unroll
-  for (int i = 0; i < LD; ++i)
-    if (i < nr) {
-#pragma unroll
-      for (int j = 0; j < NC; ++j) x[i][j] = M[((c0 + j) * LD + r0 + i) * ES];
-    }
-#pragma unroll
-  for (int i = 0; i < LD; ++i)
-    if (i < nr) {
-      double tmp = 0.0;
-#pragma unroll
-      for (int j = 1; j < NC; ++j) tmp += x[i][j] * ess[j - 1];
-      tmp += x[i][0];
-      x[i][0] -= tau * tmp;
-#pragma unroll
-      for (int j = 1; j < NC; ++j) x[i][j] -= tau * tmp * ess[j - 1];
-    }
-#pragma unroll
-  for (int i = 0; i < LD; ++i)
-    if (i < nr) {
-#pragma unroll
-      for (int j = 0; j < NC; ++j) M[((c0 + j) * LD + r0 + i) * ES] = x[i][j];
-    }
-}
-
 // ColPivHouseholderQR::computeInPlace on qr (rows x cols, rows >= cols here), ld = rows.
 template <int ES = 1>
 DSM_DEV void pl_colpiv_qr(double* qr, int rows, int cols, double* hcoeffs) {
@@ -540,14 +478,9 @@ DSM_DEV bool pl_hessenberg_eigenvalues_impl(double* T, int n, double* re, double
               TT(k, k - 1) = -TT(k, k - 1);
             else if (!first)
               TT(k, k - 1) = beta;
+            pl_apply_householder_left<ES>(T, LD, k, k, 3, (VALUES_ONLY ? iu + 1 : n) - k, &v[1], tau);
             const int nr = ((iu < k + 3) ? iu : k + 3) + 1;
-            if constexpr (ES == 1) {
-              pl_apply_householder_left<ES>(T, LD, k, k, 3, (VALUES_ONLY ? iu + 1 : n) - k, &v[1], tau);
-              pl_apply_householder_right<ES>(T, LD, 0, k, nr, 3, &v[1], tau);
-            } else {
-              pl_hh_left_batched<LD, ES, 3>(T, k, k, (VALUES_ONLY ? iu + 1 : n) - k, &v[1], tau);
-              pl_hh_right_batched<LD, ES, 3>(T, 0, k, nr, &v[1], tau);
-            }
+            pl_apply_householder_right<ES>(T, LD, 0, k, nr, 3, &v[1], tau);
           }
         }
         {
@@ -556,13 +489,8 @@ DSM_DEV bool pl_hessenberg_eigenvalues_impl(double* T, int n, double* re, double
           pl_make_householder(v, 2, &tau, &beta);
           if (beta != 0.0) {
             TT(iu - 1, iu - 2) = beta;
-            if constexpr (ES == 1) {
-              pl_apply_householder_left<ES>(T, LD, iu - 1, iu - 1, 2, (VALUES_ONLY ? iu + 1 : n) - iu + 1, &v[1], tau);
-              pl_apply_householder_right<ES>(T, LD, 0, iu - 1, iu + 1, 2, &v[1], tau);
-            } else {
-              pl_hh_left_batched<LD, ES, 2>(T, iu - 1, iu - 1, (VALUES_ONLY ? iu + 1 : n) - iu + 1, &v[1], tau);
-              pl_hh_right_batched<LD, ES, 2>(T, 0, iu - 1, iu + 1, &v[1], tau);
-            }
+            pl_apply_householder_left<ES>(T, LD, iu - 1, iu - 1, 2, (VALUES_ONLY ? iu + 1 : n) - iu + 1, &v[1], tau);
+            pl_apply_householder_right<ES>(T, LD, 0, iu - 1, iu + 1, 2, &v[1], tau);
           }
         }
         for (int i = imm + 2; i <= iu; ++i) {
