@@ -435,11 +435,16 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
       HIPCHK(ctx, hipEventCreate(&e));
       ctx->ev.push_back(e);
     }
+    // DSM_K1_DOT4=1: the LDS-tiled v_dot4 variant of pass 1 (comparison runs only, profiles/r02_k1_variants.md)
+    const bool k1_dot4 = getenv("DSM_K1_DOT4") != nullptr;
     HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used], st));
-    launch_k1(k1, nc, max_rb, st);
+    if (k1_dot4)
+      launch_k1_dot4(k1, nc, max_rb, st);
+    else
+      launch_k1(k1, nc, max_rb, st);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 1], st));
-    launch_k1_resolve(k1, nc, max_rb, st);
+    if (!k1_dot4) launch_k1_resolve(k1, nc, max_rb, st);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 2], st));
     if (max_rb) ctx->k1_launches++;

@@ -173,6 +173,7 @@ void launch_compact_inliers(const uint64_t* match_off, const uint64_t* inl_off, 
 
 void launch_k0(const uint8_t* in_u8, int8_t* out_s8, int32_t* rterm, uint64_t n_rows, hipStream_t st);
 void launch_k1(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st);
+void launch_k1_dot4(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st);
 void launch_k1_resolve(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st);
 void launch_k2(const K2Params& p, uint32_t n_pairs, bool write, hipStream_t st);
 void launch_k2_entries(const K2eParams& p, uint32_t n_pairs, bool write, hipStream_t st);

@@ -373,6 +373,104 @@ __global__ __launch_bounds__(256) void k1_resolve_index(const K1Params p) {
   }
 }
 
+// ------------------------------------------------------------------------------------ K1-dot4 (comparison variant)
+// The LDS-tiled VALU form of pass 1 that BASELINE.json configs[1]/[2] name ("int8 LDS-tiled distance kernel" vs "MFMA
+// int8 distance GEMM"): thread = one row of image a with its 128-byte descriptor in 32 registers, the columns of
+// image b stream through LDS in 64-column tiles and every lane reads the same column (LDS broadcast), 32
+// v_dot4_i32_i8 per element, then the reference's own scan (strict >, ascending columns: sift.cc:119-133), so the
+// exact column index falls out directly and k1_resolve_index is not needed.  Kept behind DSM_K1_DOT4=1 for the
+// rocprof comparison in profiles/ (it is ~5x slower than the MFMA kernel: 34 VALU per matrix element against
+// 1.4); same results bit for bit.
+__global__ __launch_bounds__(256) void k1_best_rows_dot4(const K1Params p) {
+  const uint32_t d = p.order ? p.order[blockIdx.x] : blockIdx.x;
+  const uint32_t rb = blockIdx.y;
+  const uint2 ab = p.dpairs[d];
+  const uint32_t a_rows = p.img_rows[ab.x];
+  if (rb * 512u >= a_rows) return;
+  const uint32_t b_cols = p.img_rows[ab.y];
+  const uint32_t a_row0 = p.img_row0[ab.x], b_row0 = p.img_row0[ab.y];
+  const int tid = threadIdx.x;
+  // two rows per thread (register blocking: one LDS read of a column feeds 64 v_dot4 instead of 32, which moves the
+  // kernel from LDS-bound to VALU-bound); images are padded to 256 rows, so the second row may not exist
+  const uint32_t row[2] = {rb * 512u + tid, rb * 512u + 256u + tid};
+  const bool has2 = row[1] < a_rows;
+  __shared__ __attribute__((aligned(16))) int8_t sB[2][64 * 128];
+  __shared__ int sR[2][64];
+  v4i a[2][8];
+  int rterm_i[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const uint32_t rr = (r == 0 || has2) ? row[r] : row[0];
+    const int8_t* arow = p.desc + (size_t)(a_row0 + rr) * 128;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a[r][c] = *reinterpret_cast<const v4i*>(arow + c * 16);
+    rterm_i[r] = p.rterm[a_row0 + rr];
+  }
+  int best[2] = {0, 0}, second[2] = {0, 0}, best_j[2] = {-1, -1};
+  const uint32_t nsteps = b_cols >> 6;
+  v4i st[2];
+  int sr = 0;
+  auto fetch = [&](uint32_t s) {  // global -> registers (consumed after the step's arithmetic)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      st[u] = *reinterpret_cast<const v4i*>(p.desc + (size_t)(b_row0 + s * 64) * 128 + (size_t)(tid + 256 * u) * 16);
+    sr = p.rterm[b_row0 + s * 64 + (tid & 63)];
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) *reinterpret_cast<v4i*>(&sB[buf][(tid + 256 * u) * 16]) = st[u];
+    if (tid < 64) sR[buf][tid] = sr;
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (uint32_t s = 0; s < nsteps; ++s) {
+    const int cur = s & 1;
+    const bool more = s + 1 < nsteps;
+    if (more) fetch(s + 1);
+    for (int j = 0; j < 64; ++j) {
+      int acc[2] = {0, 0};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const v4i b = *reinterpret_cast<const v4i*>(&sB[cur][j * 128 + c * 16]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0] = __builtin_amdgcn_sdot4(a[0][c][e], b[e], acc[0], false);
+          acc[1] = __builtin_amdgcn_sdot4(a[1][c][e], b[e], acc[1], false);
+        }
+      }
+      const int cterm = sR[cur][j] + (1 << 21);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int dist = acc[r] + rterm_i[r] + cterm;
+        if (dist > best[r]) {  // sift.cc:126-132
+          second[r] = best[r];
+          best[r] = dist;
+          best_j[r] = (int)(s * 64 + j);
+        } else if (dist > second[r]) {
+          second[r] = dist;
+        }
+      }
+    }
+    if (more) commit(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (r == 1 && !has2) break;
+    int res = -1;
+    if (best_j[r] >= 0) {
+      const float bn = p.lut[min(best[r], 262144)];
+      if (!(bn > p.max_distance)) {
+        const float sn = p.lut[min(second[r], 262144)];
+        const float rhs = __fmul_rn(p.max_ratio, sn);
+        if (!(bn >= rhs)) res = best_j[r];
+      }
+    }
+    p.out[p.d_out_off[d] + row[r]] = res;
+  }
+}
+
 // ------------------------------------------------------------------------------------ KG (guided matching)
 // The guided filters of MatchGuidedSiftFeaturesCPU (sift.cc:838-866) in float, same operation order as
 // oracle_guided_filter (oracle/sift_match.c): true = the keypoint pair violates the geometry.
@@ -617,6 +715,11 @@ void launch_k1(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, 
     hipLaunchKernelGGL(k1_best_rows<true>, dim3(n_directed, (max_row_blocks + 1) / 2), dim3(256), 0, st, p);
   else
     hipLaunchKernelGGL(k1_best_rows<false>, dim3(n_directed, (max_row_blocks + 1) / 2), dim3(256), 0, st, p);
+}
+// comparison variant (DSM_K1_DOT4): pass 1 on the VALU; writes exact column indices, no resolve pass
+void launch_k1_dot4(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st) {
+  if (n_directed == 0 || max_row_blocks == 0) return;
+  hipLaunchKernelGGL(k1_best_rows_dot4, dim3(n_directed, (max_row_blocks + 1) / 2), dim3(256), 0, st, p);
 }
 void launch_k1_resolve(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st) {
   if (n_directed == 0 || max_row_blocks == 0) return;

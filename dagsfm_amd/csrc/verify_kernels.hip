@@ -2308,30 +2308,31 @@ __global__ __launch_bounds__(64, 4) void k_lo_prepare(const VerifyParams p) {
   }
 }
 
-// LO step 2, a 16-lane group per queued pair (four per wave): the Jacobi sweeps of JacobiSVD on the 9 x 9 (or
+// LO step 2, a group of LOJ_G lanes per queued pair (64 / LOJ_G pairs per wave): the Jacobi sweeps of JacobiSVD on the 9 x 9 (or
 // smaller) problem; the sorted right factor V goes back to the pair's record.
 #define LOJ_GROUP_DOUBLES (81 + 81 + 9)
+#define LOJ_G 8  // lanes per problem
 template <int FAM>
 __global__ __launch_bounds__(64) void k_lo_jacobi(const VerifyParams p) {
-  __shared__ double lds[4 * LOJ_GROUP_DOUBLES];
+  __shared__ double lds[(64 / LOJ_G) * LOJ_GROUP_DOUBLES];
   const int lane = threadIdx.x;
-  const int g = lane >> 4, gl = lane & 15;
-  const uint32_t widx = blockIdx.x * 4u + (uint32_t)g;
+  const int g = lane / LOJ_G, gl = lane % LOJ_G;
+  const uint32_t widx = blockIdx.x * (uint32_t)(64 / LOJ_G) + (uint32_t)g;
   if (widx >= p.n_work) return;
   const uint32_t pl = p.worklist[widx];
   const double* in = p.lo_work + (size_t)pl * LO_WORK_DOUBLES;
   grp_vd W = lds + g * LOJ_GROUP_DOUBLES;
   grp_vd V = W + 81;
   grp_vd sv = V + 81;
-  for (int e = gl; e < 81; e += 16) {
+  for (int e = gl; e < 81; e += LOJ_G) {
     W[e] = in[e];
     V[e] = in[81 + e];
   }
   const double scale = in[168];
   const int dsz = (int)in[169];
-  grp_jacobi_sweeps(W, V, dsz, scale, sv, gl);
+  grp_jacobi_sweeps<LOJ_G>(W, V, dsz, scale, sv, gl);
   double* outV = p.lo_work + (size_t)pl * LO_WORK_DOUBLES + 81;  // sorted right factor back to the pair's record
-  for (int e = gl; e < 81; e += 16) outV[e] = V[e];
+  for (int e = gl; e < 81; e += LOJ_G) outV[e] = V[e];
 }
 
 // LO step 2b (F, H), lane per queued pair: the family's finish on the null vector V(:, 8) -- rank-2 projection +
@@ -2407,7 +2408,7 @@ void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, hipS
 void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st) {
   if (!p.n_work || !n_blocks) return;
   const uint32_t nb_prep = p.n_work < n_blocks ? p.n_work : n_blocks;  // one scratch area per workgroup (wg_scratch)
-  const dim3 g4((p.n_work + 3) / 4), g64((p.n_work + 63) / 64);
+  const dim3 g4((p.n_work + 64 / LOJ_G - 1) / (64 / LOJ_G)), g64((p.n_work + 63) / 64);
   if (fam == FAM_E) {
     hipLaunchKernelGGL(k_lo_prepare<FAM_E>, dim3(nb_prep), dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_lo_jacobi<FAM_E>, g4, dim3(64), 0, st, p);

@@ -1133,12 +1133,16 @@ DSM_DEV void wv_svd_V_mx9(double* A, double* At, int m, WvSvdShared* sh, double*
   LSEC_END(5);
 }
 
-// The same sweeps (same rotations, same order, same arithmetic as wv_jacobi_sweeps) by a GROUP of 16 lanes that
-// owns one problem in LDS -- four problems per wave.  gl = lane within the group.  All lanes of a group read the
+// The same sweeps (same rotations, same order, same arithmetic as wv_jacobi_sweeps) by a GROUP of G lanes that
+// owns one problem in LDS -- 64 / G problems per wave.  The 2 x 2 rotation (five divisions and three square roots
+// in a dependent chain, ~200 instructions) is what a sweep costs; it is computed once per wave instruction for
+// all groups, so the wave's cost per rotation hardly depends on G while its yield is 64 / G problems.  gl = lane
+// within the group; lane gl updates elements gl, gl + G, ... of the two rows / columns.  All lanes of a group read the
 // same LDS words and take the same branches; different groups of a wave diverge.  W, V, sv are the group's LDS
 // areas, accessed through volatile pointers: the instruction order of the wave is the only synchronisation that
 // the lanes of a group need (as in verify_fivept_coop.h).
 typedef volatile double* grp_vd;
+template <int G>
 DSM_DEV void grp_jacobi_sweeps(grp_vd W, grp_vd V, int dsz, double scale, grp_vd sv, int gl) {
   const double precision = 2.0 * DBL_EPSILON;
   double max_diag = 0.0;
@@ -1158,22 +1162,22 @@ DSM_DEV void grp_jacobi_sweeps(grp_vd W, grp_vd V, int dsz, double scale, grp_vd
           double lc, ls, rc, rs;
           dsm_jacobi_2x2(W[p * dsz + p], wpq, wqp, W[q * dsz + q], &lc, &ls, &rc, &rs);
           if (!(lc == 1.0 && ls == 0.0)) {
-            if (gl < dsz) {  // rows p, q: element (p, gl), (q, gl)
-              const double xi = W[gl * dsz + p], yi = W[gl * dsz + q];
-              W[gl * dsz + p] = lc * xi + ls * yi;
-              W[gl * dsz + q] = -ls * xi + lc * yi;
+            for (int e = gl; e < dsz; e += G) {  // rows p, q: elements (p, e), (q, e)
+              const double xi = W[e * dsz + p], yi = W[e * dsz + q];
+              W[e * dsz + p] = lc * xi + ls * yi;
+              W[e * dsz + q] = -ls * xi + lc * yi;
             }
           }
           if (!(rc == 1.0 && -rs == 0.0)) {
-            if (gl < dsz) {  // columns p, q of W
-              const double xi = W[p * dsz + gl], yi = W[q * dsz + gl];
-              W[p * dsz + gl] = rc * xi + (-rs) * yi;
-              W[q * dsz + gl] = rs * xi + rc * yi;
+            for (int e = gl; e < dsz; e += G) {  // columns p, q of W
+              const double xi = W[p * dsz + e], yi = W[q * dsz + e];
+              W[p * dsz + e] = rc * xi + (-rs) * yi;
+              W[q * dsz + e] = rs * xi + rc * yi;
             }
-            if (gl < 9) {  // columns p, q of V (9 rows)
-              const double xi = V[p * 9 + gl], yi = V[q * 9 + gl];
-              V[p * 9 + gl] = rc * xi + (-rs) * yi;
-              V[q * 9 + gl] = rs * xi + rc * yi;
+            for (int e = gl; e < 9; e += G) {  // columns p, q of V (9 rows)
+              const double xi = V[p * 9 + e], yi = V[q * 9 + e];
+              V[p * 9 + e] = rc * xi + (-rs) * yi;
+              V[q * 9 + e] = rs * xi + rc * yi;
             }
           }
           const double app = fabs(W[p * dsz + p]), aqq = fabs(W[q * dsz + q]);

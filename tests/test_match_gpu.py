@@ -191,3 +191,23 @@ def test_more_than_one_column_segment(dsm, oracle):
         check_equal(dsm.match_sift_features(d2, d1, o), oracle.match_sift_features_cpu(d2, d1, 0.8, 0.7, bool(cross)))
     o = capi.default_match_options(max_ratio=2.0, max_distance=3.0, cross_check=0)
     check_equal(dsm.match_sift_features(d1, d2, o), oracle.match_sift_features_cpu(d1, d2, 2.0, 3.0, False))
+
+
+def test_dot4_variant_matches_mfma_kernel(dsm, oracle, monkeypatch):
+    """DSM_K1_DOT4=1 (the LDS-tiled v_dot4 comparison variant of pass 1, profiles/r02_k1_variants.md) produces the
+    same matches as the MFMA kernel and the oracle, ragged sizes included."""
+    from dagsfm_amd import synthetic
+    scene = synthetic.Scene(4, 700, seed=12, n_pool=1500)
+    ims = [scene.image(i) for i in range(4)]
+    descs = [ims[0][0], ims[1][0][:513], ims[2][0][:255], ims[3][0]]
+    pairs = synthetic.exhaustive_pairs(4)
+    dsm.set_images(descs)
+    dsm.match_pairs(pairs)
+    offs0, m0 = dsm.matches()
+    monkeypatch.setenv("DSM_K1_DOT4", "1")
+    dsm.match_pairs(pairs)
+    offs1, m1 = dsm.matches()
+    assert (offs0 == offs1).all() and (m0 == m1).all() and len(m0) > 100
+    ref = oracle.match_sift_features_cpu(descs[0], descs[3])
+    k = [tuple(p) for p in pairs].index((0, 3))
+    assert (m1[int(offs1[k]):int(offs1[k + 1])] == ref).all()
