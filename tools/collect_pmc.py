@@ -21,11 +21,19 @@ out_dir = os.path.join(ROOT, "gpurun_out", "pmc")
 os.makedirs(out_dir, exist_ok=True)
 argv = sys.argv[1:]
 util = "--util" in argv
-argv = [a for a in argv if a != "--util"]
+util1 = "--util1" in argv  # only the MFMA / VALU instruction and busy counters
+tag_out = None
+if "--out" in argv:
+    tag_out = argv[argv.index("--out") + 1]
+    del argv[argv.index("--out"):argv.index("--out") + 2]
+argv = [a for a in argv if a not in ("--util", "--util1")]
 bench_args = argv or ["--steps", "1", "--warmup", "0", "--cpu-seconds", "0"]
 res = {"bench_args": bench_args}
 env = dict(os.environ, TMPDIR="/tmp")
 passes = [("FETCH_SIZE",), ("WRITE_SIZE",)]
+if util1:
+    passes += [("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_I8", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU",
+                "SQ_INSTS_LDS", "SQ_WAVE_CYCLES")]
 if util:
     passes += [("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_I8"),
                ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"),
@@ -47,6 +55,11 @@ for counters in passes:
     with open(os.path.join(out_dir, tag + ".log"), "w") as log:
         subprocess.run(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, check=False)
     acc = {}
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):  # durations of the same dispatches
+        for row in csv.DictReader(open(f)):
+            k = kname(row)
+            if k is not None:
+                res.setdefault("duration_ms_" + tag, {}).setdefault(k, []).append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             k = kname(row)
@@ -63,6 +76,7 @@ def _arg(name, default):
 
 res["images"], res["feats"] = _arg("--images", 500), _arg("--feats", 4096)
 res["pairs"] = res["images"] * (res["images"] - 1) // 2 if "--pairs" not in bench_args else None
+res["variant"] = "dot4 (DSM_K1_DOT4)" if os.environ.get("DSM_K1_DOT4") else "mfma"
 f, w = res.get("FETCH_SIZE", {}), res.get("WRITE_SIZE", {})
 if f and w:
     # per step (one launch of each pass): FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as reported; KiB -> bytes
@@ -83,3 +97,5 @@ if util and "SQ_VALU_MFMA_BUSY_CYCLES" in res and "SQ_BUSY_CU_CYCLES" in res:
             pass
 print(json.dumps(res))
 json.dump(res, open(os.path.join(out_dir, "k1_pmc.json"), "w"), indent=1)
+if tag_out:
+    json.dump(res, open(tag_out, "w"), indent=1)
