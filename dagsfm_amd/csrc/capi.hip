@@ -171,6 +171,12 @@ void dsm_default_two_view_options(dsm_two_view_options* o) {
   o->max_num_trials = 10000;            // sift.h:149
 }
 
+int dsm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n < 0 ? 0 : n;
+}
+
 int dsm_ctx_create(int device, dsm_ctx** out_ctx) {
   if (!out_ctx) return DSM_ERR_INVALID_ARGUMENT;
   *out_ctx = nullptr;

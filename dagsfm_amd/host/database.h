@@ -72,10 +72,24 @@ class Database {
 class DatabaseTransaction {
  public:
   explicit DatabaseTransaction(Database* database) : database_(database) { database_->BeginTransaction(); }
-  ~DatabaseTransaction() { database_->EndTransaction(); }
+  // END failing while another exception unwinds must not terminate the process: errors surface through Commit(),
+  // the destructor only makes sure the transaction is closed and swallows what it cannot report.
+  ~DatabaseTransaction() noexcept {
+    if (!done_) {
+      try {
+        database_->EndTransaction();
+      } catch (...) {
+      }
+    }
+  }
+  void Commit() {
+    done_ = true;
+    database_->EndTransaction();
+  }
 
  private:
   Database* database_;
+  bool done_ = false;
 };
 
 }  // namespace dagsfm_amd

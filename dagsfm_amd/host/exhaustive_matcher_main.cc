@@ -20,10 +20,11 @@ int main(int argc, char** argv) {
     else if (k == "--random_seed") seed = static_cast<unsigned>(std::strtoul(argv[i + 1], nullptr, 10));
     else if (k == "--SiftMatching.guided_matching") guided = std::atoi(argv[i + 1]);
     else if (k == "--SiftMatching.multiple_models") multiple = std::atoi(argv[i + 1]);
+    else if (k == "--SiftMatching.gpu_index") setenv("DSM_GPU_INDEX", argv[i + 1], 1);  // "-1" (default): all visible devices
   }
   if (db.empty()) {
     std::cerr << "usage: dsm_exhaustive_matcher --database_path database.db [--ExhaustiveMatching.block_size 1000] [--random_seed 0]"
-                 " [--SiftMatching.guided_matching 0] [--SiftMatching.multiple_models 0]\n";
+                 " [--SiftMatching.guided_matching 0] [--SiftMatching.multiple_models 0] [--SiftMatching.gpu_index -1]\n";
     return 64;
   }
   return dsm_host_exhaustive_matcher_ex(db.c_str(), block, 1, seed, 0, 0, 1, 15, guided, multiple);

@@ -34,17 +34,58 @@ std::vector<image_t> FeatureMatcherCache::GetImageIds() const {
   return ids;
 }
 
+FeatureMatcherCache::Features& FeatureMatcherCache::Touch(image_t image_id) {
+  auto it = features_.find(image_id);
+  if (it != features_.end()) {
+    lru_.splice(lru_.begin(), lru_, it->second.lru_it);
+  } else {
+    // LRUCache of cache_size images (util/cache.h), except that an image requested since the last ReleasePins()
+    // is never evicted: Match() holds pointers into the cache while it uploads
+    if (features_.size() >= std::max<size_t>(cache_size_, 1)) {
+      for (auto rit = lru_.end(); rit != lru_.begin();) {
+        --rit;
+        auto victim = features_.find(*rit);
+        if (!victim->second.pinned) {
+          lru_.erase(rit);
+          features_.erase(victim);
+          break;
+        }
+      }
+    }
+    lru_.push_front(image_id);
+    it = features_.emplace(image_id, Features()).first;
+    it->second.lru_it = lru_.begin();
+  }
+  it->second.pinned = true;
+  return it->second;
+}
+
+void FeatureMatcherCache::ReleasePins() {
+  std::lock_guard<std::mutex> lock(mutex_);
+  for (auto& kv : features_) kv.second.pinned = false;
+  while (features_.size() > std::max<size_t>(cache_size_, 1) && !lru_.empty()) {
+    features_.erase(lru_.back());
+    lru_.pop_back();
+  }
+}
+
 const FeatureKeypoints& FeatureMatcherCache::GetKeypoints(image_t image_id) {
   std::lock_guard<std::mutex> lock(mutex_);
-  auto it = keypoints_cache_.find(image_id);
-  if (it == keypoints_cache_.end()) it = keypoints_cache_.emplace(image_id, database_->ReadKeypoints(image_id)).first;
-  return it->second;
+  Features& f = Touch(image_id);
+  if (!f.have_kp) {
+    f.keypoints = database_->ReadKeypoints(image_id);
+    f.have_kp = true;
+  }
+  return f.keypoints;
 }
 const FeatureDescriptors& FeatureMatcherCache::GetDescriptors(image_t image_id) {
   std::lock_guard<std::mutex> lock(mutex_);
-  auto it = descriptors_cache_.find(image_id);
-  if (it == descriptors_cache_.end()) it = descriptors_cache_.emplace(image_id, database_->ReadDescriptors(image_id)).first;
-  return it->second;
+  Features& f = Touch(image_id);
+  if (!f.have_desc) {
+    f.descriptors = database_->ReadDescriptors(image_id);
+    f.have_desc = true;
+  }
+  return f.descriptors;
 }
 
 SiftFeatureMatcher::SiftFeatureMatcher(const SiftMatchingOptions& options, Database* database, FeatureMatcherCache* cache)
@@ -54,7 +95,7 @@ SiftFeatureMatcher::SiftFeatureMatcher(const SiftMatchingOptions& options, Datab
 
 SiftFeatureMatcher::~SiftFeatureMatcher() {
   if (writer_.joinable()) writer_.join();  // errors of a never-flushed write-back are lost with the object
-  if (ctx_) dsm_ctx_destroy(ctx_);
+  for (dsm_ctx* c : ctxs_) dsm_ctx_destroy(c);
 }
 
 void SiftFeatureMatcher::Flush() {
@@ -66,33 +107,78 @@ void SiftFeatureMatcher::Flush() {
   }
 }
 
+// gpu_index: "-1" = one matcher per visible device, otherwise a comma-separated device list
+// (matching.cc:631-645: one SiftGPUFeatureMatcher thread per CUDA device; CSVToVector<int>(gpu_index)).
 bool SiftFeatureMatcher::Setup() {
-  int device = 0;
-  if (options_.gpu_index != "-1" && !options_.gpu_index.empty()) device = std::atoi(options_.gpu_index.c_str());
-  const int rc = dsm_ctx_create(device, &ctx_);
-  if (rc != DSM_OK) {
-    last_error_ = dsm_last_error(nullptr);
-    return false;
+  devices_.clear();
+  if (options_.gpu_index.empty() || options_.gpu_index == "-1") {
+    const int n = dsm_device_count();
+    for (int d = 0; d < n; ++d) devices_.push_back(d);
+  } else {
+    size_t pos = 0;
+    while (pos <= options_.gpu_index.size()) {
+      const size_t comma = options_.gpu_index.find(',', pos);
+      const std::string tok = options_.gpu_index.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+      if (!tok.empty()) devices_.push_back(std::atoi(tok.c_str()));
+      if (comma == std::string::npos) break;
+      pos = comma + 1;
+    }
   }
+  if (devices_.empty()) {
+    last_error_ = "no HIP device visible";
+    return false;  // matching.cc:732-742
+  }
+  for (int d : devices_) {
+    dsm_ctx* c = nullptr;
+    if (dsm_ctx_create(d, &c) != DSM_OK) {
+      last_error_ = dsm_last_error(nullptr);
+      for (dsm_ctx* x : ctxs_) dsm_ctx_destroy(x);
+      ctxs_.clear();
+      return false;
+    }
+    ctxs_.push_back(c);
+  }
+  max_resident_ = cache_ ? cache_->CacheSize() : 0;
   is_setup_ = true;
   return true;
 }
 
-bool SiftFeatureMatcher::UploadImages() {
-  image_ids_ = cache_->GetImageIds();
-  image_index_.clear();
-  const uint32_t n = static_cast<uint32_t>(image_ids_.size());
+bool SiftFeatureMatcher::EnsureResident(const std::vector<std::pair<image_t, image_t>>& a,
+                                        const std::vector<std::pair<image_t, image_t>>& b) {
+  std::vector<image_t> needed;
+  bool all_there = true;
+  {
+    std::unordered_set<image_t> seen;
+    for (const auto* list : {&a, &b})
+      for (const auto& pr : *list)
+        for (image_t id : {pr.first, pr.second})
+          if (seen.insert(id).second) {
+            needed.push_back(id);
+            if (!image_index_.count(id)) all_there = false;
+          }
+  }
+  if (all_there) return true;
+  // keep the resident images too while the union stays within the cache size (consecutive blocks of the
+  // exhaustive / sequential matchers share most of their images)
+  std::vector<image_t> ids = needed;
+  if (image_ids_.size() + needed.size() <= std::max(max_resident_, needed.size())) {
+    std::unordered_set<image_t> in(needed.begin(), needed.end());
+    for (image_t id : image_ids_)
+      if (in.insert(id).second) ids.push_back(id);
+  }
+  std::sort(ids.begin(), ids.end());
+  const uint32_t n = static_cast<uint32_t>(ids.size());
   std::vector<uint32_t> nfeat(n);
   std::vector<const uint8_t*> desc(n);
   std::vector<const float*> kp(n);
   std::vector<dsm_camera> cams(n);
   for (uint32_t i = 0; i < n; ++i) {
-    const image_t id = image_ids_[i];
-    image_index_[id] = i;
+    const image_t id = ids[i];
     const FeatureDescriptors& d = cache_->GetDescriptors(id);
     const FeatureKeypoints& k = cache_->GetKeypoints(id);
     if (d.rows != k.size() || (d.rows && d.cols != 128)) {
       last_error_ = "keypoints/descriptors mismatch for image " + std::to_string(id);
+      cache_->ReleasePins();
       return false;
     }
     nfeat[i] = static_cast<uint32_t>(d.rows);
@@ -111,19 +197,30 @@ bool SiftFeatureMatcher::UploadImages() {
   std::vector<float> dummy(2, 0.f);
   for (uint32_t i = 0; i < n; ++i)
     if (!kp[i]) kp[i] = dummy.data();
-  const int rc = dsm_set_images(ctx_, n, nfeat.data(), desc.data(), kp.data(), 6, cams.data());
-  if (rc != DSM_OK) {
-    last_error_ = dsm_last_error(ctx_);
-    return false;
-  }
-  images_uploaded_ = true;
+  // every device gets every image of the list (the pair list is what is sharded), in parallel
+  std::vector<int> rcs(ctxs_.size(), DSM_OK);
+  std::vector<std::thread> th;
+  for (size_t d = 0; d < ctxs_.size(); ++d)
+    th.emplace_back([&, d]() { rcs[d] = dsm_set_images(ctxs_[d], n, nfeat.data(), desc.data(), kp.data(), 6, cams.data()); });
+  for (auto& t : th) t.join();
+  cache_->ReleasePins();
+  for (size_t d = 0; d < ctxs_.size(); ++d)
+    if (rcs[d] != DSM_OK) {
+      last_error_ = dsm_last_error(ctxs_[d]);  // e.g. a camera model id the reference does not know either
+      image_ids_.clear();
+      image_index_.clear();
+      return false;
+    }
+  image_ids_ = ids;
+  image_nfeat_ = nfeat;
+  image_index_.clear();
+  for (uint32_t i = 0; i < n; ++i) image_index_[ids[i]] = i;
   return true;
 }
 
 void SiftFeatureMatcher::Match(const std::vector<std::pair<image_t, image_t>>& image_pairs) {
   if (!database_ || !cache_ || !is_setup_) throw std::logic_error("SiftFeatureMatcher::Match before Setup");  // CHECKs :751-753
   if (image_pairs.empty()) return;
-  if (!images_uploaded_ && !UploadImages()) throw std::runtime_error(last_error_);
 
   // ---- dedupe, resume semantics (matching.cc:763-813)
   std::unordered_set<image_pair_t> seen;
@@ -146,9 +243,9 @@ void SiftFeatureMatcher::Match(const std::vector<std::pair<image_t, image_t>>& i
       } else {
         to_match.push_back(pr);
       }
-      if (options_.async_write_back) cache_->MarkPendingUnlocked(pr.first, pr.second);
     }
   }
+  if (!EnsureResident(to_match, to_verify_only)) throw std::runtime_error(last_error_);
   dsm_match_options mo;
   dsm_default_match_options(&mo);
   mo.max_ratio = options_.max_ratio;
@@ -165,43 +262,121 @@ void SiftFeatureMatcher::Match(const std::vector<std::pair<image_t, image_t>>& i
   to.min_inlier_ratio = options_.min_inlier_ratio;
   to.multiple_models = options_.multiple_models ? 1 : 0;  // TwoViewGeometry::Options::multiple_ignore_watermark stays at its default (true)
 
-  auto run = [&](const std::vector<std::pair<image_t, image_t>>& prs, const std::vector<FeatureMatches>* given) {
-    if (prs.empty()) return;
-    const uint32_t np = static_cast<uint32_t>(prs.size());
+  // One share of the pair list on one device: match (or install the given matches), verify, fetch.
+  struct Share {
+    uint32_t begin = 0, end = 0;
+    std::vector<uint64_t> moff, ioff;
+    std::vector<uint32_t> m, im;
+    std::vector<dsm_two_view_geometry> tv;
+    std::string error;
+  };
+  auto run_share = [&](dsm_ctx* ctx, const std::vector<std::pair<image_t, image_t>>& prs, const std::vector<FeatureMatches>* given,
+                       Share* sh) {
+    const uint32_t np = sh->end - sh->begin;
+    if (np == 0) return;
     std::vector<uint32_t> idx(2 * static_cast<size_t>(np)), seeds(np);
     for (uint32_t i = 0; i < np; ++i) {
-      idx[2 * i] = image_index_.at(prs[i].first);
-      idx[2 * i + 1] = image_index_.at(prs[i].second);
-      seeds[i] = dsm_pair_seed(prs[i].first, prs[i].second, options_.random_seed);
+      const auto& pr = prs[sh->begin + i];
+      idx[2 * i] = image_index_.at(pr.first);
+      idx[2 * i + 1] = image_index_.at(pr.second);
+      seeds[i] = dsm_pair_seed(pr.first, pr.second, options_.random_seed);
     }
     int rc;
     if (given) {
       std::vector<uint64_t> off(np + 1, 0);
-      for (uint32_t i = 0; i < np; ++i) off[i + 1] = off[i] + (*given)[i].size();
+      for (uint32_t i = 0; i < np; ++i) off[i + 1] = off[i] + (*given)[sh->begin + i].size();
       std::vector<uint32_t> flat(2 * off[np]);
-      for (uint32_t i = 0; i < np; ++i)
-        for (size_t k = 0; k < (*given)[i].size(); ++k) {
-          flat[2 * (off[i] + k)] = (*given)[i][k].point2D_idx1;
-          flat[2 * (off[i] + k) + 1] = (*given)[i][k].point2D_idx2;
+      for (uint32_t i = 0; i < np; ++i) {
+        const FeatureMatches& g = (*given)[sh->begin + i];
+        for (size_t k = 0; k < g.size(); ++k) {
+          flat[2 * (off[i] + k)] = g[k].point2D_idx1;
+          flat[2 * (off[i] + k) + 1] = g[k].point2D_idx2;
         }
-      rc = dsm_set_matches(ctx_, np, idx.data(), off.data(), flat.data());
+      }
+      rc = dsm_set_matches(ctx, np, idx.data(), off.data(), flat.data());
     } else {
-      rc = dsm_match_pairs(ctx_, np, idx.data(), &mo);
+      rc = dsm_match_pairs(ctx, np, idx.data(), &mo);
     }
     // guided_matching (matching.cc:647-667): verifier -> guided matcher -> output; the post-filter then sees the guided counts
-    if (rc == DSM_OK) rc = dsm_verify_pairs(ctx_, &to, seeds.data(), 0, options_.guided_matching ? 0 : 1);
-    if (rc == DSM_OK && options_.guided_matching) rc = dsm_guided_match_pairs(ctx_, &mo, &to, 1);
-    if (rc != DSM_OK) throw std::runtime_error(std::string("device matching failed: ") + dsm_last_error(ctx_));
-    std::vector<uint64_t> moff(np + 1), ioff(np + 1);
-    rc = dsm_get_matches(ctx_, moff.data(), nullptr, 0);
-    std::vector<uint32_t> m(2 * std::max<uint64_t>(moff[np], 1));
-    if (rc == DSM_OK) rc = dsm_get_matches(ctx_, nullptr, m.data(), moff[np]);
+    if (rc == DSM_OK) rc = dsm_verify_pairs(ctx, &to, seeds.data(), 0, options_.guided_matching ? 0 : 1);
+    if (rc == DSM_OK && options_.guided_matching) rc = dsm_guided_match_pairs(ctx, &mo, &to, 1);
+    if (rc != DSM_OK) {
+      sh->error = std::string("device matching failed: ") + dsm_last_error(ctx);
+      return;
+    }
+    sh->moff.assign(np + 1, 0);
+    sh->ioff.assign(np + 1, 0);
+    rc = dsm_get_matches(ctx, sh->moff.data(), nullptr, 0);
+    sh->m.assign(2 * std::max<uint64_t>(sh->moff[np], 1), 0);
+    if (rc == DSM_OK) rc = dsm_get_matches(ctx, nullptr, sh->m.data(), sh->moff[np]);
+    sh->tv.resize(np);
+    if (rc == DSM_OK) rc = dsm_get_two_view_geometries(ctx, sh->tv.data());
+    if (rc == DSM_OK) rc = dsm_get_inlier_matches(ctx, sh->ioff.data(), nullptr, 0);
+    sh->im.assign(2 * std::max<uint64_t>(sh->ioff[np], 1), 0);
+    if (rc == DSM_OK) rc = dsm_get_inlier_matches(ctx, nullptr, sh->im.data(), sh->ioff[np]);
+    if (rc != DSM_OK) sh->error = std::string("result fetch failed: ") + dsm_last_error(ctx);
+  };
+
+  auto run = [&](const std::vector<std::pair<image_t, image_t>>& prs, const std::vector<FeatureMatches>* given) {
+    if (prs.empty()) return;
+    const uint32_t np = static_cast<uint32_t>(prs.size());
+    // Contiguous blocks of the list, one per device, cut by cost (descriptor-matrix size + a per-pair term for
+    // the verification): the reference lets its per-GPU matcher threads pull pairs from one queue
+    // (matching.cc:640-645); a static cut by cost gives the same balance without a queue and keeps list order.
+    const size_t nd = std::min<size_t>(ctxs_.size(), np);
+    std::vector<double> cum(np + 1, 0.0);
+    for (uint32_t i = 0; i < np; ++i) {
+      const double n1 = image_nfeat_[image_index_.at(prs[i].first)], n2 = image_nfeat_[image_index_.at(prs[i].second)];
+      cum[i + 1] = cum[i] + (given ? 0.0 : n1 * n2) + 4096.0 * 1024.0;
+    }
+    std::vector<Share> shares(nd);
+    uint32_t at = 0;
+    for (size_t d = 0; d < nd; ++d) {
+      shares[d].begin = at;
+      const double target = cum[np] * static_cast<double>(d + 1) / static_cast<double>(nd);
+      while (at < np && (cum[at + 1] <= target || d + 1 == nd)) ++at;
+      if (d + 1 < nd && at == shares[d].begin && at < np) ++at;  // never an empty share while pairs are left
+      shares[d].end = at;
+    }
+    shares[nd - 1].end = np;
+    if (nd == 1) {
+      run_share(ctxs_[0], prs, given, &shares[0]);
+    } else {
+      std::vector<std::thread> th;
+      for (size_t d = 0; d < nd; ++d) th.emplace_back([&, d]() { run_share(ctxs_[d], prs, given, &shares[d]); });
+      for (auto& t : th) t.join();
+    }
+    for (const Share& sh : shares)
+      if (!sh.error.empty()) throw std::runtime_error(sh.error);
+    // merge the shares in list order
+    std::vector<uint64_t> moff(np + 1, 0), ioff(np + 1, 0);
     std::vector<dsm_two_view_geometry> tv(np);
-    if (rc == DSM_OK) rc = dsm_get_two_view_geometries(ctx_, tv.data());
-    if (rc == DSM_OK) rc = dsm_get_inlier_matches(ctx_, ioff.data(), nullptr, 0);
-    std::vector<uint32_t> im(2 * std::max<uint64_t>(ioff[np], 1));
-    if (rc == DSM_OK) rc = dsm_get_inlier_matches(ctx_, nullptr, im.data(), ioff[np]);
-    if (rc != DSM_OK) throw std::runtime_error(std::string("result fetch failed: ") + dsm_last_error(ctx_));
+    uint64_t mt = 0, it = 0;
+    for (const Share& sh : shares) {
+      for (uint32_t i = sh.begin; i < sh.end; ++i) {
+        moff[i] = mt + sh.moff[i - sh.begin];
+        ioff[i] = it + sh.ioff[i - sh.begin];
+        tv[i] = sh.tv[i - sh.begin];
+      }
+      if (sh.end > sh.begin) {
+        mt += sh.moff[sh.end - sh.begin];
+        it += sh.ioff[sh.end - sh.begin];
+      }
+    }
+    moff[np] = mt;
+    ioff[np] = it;
+    std::vector<uint32_t> m(2 * std::max<uint64_t>(mt, 1)), im(2 * std::max<uint64_t>(it, 1));
+    for (const Share& sh : shares) {
+      if (sh.end == sh.begin) continue;
+      std::copy(sh.m.begin(), sh.m.begin() + 2 * sh.moff[sh.end - sh.begin], m.begin() + 2 * moff[sh.begin]);
+      std::copy(sh.im.begin(), sh.im.begin() + 2 * sh.ioff[sh.end - sh.begin], im.begin() + 2 * ioff[sh.begin]);
+    }
+    if (options_.async_write_back) {
+      // the rows are on their way: later Match() calls must skip these pairs.  Marked only now, with the device
+      // results on the host -- a failed device call above leaves the cache saying what the database says.
+      const auto lock = cache_->Lock();
+      for (const auto& pr : prs) cache_->MarkPendingUnlocked(pr.first, pr.second);
+    }
     // ---- write results (matching.cc:819-836), on this thread or handed to the write-back thread
     const int min_num_inliers = options_.min_num_inliers;
     FeatureMatcherCache* cache = cache_;
@@ -287,6 +462,7 @@ bool ExhaustiveFeatureMatcher::Run() {
       } else {
         DatabaseTransaction database_transaction(&database_);
         matcher_.Match(image_pairs);
+        database_transaction.Commit();
       }
     }
   }
@@ -319,6 +495,7 @@ int dsm_host_exhaustive_matcher_ex(const char* database_path, int block_size, in
     mo.guided_matching = guided_matching != 0;
     mo.multiple_models = multiple_models != 0;
     mo.async_write_back = std::getenv("DSM_ASYNC_WRITE_BACK") != nullptr;  // CLI / tests: overlap SQLite with the device
+    if (const char* g = std::getenv("DSM_GPU_INDEX")) mo.gpu_index = g;    // SiftMatchingOptions::gpu_index ("-1": all devices)
     mo.random_seed = random_seed;
     ExhaustiveFeatureMatcher m(eo, mo, database_path);
     return m.Run() ? 0 : 2;
@@ -418,5 +595,30 @@ int dsm_host_db_read_pair(const char* database_path, uint32_t image_id1, uint32_
 }
 
 uint64_t dsm_host_image_pair_to_pair_id(uint32_t a, uint32_t b) { return Database::ImagePairToPairId(a, b); }
+
+// CPU-only probe of FeatureMatcherCache's LRU: touches the given image ids in order (releasing the pins after every
+// `pin_batch` requests, like one Match() call does) and returns the largest number of images the cache ever held.
+int dsm_host_cache_lru_probe(const char* database_path, uint32_t cache_size, const uint32_t* image_ids, uint32_t n,
+                             uint32_t pin_batch) {
+  try {
+    Database db(database_path);
+    FeatureMatcherCache cache(cache_size, &db);
+    cache.Setup();
+    size_t peak = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      const FeatureDescriptors& d = cache.GetDescriptors(image_ids[i]);
+      const FeatureKeypoints& k = cache.GetKeypoints(image_ids[i]);
+      if (d.rows != k.size()) return -2;
+      peak = std::max(peak, cache.NumCachedImages());
+      if ((i + 1) % std::max<uint32_t>(pin_batch, 1) == 0) cache.ReleasePins();
+    }
+    cache.ReleasePins();
+    if (cache.NumCachedImages() > std::max<uint32_t>(cache_size, 1)) return -3;
+    return static_cast<int>(peak);
+  } catch (const std::exception& e) {
+    std::cerr << "ERROR: " << e.what() << std::endl;
+    return -1;
+  }
+}
 
 }  // extern "C"

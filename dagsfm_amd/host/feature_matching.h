@@ -15,6 +15,7 @@
 
 #include <string>
 #include <exception>
+#include <list>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -32,18 +33,24 @@ struct ExhaustiveMatchingOptions {  // matching.h:52-60
   bool Check() const { return block_size > 1; }
 };
 
-// All cameras / images resident; keypoints and descriptors of every image are bulk-loaded once and
-// stay resident in HBM (the reference keeps an LRU of 5 * block_size images in host RAM).
+// All cameras / images resident (matching.cc:221-243); keypoints and descriptors go through an LRU of cache_size
+// images like the reference's (matching.h:203-206): Match() asks for the images of ITS pair list only, so a
+// database far larger than host RAM is matched block by block.
 class FeatureMatcherCache {
  public:
   FeatureMatcherCache(size_t cache_size, const Database* database);
   void Setup();
+  size_t CacheSize() const { return cache_size_; }
 
   const Camera& GetCamera(camera_t camera_id) const { return cameras_cache_.at(camera_id); }
   const Image& GetImage(image_t image_id) const { return images_cache_.at(image_id); }
   std::vector<image_t> GetImageIds() const;
+  // The references stay valid until the next Get* call that has to evict (the LRU never evicts an image that was
+  // requested since the last ReleasePins()).
   const FeatureKeypoints& GetKeypoints(image_t image_id);
   const FeatureDescriptors& GetDescriptors(image_t image_id);
+  void ReleasePins();
+  size_t NumCachedImages() const { return features_.size(); }
   FeatureMatches GetMatches(image_t a, image_t b) const {
     std::lock_guard<std::mutex> lock(mutex_);
     return database_->ReadMatches(a, b);
@@ -118,8 +125,15 @@ class FeatureMatcherCache {
   const Database* database_;
   std::unordered_map<camera_t, Camera> cameras_cache_;
   std::unordered_map<image_t, Image> images_cache_;
-  std::unordered_map<image_t, FeatureKeypoints> keypoints_cache_;
-  std::unordered_map<image_t, FeatureDescriptors> descriptors_cache_;
+  struct Features {
+    FeatureKeypoints keypoints;
+    FeatureDescriptors descriptors;
+    bool have_kp = false, have_desc = false, pinned = false;
+    std::list<image_t>::iterator lru_it;
+  };
+  Features& Touch(image_t image_id);  // mutex_ held
+  std::unordered_map<image_t, Features> features_;
+  std::list<image_t> lru_;  // front = most recently used
   std::unordered_set<image_pair_t> have_matches_, have_inliers_;
   mutable std::mutex mutex_;
 };
@@ -139,16 +153,22 @@ class SiftFeatureMatcher {
   void Flush();
 
   const std::string& LastError() const { return last_error_; }
+  size_t NumDevices() const { return ctxs_.size(); }
+  size_t NumResidentImages() const { return image_ids_.size(); }
 
  private:
-  bool UploadImages();
+  // Makes the images the pair lists refer to resident on every device (replicated: SURVEY 8e); keeps what is
+  // already there when the union fits cache_size images, otherwise replaces it.
+  bool EnsureResident(const std::vector<std::pair<image_t, image_t>>& a, const std::vector<std::pair<image_t, image_t>>& b);
   SiftMatchingOptions options_;
   Database* database_;
   FeatureMatcherCache* cache_;
   bool is_setup_ = false;
-  bool images_uploaded_ = false;
-  dsm_ctx* ctx_ = nullptr;
+  std::vector<dsm_ctx*> ctxs_;                         // one per device of gpu_index ("-1": every visible device)
+  std::vector<int> devices_;
+  size_t max_resident_ = 0;                            // cache_size of the FeatureMatcherCache
   std::vector<image_t> image_ids_;                    // device image index -> image_id
+  std::vector<uint32_t> image_nfeat_;
   std::unordered_map<image_t, uint32_t> image_index_;  // image_id -> device image index
   std::string last_error_;
   std::thread writer_;                // at most one write-back in flight

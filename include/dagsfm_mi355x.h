@@ -117,6 +117,10 @@ typedef struct dsm_two_view_geometry {
 /* ------------------------------------------------------------------ context */
 typedef struct dsm_ctx dsm_ctx;
 
+/* Number of HIP devices visible to this process (0 when there is none).  SiftMatchingOptions::gpu_index "-1" means
+ * "all of them", one matcher per device (src/feature/matching.cc:631-645, doc/faq.rst:322-331). */
+int dsm_device_count(void);
+
 /* Creates a context bound to HIP device `device`.  Replaces SiftFeatureMatcher's
  * ctor + Setup() (src/feature/matching.cc:610-675, 713-747): returns
  * DSM_ERR_NO_DEVICE where Setup() would return false. */

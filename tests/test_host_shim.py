@@ -267,3 +267,45 @@ def test_exhaustive_matcher_guided_matching(tmp_path, oracle):
             else:
                 assert t["config"] == 0 and len(t["inliers"]) == 0
     assert n_guided >= 3
+
+
+def test_feature_matcher_cache_is_a_bounded_lru(tmp_path):
+    """FeatureMatcherCache keeps at most cache_size images of keypoints / descriptors (matching.h:203-206), except
+    that what one Match() call has requested stays pinned until it is done (no whole-database load)."""
+    L = host()
+    L.dsm_host_cache_lru_probe.argtypes = [ctypes.c_char_p, ctypes.c_uint32, u32p, ctypes.c_uint32, ctypes.c_uint32]
+    rng = np.random.default_rng(0)
+    ims = [(rng.integers(0, 255, (8, 128)).astype(np.uint8), rng.uniform(0, 100, (8, 2)).astype(np.float32)) for _ in range(20)]
+    path = str(tmp_path / "db.db")
+    dbutil.create(path, ims)
+    ids = np.array(list(range(1, 21)) * 2, dtype=np.uint32)
+    assert L.dsm_host_cache_lru_probe(path.encode(), 5, ids.ctypes.data_as(u32p), len(ids), 1) == 5
+    assert L.dsm_host_cache_lru_probe(path.encode(), 5, ids.ctypes.data_as(u32p), len(ids), 8) == 8  # a call may pin more
+    assert L.dsm_host_cache_lru_probe(path.encode(), 100, ids.ctypes.data_as(u32p), len(ids), 1) == 20
+
+
+@pytest.mark.gpu
+def test_exhaustive_matcher_several_device_contexts(tmp_path):
+    """SiftMatchingOptions::gpu_index with a device list: one context (and one host thread) per entry, the pair list
+    cut into one contiguous share per context, results merged in list order before the rows are written.  "0,0" puts
+    two contexts on the one GPU of the test box; the database must equal the single-context run's row for row.  With
+    a block size below the image count the resident image set is also replaced between Match() calls."""
+    from dagsfm_amd import synthetic
+    n_img = 7
+    scene = synthetic.Scene(n_img, 512, seed=35, n_pool=1400)
+    ims = [scene.image(i) for i in range(n_img)]
+    res = []
+    for k, gpu_index in enumerate(["0", "0,0", "-1"]):
+        path = str(tmp_path / ("database%d.db" % k))
+        dbutil.create(path, [(im[0], im[1]) for im in ims], prior=True)
+        subprocess.check_call([CLI, "--database_path", path, "--ExhaustiveMatching.block_size", "3", "--random_seed", "4",
+                               "--SiftMatching.gpu_index", gpu_index])
+        res.append(dbutil.read_results(path))
+    base_m, base_t = res[0]
+    assert len(base_m) == n_img * (n_img - 1) // 2 and sum(len(v) for v in base_m.values()) > 300
+    for m, t in res[1:]:
+        assert m.keys() == base_m.keys() and t.keys() == base_t.keys()
+        for pid in base_m:
+            assert (m[pid] == base_m[pid]).all()
+            assert t[pid]["config"] == base_t[pid]["config"] and (t[pid]["inliers"] == base_t[pid]["inliers"]).all()
+            assert t[pid]["F"] == base_t[pid]["F"] and t[pid]["E"] == base_t[pid]["E"]
