@@ -23,7 +23,10 @@
 #include <utility>
 #include <vector>
 
+#include <cstring>
+
 #include "database.h"
+#include "sift_feature_matcher_impl.h"
 #include "types.h"
 
 namespace dagsfm_amd {
@@ -52,7 +55,7 @@ class FeatureMatcherCache {
   void ReleasePins();
   size_t NumCachedImages() const { return features_.size(); }
   FeatureMatches GetMatches(image_t a, image_t b) const {
-    std::lock_guard<std::mutex> lock(mutex_);
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
     return database_->ReadMatches(a, b);
   }
   // The pair ids of both result tables are read in bulk by Setup() and kept current here, so the two existence
@@ -60,16 +63,16 @@ class FeatureMatcherCache {
   // One mutex serialises every touch of the (single, NOMUTEX) connection and of the id sets, like the reference's
   // database_mutex_ (matching.h:208): the asynchronous write-back thread and the caller may both be here.
   bool ExistsMatches(image_t a, image_t b) const {
-    std::lock_guard<std::mutex> lock(mutex_);
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
     return have_matches_.count(Database::ImagePairToPairId(a, b)) != 0;
   }
   bool ExistsInlierMatches(image_t a, image_t b) const {
-    std::lock_guard<std::mutex> lock(mutex_);
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
     return have_inliers_.count(Database::ImagePairToPairId(a, b)) != 0;
   }
   // Holds the mutex for a whole batch of the calls below (the *Unlocked variants), so that a batch is not
   // interleaved lock by lock with the write-back thread.
-  std::unique_lock<std::mutex> Lock() const { return std::unique_lock<std::mutex>(mutex_); }
+  std::unique_lock<std::recursive_mutex> Lock() const { return std::unique_lock<std::recursive_mutex>(mutex_); }
   bool ExistsMatchesUnlocked(image_t a, image_t b) const { return have_matches_.count(Database::ImagePairToPairId(a, b)) != 0; }
   bool ExistsInlierMatchesUnlocked(image_t a, image_t b) const { return have_inliers_.count(Database::ImagePairToPairId(a, b)) != 0; }
   FeatureMatches GetMatchesUnlocked(image_t a, image_t b) const { return database_->ReadMatches(a, b); }
@@ -87,36 +90,36 @@ class FeatureMatcherCache {
   }
   // the rows of this pair are on their way (asynchronous write-back): later Match() calls must skip it
   void MarkPending(image_t a, image_t b) {
-    std::lock_guard<std::mutex> lock(mutex_);
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
     have_matches_.insert(Database::ImagePairToPairId(a, b));
     have_inliers_.insert(Database::ImagePairToPairId(a, b));
   }
   void WriteMatches(image_t a, image_t b, const FeatureMatches& m) {
-    std::lock_guard<std::mutex> lock(mutex_);
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
     database_->WriteMatches(a, b, m);
     have_matches_.insert(Database::ImagePairToPairId(a, b));
   }
   void WriteTwoViewGeometry(image_t a, image_t b, const TwoViewGeometry& t) {
-    std::lock_guard<std::mutex> lock(mutex_);
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
     database_->WriteTwoViewGeometry(a, b, t);
     have_inliers_.insert(Database::ImagePairToPairId(a, b));
   }
   void DeleteMatches(image_t a, image_t b) {
-    std::lock_guard<std::mutex> lock(mutex_);
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
     database_->DeleteMatches(a, b);
     have_matches_.erase(Database::ImagePairToPairId(a, b));
   }
   void DeleteInlierMatches(image_t a, image_t b) {
-    std::lock_guard<std::mutex> lock(mutex_);
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
     database_->DeleteInlierMatches(a, b);
     have_inliers_.erase(Database::ImagePairToPairId(a, b));
   }
   void BeginTransaction() const {
-    std::lock_guard<std::mutex> lock(mutex_);
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
     database_->BeginTransaction();
   }
   void EndTransaction() const {
-    std::lock_guard<std::mutex> lock(mutex_);
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
     database_->EndTransaction();
   }
 
@@ -135,44 +138,78 @@ class FeatureMatcherCache {
   std::unordered_map<image_t, Features> features_;
   std::list<image_t> lru_;  // front = most recently used
   std::unordered_set<image_pair_t> have_matches_, have_inliers_;
-  mutable std::mutex mutex_;
+  mutable std::recursive_mutex mutex_;  // recursive: Lock() (a whole batch) composes with the per-call methods
 };
 
-class SiftFeatureMatcher {
+// The types of this repository's own host side, as SiftFeatureMatcherT sees them (sift_feature_matcher_impl.h).
+struct NativeTraits {
+  typedef SiftMatchingOptions Options;
+  typedef dagsfm_amd::Database Database;
+  typedef FeatureMatcherCache Cache;
+  typedef dagsfm_amd::Camera Camera;
+  typedef dagsfm_amd::Image Image;
+  typedef dagsfm_amd::FeatureKeypoints FeatureKeypoints;
+  typedef dagsfm_amd::FeatureDescriptors FeatureDescriptors;
+  typedef dagsfm_amd::FeatureMatches FeatureMatches;
+  typedef dagsfm_amd::TwoViewGeometry TwoViewGeometry;
+  static constexpr bool kCachePinsRequested = true;
+  static constexpr bool kAsyncWriteBack = true;
+  static uint64_t PairId(image_t a, image_t b) { return Database::ImagePairToPairId(a, b); }
+  static size_t CacheSize(const Cache* c) { return c->CacheSize(); }
+  static void ReleasePins(Cache* c) { c->ReleasePins(); }
+  static std::unique_lock<std::recursive_mutex> LockBatch(const Cache* c) { return c->Lock(); }
+  static void ToDsmCamera(const Camera& c, dsm_camera* out) {
+    out->model_id = c.model_id;
+    out->has_prior_focal_length = c.HasPriorFocalLength() ? 1 : 0;
+    out->width = c.width;
+    out->height = c.height;
+    for (size_t p = 0; p < c.params.size() && p < 12; ++p) out->params[p] = c.params[p];
+  }
+  static camera_t CameraIdOf(const Image& im) { return im.camera_id; }
+  static const float* KeypointData(const FeatureKeypoints& k, size_t* n, uint32_t* stride) {
+    static_assert(sizeof(FeatureKeypoint) == 6 * sizeof(float), "FeatureKeypoint layout");
+    *n = k.size();
+    *stride = 6;
+    return k.empty() ? nullptr : &k[0].x;
+  }
+  static const uint8_t* DescriptorData(const FeatureDescriptors& d, size_t* rows, size_t* cols) {
+    *rows = d.rows;
+    *cols = d.cols;
+    return d.data.data();
+  }
+  static void AppendFlat(const FeatureMatches& m, std::vector<uint32_t>* flat) {
+    for (const FeatureMatch& x : m) {
+      flat->push_back(x.point2D_idx1);
+      flat->push_back(x.point2D_idx2);
+    }
+  }
+  static FeatureMatches MakeMatches(const uint32_t* flat, size_t n) {
+    FeatureMatches m(n);
+    for (size_t k = 0; k < n; ++k) m[k] = FeatureMatch(flat[2 * k], flat[2 * k + 1]);
+    return m;
+  }
+  static TwoViewGeometry MakeTwoViewGeometry(const dsm_two_view_geometry* r, const uint32_t* inliers, size_t n) {
+    TwoViewGeometry t;
+    if (!r) return t;
+    t.config = r->config;
+    std::memcpy(t.E, r->E, sizeof(t.E));
+    std::memcpy(t.F, r->F, sizeof(t.F));
+    std::memcpy(t.H, r->H, sizeof(t.H));
+    std::memcpy(t.qvec, r->qvec, sizeof(t.qvec));
+    std::memcpy(t.tvec, r->tvec, sizeof(t.tvec));
+    t.tri_angle = r->tri_angle;
+    t.inlier_matches = MakeMatches(inliers, n);
+    return t;
+  }
+  static uint32_t RandomSeed(const Options& o) { return o.random_seed; }
+  static bool AsyncWriteBack(const Options& o) { return o.async_write_back; }
+};
+
+// SiftFeatureMatcher of this repository's host side: Setup() / Match() / Flush() as documented in
+// sift_feature_matcher_impl.h.
+class SiftFeatureMatcher : public SiftFeatureMatcherT<NativeTraits> {
  public:
-  SiftFeatureMatcher(const SiftMatchingOptions& options, Database* database, FeatureMatcherCache* cache);
-  ~SiftFeatureMatcher();
-
-  // Creates the device context; false when no usable GPU is present (matching.cc:732-742).
-  bool Setup();
-  // Matches + verifies the pairs and writes `matches` / `two_view_geometries` rows, with the
-  // reference's dedupe / skip / partial-recompute / post-filter semantics (matching.cc:749-839).
-  void Match(const std::vector<std::pair<image_t, image_t>>& image_pairs);
-
-  // Waits for an asynchronous write-back (SiftMatchingOptions::async_write_back) and rethrows its error, if any.
-  void Flush();
-
-  const std::string& LastError() const { return last_error_; }
-  size_t NumDevices() const { return ctxs_.size(); }
-  size_t NumResidentImages() const { return image_ids_.size(); }
-
- private:
-  // Makes the images the pair lists refer to resident on every device (replicated: SURVEY 8e); keeps what is
-  // already there when the union fits cache_size images, otherwise replaces it.
-  bool EnsureResident(const std::vector<std::pair<image_t, image_t>>& a, const std::vector<std::pair<image_t, image_t>>& b);
-  SiftMatchingOptions options_;
-  Database* database_;
-  FeatureMatcherCache* cache_;
-  bool is_setup_ = false;
-  std::vector<dsm_ctx*> ctxs_;                         // one per device of gpu_index ("-1": every visible device)
-  std::vector<int> devices_;
-  size_t max_resident_ = 0;                            // cache_size of the FeatureMatcherCache
-  std::vector<image_t> image_ids_;                    // device image index -> image_id
-  std::vector<uint32_t> image_nfeat_;
-  std::unordered_map<image_t, uint32_t> image_index_;  // image_id -> device image index
-  std::string last_error_;
-  std::thread writer_;                // at most one write-back in flight
-  std::exception_ptr writer_error_;
+  using SiftFeatureMatcherT<NativeTraits>::SiftFeatureMatcherT;
 };
 
 // ExhaustiveFeatureMatcher::Run, matching.cc:853-915: blocks of block_size x block_size images,

@@ -1,0 +1,405 @@
+// sift_feature_matcher_impl.h -- SiftFeatureMatcher (/root/reference/src/feature/matching.h:334-368, matching.cc:610-839)
+// over the C-ABI, as a template over the HOST PROJECT'S OWN TYPES.
+//
+// The reference's controllers construct `SiftFeatureMatcher(options, &database, &cache)` with colmap::Database* and
+// colmap::FeatureMatcherCache* (src/controllers/distributed_mapper_controller.cpp:506-520), so a drop-in must take
+// exactly those types.  Everything the matcher does with them goes through `Traits`:
+//
+//   types      Options, Database, Cache, Camera, Image, FeatureKeypoints, FeatureDescriptors, FeatureMatches,
+//              TwoViewGeometry
+//   constants  kCachePinsRequested   references returned by Cache::GetKeypoints / GetDescriptors stay valid until
+//                                    Traits::ReleasePins (else the matcher copies before the next Get: an LRU may evict)
+//              kAsyncWriteBack       the Options / Cache carry this repository's asynchronous write-back extension
+//   functions  PairId(a, b); CacheSize(cache); ReleasePins(cache); LockBatch(cache) (RAII guard, may be empty);
+//              ToDsmCamera(camera, &out); CameraIdOf(image); KeypointData(kps, &n, &stride_in_floats);
+//              DescriptorData(desc, &rows, &cols); AppendFlat(matches, &flat); MakeMatches(flat, n);
+//              MakeTwoViewGeometry(record or nullptr, inliers, n); RandomSeed(options); AsyncWriteBack(options)
+//
+// feature_matching.h instantiates it with this repository's own types (NativeTraits); colmap_traits.h with the
+// reference's (compile-checked against tests/colmap_stub, which carries the reference's exact signatures).
+#ifndef DAGSFM_AMD_HOST_SIFT_FEATURE_MATCHER_IMPL_H_
+#define DAGSFM_AMD_HOST_SIFT_FEATURE_MATCHER_IMPL_H_
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <unordered_set>
+#include <utility>
+#include <vector>
+
+#include "../../include/dagsfm_mi355x.h"
+
+namespace dagsfm_amd {
+
+template <typename Traits>
+class SiftFeatureMatcherT {
+ public:
+  typedef uint32_t image_id_t;
+  typedef std::vector<std::pair<image_id_t, image_id_t>> PairList;
+
+  SiftFeatureMatcherT(const typename Traits::Options& options, typename Traits::Database* database, typename Traits::Cache* cache)
+      : options_(options), database_(database), cache_(cache) {
+    if (!options_.Check()) throw std::invalid_argument("SiftMatchingOptions::Check failed");  // CHECK(options_.Check()), matching.cc:614
+  }
+  ~SiftFeatureMatcherT() {
+    if (writer_.joinable()) writer_.join();  // errors of a never-flushed write-back are lost with the object
+    for (dsm_ctx* c : ctxs_) dsm_ctx_destroy(c);
+  }
+  SiftFeatureMatcherT(const SiftFeatureMatcherT&) = delete;
+  SiftFeatureMatcherT& operator=(const SiftFeatureMatcherT&) = delete;
+
+  // Creates one device context per entry of gpu_index ("-1": every visible device; matching.cc:631-645, doc/faq.rst:
+  // 322-331); false when a device cannot be set up (matching.cc:732-742).
+  bool Setup() {
+    devices_.clear();
+    if (options_.gpu_index.empty() || options_.gpu_index == "-1") {
+      const int n = dsm_device_count();
+      for (int d = 0; d < n; ++d) devices_.push_back(d);
+    } else {
+      size_t pos = 0;
+      while (pos <= options_.gpu_index.size()) {
+        const size_t comma = options_.gpu_index.find(',', pos);
+        const std::string tok = options_.gpu_index.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+        if (!tok.empty()) devices_.push_back(std::atoi(tok.c_str()));
+        if (comma == std::string::npos) break;
+        pos = comma + 1;
+      }
+    }
+    if (devices_.empty()) {
+      last_error_ = "no HIP device visible";
+      return false;
+    }
+    for (int d : devices_) {
+      dsm_ctx* c = nullptr;
+      if (dsm_ctx_create(d, &c) != DSM_OK) {
+        last_error_ = dsm_last_error(nullptr);
+        for (dsm_ctx* x : ctxs_) dsm_ctx_destroy(x);
+        ctxs_.clear();
+        return false;
+      }
+      ctxs_.push_back(c);
+    }
+    max_resident_ = cache_ ? Traits::CacheSize(cache_) : 0;
+    is_setup_ = true;
+    return true;
+  }
+
+  // Waits for an asynchronous write-back and rethrows its error, if any.
+  void Flush() {
+    if (writer_.joinable()) writer_.join();
+    if (writer_error_) {
+      std::exception_ptr e = writer_error_;
+      writer_error_ = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+
+  const std::string& LastError() const { return last_error_; }
+  size_t NumDevices() const { return ctxs_.size(); }
+  size_t NumResidentImages() const { return image_ids_.size(); }
+
+  // Matches + verifies the pairs and writes `matches` / `two_view_geometries` rows, with the reference's dedupe /
+  // skip / partial-recompute / post-filter semantics (matching.cc:749-839).
+  void Match(const PairList& image_pairs) {
+    if (!database_ || !cache_ || !is_setup_) throw std::logic_error("SiftFeatureMatcher::Match before Setup");  // CHECKs :751-753
+    if (image_pairs.empty()) return;
+
+    // ---- dedupe, resume semantics (matching.cc:763-813)
+    std::unordered_set<uint64_t> seen;
+    PairList to_match, to_verify_only;
+    std::vector<typename Traits::FeatureMatches> existing;
+    {
+      const auto lock = Traits::LockBatch(cache_);  // one acquisition for the whole list where the cache offers it
+      (void)lock;
+      for (const auto& pr : image_pairs) {
+        if (pr.first == pr.second) continue;
+        if (!seen.insert(Traits::PairId(pr.first, pr.second)).second) continue;
+        const bool exists_matches = cache_->ExistsMatches(pr.first, pr.second);
+        const bool exists_inlier_matches = cache_->ExistsInlierMatches(pr.first, pr.second);
+        if (exists_matches && exists_inlier_matches) continue;
+        if (exists_inlier_matches) cache_->DeleteInlierMatches(pr.first, pr.second);
+        if (exists_matches) {
+          existing.push_back(cache_->GetMatches(pr.first, pr.second));
+          cache_->DeleteMatches(pr.first, pr.second);
+          to_verify_only.push_back(pr);
+        } else {
+          to_match.push_back(pr);
+        }
+      }
+    }
+    if (!EnsureResident(to_match, to_verify_only)) throw std::runtime_error(last_error_);
+    dsm_match_options mo;
+    dsm_default_match_options(&mo);
+    mo.max_ratio = options_.max_ratio;
+    mo.max_distance = options_.max_distance;
+    mo.cross_check = options_.cross_check ? 1 : 0;
+    mo.max_num_matches = options_.max_num_matches;
+    dsm_two_view_options to;
+    dsm_default_two_view_options(&to);  // TwoViewGeometryVerifier ctor, matching.cc:559-568
+    to.min_num_inliers = static_cast<uint64_t>(options_.min_num_inliers);
+    to.max_error = options_.max_error;
+    to.confidence = options_.confidence;
+    to.min_num_trials = static_cast<uint64_t>(options_.min_num_trials);
+    to.max_num_trials = static_cast<uint64_t>(options_.max_num_trials);
+    to.min_inlier_ratio = options_.min_inlier_ratio;
+    to.multiple_models = options_.multiple_models ? 1 : 0;  // multiple_ignore_watermark stays at its default (true)
+    Run(to_match, nullptr, mo, to);
+    Run(to_verify_only, &existing, mo, to);
+  }
+
+ private:
+  // One share of the pair list on one device: match (or install the given matches), verify, fetch.
+  struct Share {
+    uint32_t begin = 0, end = 0;
+    std::vector<uint64_t> moff, ioff;
+    std::vector<uint32_t> m, im;
+    std::vector<dsm_two_view_geometry> tv;
+    std::string error;
+  };
+
+  void RunShare(dsm_ctx* ctx, const PairList& prs, const std::vector<typename Traits::FeatureMatches>* given,
+                const dsm_match_options& mo, const dsm_two_view_options& to, Share* sh) const {
+    const uint32_t np = sh->end - sh->begin;
+    if (np == 0) return;
+    std::vector<uint32_t> idx(2 * static_cast<size_t>(np)), seeds(np);
+    for (uint32_t i = 0; i < np; ++i) {
+      const auto& pr = prs[sh->begin + i];
+      idx[2 * i] = image_index_.at(pr.first);
+      idx[2 * i + 1] = image_index_.at(pr.second);
+      seeds[i] = dsm_pair_seed(pr.first, pr.second, Traits::RandomSeed(options_));
+    }
+    int rc;
+    if (given) {
+      std::vector<uint64_t> off(np + 1, 0);
+      std::vector<uint32_t> flat;
+      for (uint32_t i = 0; i < np; ++i) {
+        Traits::AppendFlat((*given)[sh->begin + i], &flat);
+        off[i + 1] = flat.size() / 2;
+      }
+      if (flat.empty()) flat.resize(2);
+      rc = dsm_set_matches(ctx, np, idx.data(), off.data(), flat.data());
+    } else {
+      rc = dsm_match_pairs(ctx, np, idx.data(), &mo);
+    }
+    // guided_matching (matching.cc:647-667): verifier -> guided matcher -> output; the post-filter then sees the guided counts
+    if (rc == DSM_OK) rc = dsm_verify_pairs(ctx, &to, seeds.data(), 0, options_.guided_matching ? 0 : 1);
+    if (rc == DSM_OK && options_.guided_matching) rc = dsm_guided_match_pairs(ctx, &mo, &to, 1);
+    if (rc != DSM_OK) {
+      sh->error = std::string("device matching failed: ") + dsm_last_error(ctx);
+      return;
+    }
+    sh->moff.assign(np + 1, 0);
+    sh->ioff.assign(np + 1, 0);
+    rc = dsm_get_matches(ctx, sh->moff.data(), nullptr, 0);
+    sh->m.assign(2 * std::max<uint64_t>(sh->moff[np], 1), 0);
+    if (rc == DSM_OK) rc = dsm_get_matches(ctx, nullptr, sh->m.data(), sh->moff[np]);
+    sh->tv.resize(np);
+    if (rc == DSM_OK) rc = dsm_get_two_view_geometries(ctx, sh->tv.data());
+    if (rc == DSM_OK) rc = dsm_get_inlier_matches(ctx, sh->ioff.data(), nullptr, 0);
+    sh->im.assign(2 * std::max<uint64_t>(sh->ioff[np], 1), 0);
+    if (rc == DSM_OK) rc = dsm_get_inlier_matches(ctx, nullptr, sh->im.data(), sh->ioff[np]);
+    if (rc != DSM_OK) sh->error = std::string("result fetch failed: ") + dsm_last_error(ctx);
+  }
+
+  void Run(const PairList& prs, const std::vector<typename Traits::FeatureMatches>* given, const dsm_match_options& mo,
+           const dsm_two_view_options& to) {
+    if (prs.empty()) return;
+    const uint32_t np = static_cast<uint32_t>(prs.size());
+    // Contiguous blocks of the list, one per device, cut by cost (descriptor-matrix size + a per-pair term for
+    // the verification): the reference lets its per-GPU matcher threads pull pairs from one queue
+    // (matching.cc:640-645); a static cut by cost gives the same balance without a queue and keeps list order.
+    const size_t nd = std::min<size_t>(ctxs_.size(), np);
+    std::vector<double> cum(np + 1, 0.0);
+    for (uint32_t i = 0; i < np; ++i) {
+      const double n1 = image_nfeat_[image_index_.at(prs[i].first)], n2 = image_nfeat_[image_index_.at(prs[i].second)];
+      cum[i + 1] = cum[i] + (given ? 0.0 : n1 * n2) + 4096.0 * 1024.0;
+    }
+    std::vector<Share> shares(nd);
+    uint32_t at = 0;
+    for (size_t d = 0; d < nd; ++d) {
+      shares[d].begin = at;
+      const double target = cum[np] * static_cast<double>(d + 1) / static_cast<double>(nd);
+      while (at < np && (cum[at + 1] <= target || d + 1 == nd)) ++at;
+      if (d + 1 < nd && at == shares[d].begin && at < np) ++at;  // never an empty share while pairs are left
+      shares[d].end = at;
+    }
+    shares[nd - 1].end = np;
+    if (nd == 1) {
+      RunShare(ctxs_[0], prs, given, mo, to, &shares[0]);
+    } else {
+      std::vector<std::thread> th;
+      for (size_t d = 0; d < nd; ++d) th.emplace_back([&, d]() { RunShare(ctxs_[d], prs, given, mo, to, &shares[d]); });
+      for (auto& t : th) t.join();
+    }
+    for (const Share& sh : shares)
+      if (!sh.error.empty()) throw std::runtime_error(sh.error);
+    // merge the shares in list order
+    std::vector<uint64_t> moff(np + 1, 0), ioff(np + 1, 0);
+    std::vector<dsm_two_view_geometry> tv(np);
+    uint64_t mt = 0, it = 0;
+    for (const Share& sh : shares) {
+      for (uint32_t i = sh.begin; i < sh.end; ++i) {
+        moff[i] = mt + sh.moff[i - sh.begin];
+        ioff[i] = it + sh.ioff[i - sh.begin];
+        tv[i] = sh.tv[i - sh.begin];
+      }
+      if (sh.end > sh.begin) {
+        mt += sh.moff[sh.end - sh.begin];
+        it += sh.ioff[sh.end - sh.begin];
+      }
+    }
+    moff[np] = mt;
+    ioff[np] = it;
+    std::vector<uint32_t> m(2 * std::max<uint64_t>(mt, 1)), im(2 * std::max<uint64_t>(it, 1));
+    for (const Share& sh : shares) {
+      if (sh.end == sh.begin) continue;
+      std::copy(sh.m.begin(), sh.m.begin() + 2 * sh.moff[sh.end - sh.begin], m.begin() + 2 * moff[sh.begin]);
+      std::copy(sh.im.begin(), sh.im.begin() + 2 * sh.ioff[sh.end - sh.begin], im.begin() + 2 * ioff[sh.begin]);
+    }
+    // ---- write results (matching.cc:819-836), on this thread or handed to the write-back thread
+    const int min_num_inliers = options_.min_num_inliers;
+    typename Traits::Cache* cache = cache_;
+    auto write = [cache, min_num_inliers, np, prs, moff = std::move(moff), m = std::move(m), tv = std::move(tv),
+                  ioff = std::move(ioff), im = std::move(im)]() {
+      for (uint32_t i = 0; i < np; ++i) {
+        size_t nm = moff[i + 1] - moff[i];
+        if (nm < static_cast<size_t>(min_num_inliers)) nm = 0;  // matching.cc:824-826
+        const typename Traits::FeatureMatches matches = Traits::MakeMatches(m.data() + 2 * moff[i], nm);
+        // stays TwoViewGeometry() when the device post-filter zeroed the pair (matching.cc:828-831)
+        const bool keep = tv[i].num_inliers >= static_cast<uint32_t>(min_num_inliers) && tv[i].num_inliers > 0;
+        const typename Traits::TwoViewGeometry t =
+            Traits::MakeTwoViewGeometry(keep ? &tv[i] : nullptr, im.data() + 2 * ioff[i], keep ? ioff[i + 1] - ioff[i] : 0);
+        cache->WriteMatches(prs[i].first, prs[i].second, matches);
+        cache->WriteTwoViewGeometry(prs[i].first, prs[i].second, t);
+      }
+    };
+    if constexpr (Traits::kAsyncWriteBack) {
+      if (Traits::AsyncWriteBack(options_)) {
+        {
+          // the rows are on their way: later Match() calls must skip these pairs.  Marked only now, with the device
+          // results on the host -- a failed device call above leaves the cache saying what the database says.
+          const auto lock = Traits::LockBatch(cache_);
+          (void)lock;
+          for (const auto& pr : prs) cache_->MarkPending(pr.first, pr.second);
+        }
+        Flush();  // one write-back in flight
+        writer_ = std::thread([this, cache, write = std::move(write)]() {
+          try {
+            cache->BeginTransaction();
+            write();
+            cache->EndTransaction();
+          } catch (...) {
+            writer_error_ = std::current_exception();
+          }
+        });
+        return;
+      }
+    }
+    write();
+  }
+
+  // Makes the images the pair lists refer to resident on every device (replicated: SURVEY 8e); keeps what is
+  // already there when the union fits cache_size images, otherwise replaces it.
+  bool EnsureResident(const PairList& a, const PairList& b) {
+    std::vector<image_id_t> needed;
+    bool all_there = true;
+    {
+      std::unordered_set<image_id_t> seen;
+      for (const PairList* list : {&a, &b})
+        for (const auto& pr : *list)
+          for (image_id_t id : {pr.first, pr.second})
+            if (seen.insert(id).second) {
+              needed.push_back(id);
+              if (!image_index_.count(id)) all_there = false;
+            }
+    }
+    if (all_there) return true;
+    std::vector<image_id_t> ids = needed;
+    if (image_ids_.size() + needed.size() <= std::max(max_resident_, needed.size())) {
+      std::unordered_set<image_id_t> in(needed.begin(), needed.end());
+      for (image_id_t id : image_ids_)
+        if (in.insert(id).second) ids.push_back(id);
+    }
+    std::sort(ids.begin(), ids.end());
+    const uint32_t n = static_cast<uint32_t>(ids.size());
+    std::vector<uint32_t> nfeat(n);
+    std::vector<const uint8_t*> desc(n);
+    std::vector<const float*> kp(n);
+    std::vector<dsm_camera> cams(n);
+    // staging copies when the cache cannot promise stable references (a plain LRU evicts on the next Get)
+    std::vector<std::vector<uint8_t>> desc_copy(Traits::kCachePinsRequested ? 0 : n);
+    std::vector<std::vector<float>> kp_copy(Traits::kCachePinsRequested ? 0 : n);
+    uint32_t stride = 6;
+    for (uint32_t i = 0; i < n; ++i) {
+      const image_id_t id = ids[i];
+      size_t rows = 0, cols = 128, nk = 0;
+      uint32_t st = 6;
+      const uint8_t* dptr = Traits::DescriptorData(cache_->GetDescriptors(id), &rows, &cols);
+      if (!Traits::kCachePinsRequested) {
+        desc_copy[i].assign(dptr, dptr + rows * cols);
+        dptr = desc_copy[i].data();
+      }
+      const float* kptr = Traits::KeypointData(cache_->GetKeypoints(id), &nk, &st);
+      if (!Traits::kCachePinsRequested) {
+        kp_copy[i].assign(kptr, kptr + nk * st);
+        kptr = kp_copy[i].data();
+      }
+      if (rows != nk || (rows && cols != 128)) {
+        last_error_ = "keypoints/descriptors mismatch for image " + std::to_string(id);
+        Traits::ReleasePins(cache_);
+        return false;
+      }
+      stride = st;
+      nfeat[i] = static_cast<uint32_t>(rows);
+      desc[i] = dptr;
+      kp[i] = nk ? kptr : nullptr;
+      std::memset(&cams[i], 0, sizeof(dsm_camera));
+      Traits::ToDsmCamera(cache_->GetCamera(Traits::CameraIdOf(cache_->GetImage(id))), &cams[i]);
+    }
+    std::vector<float> dummy(8, 0.f);
+    for (uint32_t i = 0; i < n; ++i)
+      if (!kp[i]) kp[i] = dummy.data();
+    // every device gets every image of the list (the pair list is what is sharded), in parallel
+    std::vector<int> rcs(ctxs_.size(), DSM_OK);
+    std::vector<std::thread> th;
+    for (size_t d = 0; d < ctxs_.size(); ++d)
+      th.emplace_back([&, d]() { rcs[d] = dsm_set_images(ctxs_[d], n, nfeat.data(), desc.data(), kp.data(), stride, cams.data()); });
+    for (auto& t : th) t.join();
+    Traits::ReleasePins(cache_);
+    for (size_t d = 0; d < ctxs_.size(); ++d)
+      if (rcs[d] != DSM_OK) {
+        last_error_ = dsm_last_error(ctxs_[d]);  // e.g. a camera model id the reference does not know either
+        image_ids_.clear();
+        image_index_.clear();
+        return false;
+      }
+    image_ids_ = ids;
+    image_nfeat_ = nfeat;
+    image_index_.clear();
+    for (uint32_t i = 0; i < n; ++i) image_index_[ids[i]] = i;
+    return true;
+  }
+
+  typename Traits::Options options_;
+  typename Traits::Database* database_;
+  typename Traits::Cache* cache_;
+  bool is_setup_ = false;
+  std::vector<dsm_ctx*> ctxs_;  // one per device of gpu_index
+  std::vector<int> devices_;
+  size_t max_resident_ = 0;     // cache_size of the FeatureMatcherCache
+  std::vector<image_id_t> image_ids_;  // device image index -> image_id
+  std::vector<uint32_t> image_nfeat_;
+  std::unordered_map<image_id_t, uint32_t> image_index_;  // image_id -> device image index
+  std::string last_error_;
+  std::thread writer_;  // at most one write-back in flight
+  std::exception_ptr writer_error_;
+};
+
+}  // namespace dagsfm_amd
+#endif  // DAGSFM_AMD_HOST_SIFT_FEATURE_MATCHER_IMPL_H_
