@@ -58,6 +58,10 @@ def parse_args():
     ap.add_argument("--uncalibrated", action="store_true",
                     help="cameras without focal prior: F + H path (EstimateUncalibrated) instead of E + F + H + pose")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU-baseline samples (0 = skip)")
+    ap.add_argument("--contexts", type=int, default=1,
+                    help="dsm contexts per GPU: the rank's share of the pair list is cut into that many contiguous parts, each "
+                         "matched + verified by its own context / stream / host thread (the latency-bound tails of one part's "
+                         "RANSAC rounds overlap with the bulk kernels of another)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="debug: all ranks on device 0 over gloo (exercises the multi-rank path on a 1-GPU box)")
     return ap.parse_args()
@@ -208,18 +212,23 @@ def main():
     bounds = sharding.shard_bounds(len(pairs), world)
     my_pairs = sharding.shard(pairs, rank, world)
 
-    ctx = capi.Context(dev_index)
+    n_ctx = max(1, args.contexts)
+    ctxs = [capi.Context(dev_index) for _ in range(n_ctx)]
+    ctx = ctxs[0]
     info = ctx.device_info()
     cams = [capi.simple_pinhole(scene.focal, scene.width / 2.0, scene.height / 2.0, scene.width, scene.height, calibrated)
             for _ in range(len(images))]
-    ctx.set_images([im[0] for im in images], [im[1] for im in images], cams)
+    for c in ctxs:
+        c.set_images([im[0] for im in images], [im[1] for im in images], cams)
+    cbounds = sharding.shard_bounds(len(my_pairs), n_ctx)
+    cparts = [my_pairs[cbounds[k]:cbounds[k + 1]] for k in range(n_ctx)]
     opts = capi.default_match_options()
     topts = capi.default_two_view_options()
     if args.fixed_trials:
         topts = capi.default_two_view_options(min_num_trials=args.fixed_trials, max_num_trials=args.fixed_trials,
                                               confidence=0.999999, min_inlier_ratio=0.01)
     user_seed = 0
-    source = sharding.CtxSource(ctx, len(my_pairs), dev)
+    source = sharding.CtxSource(ctx, len(my_pairs), dev) if n_ctx == 1 else sharding.MultiCtxSource(ctxs, [len(p) for p in cparts], dev)
     if comm_dev.type == "cpu":
         class HostSource:  # gloo debug path: the same fetches, staged through the host
             def __getattr__(self, name):
@@ -234,10 +243,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        ctx.match_pairs(my_pairs, opts)
+    def run_part(k):
+        ctxs[k].match_pairs(cparts[k], opts)
         if verify:
-            ctx.verify_pairs(topts, user_seed=user_seed, stage_filter=True)
+            ctxs[k].verify_pairs(topts, user_seed=user_seed, stage_filter=True)
+
+    def step():
+        if n_ctx == 1:
+            run_part(0)
+        else:
+            import threading
+            th = [threading.Thread(target=run_part, args=(k,)) for k in range(n_ctx)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
         return sharding.gather_match_graph(dist, gsource, rank, world, bounds, verify)
 
     for _ in range(args.warmup):
@@ -248,13 +268,14 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         graph = step()
-        ms, nl = ctx.match_kernel_time()  # host-side reads of HIP-event times already taken inside the library
-        k1_ms += ms
-        k1_launches += nl
-        k1b_ms += ctx.match_resolve_time()
-        k1g_ms += ctx.match_gather_time()
-        if verify:
-            kv_ms += ctx.verify_kernel_time()
+        for c in ctxs:  # host-side reads of HIP-event times already taken inside the library
+            ms, nl = c.match_kernel_time()
+            k1_ms += ms
+            k1_launches += nl
+            k1b_ms += c.match_resolve_time()
+            k1g_ms += c.match_gather_time()
+            if verify:
+                kv_ms += c.verify_kernel_time()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -328,6 +349,7 @@ def main():
                 "pairs": n_pairs, "images_resident": len(images), "total_matches": res["matches"],
                 "total_inlier_matches": res["inliers"], "pairs_with_geometry": res["verified"],
                 "hypotheses_per_step": res["models"],
+                "contexts_per_gpu": n_ctx,
                 "parallelism": "pair-sharded x%d + %s all-gather of the match graph" % (world, "gloo (debug, oversubscribed)" if args.oversubscribe else "RCCL")},
             "hypotheses_per_s": res["models"] * args.steps / dt if verify else None,
             "device": {"name": info.name.decode(), "arch": info.arch.decode(), "compute_units": cus, "clock_mhz": clk / 1e6,

@@ -152,3 +152,41 @@ class CtxSource:
         if total:
             self._chk(self.L.dsm_get_inlier_matches(self.ctx._h, None, m.data_ptr(), total))
         return m
+
+
+class MultiCtxSource:
+    """Several contexts on one device, each holding a contiguous part of this rank's pair list: the parts'
+    results concatenated in list order (offsets rebased)."""
+
+    def __init__(self, ctxs, counts, device):
+        self.parts = [CtxSource(c, n, device) for c, n in zip(ctxs, counts)]
+        self.tvg_bytes = self.parts[0].tvg_bytes
+
+    @staticmethod
+    def _cat_offsets(offs):
+        import torch
+        out, base = [offs[0][:1] * 0], 0
+        for o in offs:
+            out.append(o[1:] + base)
+            base = base + int(o[-1].item())
+        return torch.cat(out)
+
+    def match_offsets(self):
+        self._mo = [p.match_offsets() for p in self.parts]
+        return self._cat_offsets(self._mo)
+
+    def matches(self, total):
+        import torch
+        return torch.cat([p.matches(int(o[-1].item())) for p, o in zip(self.parts, self._mo)])
+
+    def two_view_geometries(self):
+        import torch
+        return torch.cat([p.two_view_geometries() for p in self.parts])
+
+    def inlier_offsets(self):
+        self._io = [p.inlier_offsets() for p in self.parts]
+        return self._cat_offsets(self._io)
+
+    def inlier_matches(self, total):
+        import torch
+        return torch.cat([p.inlier_matches(int(o[-1].item())) for p, o in zip(self.parts, self._io)])
