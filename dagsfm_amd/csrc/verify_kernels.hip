@@ -2414,7 +2414,7 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, hipS
     hipLaunchKernelGGL(k_lo_jacobi<FAM_E>, g4, dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_lo_e_build, g64, dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_lo_e_lu, g64, dim3(64), ELU_SMEM, st, p);
-    hipLaunchKernelGGL(k_lo_e_roots_models, g64, dim3(64), PL_HESS_PACKED_DOUBLES * 64 * sizeof(double), st, p);
+    hipLaunchKernelGGL(k_lo_e_roots_models, g64, dim3(64), 100 * 64 * sizeof(double), st, p);
   }
   if (fam == FAM_F) {
     hipLaunchKernelGGL(k_lo_prepare<FAM_F>, dim3(nb_prep), dim3(64), 0, st, p);
@@ -2446,7 +2446,7 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
   if (fam == FAM_E) {
     hipLaunchKernelGGL(k_solve_e_build, grid, dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_solve_e_lu, grid, dim3(64), ELU_SMEM, st, p);
-    hipLaunchKernelGGL(k_roots_e, grid, dim3(64), PL_HESS_PACKED_DOUBLES * 64 * sizeof(double), st, p);
+    hipLaunchKernelGGL(k_roots_e, grid, dim3(64), 100 * 64 * sizeof(double), st, p);
     hipLaunchKernelGGL(k_models_score_e, grid, dim3(64), smem, st, p);
   }
   if (fam == FAM_F) {

@@ -86,40 +86,6 @@ DSM_DEV void pl_apply_householder_right(double* M, int ld, int r0, int c0, int n
   }
 }
 
-// Packed storage of a 10 x 10 upper-Hessenberg matrix under Francis steps: column c keeps rows 0 .. min(9, c + 3)
-// (the Hessenberg band plus the two rows a bulge reaches below it), 79 doubles instead of 100 -- what lets a fourth
-// wave of k_roots_e fit the 160 KB of LDS.  Entries below the band are structurally zero and never touched.
-DSM_DEV int pl_hess_off(int c) { return c < 7 ? (c * (c + 7)) >> 1 : 10 * c - 21; }
-#define PL_HESS_PACKED_DOUBLES 79
-template <int LD, bool PACKED>
-DSM_DEV int pl_hess_idx(int r, int c) { return PACKED ? pl_hess_off(c) + r : c * LD + r; }
-
-template <int LD, int ES, bool PACKED>
-DSM_DEV void pl_hess_householder_left(double* M, int r0, int c0, int nr, int nc, const double* ess, double tau) {
-  if (tau == 0.0) return;  // nr is 2 or 3 here
-  for (int j = 0; j < nc; ++j) {
-    double* col = M + pl_hess_idx<LD, PACKED>(r0, c0 + j) * ES;
-    double tmp = 0.0;
-    for (int i = 1; i < nr; ++i) tmp += ess[i - 1] * col[i * ES];
-    tmp += col[0];
-    col[0] -= tau * tmp;
-    for (int i = 1; i < nr; ++i) col[i * ES] -= tau * ess[i - 1] * tmp;
-  }
-}
-template <int LD, int ES, bool PACKED>
-DSM_DEV void pl_hess_householder_right(double* M, int r0, int c0, int nr, int nc, const double* ess, double tau) {
-  if (tau == 0.0) return;  // nc is 2 or 3 here
-  int base[3];
-  for (int j = 0; j < nc; ++j) base[j] = pl_hess_idx<LD, PACKED>(r0, c0 + j);
-  for (int i = 0; i < nr; ++i) {
-    double tmp = 0.0;
-    for (int j = 1; j < nc; ++j) tmp += M[(base[j] + i) * ES] * ess[j - 1];
-    tmp += M[(base[0] + i) * ES];
-    M[(base[0] + i) * ES] -= tau * tmp;
-    for (int j = 1; j < nc; ++j) M[(base[j] + i) * ES] -= tau * tmp * ess[j - 1];
-  }
-}
-
 // ColPivHouseholderQR::computeInPlace on qr (rows x cols, rows >= cols here), ld = rows.
 template <int ES = 1>
 DSM_DEV void pl_colpiv_qr(double* qr, int rows, int cols, double* hcoeffs) {
@@ -368,12 +334,9 @@ DSM_DEV void pl_jacobi_svd_square(const double* A_rowmajor, double* U, double* V
 // VALUES_ONLY: the reflectors are not applied to the columns right of the active block (c > iu).  Those columns
 // are deflated for good (iu only decreases) and their entries above the diagonal blocks never feed back into a
 // diagonal block, so the eigenvalues keep their bits (LAPACK's job = 'E'); Eigen itself updates them.
-// PACKED: T is in the packed Hessenberg layout above (LD == 10 only).
-template <int LD, int ES, bool VALUES_ONLY = false, bool PACKED = false>
+template <int LD, int ES, bool VALUES_ONLY = false>
 DSM_DEV bool pl_hessenberg_eigenvalues_impl(double* T, int n, double* re, double* im) {
-  static_assert(!PACKED || LD == 10, "packed layout is written for 10 x 10");
-#define TT(r, c) T[pl_hess_idx<LD, PACKED>((r), (c)) * ES]
-#define IN_BAND(r, c) (!PACKED || (r) <= (c) + 3)
+#define TT(r, c) T[((c) * LD + (r)) * ES]
   for (int i = 0; i < n; ++i) {
     re[i] = 0.0;
     im[i] = 0.0;
@@ -382,14 +345,12 @@ DSM_DEV bool pl_hessenberg_eigenvalues_impl(double* T, int n, double* re, double
   double scale = 0.0;
   for (int j = 0; j < n; ++j)
     for (int i = 0; i < n; ++i) {
-      if (!IN_BAND(i, j)) continue;  // structurally zero: cannot raise the maximum
       const double a = fabs(TT(i, j));
       if (a > scale) scale = a;
     }
   if (scale < DBL_MIN) return true;
   for (int j = 0; j < n; ++j)
-    for (int i = 0; i < n; ++i)
-      if (IN_BAND(i, j)) TT(i, j) /= scale;
+    for (int i = 0; i < n; ++i) TT(i, j) /= scale;
   const int max_iters = 40 * n;
   int iu = n - 1, iter = 0, total_iter = 0;
   double exshift = 0.0;
@@ -517,14 +478,9 @@ DSM_DEV bool pl_hessenberg_eigenvalues_impl(double* T, int n, double* re, double
               TT(k, k - 1) = -TT(k, k - 1);
             else if (!first)
               TT(k, k - 1) = beta;
+            pl_apply_householder_left<ES>(T, LD, k, k, 3, (VALUES_ONLY ? iu + 1 : n) - k, &v[1], tau);
             const int nr = ((iu < k + 3) ? iu : k + 3) + 1;
-            if constexpr (PACKED) {
-              pl_hess_householder_left<LD, ES, true>(T, k, k, 3, (VALUES_ONLY ? iu + 1 : n) - k, &v[1], tau);
-              pl_hess_householder_right<LD, ES, true>(T, 0, k, nr, 3, &v[1], tau);
-            } else {
-              pl_apply_householder_left<ES>(T, LD, k, k, 3, (VALUES_ONLY ? iu + 1 : n) - k, &v[1], tau);
-              pl_apply_householder_right<ES>(T, LD, 0, k, nr, 3, &v[1], tau);
-            }
+            pl_apply_householder_right<ES>(T, LD, 0, k, nr, 3, &v[1], tau);
           }
         }
         {
@@ -533,13 +489,8 @@ DSM_DEV bool pl_hessenberg_eigenvalues_impl(double* T, int n, double* re, double
           pl_make_householder(v, 2, &tau, &beta);
           if (beta != 0.0) {
             TT(iu - 1, iu - 2) = beta;
-            if constexpr (PACKED) {
-              pl_hess_householder_left<LD, ES, true>(T, iu - 1, iu - 1, 2, (VALUES_ONLY ? iu + 1 : n) - iu + 1, &v[1], tau);
-              pl_hess_householder_right<LD, ES, true>(T, 0, iu - 1, iu + 1, 2, &v[1], tau);
-            } else {
-              pl_apply_householder_left<ES>(T, LD, iu - 1, iu - 1, 2, (VALUES_ONLY ? iu + 1 : n) - iu + 1, &v[1], tau);
-              pl_apply_householder_right<ES>(T, LD, 0, iu - 1, iu + 1, 2, &v[1], tau);
-            }
+            pl_apply_householder_left<ES>(T, LD, iu - 1, iu - 1, 2, (VALUES_ONLY ? iu + 1 : n) - iu + 1, &v[1], tau);
+            pl_apply_householder_right<ES>(T, LD, 0, iu - 1, iu + 1, 2, &v[1], tau);
           }
         }
         for (int i = imm + 2; i <= iu; ++i) {
@@ -551,8 +502,7 @@ DSM_DEV bool pl_hessenberg_eigenvalues_impl(double* T, int n, double* re, double
   }
   if (total_iter > max_iters) return false;
   for (int j = 0; j < n; ++j)
-    for (int i = 0; i < n; ++i)
-      if (IN_BAND(i, j)) TT(i, j) *= scale;
+    for (int i = 0; i < n; ++i) TT(i, j) *= scale;
   int i = 0;
   while (i < n) {
     if (i == n - 1 || TT(i + 1, i) == 0.0) {
@@ -580,7 +530,6 @@ DSM_DEV bool pl_hessenberg_eigenvalues_impl(double* T, int n, double* re, double
   }
   return true;
 #undef TT
-#undef IN_BAND
 }
 template <int LD>
 DSM_DEVN bool pl_hessenberg_eigenvalues(double* T, int n, double* re, double* im) {
@@ -643,20 +592,18 @@ DSM_DEV int pl_poly_roots(const double* coeffs_all, int ncoef, double* real, dou
   }
   const int n = nc - 1;
   constexpr int LD = MAXC - 1;
-  constexpr bool PACKED = (ES != 1) && (LD == 10);  // lane-interleaved LDS workspace: PL_HESS_PACKED_DOUBLES per lane
   double C_loc[ES == 1 ? LD * LD : 1];
-  double* C;  // optional caller-provided (LDS) workspace of LD*LD doubles (packed: PL_HESS_PACKED_DOUBLES)
+  double* C;  // optional caller-provided (LDS) workspace of LD*LD doubles
   if constexpr (ES == 1) C = ws ? ws : C_loc; else C = ws;
   for (int j = 0; j < n; ++j)
-    for (int i = 0; i < n; ++i)
-      if (!PACKED || i <= j + 3) C[pl_hess_idx<LD, PACKED>(i, j) * ES] = 0.0;
-  for (int i = 1; i < n; ++i) C[pl_hess_idx<LD, PACKED>(i, i - 1) * ES] = 1.0;
-  for (int j = 0; j < n; ++j) C[pl_hess_idx<LD, PACKED>(0, j) * ES] = -coeffs[j + 1] / coeffs[0];
+    for (int i = 0; i < n; ++i) C[(j * LD + i) * ES] = 0.0;
+  for (int i = 1; i < n; ++i) C[((i - 1) * LD + i) * ES] = 1.0;
+  for (int j = 0; j < n; ++j) C[(j * LD + 0) * ES] = -coeffs[j + 1] / coeffs[0];
   double re[LD], im[LD];
   if (ES == 1) {
     if (!pl_hessenberg_eigenvalues<LD>(C, n, re, im)) return -1;
   } else {
-    if (!pl_hessenberg_eigenvalues_impl<LD, ES, true, PACKED>(C, n, re, im)) return -1;
+    if (!pl_hessenberg_eigenvalues_impl<LD, ES, true>(C, n, re, im)) return -1;
   }
   const int effective_degree = n < degree ? n + 1 : n;
   for (int i = 0; i < effective_degree; ++i) {
