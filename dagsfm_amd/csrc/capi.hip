@@ -800,7 +800,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     uint32_t batch[3], bmax = 0;
     uint64_t bm_max = 0;
     for (int f = 0; f < 3; ++f) {
-      batch[f] = vp_batch(f, vp.max_trials[f]);
+      batch[f] = vp_batch(f, vp.max_trials[f], (uint32_t)std::min<uint64_t>(o->min_num_trials, 0xffffffffull));
       bmax = std::max(bmax, batch[f]);
       bm_max = std::max<uint64_t>(bm_max, (uint64_t)batch[f] * vp_maxm(f));
     }

@@ -162,7 +162,7 @@ void launch_vp_replay(const VerifyParams& p, int fam, uint32_t n_blocks, hipStre
 void launch_vp_final(const VerifyParams& p, uint32_t n_blocks, hipStream_t st);
 void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st);
 void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st);  // over p.worklist / p.n_work
-uint32_t vp_batch(int fam, uint32_t max_trials);
+uint32_t vp_batch(int fam, uint32_t max_trials, uint32_t min_trials);
 uint32_t vp_maxm(int fam);
 void debug_read_prof(unsigned long long* out16);
 void launch_debug_samples(uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out, uint32_t* idx, uint32_t* tmp7,

@@ -1430,11 +1430,18 @@ void launch_verify(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
 //                   nothing), re-scores candidates with the in-order residual_sum, runs the local
 //                   optimisation, applies the dynamic stop, rewinds the generator on an early stop
 // The host repeats the round while any pair is still active (active_count).
-uint32_t vp_batch(int fam, uint32_t max_trials) {
-  if (fam == FAM_E) return 64;
-  if (fam == FAM_F) return 128;
-  const uint32_t b = ((max_trials + 63u) / 64u) * 64u;  // H runs to its cap on non-planar scenes
-  return b < 64u ? 64u : (b > 2048u ? 2048u : b);
+uint32_t vp_batch(int fam, uint32_t max_trials, uint32_t min_trials) {
+  // E / F normally stop after ~60-250 trials (64 / 128 speculated per round); a pair can never stop before
+  // min_num_trials, so with a large minimum (fixed-trial schedules: min = max = 4 096) whole
+  // rounds of that size are certain to be consumed -- fewer, larger rounds
+  uint32_t b;
+  if (fam == FAM_E) b = 64;
+  else if (fam == FAM_F) b = 128;
+  else b = ((max_trials + 63u) / 64u) * 64u;  // H runs to its cap on non-planar scenes
+  const uint32_t cap = fam == FAM_E ? 512u : (fam == FAM_F ? 1024u : 2048u);
+  const uint32_t want = ((min_trials < max_trials ? min_trials : max_trials) + 63u) / 64u * 64u;
+  if (want > b) b = want;
+  return b < 64u ? 64u : (b > cap ? cap : b);
 }
 uint32_t vp_maxm(int fam) { return fam == FAM_E ? 10u : (fam == FAM_F ? 3u : 1u); }
 
