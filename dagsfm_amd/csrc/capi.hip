@@ -833,7 +833,12 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     HIPCHK(ctx, ctx->d_vcounts.reserve((size_t)chunk * bm_max * 4));
     HIPCHK(ctx, ctx->d_models.reserve((size_t)chunk * bm_max * 72));
     HIPCHK(ctx, ctx->d_ework.reserve((size_t)chunk * batch[0] * 200 * 8));
-    const bool inline_lo = getenv("DSM_VERIFY_INLINE_LO") != nullptr;  // reference schedule: k_replay with the LO inline
+    // Local optimisation: batched kernels (k_replay_lo + k_lo_*) or inline in the replay (k_replay).  The batched form
+    // wins on throughput (config 2: 601 vs 708 ms) but every LO costs a kernel round trip, so a short pair list, whose
+    // time is the serial latency of its slowest pair, is faster inline (config 1, 1 225 pairs: 15.5 vs 23.1 ms; the two
+    // meet at ~11 000 pairs).  DSM_VERIFY_INLINE_LO=1 / =0 forces one or the other (tests cover both).
+    bool inline_lo = n_pairs < 16384u;
+    if (const char* e = getenv("DSM_VERIFY_INLINE_LO")) inline_lo = atoi(e) != 0;
     HIPCHK(ctx, ctx->d_lo_inl.reserve(tm * 4));
     HIPCHK(ctx, ctx->d_lo_queue.reserve((size_t)chunk * 2 * 4));
     HIPCHK(ctx, ctx->d_lo_work.reserve((size_t)chunk * LO_WORK_DOUBLES * 8));

@@ -17,6 +17,14 @@ from tests.test_verify_gpu import tvg_equal
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["batched_lo", "inline_lo"])
+def lo_schedule(request, monkeypatch):
+    """Both schedules of the local optimisation: the batched kernels that long pair lists (bench.py) run, and the inline
+    form that the library picks by itself for lists as short as these tests'."""
+    monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "0" if request.param == "batched_lo" else "1")
+    return request.param
+
+
 def _workers():
     try:
         n = len(os.sched_getaffinity(0))
