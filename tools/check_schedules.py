@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""At-scale consistency check of the verification schedules (GPU): the phase-split pipeline (wave sampler, dynamic
-hand-out of pairs, LDS / register solvers) and the first schedule of the round (DSM_VERIFY_LEGACY: one k_ransac kernel
-per family, lane-0 sampler, per-lane scratch solvers) must produce byte-identical TwoViewGeometry records and inlier
-matches on the whole workload -- this exercises the paths too rare for the oracle-sized tests (a Lemire rejection in
-the sampler happens for a few dozen pairs of config 2).
+"""At-scale consistency check of the verification schedules (GPU).  Three independently written device schedules must
+produce byte-identical TwoViewGeometry records and inlier matches on the whole workload:
+  batched   phase-split pipeline, local optimisation as batched kernels (k_replay_lo + k_lo_*; what bench.py runs)
+  inline    phase-split pipeline, local optimisation inline in the wave-per-pair replay (DSM_VERIFY_INLINE_LO=1)
+  legacy    one k_ransac kernel per family, lane-0 sampler, per-lane scratch solvers (DSM_VERIFY_LEGACY=1; --legacy)
+This exercises the paths too rare for the oracle-sized tests (a Lemire rejection in the sampler happens for a few
+dozen pairs of config 2; pairs with > 15 local optimisations in one round).
 
-    python tools/check_schedules.py [--images 500] [--feats 4096]"""
+    python tools/check_schedules.py [--images 500] [--feats 4096] [--legacy]"""
 import argparse
 import ctypes
 import os
@@ -17,11 +19,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dagsfm_amd import capi, synthetic  # noqa: E402
 
 
-def run(ctx, opts, legacy):
-    if legacy:
+def run(ctx, opts, schedule):
+    os.environ.pop("DSM_VERIFY_LEGACY", None)
+    os.environ["DSM_VERIFY_INLINE_LO"] = "1" if schedule == "inline" else "0"
+    if schedule == "legacy":
         os.environ["DSM_VERIFY_LEGACY"] = "1"
-    else:
-        os.environ.pop("DSM_VERIFY_LEGACY", None)
     ctx.verify_pairs(opts, user_seed=0, stage_filter=True)
     recs = np.zeros((ctx.n_pairs, ctypes.sizeof(capi.TwoViewGeometry)), dtype=np.uint8)
     rc = capi.lib().dsm_get_two_view_geometries(ctx._h, recs.ctypes.data)
@@ -34,6 +36,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=500)
     ap.add_argument("--feats", type=int, default=4096)
+    ap.add_argument("--legacy", action="store_true", help="also run the (slow) single-kernel-per-family schedule")
     a = ap.parse_args()
     scene = synthetic.Scene(a.images, a.feats, seed=0)
     ims = [scene.image(i) for i in range(a.images)]
@@ -43,14 +46,18 @@ def main():
     ctx.set_images([im[0] for im in ims], [im[1] for im in ims], cams)
     ctx.match_pairs(pairs)
     opts = capi.default_two_view_options()
-    r0 = run(ctx, opts, False)
-    r1 = run(ctx, opts, True)
-    same = (r0[0] == r1[0]).all() and (r0[1] == r1[1]).all() and (r0[2] == r1[2]).all()
-    # num_trials / num_models are the last 32 bytes of the record
-    print("pairs %d  inlier matches %d  pipeline %.0f ms  legacy %.0f ms  identical: %s" % (len(pairs), len(r0[2]), r0[3], r1[3], same))
-    if not same:
-        bad = np.nonzero((r0[0] != r1[0]).any(axis=1))[0]
-        print("first differing pairs:", bad[:10])
+    r0 = run(ctx, opts, "batched")
+    ok = True
+    for name in ["inline"] + (["legacy"] if a.legacy else []):
+        r1 = run(ctx, opts, name)
+        same = (r0[0] == r1[0]).all() and (r0[1] == r1[1]).all() and (r0[2] == r1[2]).all()
+        # num_trials / num_models are the last 32 bytes of the record
+        print("pairs %d  inlier matches %d  batched %.0f ms  %s %.0f ms  identical: %s" % (len(pairs), len(r0[2]), r0[3], name, r1[3], same))
+        if not same:
+            bad = np.nonzero((r0[0] != r1[0]).any(axis=1))[0]
+            print("first differing pairs:", bad[:10])
+            ok = False
+    if not ok:
         sys.exit(1)
 
 
