@@ -54,6 +54,12 @@ class DeviceInfo(ctypes.Structure):
                 ("total_memory", ctypes.c_uint64), ("l2_bytes", ctypes.c_int32), ("lds_per_cu", ctypes.c_int32)]
 
 
+class Vocabulary(ctypes.Structure):
+    """dsm_vocabulary: visual words, Hamming-embedding projection and per-word thresholds (visual_index.h / inverted_index.h)."""
+    _fields_ = [("num_words", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("words", ctypes.c_void_p),
+                ("projection", ctypes.c_void_p), ("thresholds", ctypes.c_void_p)]
+
+
 _lib = None
 
 
@@ -96,6 +102,11 @@ def lib():
         L.dsm_debug_sample_sequence.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, u32p]
         L.dsm_get_device_info.argtypes = [vp, ctypes.POINTER(DeviceInfo)]
         L.dsm_get_match_gather_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+        L.dsm_retrieval_set_vocabulary.argtypes = [vp, ctypes.POINTER(Vocabulary)]
+        L.dsm_retrieval_index.argtypes = [vp]
+        L.dsm_retrieval_query.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp]
+        L.dsm_retrieval_debug_word_ids.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp]
+        L.dsm_get_retrieval_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.dsm_debug_image_to_world.argtypes = [vp, ctypes.POINTER(Camera), ctypes.c_uint32, ctypes.POINTER(ctypes.c_double),
                                                ctypes.POINTER(ctypes.c_double)]
         L.dsm_default_match_options.argtypes = [ctypes.POINTER(MatchOptions)]
@@ -291,6 +302,36 @@ class Context:
         mo = match_options if match_options is not None else default_match_options()
         to = options if options is not None else default_two_view_options()
         self._chk(lib().dsm_guided_match_pairs(self._h, ctypes.byref(mo), ctypes.byref(to), 1 if stage_filter else 0))
+
+    # ---- vocabulary-tree retrieval (candidate pairs)
+    def retrieval_set_vocabulary(self, words, projection, thresholds):
+        self._voc = (np.ascontiguousarray(words, np.uint8).reshape(-1, 128), np.ascontiguousarray(projection, np.float32).reshape(64, 128),
+                     np.ascontiguousarray(thresholds, np.float32).reshape(-1, 64))
+        assert self._voc[2].shape[0] == self._voc[0].shape[0]
+        v = Vocabulary(num_words=self._voc[0].shape[0], reserved=0, words=self._voc[0].ctypes.data, projection=self._voc[1].ctypes.data,
+                       thresholds=self._voc[2].ctypes.data)
+        self._chk(lib().dsm_retrieval_set_vocabulary(self._h, ctypes.byref(v)))
+
+    def retrieval_index(self):
+        self._chk(lib().dsm_retrieval_index(self._h))
+
+    def retrieval_query(self, n_images, num_neighbors=5, max_num_images=100):
+        """Returns a list (per query image, in dsm_set_images order) of (image_idx [c], scores [c]) in retrieval order."""
+        cnt = np.zeros(n_images, np.uint32)
+        idx = np.zeros((n_images, max_num_images), np.uint32)
+        sc = np.zeros((n_images, max_num_images), np.float32)
+        self._chk(lib().dsm_retrieval_query(self._h, num_neighbors, max_num_images, cnt.ctypes.data, idx.ctypes.data, sc.ctypes.data))
+        return [(idx[q, :cnt[q]].copy(), sc[q, :cnt[q]].copy()) for q in range(n_images)]
+
+    def retrieval_debug_word_ids(self, image, n_feats, k):
+        out = np.zeros((max(n_feats, 1), k), np.int32)
+        self._chk(lib().dsm_retrieval_debug_word_ids(self._h, image, k, out.ctypes.data))
+        return out[:n_feats]
+
+    def retrieval_time(self):
+        a, b = ctypes.c_double(0), ctypes.c_double(0)
+        self._chk(lib().dsm_get_retrieval_time(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def device_info(self):
         d = DeviceInfo()

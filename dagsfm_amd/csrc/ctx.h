@@ -1,0 +1,129 @@
+// ctx.h -- the context behind the C-ABI (shared by capi.hip and capi_retrieval.hip; not part of the public header).
+#ifndef DAGSFM_AMD_CSRC_CTX_H_
+#define DAGSFM_AMD_CSRC_CTX_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/dagsfm_mi355x.h"
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      e = hipMalloc(&p, bytes);
+      want = bytes;
+    }
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  // reserve keeping the old contents (first `keep` bytes)
+  hipError_t grow(size_t bytes, size_t keep, hipStream_t st) {
+    if (bytes <= cap) return hipSuccess;
+    void* np = nullptr;
+    size_t want = bytes + bytes / 2 + 256;
+    hipError_t e = hipMalloc(&np, want);
+    if (e != hipSuccess) {
+      want = bytes;
+      e = hipMalloc(&np, want);
+    }
+    if (e != hipSuccess) return e;
+    if (p && keep) {
+      e = hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (p) (void)hipFree(p);
+    p = np;
+    cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+
+struct dsm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // resident images
+  uint32_t n_images = 0;
+  uint64_t total_rows = 0;
+  std::vector<uint32_t> nfeat, row0, rows;
+  std::vector<dsm_camera> cameras;
+  bool have_kp = false;
+  DevBuf d_desc, d_rterm, d_kp, d_img_row0, d_img_rows, d_lut;
+
+  // last dsm_match_pairs
+  bool matched = false;
+  uint32_t n_pairs = 0;
+  std::vector<uint32_t> pairs;  // n_pairs x 2
+  DevBuf d_dpairs, d_doutoff, d_pair_dir, d_m, d_counts, d_offsets, d_matches, d_total;
+  uint64_t total_matches = 0;
+  double k1_ms = 0.0;
+  double k1b_ms = 0.0;  // k1_resolve_index
+  double k1g_ms = 0.0;  // k1_best_rows<GATHER> (pass 2 of the cross-check)
+  DevBuf d_order, d_dpairs2, d_ecnt, d_eoff, d_etotal, d_entries, d_out2;
+  uint32_t k1_launches = 0;
+  std::vector<hipEvent_t> ev;
+
+  // last dsm_verify_pairs
+  bool verified = false;
+  DevBuf d_cams, d_pairs_dev, d_seeds, d_tvg, d_inl, d_inl_counts, d_inl_off, d_inl_compact, d_vscratch, d_inl_total;
+  DevBuf d_nt_table, d_nt_off, d_nt_off_t, d_pair_state, d_pts_px, d_pts_norm, d_reports, d_masks;
+  DevBuf d_fam_state, d_samples, d_draws_end, d_nmodels, d_vcounts, d_models, d_sidx, d_active;
+  DevBuf d_ework;
+  DevBuf d_lo_inl, d_lo_queue, d_lo_work, d_lo_models, d_lo_slots, d_lo_ework;  // batched local optimisation
+  uint32_t verify_lo_iters[3] = {0, 0, 0};
+  DevBuf d_g_nfeat, d_g_dpairs, d_g_doff, d_g_pdir, d_g_params, d_g_m, d_g_counts, d_g_offsets, d_g_total, d_g_matches,
+      d_g_plan, d_g_inl, d_g_inl_off;  // guided matching
+  DevBuf d_mm_matches[2], d_mm_off[2], d_mm_counts, d_mm_state, d_mm_first, d_mm_acc, d_mm_keep, d_mm_total;  // EstimateMultiple
+  uint32_t verify_rounds[3] = {0, 0, 0};
+  uint64_t total_inliers = 0;
+  double verify_ms = 0.0;
+  // cache of the tabulated RANSAC::ComputeNumTrials (host libm), keyed by confidence
+  double nt_confidence = -1.0;
+  std::vector<uint32_t> nt_table;        // all tables back to back
+  std::vector<uint64_t> nt_off, nt_off_t;  // per N (0 = absent; offsets are stored +1)
+  bool nt_dirty = true;
+  hipEvent_t vev0 = nullptr, vev1 = nullptr;
+
+  dsm_ctx* leaf = nullptr;  // private context of the one-shot leaf entry points
+
+  struct RetrievalState* retrieval = nullptr;  // vocabulary-tree retrieval (retrieval.hip), created on first use
+};
+void dsm_retrieval_destroy(dsm_ctx* ctx);     // retrieval.hip
+void dsm_retrieval_invalidate(dsm_ctx* ctx);  // retrieval.hip: the resident images changed
+
+#define HIPCHK(ctx, call)                                                              \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+      return DSM_ERR_HIP;                                                              \
+    }                                                                                  \
+  } while (0)
+
+
+static inline int dsm_fail(dsm_ctx* ctx, int code, const char* msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+#endif  // DAGSFM_AMD_CSRC_CTX_H_

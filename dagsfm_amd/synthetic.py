@@ -180,3 +180,22 @@ def exhaustive_pairs(n_images):
     (/root/reference/src/feature/matching.cc:853-915 with one block: idx1 < idx2)."""
     i, j = np.triu_indices(n_images, k=1)
     return np.stack([i, j], axis=1).astype(np.uint32)
+
+
+def vocabulary(scene, num_words, seed=0):
+    """A vocabulary for the retrieval tests / bench (no pre-trained vocab tree is reachable offline): visual words =
+    `num_words` descriptors of the scene's pool with a little noise (what hierarchical k-means centres look like for
+    this generator), an orthonormal 64 x 128 projection from the QR of a seeded Gaussian matrix
+    (InvertedIndex::GenerateHammingEmbeddingProjection, /root/reference/src/retrieval/inverted_index.h:175-184) and
+    per-word thresholds = the projection of the word itself plus noise (stand-in for the per-word medians of
+    ComputeHammingEmbedding, :186-217).  Returns (words u8 [W,128], projection f32 [64,128], thresholds f32 [W,64])."""
+    rng = np.random.default_rng([scene.seed, 0x70CAB, seed])
+    pick = rng.choice(scene.n_pool, size=num_words, replace=num_words > scene.n_pool)
+    w = scene.base[pick] + rng.normal(scale=0.02, size=(num_words, 128)).astype(np.float32)
+    np.maximum(w, 0.0, out=w)
+    w /= np.linalg.norm(w, axis=1, keepdims=True)
+    words = _to_u8(w)
+    q, _ = np.linalg.qr(rng.normal(size=(128, 128)))
+    proj = np.ascontiguousarray(q[:64].astype(np.float32))
+    thr = (words.astype(np.float32) @ proj.T + rng.normal(scale=8.0, size=(num_words, 64))).astype(np.float32)
+    return words, proj, np.ascontiguousarray(thr)

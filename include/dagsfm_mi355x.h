@@ -264,6 +264,34 @@ int dsm_debug_sample_sequence(dsm_ctx* ctx, uint32_t seed, uint32_t k, uint32_t 
 /* Test hook: Camera::ImageToWorld (src/base/camera.cc:210-214) of n pixel points (x, y) on the device. */
 int dsm_debug_image_to_world(dsm_ctx* ctx, const dsm_camera* camera, uint32_t n, const double* xy, double* out_uv);
 
+/* ------------------------------------------------------------------ vocabulary-tree retrieval (candidate pairs)
+ * The step BEFORE matching: VocabSimilarityGraph::Run (src/graph/similarity_graph.cpp:101-199)
+ * indexes every image in a retrieval::VisualIndex (src/retrieval/visual_index.h) and queries every image against it;
+ * an image and each image retrieved for it become a candidate pair.  Works on the images of dsm_set_images
+ * (descriptors only).  Deviations from the reference, all in DESIGN.md: the nearest visual words are EXACT (the
+ * reference asks FLANN for approximate ones), float sums run left to right, ties keep first-seen order. */
+typedef struct dsm_vocabulary {
+  uint32_t num_words;      /* visual words (leaves of the vocabulary tree), VisualIndex::NumVisualWords */
+  uint32_t reserved;
+  const uint8_t* words;    /* [num_words][128] uint8 centroids, visual_words_ (visual_index.h:176-178) */
+  const float* projection; /* [64][128] row-major Hamming-embedding projection, InvertedIndex::proj_matrix_ */
+  const float* thresholds; /* [num_words][64] per-word embedding thresholds, InvertedFile::thresholds_ */
+} dsm_vocabulary;
+int dsm_retrieval_set_vocabulary(dsm_ctx* ctx, const dsm_vocabulary* vocabulary);
+/* VisualIndex::Add (IndexOptions::num_neighbors = 1) for every resident image in list order, then Prepare()
+ * (visual_index.h:201-243, 501-505): inverted files sorted by image, IDF weights, normalisation constants. */
+int dsm_retrieval_index(dsm_ctx* ctx);
+/* VisualIndex::Query (num_images_after_verification = 0, visual_index.h:664-693) for every resident image:
+ * counts[q] image scores (<= max_num_images) for query image q, image_idx / scores at [q * max_num_images + k] in
+ * retrieval order (descending score).  The query image itself is among its results, as in the reference.
+ * num_neighbors: QueryOptions::num_neighbors (VocabSimilaritySearchOptions::num_nearest_neighbors, default 5, max 8). */
+int dsm_retrieval_query(dsm_ctx* ctx, uint32_t num_neighbors, uint32_t max_num_images, uint32_t* counts,
+                        uint32_t* image_idx, float* scores);
+/* Test hook: the k nearest visual words (ascending distance, ties to the lower id) of every feature of one image. */
+int dsm_retrieval_debug_word_ids(dsm_ctx* ctx, uint32_t image, uint32_t k, int32_t* out);
+/* Device time (HIP events) of the last dsm_retrieval_index / dsm_retrieval_query. */
+int dsm_get_retrieval_time(dsm_ctx* ctx, double* index_ms, double* query_ms);
+
 void dsm_default_match_options(dsm_match_options* o);
 void dsm_default_two_view_options(dsm_two_view_options* o);
 

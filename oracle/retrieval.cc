@@ -1,0 +1,286 @@
+// retrieval.cc -- CPU restatement of the reference's vocabulary-tree image retrieval, the candidate-pair generation
+// that feeds the matcher: VocabSimilarityGraph::Run
+// (/root/reference/src/graph/similarity_graph.cpp:101-199) = index every image in a VisualIndex, query every image,
+// keep (image, retrieved image) with image < retrieved.
+//
+// TEST INFRASTRUCTURE ONLY (see oracle/Makefile): the checker of the HIP path in dagsfm_amd/csrc/retrieval_kernels.hip.
+//
+// Restated, function by function:
+//   VisualIndex::Add                 src/retrieval/visual_index.h:201-243   word of every feature, entry per word
+//   VisualIndex::Prepare             :501-505 -> InvertedIndex::Finalize (inverted_index.h:163-172)
+//   InvertedFile::SortEntries        src/retrieval/inverted_file.h:223-230
+//   InvertedFile::ComputeIDFWeight   :260-271         ComputeImageSelfSimilarities :374-381
+//   InvertedIndex::ComputeWeightsAndNormalizationConstants  inverted_index.h:413-440
+//   VisualIndex::QueryAndFindWordIds visual_index.h:664-693    InvertedIndex::Query inverted_index.h:237-286
+//   InvertedFile::ScoreFeature       inverted_file.h:297-361   ConvertToBinaryDescriptor :248-257
+//   HammingDistWeightFunctor         src/retrieval/utils.h:47-78
+//   InvertedIndex::ComputeSelfSimilarity inverted_index.h:327-339
+//
+// Third-party arithmetic that is NOT restated, and what stands in its place (DESIGN.md "Retrieval"):
+//   * FindWordIds (visual_index.h:695-738) asks FLANN's AutotunedIndex (lib/FLANN, randomised kd-trees / k-means
+//     tree, `num_checks` leaves) for APPROXIMATE nearest visual words.  Its answer depends on FLANN's random seeds and
+//     is not reproducible; here the search is EXACT: the num_neighbors words with the smallest squared L2 distance
+//     (integer arithmetic), ties to the lower word id, in ascending distance as FLANN returns them.
+//   * `proj_matrix_ * descriptor.cast<float>()` is an Eigen float matrix-vector product whose summation order depends
+//     on Eigen's vectorisation; here each of the 64 sums runs over the 128 dimensions left to right in float
+//     (one rounding per multiply and per add).
+//   * std::sort / std::partial_sort are not stable: entries of one image inside an inverted file are kept in feature
+//     order, and images of equal score in the order they were first scored.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+namespace {
+
+const int kDescDim = 128, kEmbeddingDim = 64;
+const int kInvalidWordId = std::numeric_limits<int>::max();
+
+struct Entry {  // InvertedFileEntry, inverted_file_entry.h:44-62 (the geometry is only used by spatial verification)
+  int image_id;
+  int feature_idx;
+  uint64_t descriptor;
+};
+
+// HammingDistWeightFunctor<64, 16>, utils.h:47-78
+struct HammingWeights {
+  static const size_t kMaxHammingDistance = static_cast<size_t>(1.5f * 16);
+  float lut[kEmbeddingDim + 1];
+  HammingWeights() {
+    const float sigma_squared = 16 * 16;
+    for (int n = 0; n <= kEmbeddingDim; ++n) {
+      const float hamming_dist = static_cast<float>(n);
+      lut[n] = hamming_dist <= kMaxHammingDistance ? std::exp(-hamming_dist * hamming_dist / sigma_squared) : 0.0f;
+    }
+  }
+};
+
+struct ImageScore {
+  int image_id = -1;
+  float score = 0.0f;
+};
+
+struct InvertedFile {
+  std::vector<Entry> entries;
+  float thresholds[kEmbeddingDim];
+  float idf_weight = 0.0f;
+};
+
+struct Index {
+  int num_words = 0;
+  std::vector<uint8_t> words;  // [W][128]
+  std::vector<float> proj;     // [64][128] row-major
+  std::vector<InvertedFile> files;
+  std::unordered_map<int, float> normalization_constants;
+  HammingWeights weights;
+};
+
+// exact stand-in for VisualIndex::FindWordIds (see the header): ids[i*k + n], ascending distance, ties to the lower id
+void FindWordIds(const Index& ix, const uint8_t* desc, int n_desc, int k, std::vector<int>* ids) {
+  ids->assign(static_cast<size_t>(n_desc) * k, kInvalidWordId);
+  std::vector<std::pair<int64_t, int>> best(k);
+  for (int i = 0; i < n_desc; ++i) {
+    const uint8_t* d = desc + static_cast<size_t>(i) * kDescDim;
+    int have = 0;
+    for (int w = 0; w < ix.num_words; ++w) {
+      const uint8_t* c = ix.words.data() + static_cast<size_t>(w) * kDescDim;
+      int64_t dist = 0;
+      for (int j = 0; j < kDescDim; ++j) {
+        const int t = static_cast<int>(d[j]) - static_cast<int>(c[j]);
+        dist += t * t;
+      }
+      if (have < k) {
+        best[have++] = std::make_pair(dist, w);
+        for (int p = have - 1; p > 0 && best[p] < best[p - 1]; --p) std::swap(best[p], best[p - 1]);
+      } else if (std::make_pair(dist, w) < best[k - 1]) {
+        best[k - 1] = std::make_pair(dist, w);
+        for (int p = k - 1; p > 0 && best[p] < best[p - 1]; --p) std::swap(best[p], best[p - 1]);
+      }
+    }
+    for (int n = 0; n < have; ++n) (*ids)[static_cast<size_t>(i) * k + n] = best[n].second;
+  }
+}
+
+// proj_matrix_ * descriptor.cast<float>(), inverted_index.h:222-223 (summation order: see the header)
+void Project(const Index& ix, const uint8_t* d, float* out) {
+  for (int i = 0; i < kEmbeddingDim; ++i) {
+    float s = 0.0f;
+    const float* row = ix.proj.data() + static_cast<size_t>(i) * kDescDim;
+    for (int j = 0; j < kDescDim; ++j) s = s + row[j] * static_cast<float>(d[j]);
+    out[i] = s;
+  }
+}
+
+// InvertedFile::ConvertToBinaryDescriptor, inverted_file.h:248-257
+uint64_t Binarize(const InvertedFile& f, const float* proj) {
+  uint64_t b = 0;
+  for (int i = 0; i < kEmbeddingDim; ++i)
+    if (proj[i] > f.thresholds[i]) b |= (1ull << i);
+  return b;
+}
+
+// InvertedFile::ScoreFeature, inverted_file.h:297-361
+void ScoreFeature(const Index& ix, const InvertedFile& f, const float* proj, std::vector<ImageScore>* image_scores) {
+  image_scores->clear();
+  if (f.entries.empty()) return;  // every file is usable once its entries are sorted (status & USABLE, :203-205)
+  const float squared_idf_weight = f.idf_weight * f.idf_weight;
+  const uint64_t bin_descriptor = Binarize(f, proj);
+  ImageScore image_score;
+  image_score.image_id = f.entries.front().image_id;
+  image_score.score = 0.0f;
+  int num_image_votes = 0;
+  for (const Entry& entry : f.entries) {
+    if (image_score.image_id < entry.image_id) {
+      if (num_image_votes > 0) {
+        image_score.score /= std::sqrt(static_cast<float>(num_image_votes));
+        image_score.score *= squared_idf_weight;
+        image_scores->push_back(image_score);
+      }
+      image_score.image_id = entry.image_id;
+      image_score.score = 0.0f;
+      num_image_votes = 0;
+    }
+    const size_t hamming_dist = static_cast<size_t>(__builtin_popcountll(bin_descriptor ^ entry.descriptor));
+    if (hamming_dist <= HammingWeights::kMaxHammingDistance) {
+      image_score.score += ix.weights.lut[hamming_dist];
+      num_image_votes += 1;
+    }
+  }
+  if (num_image_votes > 0) {
+    image_score.score /= std::sqrt(static_cast<float>(num_image_votes));
+    image_score.score *= squared_idf_weight;
+    image_scores->push_back(image_score);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+struct OracleVocabulary {
+  uint32_t num_words;
+  const uint8_t* words;     // [W][128]
+  const float* proj;        // [64][128]
+  const float* thresholds;  // [W][64]
+};
+
+void* oracle_retrieval_create(const OracleVocabulary* v) {
+  Index* ix = new Index();
+  ix->num_words = static_cast<int>(v->num_words);
+  ix->words.assign(v->words, v->words + static_cast<size_t>(v->num_words) * kDescDim);
+  ix->proj.assign(v->proj, v->proj + kEmbeddingDim * kDescDim);
+  ix->files.resize(v->num_words);
+  for (uint32_t w = 0; w < v->num_words; ++w)
+    std::memcpy(ix->files[w].thresholds, v->thresholds + static_cast<size_t>(w) * kEmbeddingDim, sizeof(float) * kEmbeddingDim);
+  return ix;
+}
+void oracle_retrieval_destroy(void* h) { delete static_cast<Index*>(h); }
+
+// exact nearest words (test hook for the device's word assignment)
+void oracle_retrieval_find_word_ids(void* h, const uint8_t* desc, uint32_t n, uint32_t k, int32_t* out) {
+  std::vector<int> ids;
+  FindWordIds(*static_cast<Index*>(h), desc, static_cast<int>(n), static_cast<int>(k), &ids);
+  for (size_t i = 0; i < ids.size(); ++i) out[i] = ids[i];
+}
+
+// VisualIndex::Add with IndexOptions::num_neighbors = 1 (visual_index.h:62-73, 201-243)
+void oracle_retrieval_add(void* h, int image_id, const uint8_t* desc, uint32_t n) {
+  Index& ix = *static_cast<Index*>(h);
+  if (n == 0) return;
+  std::vector<int> ids;
+  FindWordIds(ix, desc, static_cast<int>(n), 1, &ids);
+  float proj[kEmbeddingDim];
+  for (uint32_t i = 0; i < n; ++i) {
+    const int word_id = ids[i];
+    if (word_id == kInvalidWordId) continue;
+    Project(ix, desc + static_cast<size_t>(i) * kDescDim, proj);
+    Entry e;
+    e.image_id = image_id;
+    e.feature_idx = static_cast<int>(i);
+    e.descriptor = Binarize(ix.files[word_id], proj);
+    ix.files[word_id].entries.push_back(e);
+  }
+}
+
+// VisualIndex::Prepare -> InvertedIndex::Finalize (inverted_index.h:163-172, 413-440)
+void oracle_retrieval_prepare(void* h) {
+  Index& ix = *static_cast<Index*>(h);
+  std::unordered_set<int> image_ids;
+  for (InvertedFile& f : ix.files) {
+    std::stable_sort(f.entries.begin(), f.entries.end(), [](const Entry& a, const Entry& b) { return a.image_id < b.image_id; });
+    for (const Entry& e : f.entries) image_ids.insert(e.image_id);
+  }
+  for (InvertedFile& f : ix.files) {  // InvertedFile::ComputeIDFWeight, inverted_file.h:260-271
+    if (f.entries.empty()) continue;
+    std::unordered_set<int> ids;
+    for (const Entry& e : f.entries) ids.insert(e.image_id);
+    f.idf_weight = std::log(static_cast<double>(image_ids.size()) / static_cast<double>(ids.size()));
+  }
+  std::unordered_map<int, double> self_similarities;
+  for (const InvertedFile& f : ix.files) {  // ComputeImageSelfSimilarities, :374-381
+    const double squared_idf_weight = f.idf_weight * f.idf_weight;
+    for (const Entry& e : f.entries) self_similarities[e.image_id] += squared_idf_weight;
+  }
+  ix.normalization_constants.clear();
+  for (const auto& s : self_similarities)
+    ix.normalization_constants[s.first] = s.second > 0.0 ? static_cast<float>(1.0 / std::sqrt(s.second)) : 0.0f;
+}
+
+// VisualIndex::QueryAndFindWordIds (visual_index.h:664-693) with num_images_after_verification = 0.
+// Returns the number of image scores written (<= capacity): ids / scores in retrieval order.
+uint32_t oracle_retrieval_query(void* h, const uint8_t* desc, uint32_t n, uint32_t num_neighbors, int32_t max_num_images,
+                                int32_t* out_ids, float* out_scores, uint32_t capacity) {
+  Index& ix = *static_cast<Index*>(h);
+  if (n == 0) return 0;
+  std::vector<int> word_ids;  // (i, nn) row-major here
+  FindWordIds(ix, desc, static_cast<int>(n), static_cast<int>(num_neighbors), &word_ids);
+  // InvertedIndex::ComputeSelfSimilarity (inverted_index.h:327-339): linear index over the COLUMN-major Eigen::MatrixXi
+  double self_similarity_d = 0.0;
+  for (uint32_t nn = 0; nn < num_neighbors; ++nn)
+    for (uint32_t i = 0; i < n; ++i) {
+      const int word_id = word_ids[static_cast<size_t>(i) * num_neighbors + nn];
+      if (word_id != kInvalidWordId) self_similarity_d += ix.files[word_id].idf_weight * ix.files[word_id].idf_weight;
+    }
+  const float self_similarity = static_cast<float>(self_similarity_d);
+  float normalization_weight = 1.0f;
+  if (self_similarity > 0.0f) normalization_weight = 1.0f / std::sqrt(self_similarity);
+
+  std::vector<ImageScore> image_scores, inverted_file_scores;
+  std::unordered_map<int, int> score_map;
+  float proj[kEmbeddingDim];
+  for (uint32_t i = 0; i < n; ++i) {
+    Project(ix, desc + static_cast<size_t>(i) * kDescDim, proj);
+    for (uint32_t nn = 0; nn < num_neighbors; ++nn) {
+      const int word_id = word_ids[static_cast<size_t>(i) * num_neighbors + nn];
+      if (word_id == kInvalidWordId) continue;
+      ScoreFeature(ix, ix.files[word_id], proj, &inverted_file_scores);
+      for (const ImageScore& score : inverted_file_scores) {
+        const auto it = score_map.find(score.image_id);
+        if (it == score_map.end()) {
+          score_map.emplace(score.image_id, static_cast<int>(image_scores.size()));
+          image_scores.push_back(score);
+        } else {
+          image_scores[it->second].score += score.score;
+        }
+      }
+    }
+  }
+  for (ImageScore& score : image_scores) score.score *= normalization_weight * ix.normalization_constants.at(score.image_id);
+  auto SortFunc = [](const ImageScore& a, const ImageScore& b) { return a.score > b.score; };
+  size_t num_images = image_scores.size();
+  if (max_num_images >= 0) num_images = std::min<size_t>(image_scores.size(), static_cast<size_t>(max_num_images));
+  std::stable_sort(image_scores.begin(), image_scores.end(), SortFunc);  // partial_sort + resize, ties: see the header
+  image_scores.resize(num_images);
+  const uint32_t m = static_cast<uint32_t>(std::min<size_t>(image_scores.size(), capacity));
+  for (uint32_t k = 0; k < m; ++k) {
+    out_ids[k] = image_scores[k].image_id;
+    out_scores[k] = image_scores[k].score;
+  }
+  return m;
+}
+
+}  // extern "C"

@@ -261,3 +261,55 @@ def load_native(build_dir=None):
         return Oracle(ctypes.CDLL(os.path.join(d, "liboracle_native.so")))
     except Exception:
         return None
+
+
+class OracleVocabulary(ctypes.Structure):
+    _fields_ = [("num_words", ctypes.c_uint32), ("words", ctypes.c_void_p), ("proj", ctypes.c_void_p), ("thresholds", ctypes.c_void_p)]
+
+
+class RetrievalOracle:
+    """oracle/retrieval.cc: VisualIndex Add / Prepare / Query restated (exact nearest words)."""
+
+    def __init__(self, words, projection, thresholds):
+        self.L = load().lib
+        L = self.L
+        L.oracle_retrieval_create.restype = ctypes.c_void_p
+        L.oracle_retrieval_create.argtypes = [ctypes.POINTER(OracleVocabulary)]
+        L.oracle_retrieval_destroy.argtypes = [ctypes.c_void_p]
+        L.oracle_retrieval_find_word_ids.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+        L.oracle_retrieval_add.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32]
+        L.oracle_retrieval_prepare.argtypes = [ctypes.c_void_p]
+        L.oracle_retrieval_query.restype = ctypes.c_uint32
+        L.oracle_retrieval_query.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+        self._keep = (np.ascontiguousarray(words, np.uint8).reshape(-1, 128), np.ascontiguousarray(projection, np.float32).reshape(64, 128),
+                      np.ascontiguousarray(thresholds, np.float32).reshape(-1, 64))
+        v = OracleVocabulary(num_words=self._keep[0].shape[0], words=self._keep[0].ctypes.data, proj=self._keep[1].ctypes.data,
+                             thresholds=self._keep[2].ctypes.data)
+        self.h = L.oracle_retrieval_create(ctypes.byref(v))
+
+    def __del__(self):
+        try:
+            self.L.oracle_retrieval_destroy(self.h)
+        except Exception:
+            pass
+
+    def find_word_ids(self, desc, k):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 128)
+        out = np.zeros((len(d), k), np.int32)
+        self.L.oracle_retrieval_find_word_ids(self.h, d.ctypes.data, len(d), k, out.ctypes.data)
+        return out
+
+    def add(self, image_id, desc):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 128)
+        self.L.oracle_retrieval_add(self.h, image_id, d.ctypes.data, len(d))
+
+    def prepare(self):
+        self.L.oracle_retrieval_prepare(self.h)
+
+    def query(self, desc, num_neighbors=5, max_num_images=-1, capacity=100000):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 128)
+        ids = np.zeros(capacity, np.int32)
+        sc = np.zeros(capacity, np.float32)
+        n = self.L.oracle_retrieval_query(self.h, d.ctypes.data, len(d), num_neighbors, max_num_images, ids.ctypes.data, sc.ctypes.data, capacity)
+        return ids[:n].copy(), sc[:n].copy()
