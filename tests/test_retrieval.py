@@ -81,6 +81,7 @@ def test_device_retrieval_equals_oracle(dsm, n_img, feats, n_words, max_images):
         ids, sc = orc.query(d, 5, max_images)
         assert list(res[q][0]) == list(ids), (q, list(res[q][0])[:8], list(ids)[:8])
         assert (res[q][1] == sc).all(), q
-        assert res[q][0][0] == q  # an image retrieves itself first
+        if n_words >= 256:
+            assert res[q][0][0] == q  # with a vocabulary that discriminates, an image retrieves itself first
     t_index, t_query = dsm.retrieval_time()
     assert t_index > 0 and t_query > 0
