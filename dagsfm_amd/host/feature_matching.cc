@@ -2,6 +2,7 @@
 #include "feature_matching.h"
 
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 
 #include <algorithm>
@@ -136,6 +137,101 @@ bool ExhaustiveFeatureMatcher::Run() {
   return true;
 }
 
+// ---------------------------------------------------------------------------------------- retrieval
+bool VocabularyFile::Read(const std::string& path) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;
+  char magic[8];
+  uint32_t hdr[2];
+  bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "DSMVOC1", 8) == 0 && std::fread(hdr, 4, 2, f) == 2 && hdr[0] > 0;
+  if (ok) {
+    num_words = hdr[0];
+    words.resize(static_cast<size_t>(num_words) * 128);
+    projection.resize(64 * 128);
+    thresholds.resize(static_cast<size_t>(num_words) * 64);
+    ok = std::fread(words.data(), 1, words.size(), f) == words.size() &&
+         std::fread(projection.data(), 4, projection.size(), f) == projection.size() &&
+         std::fread(thresholds.data(), 4, thresholds.size(), f) == thresholds.size();
+  }
+  std::fclose(f);
+  return ok;
+}
+bool VocabularyFile::Write(const std::string& path) const {
+  FILE* f = std::fopen(path.c_str(), "wb");
+  if (!f) return false;
+  const uint32_t hdr[2] = {num_words, 0};
+  const bool ok = std::fwrite("DSMVOC1", 1, 8, f) == 8 && std::fwrite(hdr, 4, 2, f) == 2 &&
+                  std::fwrite(words.data(), 1, words.size(), f) == words.size() &&
+                  std::fwrite(projection.data(), 4, projection.size(), f) == projection.size() &&
+                  std::fwrite(thresholds.data(), 4, thresholds.size(), f) == thresholds.size();
+  std::fclose(f);
+  return ok;
+}
+
+VocabSimilarityGraph::VocabSimilarityGraph(const VocabSimilaritySearchOptions& options, const Database& database)
+    : options_(options), database_(&database), cache_(5 * static_cast<size_t>(options.num_images), &database) {}
+
+bool VocabSimilarityGraph::Run() {
+  image_pairs_.clear();
+  scores_.clear();
+  if (!options_.Check()) {
+    last_error_ = "VocabSimilaritySearchOptions::Check failed (spatial verification and max_num_features are not built)";
+    return false;
+  }
+  VocabularyFile voc;
+  if (!voc.Read(options_.vocab_tree_path)) {
+    last_error_ = "cannot read vocabulary " + options_.vocab_tree_path;
+    return false;
+  }
+  cache_.Setup();
+  const std::vector<image_t> ids = cache_.GetImageIds();
+  const uint32_t n = static_cast<uint32_t>(ids.size());
+  if (n == 0) return true;
+  dsm_ctx* ctx = nullptr;
+  if (dsm_ctx_create(0, &ctx) != DSM_OK) {
+    last_error_ = dsm_last_error(nullptr);
+    return false;
+  }
+  // descriptors only; copied, because the cache is an LRU (all images are indexed at once, like the reference's
+  // IndexImagesInVisualIndex, similarity_graph.cpp:56-85)
+  std::vector<std::vector<uint8_t>> copies(n);
+  std::vector<uint32_t> nfeat(n);
+  std::vector<const uint8_t*> desc(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const FeatureDescriptors& d = cache_.GetDescriptors(ids[i]);
+    copies[i] = d.data;
+    nfeat[i] = static_cast<uint32_t>(d.rows);
+    desc[i] = copies[i].data();
+    cache_.ReleasePins();
+  }
+  dsm_vocabulary v;
+  v.num_words = voc.num_words;
+  v.reserved = 0;
+  v.words = voc.words.data();
+  v.projection = voc.projection.data();
+  v.thresholds = voc.thresholds.data();
+  const uint32_t max_images = std::min<uint32_t>(static_cast<uint32_t>(options_.num_images), n);
+  std::vector<uint32_t> counts(n), idx(static_cast<size_t>(n) * max_images);
+  std::vector<float> sc(static_cast<size_t>(n) * max_images);
+  int rc = dsm_set_images(ctx, n, nfeat.data(), desc.data(), nullptr, 0, nullptr);
+  if (rc == DSM_OK) rc = dsm_retrieval_set_vocabulary(ctx, &v);
+  if (rc == DSM_OK) rc = dsm_retrieval_index(ctx);
+  if (rc == DSM_OK)
+    rc = dsm_retrieval_query(ctx, static_cast<uint32_t>(options_.num_nearest_neighbors), max_images, counts.data(), idx.data(), sc.data());
+  if (rc != DSM_OK) last_error_ = dsm_last_error(ctx);
+  dsm_ctx_destroy(ctx);
+  if (rc != DSM_OK) return false;
+  for (uint32_t q = 0; q < n; ++q)  // similarity_graph.cpp:183-194
+    for (uint32_t k = 0; k < counts[q]; ++k) {
+      const image_t other = ids[idx[static_cast<size_t>(q) * max_images + k]];
+      if (ids[q] < other) {
+        image_pairs_.emplace_back(ids[q], other);
+        scores_.push_back(sc[static_cast<size_t>(q) * max_images + k] * 1e3f);
+      }
+    }
+  return true;
+}
+
 }  // namespace dagsfm_amd
 
 // ---------------------------------------------------------------------------------------- flat C API
@@ -261,6 +357,43 @@ int dsm_host_db_read_pair(const char* database_path, uint32_t image_id1, uint32_
 }
 
 uint64_t dsm_host_image_pair_to_pair_id(uint32_t a, uint32_t b) { return Database::ImagePairToPairId(a, b); }
+
+// VocabSimilarityGraph::Run over database_path with the vocabulary file; writes up to `capacity` pairs (image ids) and
+// their scores.  Returns the number of pairs, or < 0 on error.
+int64_t dsm_host_vocab_candidate_pairs(const char* database_path, const char* vocab_path, int num_images, int num_nearest_neighbors,
+                                       uint32_t* pairs, float* scores, uint64_t capacity) {
+  try {
+    Database db(database_path);
+    VocabSimilaritySearchOptions o;
+    o.num_images = num_images;
+    o.num_nearest_neighbors = num_nearest_neighbors;
+    o.vocab_tree_path = vocab_path;
+    VocabSimilarityGraph g(o, db);
+    if (!g.Run()) {
+      std::cerr << "ERROR: " << g.LastError() << std::endl;
+      return -2;
+    }
+    const uint64_t n = std::min<uint64_t>(capacity, g.ImagePairs().size());
+    for (uint64_t k = 0; k < n; ++k) {
+      pairs[2 * k] = g.ImagePairs()[k].first;
+      pairs[2 * k + 1] = g.ImagePairs()[k].second;
+      scores[k] = g.Scores()[k];
+    }
+    return static_cast<int64_t>(g.ImagePairs().size());
+  } catch (const std::exception& e) {
+    std::cerr << "ERROR: " << e.what() << std::endl;
+    return -1;
+  }
+}
+
+int dsm_host_write_vocabulary(const char* path, uint32_t num_words, const uint8_t* words, const float* projection, const float* thresholds) {
+  VocabularyFile v;
+  v.num_words = num_words;
+  v.words.assign(words, words + static_cast<size_t>(num_words) * 128);
+  v.projection.assign(projection, projection + 64 * 128);
+  v.thresholds.assign(thresholds, thresholds + static_cast<size_t>(num_words) * 64);
+  return v.Write(path) ? 0 : 1;
+}
 
 // CPU-only probe of FeatureMatcherCache's LRU: touches the given image ids in order (releasing the pins after every
 // `pin_batch` requests, like one Match() call does) and returns the largest number of images the cache ever held.

@@ -228,5 +228,47 @@ class ExhaustiveFeatureMatcher {
   SiftFeatureMatcher matcher_;
 };
 
+// Candidate pairs by vocabulary-tree retrieval: DAGSfM::VocabSimilarityGraph (src/graph/similarity_graph.h:52-89,
+// similarity_graph.cpp:101-199) over the C-ABI's dsm_retrieval_* entry points.  Run() indexes every image of the
+// database, queries every image and keeps (image_id, retrieved image_id) for image_id < retrieved, with
+// score * 1e3 (similarity_graph.cpp:186-193), in the order of the image ids.
+struct VocabSimilaritySearchOptions {  // similarity_graph.h:52-76
+  int num_images = 100;
+  int num_nearest_neighbors = 5;
+  int num_checks = 256;                   // FLANN search effort in the reference; the search is exact here
+  int num_images_after_verification = 0;  // spatial verification is not built (0 = off is the reference's default)
+  int max_num_features = -1;
+  int num_threads = 8;
+  std::string vocab_tree_path;
+  bool Check() const { return num_images > 0 && !vocab_tree_path.empty() && num_images_after_verification == 0 && max_num_features <= 0; }
+};
+
+// The vocabulary as this library reads it (a flat file; INTEGRATION.md shows how to write it from a VisualIndex):
+//   "DSMVOC1\0", uint32 num_words, uint32 reserved, words u8 [W][128], projection f32 [64][128], thresholds f32 [W][64]
+struct VocabularyFile {
+  uint32_t num_words = 0;
+  std::vector<uint8_t> words;
+  std::vector<float> projection, thresholds;
+  bool Read(const std::string& path);
+  bool Write(const std::string& path) const;
+};
+
+class VocabSimilarityGraph {
+ public:
+  VocabSimilarityGraph(const VocabSimilaritySearchOptions& options, const Database& database);
+  bool Run();
+  const std::vector<std::pair<image_t, image_t>>& ImagePairs() const { return image_pairs_; }
+  const std::vector<float>& Scores() const { return scores_; }
+  const std::string& LastError() const { return last_error_; }
+
+ private:
+  VocabSimilaritySearchOptions options_;
+  const Database* database_;
+  FeatureMatcherCache cache_;
+  std::vector<std::pair<image_t, image_t>> image_pairs_;
+  std::vector<float> scores_;
+  std::string last_error_;
+};
+
 }  // namespace dagsfm_amd
 #endif

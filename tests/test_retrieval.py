@@ -85,3 +85,42 @@ def test_device_retrieval_equals_oracle(dsm, n_img, feats, n_words, max_images):
             assert res[q][0][0] == q  # with a vocabulary that discriminates, an image retrieves itself first
     t_index, t_query = dsm.retrieval_time()
     assert t_index > 0 and t_query > 0
+
+
+@pytest.mark.gpu
+def test_host_vocab_similarity_graph_over_database(tmp_path, dsm):
+    """dagsfm_amd::VocabSimilarityGraph (the C++ mirror of DAGSfM::VocabSimilarityGraph::Run) over a database.db and a
+    vocabulary file == the pairs composed from the C-ABI results: (image_id, retrieved) with image_id < retrieved,
+    score * 1e3, image ids in ascending order (similarity_graph.cpp:183-194)."""
+    import ctypes
+    import os
+    from tests import dbutil
+    n_img = 9
+    scene, ims, voc = _scene(n_img, 300, 512)
+    path = str(tmp_path / "database.db")
+    dbutil.create(path, [(im[0], im[1]) for im in ims])
+    L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dagsfm_amd", "libdagsfm_host.so"))
+    L.dsm_host_write_vocabulary.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.dsm_host_vocab_candidate_pairs.restype = ctypes.c_int64
+    L.dsm_host_vocab_candidate_pairs.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_uint64]
+    vpath = str(tmp_path / "vocab.bin")
+    w, p, t = [np.ascontiguousarray(x) for x in voc]
+    assert L.dsm_host_write_vocabulary(vpath.encode(), len(w), w.ctypes.data, p.ctypes.data, t.ctypes.data) == 0
+    pairs = np.zeros((1000, 2), np.uint32)
+    scores = np.zeros(1000, np.float32)
+    n = L.dsm_host_vocab_candidate_pairs(path.encode(), vpath.encode(), 4, 5, pairs.ctypes.data, scores.ctypes.data, 1000)
+    assert n > 0
+    dsm.set_images([im[0] for im in ims])
+    dsm.retrieval_set_vocabulary(*voc)
+    dsm.retrieval_index()
+    res = dsm.retrieval_query(n_img, 5, 4)
+    exp_pairs, exp_scores = [], []
+    for q, (ids, sc) in enumerate(res):
+        for d, s in zip(ids, sc):
+            if q < int(d):
+                exp_pairs.append((q + 1, int(d) + 1))  # dbutil's image ids are 1-based
+                exp_scores.append(np.float32(s) * np.float32(1e3))
+    assert n == len(exp_pairs)
+    assert [tuple(x) for x in pairs[:n]] == exp_pairs
+    assert (scores[:n] == np.array(exp_scores, np.float32)).all()
