@@ -107,6 +107,7 @@ def lib():
         L.dsm_retrieval_query.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp]
         L.dsm_retrieval_debug_word_ids.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp]
         L.dsm_get_retrieval_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        L.dsm_view_graph_filter_cycles.argtypes = [vp, ctypes.c_uint32, vp, vp, ctypes.c_double, vp, vp]
         L.dsm_debug_image_to_world.argtypes = [vp, ctypes.POINTER(Camera), ctypes.c_uint32, ctypes.POINTER(ctypes.c_double),
                                                ctypes.POINTER(ctypes.c_double)]
         L.dsm_default_match_options.argtypes = [ctypes.POINTER(MatchOptions)]
@@ -332,6 +333,17 @@ class Context:
         a, b = ctypes.c_double(0), ctypes.c_double(0)
         self._chk(lib().dsm_get_retrieval_time(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def view_graph_filter_cycles(self, pairs, qvecs, max_loop_error_degrees=5.0):
+        """ViewGraph::FilterViewGraphCyclesByRotation over (pairs, qvecs): returns (keep [n] bool, number of triplets)."""
+        p = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+        q = np.ascontiguousarray(qvecs, np.float64).reshape(-1, 4)
+        assert len(p) == len(q)
+        keep = np.zeros(max(len(p), 1), np.uint8)
+        nt = ctypes.c_uint64(0)
+        self._chk(lib().dsm_view_graph_filter_cycles(self._h, len(p), p.ctypes.data, q.ctypes.data, max_loop_error_degrees,
+                                                     keep.ctypes.data, ctypes.addressof(nt)))
+        return keep[:len(p)].astype(bool), nt.value
 
     def device_info(self):
         d = DeviceInfo()

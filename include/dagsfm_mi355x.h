@@ -292,6 +292,18 @@ int dsm_retrieval_debug_word_ids(dsm_ctx* ctx, uint32_t image, uint32_t k, int32
 /* Device time (HIP events) of the last dsm_retrieval_index / dsm_retrieval_query. */
 int dsm_get_retrieval_time(dsm_ctx* ctx, double* index_ms, double* query_ms);
 
+/* ------------------------------------------------------------------ view-graph ingest + rotation-cycle filter
+ * The step AFTER the stage: DistributedMapperController::LoadTwoviewGeometries
+ * (src/controllers/distributed_mapper_controller.cpp:585-631) turns every two_view_geometries row into a view-graph
+ * edge (rotation = the row's qvec), ViewGraph::FilterViewGraphCyclesByRotation(5.0) (src/graph/view_graph.cpp:115-165)
+ * keeps an edge iff it lies on a cycle of length 3 whose loop rotation R23 * R12 * R13^T is below the threshold.
+ *   pairs  n_pairs x 2 image ids (any ids; a repeat of an earlier pair is ignored: keep = 0)
+ *   qvecs  n_pairs x 4 (w, x, y, z): the relative rotation of the pair as stored, i.e. for image_id1 < image_id2
+ *   keep   n_pairs flags out;  n_triplets (optional): cycles of length 3 found
+ * Host pointers. */
+int dsm_view_graph_filter_cycles(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const double* qvecs,
+                                 double max_loop_error_degrees, uint8_t* keep, uint64_t* n_triplets);
+
 void dsm_default_match_options(dsm_match_options* o);
 void dsm_default_two_view_options(dsm_two_view_options* o);
 
