@@ -266,7 +266,8 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
   HIPCHK(ctx, hipMemsetAsync(ctx->d_offsets.p, 0, 8, st));
 
   // Chunk the pair list so that the K1 output scratch stays below a fixed budget.
-  const uint64_t budget_rows = (6ull << 30) / 4;
+  uint64_t budget_rows = (6ull << 30) / 4;
+  if (const char* e = getenv("DSM_MATCH_CHUNK_ROWS")) budget_rows = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // test hook
   std::vector<uint2> dpairs, dpairs2;
   std::vector<uint64_t> doff;
   std::vector<uint4> pdir;

@@ -211,3 +211,29 @@ def test_dot4_variant_matches_mfma_kernel(dsm, oracle, monkeypatch):
     ref = oracle.match_sift_features_cpu(descs[0], descs[3])
     k = [tuple(p) for p in pairs].index((0, 3))
     assert (m1[int(offs1[k]):int(offs1[k + 1])] == ref).all()
+
+
+@pytest.mark.parametrize("cross", [1, 0])
+def test_several_chunks_of_the_pair_list(dsm, oracle, cross, monkeypatch):
+    """The matcher works through a long pair list in chunks of bounded scratch (6 GiB of rows by default; the
+    2 000-image bench runs 6 of them).  Forced here to a few pairs per chunk: same matches as one chunk and as the
+    oracle, with an empty image and a pair listed twice in between."""
+    from dagsfm_amd import synthetic
+    scene = synthetic.Scene(6, 520, seed=13, n_pool=1400)
+    ims = [scene.image(i) for i in range(6)]
+    descs = [im[0] for im in ims]
+    descs[4] = descs[4][:0]  # no features at all
+    pairs = np.array([(0, 1), (2, 1), (0, 3), (4, 5), (1, 4), (5, 0), (0, 1), (3, 2), (5, 2)], dtype=np.uint32)
+    o = capi.default_match_options(cross_check=cross)
+    dsm.set_images(descs)
+    dsm.match_pairs(pairs, o)
+    offs0, m0 = dsm.matches()
+    monkeypatch.setenv("DSM_MATCH_CHUNK_ROWS", "1400")  # two or three pairs per chunk
+    dsm.match_pairs(pairs, o)
+    offs1, m1 = dsm.matches()
+    assert (offs0 == offs1).all() and (m0 == m1).all()
+    for k, (i, j) in enumerate(pairs):
+        ref = oracle.match_sift_features_cpu(descs[i], descs[j], cross_check=bool(cross)) if len(descs[i]) and len(descs[j]) \
+            else np.zeros((0, 2), np.uint32)
+        assert (m1[int(offs1[k]):int(offs1[k + 1])] == ref).all(), (k, i, j)
+    assert int(offs1[-1]) > 300
