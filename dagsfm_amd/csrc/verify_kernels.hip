@@ -204,16 +204,65 @@ DSM_DEV void wv_draw_samples(MtState* gen, WvSampler* ws, uint32_t* sidx, uint32
       break;
     }
     if (lane == 0) {
+      // The first K_ entries of the index array are touched by every trial: they live in registers (h[]) for the
+      // block.  A trial's K_ partner reads are independent unless two draws name the same partner or a partner lies
+      // inside the head; those (rare) trials take the one-swap-at-a-time form.  Either way the state after the trial
+      // is that of K_ sequential swaps.
+      uint32_t h[K_], jn[K_];
+#pragma unroll
+      for (int i = 0; i < K_; ++i) h[i] = sidx[i];
+#pragma unroll
+      for (int i = 0; i < K_; ++i) jn[i] = ws->jb[i];
       for (int tt = 0; tt < nt; ++tt) {
+        uint32_t j[K_], v[K_];
+        bool plain = true;
+#pragma unroll
         for (int i = 0; i < K_; ++i) {
-          const uint32_t j = ws->jb[tt * K_ + i];
-          const uint32_t a = sidx[i];
-          sidx[i] = sidx[j];
-          sidx[j] = a;
+          j[i] = jn[i];
+          plain = plain && j[i] >= (uint32_t)K_;
         }
-        for (int i = 0; i < K_; ++i) smp[(size_t)(t + tt) * 7 + i] = sidx[i];
+#pragma unroll
+        for (int i = 0; i < K_; ++i) v[i] = sidx[j[i]];  // j < n always; a value read here is only used if plain
+        if (tt + 1 < nt) {
+#pragma unroll
+          for (int i = 0; i < K_; ++i) jn[i] = ws->jb[(tt + 1) * K_ + i];
+        }
+#pragma unroll
+        for (int i = 1; i < K_; ++i) {
+#pragma unroll
+          for (int i2 = 0; i2 < i; ++i2) plain = plain && j[i] != j[i2];
+        }
+        if (plain) {
+#pragma unroll
+          for (int i = 0; i < K_; ++i) {
+            sidx[j[i]] = h[i];
+            h[i] = v[i];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < K_; ++i) {
+            if (j[i] >= (uint32_t)K_) {
+              const uint32_t a = h[i];
+              h[i] = sidx[j[i]];
+              sidx[j[i]] = a;
+            } else {
+#pragma unroll
+              for (int jj = i + 1; jj < K_; ++jj) {  // j >= i by construction; j == i is a swap with itself
+                if (j[i] == (uint32_t)jj) {
+                  const uint32_t a = h[i];
+                  h[i] = h[jj];
+                  h[jj] = a;
+                }
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < K_; ++i) smp[(size_t)(t + tt) * 7 + i] = h[i];
         if (de) de[t + tt] = calls + (uint32_t)(tt + 1) * K_;
       }
+#pragma unroll
+      for (int i = 0; i < K_; ++i) sidx[i] = h[i];
     }
     pos += nd;
     have -= nd;

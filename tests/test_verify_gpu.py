@@ -28,7 +28,8 @@ def tvg_equal(g, r, tag=""):
 def test_sampler_matches_libstdcxx(dsm, oracle):
     """Device MT19937 + Lemire + partial Fisher-Yates == std::mt19937 + std::uniform_int_distribution."""
     for seed, k, total, draws in [(0, 7, 50, 300), (5489, 5, 5, 10), (123456789, 4, 4096, 2000), (42, 1, 1, 5),
-                                  (7, 7, 257, 1000), (4294967295, 4, 3, 0)]:
+                                  (7, 7, 257, 1000), (4294967295, 4, 3, 0),
+                                  (11, 4, 6, 700), (12, 7, 9, 700), (13, 5, 8, 700), (14, 7, 7, 50)]:  # partners inside the head, repeats
         if k > total or draws == 0:
             continue
         ref = oracle.sample_sequence(seed, k, total, draws)
