@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dagsfm_mi355x.h"
@@ -125,14 +126,21 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
                     &ctx->d_tvg, &ctx->d_inl, &ctx->d_inl_counts, &ctx->d_inl_off, &ctx->d_inl_compact,
                     &ctx->d_vscratch, &ctx->d_inl_total, &ctx->d_nt_table, &ctx->d_nt_off, &ctx->d_nt_off_t,
                     &ctx->d_pair_state, &ctx->d_pts_px, &ctx->d_pts_norm, &ctx->d_reports, &ctx->d_masks,
-                    &ctx->d_fam_state, &ctx->d_samples, &ctx->d_draws_end, &ctx->d_nmodels, &ctx->d_vcounts, &ctx->d_models,
-                    &ctx->d_sidx, &ctx->d_active, &ctx->d_ework, &ctx->d_g_nfeat, &ctx->d_g_dpairs, &ctx->d_g_doff, &ctx->d_g_pdir,
+                    &ctx->d_fam_state,
+                    &ctx->d_sidx, &ctx->d_g_nfeat, &ctx->d_g_dpairs, &ctx->d_g_doff, &ctx->d_g_pdir,
                     &ctx->d_g_params, &ctx->d_g_m, &ctx->d_g_counts, &ctx->d_g_offsets, &ctx->d_g_total, &ctx->d_g_matches, &ctx->d_g_plan,
                     &ctx->d_g_inl, &ctx->d_g_inl_off, &ctx->d_mm_matches[0], &ctx->d_mm_matches[1], &ctx->d_mm_off[0],
                     &ctx->d_mm_off[1], &ctx->d_mm_counts, &ctx->d_mm_state, &ctx->d_mm_first, &ctx->d_mm_acc, &ctx->d_mm_keep,
                     &ctx->d_mm_total, &ctx->d_order, &ctx->d_dpairs2, &ctx->d_ecnt, &ctx->d_eoff, &ctx->d_etotal, &ctx->d_entries,
-                    &ctx->d_out2, &ctx->d_lo_inl, &ctx->d_lo_queue, &ctx->d_lo_work, &ctx->d_lo_models, &ctx->d_lo_slots,
-                    &ctx->d_lo_ework};
+                    &ctx->d_out2, &ctx->d_lo_inl};
+  for (VerifyLane& L : ctx->lanes) {
+    for (DevBuf* b : {&L.samples, &L.draws_end, &L.nmodels, &L.vcounts, &L.models, &L.ework, &L.active, &L.vscratch, &L.lo_queue,
+                      &L.lo_work, &L.lo_models, &L.lo_slots, &L.lo_ework})
+      b->release();
+    if (L.done) (void)hipEventDestroy(L.done);
+    if (L.host_ctr) (void)hipHostFree(L.host_ctr);
+    if (L.stream) (void)hipStreamDestroy(L.stream);
+  }
   if (ctx->vev0) (void)hipEventDestroy(ctx->vev0);
   if (ctx->vev1) (void)hipEventDestroy(ctx->vev1);
   for (DevBuf* b : bufs) b->release();
@@ -606,6 +614,111 @@ static int ensure_nt_tables(dsm_ctx* ctx, const dsm_two_view_options* o, const s
   return DSM_OK;
 }
 
+// What the lanes of one dsm_verify_pairs call share
+struct VerifyPlan {
+  uint32_t batch[3] = {0, 0, 0}, bmax = 0;
+  uint64_t bm_max = 0;
+  uint32_t chunk = 0, n_lanes = 1;
+  int dev_cus = 256;
+  bool inline_lo = false;
+};
+
+#define LANECHK(L, call)                                              \
+  do {                                                                \
+    hipError_t e_ = (call);                                           \
+    if (e_ != hipSuccess) {                                           \
+      (L).err = std::string(#call) + ": " + hipGetErrorString(e_);    \
+      (L).rc = DSM_ERR_HIP;                                           \
+      return;                                                         \
+    }                                                                 \
+  } while (0)
+
+// One lane (host thread + stream) of the phase-split pipeline: chunks li, li + n_lanes, ... of the pair list.
+static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPlan plan) {
+  VerifyLane& L = ctx->lanes[li];
+  LANECHK(L, hipSetDevice(ctx->device));
+  hipStream_t st = L.stream;
+  LANECHK(L, hipStreamWaitEvent(st, ctx->vev0, 0));
+  LANECHK(L, hipMemsetAsync(L.active.p, 0, 128, st));
+  const uint32_t chunk = plan.chunk, n_pairs = vp.n_pairs;
+  vp.scratch = L.vscratch.as<double>();
+  vp.samples = L.samples.as<uint32_t>();
+  vp.draws_end = L.draws_end.as<uint32_t>();
+  vp.nmodels = L.nmodels.as<int32_t>();
+  vp.counts = L.vcounts.as<int32_t>();
+  vp.models = L.models.as<double>();
+  vp.e_work = L.ework.as<double>();
+  vp.active_count = L.active.as<uint32_t>();
+  vp.lo_work = L.lo_work.as<double>();
+  vp.lo_models = L.lo_models.as<double>();
+  vp.lo_slots = L.lo_slots.as<double>();
+  vp.lo_ework = L.lo_ework.as<double>();
+  char* const actr = static_cast<char*>(L.active.p);
+  for (uint64_t c0 = (uint64_t)li * chunk; c0 < n_pairs; c0 += (uint64_t)chunk * plan.n_lanes) {
+    vp.pair0 = (uint32_t)c0;
+    vp.n_chunk = (uint32_t)std::min<uint64_t>(chunk, n_pairs - c0);
+    const uint32_t nb_light = std::min<uint32_t>(vp.n_chunk, (uint32_t)plan.dev_cus * 32u);
+    const uint32_t nb_heavy = std::min<uint32_t>(vp.n_chunk, (uint32_t)plan.dev_cus * 16u);
+    vp.batch = 0;
+    launch_vp_prep(vp, nb_light, st);
+    LANECHK(L, hipGetLastError());
+    for (int f = 0; f < 3; ++f) {
+      vp.batch = plan.batch[f];
+      for (uint32_t round = 0; round < 100000; ++round) {
+        LANECHK(L, hipMemsetAsync(actr, 0, 4, st));
+        LANECHK(L, hipMemsetAsync(actr + 72, 0, 4, st));  // k_sample's work counter
+        launch_vp_sample(vp, f, nb_light, st);
+        launch_vp_solve_score(vp, f, st);
+        uint32_t active = 0;
+        if (plan.inline_lo) {
+          LANECHK(L, hipMemsetAsync(actr + 64, 0, 4, st));  // k_replay's work counter
+          launch_vp_replay(vp, f, nb_heavy, st);
+          LANECHK(L, hipGetLastError());
+          LANECHK(L, hipMemcpyAsync(L.host_ctr, actr, 4, hipMemcpyDeviceToHost, st));
+          LANECHK(L, hipStreamSynchronize(st));
+          active = L.host_ctr[0];
+        } else {
+          // replay until every pair of the chunk has either consumed the batch or stopped; a pair that reaches a
+          // local optimisation is suspended onto the queue, the optimisation runs for the whole queue, and the
+          // next replay launch works through exactly that queue
+          uint32_t* queues = L.lo_queue.as<uint32_t>();
+          vp.worklist = nullptr;
+          vp.n_work = vp.n_chunk;
+          for (uint32_t cur = 0;; cur ^= 1u) {
+            uint32_t* cnt_dev = L.active.as<uint32_t>() + 20 + cur;
+            LANECHK(L, hipMemsetAsync(cnt_dev, 0, 4, st));
+            LANECHK(L, hipMemsetAsync(actr + 64, 0, 4, st));  // work counter [16]
+            vp.lo_queue = queues + (size_t)cur * chunk;
+            vp.lo_count = cnt_dev;
+            launch_vp_replay_lo(vp, f, nb_heavy, st);
+            LANECHK(L, hipGetLastError());
+            uint32_t* host_ctr = L.host_ctr;
+            LANECHK(L, hipMemcpyAsync(host_ctr, actr, 128, hipMemcpyDeviceToHost, st));
+            LANECHK(L, hipStreamSynchronize(st));
+            active = host_ctr[0];
+            const uint32_t nq = host_ctr[20 + cur];
+            if (nq == 0) break;
+            L.lo_iters[f]++;
+            vp.worklist = vp.lo_queue;
+            vp.n_work = nq;
+            LANECHK(L, hipMemsetAsync(actr + 76, 0, 4, st));  // k_lo_prepare's work counter [19]
+            launch_vp_local_opt(vp, f, nb_heavy, st);
+            LANECHK(L, hipGetLastError());
+          }
+        }
+        L.rounds[f]++;
+        if (active == 0) break;
+      }
+    }
+    LANECHK(L, hipMemsetAsync(actr + 68, 0, 4, st));  // k_verify_final's work counter
+    launch_vp_final(vp, nb_heavy, st);
+    LANECHK(L, hipGetLastError());
+  }
+  if (getenv("DSM_VERIFY_DEBUG")) LANECHK(L, hipMemcpyAsync(L.dbg, actr, 128, hipMemcpyDeviceToHost, st));
+  LANECHK(L, hipEventRecord(L.done, st));
+  LANECHK(L, hipStreamSynchronize(st));
+}
+
 // core: verifies n_pairs pairs whose matches/keypoints/cameras are already on the device
 static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, const uint64_t* d_match_off,
                        const uint32_t* d_matches, uint64_t total_matches, const std::vector<uint32_t>& counts,
@@ -625,7 +738,6 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   int dev_cus = 256;
   (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
   const uint32_t n_blocks = std::min<uint32_t>(n_pairs, (uint32_t)dev_cus * 16u);
-  HIPCHK(ctx, ctx->d_vscratch.reserve(std::max<size_t>(1, (size_t)n_blocks * verify_scratch_bytes_per_block(n_max))));
   const uint64_t tm = std::max<uint64_t>(total_matches, 1);
   HIPCHK(ctx, ctx->d_pair_state.reserve(std::max<size_t>(n_pairs, 1) * 1280 * 4));
   HIPCHK(ctx, ctx->d_pts_px.reserve(tm * 32));
@@ -657,7 +769,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.tvg = ctx->d_tvg.as<dsm_two_view_geometry>();
   vp.inlier_matches = ctx->d_inl.as<uint32_t>();
   vp.inl_counts = ctx->d_inl_counts.as<uint32_t>();
-  vp.scratch = ctx->d_vscratch.as<double>();
+  vp.scratch = nullptr;
   vp.n_pairs = n_pairs;
   vp.n_max = n_max;
   vp.stage_filter = stage_filter;
@@ -688,141 +800,126 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.lo_work = vp.lo_models = vp.lo_slots = vp.lo_ework = nullptr;
   const bool legacy = getenv("DSM_VERIFY_LEGACY") != nullptr;  // single-kernel-per-family schedule (debug)
   if (legacy) {
+    HIPCHK(ctx, ctx->d_vscratch.reserve(std::max<size_t>(1, (size_t)n_blocks * verify_scratch_bytes_per_block(n_max))));
+    vp.scratch = ctx->d_vscratch.as<double>();
+    HIPCHK(ctx, ctx->lanes[0].active.reserve(128));
+    HIPCHK(ctx, hipMemsetAsync(ctx->lanes[0].active.p, 0, 128, st));
+    vp.active_count = ctx->lanes[0].active.as<uint32_t>();
     HIPCHK(ctx, hipEventRecord(ctx->vev0, st));
     launch_verify(vp, n_blocks, st);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->vev1, st));
   } else {
     // phase-split pipeline: per family, rounds of sample -> solve+score -> replay until no pair is active
-    uint32_t batch[3], bmax = 0;
+    VerifyPlan plan;
     uint64_t bm_max = 0;
     for (int f = 0; f < 3; ++f) {
-      batch[f] = vp_batch(f, vp.max_trials[f], (uint32_t)std::min<uint64_t>(o->min_num_trials, 0xffffffffull));
-      bmax = std::max(bmax, batch[f]);
-      bm_max = std::max<uint64_t>(bm_max, (uint64_t)batch[f] * vp_maxm(f));
+      plan.batch[f] = vp_batch(f, vp.max_trials[f], (uint32_t)std::min<uint64_t>(o->min_num_trials, 0xffffffffull));
+      plan.bmax = std::max(plan.bmax, plan.batch[f]);
+      bm_max = std::max<uint64_t>(bm_max, (uint64_t)plan.batch[f] * vp_maxm(f));
     }
-    const uint64_t per_pair = (uint64_t)bmax * (7 * 4 + 4 + 4) + bm_max * (4 + 72) + (uint64_t)batch[0] * 200 * 8 +
+    plan.bm_max = bm_max;
+    const uint64_t per_pair = (uint64_t)plan.bmax * (7 * 4 + 4 + 4) + bm_max * (4 + 72) + (uint64_t)plan.batch[0] * 200 * 8 +
                               (LO_WORK_DOUBLES + 90 + 90 + 200) * 8 + 8;
+    // Lanes: the pair list is dealt out in chunks to up to DSM_VERIFY_MAX_LANES lanes that run concurrently (own
+    // stream, own host thread, own scratch; see VerifyLane).  A pair's three families cannot overlap -- F starts from
+    // the generator state E ends with -- but different pairs can, and the replay / local-optimisation launches of
+    // one lane are latency chains that leave most of the chip idle.
+    uint32_t n_lanes = n_pairs >= 4096 ? 2 : 1;
+    if (const char* e = getenv("DSM_VERIFY_LANES")) n_lanes = (uint32_t)std::max(1, std::min(DSM_VERIFY_MAX_LANES, atoi(e)));
+    n_lanes = std::max<uint32_t>(1, std::min<uint32_t>(n_lanes, n_pairs));
     // Scratch of the speculated trials: as much of the pair list per chunk as memory allows (every chunk pays the
     // latency tail of its sequential rounds, so fewer chunks are faster): up to 40 % of what is free now, at
-    // least 4 GiB, at most 96 GiB (config 2 needs 38 GiB for one chunk; an MI355X has 288 GB).
+    // least 4 GiB, at most 96 GiB (config 2 needs 38 GiB for the whole list; an MI355X has 288 GB).
     uint64_t budget = 16ull << 30;
     {
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         uint64_t have = 0;  // buffers of an earlier call are reused, not allocated again
-        for (DevBuf* b : {&ctx->d_samples, &ctx->d_draws_end, &ctx->d_nmodels, &ctx->d_vcounts, &ctx->d_models, &ctx->d_ework,
-                          &ctx->d_lo_work, &ctx->d_lo_models, &ctx->d_lo_slots, &ctx->d_lo_ework})
-          have += b->cap;
+        for (VerifyLane& L : ctx->lanes)
+          for (DevBuf* b : {&L.samples, &L.draws_end, &L.nmodels, &L.vcounts, &L.models, &L.ework, &L.lo_work, &L.lo_models, &L.lo_slots,
+                            &L.lo_ework})
+            have += b->cap;
         budget = std::min<uint64_t>(96ull << 30, std::max<uint64_t>(4ull << 30, (uint64_t)((free_b + have) * 0.4)));
       }
     }
-    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_pairs, budget / per_pair));
+    const uint64_t share = ((uint64_t)n_pairs + n_lanes - 1) / n_lanes;
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(share, budget / n_lanes / per_pair));
     if (const char* cp = getenv("DSM_VERIFY_CHUNK_PAIRS"))  // test hook: force several chunks on a small pair list
       chunk = std::max<uint32_t>(1, std::min<uint32_t>(chunk, (uint32_t)atoi(cp)));
-    HIPCHK(ctx, ctx->d_fam_state.reserve(std::max<size_t>(n_pairs, 1) * 3 * sizeof(FamState)));
-    HIPCHK(ctx, ctx->d_sidx.reserve(tm * 4));
-    HIPCHK(ctx, ctx->d_active.reserve(128));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_active.p, 0, 128, st));
-    HIPCHK(ctx, ctx->d_samples.reserve((size_t)chunk * bmax * 7 * 4));
-    HIPCHK(ctx, ctx->d_draws_end.reserve((size_t)chunk * bmax * 4));
-    HIPCHK(ctx, ctx->d_nmodels.reserve((size_t)chunk * bmax * 4));
-    HIPCHK(ctx, ctx->d_vcounts.reserve((size_t)chunk * bm_max * 4));
-    HIPCHK(ctx, ctx->d_models.reserve((size_t)chunk * bm_max * 72));
-    HIPCHK(ctx, ctx->d_ework.reserve((size_t)chunk * batch[0] * 200 * 8));
+    plan.chunk = chunk;
+    plan.n_lanes = n_lanes;
+    plan.dev_cus = dev_cus;
     // Local optimisation: batched kernels (k_replay_lo + k_lo_*) or inline in the replay (k_replay).  The batched form
     // wins on throughput (config 2: 601 vs 708 ms) but every LO costs a kernel round trip, so a short pair list, whose
     // time is the serial latency of its slowest pair, is faster inline (config 1, 1 225 pairs: 15.5 vs 23.1 ms; the two
     // meet at ~11 000 pairs).  DSM_VERIFY_INLINE_LO=1 / =0 forces one or the other (tests cover both).
-    bool inline_lo = n_pairs < 16384u;
-    if (const char* e = getenv("DSM_VERIFY_INLINE_LO")) inline_lo = atoi(e) != 0;
+    plan.inline_lo = n_pairs < 16384u;
+    if (const char* e = getenv("DSM_VERIFY_INLINE_LO")) plan.inline_lo = atoi(e) != 0;
+    HIPCHK(ctx, ctx->d_fam_state.reserve(std::max<size_t>(n_pairs, 1) * 3 * sizeof(FamState)));
+    HIPCHK(ctx, ctx->d_sidx.reserve(tm * 4));
     HIPCHK(ctx, ctx->d_lo_inl.reserve(tm * 4));
-    HIPCHK(ctx, ctx->d_lo_queue.reserve((size_t)chunk * 2 * 4));
-    HIPCHK(ctx, ctx->d_lo_work.reserve((size_t)chunk * LO_WORK_DOUBLES * 8));
-    HIPCHK(ctx, ctx->d_lo_models.reserve((size_t)chunk * 90 * 8));
-    HIPCHK(ctx, ctx->d_lo_slots.reserve((size_t)chunk * 90 * 8));
-    HIPCHK(ctx, ctx->d_lo_ework.reserve((size_t)chunk * 200 * 8));
     vp.lo_inl = ctx->d_lo_inl.as<uint32_t>();
-    vp.lo_work = ctx->d_lo_work.as<double>();
-    vp.lo_models = ctx->d_lo_models.as<double>();
-    vp.lo_slots = ctx->d_lo_slots.as<double>();
-    vp.lo_ework = ctx->d_lo_ework.as<double>();
-    ctx->verify_lo_iters[0] = ctx->verify_lo_iters[1] = ctx->verify_lo_iters[2] = 0;
     vp.fam_state = ctx->d_fam_state.as<FamState>();
-    vp.samples = ctx->d_samples.as<uint32_t>();
-    vp.draws_end = ctx->d_draws_end.as<uint32_t>();
-    vp.nmodels = ctx->d_nmodels.as<int32_t>();
-    vp.counts = ctx->d_vcounts.as<int32_t>();
-    vp.models = ctx->d_models.as<double>();
-    vp.e_work = ctx->d_ework.as<double>();
     vp.sidx_g = ctx->d_sidx.as<uint32_t>();
-    vp.active_count = ctx->d_active.as<uint32_t>();
-    ctx->verify_rounds[0] = ctx->verify_rounds[1] = ctx->verify_rounds[2] = 0;
+    const uint32_t lane_blocks = std::min<uint32_t>(chunk, (uint32_t)dev_cus * 16u);
+    for (uint32_t li = 0; li < n_lanes; ++li) {
+      VerifyLane& L = ctx->lanes[li];
+      if (!L.stream) HIPCHK(ctx, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+      if (!L.done) HIPCHK(ctx, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+      if (!L.host_ctr) HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&L.host_ctr), 128, hipHostMallocDefault));
+      HIPCHK(ctx, L.active.reserve(128));
+      HIPCHK(ctx, L.vscratch.reserve(std::max<size_t>(1, (size_t)lane_blocks * verify_scratch_bytes_per_block(n_max))));
+      HIPCHK(ctx, L.samples.reserve((size_t)chunk * plan.bmax * 7 * 4));
+      HIPCHK(ctx, L.draws_end.reserve((size_t)chunk * plan.bmax * 4));
+      HIPCHK(ctx, L.nmodels.reserve((size_t)chunk * plan.bmax * 4));
+      HIPCHK(ctx, L.vcounts.reserve((size_t)chunk * bm_max * 4));
+      HIPCHK(ctx, L.models.reserve((size_t)chunk * bm_max * 72));
+      HIPCHK(ctx, L.ework.reserve((size_t)chunk * plan.batch[0] * 200 * 8));
+      HIPCHK(ctx, L.lo_queue.reserve((size_t)chunk * 2 * 4));
+      HIPCHK(ctx, L.lo_work.reserve((size_t)chunk * LO_WORK_DOUBLES * 8));
+      HIPCHK(ctx, L.lo_models.reserve((size_t)chunk * 90 * 8));
+      HIPCHK(ctx, L.lo_slots.reserve((size_t)chunk * 90 * 8));
+      HIPCHK(ctx, L.lo_ework.reserve((size_t)chunk * 200 * 8));
+      L.rc = DSM_OK;
+      L.err.clear();
+      for (int f = 0; f < 3; ++f) L.rounds[f] = L.lo_iters[f] = 0;
+      memset(L.dbg, 0, sizeof(L.dbg));
+    }
+    ctx->verify_lanes = n_lanes;
     HIPCHK(ctx, hipEventRecord(ctx->vev0, st));
-    for (uint32_t c0 = 0; c0 < n_pairs; c0 += chunk) {
-      vp.pair0 = c0;
-      vp.n_chunk = std::min<uint32_t>(chunk, n_pairs - c0);
-      const uint32_t nb_light = std::min<uint32_t>(vp.n_chunk, (uint32_t)dev_cus * 32u);
-      const uint32_t nb_heavy = std::min<uint32_t>(vp.n_chunk, (uint32_t)dev_cus * 16u);
-      vp.batch = 0;
-      launch_vp_prep(vp, nb_light, st);
-      HIPCHK(ctx, hipGetLastError());
-      for (int f = 0; f < 3; ++f) {
-        vp.batch = batch[f];
-        for (uint32_t round = 0; round < 100000; ++round) {
-          HIPCHK(ctx, hipMemsetAsync(ctx->d_active.p, 0, 4, st));
-          HIPCHK(ctx, hipMemsetAsync(static_cast<char*>(ctx->d_active.p) + 72, 0, 4, st));  // k_sample's work counter
-          launch_vp_sample(vp, f, nb_light, st);
-          launch_vp_solve_score(vp, f, st);
-          uint32_t active = 0;
-          if (inline_lo) {
-            HIPCHK(ctx, hipMemsetAsync(static_cast<char*>(ctx->d_active.p) + 64, 0, 4, st));  // k_replay's work counter
-            launch_vp_replay(vp, f, nb_heavy, st);
-            HIPCHK(ctx, hipGetLastError());
-            HIPCHK(ctx, hipMemcpyAsync(&active, ctx->d_active.p, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));
-          } else {
-            // replay until every pair of the chunk has either consumed the batch or stopped; a pair that reaches a
-            // local optimisation is suspended onto the queue, the optimisation runs for the whole queue, and the
-            // next replay launch works through exactly that queue
-            uint32_t* queues = ctx->d_lo_queue.as<uint32_t>();
-            vp.worklist = nullptr;
-            vp.n_work = vp.n_chunk;
-            for (uint32_t cur = 0;; cur ^= 1u) {
-              uint32_t* cnt_dev = ctx->d_active.as<uint32_t>() + 20 + cur;
-              HIPCHK(ctx, hipMemsetAsync(cnt_dev, 0, 4, st));
-              HIPCHK(ctx, hipMemsetAsync(static_cast<char*>(ctx->d_active.p) + 64, 0, 4, st));  // work counter [16]
-              vp.lo_queue = queues + (size_t)cur * chunk;
-              vp.lo_count = cnt_dev;
-              launch_vp_replay_lo(vp, f, nb_heavy, st);
-              HIPCHK(ctx, hipGetLastError());
-              uint32_t host_ctr[32];
-              HIPCHK(ctx, hipMemcpyAsync(host_ctr, ctx->d_active.p, 128, hipMemcpyDeviceToHost, st));
-              HIPCHK(ctx, hipStreamSynchronize(st));
-              active = host_ctr[0];
-              const uint32_t nq = host_ctr[20 + cur];
-              if (nq == 0) break;
-              ctx->verify_lo_iters[f]++;
-              vp.worklist = vp.lo_queue;
-              vp.n_work = nq;
-              HIPCHK(ctx, hipMemsetAsync(static_cast<char*>(ctx->d_active.p) + 76, 0, 4, st));  // k_lo_prepare's work counter [19]
-              launch_vp_local_opt(vp, f, nb_heavy, st);
-              HIPCHK(ctx, hipGetLastError());
-            }
-          }
-          ctx->verify_rounds[f]++;
-          if (active == 0) break;
-        }
+    if (n_lanes == 1) {
+      verify_lane_run(ctx, 0, vp, plan);
+    } else {
+      std::vector<std::thread> th;
+      for (uint32_t li = 0; li < n_lanes; ++li) th.emplace_back(verify_lane_run, ctx, li, vp, plan);
+      for (std::thread& t : th) t.join();
+    }
+    for (uint32_t li = 0; li < n_lanes; ++li) {
+      VerifyLane& L = ctx->lanes[li];
+      if (L.rc != DSM_OK) {
+        ctx->err = L.err;
+        (void)hipDeviceSynchronize();
+        return L.rc;
       }
-      HIPCHK(ctx, hipMemsetAsync(static_cast<char*>(ctx->d_active.p) + 68, 0, 4, st));  // k_verify_final's work counter
-      launch_vp_final(vp, nb_heavy, st);
-      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipStreamWaitEvent(st, L.done, 0));
     }
     HIPCHK(ctx, hipEventRecord(ctx->vev1, st));
+    for (int f = 0; f < 3; ++f) {
+      ctx->verify_rounds[f] = ctx->verify_lo_iters[f] = 0;
+      for (uint32_t li = 0; li < n_lanes; ++li) {
+        ctx->verify_rounds[f] = std::max(ctx->verify_rounds[f], ctx->lanes[li].rounds[f]);
+        ctx->verify_lo_iters[f] = std::max(ctx->verify_lo_iters[f], ctx->lanes[li].lo_iters[f]);
+      }
+    }
     if (getenv("DSM_VERIFY_DEBUG")) {
-      uint32_t dbg[32];
-      HIPCHK(ctx, hipMemcpy(dbg, ctx->d_active.p, 128, hipMemcpyDeviceToHost));
-      const unsigned long long* cyc = reinterpret_cast<const unsigned long long*>(dbg + 8);
+      uint32_t dbg[32] = {0};
+      unsigned long long cyc[3] = {0, 0, 0};
+      for (uint32_t li = 0; li < n_lanes; ++li) {
+        for (int k = 0; k < 8; ++k) dbg[k] += ctx->lanes[li].dbg[k];
+        const unsigned long long* c = reinterpret_cast<const unsigned long long*>(ctx->lanes[li].dbg + 8);
+        for (int k = 0; k < 3; ++k) cyc[k] += c[k];
+      }
       fprintf(stderr, "[dsm verify] replay cycles (all families): candidates %llu  local-opt %llu  whole-pair loop %llu\n", cyc[0], cyc[1], cyc[2]);
 #ifdef DSM_PROFILE_SECTIONS
       {
@@ -833,8 +930,8 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
                 prof[8] >> 20, prof[9] >> 20, prof[10] >> 20, prof[11] >> 20, prof[12] >> 20, prof[13] >> 20, prof[14] >> 20);
       }
 #endif
-      fprintf(stderr, "[dsm verify] local-optimisation iterations E/F/H %u/%u/%u\n", ctx->verify_lo_iters[0], ctx->verify_lo_iters[1],
-              ctx->verify_lo_iters[2]);
+      fprintf(stderr, "[dsm verify] lanes %u (chunk %u pairs); per lane at most: local-optimisation iterations E/F/H %u/%u/%u\n", n_lanes, chunk,
+              ctx->verify_lo_iters[0], ctx->verify_lo_iters[1], ctx->verify_lo_iters[2]);
       fprintf(stderr, "[dsm verify] pairs %u rounds E/F/H %u/%u/%u candidates E/F/H %u/%u/%u LO calls E/F/H %u/%u/%u\n", n_pairs,
               ctx->verify_rounds[0], ctx->verify_rounds[1], ctx->verify_rounds[2], dbg[1], dbg[3], dbg[5], dbg[2], dbg[4], dbg[6]);
     }

@@ -57,6 +57,22 @@ struct DevBuf {
 };
 
 
+// One lane of dsm_verify_pairs: a share of the pair list runs through the whole E -> F -> H pipeline on the lane's own
+// stream, driven by its own host thread, with its own chunk-local buffers.  The rounds of one lane are a serial chain
+// of small launches and host round trips (its length is set by the slowest pair); lanes fill each other's bubbles.
+struct VerifyLane {
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  DevBuf samples, draws_end, nmodels, vcounts, models, ework, active, vscratch;
+  DevBuf lo_queue, lo_work, lo_models, lo_slots, lo_ework;  // batched local optimisation
+  uint32_t rounds[3] = {0, 0, 0}, lo_iters[3] = {0, 0, 0};
+  uint32_t dbg[32] = {0};
+  uint32_t* host_ctr = nullptr;  // pinned read-back target of the lane's counters
+  std::string err;
+  int rc = 0;
+};
+#define DSM_VERIFY_MAX_LANES 4
+
 struct dsm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -87,9 +103,9 @@ struct dsm_ctx {
   bool verified = false;
   DevBuf d_cams, d_pairs_dev, d_seeds, d_tvg, d_inl, d_inl_counts, d_inl_off, d_inl_compact, d_vscratch, d_inl_total;
   DevBuf d_nt_table, d_nt_off, d_nt_off_t, d_pair_state, d_pts_px, d_pts_norm, d_reports, d_masks;
-  DevBuf d_fam_state, d_samples, d_draws_end, d_nmodels, d_vcounts, d_models, d_sidx, d_active;
-  DevBuf d_ework;
-  DevBuf d_lo_inl, d_lo_queue, d_lo_work, d_lo_models, d_lo_slots, d_lo_ework;  // batched local optimisation
+  DevBuf d_fam_state, d_sidx, d_lo_inl;
+  VerifyLane lanes[DSM_VERIFY_MAX_LANES];
+  uint32_t verify_lanes = 1;  // lanes of the last call
   uint32_t verify_lo_iters[3] = {0, 0, 0};
   DevBuf d_g_nfeat, d_g_dpairs, d_g_doff, d_g_pdir, d_g_params, d_g_m, d_g_counts, d_g_offsets, d_g_total, d_g_matches,
       d_g_plan, d_g_inl, d_g_inl_off;  // guided matching

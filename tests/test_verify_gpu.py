@@ -110,7 +110,8 @@ def test_watermark_configuration(dsm, oracle):
 
 @pytest.mark.parametrize("prior,sampler_serial,legacy", [(0, False, False), (1, False, False), (1, True, False), (1, False, True),
                                                          (1, False, "inline_lo"), (0, False, "inline_lo"), (1, False, "chunks"),
-                                                         (1, False, "batched_lo"), (0, False, "batched_lo")])
+                                                         (1, False, "batched_lo"), (0, False, "batched_lo"),
+                                                         (1, False, "lanes"), (0, False, "lanes_inline")])
 def test_stage_match_and_verify_many_pairs(dsm, oracle, prior, sampler_serial, legacy, monkeypatch):
     """dsm_match_pairs + dsm_verify_pairs over an exhaustive pair list == oracle matcher + oracle verifier
     with SiftFeatureMatcher::Match's post-filter (matching.cc:824-831).  sampler_serial forces the sampler's
@@ -121,6 +122,10 @@ def test_stage_match_and_verify_many_pairs(dsm, oracle, prior, sampler_serial, l
     if legacy == "chunks":  # several chunks of the pair list (one chunk is the rule on a 288 GB device)
         monkeypatch.setenv("DSM_VERIFY_CHUNK_PAIRS", "5")
         monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "0")
+    elif legacy in ("lanes", "lanes_inline"):  # three concurrent lanes (host threads + streams), several chunks each
+        monkeypatch.setenv("DSM_VERIFY_LANES", "3")
+        monkeypatch.setenv("DSM_VERIFY_CHUNK_PAIRS", "4")
+        monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "0" if legacy == "lanes" else "1")
     elif legacy == "batched_lo":  # the schedule long pair lists get (short ones default to the inline form)
         monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "0")
     elif legacy == "inline_lo":  # phase-split pipeline with the local optimisation inline in the replay (round-1 schedule)
