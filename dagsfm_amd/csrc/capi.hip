@@ -618,7 +618,8 @@ static int ensure_nt_tables(dsm_ctx* ctx, const dsm_two_view_options* o, const s
 struct VerifyPlan {
   uint32_t batch[3] = {0, 0, 0}, bmax = 0;
   uint64_t bm_max = 0;
-  uint32_t chunk = 0, n_lanes = 1;
+  uint32_t n_lanes = 1;
+  uint32_t begin[DSM_VERIFY_MAX_LANES] = {0}, end[DSM_VERIFY_MAX_LANES] = {0}, chunk[DSM_VERIFY_MAX_LANES] = {0};  // per lane
   int dev_cus = 256;
   bool inline_lo = false;
 };
@@ -633,14 +634,14 @@ struct VerifyPlan {
     }                                                                 \
   } while (0)
 
-// One lane (host thread + stream) of the phase-split pipeline: chunks li, li + n_lanes, ... of the pair list.
+// One lane (host thread + stream) of the phase-split pipeline: its range of the pair list, chunk by chunk.
 static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPlan plan) {
   VerifyLane& L = ctx->lanes[li];
   LANECHK(L, hipSetDevice(ctx->device));
   hipStream_t st = L.stream;
   LANECHK(L, hipStreamWaitEvent(st, ctx->vev0, 0));
   LANECHK(L, hipMemsetAsync(L.active.p, 0, 128, st));
-  const uint32_t chunk = plan.chunk, n_pairs = vp.n_pairs;
+  const uint32_t chunk = plan.chunk[li];
   vp.scratch = L.vscratch.as<double>();
   vp.samples = L.samples.as<uint32_t>();
   vp.draws_end = L.draws_end.as<uint32_t>();
@@ -654,9 +655,9 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
   vp.lo_slots = L.lo_slots.as<double>();
   vp.lo_ework = L.lo_ework.as<double>();
   char* const actr = static_cast<char*>(L.active.p);
-  for (uint64_t c0 = (uint64_t)li * chunk; c0 < n_pairs; c0 += (uint64_t)chunk * plan.n_lanes) {
+  for (uint64_t c0 = plan.begin[li]; c0 < plan.end[li]; c0 += chunk) {
     vp.pair0 = (uint32_t)c0;
-    vp.n_chunk = (uint32_t)std::min<uint64_t>(chunk, n_pairs - c0);
+    vp.n_chunk = (uint32_t)std::min<uint64_t>(chunk, plan.end[li] - c0);
     const uint32_t nb_light = std::min<uint32_t>(vp.n_chunk, (uint32_t)plan.dev_cus * 32u);
     const uint32_t nb_heavy = std::min<uint32_t>(vp.n_chunk, (uint32_t)plan.dev_cus * 16u);
     vp.batch = 0;
@@ -843,11 +844,22 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
         budget = std::min<uint64_t>(96ull << 30, std::max<uint64_t>(4ull << 30, (uint64_t)((free_b + have) * 0.4)));
       }
     }
-    const uint64_t share = ((uint64_t)n_pairs + n_lanes - 1) / n_lanes;
-    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(share, budget / n_lanes / per_pair));
-    if (const char* cp = getenv("DSM_VERIFY_CHUNK_PAIRS"))  // test hook: force several chunks on a small pair list
-      chunk = std::max<uint32_t>(1, std::min<uint32_t>(chunk, (uint32_t)atoi(cp)));
-    plan.chunk = chunk;
+    // Equal shares (measured: giving the first lane 0.6 - 0.8 of the list to push the lanes out of phase is 1 - 2 %
+    // slower than 0.5; three lanes are slower than two).  DSM_VERIFY_LANE_SPLIT = share of the first lane.
+    double first_share = 1.0 / n_lanes;
+    if (const char* e = getenv("DSM_VERIFY_LANE_SPLIT")) first_share = std::min(0.95, std::max(0.05, atof(e)));
+    const char* cp = getenv("DSM_VERIFY_CHUNK_PAIRS");  // test hook: force several chunks on a small pair list
+    uint32_t at = 0;
+    for (uint32_t li = 0; li < n_lanes; ++li) {
+      uint32_t cnt = (li == 0 && n_lanes > 1) ? (uint32_t)(n_pairs * first_share + 0.5) : (n_pairs - at) / (n_lanes - li);
+      cnt = std::min<uint32_t>(std::max<uint32_t>(cnt, 1), n_pairs - at - (n_lanes - 1 - li));
+      plan.begin[li] = at;
+      plan.end[li] = at + cnt;
+      at += cnt;
+      const uint64_t lane_budget = (uint64_t)(budget * ((double)cnt / n_pairs));
+      plan.chunk[li] = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cnt, lane_budget / per_pair));
+      if (cp) plan.chunk[li] = std::max<uint32_t>(1, std::min<uint32_t>(plan.chunk[li], (uint32_t)atoi(cp)));
+    }
     plan.n_lanes = n_lanes;
     plan.dev_cus = dev_cus;
     // Local optimisation: batched kernels (k_replay_lo + k_lo_*) or inline in the replay (k_replay).  The batched form
@@ -862,9 +874,10 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     vp.lo_inl = ctx->d_lo_inl.as<uint32_t>();
     vp.fam_state = ctx->d_fam_state.as<FamState>();
     vp.sidx_g = ctx->d_sidx.as<uint32_t>();
-    const uint32_t lane_blocks = std::min<uint32_t>(chunk, (uint32_t)dev_cus * 16u);
     for (uint32_t li = 0; li < n_lanes; ++li) {
       VerifyLane& L = ctx->lanes[li];
+      const uint32_t chunk = plan.chunk[li];
+      const uint32_t lane_blocks = std::min<uint32_t>(chunk, (uint32_t)dev_cus * 16u);
       if (!L.stream) HIPCHK(ctx, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
       if (!L.done) HIPCHK(ctx, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
       if (!L.host_ctr) HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&L.host_ctr), 128, hipHostMallocDefault));
@@ -930,7 +943,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
                 prof[8] >> 20, prof[9] >> 20, prof[10] >> 20, prof[11] >> 20, prof[12] >> 20, prof[13] >> 20, prof[14] >> 20);
       }
 #endif
-      fprintf(stderr, "[dsm verify] lanes %u (chunk %u pairs); per lane at most: local-optimisation iterations E/F/H %u/%u/%u\n", n_lanes, chunk,
+      fprintf(stderr, "[dsm verify] lanes %u (chunk %u pairs); per lane at most: local-optimisation iterations E/F/H %u/%u/%u\n", n_lanes, plan.chunk[0],
               ctx->verify_lo_iters[0], ctx->verify_lo_iters[1], ctx->verify_lo_iters[2]);
       fprintf(stderr, "[dsm verify] pairs %u rounds E/F/H %u/%u/%u candidates E/F/H %u/%u/%u LO calls E/F/H %u/%u/%u\n", n_pairs,
               ctx->verify_rounds[0], ctx->verify_rounds[1], ctx->verify_rounds[2], dbg[1], dbg[3], dbg[5], dbg[2], dbg[4], dbg[6]);
