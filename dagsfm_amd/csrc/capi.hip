@@ -134,7 +134,7 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
                     &ctx->d_mm_total, &ctx->d_order, &ctx->d_dpairs2, &ctx->d_ecnt, &ctx->d_eoff, &ctx->d_etotal, &ctx->d_entries,
                     &ctx->d_out2, &ctx->d_lo_inl};
   for (VerifyLane& L : ctx->lanes) {
-    for (DevBuf* b : {&L.samples, &L.draws_end, &L.nmodels, &L.vcounts, &L.models, &L.ework, &L.active, &L.vscratch, &L.lo_queue,
+    for (DevBuf* b : {&L.samples, &L.draws_end, &L.nmodels, &L.vcounts, &L.vsums, &L.models, &L.ework, &L.active, &L.vscratch, &L.lo_queue,
                       &L.lo_work, &L.lo_models, &L.lo_slots, &L.lo_ework})
       b->release();
     if (L.done) (void)hipEventDestroy(L.done);
@@ -647,6 +647,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
   vp.draws_end = L.draws_end.as<uint32_t>();
   vp.nmodels = L.nmodels.as<int32_t>();
   vp.counts = L.vcounts.as<int32_t>();
+  vp.sums = L.vsums.as<double>();
   vp.models = L.models.as<double>();
   vp.e_work = L.ework.as<double>();
   vp.active_count = L.active.as<uint32_t>();
@@ -789,6 +790,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.draws_end = nullptr;
   vp.nmodels = nullptr;
   vp.counts = nullptr;
+  vp.sums = nullptr;
   vp.models = nullptr;
   vp.e_work = nullptr;
   vp.sidx_g = nullptr;
@@ -820,7 +822,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
       bm_max = std::max<uint64_t>(bm_max, (uint64_t)plan.batch[f] * vp_maxm(f));
     }
     plan.bm_max = bm_max;
-    const uint64_t per_pair = (uint64_t)plan.bmax * (7 * 4 + 4 + 4) + bm_max * (4 + 72) + (uint64_t)plan.batch[0] * 200 * 8 +
+    const uint64_t per_pair = (uint64_t)plan.bmax * (7 * 4 + 4 + 4) + bm_max * (4 + 8 + 72) + (uint64_t)plan.batch[0] * 200 * 8 +
                               (LO_WORK_DOUBLES + 90 + 90 + 200) * 8 + 8;
     // Lanes: the pair list is dealt out in chunks to up to DSM_VERIFY_MAX_LANES lanes that run concurrently (own
     // stream, own host thread, own scratch; see VerifyLane).  A pair's three families cannot overlap -- F starts from
@@ -838,7 +840,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         uint64_t have = 0;  // buffers of an earlier call are reused, not allocated again
         for (VerifyLane& L : ctx->lanes)
-          for (DevBuf* b : {&L.samples, &L.draws_end, &L.nmodels, &L.vcounts, &L.models, &L.ework, &L.lo_work, &L.lo_models, &L.lo_slots,
+          for (DevBuf* b : {&L.samples, &L.draws_end, &L.nmodels, &L.vcounts, &L.vsums, &L.models, &L.ework, &L.lo_work, &L.lo_models, &L.lo_slots,
                             &L.lo_ework})
             have += b->cap;
         budget = std::min<uint64_t>(96ull << 30, std::max<uint64_t>(4ull << 30, (uint64_t)((free_b + have) * 0.4)));
@@ -887,6 +889,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
       HIPCHK(ctx, L.draws_end.reserve((size_t)chunk * plan.bmax * 4));
       HIPCHK(ctx, L.nmodels.reserve((size_t)chunk * plan.bmax * 4));
       HIPCHK(ctx, L.vcounts.reserve((size_t)chunk * bm_max * 4));
+      HIPCHK(ctx, L.vsums.reserve((size_t)chunk * bm_max * 8));
       HIPCHK(ctx, L.models.reserve((size_t)chunk * bm_max * 72));
       HIPCHK(ctx, L.ework.reserve((size_t)chunk * plan.batch[0] * 200 * 8));
       HIPCHK(ctx, L.lo_queue.reserve((size_t)chunk * 2 * 4));

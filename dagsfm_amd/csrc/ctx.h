@@ -63,7 +63,7 @@ struct DevBuf {
 struct VerifyLane {
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
-  DevBuf samples, draws_end, nmodels, vcounts, models, ework, active, vscratch;
+  DevBuf samples, draws_end, nmodels, vcounts, vsums, models, ework, active, vscratch;
   DevBuf lo_queue, lo_work, lo_models, lo_slots, lo_ework;  // batched local optimisation
   uint32_t rounds[3] = {0, 0, 0}, lo_iters[3] = {0, 0, 0};
   uint32_t dbg[32] = {0};

@@ -126,6 +126,7 @@ struct VerifyParams {
   uint32_t* draws_end;         // [n_chunk][batch] generator calls consumed up to the end of each trial's sample
   int32_t* nmodels;            // [n_chunk][batch]
   int32_t* counts;             // [n_chunk][batch][maxm]
+  double* sums;                // [n_chunk][batch][maxm] in-order residual sums of the inliers (F and H; k_score)
   double* models;              // [n_chunk][batch][maxm][9]
   uint32_t* sidx_g;            // [total] RandomSampler's persistent index array of every pair (at match offsets)
   uint32_t* active_count;      // pairs that still need trials after a replay round

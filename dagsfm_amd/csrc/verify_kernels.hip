@@ -1625,9 +1625,19 @@ __global__ __launch_bounds__(64, 8) void k_score(const VerifyParams p) {
   const double* gm = p.models + ((size_t)pl * p.batch + t) * F::MAXM * 9 + m * 9;
   double M[9];
   for (int k = 0; k < 9; ++k) M[k] = gm[k];
+  // InlierSupportMeasurer::Evaluate (support_measurement.cc:43-48): the lane walks the correspondences in index
+  // order, so its running sum IS the in-order residual_sum that decides ties between equal inlier counts
   int cnt = 0;
-  for (int i = 0; i < n; ++i) cnt += (fam_residual<FAM>(M, pts + (size_t)i * 4) <= max_residual) ? 1 : 0;
+  double sum = 0;
+  for (int i = 0; i < n; ++i) {
+    const double r = fam_residual<FAM>(M, pts + (size_t)i * 4);
+    if (r <= max_residual) {
+      cnt += 1;
+      sum += r;
+    }
+  }
   p.counts[((size_t)pl * p.batch + t) * F::MAXM + m] = cnt;
+  p.sums[((size_t)pl * p.batch + t) * F::MAXM + m] = sum;
 }
 
 // E family: the minimal solve is split in two kernels.  One lane per hypothesis keeps ~5 KB of matrices in
@@ -1858,6 +1868,58 @@ __global__ __launch_bounds__(64, 4) void k_models_score_e(const VerifyParams p) 
 #endif
 
 
+// Skip-ahead of the replay: from trial t on, the first trial that can change anything -- one with a model that would
+// replace the best one (more inliers, or as many and a smaller residual sum: Compare, support_measurement.cc:52-60),
+// or any trial with a model at or past the stopping threshold.  Returns its index (>= nb: none) and adds the models
+// of the trials skipped over to *num_models (they are "scored" models for the report's bookkeeping).  Four 64-trial
+// windows are loaded at once; count slots at and beyond a trial's model count hold stale values and are masked.
+// The essential family has no precomputed sums (its scoring is wave-per-model): every tie is an event there.
+template <int FAM>
+DSM_DEV int replay_next_event(int t, int nb, const int32_t* nmod, const int32_t* cnts, const double* sums, uint32_t best_n,
+                              double best_sum, uint32_t thr, uint32_t T0, uint32_t* num_models, int lane) {
+  constexpr int MAXM = Fam<FAM>::MAXM;
+  constexpr int PF = 4;
+  while (t < nb) {
+    int nm_k[PF];
+    bool hit_k[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int tt = t + 64 * k + lane;
+      nm_k[k] = 0;
+      hit_k[k] = false;
+      if (tt < nb) {
+        const int nm_l = nmod[tt];
+        int c[MAXM];
+#pragma unroll
+        for (int m = 0; m < MAXM; ++m) c[m] = cnts[(size_t)tt * MAXM + m];
+        bool hit = false;
+#pragma unroll
+        for (int m = 0; m < MAXM; ++m) {
+          if (m < nm_l) {
+            if ((uint32_t)c[m] > best_n) hit = true;
+            if ((uint32_t)c[m] == best_n) hit = hit || (FAM == FAM_E ? true : sums[(size_t)tt * MAXM + m] < best_sum);
+          }
+        }
+        nm_k[k] = nm_l;
+        hit_k[k] = hit;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int tt = t + 64 * k + lane;
+      const bool ev = nm_k[k] > 0 && (hit_k[k] || (T0 + (uint32_t)tt) >= thr);
+      const unsigned long long bal = __ballot(ev);
+      const int f = bal ? (__ffsll((long long)bal) - 1) : 64;
+      int skipped = (lane < f) ? nm_k[k] : 0;
+      for (int o = 32; o > 0; o >>= 1) skipped += __shfl_xor(skipped, o);
+      *num_models += (uint32_t)skipped;
+      if (bal) return t + 64 * k + f;
+    }
+    t += 64 * PF;
+  }
+  return t;
+}
+
 template <int FAM>
 __global__ __launch_bounds__(64, 4) void k_replay(const VerifyParams p) {
   uint32_t* p_dbg = p.active_count + 8;
@@ -1910,6 +1972,7 @@ __global__ __launch_bounds__(64, 4) void k_replay(const VerifyParams p) {
     const int nb = (int)fs->nb;
     const int32_t* nmod = p.nmodels + (size_t)pl * p.batch;
     const int32_t* cnts = p.counts + (size_t)pl * p.batch * F::MAXM;
+    const double* sums = p.sums + (size_t)pl * p.batch * F::MAXM;  // F and H only
     const double* mods = p.models + (size_t)pl * p.batch * F::MAXM * 9;
 
     bool abort = false;
@@ -1920,30 +1983,8 @@ __global__ __launch_bounds__(64, 4) void k_replay(const VerifyParams p) {
     (void)t_pair0;
     while (t < nb) {
       // ---- skip ahead to the next trial that can change anything
-      const int tt = t + lane;
-      int nm_l = 0;
-      bool ev = false;
-      if (tt < nb) {
-        nm_l = nmod[tt];
-        int mx = -1;
-        for (int m = 0; m < nm_l; ++m) {
-          const int c = cnts[(size_t)tt * F::MAXM + m];
-          mx = c > mx ? c : mx;
-        }
-        const uint32_t thr = dyn_max > min_trials ? dyn_max : min_trials;
-        ev = nm_l > 0 && ((uint32_t)mx >= best_n || (T0 + (uint32_t)tt) >= thr);
-      }
-      const unsigned long long bal = __ballot(ev);
-      const int f = bal ? (__ffsll((long long)bal) - 1) : 64;
-      // models of the skipped trials are still "scored" models (bookkeeping only)
-      int skipped = (lane < f) ? nm_l : 0;
-      for (int o = 32; o > 0; o >>= 1) skipped += __shfl_xor(skipped, o);
-      num_models += (uint32_t)skipped;
-      if (!bal) {
-        t += 64;
-        continue;
-      }
-      t += f;
+      t = replay_next_event<FAM>(t, nb, nmod, cnts, sums, best_n, best_sum, dyn_max > min_trials ? dyn_max : min_trials, T0, &num_models, lane);
+      if (t >= nb) break;
       trial_abs = T0 + (uint32_t)t;
       // ---- exact sequential processing of trial t (loransac.h:142-198)
       const int nm = nmod[t];
@@ -1954,11 +1995,13 @@ __global__ __launch_bounds__(64, 4) void k_replay(const VerifyParams p) {
         if (cnt >= best_n) {
           if (lane == 0) atomicAdd(p.active_count + 1 + FAM * 2, 1u);
           double sum;
-          {
+          if constexpr (FAM == FAM_E) {
             TSEC_BEGIN();
             score_model<FAM>(w, M, max_residual, true);
             sum = ordered_residual_sum(w, max_residual);
             TSEC_END(0);
+          } else {
+            sum = sums[(size_t)t * F::MAXM + m];  // k_score's in-order sum
           }
           if (cnt > best_n || (cnt == best_n && sum < best_sum)) {
             best_n = cnt;
@@ -1969,6 +2012,10 @@ __global__ __launch_bounds__(64, 4) void k_replay(const VerifyParams p) {
               int ninl, nlo;
               {
                 TSEC_BEGIN();
+                if constexpr (FAM != FAM_E) {  // the residuals of the new best model, for the compaction
+                  score_model<FAM>(w, M, max_residual, true);
+                  wv_sync();
+                }
                 ninl = compact_inliers(w, max_residual);
                 nlo = fam_local<FAM>(w, ninl);
                 TSEC_END(1);
@@ -2109,6 +2156,7 @@ __global__ __launch_bounds__(64, 4) void k_replay_lo(const VerifyParams p) {
     const int nb = (int)fs->nb;
     const int32_t* nmod = p.nmodels + (size_t)pl * p.batch;
     const int32_t* cnts = p.counts + (size_t)pl * p.batch * F::MAXM;
+    const double* sums = p.sums + (size_t)pl * p.batch * F::MAXM;  // F and H only
     const double* mods = p.models + (size_t)pl * p.batch * F::MAXM * 9;
 
     bool abort = false, suspended = false;
@@ -2143,29 +2191,8 @@ __global__ __launch_bounds__(64, 4) void k_replay_lo(const VerifyParams p) {
     while (!abort && t < nb) {
       if (!in_trial) {
         // ---- skip ahead to the next trial that can change anything
-        const int tt = t + lane;
-        int nm_l = 0;
-        bool ev = false;
-        if (tt < nb) {
-          nm_l = nmod[tt];
-          int mx = -1;
-          for (int m = 0; m < nm_l; ++m) {
-            const int c = cnts[(size_t)tt * F::MAXM + m];
-            mx = c > mx ? c : mx;
-          }
-          const uint32_t thr = dyn_max > min_trials ? dyn_max : min_trials;
-          ev = nm_l > 0 && ((uint32_t)mx >= best_n || (T0 + (uint32_t)tt) >= thr);
-        }
-        const unsigned long long bal = __ballot(ev);
-        const int f = bal ? (__ffsll((long long)bal) - 1) : 64;
-        int skipped = (lane < f) ? nm_l : 0;
-        for (int o = 32; o > 0; o >>= 1) skipped += __shfl_xor(skipped, o);
-        num_models += (uint32_t)skipped;
-        if (!bal) {
-          t += 64;
-          continue;
-        }
-        t += f;
+        t = replay_next_event<FAM>(t, nb, nmod, cnts, sums, best_n, best_sum, dyn_max > min_trials ? dyn_max : min_trials, T0, &num_models, lane);
+        if (t >= nb) break;
         m_start = 0;
       }
       in_trial = false;
@@ -2178,14 +2205,23 @@ __global__ __launch_bounds__(64, 4) void k_replay_lo(const VerifyParams p) {
         const double* M = mods + ((size_t)t * F::MAXM + m) * 9;
         if (cnt >= best_n) {
           if (lane == 0) atomicAdd(p.active_count + 1 + FAM * 2, 1u);
-          uint32_t cnt_again;
-          const double sum = score_and_sum<FAM>(w, M, max_residual, &cnt_again);
+          double sum;
+          if constexpr (FAM == FAM_E) {
+            uint32_t cnt_again;
+            sum = score_and_sum<FAM>(w, M, max_residual, &cnt_again);
+          } else {
+            sum = sums[(size_t)t * F::MAXM + m];  // k_score's in-order sum
+          }
           if (cnt > best_n || (cnt == best_n && sum < best_sum)) {
             best_n = cnt;
             best_sum = sum;
             for (int k = 0; k < 9; ++k) best_model[k] = M[k];
             if (cnt > (uint32_t)F::K && cnt >= (uint32_t)F::LO_MIN) {
               if (lane == 0) atomicAdd(p.active_count + 2 + FAM * 2, 1u);
+              if constexpr (FAM != FAM_E) {  // the residuals of the new best model, for the compaction
+                score_model<FAM>(w, M, max_residual, true);
+                wv_sync();
+              }
               const int ninl = compact_inliers(w, max_residual);  // -> lo_inl
               if (lane == 0) {
                 fs->t_pos = (uint32_t)t;
