@@ -1760,17 +1760,21 @@ __global__ __launch_bounds__(64) void k_solve_e_lu(const VerifyParams p) {
 
 // slot coefficients -> slot roots (real parts); returns the code for nmodels: bits 0..9 root i is real
 // (essential_matrix.cc:126), bits 16..: number of roots
-DSM_DEV int e_roots_body(double* slot, double* Tl) {
+DSM_DEV int e_roots_body(double* slot) {
   double coeffs[11], rr[11], ri[11];
+#pragma unroll
   for (int k = 0; k < 11; ++k) coeffs[k] = slot[EPOLY_COEFFS + k];
   LSEC_BEGIN4();
-  const int nroots = pl_poly_roots<11, 64>(coeffs, 11, rr, ri, Tl);
+  const int nroots = pr_poly_roots<11>(coeffs, rr, ri);  // companion matrix in registers
   LSEC_END4(11);
   int code = 0;
   if (nroots > 0) {
-    for (int i = 0; i < nroots; ++i) {
-      if (!(fabs(ri[i]) > 1e-10)) code |= 1 << i;
-      slot[EPOLY_COEFFS + i] = rr[i];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      if (i < nroots) {
+        if (!(fabs(ri[i]) > 1e-10)) code |= 1 << i;
+        slot[EPOLY_COEFFS + i] = rr[i];
+      }
     }
     code |= nroots << 16;
   }
@@ -1793,6 +1797,17 @@ DSM_DEV int e_models_body(const double* slot, int code, double* models_out) {
 // roots of the determinant polynomial: slot coefficients -> slot roots (real parts) + nmodels = root count /
 // real-root mask for k_models_score_e
 __global__ __launch_bounds__(64) void k_roots_e(const VerifyParams p) {
+  const uint32_t pl = blockIdx.x;
+  const uint32_t pi = p.pair0 + pl;
+  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
+  if (!fs->active) return;
+  const int t = blockIdx.y * 64 + threadIdx.x;
+  if (t >= (int)fs->nb) return;
+  p.nmodels[(size_t)pl * p.batch + t] = e_roots_body(p.models + ((size_t)pl * p.batch + t) * 90);
+}
+// The round-2 form of the same kernel, kept for comparison (DSM_ROOTS_LDS=1): the companion matrix of every lane in
+// lane-interleaved LDS (51 KB per wave), dynamically indexed.
+__global__ __launch_bounds__(64) void k_roots_e_lds(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* Tl = reinterpret_cast<double*>(smem_raw) + threadIdx.x;  // this lane's companion matrix, stride 64
   const uint32_t pl = blockIdx.x;
@@ -1801,7 +1816,19 @@ __global__ __launch_bounds__(64) void k_roots_e(const VerifyParams p) {
   if (!fs->active) return;
   const int t = blockIdx.y * 64 + threadIdx.x;
   if (t >= (int)fs->nb) return;
-  p.nmodels[(size_t)pl * p.batch + t] = e_roots_body(p.models + ((size_t)pl * p.batch + t) * 90, Tl);
+  double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
+  double coeffs[11], rr[11], ri[11];
+  for (int k = 0; k < 11; ++k) coeffs[k] = slot[EPOLY_COEFFS + k];
+  const int nroots = pl_poly_roots<11, 64>(coeffs, 11, rr, ri, Tl);
+  int code = 0;
+  if (nroots > 0) {
+    for (int i = 0; i < nroots; ++i) {
+      if (!(fabs(ri[i]) > 1e-10)) code |= 1 << i;
+      slot[EPOLY_COEFFS + i] = rr[i];
+    }
+    code |= nroots << 16;
+  }
+  p.nmodels[(size_t)pl * p.batch + t] = code;
 }
 
 // models of every hypothesis (one lane each), then the inlier counts of ALL models of the block's 64
@@ -2475,14 +2502,12 @@ __global__ __launch_bounds__(64) void k_lo_e_lu(const VerifyParams p) {
   e_lu_body(p.lo_ework + (size_t)pl * 200, p.lo_slots + (size_t)pl * 90, Al, idx);
 }
 __global__ __launch_bounds__(64) void k_lo_e_roots_models(const VerifyParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  double* Tl = reinterpret_cast<double*>(smem_raw) + threadIdx.x;
   const uint32_t widx = blockIdx.x * 64u + threadIdx.x;
   if (widx >= p.n_work) return;
   const uint32_t pl = p.worklist[widx];
   const uint32_t pi = p.pair0 + pl;
   double* slot = p.lo_slots + (size_t)pl * 90;
-  const int code = e_roots_body(slot, Tl);
+  const int code = e_roots_body(slot);
   double mloc[90];
   const int nm = e_models_body(slot, code, mloc);
   double* om = p.lo_models + (size_t)pl * 90;
@@ -2506,7 +2531,7 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, hipS
     hipLaunchKernelGGL(k_lo_jacobi<FAM_E>, g4, dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_lo_e_build, g64, dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_lo_e_lu, g64, dim3(64), ELU_SMEM, st, p);
-    hipLaunchKernelGGL(k_lo_e_roots_models, g64, dim3(64), 100 * 64 * sizeof(double), st, p);
+    hipLaunchKernelGGL(k_lo_e_roots_models, g64, dim3(64), 0, st, p);
   }
   if (fam == FAM_F) {
     hipLaunchKernelGGL(k_lo_prepare<FAM_F>, dim3(nb_prep), dim3(64), 0, st, p);
@@ -2538,7 +2563,11 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
   if (fam == FAM_E) {
     hipLaunchKernelGGL(k_solve_e_build, grid, dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_solve_e_lu, grid, dim3(64), ELU_SMEM, st, p);
-    hipLaunchKernelGGL(k_roots_e, grid, dim3(64), 100 * 64 * sizeof(double), st, p);
+    const bool roots_lds = getenv("DSM_ROOTS_LDS") != nullptr;
+    if (roots_lds)
+      hipLaunchKernelGGL(k_roots_e_lds, grid, dim3(64), 100 * 64 * sizeof(double), st, p);
+    else
+      hipLaunchKernelGGL(k_roots_e, grid, dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_models_score_e, grid, dim3(64), smem, st, p);
   }
   if (fam == FAM_F) {
