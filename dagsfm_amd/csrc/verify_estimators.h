@@ -148,6 +148,69 @@ DSM_DEV int seven_point_t(const double* xs, double* models, double* At_ext) {
   return nm;
 }
 DSM_DEVN int seven_point(const double* xs, double* models) { return seven_point_t<1>(xs, models, nullptr); }
+// seven_point_t with every array in registers (pr_nullspace_9xm, pr_poly_roots): what the batch kernel k_solve<F> runs.
+// models: 3 x 9, slots beyond the returned count are left untouched.
+DSM_DEV int seven_point_reg(const double (&xs)[28], double (&models)[27]) {
+  double At[63];  // A^T, 9 x 7 column-major: At[i*9 + c] = A(i, c)
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const double x0 = xs[i * 4 + 0], y0 = xs[i * 4 + 1], x1 = xs[i * 4 + 2], y1 = xs[i * 4 + 3];
+    At[i * 9 + 0] = x1 * x0; At[i * 9 + 1] = x1 * y0; At[i * 9 + 2] = x1;
+    At[i * 9 + 3] = y1 * x0; At[i * 9 + 4] = y1 * y0; At[i * 9 + 5] = y1;
+    At[i * 9 + 6] = x0; At[i * 9 + 7] = y0; At[i * 9 + 8] = 1;
+  }
+  double nv[18];
+  pr_nullspace_9xm<7>(At, nv);
+  double f1[9], f2[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    f2[k] = nv[9 + k];
+    f1[k] = nv[k] - f2[k];
+  }
+  const double t0 = f1[4] * f1[8] - f1[5] * f1[7];
+  const double t1 = f1[3] * f1[8] - f1[5] * f1[6];
+  const double t2 = f1[3] * f1[7] - f1[4] * f1[6];
+  const double t3 = f2[4] * f2[8] - f2[5] * f2[7];
+  const double t4 = f2[3] * f2[8] - f2[5] * f2[6];
+  const double t5 = f2[3] * f2[7] - f2[4] * f2[6];
+  double coeffs[4];
+  coeffs[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
+  coeffs[1] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2 - f2[3] * (f1[1] * f1[8] - f1[2] * f1[7]) +
+              f2[4] * (f1[0] * f1[8] - f1[2] * f1[6]) - f2[5] * (f1[0] * f1[7] - f1[1] * f1[6]) +
+              f2[6] * (f1[1] * f1[5] - f1[2] * f1[4]) - f2[7] * (f1[0] * f1[5] - f1[2] * f1[3]) +
+              f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
+  coeffs[2] = f1[0] * t3 - f1[1] * t4 + f1[2] * t5 - f1[3] * (f2[1] * f2[8] - f2[2] * f2[7]) +
+              f1[4] * (f2[0] * f2[8] - f2[2] * f2[6]) - f1[5] * (f2[0] * f2[7] - f2[1] * f2[6]) +
+              f1[6] * (f2[1] * f2[5] - f2[2] * f2[4]) - f1[7] * (f2[0] * f2[5] - f2[2] * f2[3]) +
+              f1[8] * (f2[0] * f2[4] - f2[1] * f2[3]);
+  coeffs[3] = f2[0] * t3 - f2[1] * t4 + f2[2] * t5;
+  double rr[4], ri[4];
+  const int nroots = pr_poly_roots<4>(coeffs, rr, ri);
+  if (nroots < 0) return 0;
+  int nm = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (i < nroots && !(fabs(ri[i]) > 1e-10)) {
+      const double lambda = rr[i];
+      const double mu = 1;
+      double F[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) F[k] = lambda * f1[k] + mu * f2[k];
+      if (!(fabs(F[8]) < 1e-10)) {
+        const double f22 = F[8];
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+          if (sl == nm) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) models[sl * 9 + k] = F[k] / f22;
+          }
+        }
+        ++nm;
+      }
+    }
+  }
+  return nm;
+}
 
 // Rank-2 projection + de-normalisation of the 8-point estimator (fundamental_matrix.cc:172-191);
 // nullvec = cmatrix_svd.matrixV().col(8); N1/N2 given as (nf, m02, m12).
@@ -675,6 +738,24 @@ DSM_DEV void five_point_basis(const double* xs, double* Eb) {
   pl_nullspace_9xm(At, 5, 5, nv);
   for (int r = 0; r < 9; ++r)
     for (int c = 0; c < 4; ++c) Eb[r * 4 + c] = nv[c * 9 + r];
+}
+// five_point_basis with the 9 x 5 matrix in registers (batch kernels)
+DSM_DEV void five_point_basis_reg(const double (&xs)[20], double (&Eb)[36]) {
+  double At[45];  // Q^T, 9 x 5
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const double x1_0 = xs[i * 4 + 0], x1_1 = xs[i * 4 + 1], x2_0 = xs[i * 4 + 2], x2_1 = xs[i * 4 + 3];
+    At[i * 9 + 0] = x1_0 * x2_0; At[i * 9 + 1] = x1_1 * x2_0; At[i * 9 + 2] = x2_0;
+    At[i * 9 + 3] = x1_0 * x2_1; At[i * 9 + 4] = x1_1 * x2_1; At[i * 9 + 5] = x2_1;
+    At[i * 9 + 6] = x1_0; At[i * 9 + 7] = x1_1; At[i * 9 + 8] = 1;
+  }
+  double nv[36];  // columns 5..8 of V, nv[c*9 + r]
+  pr_nullspace_9xm<5>(At, nv);
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Eb[r * 4 + c] = nv[c * 9 + r];
+  }
 }
 DSM_DEVN int five_point_minimal(const double* xs, double* models) {
   double Eb[36];

@@ -1569,10 +1569,8 @@ __global__ __launch_bounds__(64) void k_sample(const VerifyParams p) {
 // with a 9-double model per lane and wants many resident waves; k_score gives every (trial, model) slot its
 // own lane, so a 7-point sample with three roots costs three lanes instead of three passes of its lane.
 template <int FAM>
-__global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_solve(const VerifyParams p) {
+__global__ __launch_bounds__(64, 2) void k_solve(const VerifyParams p) {
   typedef Fam<FAM> F;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  double* At_l = reinterpret_cast<double*>(smem_raw) + threadIdx.x;  // F only: 63 x 64 doubles
   const uint32_t pl = blockIdx.x;
   const uint32_t pi = p.pair0 + pl;
   const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
@@ -1582,6 +1580,7 @@ __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_solve(const Veri
   const double* pts = p.pts_px + 4 * p.match_off[pi];
   const uint32_t* smp = p.samples + ((size_t)pl * p.batch + t) * 7;
   double xs[F::K * 4];
+#pragma unroll
   for (int i = 0; i < F::K; ++i) {
     const double* q = pts + (size_t)smp[i] * 4;
     xs[i * 4 + 0] = q[0]; xs[i * 4 + 1] = q[1]; xs[i * 4 + 2] = q[2]; xs[i * 4 + 3] = q[3];
@@ -1589,12 +1588,14 @@ __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_solve(const Veri
   double mloc[F::MAXM * 9];
   int nm;
   if constexpr (FAM == FAM_F)
-    nm = seven_point_t<64>(xs, mloc, At_l);
+    nm = seven_point_reg(xs, mloc);  // 9 x 7 pivoted QR, cubic roots: all in registers
   else
     nm = fam_minimal<FAM>(xs, mloc);
   p.nmodels[(size_t)pl * p.batch + t] = nm;
   double* gm = p.models + ((size_t)pl * p.batch + t) * F::MAXM * 9;
-  for (int k = 0; k < nm * 9; ++k) gm[k] = mloc[k];
+#pragma unroll
+  for (int k = 0; k < F::MAXM * 9; ++k)
+    if (k < nm * 9) gm[k] = mloc[k];
 }
 
 template <int FAM>
@@ -1661,12 +1662,13 @@ __global__ __launch_bounds__(64, 2) void k_solve_e_build(const VerifyParams p) {
   const double* pts = p.pts_norm + 4 * p.match_off[pi];
   const uint32_t* smp = p.samples + ((size_t)pl * p.batch + t) * 7;
   double xs[20];
+#pragma unroll
   for (int i = 0; i < 5; ++i) {
     const double* q = pts + (size_t)smp[i] * 4;
     xs[i * 4 + 0] = q[0]; xs[i * 4 + 1] = q[1]; xs[i * 4 + 2] = q[2]; xs[i * 4 + 3] = q[3];
   }
   double Eb[36];
-  five_point_basis(xs, Eb);
+  five_point_basis_reg(xs, Eb);
   double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
   for (int k = 0; k < 36; ++k) slot[EPOLY_EB + k] = Eb[k];
   five_point_build_A_rows(Eb, p.e_work + ((size_t)pl * p.batch + t) * 200);
@@ -2571,7 +2573,7 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
     hipLaunchKernelGGL(k_models_score_e, grid, dim3(64), smem, st, p);
   }
   if (fam == FAM_F) {
-    hipLaunchKernelGGL(k_solve<FAM_F>, grid, dim3(64), 63 * 64 * sizeof(double), st, p);
+    hipLaunchKernelGGL(k_solve<FAM_F>, grid, dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_score<FAM_F>, dim3(p.n_chunk, (p.batch * 3 + 63) / 64), dim3(64), smem, st, p);
   }
   if (fam == FAM_H) {

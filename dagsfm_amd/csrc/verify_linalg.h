@@ -185,6 +185,165 @@ DSM_DEV void pl_nullspace_9xm(double* At, int m, int first, double* out) {
   for (int c = first; c < 9; ++c) pl_householder_q_col<ES>(At, 9, m, hco, c, out + (c - first) * 9);
 }
 
+// ---------------------------------------------------------------------- register-resident forms (static indices only)
+// pl_colpiv_qr / pl_householder_q_col / pl_nullspace_9xm for a 9 x M matrix held in registers: every loop is unrolled
+// over its static range and the one data-dependent index -- the pivot column -- becomes a chain of predicated column
+// swaps.  Same operations in the same order as the pl_ routines (which the single-kernel reference schedule keeps).
+template <int M>
+DSM_DEV void pr_colpiv_qr9(double (&qr)[9 * M], double (&hco)[M]) {
+#define QRE(i, k) qr[(k) * 9 + (i)]
+  double norms_updated[M], norms_direct[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s += QRE(i, k) * QRE(i, k);
+    norms_direct[k] = sqrt(s);
+    norms_updated[k] = norms_direct[k];
+  }
+  const double norm_downdate_threshold = sqrt(DBL_EPSILON);
+#pragma unroll
+  for (int k = 0; k < M; ++k) {
+    int biggest = k;
+    double mx = norms_updated[k];
+#pragma unroll
+    for (int j = k + 1; j < M; ++j) {
+      if (norms_updated[j] > mx) {
+        mx = norms_updated[j];
+        biggest = j;
+      }
+    }
+#pragma unroll
+    for (int j = k + 1; j < M; ++j) {
+      if (j == biggest) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          const double t = QRE(i, k);
+          QRE(i, k) = QRE(i, j);
+          QRE(i, j) = t;
+        }
+        double t = norms_updated[k];
+        norms_updated[k] = norms_updated[j];
+        norms_updated[j] = t;
+        t = norms_direct[k];
+        norms_direct[k] = norms_direct[j];
+        norms_direct[j] = t;
+      }
+    }
+    // pl_make_householder on rows k..8 of column k
+    double tail_sq = 0.0;
+#pragma unroll
+    for (int i = k + 1; i < 9; ++i) tail_sq += QRE(i, k) * QRE(i, k);
+    const double c0 = QRE(k, k);
+    double tau, beta;
+    if (tail_sq <= DBL_MIN) {
+      tau = 0.0;
+      beta = c0;
+#pragma unroll
+      for (int i = k + 1; i < 9; ++i) QRE(i, k) = 0.0;
+    } else {
+      double b = sqrt(c0 * c0 + tail_sq);
+      if (c0 >= 0.0) b = -b;
+#pragma unroll
+      for (int i = k + 1; i < 9; ++i) QRE(i, k) = QRE(i, k) / (c0 - b);
+      tau = (b - c0) / b;
+      beta = b;
+    }
+    hco[k] = tau;
+    QRE(k, k) = beta;
+    if (tau != 0.0) {  // rows k..8 (never a single row: k <= M - 1 <= 7)
+#pragma unroll
+      for (int j = k + 1; j < M; ++j) {
+        double tmp = 0.0;
+#pragma unroll
+        for (int i = k + 1; i < 9; ++i) tmp += QRE(i, k) * QRE(i, j);
+        tmp += QRE(k, j);
+        QRE(k, j) -= tau * tmp;
+#pragma unroll
+        for (int i = k + 1; i < 9; ++i) QRE(i, j) -= tau * QRE(i, k) * tmp;
+      }
+    }
+#pragma unroll
+    for (int j = k + 1; j < M; ++j) {
+      if (norms_updated[j] != 0.0) {
+        double temp = fabs(QRE(k, j)) / norms_updated[j];
+        temp = (1.0 + temp) * (1.0 - temp);
+        temp = temp < 0.0 ? 0.0 : temp;
+        const double ratio = norms_updated[j] / norms_direct[j];
+        const double temp2 = temp * (ratio * ratio);
+        if (temp2 <= norm_downdate_threshold) {
+          double s = 0.0;
+#pragma unroll
+          for (int i = k + 1; i < 9; ++i) s += QRE(i, j) * QRE(i, j);
+          norms_direct[j] = sqrt(s);
+          norms_updated[j] = norms_direct[j];
+        } else {
+          norms_updated[j] *= sqrt(temp);
+        }
+      }
+    }
+  }
+#undef QRE
+}
+
+// column J of householderQ() (9 x 9) of the pivoted QR above
+template <int M, int J>
+DSM_DEV void pr_householder_q_col9(const double (&qr)[9 * M], const double (&hco)[M], double (&q)[9]) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) q[i] = (i == J) ? 1.0 : 0.0;
+#pragma unroll
+  for (int k = M - 1; k >= 0; --k) {
+    if (J < k) continue;  // the block starts at column k
+    const double tau = hco[k];
+    if (tau != 0.0) {
+      double tmp = 0.0;
+#pragma unroll
+      for (int i = k + 1; i < 9; ++i) tmp += qr[k * 9 + i] * q[i];
+      tmp += q[k];
+      q[k] -= tau * tmp;
+#pragma unroll
+      for (int i = k + 1; i < 9; ++i) q[i] -= tau * qr[k * 9 + i] * tmp;
+    }
+  }
+}
+
+// pl_nullspace_9xm for an M-column A^T in registers: columns M..8 of V into out[(c - M) * 9 + r]
+template <int M>
+DSM_DEV void pr_nullspace_9xm(double (&At)[9 * M], double (&out)[(9 - M) * 9]) {
+  double scale = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9 * M; ++i) {
+    const double a = fabs(At[i]);
+    if (a > scale) scale = a;
+  }
+  if (scale == 0.0) scale = 1.0;
+#pragma unroll
+  for (int i = 0; i < 9 * M; ++i) At[i] /= scale;
+  double hco[M];
+  pr_colpiv_qr9<M>(At, hco);
+  double q[9];
+  if constexpr (M <= 8) {
+    pr_householder_q_col9<M, 8>(At, hco, q);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out[(8 - M) * 9 + i] = q[i];
+  }
+  if constexpr (M <= 7) {
+    pr_householder_q_col9<M, 7>(At, hco, q);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out[(7 - M) * 9 + i] = q[i];
+  }
+  if constexpr (M <= 6) {
+    pr_householder_q_col9<M, 6>(At, hco, q);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out[(6 - M) * 9 + i] = q[i];
+  }
+  if constexpr (M <= 5) {
+    pr_householder_q_col9<M, 5>(At, hco, q);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out[(5 - M) * 9 + i] = q[i];
+  }
+}
+
 // makeJacobi(x, y, z)
 DSM_DEV void dsm_make_jacobi(double x, double y, double z, double* c, double* s) {
   const double deno = 2.0 * fabs(y);
