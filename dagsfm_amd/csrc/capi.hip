@@ -865,10 +865,11 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     plan.n_lanes = n_lanes;
     plan.dev_cus = dev_cus;
     // Local optimisation: batched kernels (k_replay_lo + k_lo_*) or inline in the replay (k_replay).  The batched form
-    // wins on throughput (config 2: 601 vs 708 ms) but every LO costs a kernel round trip, so a short pair list, whose
-    // time is the serial latency of its slowest pair, is faster inline (config 1, 1 225 pairs: 15.5 vs 23.1 ms; the two
-    // meet at ~11 000 pairs).  DSM_VERIFY_INLINE_LO=1 / =0 forces one or the other (tests cover both).
-    plan.inline_lo = n_pairs < 16384u;
+    // wins on throughput (config 2, 124 750 pairs: 430 vs 516 ms) but every LO costs a kernel round trip, so a short
+    // pair list, whose time is the serial latency of its slowest pair, is faster inline (1/8 of config 2, 15 593 pairs:
+    // 74 vs 82 ms; config 1, 1 225 pairs: 15 vs 23 ms); at 31 187 pairs the batched form is ahead again (130 vs 139 ms).
+    // DSM_VERIFY_INLINE_LO=1 / =0 forces one or the other (tests cover both).
+    plan.inline_lo = n_pairs < 24576u;
     if (const char* e = getenv("DSM_VERIFY_INLINE_LO")) plan.inline_lo = atoi(e) != 0;
     HIPCHK(ctx, ctx->d_fam_state.reserve(std::max<size_t>(n_pairs, 1) * 3 * sizeof(FamState)));
     HIPCHK(ctx, ctx->d_sidx.reserve(tm * 4));
