@@ -149,7 +149,7 @@ DSM_DEV int seven_point_t(const double* xs, double* models, double* At_ext) {
 }
 DSM_DEVN int seven_point(const double* xs, double* models) { return seven_point_t<1>(xs, models, nullptr); }
 // seven_point_t with every array in registers (pr_nullspace_9xm, pr_poly_roots): what the batch kernel k_solve<F> runs.
-// models: 3 x 9, slots beyond the returned count are left untouched.
+// models: 3 x 9, slots beyond the returned count are zero.
 DSM_DEV int seven_point_reg(const double (&xs)[28], double (&models)[27]) {
   double At[63];  // A^T, 9 x 7 column-major: At[i*9 + c] = A(i, c)
 #pragma unroll
@@ -189,6 +189,8 @@ DSM_DEV int seven_point_reg(const double (&xs)[28], double (&models)[27]) {
   if (nroots < 0) return 0;
   int nm = 0;
 #pragma unroll
+  for (int k = 0; k < 27; ++k) models[k] = 0.0;
+#pragma unroll
   for (int i = 0; i < 3; ++i) {
     if (i < nroots && !(fabs(ri[i]) > 1e-10)) {
       const double lambda = rr[i];
@@ -199,11 +201,10 @@ DSM_DEV int seven_point_reg(const double (&xs)[28], double (&models)[27]) {
       if (!(fabs(F[8]) < 1e-10)) {
         const double f22 = F[8];
 #pragma unroll
-        for (int sl = 0; sl < 3; ++sl) {
-          if (sl == nm) {
+        for (int k = 0; k < 9; ++k) {
+          const double v = F[k] / f22;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) models[sl * 9 + k] = F[k] / f22;
-          }
+          for (int sl = 0; sl < 3; ++sl) models[sl * 9 + k] = (sl == nm) ? v : models[sl * 9 + k];
         }
         ++nm;
       }

@@ -2433,7 +2433,7 @@ __global__ __launch_bounds__(64, 4) void k_lo_prepare(const VerifyParams p) {
 // smaller) problem; the sorted right factor V goes back to the pair's record.
 #define LOJ_GROUP_DOUBLES (81 + 81 + 9)
 #define LOJ_G 8  // lanes per problem
-template <int FAM>
+template <int FAM, bool SMALL_ONLY>
 __global__ __launch_bounds__(64) void k_lo_jacobi(const VerifyParams p) {
   __shared__ double lds[(64 / LOJ_G) * LOJ_GROUP_DOUBLES];
   const int lane = threadIdx.x;
@@ -2445,15 +2445,35 @@ __global__ __launch_bounds__(64) void k_lo_jacobi(const VerifyParams p) {
   grp_vd W = lds + g * LOJ_GROUP_DOUBLES;
   grp_vd V = W + 81;
   grp_vd sv = V + 81;
+  const double scale = in[168];
+  const int dsz = (int)in[169];
+  if (SMALL_ONLY && dsz == 9) return;  // a full 9 x 9 problem belongs to k_lo_jacobi_reg
   for (int e = gl; e < 81; e += LOJ_G) {
     W[e] = in[e];
     V[e] = in[81 + e];
   }
-  const double scale = in[168];
-  const int dsz = (int)in[169];
   grp_jacobi_sweeps<LOJ_G>(W, V, dsz, scale, sv, gl);
   double* outV = p.lo_work + (size_t)pl * LO_WORK_DOUBLES + 81;  // sorted right factor back to the pair's record
   for (int e = gl; e < 81; e += LOJ_G) outV[e] = V[e];
+}
+
+// The same step with a LANE per queued pair and the 9 x 9 problem in registers (pr_jacobi_sweeps9); problems that
+// the preconditioner left smaller than 9 x 9 (fewer than nine constraint rows: at most 8 inliers) go to k_lo_jacobi.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_lo_jacobi_reg(const VerifyParams p) {
+  const uint32_t widx = blockIdx.x * 64u + threadIdx.x;
+  if (widx >= p.n_work) return;
+  const uint32_t pl = p.worklist[widx];
+  double* rec = p.lo_work + (size_t)pl * LO_WORK_DOUBLES;
+  if ((int)rec[169] != 9) return;
+  double W[81], V[81], sv[9];
+#pragma unroll
+  for (int e = 0; e < 81; ++e) {
+    W[e] = rec[e];
+    V[e] = rec[81 + e];
+  }
+  pr_jacobi_sweeps9(W, V, rec[168], sv);
+#pragma unroll
+  for (int e = 0; e < 81; ++e) rec[81 + e] = V[e];  // sorted right factor back to the pair's record
 }
 
 // LO step 2b (F, H), lane per queued pair: the family's finish on the null vector V(:, 8) -- rank-2 projection +
@@ -2528,21 +2548,37 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, hipS
   if (!p.n_work || !n_blocks) return;
   const uint32_t nb_prep = p.n_work < n_blocks ? p.n_work : n_blocks;  // one scratch area per workgroup (wg_scratch)
   const dim3 g4((p.n_work + 64 / LOJ_G - 1) / (64 / LOJ_G)), g64((p.n_work + 63) / 64);
+  const bool reg_jacobi = getenv("DSM_LO_JACOBI_GROUPS") == nullptr;  // =1: the 8-lane-group kernel for every problem (round-2 form)
   if (fam == FAM_E) {
     hipLaunchKernelGGL(k_lo_prepare<FAM_E>, dim3(nb_prep), dim3(64), 0, st, p);
-    hipLaunchKernelGGL(k_lo_jacobi<FAM_E>, g4, dim3(64), 0, st, p);
+    if (reg_jacobi) {
+      hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
+      hipLaunchKernelGGL((k_lo_jacobi<FAM_E, true>), g4, dim3(64), 0, st, p);
+    } else {
+      hipLaunchKernelGGL((k_lo_jacobi<FAM_E, false>), g4, dim3(64), 0, st, p);
+    }
     hipLaunchKernelGGL(k_lo_e_build, g64, dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_lo_e_lu, g64, dim3(64), ELU_SMEM, st, p);
     hipLaunchKernelGGL(k_lo_e_roots_models, g64, dim3(64), 0, st, p);
   }
   if (fam == FAM_F) {
     hipLaunchKernelGGL(k_lo_prepare<FAM_F>, dim3(nb_prep), dim3(64), 0, st, p);
-    hipLaunchKernelGGL(k_lo_jacobi<FAM_F>, g4, dim3(64), 0, st, p);
+    if (reg_jacobi) {
+      hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
+      hipLaunchKernelGGL((k_lo_jacobi<FAM_F, true>), g4, dim3(64), 0, st, p);
+    } else {
+      hipLaunchKernelGGL((k_lo_jacobi<FAM_F, false>), g4, dim3(64), 0, st, p);
+    }
     hipLaunchKernelGGL(k_lo_finish<FAM_F>, g64, dim3(64), 0, st, p);
   }
   if (fam == FAM_H) {
     hipLaunchKernelGGL(k_lo_prepare<FAM_H>, dim3(nb_prep), dim3(64), 0, st, p);
-    hipLaunchKernelGGL(k_lo_jacobi<FAM_H>, g4, dim3(64), 0, st, p);
+    if (reg_jacobi) {
+      hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
+      hipLaunchKernelGGL((k_lo_jacobi<FAM_H, true>), g4, dim3(64), 0, st, p);
+    } else {
+      hipLaunchKernelGGL((k_lo_jacobi<FAM_H, false>), g4, dim3(64), 0, st, p);
+    }
     hipLaunchKernelGGL(k_lo_finish<FAM_H>, g64, dim3(64), 0, st, p);
   }
 }

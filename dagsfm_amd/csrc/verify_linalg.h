@@ -214,21 +214,20 @@ DSM_DEV void pr_colpiv_qr9(double (&qr)[9 * M], double (&hco)[M]) {
       }
     }
 #pragma unroll
-    for (int j = k + 1; j < M; ++j) {
-      if (j == biggest) {
+    for (int j = k + 1; j < M; ++j) {  // unconditional stores of selected values (see pr_jacobi_sweeps9)
+      const bool sw = (j == biggest);
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-          const double t = QRE(i, k);
-          QRE(i, k) = QRE(i, j);
-          QRE(i, j) = t;
-        }
-        double t = norms_updated[k];
-        norms_updated[k] = norms_updated[j];
-        norms_updated[j] = t;
-        t = norms_direct[k];
-        norms_direct[k] = norms_direct[j];
-        norms_direct[j] = t;
+      for (int i = 0; i < 9; ++i) {
+        const double a = QRE(i, k), b = QRE(i, j);
+        QRE(i, k) = sw ? b : a;
+        QRE(i, j) = sw ? a : b;
       }
+      const double ua = norms_updated[k], ub = norms_updated[j];
+      norms_updated[k] = sw ? ub : ua;
+      norms_updated[j] = sw ? ua : ub;
+      const double da = norms_direct[k], db = norms_direct[j];
+      norms_direct[k] = sw ? db : da;
+      norms_direct[j] = sw ? da : db;
     }
     // pl_make_householder on rows k..8 of column k
     double tail_sq = 0.0;
@@ -1855,6 +1854,100 @@ DSM_DEV void grp_jacobi_sweeps(grp_vd W, grp_vd V, int dsz, double scale, grp_vd
           t = V[i * 9 + r];
           V[i * 9 + r] = V[pos * 9 + r];
           V[pos * 9 + r] = t;
+        }
+      }
+    }
+  }
+}
+
+// The sweeps of grp_jacobi_sweeps for a full 9 x 9 problem by ONE lane with W and V in registers: the (p, q) order is
+// static, so all 36 rotations of a sweep are unrolled with compile-time indices; a lane whose off-diagonal pair is
+// already below the threshold skips its rotation by predicate, a lane that has converged leaves the sweep loop.
+// The 2 x 2 rotation chain (five divisions, three square roots) is issued once per wave instruction for 64 problems
+// (the 8-lane groups: for 8).  W, V column-major 9 x 9; on return V's columns are sorted by descending singular value
+// exactly like JacobiSVD does (selection sort with column swaps), sv holds the values.
+DSM_DEV void pr_jacobi_sweeps9(double (&W)[81], double (&V)[81], double scale, double (&sv)[9]) {
+  const double precision = 2.0 * DBL_EPSILON;
+  double max_diag = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const double a = fabs(W[i * 9 + i]);
+    if (a > max_diag) max_diag = a;
+  }
+  bool finished = false;
+  while (!finished) {
+    finished = true;
+#pragma unroll
+    for (int p = 1; p < 9; ++p) {
+#pragma unroll
+      for (int q = 0; q < p; ++q) {
+        const double thr = DBL_MIN > precision * max_diag ? DBL_MIN : precision * max_diag;
+        const double wpq = W[q * 9 + p], wqp = W[p * 9 + q];
+        if (fabs(wpq) > thr || fabs(wqp) > thr) {
+          finished = false;
+          double lc, ls, rc, rs;
+          dsm_jacobi_2x2(W[p * 9 + p], wpq, wqp, W[q * 9 + q], &lc, &ls, &rc, &rs);
+          if (!(lc == 1.0 && ls == 0.0)) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {  // rows p, q: elements (p, e), (q, e)
+              const double xi = W[e * 9 + p], yi = W[e * 9 + q];
+              W[e * 9 + p] = lc * xi + ls * yi;
+              W[e * 9 + q] = -ls * xi + lc * yi;
+            }
+          }
+          if (!(rc == 1.0 && -rs == 0.0)) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {  // columns p, q of W
+              const double xi = W[p * 9 + e], yi = W[q * 9 + e];
+              W[p * 9 + e] = rc * xi + (-rs) * yi;
+              W[q * 9 + e] = rs * xi + rc * yi;
+            }
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {  // columns p, q of V
+              const double xi = V[p * 9 + e], yi = V[q * 9 + e];
+              V[p * 9 + e] = rc * xi + (-rs) * yi;
+              V[q * 9 + e] = rs * xi + rc * yi;
+            }
+          }
+          const double app = fabs(W[p * 9 + p]), aqq = fabs(W[q * 9 + q]);
+          const double mm = app > aqq ? app : aqq;
+          if (mm > max_diag) max_diag = mm;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) sv[i] = fabs(W[i * 9 + i]) * scale;
+  bool stop = false;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    if (!stop) {
+      int pos = i;
+      double mx = sv[i];
+#pragma unroll
+      for (int j = i + 1; j < 9; ++j) {
+        if (sv[j] > mx) {
+          mx = sv[j];
+          pos = j;
+        }
+      }
+      if (mx == 0.0) {
+        stop = true;
+      } else {
+        // predicated swaps written as unconditional stores of selected VALUES: a store under `if (j == pos)` gets
+        // merged by the optimiser into one store through a selected ADDRESS, which sends the whole array to scratch
+#pragma unroll
+        for (int j = i + 1; j < 9; ++j) {
+          const bool sw = (j == pos);
+          const double si = sv[i], sj = sv[j];
+          sv[i] = sw ? sj : si;
+          sv[j] = sw ? si : sj;
+#pragma unroll
+          for (int r = 0; r < 9; ++r) {
+            const double a = V[i * 9 + r], b = V[j * 9 + r];
+            V[i * 9 + r] = sw ? b : a;
+            V[j * 9 + r] = sw ? a : b;
+          }
         }
       }
     }
