@@ -690,6 +690,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
             uint32_t* cnt_dev = L.active.as<uint32_t>() + 20 + cur;
             LANECHK(L, hipMemsetAsync(cnt_dev, 0, 4, st));
             LANECHK(L, hipMemsetAsync(actr + 64, 0, 4, st));  // work counter [16]
+            LANECHK(L, hipMemsetAsync(actr + 88, 0, 8, st));  // [22], [23]: queued problems for the general LO kernels
             vp.lo_queue = queues + (size_t)cur * chunk;
             vp.lo_count = cnt_dev;
             launch_vp_replay_lo(vp, f, nb_heavy, st);
@@ -704,7 +705,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
             vp.worklist = vp.lo_queue;
             vp.n_work = nq;
             LANECHK(L, hipMemsetAsync(actr + 76, 0, 4, st));  // k_lo_prepare's work counter [19]
-            launch_vp_local_opt(vp, f, nb_heavy, st);
+            launch_vp_local_opt(vp, f, nb_heavy, host_ctr[22], host_ctr[23], st);
             LANECHK(L, hipGetLastError());
           }
         }
@@ -791,6 +792,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.nmodels = nullptr;
   vp.counts = nullptr;
   vp.sums = nullptr;
+  vp.lo_reg_prepare = getenv("DSM_LO_PREPARE_WAVE") ? 0 : 1;  // =1: the round-2 kernel (matrix in global scratch) for every problem
   vp.models = nullptr;
   vp.e_work = nullptr;
   vp.sidx_g = nullptr;

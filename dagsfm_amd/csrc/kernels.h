@@ -127,6 +127,7 @@ struct VerifyParams {
   int32_t* nmodels;            // [n_chunk][batch]
   int32_t* counts;             // [n_chunk][batch][maxm]
   double* sums;                // [n_chunk][batch][maxm] in-order residual sums of the inliers (F and H; k_score)
+  int lo_reg_prepare;          // k_lo_prepare_reg takes the tall problems, k_lo_prepare only the rest
   double* models;              // [n_chunk][batch][maxm][9]
   uint32_t* sidx_g;            // [total] RandomSampler's persistent index array of every pair (at match offsets)
   uint32_t* active_count;      // pairs that still need trials after a replay round
@@ -162,7 +163,9 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st);
 void launch_vp_replay(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st);
 void launch_vp_final(const VerifyParams& p, uint32_t n_blocks, hipStream_t st);
 void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st);
-void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st);  // over p.worklist / p.n_work
+// over p.worklist / p.n_work; n_wave_prepare / n_small_jacobi: how many of the queued problems need the general kernels
+// (k_lo_prepare: not register-preparable; k_lo_jacobi: smaller than 9 x 9), counted by k_replay_lo at [22] / [23]
+void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint32_t n_wave_prepare, uint32_t n_small_jacobi, hipStream_t st);
 uint32_t vp_batch(int fam, uint32_t max_trials, uint32_t min_trials);
 uint32_t vp_maxm(int fam);
 void debug_read_prof(unsigned long long* out16);

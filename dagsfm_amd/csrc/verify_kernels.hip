@@ -2127,6 +2127,15 @@ __global__ __launch_bounds__(64, 4) void k_replay(const VerifyParams p) {
   }
 }
 
+// Which problems k_lo_prepare_reg takes: a tall matrix (more than nine constraint rows) whose rows fit the lanes'
+// registers -- up to LOP_PPL inliers per lane.
+#define LOP_PPL 4
+template <int FAM>
+__host__ __device__ inline bool lo_prepare_in_registers(int ninl) {
+  const int m = FAM == FAM_H ? 2 * ninl : ninl;
+  return FAM != FAM_H && m > 9 && ninl <= 64 * LOP_PPL;  // H (2n rows, 8 per lane) measured slower than k_lo_prepare
+}
+
 // ------------------------------------------------------------------------------------ replay with batched local optimisation
 // k_replay runs a pair's local optimisations inline: ONE problem on a 64-lane wave, most of it scalar chains
 // (2 x 2 rotations of the 9 x 9 Jacobi, the 5-point finish) that every lane executes redundantly -- 72 % of its
@@ -2258,6 +2267,8 @@ __global__ __launch_bounds__(64, 4) void k_replay_lo(const VerifyParams p) {
                 fs->lo_wait = 1;
                 fs->lo_ninl = (uint32_t)ninl;
                 p.lo_queue[atomicAdd(p.lo_count, 1u)] = pl;
+                if (!(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) atomicAdd(p.active_count + 22, 1u);
+                if ((FAM == FAM_H ? 2 * ninl : ninl) < 9) atomicAdd(p.active_count + 23, 1u);
               }
               suspended = true;
               break;
@@ -2338,6 +2349,194 @@ __global__ __launch_bounds__(64, 4) void k_replay_lo(const VerifyParams p) {
   }
 }
 
+// LO step 1 with the constraint matrix in registers (wr_colpiv_qr9): a wave per queued pair, lane l owns rows l,
+// l + 64, ...; the pair's inlier points are loaded once and serve the in-order normalisation sums (the four / two
+// independent chains of CenterAndNormalizeImagePoints advance together) and the rows.  Same operations as k_lo_prepare.
+template <int FAM>
+__global__ __launch_bounds__(64) void k_lo_prepare_reg(const VerifyParams p) {
+  constexpr int PPL = LOP_PPL;
+  constexpr int RPL = FAM == FAM_H ? 2 * PPL : PPL;
+  const int lane = threadIdx.x;
+  const uint32_t widx = blockIdx.x;
+  if (widx >= p.n_work) return;
+  const uint32_t pl = p.worklist[widx];
+  const uint32_t pi = p.pair0 + pl;
+  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
+  const int ninl = (int)fs->lo_ninl;
+  if (!lo_prepare_in_registers<FAM>(ninl)) return;
+  const uint64_t moff = p.match_off[pi];
+  const double* pts = (FAM == FAM_E ? p.pts_norm : p.pts_px) + 4 * moff;
+  const int* inl = reinterpret_cast<const int*>(p.lo_inl + moff);
+  double* out = p.lo_work + (size_t)pl * LO_WORK_DOUBLES;
+  const int m = FAM == FAM_H ? 2 * ninl : ninl;
+  double px[PPL][4];
+#pragma unroll
+  for (int r = 0; r < PPL; ++r) {
+    const int i = lane + 64 * r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) px[r][k] = 0.0;
+    if (i < ninl) {
+      const double* q = pts + (size_t)inl[i] * 4;
+      px[r][0] = q[0]; px[r][1] = q[1]; px[r][2] = q[2]; px[r][3] = q[3];
+    }
+  }
+  double n1[3] = {0, 0, 0}, n2[3] = {0, 0, 0};
+  if (FAM != FAM_E) {
+    // CenterAndNormalizeImagePoints (utils.cc:40-64) for both images: sums in index order
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      if (64 * r < ninl) {
+        const int cnt = (ninl - 64 * r) < 64 ? (ninl - 64 * r) : 64;
+        for (int k = 0; k < cnt; ++k) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) s[c] += wv_readlane_f64(px[r][c], k);
+        }
+      }
+    }
+    const double cx1 = s[0] / ninl, cy1 = s[1] / ninl, cx2 = s[2] / ninl, cy2 = s[3] / ninl;
+    double d[PPL][2];
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      const double dx1 = px[r][0] - cx1, dy1 = px[r][1] - cy1, dx2 = px[r][2] - cx2, dy2 = px[r][3] - cy2;
+      d[r][0] = dx1 * dx1 + dy1 * dy1;
+      d[r][1] = dx2 * dx2 + dy2 * dy2;
+    }
+    double q1 = 0.0, q2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      if (64 * r < ninl) {
+        const int cnt = (ninl - 64 * r) < 64 ? (ninl - 64 * r) : 64;
+        for (int k = 0; k < cnt; ++k) {
+          q1 += wv_readlane_f64(d[r][0], k);
+          q2 += wv_readlane_f64(d[r][1], k);
+        }
+      }
+    }
+    const double rms1 = sqrt(q1 / ninl), rms2 = sqrt(q2 / ninl);
+    n1[0] = sqrt(2.0) / rms1; n1[1] = -n1[0] * cx1; n1[2] = -n1[0] * cy1;
+    n2[0] = sqrt(2.0) / rms2; n2[1] = -n2[0] * cx2; n2[2] = -n2[0] * cy2;
+  }
+  double a[9][RPL];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) a[c][r] = 0.0;
+  }
+  if (FAM == FAM_E) {
+    // EssentialMatrixFivePointEstimator::Estimate with all inliers, essential_matrix.cc:52-66
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      const double x1_0 = px[r][0], x1_1 = px[r][1], x2_0 = px[r][2], x2_1 = px[r][3];
+      a[0][r] = x1_0 * x2_0; a[1][r] = x1_1 * x2_0; a[2][r] = x2_0;
+      a[3][r] = x1_0 * x2_1; a[4][r] = x1_1 * x2_1; a[5][r] = x2_1;
+      a[6][r] = x1_0; a[7][r] = x1_1; a[8][r] = 1;
+    }
+  } else if (FAM == FAM_F) {
+    // FundamentalMatrixEightPointEstimator::Estimate, fundamental_matrix.cc:150-171
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      double a0, a1, b0, b1;
+      apply_norm(n1[0], n1[1], n1[2], px[r][0], px[r][1], &a0, &a1);
+      apply_norm(n2[0], n2[1], n2[2], px[r][2], px[r][3], &b0, &b1);
+      const double h[3] = {a0, a1, 1.0};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        a[k][r] = h[k] * b0;
+        a[3 + k][r] = h[k] * b1;
+        a[6 + k][r] = h[k];
+      }
+    }
+  } else {
+    // HomographyMatrixEstimator::Estimate, homography_matrix.cc:44-82: row R < N from inlier R (x block), row
+    // R >= N from inlier R - N (y block).  The owner of a row of the second block is not the lane that holds the
+    // inlier's point, so the normalised points go through one rotation per slot pair.
+    double sn[PPL][4];  // normalised (s_0, s_1, d_0, d_1) of this lane's inliers
+#pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      apply_norm(n1[0], n1[1], n1[2], px[r][0], px[r][1], &sn[r][0], &sn[r][1]);
+      apply_norm(n2[0], n2[1], n2[2], px[r][2], px[r][3], &sn[r][2], &sn[r][3]);
+    }
+    const int N = ninl;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      if (64 * r < m) {  // uniform: the shuffles below need every lane
+        const int R = lane + 64 * r;
+        const bool valid = R < m;
+        const bool second = R >= N;
+        const int src = valid ? (second ? R - N : R) : 0;  // inlier index: lane src & 63, slot src >> 6
+        double v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          double got = 0.0;
+#pragma unroll
+          for (int sl = 0; sl < PPL; ++sl) {
+            const double w = __shfl(sn[sl][k], src & 63);
+            got = ((src >> 6) == sl) ? w : got;
+          }
+          v[k] = got;
+        }
+        const double s_0 = v[0], s_1 = v[1], d_0 = v[2], d_1 = v[3];
+        if (valid && !second) {
+          a[0][r] = -s_0; a[1][r] = -s_1; a[2][r] = -1;
+          a[6][r] = s_0 * d_0; a[7][r] = s_1 * d_0; a[8][r] = d_0;
+        } else if (valid) {
+          a[3][r] = -s_0; a[4][r] = -s_1; a[5][r] = -1;
+          a[6][r] = s_0 * d_1; a[7][r] = s_1 * d_1; a[8][r] = d_1;
+        }
+      }
+    }
+  }
+  // wv_svd_prepare_mx9, m > 9: scale = max |a_ij| (exact, order independent), pivoted QR, W = R, V = permutation
+  double mxl = 0.0;
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    if (lane + 64 * r < m) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        const double v = fabs(a[c][r]);
+        if (v > mxl) mxl = v;
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double other = __shfl_xor(mxl, o);
+    if (other > mxl) mxl = other;
+  }
+  double scale = mxl;
+  if (scale == 0.0) scale = 1.0;
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    if (lane + 64 * r < m) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) a[c][r] /= scale;
+    }
+  }
+  double hco[9];
+  int perm[9];
+  wr_colpiv_qr9<RPL>(a, m, lane, hco, perm);
+  (void)hco;
+  if (lane < 9) {
+    int pc = 0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      out[c * 9 + lane] = (lane <= c) ? a[c][0] : 0.0;  // W(i, j) = R(i, j) for i <= j
+      pc = (lane == c) ? perm[c] : pc;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out[81 + lane * 9 + i] = (i == pc) ? 1.0 : 0.0;  // V = the column permutation
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      out[162 + k] = n1[k];
+      out[165 + k] = n2[k];
+    }
+    out[168] = scale;
+    out[169] = 9.0;
+  }
+}
+
 // LO step 1, wave per queued pair: the local estimator's constraint matrix over the pair's inlier list and its
 // reduction to the square problem -- fam_local up to (not including) the Jacobi sweeps.
 template <int FAM>
@@ -2359,6 +2558,7 @@ __global__ __launch_bounds__(64, 4) void k_lo_prepare(const VerifyParams p) {
     const double* pts = (FAM == FAM_E ? p.pts_norm : p.pts_px) + 4 * moff;
     const int* inl = reinterpret_cast<const int*>(p.lo_inl + moff);
     const int ninl = (int)fs->lo_ninl;
+    if (p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl)) continue;  // k_lo_prepare_reg's
     double* out = p.lo_work + (size_t)pl * LO_WORK_DOUBLES;
     double n1[3] = {0, 0, 0}, n2[3] = {0, 0, 0};
     auto idx = [inl](int i) { return inl[i]; };
@@ -2544,16 +2744,19 @@ void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, hipS
   if (fam == FAM_F) hipLaunchKernelGGL(k_replay_lo<FAM_F>, dim3(n_blocks), dim3(64), smem, st, p);
   if (fam == FAM_H) hipLaunchKernelGGL(k_replay_lo<FAM_H>, dim3(n_blocks), dim3(64), smem, st, p);
 }
-void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st) {
+void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint32_t n_wave_prepare, uint32_t n_small_jacobi,
+                         hipStream_t st) {
   if (!p.n_work || !n_blocks) return;
   const uint32_t nb_prep = p.n_work < n_blocks ? p.n_work : n_blocks;  // one scratch area per workgroup (wg_scratch)
   const dim3 g4((p.n_work + 64 / LOJ_G - 1) / (64 / LOJ_G)), g64((p.n_work + 63) / 64);
   const bool reg_jacobi = getenv("DSM_LO_JACOBI_GROUPS") == nullptr;  // =1: the 8-lane-group kernel for every problem (round-2 form)
+  const bool reg_prepare = p.lo_reg_prepare && n_wave_prepare < p.n_work;
   if (fam == FAM_E) {
-    hipLaunchKernelGGL(k_lo_prepare<FAM_E>, dim3(nb_prep), dim3(64), 0, st, p);
+    if (reg_prepare) hipLaunchKernelGGL(k_lo_prepare_reg<FAM_E>, dim3(p.n_work), dim3(64), 0, st, p);
+    if (n_wave_prepare) hipLaunchKernelGGL(k_lo_prepare<FAM_E>, dim3(nb_prep), dim3(64), 0, st, p);
     if (reg_jacobi) {
       hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
-      hipLaunchKernelGGL((k_lo_jacobi<FAM_E, true>), g4, dim3(64), 0, st, p);
+      if (n_small_jacobi) hipLaunchKernelGGL((k_lo_jacobi<FAM_E, true>), g4, dim3(64), 0, st, p);
     } else {
       hipLaunchKernelGGL((k_lo_jacobi<FAM_E, false>), g4, dim3(64), 0, st, p);
     }
@@ -2562,10 +2765,11 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, hipS
     hipLaunchKernelGGL(k_lo_e_roots_models, g64, dim3(64), 0, st, p);
   }
   if (fam == FAM_F) {
-    hipLaunchKernelGGL(k_lo_prepare<FAM_F>, dim3(nb_prep), dim3(64), 0, st, p);
+    if (reg_prepare) hipLaunchKernelGGL(k_lo_prepare_reg<FAM_F>, dim3(p.n_work), dim3(64), 0, st, p);
+    if (n_wave_prepare) hipLaunchKernelGGL(k_lo_prepare<FAM_F>, dim3(nb_prep), dim3(64), 0, st, p);
     if (reg_jacobi) {
       hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
-      hipLaunchKernelGGL((k_lo_jacobi<FAM_F, true>), g4, dim3(64), 0, st, p);
+      if (n_small_jacobi) hipLaunchKernelGGL((k_lo_jacobi<FAM_F, true>), g4, dim3(64), 0, st, p);
     } else {
       hipLaunchKernelGGL((k_lo_jacobi<FAM_F, false>), g4, dim3(64), 0, st, p);
     }
@@ -2575,7 +2779,7 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, hipS
     hipLaunchKernelGGL(k_lo_prepare<FAM_H>, dim3(nb_prep), dim3(64), 0, st, p);
     if (reg_jacobi) {
       hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
-      hipLaunchKernelGGL((k_lo_jacobi<FAM_H, true>), g4, dim3(64), 0, st, p);
+      if (n_small_jacobi) hipLaunchKernelGGL((k_lo_jacobi<FAM_H, true>), g4, dim3(64), 0, st, p);
     } else {
       hipLaunchKernelGGL((k_lo_jacobi<FAM_H, false>), g4, dim3(64), 0, st, p);
     }

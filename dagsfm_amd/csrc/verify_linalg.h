@@ -1860,6 +1860,159 @@ DSM_DEV void grp_jacobi_sweeps(grp_vd W, grp_vd V, int dsz, double scale, grp_vd
   }
 }
 
+// ---------------------------------------------------------------------- tall matrix in registers, rows over the lanes
+// wv_colpiv_qr for a tall m x 9 matrix (9 < m <= 64 * RPL) whose rows live in REGISTERS: lane l owns rows l, l + 64,
+// ... (a[c][r] = element (l + 64 r, c)).  wv_colpiv_qr keeps the matrix in the workgroup's global scratch, so every
+// one of its ~60 dependent steps per problem is a memory round trip; here a step is register arithmetic plus the
+// reduction.  The reductions are wide_sum()'s (oracle/linalg.h): 64 interleaved partial sums over the SUB-vector that
+// starts at row r0, combined by the xor butterfly.  Partial b of that sum covers rows r0 + b + 64 j -- all owned by
+// lane (r0 + b) mod 64, in the owner's ascending order -- so the owner accumulates it and one lane rotation puts it
+// where the butterfly expects it.  Every lane ends with the same norms / pivots / reflector scalars (they are
+// computed redundantly from butterfly results), so nothing goes through LDS.
+DSM_DEV double wr_tree_finish(double acc, int r0, int lane) {
+  double s = __shfl(acc, (lane + r0) & 63);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  return s;
+}
+template <int RPL>
+DSM_DEV void wr_colpiv_qr9(double (&a)[9][RPL], int m, int lane, double (&hco)[9], int (&perm)[9]) {
+  double nu[9], nd[9];
+  {
+    double acc[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) acc[c] = 0.0;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      if (64 * r < m) {
+        if (lane + 64 * r < m) {
+#pragma unroll
+          for (int c = 0; c < 9; ++c) acc[c] += a[c][r] * a[c][r];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      nd[c] = sqrt(wr_tree_finish(acc[c], 0, lane));
+      nu[c] = nd[c];
+      perm[c] = c;
+    }
+  }
+  const double norm_downdate_threshold = sqrt(DBL_EPSILON);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    int biggest = k;
+    double mx = nu[k];
+#pragma unroll
+    for (int j = k + 1; j < 9; ++j) {
+      if (nu[j] > mx) {
+        mx = nu[j];
+        biggest = j;
+      }
+    }
+#pragma unroll
+    for (int j = k + 1; j < 9; ++j) {  // unconditional stores of selected values (see pr_jacobi_sweeps9)
+      const bool sw = (j == biggest);
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        const double x = a[k][r], y = a[j][r];
+        a[k][r] = sw ? y : x;
+        a[j][r] = sw ? x : y;
+      }
+      const double ua = nu[k], ub = nu[j];
+      nu[k] = sw ? ub : ua;
+      nu[j] = sw ? ua : ub;
+      const double da = nd[k], db = nd[j];
+      nd[k] = sw ? db : da;
+      nd[j] = sw ? da : db;
+      const int pa = perm[k], pb = perm[j];
+      perm[k] = sw ? pb : pa;
+      perm[j] = sw ? pa : pb;
+    }
+    // makeHouseholder on column k, rows k..m-1 (row k = lane k, slot 0)
+    const int r0 = k + 1;
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      const int R = lane + 64 * r;
+      if (64 * r < m && R >= r0 && R < m) acc += a[k][r] * a[k][r];
+    }
+    const double tail_sq = wr_tree_finish(acc, r0, lane);
+    const double c0 = wv_readlane_f64(a[k][0], k);  // row k = lane k, slot 0
+    double tau, beta, den = 0.0;
+    bool zero_tail;
+    if (tail_sq <= DBL_MIN) {
+      tau = 0.0;
+      beta = c0;
+      zero_tail = true;
+    } else {
+      double b = sqrt(c0 * c0 + tail_sq);
+      if (c0 >= 0.0) b = -b;
+      tau = (b - c0) / b;
+      beta = b;
+      den = c0 - b;
+      zero_tail = false;
+    }
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      const int R = lane + 64 * r;
+      if (64 * r < m && R >= r0 && R < m) a[k][r] = zero_tail ? 0.0 : a[k][r] / den;
+    }
+    if (lane == k) a[k][0] = beta;
+    hco[k] = tau;
+    if (k < 8) {
+      if (tau != 0.0) {  // m - k >= 2 rows: never the single-row form
+        double t[8];
+#pragma unroll
+        for (int c = 0; c < 8 - k; ++c) {
+          double ac = 0.0;
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) {
+            const int R = lane + 64 * r;
+            if (64 * r < m && R >= r0 && R < m) ac += a[k][r] * a[k + 1 + c][r];
+          }
+          t[c] = wr_tree_finish(ac, r0, lane) + wv_readlane_f64(a[k + 1 + c][0], k);
+        }
+#pragma unroll
+        for (int c = 0; c < 8 - k; ++c) {
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) {
+            const int R = lane + 64 * r;
+            if (64 * r < m && R < m) {
+              if (R == k)
+                a[k + 1 + c][r] -= tau * t[c];
+              else if (R > k)
+                a[k + 1 + c][r] -= tau * a[k][r] * t[c];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 8 - k; ++c) {  // norm downdating (every lane the same values)
+        const int j = k + 1 + c;
+        if (nu[j] != 0.0) {
+          double temp = fabs(wv_readlane_f64(a[j][0], k)) / nu[j];
+          temp = (1.0 + temp) * (1.0 - temp);
+          temp = temp < 0.0 ? 0.0 : temp;
+          const double ratio = nu[j] / nd[j];
+          const double temp2 = temp * (ratio * ratio);
+          if (temp2 <= norm_downdate_threshold) {
+            double ac = 0.0;
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+              const int R = lane + 64 * r;
+              if (64 * r < m && R >= r0 && R < m) ac += a[j][r] * a[j][r];
+            }
+            nd[j] = sqrt(wr_tree_finish(ac, r0, lane));
+            nu[j] = nd[j];
+          } else {
+            nu[j] *= sqrt(temp);
+          }
+        }
+      }
+    }
+  }
+}
+
 // The sweeps of grp_jacobi_sweeps for a full 9 x 9 problem by ONE lane with W and V in registers: the (p, q) order is
 // static, so all 36 rotations of a sweep are unrolled with compile-time indices; a lane whose off-diagonal pair is
 // already below the threshold skips its rotation by predicate, a lane that has converged leaves the sweep loop.
