@@ -622,6 +622,7 @@ struct VerifyPlan {
   uint32_t begin[DSM_VERIFY_MAX_LANES] = {0}, end[DSM_VERIFY_MAX_LANES] = {0}, chunk[DSM_VERIFY_MAX_LANES] = {0};  // per lane
   int dev_cus = 256;
   bool inline_lo = false;
+  uint32_t lo_tail = 0;  // queue length at and below which the batched schedule finishes a round inline
 };
 
 #define LANECHK(L, call)                                              \
@@ -693,7 +694,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
             LANECHK(L, hipMemsetAsync(actr + 88, 0, 8, st));  // [22], [23]: queued problems for the general LO kernels
             vp.lo_queue = queues + (size_t)cur * chunk;
             vp.lo_count = cnt_dev;
-            launch_vp_replay_lo(vp, f, nb_heavy, st);
+            launch_vp_replay_lo(vp, f, nb_heavy, false, st);
             LANECHK(L, hipGetLastError());
             uint32_t* host_ctr = L.host_ctr;
             LANECHK(L, hipMemcpyAsync(host_ctr, actr, 128, hipMemcpyDeviceToHost, st));
@@ -704,6 +705,16 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
             L.lo_iters[f]++;
             vp.worklist = vp.lo_queue;
             vp.n_work = nq;
+            if (nq <= plan.lo_tail) {
+              // the last few suspended pairs finish the round with their local optimisations inline (k_replay_lo<TAIL>)
+              LANECHK(L, hipMemsetAsync(actr + 64, 0, 4, st));  // work counter [16]
+              launch_vp_replay_lo(vp, f, std::min<uint32_t>(nb_heavy, nq), true, st);
+              LANECHK(L, hipGetLastError());
+              LANECHK(L, hipMemcpyAsync(host_ctr, actr, 4, hipMemcpyDeviceToHost, st));
+              LANECHK(L, hipStreamSynchronize(st));
+              active = host_ctr[0];
+              break;
+            }
             LANECHK(L, hipMemsetAsync(actr + 76, 0, 4, st));  // k_lo_prepare's work counter [19]
             launch_vp_local_opt(vp, f, nb_heavy, host_ctr[22], host_ctr[23], st);
             LANECHK(L, hipGetLastError());
@@ -873,6 +884,8 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     // DSM_VERIFY_INLINE_LO=1 / =0 forces one or the other (tests cover both).
     plan.inline_lo = n_pairs < 24576u;
     if (const char* e = getenv("DSM_VERIFY_INLINE_LO")) plan.inline_lo = atoi(e) != 0;
+    plan.lo_tail = 2048;  // measured: 0 / 128 / 512 / 2048 / 8192 -> 415 / 412 / 412 / 408 / 411 ms at config 2, 74.8 / 72.7 / 70.5 / 69.5 / 75.3 ms on its 1/8 shard
+    if (const char* e = getenv("DSM_LO_TAIL")) plan.lo_tail = (uint32_t)std::max(0, atoi(e));
     HIPCHK(ctx, ctx->d_fam_state.reserve(std::max<size_t>(n_pairs, 1) * 3 * sizeof(FamState)));
     HIPCHK(ctx, ctx->d_sidx.reserve(tm * 4));
     HIPCHK(ctx, ctx->d_lo_inl.reserve(tm * 4));

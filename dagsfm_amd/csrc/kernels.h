@@ -162,7 +162,7 @@ void launch_vp_sample(const VerifyParams& p, int fam, uint32_t n_blocks, hipStre
 void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st);
 void launch_vp_replay(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st);
 void launch_vp_final(const VerifyParams& p, uint32_t n_blocks, hipStream_t st);
-void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st);
+void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, bool tail, hipStream_t st);
 // over p.worklist / p.n_work; n_wave_prepare / n_small_jacobi: how many of the queued problems need the general kernels
 // (k_lo_prepare: not register-preparable; k_lo_jacobi: smaller than 9 x 9), counted by k_replay_lo at [22] / [23]
 void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint32_t n_wave_prepare, uint32_t n_small_jacobi, hipStream_t st);

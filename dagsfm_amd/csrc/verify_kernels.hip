@@ -2145,7 +2145,11 @@ __host__ __device__ inline bool lo_prepare_in_registers(int ninl) {
 // sweeps and the 8-point / DLT finish; the essential family re-uses the flat 5-point kernels, lane per problem);
 // the next k_replay_lo launch (work list = that queue) scores the returned models and scans on.  Same operations
 // in the same order as k_replay, which stays as the reference schedule (DSM_VERIFY_INLINE_LO=1).
-template <int FAM>
+// TAIL: the same replay for the last few queued pairs of a round, with every local optimisation -- the pending one the
+// pair was suspended at, and all later ones -- run inline by the wave (fam_local, as in k_replay): once the queue is
+// short, a batched iteration costs its full chain of launches for a handful of problems, and the wave-wide solve's
+// latency is the smaller price.  Never suspends.
+template <int FAM, bool TAIL>
 __global__ __launch_bounds__(64, 4) void k_replay_lo(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   VSmem* sm = reinterpret_cast<VSmem*>(smem_raw);
@@ -2205,8 +2209,15 @@ __global__ __launch_bounds__(64, 4) void k_replay_lo(const VerifyParams p) {
     bool in_trial = false;  // resume inside trial t at model m_start
     if (fs->lo_wait) {
       // the local optimisation of (trial t, model m_start - 1) has returned: loransac.h:160-178
-      const int nlo = (int)fs->lo_nm;
-      const double* lom = p.lo_models + (size_t)pl * 90;
+      int nlo;
+      const double* lom;
+      if constexpr (TAIL) {
+        nlo = fam_local<FAM>(w, (int)fs->lo_ninl);  // the inlier list is still in lo_inl
+        lom = sm->lo_models;
+      } else {
+        nlo = (int)fs->lo_nm;
+        lom = p.lo_models + (size_t)pl * 90;
+      }
       for (int l = 0; l < nlo; ++l) {
         num_models += 1;
         double M[9];
@@ -2261,17 +2272,33 @@ __global__ __launch_bounds__(64, 4) void k_replay_lo(const VerifyParams p) {
                 wv_sync();
               }
               const int ninl = compact_inliers(w, max_residual);  // -> lo_inl
-              if (lane == 0) {
-                fs->t_pos = (uint32_t)t;
-                fs->m_pos = (uint32_t)(m + 1);
-                fs->lo_wait = 1;
-                fs->lo_ninl = (uint32_t)ninl;
-                p.lo_queue[atomicAdd(p.lo_count, 1u)] = pl;
-                if (!(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) atomicAdd(p.active_count + 22, 1u);
-                if ((FAM == FAM_H ? 2 * ninl : ninl) < 9) atomicAdd(p.active_count + 23, 1u);
+              if constexpr (TAIL) {
+                const int nlo = fam_local<FAM>(w, ninl);
+                for (int l = 0; l < nlo; ++l) {
+                  num_models += 1;
+                  double ML[9];
+                  for (int k = 0; k < 9; ++k) ML[k] = sm->lo_models[l * 9 + k];
+                  uint32_t lc;
+                  const double lsum = score_and_sum<FAM>(w, ML, max_residual, &lc);
+                  if (lc > best_n || (lc == best_n && lsum < best_sum)) {
+                    best_n = lc;
+                    best_sum = lsum;
+                    for (int k = 0; k < 9; ++k) best_model[k] = ML[k];
+                  }
+                }
+              } else {
+                if (lane == 0) {
+                  fs->t_pos = (uint32_t)t;
+                  fs->m_pos = (uint32_t)(m + 1);
+                  fs->lo_wait = 1;
+                  fs->lo_ninl = (uint32_t)ninl;
+                  p.lo_queue[atomicAdd(p.lo_count, 1u)] = pl;
+                  if (!(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) atomicAdd(p.active_count + 22, 1u);
+                  if ((FAM == FAM_H ? 2 * ninl : ninl) < 9) atomicAdd(p.active_count + 23, 1u);
+                }
+                suspended = true;
+                break;
               }
-              suspended = true;
-              break;
             }
             dyn_max = w.nt_table[best_n];
           }
@@ -2737,12 +2764,18 @@ __global__ __launch_bounds__(64) void k_lo_e_roots_models(const VerifyParams p) 
   p.fam_state[(size_t)pi * 3 + FAM_E].lo_nm = (uint32_t)nm;
 }
 
-void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st) {
+void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, bool tail, hipStream_t st) {
   if (!p.n_work || !n_blocks) return;
   const size_t smem = ((offsetof(VSmem, gen) + 15) / 16) * 16;
-  if (fam == FAM_E) hipLaunchKernelGGL(k_replay_lo<FAM_E>, dim3(n_blocks), dim3(64), smem, st, p);
-  if (fam == FAM_F) hipLaunchKernelGGL(k_replay_lo<FAM_F>, dim3(n_blocks), dim3(64), smem, st, p);
-  if (fam == FAM_H) hipLaunchKernelGGL(k_replay_lo<FAM_H>, dim3(n_blocks), dim3(64), smem, st, p);
+  if (tail) {
+    if (fam == FAM_E) hipLaunchKernelGGL((k_replay_lo<FAM_E, true>), dim3(n_blocks), dim3(64), smem, st, p);
+    if (fam == FAM_F) hipLaunchKernelGGL((k_replay_lo<FAM_F, true>), dim3(n_blocks), dim3(64), smem, st, p);
+    if (fam == FAM_H) hipLaunchKernelGGL((k_replay_lo<FAM_H, true>), dim3(n_blocks), dim3(64), smem, st, p);
+  } else {
+    if (fam == FAM_E) hipLaunchKernelGGL((k_replay_lo<FAM_E, false>), dim3(n_blocks), dim3(64), smem, st, p);
+    if (fam == FAM_F) hipLaunchKernelGGL((k_replay_lo<FAM_F, false>), dim3(n_blocks), dim3(64), smem, st, p);
+    if (fam == FAM_H) hipLaunchKernelGGL((k_replay_lo<FAM_H, false>), dim3(n_blocks), dim3(64), smem, st, p);
+  }
 }
 void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint32_t n_wave_prepare, uint32_t n_small_jacobi,
                          hipStream_t st) {

@@ -111,7 +111,8 @@ def test_watermark_configuration(dsm, oracle):
 @pytest.mark.parametrize("prior,sampler_serial,legacy", [(0, False, False), (1, False, False), (1, True, False), (1, False, True),
                                                          (1, False, "inline_lo"), (0, False, "inline_lo"), (1, False, "chunks"),
                                                          (1, False, "batched_lo"), (0, False, "batched_lo"),
-                                                         (1, False, "lanes"), (0, False, "lanes_inline")])
+                                                         (1, False, "lanes"), (0, False, "lanes_inline"),
+                                                         (1, False, "batched_tail"), (0, False, "batched_tail")])
 def test_stage_match_and_verify_many_pairs(dsm, oracle, prior, sampler_serial, legacy, monkeypatch):
     """dsm_match_pairs + dsm_verify_pairs over an exhaustive pair list == oracle matcher + oracle verifier
     with SiftFeatureMatcher::Match's post-filter (matching.cc:824-831).  sampler_serial forces the sampler's
@@ -119,6 +120,9 @@ def test_stage_match_and_verify_many_pairs(dsm, oracle, prior, sampler_serial, l
     schedule (DSM_VERIFY_LEGACY)."""
     if sampler_serial:
         monkeypatch.setenv("DSM_SAMPLER_SERIAL", "1")
+    # DSM_LO_TAIL: queue length at which the batched schedule finishes a round inline (default 2 048 = always on lists
+    # this short); 0 keeps every local optimisation in the batched kernels, "batched_tail" mixes the two
+    monkeypatch.setenv("DSM_LO_TAIL", "6" if legacy == "batched_tail" else "0")
     if legacy == "chunks":  # several chunks of the pair list (one chunk is the rule on a 288 GB device)
         monkeypatch.setenv("DSM_VERIFY_CHUNK_PAIRS", "5")
         monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "0")
@@ -126,7 +130,7 @@ def test_stage_match_and_verify_many_pairs(dsm, oracle, prior, sampler_serial, l
         monkeypatch.setenv("DSM_VERIFY_LANES", "3")
         monkeypatch.setenv("DSM_VERIFY_CHUNK_PAIRS", "4")
         monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "0" if legacy == "lanes" else "1")
-    elif legacy == "batched_lo":  # the schedule long pair lists get (short ones default to the inline form)
+    elif legacy in ("batched_lo", "batched_tail"):  # the schedule long pair lists get (short ones default to the inline form)
         monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "0")
     elif legacy == "inline_lo":  # phase-split pipeline with the local optimisation inline in the replay (round-1 schedule)
         monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "1")
@@ -164,8 +168,14 @@ def test_stage_match_and_verify_many_pairs(dsm, oracle, prior, sampler_serial, l
     assert dsm.verify_kernel_time() > 0
 
 
-def test_radial_camera_and_small_lo_systems(dsm, oracle):
-    """SIMPLE_RADIAL cameras (iterative undistortion) and tiny inlier sets (6..9-row LO systems)."""
+@pytest.mark.parametrize("schedule", ["default", "batched"])
+def test_radial_camera_and_small_lo_systems(dsm, oracle, schedule, monkeypatch):
+    """SIMPLE_RADIAL cameras (iterative undistortion) and tiny inlier sets (6..9-row LO systems).  "batched": the
+    local optimisations through the batched kernels, where such a system is one of the few that the general kernels
+    (k_lo_prepare, k_lo_jacobi) still serve next to the register-resident ones."""
+    if schedule == "batched":
+        monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "0")
+        monkeypatch.setenv("DSM_LO_TAIL", "0")
     scene = synthetic.Scene(3, 512, seed=8)
     cam = capi.Camera(model_id=2, has_prior_focal_length=1, width=1000, height=750)
     cam.params[0], cam.params[1], cam.params[2], cam.params[3] = 800.0, 500.0, 375.0, 0.05
