@@ -803,6 +803,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.nmodels = nullptr;
   vp.counts = nullptr;
   vp.sums = nullptr;
+  vp.first_batch[0] = vp.first_batch[1] = vp.first_batch[2] = 0;
   vp.lo_reg_prepare = getenv("DSM_LO_PREPARE_WAVE") ? 0 : 1;  // =1: the round-2 kernel (matrix in global scratch) for every problem
   vp.models = nullptr;
   vp.e_work = nullptr;
@@ -828,15 +829,21 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   } else {
     // phase-split pipeline: per family, rounds of sample -> solve+score -> replay until no pair is active
     VerifyPlan plan;
-    uint64_t bm_max = 0;
     for (int f = 0; f < 3; ++f) {
       plan.batch[f] = vp_batch(f, vp.max_trials[f], (uint32_t)std::min<uint64_t>(o->min_num_trials, 0xffffffffull));
-      plan.bmax = std::max(plan.bmax, plan.batch[f]);
-      bm_max = std::max<uint64_t>(bm_max, (uint64_t)plan.batch[f] * vp_maxm(f));
+      vp.first_batch[f] = plan.batch[f];
     }
-    plan.bm_max = bm_max;
-    const uint64_t per_pair = (uint64_t)plan.bmax * (7 * 4 + 4 + 4) + bm_max * (4 + 8 + 72) + (uint64_t)plan.batch[0] * 200 * 8 +
-                              (LO_WORK_DOUBLES + 90 + 90 + 200) * 8 + 8;
+    auto per_pair_bytes = [&](const uint32_t* b, uint32_t* bmax_out, uint64_t* bm_out) {
+      uint32_t bmax = 0;
+      uint64_t bm = 0;
+      for (int f = 0; f < 3; ++f) {
+        bmax = std::max(bmax, b[f]);
+        bm = std::max<uint64_t>(bm, (uint64_t)b[f] * vp_maxm(f));
+      }
+      if (bmax_out) *bmax_out = bmax;
+      if (bm_out) *bm_out = bm;
+      return (uint64_t)bmax * (7 * 4 + 4 + 4) + bm * (4 + 8 + 72) + (uint64_t)b[0] * 200 * 8 + (LO_WORK_DOUBLES + 90 + 90 + 200) * 8 + 8;
+    };
     // Lanes: the pair list is dealt out in chunks to up to DSM_VERIFY_MAX_LANES lanes that run concurrently (own
     // stream, own host thread, own scratch; see VerifyLane).  A pair's three families cannot overlap -- F starts from
     // the generator state E ends with -- but different pairs can, and the replay / local-optimisation launches of
@@ -859,6 +866,28 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
         budget = std::min<uint64_t>(96ull << 30, std::max<uint64_t>(4ull << 30, (uint64_t)((free_b + have) * 0.4)));
       }
     }
+    // Round buffers: a pair's FIRST round speculates first_batch trials (sized for the easy regime: E / F stop after
+    // ~60 / ~150 trials at a 64 % inlier ratio), every later round what its dynamic stop still asks for.  At a 25 %
+    // ratio that is thousands of trials (E 5 400, F 10 000: measured), i.e. a hundred rounds of 64 -- so the buffers
+    // grow (E up to 512, F up to 1 024 trials per round) as long as the whole list still fits a quarter of the budget.
+    if (!getenv("DSM_VERIFY_FIXED_BATCH")) {
+      for (bool grew = true; grew;) {
+        grew = false;
+        for (int f = 1; f >= 0; --f) {
+          const uint32_t cap = f == 0 ? 512u : 1024u;
+          if (plan.batch[f] * 2 > cap) continue;
+          uint32_t trial[3] = {plan.batch[0], plan.batch[1], plan.batch[2]};
+          trial[f] *= 2;
+          if (per_pair_bytes(trial, nullptr, nullptr) * (uint64_t)n_pairs <= budget / 4) {
+            plan.batch[f] = trial[f];
+            grew = true;
+          }
+        }
+      }
+    }
+    uint64_t bm_max = 0;
+    const uint64_t per_pair = per_pair_bytes(plan.batch, &plan.bmax, &bm_max);
+    plan.bm_max = bm_max;
     // Equal shares (measured: giving the first lane 0.6 - 0.8 of the list to push the lanes out of phase is 1 - 2 %
     // slower than 0.5; three lanes are slower than two).  DSM_VERIFY_LANE_SPLIT = share of the first lane.
     double first_share = 1.0 / n_lanes;

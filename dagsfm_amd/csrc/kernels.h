@@ -109,6 +109,7 @@ struct VerifyParams {
   const uint64_t* nt_off;      // [n_max+1]: offset of the E/F/H tables (3 x (N+1)) for N matches
   const uint64_t* nt_off_t;    // [n_max+1]: offset of the translation table (N+1) for N inliers
   uint32_t max_trials[4];      // RANSAC ctor's max_num_trials per family (E, F, H, T)
+  uint32_t first_batch[3];     // trials speculated in a pair's first round (<= batch; later rounds draw what the dynamic stop asks for, up to batch)
   dsm_two_view_geometry* tvg;  // [n_pairs]
   uint32_t* inlier_matches;    // [total][2], pair p at match_off[p]
   uint32_t* inl_counts;        // [n_pairs]

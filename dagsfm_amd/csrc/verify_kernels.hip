@@ -1536,8 +1536,9 @@ __global__ __launch_bounds__(64) void k_sample(const VerifyParams p) {
     // min_num_trials) that yields a model (loransac.h:190-194), and dyn_max_num_trials never grows (the best inlier
     // count never shrinks).  After the first round, draw just that many trials plus a margin for samples without a
     // model; if the margin was too small the pair simply stays active for another round.
-    uint32_t want = p.batch;
+    uint32_t want = p.first_batch[FAM] < p.batch ? p.first_batch[FAM] : p.batch;
     if (fs->rounds > 0) {
+      want = p.batch;
       const uint32_t mt = (uint32_t)p.opt.min_num_trials;
       const uint32_t thr = fs->dyn_max > mt ? fs->dyn_max : mt;
       const uint32_t T0 = fs->rep.num_trials;
