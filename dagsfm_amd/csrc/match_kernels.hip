@@ -336,39 +336,55 @@ __global__ __launch_bounds__(256) void k1_resolve_index(const K1Params p) {
     const int t = in_range ? out[lane] : -1;
     const uint32_t my_row = GATHER ? (in_range ? ent[row_w + lane].y : 0u) : (uint32_t)lane;  // row inside the image (relative to arow)
     unsigned long long mask = __ballot(t >= 0);
+    // four flagged rows per trip: their loads (row descriptor, 4 KB tile, column terms) are issued together, so a trip
+    // pays one memory round trip instead of four (a wave resolves ~100 rows one after the other)
+    constexpr int RU = 4;
     while (mask) {
-      const int r = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      const int tile = __builtin_amdgcn_readlane(t, r);
-      const uint32_t rr = GATHER ? (uint32_t)__builtin_amdgcn_readlane((int)my_row, r) : (uint32_t)r;
+      int rr_l[RU], r_l[RU], tile_l[RU];
+      bool on[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        on[u] = mask != 0ull;
+        const int r = on[u] ? (__ffsll((long long)mask) - 1) : 0;
+        if (on[u]) mask &= mask - 1;
+        r_l[u] = r;
+        tile_l[u] = on[u] ? __builtin_amdgcn_readlane(t, r) : 0;
+        rr_l[u] = GATHER ? __builtin_amdgcn_readlane((int)my_row, r) : r;
+      }
       // the tile's 32 columns are 4 KB of contiguous memory: four fully coalesced 1-KB loads, lane =
       // (column i*8 + (lane>>3), 16-byte chunk lane&7) -- eight lanes share one dot product
-      const v4i x = *reinterpret_cast<const v4i*>(arow + (size_t)rr * 128 + (lane & 7) * 16);
-      const int8_t* tbase = bimg + (size_t)tile * 4096 + lane * 16;
-      const int32_t* tterm = rt_b + tile * 32 + (lane >> 3);
-      v4i y[4];
-      int ct[4];
+      v4i x[RU], y[RU][4];
+      int ct[RU][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        y[i] = *reinterpret_cast<const v4i*>(tbase + i * 1024);
-        ct[i] = tterm[i * 8];
+      for (int u = 0; u < RU; ++u) {
+        x[u] = *reinterpret_cast<const v4i*>(arow + (size_t)(uint32_t)rr_l[u] * 128 + (lane & 7) * 16);
+        const int8_t* tbase = bimg + (size_t)tile_l[u] * 4096 + lane * 16;
+        const int32_t* tterm = rt_b + tile_l[u] * 32 + (lane >> 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          y[u][i] = *reinterpret_cast<const v4i*>(tbase + i * 1024);
+          ct[u][i] = tterm[i * 8];
+        }
       }
-      int key = INT32_MIN;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int acc = 0;
+      for (int u = 0; u < RU; ++u) {
+        int key = INT32_MIN;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_sdot4(x[e], y[i][e], acc, false);
-        acc += __shfl_xor(acc, 1);
-        acc += __shfl_xor(acc, 2);
-        acc += __shfl_xor(acc, 4);
-        const int col = i * 8 + (lane >> 3);
-        key = max(key, (int)((uint32_t)(acc + ct[i]) << 5) | (31 - col));  // |S + rterm(j)| <= 2^22
+        for (int i = 0; i < 4; ++i) {
+          int acc = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_sdot4(x[u][e], y[u][i][e], acc, false);
+          acc += __shfl_xor(acc, 1);
+          acc += __shfl_xor(acc, 2);
+          acc += __shfl_xor(acc, 4);
+          const int col = i * 8 + (lane >> 3);
+          key = max(key, (int)((uint32_t)(acc + ct[u][i]) << 5) | (31 - col));  // |S + rterm(j)| <= 2^22
+        }
+        key = max(key, __shfl_xor(key, 8));
+        key = max(key, __shfl_xor(key, 16));
+        key = max(key, __shfl_xor(key, 32));
+        if (lane == 0 && on[u]) out[r_l[u]] = tile_l[u] * 32 + (31 - (key & 31));
       }
-      key = max(key, __shfl_xor(key, 8));
-      key = max(key, __shfl_xor(key, 16));
-      key = max(key, __shfl_xor(key, 32));
-      if (lane == 0) out[r] = tile * 32 + (31 - (key & 31));
     }
   }
 }
