@@ -705,7 +705,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
             L.lo_iters[f]++;
             vp.worklist = vp.lo_queue;
             vp.n_work = nq;
-            if (nq <= plan.lo_tail) {
+            if (nq <= plan.lo_tail && f != 0) {  // not for E: its inline solver does not fit the registers (k_replay_lo<TAIL> note)
               // the last few suspended pairs finish the round with their local optimisations inline (k_replay_lo<TAIL>)
               LANECHK(L, hipMemsetAsync(actr + 64, 0, 4, st));  // work counter [16]
               launch_vp_replay_lo(vp, f, std::min<uint32_t>(nb_heavy, nq), true, st);

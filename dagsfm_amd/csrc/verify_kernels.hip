@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_ransac(const Ver
   }
 }
 
-__global__ __launch_bounds__(64, 2) void k_verify_final(const VerifyParams p) {
+__global__ __launch_bounds__(64, 1) void k_verify_final(const VerifyParams p) {  // 512 VGPRs: no register spills next to its SGPR spills (see k_replay_lo<TAIL>)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   VSmem* sm = reinterpret_cast<VSmem*>(smem_raw);
   uint32_t* sidx = reinterpret_cast<uint32_t*>(smem_raw + ((sizeof(VSmem) + 15) / 16) * 16);
@@ -1951,7 +1951,7 @@ DSM_DEV int replay_next_event(int t, int nb, const int32_t* nmod, const int32_t*
 }
 
 template <int FAM>
-__global__ __launch_bounds__(64, 4) void k_replay(const VerifyParams p) {
+__global__ __launch_bounds__(64, (FAM == FAM_E ? 1 : 2)) void k_replay(const VerifyParams p) {  // no VGPR spills: see k_replay_lo<TAIL>
   uint32_t* p_dbg = p.active_count + 8;
   (void)p_dbg;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -2150,8 +2150,11 @@ __host__ __device__ inline bool lo_prepare_in_registers(int ninl) {
 // pair was suspended at, and all later ones -- run inline by the wave (fam_local, as in k_replay): once the queue is
 // short, a batched iteration costs its full chain of launches for a handful of problems, and the wave-wide solve's
 // latency is the smaller price.  Never suspends.
+// (TAIL at one wave per SIMD: at four, 128 VGPRs, the inlined local optimisation spills 127 - 717 VGPRs and 66 - 102 SGPRs,
+// and hipcc 7.2 then corrupts an SGPR tuple spilled through VGPR lanes -- the uniform best_model[4..7] of the H family
+// came back wrong on 34 of 124 750 pairs; with 512 VGPRs nothing is spilled to memory.  The tail is latency-bound anyway.)
 template <int FAM, bool TAIL>
-__global__ __launch_bounds__(64, 4) void k_replay_lo(const VerifyParams p) {
+__global__ __launch_bounds__(64, (TAIL ? 1 : 4)) void k_replay_lo(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   VSmem* sm = reinterpret_cast<VSmem*>(smem_raw);
   typedef Fam<FAM> F;
@@ -2211,18 +2214,20 @@ __global__ __launch_bounds__(64, 4) void k_replay_lo(const VerifyParams p) {
     if (fs->lo_wait) {
       // the local optimisation of (trial t, model m_start - 1) has returned: loransac.h:160-178
       int nlo;
-      const double* lom;
-      if constexpr (TAIL) {
-        nlo = fam_local<FAM>(w, (int)fs->lo_ninl);  // the inlier list is still in lo_inl
-        lom = sm->lo_models;
-      } else {
+      if constexpr (TAIL)
+        nlo = fam_local<FAM>(w, (int)fs->lo_ninl);  // the inlier list is still in lo_inl; models -> sm->lo_models
+      else
         nlo = (int)fs->lo_nm;
-        lom = p.lo_models + (size_t)pl * 90;
-      }
+      const double* glom = p.lo_models + (size_t)pl * 90;
       for (int l = 0; l < nlo; ++l) {
         num_models += 1;
         double M[9];
-        for (int k = 0; k < 9; ++k) M[k] = lom[l * 9 + k];
+        for (int k = 0; k < 9; ++k) {
+          if constexpr (TAIL)
+            M[k] = sm->lo_models[l * 9 + k];
+          else
+            M[k] = glom[l * 9 + k];
+        }
         uint32_t lc;
         const double lsum = score_and_sum<FAM>(w, M, max_residual, &lc);
         if (lc > best_n || (lc == best_n && lsum < best_sum)) {
@@ -2768,8 +2773,7 @@ __global__ __launch_bounds__(64) void k_lo_e_roots_models(const VerifyParams p) 
 void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, bool tail, hipStream_t st) {
   if (!p.n_work || !n_blocks) return;
   const size_t smem = ((offsetof(VSmem, gen) + 15) / 16) * 16;
-  if (tail) {
-    if (fam == FAM_E) hipLaunchKernelGGL((k_replay_lo<FAM_E, true>), dim3(n_blocks), dim3(64), smem, st, p);
+  if (tail) {  // F and H only: the E instance would still spill 134 VGPRs at 512 (its 16-lane 5-point finish is inlined)
     if (fam == FAM_F) hipLaunchKernelGGL((k_replay_lo<FAM_F, true>), dim3(n_blocks), dim3(64), smem, st, p);
     if (fam == FAM_H) hipLaunchKernelGGL((k_replay_lo<FAM_H, true>), dim3(n_blocks), dim3(64), smem, st, p);
   } else {

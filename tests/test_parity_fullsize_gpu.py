@@ -17,14 +17,16 @@ from tests.test_verify_gpu import tvg_equal
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["batched_lo", "batched_tail", "inline_lo"])
+@pytest.fixture(autouse=True, params=["batched_lo", "batched_tail", "batched_tail_all", "inline_lo"])
 def lo_schedule(request, monkeypatch):
     """The schedules of the local optimisation: the batched kernels that long pair lists (bench.py) run -- pure
     (DSM_LO_TAIL=0: every queued pair goes through k_lo_prepare* / k_lo_jacobi*) and with the inline tail (a queue of
     <= 4 pairs finishes its round in k_replay_lo<TAIL>; the default of 512 would swallow these short lists whole) --
     and the inline form that the library picks by itself for lists as short as these tests'."""
     monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "1" if request.param == "inline_lo" else "0")
-    monkeypatch.setenv("DSM_LO_TAIL", "4" if request.param == "batched_tail" else "0")
+    # batched_tail_all: every pair goes to the inline finish right after its first suspension (the configuration that
+    # exposed a register-spill miscompile of k_replay_lo<TAIL> in round 2: tools/bisect_schedules.py)
+    monkeypatch.setenv("DSM_LO_TAIL", {"batched_tail": "4", "batched_tail_all": "100000"}.get(request.param, "0"))
     return request.param
 
 
