@@ -907,11 +907,12 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     plan.n_lanes = n_lanes;
     plan.dev_cus = dev_cus;
     // Local optimisation: batched kernels (k_replay_lo + k_lo_*) or inline in the replay (k_replay).  The batched form
-    // wins on throughput (config 2, 124 750 pairs: 408 vs 513 ms) but every LO iteration costs a kernel round trip; it
-    // hands the last <= lo_tail queued pairs of a round to an inline finish, which makes it the faster one down to
-    // ~10 000 pairs (15 593 pairs: 69 vs 75 ms; 14 365: 64 vs 70; 7 140: 42 vs 40; 1 225: 11.8 vs 11.5).
+    // wins on throughput (config 2, 124 750 pairs: 416 vs 702 ms) but every LO iteration costs a kernel round trip; it
+    // hands the last <= lo_tail queued pairs of a round (F, H) to an inline finish, which keeps it ahead or level down
+    // to ~1 000 pairs (7 140 pairs: 42 vs 50 ms; 4 950: 34.5 vs 36.4; 1 225: 9.5 vs 9.3).  The inline form remains for
+    // lists shorter than lo_tail, where the batched one would only add a launch.
     // DSM_VERIFY_INLINE_LO=1 / =0 forces one or the other (tests cover both).
-    plan.inline_lo = n_pairs < 8192u;
+    plan.inline_lo = n_pairs < 2048u;
     if (const char* e = getenv("DSM_VERIFY_INLINE_LO")) plan.inline_lo = atoi(e) != 0;
     plan.lo_tail = 2048;  // measured: 0 / 128 / 512 / 2048 / 8192 -> 415 / 412 / 412 / 408 / 411 ms at config 2, 74.8 / 72.7 / 70.5 / 69.5 / 75.3 ms on its 1/8 shard
     if (const char* e = getenv("DSM_LO_TAIL")) plan.lo_tail = (uint32_t)std::max(0, atoi(e));

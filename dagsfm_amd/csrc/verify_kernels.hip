@@ -2573,7 +2573,7 @@ __global__ __launch_bounds__(64) void k_lo_prepare_reg(const VerifyParams p) {
 // LO step 1, wave per queued pair: the local estimator's constraint matrix over the pair's inlier list and its
 // reduction to the square problem -- fam_local up to (not including) the Jacobi sweeps.
 template <int FAM>
-__global__ __launch_bounds__(64, 4) void k_lo_prepare(const VerifyParams p) {
+__global__ __launch_bounds__(64, 2) void k_lo_prepare(const VerifyParams p) {  // two waves per SIMD: no register spills (see k_replay_lo<TAIL>)
   __shared__ WvSvdShared svd;
   const int lane = threadIdx.x;
   const WgScratch ws = wg_scratch(p);
