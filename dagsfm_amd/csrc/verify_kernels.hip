@@ -1053,7 +1053,13 @@ __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_ransac(const Ver
   }
 }
 
-__global__ __launch_bounds__(64, 1) void k_verify_final(const VerifyParams p) {  // 512 VGPRs: no register spills next to its SGPR spills (see k_replay_lo<TAIL>)
+// WAVES = waves per SIMD the register allocation aims at.  2 (256 VGPRs): 102 VGPRs spilled next to 80 spilled SGPRs -- the
+// pattern that broke k_replay_lo<TAIL>; 1 (512 VGPRs): nothing spilled.  The spill-free instance is the product path: on
+// its own it is slower (41 vs 29 ms per step on one lane) but with the two verification lanes overlapping the step time
+// is the same (418 vs 417 ms).  DSM_FINAL_WAVES=2 selects the other; tools/check_schedules.py compares the two on all
+// 124 750 pairs of config 2 (byte-identical).
+template <int WAVES>
+__global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   VSmem* sm = reinterpret_cast<VSmem*>(smem_raw);
   uint32_t* sidx = reinterpret_cast<uint32_t*>(smem_raw + ((sizeof(VSmem) + 15) / 16) * 16);
@@ -1466,7 +1472,7 @@ void launch_verify(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
   hipLaunchKernelGGL(k_ransac<FAM_E>, dim3(n_blocks), dim3(64), smem, st, p);
   hipLaunchKernelGGL(k_ransac<FAM_F>, dim3(n_blocks), dim3(64), smem, st, p);
   hipLaunchKernelGGL(k_ransac<FAM_H>, dim3(n_blocks), dim3(64), smem, st, p);
-  hipLaunchKernelGGL(k_verify_final, dim3(n_blocks), dim3(64), smem, st, p);
+  hipLaunchKernelGGL(k_verify_final<2>, dim3(n_blocks), dim3(64), smem, st, p);
 }
 
 // ------------------------------------------------------------------------------------ phase-split pipeline
@@ -2130,7 +2136,7 @@ __global__ __launch_bounds__(64, (FAM == FAM_E ? 1 : 2)) void k_replay(const Ver
 
 // Which problems k_lo_prepare_reg takes: a tall matrix (more than nine constraint rows) whose rows fit the lanes'
 // registers -- up to LOP_PPL inliers per lane.
-#define LOP_PPL 4
+#define LOP_PPL 6  // 384 inliers; beyond that (and for H) the general kernel
 template <int FAM>
 __host__ __device__ inline bool lo_prepare_in_registers(int ninl) {
   const int m = FAM == FAM_H ? 2 * ninl : ninl;
@@ -2868,7 +2874,11 @@ void launch_vp_replay(const VerifyParams& p, int fam, uint32_t n_blocks, hipStre
 }
 void launch_vp_final(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
   if (!p.n_pairs || !n_blocks) return;
-  hipLaunchKernelGGL(k_verify_final, dim3(n_blocks), dim3(64), verify_smem_bytes(p.n_max), st, p);
+  const char* fw = getenv("DSM_FINAL_WAVES");
+  if (fw && atoi(fw) == 2)
+    hipLaunchKernelGGL(k_verify_final<2>, dim3(n_blocks), dim3(64), verify_smem_bytes(p.n_max), st, p);
+  else
+    hipLaunchKernelGGL(k_verify_final<1>, dim3(n_blocks), dim3(64), verify_smem_bytes(p.n_max), st, p);
 }
 
 void debug_read_prof(unsigned long long* out16) {
