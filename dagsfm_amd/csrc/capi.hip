@@ -685,6 +685,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
           // local optimisation is suspended onto the queue, the optimisation runs for the whole queue, and the
           // next replay launch works through exactly that queue
           uint32_t* queues = L.lo_queue.as<uint32_t>();
+          vp.lo_queue_g = queues + (size_t)2 * chunk;
           vp.worklist = nullptr;
           vp.n_work = vp.n_chunk;
           for (uint32_t cur = 0;; cur ^= 1u) {
@@ -812,6 +813,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.lo_inl = nullptr;
   vp.worklist = nullptr;
   vp.n_work = 0;
+  vp.lo_queue_g = nullptr;
   vp.lo_queue = nullptr;
   vp.lo_count = nullptr;
   vp.lo_work = vp.lo_models = vp.lo_slots = vp.lo_ework = nullptr;
@@ -938,7 +940,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
       HIPCHK(ctx, L.vsums.reserve((size_t)chunk * bm_max * 8));
       HIPCHK(ctx, L.models.reserve((size_t)chunk * bm_max * 72));
       HIPCHK(ctx, L.ework.reserve((size_t)chunk * plan.batch[0] * 200 * 8));
-      HIPCHK(ctx, L.lo_queue.reserve((size_t)chunk * 2 * 4));
+      HIPCHK(ctx, L.lo_queue.reserve((size_t)chunk * 3 * 4));  // two alternating queues + the general-kernel list
       HIPCHK(ctx, L.lo_work.reserve((size_t)chunk * LO_WORK_DOUBLES * 8));
       HIPCHK(ctx, L.lo_models.reserve((size_t)chunk * 90 * 8));
       HIPCHK(ctx, L.lo_slots.reserve((size_t)chunk * 90 * 8));

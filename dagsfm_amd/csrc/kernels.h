@@ -146,6 +146,7 @@ struct VerifyParams {
   uint32_t* lo_inl;            // [total] ordered inlier indices of the pair's pending LO (at match offsets)
   const uint32_t* worklist;    // k_replay_lo / LO kernels: chunk-local pair indices to process (nullptr: all pairs)
   uint32_t n_work;
+  uint32_t* lo_queue_g;        // k_replay_lo: the queued pairs that need the general LO kernels (count at active_count[22])
   uint32_t* lo_queue;          // out: pairs that k_replay_lo suspended
   uint32_t* lo_count;          // out: their number
   double* lo_work;             // [n_chunk][LO_WORK_DOUBLES]

@@ -2305,7 +2305,7 @@ __global__ __launch_bounds__(64, (TAIL ? 1 : 4)) void k_replay_lo(const VerifyPa
                   fs->lo_wait = 1;
                   fs->lo_ninl = (uint32_t)ninl;
                   p.lo_queue[atomicAdd(p.lo_count, 1u)] = pl;
-                  if (!(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) atomicAdd(p.active_count + 22, 1u);
+                  if (!(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) p.lo_queue_g[atomicAdd(p.active_count + 22, 1u)] = pl;
                   if ((FAM == FAM_H ? 2 * ninl : ninl) < 9) atomicAdd(p.active_count + 23, 1u);
                 }
                 suspended = true;
@@ -2791,16 +2791,22 @@ void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, bool
 void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint32_t n_wave_prepare, uint32_t n_small_jacobi,
                          hipStream_t st) {
   if (!p.n_work || !n_blocks) return;
-  const uint32_t nb_prep = p.n_work < n_blocks ? p.n_work : n_blocks;  // one scratch area per workgroup (wg_scratch)
   const dim3 g4((p.n_work + 64 / LOJ_G - 1) / (64 / LOJ_G)), g64((p.n_work + 63) / 64);
   const bool reg_jacobi = getenv("DSM_LO_JACOBI_GROUPS") == nullptr;  // =1: the 8-lane-group kernel for every problem (round-2 form)
   const bool reg_prepare = p.lo_reg_prepare && n_wave_prepare < p.n_work;
+  // the general kernels work through k_replay_lo's list of the problems that need them (a handful per iteration: the
+  // first local optimisations of a pair have 6 - 9 inliers), not through the whole queue
+  VerifyParams pg = p;
+  pg.worklist = p.lo_queue_g;
+  pg.n_work = n_wave_prepare;
+  const uint32_t nb_prep = pg.n_work < n_blocks ? pg.n_work : n_blocks;  // one scratch area per workgroup (wg_scratch)
+  const dim3 g4g((pg.n_work + 64 / LOJ_G - 1) / (64 / LOJ_G));
   if (fam == FAM_E) {
     if (reg_prepare) hipLaunchKernelGGL(k_lo_prepare_reg<FAM_E>, dim3(p.n_work), dim3(64), 0, st, p);
-    if (n_wave_prepare) hipLaunchKernelGGL(k_lo_prepare<FAM_E>, dim3(nb_prep), dim3(64), 0, st, p);
+    if (n_wave_prepare) hipLaunchKernelGGL(k_lo_prepare<FAM_E>, dim3(nb_prep), dim3(64), 0, st, pg);
     if (reg_jacobi) {
       hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
-      if (n_small_jacobi) hipLaunchKernelGGL((k_lo_jacobi<FAM_E, true>), g4, dim3(64), 0, st, p);
+      if (n_small_jacobi) hipLaunchKernelGGL((k_lo_jacobi<FAM_E, true>), g4g, dim3(64), 0, st, pg);
     } else {
       hipLaunchKernelGGL((k_lo_jacobi<FAM_E, false>), g4, dim3(64), 0, st, p);
     }
@@ -2810,20 +2816,20 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint
   }
   if (fam == FAM_F) {
     if (reg_prepare) hipLaunchKernelGGL(k_lo_prepare_reg<FAM_F>, dim3(p.n_work), dim3(64), 0, st, p);
-    if (n_wave_prepare) hipLaunchKernelGGL(k_lo_prepare<FAM_F>, dim3(nb_prep), dim3(64), 0, st, p);
+    if (n_wave_prepare) hipLaunchKernelGGL(k_lo_prepare<FAM_F>, dim3(nb_prep), dim3(64), 0, st, pg);
     if (reg_jacobi) {
       hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
-      if (n_small_jacobi) hipLaunchKernelGGL((k_lo_jacobi<FAM_F, true>), g4, dim3(64), 0, st, p);
+      if (n_small_jacobi) hipLaunchKernelGGL((k_lo_jacobi<FAM_F, true>), g4g, dim3(64), 0, st, pg);
     } else {
       hipLaunchKernelGGL((k_lo_jacobi<FAM_F, false>), g4, dim3(64), 0, st, p);
     }
     hipLaunchKernelGGL(k_lo_finish<FAM_F>, g64, dim3(64), 0, st, p);
   }
-  if (fam == FAM_H) {
-    hipLaunchKernelGGL(k_lo_prepare<FAM_H>, dim3(nb_prep), dim3(64), 0, st, p);
+  if (fam == FAM_H) {  // every H problem takes the general prepare: the list is the queue
+    if (n_wave_prepare) hipLaunchKernelGGL(k_lo_prepare<FAM_H>, dim3(nb_prep), dim3(64), 0, st, pg);
     if (reg_jacobi) {
       hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
-      if (n_small_jacobi) hipLaunchKernelGGL((k_lo_jacobi<FAM_H, true>), g4, dim3(64), 0, st, p);
+      if (n_small_jacobi) hipLaunchKernelGGL((k_lo_jacobi<FAM_H, true>), g4g, dim3(64), 0, st, pg);
     } else {
       hipLaunchKernelGGL((k_lo_jacobi<FAM_H, false>), g4, dim3(64), 0, st, p);
     }

@@ -49,12 +49,13 @@ def main():
     ap.add_argument("--images", type=int, default=500)
     ap.add_argument("--feats", type=int, default=4096)
     ap.add_argument("--legacy", action="store_true", help="also run the (slow) single-kernel-per-family schedule")
+    ap.add_argument("--uncalibrated", action="store_true", help="cameras without a focal-length prior: the F + H path of the decision tree")
     a = ap.parse_args()
     scene = synthetic.Scene(a.images, a.feats, seed=0)
     ims = [scene.image(i) for i in range(a.images)]
     pairs = synthetic.exhaustive_pairs(a.images)
     ctx = capi.Context(0)
-    cams = [capi.simple_pinhole(scene.focal, scene.width / 2.0, scene.height / 2.0, scene.width, scene.height, 1) for _ in range(a.images)]
+    cams = [capi.simple_pinhole(scene.focal, scene.width / 2.0, scene.height / 2.0, scene.width, scene.height, 0 if a.uncalibrated else 1) for _ in range(a.images)]
     ctx.set_images([im[0] for im in ims], [im[1] for im in ims], cams)
     ctx.match_pairs(pairs)
     opts = capi.default_two_view_options()
