@@ -739,7 +739,7 @@ DSM_DEVN void triangulate_point(const double* R, const double* t, double p1x, do
     A[3 * 4 + c] = p2y * P2[8 + c] - P2[4 + c];
   }
   double V[16], sv[4];
-  pl_jacobi_svd_square<4, false>(A, nullptr, V, sv);
+  pr_jacobi_svd_square_V<4>(A, V, sv);  // registers only
   const double w = V[3 * 4 + 3];
   X[0] = V[3 * 4 + 0] / w;
   X[1] = V[3 * 4 + 1] / w;

@@ -486,6 +486,108 @@ DSM_DEV void pl_jacobi_svd_square(const double* A_rowmajor, double* U, double* V
   }
 }
 
+// pl_jacobi_svd_square<N, false> with every array in registers (all loops unrolled, the sort's column swaps as
+// selected values): the right factor only.
+template <int N>
+DSM_DEV void pr_jacobi_svd_square_V(const double (&A_rowmajor)[N * N], double (&V)[N * N], double (&sv)[N]) {
+  double W[N * N];
+  double scale = 0.0;
+#pragma unroll
+  for (int i = 0; i < N * N; ++i) {
+    const double a = fabs(A_rowmajor[i]);
+    if (a > scale) scale = a;
+  }
+  if (scale == 0.0) scale = 1.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      W[j * N + i] = A_rowmajor[i * N + j] / scale;
+      V[j * N + i] = (i == j) ? 1.0 : 0.0;
+    }
+  }
+  const double precision = 2.0 * DBL_EPSILON;
+  double max_diag = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (fabs(W[i * N + i]) > max_diag) max_diag = fabs(W[i * N + i]);
+  bool finished = false;
+  while (!finished) {
+    finished = true;
+#pragma unroll
+    for (int p = 1; p < N; ++p) {
+#pragma unroll
+      for (int q = 0; q < p; ++q) {
+        const double thr = DBL_MIN > precision * max_diag ? DBL_MIN : precision * max_diag;
+        if (fabs(W[q * N + p]) > thr || fabs(W[p * N + q]) > thr) {
+          finished = false;
+          double lc, ls, rc, rs;
+          dsm_jacobi_2x2(W[p * N + p], W[q * N + p], W[p * N + q], W[q * N + q], &lc, &ls, &rc, &rs);
+          if (!(lc == 1.0 && ls == 0.0)) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {  // rows p, q
+              const double xi = W[j * N + p], yi = W[j * N + q];
+              W[j * N + p] = lc * xi + ls * yi;
+              W[j * N + q] = -ls * xi + lc * yi;
+            }
+          }
+          if (!(rc == 1.0 && -rs == 0.0)) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {  // columns p, q with (rc, -rs)
+              const double xi = W[p * N + i], yi = W[q * N + i];
+              W[p * N + i] = rc * xi + (-rs) * yi;
+              W[q * N + i] = rs * xi + rc * yi;
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+              const double xi = V[p * N + i], yi = V[q * N + i];
+              V[p * N + i] = rc * xi + (-rs) * yi;
+              V[q * N + i] = rs * xi + rc * yi;
+            }
+          }
+          const double app = fabs(W[p * N + p]), aqq = fabs(W[q * N + q]);
+          const double mm = app > aqq ? app : aqq;
+          if (mm > max_diag) max_diag = mm;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) sv[i] = fabs(W[i * N + i]) * scale;
+  bool stop = false;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (!stop) {
+      int pos = i;
+      double mx = sv[i];
+#pragma unroll
+      for (int j = i + 1; j < N; ++j) {
+        if (sv[j] > mx) {
+          mx = sv[j];
+          pos = j;
+        }
+      }
+      if (mx == 0.0) {
+        stop = true;
+      } else {
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) {  // unconditional stores of selected values (see pr_jacobi_sweeps9)
+          const bool sw = (j == pos);
+          const double si = sv[i], sj = sv[j];
+          sv[i] = sw ? sj : si;
+          sv[j] = sw ? si : sj;
+#pragma unroll
+          for (int r = 0; r < N; ++r) {
+            const double a = V[i * N + r], b = V[j * N + r];
+            V[i * N + r] = sw ? b : a;
+            V[j * N + r] = sw ? a : b;
+          }
+        }
+      }
+    }
+  }
+}
+
 // Eigenvalues of an upper-Hessenberg n x n matrix T (column-major, ld = LD, destroyed):
 // EigenSolver(C, false) for companion matrices (the Hessenberg reduction is the identity on
 // them: every sub-sub-diagonal entry is already zero).  Returns false on non-convergence.
