@@ -12,7 +12,9 @@
 // Checked bit for bit against oracle/retrieval.cc, which also lists the three places where third-party arithmetic
 // (FLANN's approximate search, Eigen's float GEMV order, unstable std::sort) is replaced by a defined one.
 //
-// Kernels (all HBM / VALU bound; nothing here is a GEMM worth the matrix pipe at 128-D x 65 536 words: 0.2 ms/image):
+// Kernels:
+//   k_vocab_assign_mfma  the nearest words from int8 MFMA tiles with a per-lane top-8 epilogue (below); k_vocab_assign is
+//                      the VALU form of the same result (DSM_VOCAB_ASSIGN_VALU=1):
 //   k_vocab_assign     thread = two feature rows, visual words stream through LDS in 64-word tiles, 32 v_dot4 per
 //                      element, key = 2 d.w - |w|^2 in exact int32 (argmax key == argmin squared L2), sorted top-8
 //   k_vocab_signature  wave = feature, lane = embedding dimension: the 128-term float sum left to right, one
@@ -416,6 +418,157 @@ void dsm_retrieval_destroy(dsm_ctx* ctx) {
   ctx->retrieval = nullptr;
 }
 
+// ------------------------------------------------------------------------------------ word assignment on the matrix pipe
+// The same result as k_vocab_assign from int8 MFMA tiles (v_mfma_i32_32x32x32_i8): a workgroup is 4 waves x 128 feature
+// rows (4 resident 32-row fragments per wave, like k1_best_rows), the visual words stream through LDS in 64-word steps.
+// A lane holds, for ITS row, 16 of a tile's 32 columns (the other half-wave holds the rest), so the row's top-RK_MAX list
+// is kept per lane over the lane's own columns and the two halves are merged at the end.  Epilogue per tile: key =
+// 2 * dot + cw (one v_lshl_add per element) and a running maximum; only when that maximum beats the lane's current
+// RK_MAX-th key are the 16 elements looked at one by one, in ascending word id (strict >: equal keys keep the lower id
+// first, as in the scalar scan).  ~1.5 VALU per element against 32 v_dot4 + the scan in the VALU kernel.
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ int rk_lds_off(int col, int chunk) { return col * 128 + ((chunk ^ ((col >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ void rk_insert(int (&key)[RK_MAX], int (&id)[RK_MAX], int kv, int wid) {
+  key[RK_MAX - 1] = kv;
+  id[RK_MAX - 1] = wid;
+#pragma unroll
+  for (int q = RK_MAX - 1; q > 0; --q) {
+    const bool up = key[q] > key[q - 1] || (key[q] == key[q - 1] && id[q] < id[q - 1]);
+    const int tk = key[q], ti = id[q];
+    key[q] = up ? key[q - 1] : tk;
+    id[q] = up ? id[q - 1] : ti;
+    key[q - 1] = up ? tk : key[q - 1];
+    id[q - 1] = up ? ti : id[q - 1];
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_vocab_assign_mfma(const int8_t* __restrict__ desc, const int32_t* __restrict__ row_img,
+                                                              uint64_t n_rows, const int8_t* __restrict__ words,
+                                                              const int32_t* __restrict__ cw, uint32_t num_words, uint32_t words_padded,
+                                                              int k, int32_t* __restrict__ out) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  __shared__ __attribute__((aligned(16))) int8_t sB[2][64 * 128];
+  __shared__ __attribute__((aligned(16))) int sC[2][64];
+  // resident fragments of this wave's 128 rows (MFMA B operand: lane = row, 16 B of k per half)
+  v4i afrag[4][4];
+  uint64_t rowg[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    rowg[rt] = (uint64_t)blockIdx.x * 512u + (uint64_t)wave * 128u + (uint64_t)rt * 32u + (uint64_t)l31;
+    const uint64_t rr = rowg[rt] < n_rows ? rowg[rt] : 0;  // rows are padded per image; beyond the end: any valid row
+    const int8_t* arow = desc + rr * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) afrag[rt][ks] = *reinterpret_cast<const v4i*>(arow + ks * 32 + half * 16);
+  }
+  int key[4][RK_MAX], id[4][RK_MAX];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+    for (int q = 0; q < RK_MAX; ++q) {
+      key[rt][q] = INT32_MIN;
+      id[rt][q] = RK_INVALID;
+    }
+  }
+  const uint32_t nsteps = words_padded >> 6;
+  v4i stage[2];
+  int cstage = 0;
+  auto fetch = [&](uint32_t s) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) stage[u] = *reinterpret_cast<const v4i*>(words + (size_t)s * 64 * 128 + (size_t)(tid + 256 * u) * 16);
+    cstage = cw[s * 64 + (tid & 63)];
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = tid + 256 * u;
+      *reinterpret_cast<v4i*>(&sB[buf][rk_lds_off(q >> 3, q & 7)]) = stage[u];
+    }
+    if (tid < 64) sC[buf][tid] = cstage;
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (uint32_t s = 0; s < nsteps; ++s) {
+    const int cur = s & 1;
+    const bool more = s + 1 < nsteps;
+    if (more) fetch(s + 1);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      // MFMA A operand: lane = column (word) of the tile
+      v4i bf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bf[ks] = *reinterpret_cast<const v4i*>(&sB[cur][rk_lds_off(ct * 32 + l31, ks * 2 + half)]);
+      // column terms of this lane's 16 accumulator registers: register r <-> column 8*(r>>2) + 4*half + (r&3)
+      int cterm[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const v4i c = *reinterpret_cast<const v4i*>(&sC[cur][ct * 32 + 8 * q + 4 * half]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cterm[4 * q + e] = c[e];
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        v16i_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[ks], afrag[rt][ks], acc, 0, 0, 0);
+        int kv[16];
+        int mx = INT32_MIN;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          kv[r] = (acc[r] << 1) + cterm[r];
+          mx = kv[r] > mx ? kv[r] : mx;
+        }
+        // rare path, ONE insertion site per tile: take the lane's largest remaining element (lowest register = lowest
+        // word id on equal keys), insert it, repeat while anything is left above the threshold.  The final list does
+        // not depend on the order of insertion (rk_insert orders by key, then id).
+        const int wid0 = (int)(s * 64) + ct * 32 + 4 * half;
+        while (mx > key[rt][RK_MAX - 1]) {
+          int best = kv[0], br = 0;
+#pragma unroll
+          for (int r = 1; r < 16; ++r) {
+            const bool g = kv[r] > best;
+            best = g ? kv[r] : best;
+            br = g ? r : br;
+          }
+          const int wid = wid0 + 8 * (br >> 2) + (br & 3);
+          if ((uint32_t)wid < num_words) rk_insert(key[rt], id[rt], best, wid);  // the last tile's padding is not a word
+          mx = INT32_MIN;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            kv[r] = (r == br) ? INT32_MIN : kv[r];
+            mx = kv[r] > mx ? kv[r] : mx;
+          }
+        }
+      }
+    }
+    if (more) commit(cur ^ 1);
+    __syncthreads();
+  }
+  // the two halves of the wave hold disjoint word subsets of the same rows: merge (key descending, lower id first)
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    int ok[RK_MAX], oi[RK_MAX];
+#pragma unroll
+    for (int q = 0; q < RK_MAX; ++q) {
+      ok[q] = __shfl_xor(key[rt][q], 32);
+      oi[q] = __shfl_xor(id[rt][q], 32);
+    }
+#pragma unroll
+    for (int q = 0; q < RK_MAX; ++q) {
+      const int lk = key[rt][RK_MAX - 1], li = id[rt][RK_MAX - 1];
+      if (ok[q] > lk || (ok[q] == lk && oi[q] < li)) rk_insert(key[rt], id[rt], ok[q], oi[q]);
+    }
+    if (half == 0 && rowg[rt] < n_rows) {
+      const bool valid = row_img[rowg[rt]] >= 0;
+      int32_t* o = out + rowg[rt] * RK_MAX;
+#pragma unroll
+      for (int q = 0; q < RK_MAX; ++q) o[q] = (valid && q < k && key[rt][q] != INT32_MIN) ? id[rt][q] : RK_INVALID;
+    }
+  }
+}
+
 // words of every feature of every resident image (k nearest), signatures for them
 static int retrieval_assign(dsm_ctx* ctx, uint32_t k) {
   RetrievalState* r = ctx->retrieval;
@@ -434,9 +587,14 @@ static int retrieval_assign(dsm_ctx* ctx, uint32_t k) {
   RCHK(ctx, r->d_wid.reserve(std::max<uint64_t>(rows, 1) * RK_MAX * 4));
   RCHK(ctx, r->d_sig.reserve(std::max<uint64_t>(rows, 1) * RK_MAX * 8));
   if (rows) {
-    hipLaunchKernelGGL(k_vocab_assign, dim3((uint32_t)((rows + 511) / 512)), dim3(256), 0, st, ctx->d_desc.as<int8_t>(),
-                       r->d_row_img.as<int32_t>(), rows, r->d_words.as<int8_t>(), r->d_cw.as<int32_t>(), r->num_words, r->words_padded, (int)k,
-                       r->d_wid.as<int32_t>());
+    if (getenv("DSM_VOCAB_ASSIGN_VALU"))  // the LDS-tiled v_dot4 form (comparison / cross-check)
+      hipLaunchKernelGGL(k_vocab_assign, dim3((uint32_t)((rows + 511) / 512)), dim3(256), 0, st, ctx->d_desc.as<int8_t>(),
+                         r->d_row_img.as<int32_t>(), rows, r->d_words.as<int8_t>(), r->d_cw.as<int32_t>(), r->num_words, r->words_padded, (int)k,
+                         r->d_wid.as<int32_t>());
+    else
+      hipLaunchKernelGGL(k_vocab_assign_mfma, dim3((uint32_t)((rows + 511) / 512)), dim3(256), 0, st, ctx->d_desc.as<int8_t>(),
+                         r->d_row_img.as<int32_t>(), rows, r->d_words.as<int8_t>(), r->d_cw.as<int32_t>(), r->num_words, r->words_padded, (int)k,
+                         r->d_wid.as<int32_t>());
     RCHK(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_vocab_signature, dim3(2048), dim3(256), 0, st, ctx->d_desc.as<int8_t>(), rows, r->d_projT.as<float>(),
                        r->d_thr.as<float>(), r->d_wid.as<int32_t>(), (int)k, r->d_sig.as<uint64_t>());
