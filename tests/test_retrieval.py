@@ -48,9 +48,18 @@ def _scene(n_img, feats, words):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["mfma", "valu"])
 @pytest.mark.parametrize("n_words", [3, 100, 1000])
-def test_device_word_assignment_is_exact(dsm, n_words):
+def test_device_word_assignment_is_exact(dsm, n_words, kernel, monkeypatch):
+    """Both forms of the word assignment (int8 MFMA tiles with the per-lane top-8 epilogue = the product path; the
+    LDS-tiled v_dot4 scan) against the oracle's exact search, for k = 1, 5, 8 neighbours.  Every fourth word is a copy of
+    its predecessor, so that equal distances occur everywhere and must resolve to the lower word id."""
+    if kernel == "valu":
+        monkeypatch.setenv("DSM_VOCAB_ASSIGN_VALU", "1")
     scene, ims, voc = _scene(3, 300, n_words)
+    words = voc[0].copy()
+    words[3::4] = words[2::4][:len(words[3::4])]
+    voc = (words,) + tuple(voc[1:])
     descs = [ims[0][0], ims[1][0][:129], ims[2][0][:1]]
     dsm.set_images(descs)
     dsm.retrieval_set_vocabulary(*voc)
