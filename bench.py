@@ -243,8 +243,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import threading
+    match_turn = threading.Lock()
+
     def run_part(k):
-        ctxs[k].match_pairs(cparts[k], opts)
+        # several contexts: the matching calls take turns (they all want the matrix pipe), each context's verification
+        # (FP64 VALU, latency chains) then runs next to the following context's matching -- the reference's matcher and
+        # verifier thread pools overlap the same way (/root/reference/src/feature/matching.cc:640-674)
+        with match_turn:
+            ctxs[k].match_pairs(cparts[k], opts)
         if verify:
             ctxs[k].verify_pairs(topts, user_seed=user_seed, stage_filter=True)
 
@@ -252,7 +259,6 @@ def main():
         if n_ctx == 1:
             run_part(0)
         else:
-            import threading
             th = [threading.Thread(target=run_part, args=(k,)) for k in range(n_ctx)]
             for t in th:
                 t.start()
