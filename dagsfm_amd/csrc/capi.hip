@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -955,8 +956,18 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     if (n_lanes == 1) {
       verify_lane_run(ctx, 0, vp, plan);
     } else {
+      // lane 0 on the calling thread, the others on their own; a lane whose thread cannot be created runs here afterwards
       std::vector<std::thread> th;
-      for (uint32_t li = 0; li < n_lanes; ++li) th.emplace_back(verify_lane_run, ctx, li, vp, plan);
+      std::vector<uint32_t> here;
+      for (uint32_t li = 1; li < n_lanes; ++li) {
+        try {
+          th.emplace_back(verify_lane_run, ctx, li, vp, plan);
+        } catch (const std::system_error&) {
+          here.push_back(li);
+        }
+      }
+      verify_lane_run(ctx, 0, vp, plan);
+      for (uint32_t li : here) verify_lane_run(ctx, li, vp, plan);
       for (std::thread& t : th) t.join();
     }
     for (uint32_t li = 0; li < n_lanes; ++li) {
