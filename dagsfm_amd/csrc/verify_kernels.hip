@@ -1652,10 +1652,10 @@ __global__ __launch_bounds__(64, 8) void k_score(const VerifyParams p) {
 // scratch memory, and with thousands of resident waves that scratch lives in HBM; two thirds of the time
 // went into the companion-matrix eigenvalue iteration alone.  k_solve_e_build (null space + constraint matrix,
 // to global memory) and k_solve_e_lu (pivoted elimination in LDS, determinant polynomial) park (Eb, B,
-// coefficients) in the hypothesis' model slot; k_roots_e runs the eigenvalue
-// iteration on a lane-interleaved 10 x 10 matrix in LDS (element e of lane l at T[e * 64 + l]: conflict-free,
-// no memory traffic; 51 KB per wave, so it is kept free of everything else); k_models_score_e builds and
-// scores the models at full occupancy.  Same operations, same order.
+// coefficients) in the hypothesis' model slot; k_roots_e runs the eigenvalue iteration with the 10 x 10 companion
+// matrix in registers (pr_hessenberg_eigenvalues: static indices, the lane's deflation window as predicates; the
+// round-2 LDS form -- element e of lane l at T[e * 64 + l], 51 KB per wave -- is k_roots_e_lds); k_models_score_e
+// builds and scores the models at full occupancy.  Same operations, same order.
 #define EPOLY_EB 0
 #define EPOLY_B 36
 #define EPOLY_COEFFS 75
@@ -2148,8 +2148,9 @@ __host__ __device__ inline bool lo_prepare_in_registers(int ninl) {
 // (2 x 2 rotations of the 9 x 9 Jacobi, the 5-point finish) that every lane executes redundantly -- 72 % of its
 // wave cycles.  Here the replay SUSPENDS at every local optimisation: k_replay_lo records the pair's state, hands
 // the ordered inlier list to lo_inl and puts the pair on a queue; the optimisation then runs for all queued pairs
-// at once (k_lo_prepare: wave per pair, matrix + pivoted QR; k_lo_jacobi: a 16-lane group per pair for the 9 x 9
-// sweeps and the 8-point / DLT finish; the essential family re-uses the flat 5-point kernels, lane per problem);
+// at once (k_lo_prepare_reg / k_lo_prepare: wave per pair, matrix + pivoted QR; k_lo_jacobi_reg: a lane per pair for
+// the 9 x 9 sweeps, k_lo_jacobi: an 8-lane group for the few smaller problems; k_lo_finish: the 8-point / DLT finish;
+// the essential family re-uses the flat 5-point kernels, lane per problem);
 // the next k_replay_lo launch (work list = that queue) scores the returned models and scans on.  Same operations
 // in the same order as k_replay, which stays as the reference schedule (DSM_VERIFY_INLINE_LO=1).
 // TAIL: the same replay for the last few queued pairs of a round, with every local optimisation -- the pending one the
