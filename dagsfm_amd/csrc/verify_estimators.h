@@ -710,6 +710,46 @@ DSM_DEV int five_point_models(const double* Eb, const double* B, const double* r
   return nm;
 }
 
+// five_point_models for the batch kernels: Eb, B and the roots in registers (static indices; the root of the trip is a
+// select chain, the 3 x 3 SVD is pr_jacobi_svd_square_V), every model written straight to `out` (global memory) -- no
+// private arrays.  real_mask: bit i = root i is real (|imag| <= 1e-10).
+DSM_DEV int five_point_models_reg(const double (&Eb)[36], const double (&B)[39], const double (&rr)[10], int real_mask, int nroots,
+                                  double* out) {
+  int nm = 0;
+  for (int i = 0; i < nroots; ++i) {
+    if (!((real_mask >> i) & 1)) continue;
+    double z1 = rr[0];
+#pragma unroll
+    for (int q = 1; q < 10; ++q) z1 = (i == q) ? rr[q] : z1;
+    const double z2 = z1 * z1;
+    const double z3 = z2 * z1;
+    const double z4 = z3 * z1;
+    double Bz[9];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      Bz[j * 3 + 0] = B[0 * 3 + j] * z3 + B[1 * 3 + j] * z2 + B[2 * 3 + j] * z1 + B[3 * 3 + j];
+      Bz[j * 3 + 1] = B[4 * 3 + j] * z3 + B[5 * 3 + j] * z2 + B[6 * 3 + j] * z1 + B[7 * 3 + j];
+      Bz[j * 3 + 2] = B[8 * 3 + j] * z4 + B[9 * 3 + j] * z3 + B[10 * 3 + j] * z2 + B[11 * 3 + j] * z1 + B[12 * 3 + j];
+    }
+    double Vz[9], svz[3];
+    pr_jacobi_svd_square_V<3>(Bz, Vz, svz);
+    const double X0 = Vz[2 * 3 + 0], X1 = Vz[2 * 3 + 1], X2 = Vz[2 * 3 + 2];
+    if (fabs(X2) < 1e-10) continue;
+    const double sx = X0 / X2, sy = X1 / X2;
+    double ev[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ev[k] = Eb[k * 4 + 0] * sx + Eb[k * 4 + 1] * sy + Eb[k * 4 + 2] * z1 + Eb[k * 4 + 3];
+    double nn = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) nn += ev[k] * ev[k];
+    const double norm = sqrt(nn);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[nm * 9 + k] = ev[k] / norm;
+    ++nm;
+  }
+  return nm;
+}
+
 template <bool WS>
 DSM_DEVN int five_point_finish_t(const double* Eb, double* models, double* ws) {
   double B[39], coeffs[11];

@@ -1789,30 +1789,34 @@ DSM_DEV int e_roots_body(double* slot) {
   }
   return code;
 }
-// slot (Eb, B, roots) + code -> models; returns their number
-DSM_DEV int e_models_body(const double* slot, int code, double* models_out) {
+// slot (Eb, B, roots) + code -> models written to `out` (which may be the slot itself: its inputs are in registers by
+// then); returns their number
+DSM_DEV int e_models_body(const double* slot, int code, double* out) {
   const int nroots = code >> 16;
   if (nroots <= 0) return 0;
-  double Eb[36], B[39], rr[11], ri[11];
+  double Eb[36], B[39], rr[10];
+#pragma unroll
   for (int k = 0; k < 36; ++k) Eb[k] = slot[EPOLY_EB + k];
+#pragma unroll
   for (int k = 0; k < 39; ++k) B[k] = slot[EPOLY_B + k];
-  for (int i = 0; i < nroots; ++i) {
-    rr[i] = slot[EPOLY_COEFFS + i];
-    ri[i] = ((code >> i) & 1) ? 0.0 : 1.0;  // five_point_models only tests |imag| > 1e-10
-  }
-  return five_point_models(Eb, B, rr, ri, nroots, models_out);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) rr[i] = slot[EPOLY_COEFFS + i];  // entries beyond the root count are never selected
+  return five_point_models_reg(Eb, B, rr, code & 0x3ff, nroots, out);
 }
 
-// roots of the determinant polynomial: slot coefficients -> slot roots (real parts) + nmodels = root count /
-// real-root mask for k_models_score_e
-__global__ __launch_bounds__(64) void k_roots_e(const VerifyParams p) {
+// roots of the determinant polynomial and the essential matrices of its real roots: slot (Eb, B, coefficients) ->
+// slot models + nmodels for k_models_score_e
+__global__ __launch_bounds__(64, 2) void k_roots_e(const VerifyParams p) {
   const uint32_t pl = blockIdx.x;
   const uint32_t pi = p.pair0 + pl;
   const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
   if (!fs->active) return;
   const int t = blockIdx.y * 64 + threadIdx.x;
   if (t >= (int)fs->nb) return;
-  p.nmodels[(size_t)pl * p.batch + t] = e_roots_body(p.models + ((size_t)pl * p.batch + t) * 90);
+  // roots, then the models of the real roots in place of the hypothesis' record (its inputs are in registers by then)
+  double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
+  const int code = e_roots_body(slot);
+  p.nmodels[(size_t)pl * p.batch + t] = e_models_body(slot, code, slot);
 }
 // The round-2 form of the same kernel, kept for comparison (DSM_ROOTS_LDS=1): the companion matrix of every lane in
 // lane-interleaved LDS (51 KB per wave), dynamically indexed.
@@ -1837,13 +1841,13 @@ __global__ __launch_bounds__(64) void k_roots_e_lds(const VerifyParams p) {
     }
     code |= nroots << 16;
   }
-  p.nmodels[(size_t)pl * p.batch + t] = code;
+  p.nmodels[(size_t)pl * p.batch + t] = e_models_body(slot, code, slot);
 }
 
-// models of every hypothesis (one lane each), then the inlier counts of ALL models of the block's 64
-// hypotheses with the lanes spread over the correspondences (a hypothesis has 0..10 models: scoring them
+// the inlier counts of ALL models of the block's 64 hypotheses (built by k_roots_e) with the lanes spread over the
+// correspondences (a hypothesis has 0..10 models: scoring them
 // lane-per-hypothesis would run every lane as long as the one with the most models).
-__global__ __launch_bounds__(64, 4) void k_models_score_e(const VerifyParams p) {
+__global__ __launch_bounds__(64, 8) void k_models_score_e(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* spts = reinterpret_cast<double*>(smem_raw);  // min(n_max, VP_LDS_PTS) x 4 doubles
   const uint32_t pl = blockIdx.x;
@@ -1867,16 +1871,9 @@ __global__ __launch_bounds__(64, 4) void k_models_score_e(const VerifyParams p) 
   const double max_error =
       (image_to_world_threshold(cam1, p.opt.max_error) + image_to_world_threshold(cam2, p.opt.max_error)) / 2;
   const double max_residual = max_error * max_error;
-  int nm = 0;
-  double* slots = p.models + ((size_t)pl * p.batch + t0) * 90;
-  if (t < nb) {
-    double* slot = slots + (size_t)lane * 90;
-    double mloc[90];
-    nm = e_models_body(slot, p.nmodels[(size_t)pl * p.batch + t], mloc);
-    for (int k = 0; k < nm * 9; ++k) slot[k] = mloc[k];
-    p.nmodels[(size_t)pl * p.batch + t] = nm;
-  }
-  __syncthreads();  // models (global) and points (LDS) visible to the whole wave
+  const double* slots = p.models + ((size_t)pl * p.batch + t0) * 90;
+  const int nm = t < nb ? p.nmodels[(size_t)pl * p.batch + t] : 0;  // models per hypothesis, written by k_roots_e
+  __syncthreads();  // points (LDS) visible to the whole wave
   LSEC_BEGIN();
   int32_t* counts = p.counts + ((size_t)pl * p.batch + t0) * 10;
   const int ntr = (nb - t0) < 64 ? (nb - t0) : 64;
@@ -2770,10 +2767,7 @@ __global__ __launch_bounds__(64) void k_lo_e_roots_models(const VerifyParams p) 
   const uint32_t pi = p.pair0 + pl;
   double* slot = p.lo_slots + (size_t)pl * 90;
   const int code = e_roots_body(slot);
-  double mloc[90];
-  const int nm = e_models_body(slot, code, mloc);
-  double* om = p.lo_models + (size_t)pl * 90;
-  for (int k = 0; k < nm * 9; ++k) om[k] = mloc[k];
+  const int nm = e_models_body(slot, code, p.lo_models + (size_t)pl * 90);
   p.fam_state[(size_t)pi * 3 + FAM_E].lo_nm = (uint32_t)nm;
 }
 
