@@ -536,7 +536,9 @@ DSM_DEV void c_EEt(const double (&Eb)[36], double (&e)[10]) {  // (E E^T)(I, K) 
   c_lin_mul_acc<I, 1, K, 1>(Eb, e);
   c_lin_mul_acc<I, 2, K, 2>(Eb, e);
 }
-template <int I, int J>
+// ES: element stride of the output (1 = one hypothesis' 200 doubles back to back; 64 = the hypotheses of a wave
+// interleaved, element e of lane l at out[e * 64 + l]: coalesced stores)
+template <int I, int J, int ES = 1>
 DSM_DEV void c_trace_row(const double (&Eb)[36], const double (&ht)[10], double* out) {
   double row[20];
 #pragma unroll
@@ -550,8 +552,9 @@ DSM_DEV void c_trace_row(const double (&Eb)[36], const double (&ht)[10], double*
   c_quad_lin_mul_acc<2, J>(e, Eb, 1.0, row);
   c_quad_lin_mul_acc<I, J>(ht, Eb, -1.0, row);
 #pragma unroll
-  for (int q = 0; q < 20; ++q) out[(1 + I * 3 + J) * 20 + q] = row[q];
+  for (int q = 0; q < 20; ++q) out[((1 + I * 3 + J) * 20 + q) * ES] = row[q];
 }
+template <int ES = 1>
 DSM_DEV void five_point_build_A_rows(const double* Eb_in, double* out) {
   double Eb[36];
 #pragma unroll
@@ -584,7 +587,7 @@ DSM_DEV void five_point_build_A_rows(const double* Eb_in, double* out) {
     c_quad_lin_mul_acc<0, 1>(m1, Eb, -1.0, row);
     c_quad_lin_mul_acc<0, 2>(m2, Eb, 1.0, row);
 #pragma unroll
-    for (int q = 0; q < 20; ++q) out[q] = row[q];
+    for (int q = 0; q < 20; ++q) out[q * ES] = row[q];
   }
   double ht[10];
   {
@@ -595,15 +598,15 @@ DSM_DEV void five_point_build_A_rows(const double* Eb_in, double* out) {
 #pragma unroll
     for (int q = 0; q < 10; ++q) ht[q] = 0.5 * (e0[q] + e1[q] + e2[q]);
   }
-  c_trace_row<0, 0>(Eb, ht, out);
-  c_trace_row<0, 1>(Eb, ht, out);
-  c_trace_row<0, 2>(Eb, ht, out);
-  c_trace_row<1, 0>(Eb, ht, out);
-  c_trace_row<1, 1>(Eb, ht, out);
-  c_trace_row<1, 2>(Eb, ht, out);
-  c_trace_row<2, 0>(Eb, ht, out);
-  c_trace_row<2, 1>(Eb, ht, out);
-  c_trace_row<2, 2>(Eb, ht, out);
+  c_trace_row<0, 0, ES>(Eb, ht, out);
+  c_trace_row<0, 1, ES>(Eb, ht, out);
+  c_trace_row<0, 2, ES>(Eb, ht, out);
+  c_trace_row<1, 0, ES>(Eb, ht, out);
+  c_trace_row<1, 1, ES>(Eb, ht, out);
+  c_trace_row<1, 2, ES>(Eb, ht, out);
+  c_trace_row<2, 0, ES>(Eb, ht, out);
+  c_trace_row<2, 1, ES>(Eb, ht, out);
+  c_trace_row<2, 2, ES>(Eb, ht, out);
 }
 
 // Steps 4a: B(z) from rows 4..9 of the eliminated system (S[(r-4)*10 + c] = AA(r, c)) and the determinant

@@ -1678,7 +1678,8 @@ __global__ __launch_bounds__(64, 2) void k_solve_e_build(const VerifyParams p) {
   five_point_basis_reg(xs, Eb);
   double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
   for (int k = 0; k < 36; ++k) slot[EPOLY_EB + k] = Eb[k];
-  five_point_build_A_rows(Eb, p.e_work + ((size_t)pl * p.batch + t) * 200);
+  // the wave's 64 hypotheses interleaved: element e of lane l at block + e * 64 + l (batch is a multiple of 64)
+  five_point_build_A_rows<64>(Eb, p.e_work + ((size_t)pl * p.batch + (size_t)blockIdx.y * 64) * 200 + threadIdx.x);
 }
 
 // A[:, :10].partialPivLu().solve(A[:, 10:]) (essential_matrix.cc:80) with the 10 x 10 factor in lane-interleaved
@@ -1689,11 +1690,13 @@ __global__ __launch_bounds__(64, 2) void k_solve_e_build(const VerifyParams p) {
 #define ELU_SMEM (100 * 64 * 8 + 10 * 64)
 // Ag: the hypothesis' 10 x 20 constraint matrix A[r*20 + c]; slot: its 90-double record (B(z) and the determinant
 // polynomial are written to it); Al / idx: this lane's column of the lane-interleaved LDS work area.
+// ES: element stride of Ag (see five_point_build_A_rows)
+template <int ES = 1>
 DSM_DEV void e_lu_body(const double* Ag, double* slot, double* Al, unsigned char* idx) {
 #define LA(i, k) Al[((k) * 10 + (i)) * 64]
   LSEC_BEGIN2();
   for (int r = 0; r < 10; ++r)
-    for (int c = 0; c < 10; ++c) LA(r, c) = Ag[r * 20 + c];
+    for (int c = 0; c < 10; ++c) LA(r, c) = Ag[(r * 20 + c) * ES];
   for (int i = 0; i < 10; ++i) idx[i * 64] = (unsigned char)i;
   for (int k = 0; k < 10; ++k) {
     int r = k;
@@ -1729,7 +1732,7 @@ DSM_DEV void e_lu_body(const double* Ag, double* slot, double* Al, unsigned char
   for (int j = 0; j < 10; ++j) {
     double b[10];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) b[i] = Ag[(int)idx[i * 64] * 20 + 10 + j];
+    for (int i = 0; i < 10; ++i) b[i] = Ag[((int)idx[i * 64] * 20 + 10 + j) * ES];
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
       double s = b[i];
@@ -1764,7 +1767,7 @@ __global__ __launch_bounds__(64) void k_solve_e_lu(const VerifyParams p) {
   if (!fs->active) return;
   const int t = blockIdx.y * 64 + threadIdx.x;
   if (t >= (int)fs->nb) return;
-  e_lu_body(p.e_work + ((size_t)pl * p.batch + t) * 200, p.models + ((size_t)pl * p.batch + t) * 90, Al, idx);
+  e_lu_body<64>(p.e_work + ((size_t)pl * p.batch + (size_t)blockIdx.y * 64) * 200 + threadIdx.x, p.models + ((size_t)pl * p.batch + t) * 90, Al, idx);
 }
 
 // slot coefficients -> slot roots (real parts); returns the code for nmodels: bits 0..9 root i is real
