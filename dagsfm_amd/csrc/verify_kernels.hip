@@ -928,6 +928,24 @@ __host__ __device__ inline size_t verify_scratch_doubles(size_t n) {
   return n + (18 * n + 96) + (size_t)BATCH * 10 * 9 + 3 * n + 3 * n + 4 * n + (n + 1) / 2 + 8;
 }
 
+// Dynamic work hand-out of the persistent wave-per-pair kernels.  One atomicAdd per item on ONE counter serialises at the
+// L2 (~30 ns each): with 10^5 light items per launch that WAS the launch (k_replay_lo: 54 ns per pair).  A wave takes
+// `gr` consecutive items per atomic instead -- 4 when the grid has at least 8 items per wave to balance with, else 1.
+struct WorkGrab {
+  uint32_t next = 0, left = 0;
+};
+DSM_DEV uint32_t work_grain(uint32_t n_items) { return n_items >= 8u * gridDim.x ? 4u : 1u; }
+DSM_DEV uint32_t grab_item(WorkGrab& g, uint32_t* counter, uint32_t* s_slot, int lane, uint32_t gr) {
+  if (g.left == 0) {
+    if (lane == 0) *s_slot = atomicAdd(counter, gr);
+    __syncthreads();
+    g.next = *s_slot;
+    g.left = gr;
+  }
+  g.left--;
+  return g.next++;
+}
+
 struct WgScratch {
   double *resid, *tall, *models, *pts3d_a, *pts3d_b, *ipts;
   int* inl;
@@ -1072,14 +1090,14 @@ __global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p
   double* pts3d_b = ws.pts3d_b;
 
   __shared__ uint32_t s_next;
+  WorkGrab wgrab;
+  const uint32_t grain = work_grain(p.n_chunk);
   uint32_t pl_static = blockIdx.x;
   for (;;) {
     wv_sync();
     uint32_t pl;
     if (p.active_count != nullptr) {  // pipeline: pairs handed out dynamically (work counter [17])
-      if (threadIdx.x == 0) s_next = atomicAdd(p.active_count + 17, 1u);
-      wv_sync();
-      pl = s_next;
+      pl = grab_item(wgrab, p.active_count + 17, &s_next, threadIdx.x, grain);
     } else {
       pl = pl_static;
       pl_static += gridDim.x;
@@ -1511,14 +1529,14 @@ __global__ __launch_bounds__(64) void k_sample(const VerifyParams p) {
   typedef Fam<FAM> F;
   const int lane = threadIdx.x;
   __shared__ uint32_t s_next;
+  WorkGrab wgrab;
+  const uint32_t grain = work_grain(p.n_chunk);
   uint32_t pl_static = blockIdx.x;
   for (;;) {
     wv_sync();
     uint32_t pl;
     if (FAM == FAM_H) {  // thousands of draws per pair: dynamic hand-out as in k_replay; E / F rounds are too short for it
-      if (lane == 0) s_next = atomicAdd(p.active_count + 18, 1u);
-      wv_sync();
-      pl = s_next;
+      pl = grab_item(wgrab, p.active_count + 18, &s_next, lane, grain);
     } else {
       pl = pl_static;
       pl_static += gridDim.x;
@@ -1968,11 +1986,11 @@ __global__ __launch_bounds__(64, (FAM == FAM_E ? 1 : 2)) void k_replay(const Ver
   // pairs are handed out dynamically (their cost varies with the number of local optimisations, and from the
   // second round on most of them are inactive): p.active_count[16] is the next pair of this launch
   __shared__ uint32_t s_next;
+  WorkGrab wgrab;
+  const uint32_t grain = work_grain(p.n_chunk);
   for (;;) {
     wv_sync();
-    if (lane == 0) s_next = atomicAdd(p.active_count + 16, 1u);
-    wv_sync();
-    const uint32_t pl = s_next;
+    const uint32_t pl = grab_item(wgrab, p.active_count + 16, &s_next, lane, grain);
     if (pl >= p.n_chunk) break;
     const uint32_t pi = p.pair0 + pl;
     FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
@@ -2168,11 +2186,11 @@ __global__ __launch_bounds__(64, (TAIL ? 1 : 4)) void k_replay_lo(const VerifyPa
   const int lane = threadIdx.x;
   const WgScratch ws = wg_scratch(p);
   __shared__ uint32_t s_next;
+  WorkGrab wgrab;
+  const uint32_t grain = work_grain(p.n_work);
   for (;;) {
     wv_sync();
-    if (lane == 0) s_next = atomicAdd(p.active_count + 16, 1u);
-    wv_sync();
-    const uint32_t widx = s_next;
+    const uint32_t widx = grab_item(wgrab, p.active_count + 16, &s_next, lane, grain);
     if (widx >= p.n_work) break;
     const uint32_t pl = p.worklist ? p.worklist[widx] : widx;
     const uint32_t pi = p.pair0 + pl;
@@ -2585,11 +2603,11 @@ __global__ __launch_bounds__(64, 2) void k_lo_prepare(const VerifyParams p) {  /
   const int lane = threadIdx.x;
   const WgScratch ws = wg_scratch(p);
   __shared__ uint32_t s_next;
+  WorkGrab wgrab;
+  const uint32_t grain = work_grain(p.n_work);
   for (;;) {
     wv_sync();
-    if (lane == 0) s_next = atomicAdd(p.active_count + 19, 1u);
-    wv_sync();
-    const uint32_t widx = s_next;
+    const uint32_t widx = grab_item(wgrab, p.active_count + 19, &s_next, lane, grain);
     if (widx >= p.n_work) break;
     const uint32_t pl = p.worklist[widx];
     const uint32_t pi = p.pair0 + pl;
