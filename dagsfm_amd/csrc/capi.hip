@@ -806,6 +806,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.counts = nullptr;
   vp.sums = nullptr;
   vp.first_batch[0] = vp.first_batch[1] = vp.first_batch[2] = 0;
+  vp.stats = getenv("DSM_VERIFY_DEBUG") ? 1 : 0;
   vp.lo_reg_prepare = getenv("DSM_LO_PREPARE_WAVE") ? 0 : 1;  // =1: the round-2 kernel (matrix in global scratch) for every problem
   vp.models = nullptr;
   vp.e_work = nullptr;

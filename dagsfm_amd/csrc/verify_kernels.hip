@@ -2047,7 +2047,7 @@ __global__ __launch_bounds__(64, (FAM == FAM_E ? 1 : 2)) void k_replay(const Ver
         const uint32_t cnt = (uint32_t)cnts[(size_t)t * F::MAXM + m];
         const double* M = mods + ((size_t)t * F::MAXM + m) * 9;
         if (cnt >= best_n) {
-          if (lane == 0) atomicAdd(p.active_count + 1 + FAM * 2, 1u);
+          if (p.stats && lane == 0) atomicAdd(p.active_count + 1 + FAM * 2, 1u);
           double sum;
           if constexpr (FAM == FAM_E) {
             TSEC_BEGIN();
@@ -2062,7 +2062,7 @@ __global__ __launch_bounds__(64, (FAM == FAM_E ? 1 : 2)) void k_replay(const Ver
             best_sum = sum;
             for (int k = 0; k < 9; ++k) best_model[k] = M[k];
             if (cnt > (uint32_t)F::K && cnt >= (uint32_t)F::LO_MIN) {
-              if (lane == 0) atomicAdd(p.active_count + 2 + FAM * 2, 1u);
+              if (p.stats && lane == 0) atomicAdd(p.active_count + 2 + FAM * 2, 1u);
               int ninl, nlo;
               {
                 TSEC_BEGIN();
@@ -2284,7 +2284,7 @@ __global__ __launch_bounds__(64, (TAIL ? 1 : 4)) void k_replay_lo(const VerifyPa
         const uint32_t cnt = (uint32_t)cnts[(size_t)t * F::MAXM + m];
         const double* M = mods + ((size_t)t * F::MAXM + m) * 9;
         if (cnt >= best_n) {
-          if (lane == 0) atomicAdd(p.active_count + 1 + FAM * 2, 1u);
+          if (p.stats && lane == 0) atomicAdd(p.active_count + 1 + FAM * 2, 1u);
           double sum;
           if constexpr (FAM == FAM_E) {
             uint32_t cnt_again;
@@ -2297,7 +2297,7 @@ __global__ __launch_bounds__(64, (TAIL ? 1 : 4)) void k_replay_lo(const VerifyPa
             best_sum = sum;
             for (int k = 0; k < 9; ++k) best_model[k] = M[k];
             if (cnt > (uint32_t)F::K && cnt >= (uint32_t)F::LO_MIN) {
-              if (lane == 0) atomicAdd(p.active_count + 2 + FAM * 2, 1u);
+              if (p.stats && lane == 0) atomicAdd(p.active_count + 2 + FAM * 2, 1u);
               if constexpr (FAM != FAM_E) {  // the residuals of the new best model, for the compaction
                 score_model<FAM>(w, M, max_residual, true);
                 wv_sync();
