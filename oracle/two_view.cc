@@ -22,11 +22,9 @@
 // an explicit per-pair seed and draw E -> F -> H -> watermark from the one stream, in the order
 // of two_view_geometry.cc:325-342, 547-549.
 //
-// The generated straight-line polynomial code of the 5-point solver
-// (estimators/essential_matrix_poly.h, _coeffs.h) is not restated term by term: the same
-// 10x20 constraint matrix and degree-10 determinant polynomial are built with generic
-// polynomial arithmetic (fivept_build_A / fivept_det_poly below), which is mathematically the
-// same system with a different floating-point evaluation order.
+// The generated straight-line polynomial code of the 5-point solver (estimators/essential_matrix_poly.h,
+// _coeffs.h) is evaluated in the reference's own order of sums and products: that order is kept as a term
+// table (dagsfm_amd/csrc/fivept_terms.tbl) and expanded at build time (fivept_build_A / fivept_det_poly).
 //
 // Parity pinning: every known-answer test the reference holds for these functions is restated
 // in tests/test_oracle_estimators.py.  TwoViewGeometry::Estimate* itself and LO-RANSAC over the
@@ -410,128 +408,41 @@ struct TranslationEstimator {
   }
 };
 
-// ---- 5-point (Nister): generic polynomial arithmetic in (x, y, z) ----------------------------
-// Monomial tables.  Lin: [x, y, z, 1].  Quad (10) and Cubic (20) as listed; the cubic order is the
-// column order of the 10x20 matrix A (first 10 columns are eliminated, essential_matrix.cc:78-81).
-static const int kQuadExp[10][3] = {{2, 0, 0}, {0, 2, 0}, {0, 0, 2}, {1, 1, 0}, {1, 0, 1},
-                                    {0, 1, 1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
-static const int kCubicExp[20][3] = {{3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 0, 0}, {0, 2, 1},
-                                     {0, 2, 0}, {1, 1, 1}, {1, 1, 0}, {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2},
-                                     {0, 1, 1}, {0, 1, 0}, {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
-static const int kLinExp[4][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
-
-struct FivePtTables {
-  int LL[4][4];    // lin x lin   -> quad index
-  int QL[10][4];   // quad x lin  -> cubic index
-  FivePtTables() {
-    for (int a = 0; a < 4; ++a)
-      for (int b = 0; b < 4; ++b) {
-        int e[3];
-        for (int k = 0; k < 3; ++k) e[k] = kLinExp[a][k] + kLinExp[b][k];
-        for (int q = 0; q < 10; ++q)
-          if (kQuadExp[q][0] == e[0] && kQuadExp[q][1] == e[1] && kQuadExp[q][2] == e[2]) LL[a][b] = q;
-      }
-    for (int a = 0; a < 10; ++a)
-      for (int b = 0; b < 4; ++b) {
-        int e[3];
-        for (int k = 0; k < 3; ++k) e[k] = kQuadExp[a][k] + kLinExp[b][k];
-        for (int q = 0; q < 20; ++q)
-          if (kCubicExp[q][0] == e[0] && kCubicExp[q][1] == e[1] && kCubicExp[q][2] == e[2]) QL[a][b] = q;
-      }
+// ---- 5-point (Nister): steps 3 and 4 in the reference's own evaluation order -------------------
+// The reference builds the 10 x 20 constraint matrix and the degree-10 determinant polynomial with
+// generated straight-line code (essential_matrix.cc:76-77 `#include "estimators/essential_matrix_poly.h"`,
+// :101-102 `#include "estimators/essential_matrix_coeffs.h"`).  The order of its sums and products is data, kept
+// in dagsfm_amd/csrc/fivept_terms.tbl (tools/gen_fivept_tables.py) and expanded into fivept_poly_gen.inc by
+// this directory's Makefile; tests/test_fivept_reference_order.py compares both functions bit for bit with the
+// reference's headers compiled behind a shim (oracle/_ref/libfivept_ref.so).
+// e = E.data() (9 x 4, column-major), a = A.data() (10 x 20, column-major), b = B.data() (13 x 3, column-major).
+static void fivept_build_A(const double* e, double* a) {
+  double e2[36];
+  double e3[36];
+  for (size_t i = 0; i < 36; ++i) {
+    e2[i] = e[i] * e[i];
+    e3[i] = e2[i] * e[i];
   }
-};
-static const FivePtTables kFivePt;
-
-// quad += lin_a * lin_b ; cubic (+/-)= quad * lin
-static void lin_mul_acc(const double* a, const double* b, double* quad) {
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j) quad[kFivePt.LL[i][j]] += a[i] * b[j];
+#define FIVEPT_E(k) e[k]
+#define FIVEPT_E2(k) e2[k]
+#define FIVEPT_E3(k) e3[k]
+#define FIVEPT_A(i) a[i]
+#define FIVEPT_EMIT_A
+#include "fivept_poly_gen.inc"
+#undef FIVEPT_EMIT_A
+#undef FIVEPT_A
+#undef FIVEPT_E3
+#undef FIVEPT_E2
+#undef FIVEPT_E
 }
-static void quad_lin_mul_acc(const double* q, const double* l, double sign, double* cubic) {
-  for (int i = 0; i < 10; ++i)
-    for (int j = 0; j < 4; ++j) cubic[kFivePt.QL[i][j]] += sign * (q[i] * l[j]);
-}
-
-// Builds A (10 x 20, row r, column = cubic monomial): row 0 = det(E) = 0, rows 1..9 =
-// (E E^T E - 0.5 trace(E E^T) E)(i,j) = 0 row-major, with E = x E0 + y E1 + z E2 + E3 and
-// Ek = column k of the 9x4 null-space basis read as a row-major 3x3.
-static void fivept_build_A(const double Eb[9][4], double A[10][20]) {
-  // lin[r][c][k]
-  double lin[3][3][4];
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c)
-      for (int k = 0; k < 4; ++k) lin[r][c][k] = Eb[r * 3 + c][k];
-  for (int r = 0; r < 10; ++r)
-    for (int c = 0; c < 20; ++c) A[r][c] = 0.0;
-  // det(E) = E00 (E11 E22 - E12 E21) - E01 (E10 E22 - E12 E20) + E02 (E10 E21 - E11 E20)
-  {
-    double m0[10] = {0}, m1[10] = {0}, m2[10] = {0}, tmp[10];
-    lin_mul_acc(lin[1][1], lin[2][2], m0);
-    std::fill(tmp, tmp + 10, 0.0);
-    lin_mul_acc(lin[1][2], lin[2][1], tmp);
-    for (int i = 0; i < 10; ++i) m0[i] -= tmp[i];
-    lin_mul_acc(lin[1][0], lin[2][2], m1);
-    std::fill(tmp, tmp + 10, 0.0);
-    lin_mul_acc(lin[1][2], lin[2][0], tmp);
-    for (int i = 0; i < 10; ++i) m1[i] -= tmp[i];
-    lin_mul_acc(lin[1][0], lin[2][1], m2);
-    std::fill(tmp, tmp + 10, 0.0);
-    lin_mul_acc(lin[1][1], lin[2][0], tmp);
-    for (int i = 0; i < 10; ++i) m2[i] -= tmp[i];
-    quad_lin_mul_acc(m0, lin[0][0], 1.0, A[0]);
-    quad_lin_mul_acc(m1, lin[0][1], -1.0, A[0]);
-    quad_lin_mul_acc(m2, lin[0][2], 1.0, A[0]);
-  }
-  // EEt(i,j) = sum_k E(i,k) E(j,k)
-  double EEt[3][3][10];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      for (int q = 0; q < 10; ++q) EEt[i][j][q] = 0.0;
-      for (int k = 0; k < 3; ++k) lin_mul_acc(lin[i][k], lin[j][k], EEt[i][j]);
-    }
-  double half_trace[10];
-  for (int q = 0; q < 10; ++q) half_trace[q] = 0.5 * (EEt[0][0][q] + EEt[1][1][q] + EEt[2][2][q]);
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      double* row = A[1 + i * 3 + j];
-      for (int k = 0; k < 3; ++k) quad_lin_mul_acc(EEt[i][k], lin[k][j], 1.0, row);
-      quad_lin_mul_acc(half_trace, lin[i][j], -1.0, row);
-    }
-}
-
-// 1-D polynomial helpers, coefficients lowest degree first.
-static void poly_mul(const double* a, int na, const double* b, int nb, double* out) {
-  for (int i = 0; i < na + nb - 1; ++i) out[i] = 0.0;
-  for (int i = 0; i < na; ++i)
-    for (int j = 0; j < nb; ++j) out[i + j] += a[i] * b[j];
-}
-
-// det of the 3x3 polynomial matrix B(z) (essential_matrix.cc:83-103): column 0 and 1 entries have
-// degree 3, column 2 entries degree 4.  B is 13 x 3 as in the reference (highest degree first per
-// block); returns the 11 coefficients highest degree first.
-static void fivept_det_poly(const double B[13][3], double coeffs[11]) {
-  double b[3][3][5];  // b[j][c][deg], lowest first
-  for (int j = 0; j < 3; ++j) {
-    for (int d = 0; d < 4; ++d) {
-      b[j][0][d] = B[3 - d][j];
-      b[j][1][d] = B[7 - d][j];
-    }
-    b[j][0][4] = b[j][1][4] = 0.0;
-    for (int d = 0; d < 5; ++d) b[j][2][d] = B[12 - d][j];
-  }
-  double det[11];
-  for (int i = 0; i < 11; ++i) det[i] = 0.0;
-  // cofactor expansion along column 0: sum_j sign_j * b[j][0] * (b[j1][1] b[j2][2] - b[j2][1] b[j1][2])
-  for (int j = 0; j < 3; ++j) {
-    const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
-    double p1[8], p2[8], minor[8], term[11];
-    poly_mul(b[j1][1], 4, b[j2][2], 5, p1);
-    poly_mul(b[j2][1], 4, b[j1][2], 5, p2);
-    for (int i = 0; i < 8; ++i) minor[i] = p1[i] - p2[i];
-    poly_mul(b[j][0], 4, minor, 8, term);
-    for (int i = 0; i < 11; ++i) det[i] += term[i];
-  }
-  for (int i = 0; i < 11; ++i) coeffs[i] = det[10 - i];
+static void fivept_det_poly(const double* b, double* coeffs) {
+#define FIVEPT_B(k) b[k]
+#define FIVEPT_C(i) coeffs[i]
+#define FIVEPT_EMIT_C
+#include "fivept_poly_gen.inc"
+#undef FIVEPT_EMIT_C
+#undef FIVEPT_C
+#undef FIVEPT_B
 }
 
 struct EssentialFivePoint {
@@ -547,34 +458,36 @@ struct EssentialFivePoint {
       Q(i, 6) = x1_0; Q(i, 7) = x1_1; Q(i, 8) = 1;
     }
     const SVD svd = jacobi_svd(Q, false);
-    double Eb[9][4];
+    double Ecm[36];  // E = svd.matrixV().block<9, 4>(0, 5), column-major like Eigen's E.data()
     for (int r = 0; r < 9; ++r)
-      for (int c = 0; c < 4; ++c) Eb[r][c] = svd.V(r, 5 + c);
-    double A[10][20];
-    fivept_build_A(Eb, A);
+      for (int c = 0; c < 4; ++c) Ecm[c * 9 + r] = svd.V(r, 5 + c);
+#define Eb(r, c) Ecm[(c) * 9 + (r)]
+    double Acm[200];  // A.data(): A(r, c) = Acm[c * 10 + r]
+    fivept_build_A(Ecm, Acm);
     Mat A1(10, 10), A2(10, 10), AA;
     for (int r = 0; r < 10; ++r)
       for (int c = 0; c < 10; ++c) {
-        A1(r, c) = A[r][c];
-        A2(r, c) = A[r][10 + c];
+        A1(r, c) = Acm[c * 10 + r];
+        A2(r, c) = Acm[(10 + c) * 10 + r];
       }
     partial_piv_lu_solve(A1, A2, &AA);
-    double B[13][3];
+    double Bcm[39];  // B.data(): B(r, c) = Bcm[c * 13 + r]
+#define B(r, c) Bcm[(c) * 13 + (r)]
     for (int i = 0; i < 3; ++i) {
-      B[0][i] = 0; B[4][i] = 0; B[8][i] = 0;
+      B(0, i) = 0; B(4, i) = 0; B(8, i) = 0;
       for (int k = 0; k < 3; ++k) {
-        B[1 + k][i] = AA(i * 2 + 4, k);
-        B[5 + k][i] = AA(i * 2 + 4, 3 + k);
+        B(1 + k, i) = AA(i * 2 + 4, k);
+        B(5 + k, i) = AA(i * 2 + 4, 3 + k);
       }
-      for (int k = 0; k < 4; ++k) B[9 + k][i] = AA(i * 2 + 4, 6 + k);
+      for (int k = 0; k < 4; ++k) B(9 + k, i) = AA(i * 2 + 4, 6 + k);
       for (int k = 0; k < 3; ++k) {
-        B[0 + k][i] -= AA(i * 2 + 5, k);
-        B[4 + k][i] -= AA(i * 2 + 5, 3 + k);
+        B(0 + k, i) -= AA(i * 2 + 5, k);
+        B(4 + k, i) -= AA(i * 2 + 5, 3 + k);
       }
-      for (int k = 0; k < 4; ++k) B[8 + k][i] -= AA(i * 2 + 5, 6 + k);
+      for (int k = 0; k < 4; ++k) B(8 + k, i) -= AA(i * 2 + 5, 6 + k);
     }
     double c11[11];
-    fivept_det_poly(B, c11);
+    fivept_det_poly(Bcm, c11);
     std::vector<double> coeffs(c11, c11 + 11), roots_real, roots_imag;
     if (!FindPolynomialRootsCompanionMatrix(coeffs, &roots_real, &roots_imag)) return {};
     std::vector<M_t> models;
@@ -587,9 +500,9 @@ struct EssentialFivePoint {
       const double z4 = z3 * z1;
       Mat3 Bz;
       for (int j = 0; j < 3; ++j) {
-        Bz(j, 0) = B[0][j] * z3 + B[1][j] * z2 + B[2][j] * z1 + B[3][j];
-        Bz(j, 1) = B[4][j] * z3 + B[5][j] * z2 + B[6][j] * z1 + B[7][j];
-        Bz(j, 2) = B[8][j] * z4 + B[9][j] * z3 + B[10][j] * z2 + B[11][j] * z1 + B[12][j];
+        Bz(j, 0) = B(0, j) * z3 + B(1, j) * z2 + B(2, j) * z1 + B(3, j);
+        Bz(j, 1) = B(4, j) * z3 + B(5, j) * z2 + B(6, j) * z1 + B(7, j);
+        Bz(j, 2) = B(8, j) * z4 + B(9, j) * z3 + B(10, j) * z2 + B(11, j) * z1 + B(12, j);
       }
       const SVD s3 = jacobi_svd(to_mat(Bz), false);
       const double X0 = s3.V(0, 2), X1 = s3.V(1, 2), X2 = s3.V(2, 2);
@@ -597,7 +510,7 @@ struct EssentialFivePoint {
       if (std::abs(X2) < kMaxX3) continue;
       double ev[9];
       const double sx = X0 / X2, sy = X1 / X2;
-      for (int k = 0; k < 9; ++k) ev[k] = Eb[k][0] * sx + Eb[k][1] * sy + Eb[k][2] * z1 + Eb[k][3];
+      for (int k = 0; k < 9; ++k) ev[k] = Eb(k, 0) * sx + Eb(k, 1) * sy + Eb(k, 2) * z1 + Eb(k, 3);
       double nn = 0.0;
       for (int k = 0; k < 9; ++k) nn += ev[k] * ev[k];
       const double norm = std::sqrt(nn);
@@ -605,6 +518,8 @@ struct EssentialFivePoint {
       for (int k = 0; k < 9; ++k) model.m[k] = ev[k] / norm;
       models.push_back(model);
     }
+#undef B
+#undef Eb
     return models;
   }
   static void Residuals(const std::vector<Vec2>& p1, const std::vector<Vec2>& p2, const M_t& E, std::vector<double>* r) {
@@ -1450,6 +1365,12 @@ static std::vector<Vec2> ToVec2(const double* p, int n) {
 }
 
 extern "C" {
+
+// Steps 3 / 4 of the 5-point solver alone, for tests/test_fivept_reference_order.py (layouts of Eigen's .data()).
+void oracle_fivept_build_A(const double* e_colmajor_9x4, double* a_colmajor_10x20) {
+  oracle::fivept_build_A(e_colmajor_9x4, a_colmajor_10x20);
+}
+void oracle_fivept_coeffs(const double* b_colmajor_13x3, double* coeffs11) { oracle::fivept_det_poly(b_colmajor_13x3, coeffs11); }
 
 // TwoViewGeometry::Estimate (two_view_geometry.cc:113-126) for one pair with an explicit PRNG seed.
 // points: n x 2 doubles (FeatureKeypointsToPointsVector output); matches: n_matches x 2 uint32.
