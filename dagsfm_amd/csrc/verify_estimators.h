@@ -432,185 +432,64 @@ DSM_DEV int homography_four_point_reg(const double* xs, double* models) {
 }
 
 // ---------------------------------------------------------------------------------- 5-point E
-// Monomial tables of the generic polynomial construction of Nister's 10 x 20 system (see
-// oracle/two_view.cc: the reference's generated essential_matrix_poly.h / _coeffs.h are replaced by
-// generic polynomial arithmetic; column order x^3 y^3 x^2y xy^2 x^2z x^2 y^2z y^2 xyz xy | xz^2 xz x yz^2 yz y z^3 z^2 z 1).
-__device__ const int kLL[4][4] = {{0, 3, 4, 6}, {3, 1, 5, 7}, {4, 5, 2, 8}, {6, 7, 8, 9}};
-__device__ const int kQL[10][4] = {{0, 2, 4, 5},   {3, 1, 6, 7},   {10, 13, 16, 17}, {2, 3, 8, 9},    {4, 8, 10, 11},
-                                   {8, 6, 13, 14}, {5, 9, 11, 12}, {9, 7, 14, 15},   {11, 14, 17, 18}, {12, 15, 18, 19}};
+// Steps 3 and 4 of EssentialMatrixFivePointEstimator::Estimate evaluate machine-generated straight-line code
+// (/root/reference/src/estimators/essential_matrix.cc:76-77 includes essential_matrix_poly.h, :101-102
+// essential_matrix_coeffs.h).  The ORDER of its sums and products decides the rounding, and it is data: the term table
+// fivept_terms.tbl (tools/gen_fivept_tables.py), expanded by the Makefile into fivept_poly_gen.inc -- straight-line
+// statements for the lane-per-hypothesis kernels (every index a compile-time constant: registers) and packed term
+// words for the 16-lane cooperative solver (verify_fivept_coop.h), which interprets them.  Layouts of the reference:
+// e = E.data() (9 x 4 column-major), a = A.data() (10 x 20 column-major), b = B.data() (13 x 3 column-major); here
+// Eb[r*4 + c], A[r*20 + c], B[r*3 + c].
+#define FIVEPT_TABLE_QUAL __device__
+#define FIVEPT_EMIT_TABLES
+#include "fivept_poly_gen.inc"
+#undef FIVEPT_EMIT_TABLES
 
-DSM_DEV void lin_mul_acc(const double* a, const double* b, double* quad) {
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j) quad[kLL[i][j]] += a[i] * b[j];
-}
-DSM_DEV void quad_lin_mul_acc(const double* q, const double* l, double sign, double* cubic) {
-  for (int i = 0; i < 10; ++i)
-    for (int j = 0; j < 4; ++j) cubic[kQL[i][j]] += sign * (q[i] * l[j]);
-}
-DSM_DEV void poly_mul(const double* a, int na, const double* b, int nb, double* out) {
-  for (int i = 0; i < na + nb - 1; ++i) out[i] = 0.0;
-  for (int i = 0; i < na; ++i)
-    for (int j = 0; j < nb; ++j) out[i + j] += a[i] * b[j];
-}
+// Zero-instruction "the value may have changed" marker: the optimiser cannot merge or move arithmetic on x across it.
+DSM_DEV void fivept_launder(double& x) { asm volatile("" : "+v"(x)); }
 
-// Steps 3-5 of EssentialMatrixFivePointEstimator::Estimate (/root/reference/src/estimators/essential_matrix.cc:76-147)
-// from the 9 x 4 null-space basis Eb[r*4 + c] = svd.matrixV()(r, 5 + c).  Up to 10 models.
-// `ws`: optional workspace of FIVEPT_WS doubles (LDS when a single lane runs the local optimisation,
-// so that its long dependent chains wait on LDS instead of scratch memory); nullptr = private arrays.
-#define FIVEPT_WS (200 + 100 + 100 + 100)
-// Step 3: the 10 x 20 constraint matrix A[r*20 + c] (essential_matrix_poly.h restated by polynomial arithmetic).
-DSM_DEV void five_point_build_A(const double* Eb, double* A) {
+// Step 3: the 10 x 20 constraint matrix, element A(r, c) written to out[(r*20 + c) * ES] (ES = 1: one hypothesis'
+// 200 doubles back to back; 64: the hypotheses of a wave interleaved, element q of lane l at out[q * 64 + l]:
+// coalesced stores).  Every index is a compile-time constant: e and e2 (144 VGPRs) stay in registers.
+// Left to itself the optimiser merges the common sub-products e[i]*e[j] of all 5 600 terms into hundreds of
+// long-lived values (968 spilled VGPRs); a fence after every FIVEPT_GROUP statements confines merging and
+// scheduling to the group -- the arithmetic of every statement is untouched.
+#define FIVEPT_GROUP 4
+template <int ES = 1>
+DSM_DEV void five_point_build_A(const double (&Eb)[36], double* out) {
   LSEC_BEGIN();
-  for (int i = 0; i < 200; ++i) A[i] = 0.0;
-  // lin(r, c) = Eb row (3r + c): 4 coefficients (x, y, z, 1)
-#define LIN(r, c) (Eb + ((r) * 3 + (c)) * 4)
-  {
-    double m0[10], m1[10], m2[10], tmp[10];
-    for (int i = 0; i < 10; ++i) m0[i] = m1[i] = m2[i] = tmp[i] = 0.0;
-    lin_mul_acc(LIN(1, 1), LIN(2, 2), m0);
-    lin_mul_acc(LIN(1, 2), LIN(2, 1), tmp);
-    for (int i = 0; i < 10; ++i) {
-      m0[i] -= tmp[i];
-      tmp[i] = 0.0;
-    }
-    lin_mul_acc(LIN(1, 0), LIN(2, 2), m1);
-    lin_mul_acc(LIN(1, 2), LIN(2, 0), tmp);
-    for (int i = 0; i < 10; ++i) {
-      m1[i] -= tmp[i];
-      tmp[i] = 0.0;
-    }
-    lin_mul_acc(LIN(1, 0), LIN(2, 1), m2);
-    lin_mul_acc(LIN(1, 1), LIN(2, 0), tmp);
-    for (int i = 0; i < 10; ++i) m2[i] -= tmp[i];
-    quad_lin_mul_acc(m0, LIN(0, 0), 1.0, A);
-    quad_lin_mul_acc(m1, LIN(0, 1), -1.0, A);
-    quad_lin_mul_acc(m2, LIN(0, 2), 1.0, A);
+  // e2[i] = e[i] * e[i], e3[i] = e2[i] * e[i] as in the header's preamble; the 38 uses of e3 recompute the product
+  // (same value) so that only e and e2 stay live
+  double e[36], e2[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) {
+    e[k] = Eb[(k % 9) * 4 + k / 9];
+    e2[k] = e[k] * e[k];
   }
-  {
-    double EEt[90];  // [i][j][10]
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) {
-        double* e = EEt + (i * 3 + j) * 10;
-        for (int q = 0; q < 10; ++q) e[q] = 0.0;
-        for (int k = 0; k < 3; ++k) lin_mul_acc(LIN(i, k), LIN(j, k), e);
-      }
-    double half_trace[10];
-    for (int q = 0; q < 10; ++q) half_trace[q] = 0.5 * (EEt[0 * 10 + q] + EEt[4 * 10 + q] + EEt[8 * 10 + q]);
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) {
-        double* row = A + (1 + i * 3 + j) * 20;
-        for (int k = 0; k < 3; ++k) quad_lin_mul_acc(EEt + (i * 3 + k) * 10, LIN(k, j), 1.0, row);
-        quad_lin_mul_acc(half_trace, LIN(i, j), -1.0, row);
-      }
+#define FIVEPT_E(k) e[k]
+#define FIVEPT_E2(k) e2[k]
+#define FIVEPT_E3(k) (e2[k] * e[k])
+#define FIVEPT_A(i) out[(((i) % 10) * 20 + (i) / 10) * ES]
+#define FIVEPT_FENCE(n)                               \
+  if ((n) % FIVEPT_GROUP == FIVEPT_GROUP - 1) {       \
+    _Pragma("unroll") for (int k = 0; k < 36; ++k) {  \
+      fivept_launder(e[k]);                           \
+      fivept_launder(e2[k]);                          \
+    }                                                 \
   }
-#undef LIN
+#define FIVEPT_EMIT_A
+#include "fivept_poly_gen.inc"
+#undef FIVEPT_EMIT_A
+#undef FIVEPT_FENCE
+#undef FIVEPT_A
+#undef FIVEPT_E3
+#undef FIVEPT_E2
+#undef FIVEPT_E
   LSEC_END(8);
 }
 
-// Step 3 again, row by row with every index a compile-time constant, so that the accumulators live in
-// registers instead of a 200-double private array (the batch kernel k_solve_e_build): row r is written to
-// out[r*20 .. r*20+20) as soon as it is complete.  E E^T entries are recomputed per row (three of them, 144
-// multiply-adds) rather than kept (90 doubles).  Operation order per output element as in five_point_build_A.
-constexpr int cLL[4][4] = {{0, 3, 4, 6}, {3, 1, 5, 7}, {4, 5, 2, 8}, {6, 7, 8, 9}};
-constexpr int cQL[10][4] = {{0, 2, 4, 5},   {3, 1, 6, 7},   {10, 13, 16, 17}, {2, 3, 8, 9},    {4, 8, 10, 11},
-                            {8, 6, 13, 14}, {5, 9, 11, 12}, {9, 7, 14, 15},   {11, 14, 17, 18}, {12, 15, 18, 19}};
-template <int RA, int CA, int RB, int CB>
-DSM_DEV void c_lin_mul_acc(const double (&Eb)[36], double (&quad)[10]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) quad[cLL[i][j]] += Eb[(RA * 3 + CA) * 4 + i] * Eb[(RB * 3 + CB) * 4 + j];
-}
-template <int RL, int CL>
-DSM_DEV void c_quad_lin_mul_acc(const double (&q)[10], const double (&Eb)[36], double sign, double (&cubic)[20]) {
-#pragma unroll
-  for (int i = 0; i < 10; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) cubic[cQL[i][j]] += sign * (q[i] * Eb[(RL * 3 + CL) * 4 + j]);
-}
-template <int I, int K>
-DSM_DEV void c_EEt(const double (&Eb)[36], double (&e)[10]) {  // (E E^T)(I, K) = sum_m lin(I, m) * lin(K, m)
-#pragma unroll
-  for (int q = 0; q < 10; ++q) e[q] = 0.0;
-  c_lin_mul_acc<I, 0, K, 0>(Eb, e);
-  c_lin_mul_acc<I, 1, K, 1>(Eb, e);
-  c_lin_mul_acc<I, 2, K, 2>(Eb, e);
-}
-// ES: element stride of the output (1 = one hypothesis' 200 doubles back to back; 64 = the hypotheses of a wave
-// interleaved, element e of lane l at out[e * 64 + l]: coalesced stores)
-template <int I, int J, int ES = 1>
-DSM_DEV void c_trace_row(const double (&Eb)[36], const double (&ht)[10], double* out) {
-  double row[20];
-#pragma unroll
-  for (int q = 0; q < 20; ++q) row[q] = 0.0;
-  double e[10];
-  c_EEt<I, 0>(Eb, e);
-  c_quad_lin_mul_acc<0, J>(e, Eb, 1.0, row);
-  c_EEt<I, 1>(Eb, e);
-  c_quad_lin_mul_acc<1, J>(e, Eb, 1.0, row);
-  c_EEt<I, 2>(Eb, e);
-  c_quad_lin_mul_acc<2, J>(e, Eb, 1.0, row);
-  c_quad_lin_mul_acc<I, J>(ht, Eb, -1.0, row);
-#pragma unroll
-  for (int q = 0; q < 20; ++q) out[((1 + I * 3 + J) * 20 + q) * ES] = row[q];
-}
-template <int ES = 1>
-DSM_DEV void five_point_build_A_rows(const double* Eb_in, double* out) {
-  double Eb[36];
-#pragma unroll
-  for (int k = 0; k < 36; ++k) Eb[k] = Eb_in[k];
-  {  // determinant row
-    double m0[10], m1[10], m2[10], tmp[10], row[20];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) m0[i] = m1[i] = m2[i] = tmp[i] = 0.0;
-#pragma unroll
-    for (int q = 0; q < 20; ++q) row[q] = 0.0;
-    c_lin_mul_acc<1, 1, 2, 2>(Eb, m0);
-    c_lin_mul_acc<1, 2, 2, 1>(Eb, tmp);
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      m0[i] -= tmp[i];
-      tmp[i] = 0.0;
-    }
-    c_lin_mul_acc<1, 0, 2, 2>(Eb, m1);
-    c_lin_mul_acc<1, 2, 2, 0>(Eb, tmp);
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      m1[i] -= tmp[i];
-      tmp[i] = 0.0;
-    }
-    c_lin_mul_acc<1, 0, 2, 1>(Eb, m2);
-    c_lin_mul_acc<1, 1, 2, 0>(Eb, tmp);
-#pragma unroll
-    for (int i = 0; i < 10; ++i) m2[i] -= tmp[i];
-    c_quad_lin_mul_acc<0, 0>(m0, Eb, 1.0, row);
-    c_quad_lin_mul_acc<0, 1>(m1, Eb, -1.0, row);
-    c_quad_lin_mul_acc<0, 2>(m2, Eb, 1.0, row);
-#pragma unroll
-    for (int q = 0; q < 20; ++q) out[q * ES] = row[q];
-  }
-  double ht[10];
-  {
-    double e0[10], e1[10], e2[10];
-    c_EEt<0, 0>(Eb, e0);
-    c_EEt<1, 1>(Eb, e1);
-    c_EEt<2, 2>(Eb, e2);
-#pragma unroll
-    for (int q = 0; q < 10; ++q) ht[q] = 0.5 * (e0[q] + e1[q] + e2[q]);
-  }
-  c_trace_row<0, 0, ES>(Eb, ht, out);
-  c_trace_row<0, 1, ES>(Eb, ht, out);
-  c_trace_row<0, 2, ES>(Eb, ht, out);
-  c_trace_row<1, 0, ES>(Eb, ht, out);
-  c_trace_row<1, 1, ES>(Eb, ht, out);
-  c_trace_row<1, 2, ES>(Eb, ht, out);
-  c_trace_row<2, 0, ES>(Eb, ht, out);
-  c_trace_row<2, 1, ES>(Eb, ht, out);
-  c_trace_row<2, 2, ES>(Eb, ht, out);
-}
-
-// Steps 4a: B(z) from rows 4..9 of the eliminated system (S[(r-4)*10 + c] = AA(r, c)) and the determinant
-// polynomial (essential_matrix_coeffs.h restated), highest degree first.
+// Step 4: B(z) from rows 4..9 of the eliminated system (S[(r-4)*10 + c] = AA(r, c); essential_matrix.cc:86-97) and
+// the determinant polynomial (essential_matrix_coeffs.h), highest degree first.
 DSM_DEV void five_point_B_det(const double* S, double* B, double* coeffs) {
   LSEC_BEGIN3();
 #define AAe(r, c) S[((r)-4) * 10 + (c)]
@@ -629,32 +508,37 @@ DSM_DEV void five_point_B_det(const double* S, double* B, double* coeffs) {
     for (int k = 0; k < 4; ++k) B[(8 + k) * 3 + i] -= AAe(i * 2 + 5, 6 + k);
   }
 #undef AAe
-  // determinant polynomial of B(z), highest degree first
-  {
-    double b[45];  // b[(j*3 + c)*5 + deg], lowest degree first
-    for (int j = 0; j < 3; ++j) {
-      for (int d = 0; d < 4; ++d) {
-        b[(j * 3 + 0) * 5 + d] = B[(3 - d) * 3 + j];
-        b[(j * 3 + 1) * 5 + d] = B[(7 - d) * 3 + j];
-      }
-      b[(j * 3 + 0) * 5 + 4] = 0.0;
-      b[(j * 3 + 1) * 5 + 4] = 0.0;
-      for (int d = 0; d < 5; ++d) b[(j * 3 + 2) * 5 + d] = B[(12 - d) * 3 + j];
-    }
-    double det[11];
-    for (int i = 0; i < 11; ++i) det[i] = 0.0;
-    for (int j = 0; j < 3; ++j) {
-      const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
-      double p1[8], p2[8], minor[8], term[11];
-      poly_mul(b + (j1 * 3 + 1) * 5, 4, b + (j2 * 3 + 2) * 5, 5, p1);
-      poly_mul(b + (j2 * 3 + 1) * 5, 4, b + (j1 * 3 + 2) * 5, 5, p2);
-      for (int i = 0; i < 8; ++i) minor[i] = p1[i] - p2[i];
-      poly_mul(b + (j * 3 + 0) * 5, 4, minor, 8, term);
-      for (int i = 0; i < 11; ++i) det[i] += term[i];
-    }
-    for (int i = 0; i < 11; ++i) coeffs[i] = det[10 - i];
-  }
+#define FIVEPT_B(k) B[((k) % 13) * 3 + (k) / 13]
+#define FIVEPT_C(i) coeffs[i]
+#define FIVEPT_FENCE(n)
+#define FIVEPT_EMIT_C
+#include "fivept_poly_gen.inc"
+#undef FIVEPT_EMIT_C
+#undef FIVEPT_FENCE
+#undef FIVEPT_C
+#undef FIVEPT_B
   LSEC_END3(10);
+}
+
+// One target of the packed term table (the cooperative solver's form of the two functions above): the running sum
+// of products over terms[off[t] .. off[t+1]), factors read from `v` (FivePtVals: [e | e2 | e3] resp. b).
+template <typename V>
+DSM_DEV double five_point_eval_terms(const uint32_t* terms, uint32_t begin, uint32_t end, V v) {
+  double acc = 0.0;
+  for (uint32_t q = begin; q < end; ++q) {
+    const uint32_t w = terms[q];
+    double pr = v[w & 0xff];
+    const uint32_t lit = (w >> 24) & 3;
+    if (lit) pr = (lit == 1 ? 0.5 : (lit == 2 ? 1.5 : 3.0)) * pr;
+    const uint32_t f1 = (w >> 8) & 0xff, f2 = (w >> 16) & 0xff;
+    if (f1 != 0xff) pr = pr * v[f1];
+    if (f2 != 0xff) pr = pr * v[f2];
+    if (q == begin)
+      acc = (w >> 31) ? -pr : pr;
+    else
+      acc = (w >> 31) ? acc - pr : acc + pr;
+  }
+  return acc;
 }
 
 // Steps 3-4a for one lane with private (or caller-provided) storage.
@@ -664,7 +548,11 @@ DSM_DEV void five_point_poly_t(const double* Eb, double* B, double* coeffs, doub
   double* A = WS ? ws : A_loc;  // A[r*20 + c]
   double* A1 = WS ? ws + 200 : A1_loc;
   double* AA = WS ? ws + 300 : AA_loc;
-  five_point_build_A(Eb, A);
+  {
+    double Er[36];
+    for (int k = 0; k < 36; ++k) Er[k] = Eb[k];
+    five_point_build_A<1>(Er, A);
+  }
   LSEC_BEGIN2();
   for (int r = 0; r < 10; ++r)  // A1, AA: column-major 10 x 10
     for (int c = 0; c < 10; ++c) {

@@ -23,12 +23,9 @@
 struct G5Ws {
   double Eb[36];     // null-space basis, [r*4 + c]
   double A[200];     // [r*20 + c]; after the elimination columns 10..19 hold AA
-  double EEt[90];    // [(i*3 + j)*10 + q]
-  double ht[10];     // 0.5 * trace(E E^T)
-  double tmpq[40];   // m0, m1, m2, tmp of the determinant row
+  double ev[108];    // [e | e2 | e3] of the reference's E.data() (9 x 4 column-major): the factors of the term table
   double B[39];      // [row*3 + col]
-  double bp[45];     // b[(j*3 + c)*5 + deg]
-  double term[33];   // the three cofactor terms of det B(z)
+  double bv[39];     // B.data() of the reference (13 x 3 column-major): the factors of the determinant's terms
   double coeffs[11];
   double T[100];     // companion matrix, column-major ld 10
   double re[10], im[10];
@@ -38,15 +35,6 @@ struct G5Ws {
 };
 
 typedef volatile double* g5v;
-
-DSM_DEV void g5_lin_mul_acc(g5v a, g5v b, g5v quad) {
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j) quad[kLL[i][j]] = quad[kLL[i][j]] + a[i] * b[j];
-}
-DSM_DEV void g5_quad_lin_mul_acc(g5v q, g5v l, double sign, g5v cubic) {
-  for (int i = 0; i < 10; ++i)
-    for (int j = 0; j < 4; ++j) cubic[kQL[i][j]] = cubic[kQL[i][j]] + sign * (q[i] * l[j]);
-}
 
 // max over the 16 lanes of a group (exact, order independent)
 DSM_DEV double g5_group_max(double v) {
@@ -426,49 +414,17 @@ DSM_DEV int g5_five_point_finish(G5Ws* ws, int gl, int group_shift) {
   g5v Eb = ws->Eb;
   g5v A = ws->A;
   LSEC_BEGIN();
-#define LIN(r, c) (Eb + ((r) * 3 + (c)) * 4)
-  for (int e = gl; e < 200; e += 16) A[e] = 0.0;
-  // E E^T entries, one per lane
-  if (gl < 9) {
-    const int i = gl / 3, j = gl % 3;
-    g5v e = ws->EEt + gl * 10;
-    for (int q = 0; q < 10; ++q) e[q] = 0.0;
-    for (int k = 0; k < 3; ++k) g5_lin_mul_acc(LIN(i, k), LIN(j, k), e);
+  // step 3: the reference's generated code, interpreted from the packed term table (five_point_eval_terms), the 200
+  // entries dealt out to the 16 lanes
+  for (int k = gl; k < 36; k += 16) {
+    const double e = Eb[(k % 9) * 4 + k / 9];
+    const double e2 = e * e;
+    ws->ev[k] = e;
+    ws->ev[36 + k] = e2;
+    ws->ev[72 + k] = e2 * e;
   }
-  if (gl < 10) ws->ht[gl] = 0.5 * (ws->EEt[0 * 10 + gl] + ws->EEt[4 * 10 + gl] + ws->EEt[8 * 10 + gl]);
-  if (gl == 0) {  // determinant row
-    g5v m0 = ws->tmpq, m1 = ws->tmpq + 10, m2 = ws->tmpq + 20, tmp = ws->tmpq + 30;
-    for (int i = 0; i < 10; ++i) {
-      m0[i] = 0.0;
-      m1[i] = 0.0;
-      m2[i] = 0.0;
-      tmp[i] = 0.0;
-    }
-    g5_lin_mul_acc(LIN(1, 1), LIN(2, 2), m0);
-    g5_lin_mul_acc(LIN(1, 2), LIN(2, 1), tmp);
-    for (int i = 0; i < 10; ++i) {
-      m0[i] = m0[i] - tmp[i];
-      tmp[i] = 0.0;
-    }
-    g5_lin_mul_acc(LIN(1, 0), LIN(2, 2), m1);
-    g5_lin_mul_acc(LIN(1, 2), LIN(2, 0), tmp);
-    for (int i = 0; i < 10; ++i) {
-      m1[i] = m1[i] - tmp[i];
-      tmp[i] = 0.0;
-    }
-    g5_lin_mul_acc(LIN(1, 0), LIN(2, 1), m2);
-    g5_lin_mul_acc(LIN(1, 1), LIN(2, 0), tmp);
-    for (int i = 0; i < 10; ++i) m2[i] = m2[i] - tmp[i];
-    g5_quad_lin_mul_acc(m0, LIN(0, 0), 1.0, A);
-    g5_quad_lin_mul_acc(m1, LIN(0, 1), -1.0, A);
-    g5_quad_lin_mul_acc(m2, LIN(0, 2), 1.0, A);
-  } else if (gl <= 9) {  // trace-constraint rows
-    const int i = (gl - 1) / 3, j = (gl - 1) % 3;
-    g5v row = A + gl * 20;
-    for (int k = 0; k < 3; ++k) g5_quad_lin_mul_acc(ws->EEt + (i * 3 + k) * 10, LIN(k, j), 1.0, row);
-    g5_quad_lin_mul_acc(ws->ht, LIN(i, j), -1.0, row);
-  }
-#undef LIN
+  for (int t = gl; t < 200; t += 16)
+    A[(t % 10) * 20 + t / 10] = five_point_eval_terms(kFivePtATerms, kFivePtAOff[t], kFivePtAOff[t + 1], (g5v)ws->ev);
   LSEC_END(8);
   LSEC_BEGIN2();
   // ---- A[:, :10].partialPivLu().solve(A[:, 10:]) on the augmented 10 x 20 matrix
@@ -531,45 +487,9 @@ DSM_DEV int g5_five_point_finish(G5Ws* ws, int gl, int group_shift) {
 #undef AE
   LSEC_END2(9);
   LSEC_BEGIN3();
-  // ---- determinant polynomial of B(z)
-  if (gl < 3) {
-    const int j = gl;
-    for (int d = 0; d < 4; ++d) {
-      ws->bp[(j * 3 + 0) * 5 + d] = ws->B[(3 - d) * 3 + j];
-      ws->bp[(j * 3 + 1) * 5 + d] = ws->B[(7 - d) * 3 + j];
-    }
-    ws->bp[(j * 3 + 0) * 5 + 4] = 0.0;
-    ws->bp[(j * 3 + 1) * 5 + 4] = 0.0;
-    for (int d = 0; d < 5; ++d) ws->bp[(j * 3 + 2) * 5 + d] = ws->B[(12 - d) * 3 + j];
-  }
-  if (gl < 3) {
-    const int j = gl, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
-    double a1[4], b1[5], a2[4], b2[5], a0[4];
-    for (int d = 0; d < 4; ++d) {
-      a1[d] = ws->bp[(j1 * 3 + 1) * 5 + d];
-      a2[d] = ws->bp[(j2 * 3 + 1) * 5 + d];
-      a0[d] = ws->bp[(j * 3 + 0) * 5 + d];
-    }
-    for (int d = 0; d < 5; ++d) {
-      b1[d] = ws->bp[(j2 * 3 + 2) * 5 + d];
-      b2[d] = ws->bp[(j1 * 3 + 2) * 5 + d];
-    }
-    double p1[8], p2[8], minor[8], term[11];
-    poly_mul(a1, 4, b1, 5, p1);
-    poly_mul(a2, 4, b2, 5, p2);
-    for (int i = 0; i < 8; ++i) minor[i] = p1[i] - p2[i];
-    poly_mul(a0, 4, minor, 8, term);
-    for (int i = 0; i < 11; ++i) ws->term[j * 11 + i] = term[i];
-  }
-  if (gl == 0) {
-    for (int i = 0; i < 11; ++i) {
-      double d = 0.0;
-      d += ws->term[0 * 11 + i];
-      d += ws->term[1 * 11 + i];
-      d += ws->term[2 * 11 + i];
-      ws->coeffs[10 - i] = d;
-    }
-  }
+  // ---- determinant polynomial of B(z): one coefficient per lane (essential_matrix_coeffs.h, term table)
+  for (int k = gl; k < 39; k += 16) ws->bv[k] = ws->B[(k % 13) * 3 + k / 13];
+  if (gl < 11) ws->coeffs[gl] = five_point_eval_terms(kFivePtCTerms, kFivePtCOff[gl], kFivePtCOff[gl + 1], (g5v)ws->bv);
   LSEC_END3(10);
   LSEC_BEGIN4();
   const int nroots = g5_poly_roots(ws, gl);

@@ -1697,7 +1697,7 @@ __global__ __launch_bounds__(64, 2) void k_solve_e_build(const VerifyParams p) {
   double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
   for (int k = 0; k < 36; ++k) slot[EPOLY_EB + k] = Eb[k];
   // the wave's 64 hypotheses interleaved: element e of lane l at block + e * 64 + l (batch is a multiple of 64)
-  five_point_build_A_rows<64>(Eb, p.e_work + ((size_t)pl * p.batch + (size_t)blockIdx.y * 64) * 200 + threadIdx.x);
+  five_point_build_A<64>(Eb, p.e_work + ((size_t)pl * p.batch + (size_t)blockIdx.y * 64) * 200 + threadIdx.x);
 }
 
 // A[:, :10].partialPivLu().solve(A[:, 10:]) (essential_matrix.cc:80) with the 10 x 10 factor in lane-interleaved
@@ -1708,7 +1708,7 @@ __global__ __launch_bounds__(64, 2) void k_solve_e_build(const VerifyParams p) {
 #define ELU_SMEM (100 * 64 * 8 + 10 * 64)
 // Ag: the hypothesis' 10 x 20 constraint matrix A[r*20 + c]; slot: its 90-double record (B(z) and the determinant
 // polynomial are written to it); Al / idx: this lane's column of the lane-interleaved LDS work area.
-// ES: element stride of Ag (see five_point_build_A_rows)
+// ES: element stride of Ag (see five_point_build_A)
 template <int ES = 1>
 DSM_DEV void e_lu_body(const double* Ag, double* slot, double* Al, unsigned char* idx) {
 #define LA(i, k) Al[((k) * 10 + (i)) * 64]
@@ -2770,7 +2770,7 @@ __global__ __launch_bounds__(64, 2) void k_lo_e_build(const VerifyParams p) {
   for (int r = 0; r < 9; ++r)
     for (int c = 0; c < 4; ++c) Eb[r * 4 + c] = V[(5 + c) * 9 + r];  // Eb[r*4 + c] = V(r, 5 + c), essential_matrix.cc:72-74
   for (int k = 0; k < 36; ++k) slot[EPOLY_EB + k] = Eb[k];
-  five_point_build_A_rows(Eb, p.lo_ework + (size_t)pl * 200);
+  five_point_build_A<1>(Eb, p.lo_ework + (size_t)pl * 200);
 }
 __global__ __launch_bounds__(64) void k_lo_e_lu(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

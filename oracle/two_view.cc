@@ -427,6 +427,7 @@ static void fivept_build_A(const double* e, double* a) {
 #define FIVEPT_E2(k) e2[k]
 #define FIVEPT_E3(k) e3[k]
 #define FIVEPT_A(i) a[i]
+#define FIVEPT_FENCE(n)
 #define FIVEPT_EMIT_A
 #include "fivept_poly_gen.inc"
 #undef FIVEPT_EMIT_A
@@ -441,6 +442,7 @@ static void fivept_det_poly(const double* b, double* coeffs) {
 #define FIVEPT_EMIT_C
 #include "fivept_poly_gen.inc"
 #undef FIVEPT_EMIT_C
+#undef FIVEPT_FENCE
 #undef FIVEPT_C
 #undef FIVEPT_B
 }
