@@ -91,29 +91,6 @@ def host_cores():
         return os.cpu_count() or 1
 
 
-def knn_pairs(scene, n_images, k, seed):
-    """Candidate-pair graph standing in for the vocabulary-tree retrieval of configs[3]: the K
-    nearest images of every image by camera-centre distance (seeded scene => deterministic), deduplicated to id1 < id2
-    and sorted -- the order VocabTreeFeatureMatcher hands its pairs to Match() in (by query image)."""
-    centres = np.empty((n_images, 3))
-    for i in range(n_images):
-        R, t = scene.pose(i)
-        centres[i] = -R.T @ t
-    k = min(k, n_images - 1)
-    pairs = set()
-    blk = 1024
-    for s in range(0, n_images, blk):
-        d = ((centres[s:s + blk, None, :] - centres[None, :, :]) ** 2).sum(-1)
-        d[np.arange(d.shape[0]), np.arange(s, s + d.shape[0])] = np.inf
-        nn = np.argpartition(d, k - 1, axis=1)[:, :k]
-        for r in range(nn.shape[0]):
-            i = s + r
-            for j in nn[r]:
-                pairs.add((min(i, int(j)), max(i, int(j))))
-    out = np.array(sorted(pairs), dtype=np.uint32).reshape(-1, 2)
-    return out
-
-
 def cpu_baseline(orc, label, build, scene_images, pairs, budget_s, verify, cams, opts, user_seed, cores):
     """Times a CPU oracle build (the reference algorithm restated, oracle/) on a bounded sample of the same
     workload: worker threads pull evenly spaced pairs of the list until `budget_s` seconds have passed, one thread
@@ -194,7 +171,7 @@ def main():
         pairs = synthetic.exhaustive_pairs(args.images)
         pairs_desc = "exhaustive"
     elif args.pairs.startswith("knn:"):
-        pairs = knn_pairs(scene, args.images, int(args.pairs[4:]), args.seed)
+        pairs = synthetic.knn_pairs(scene, args.images, int(args.pairs[4:]), args.seed)
         pairs_desc = "kNN candidate graph, %s neighbours/image, id1<id2" % args.pairs[4:]
     else:
         raise SystemExit("--pairs must be exhaustive or knn:K")

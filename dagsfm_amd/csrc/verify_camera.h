@@ -15,9 +15,9 @@
 //    9  RADIAL_FISHEYE          f cx cy k1 k2                                   {0}         3
 //   10  THIN_PRISM_FISHEYE      fx fy cx cy k1 k2 p1 p2 k3 k4 sx1 sy1           {0,1}       4
 //
-// Models 0-4 and 6 use + - * / only and are bit-identical to the CPU path.  Models 5, 7, 8, 9, 10 call
-// atan / tan / sin / cos: the device's ocml and the host's glibc may differ in the last place there, which is
-// a documented tolerance of those five models, not of the others.
+// Models 0-4 and 6 use + - * / only.  Models 5, 7, 8, 9, 10 call atan / tan / sin / cos: those are the correctly
+// rounded dsm_atan / dsm_tan / dsm_sin / dsm_cos of exact_trig.h (plain double operations, the same code in the CPU
+// oracle), not ocml's -- so all eleven models are bit-identical to the CPU path.
 #ifndef DAGSFM_AMD_CSRC_VERIFY_CAMERA_H_
 #define DAGSFM_AMD_CSRC_VERIFY_CAMERA_H_
 
@@ -29,6 +29,10 @@
 #ifndef DSM_DEV
 #define DSM_DEV __device__ __forceinline__
 #endif
+
+#define DSM_XT static __device__ __noinline__
+#define DSM_XT_CONST __device__ const
+#include "exact_trig.h"
 
 #define DSM_NUM_CAMERA_MODELS 11
 
@@ -77,7 +81,7 @@ DSM_DEV void cam_distortion(int model_id, const double* e, double u, double v, d
       const double k1 = e[0], k2 = e[1], k3 = e[2], k4 = e[3];
       const double r = sqrt(u * u + v * v);
       if (r > DBL_EPSILON) {
-        const double theta = atan(r);
+        const double theta = dsm_atan(r);
         const double theta2 = theta * theta;
         const double theta4 = theta2 * theta2;
         const double theta6 = theta4 * theta2;
@@ -106,7 +110,7 @@ DSM_DEV void cam_distortion(int model_id, const double* e, double u, double v, d
       const double k = e[0];
       const double r = sqrt(u * u + v * v);
       if (r > DBL_EPSILON) {
-        const double theta = atan(r);
+        const double theta = dsm_atan(r);
         const double theta2 = theta * theta;
         const double thetad = theta * (1.0 + k * theta2);
         *du = u * thetad / r - u;
@@ -121,7 +125,7 @@ DSM_DEV void cam_distortion(int model_id, const double* e, double u, double v, d
       const double k1 = e[0], k2 = e[1];
       const double r = sqrt(u * u + v * v);
       if (r > DBL_EPSILON) {
-        const double theta = atan(r);
+        const double theta = dsm_atan(r);
         const double theta2 = theta * theta;
         const double theta4 = theta2 * theta2;
         const double thetad = theta * (1.0 + k1 * theta2 + k2 * theta4);
@@ -193,11 +197,11 @@ DSM_DEV void cam_fov_undistortion(const double* e, double u, double v, double* d
   if (omega2 < kEpsilon) {
     factor = (omega2 * radius2) / 3.0 - omega2 / 12.0 + 1.0;
   } else if (radius2 < kEpsilon) {
-    factor = (omega * (omega * omega * radius2 + 3.0)) / (6.0 * tan(omega / 2.0));
+    factor = (omega * (omega * omega * radius2 + 3.0)) / (6.0 * dsm_tan(omega / 2.0));
   } else {
     const double radius = sqrt(radius2);
-    const double numerator = tan(radius * omega);
-    factor = numerator / (radius * 2.0 * tan(omega / 2.0));
+    const double numerator = dsm_tan(radius * omega);
+    factor = numerator / (radius * 2.0 * dsm_tan(omega / 2.0));
   }
   *du = u * factor;
   *dv = v * factor;
@@ -220,9 +224,9 @@ DSM_DEV void image_to_world(const dsm_camera& cam, double x, double y, double* u
     cam_iterative_undistortion(id, &cam.params[4], u, v);
     if (id == 10) {  // THIN_PRISM_FISHEYE, :1434-1456
       const double theta = sqrt(*u * *u + *v * *v);
-      const double theta_cos_theta = theta * cos(theta);
+      const double theta_cos_theta = theta * dsm_cos(theta);
       if (theta_cos_theta > DBL_EPSILON) {
-        const double scale = sin(theta) / theta_cos_theta;
+        const double scale = dsm_sin(theta) / theta_cos_theta;
         *u *= scale;
         *v *= scale;
       }

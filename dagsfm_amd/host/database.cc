@@ -439,5 +439,6 @@ void Database::DeleteInlierMatches(image_t a, image_t b) const {
 
 void Database::BeginTransaction() const { Exec("BEGIN TRANSACTION;"); }
 void Database::EndTransaction() const { Exec("END TRANSACTION;"); }
+void Database::RollbackTransaction() const { Exec("ROLLBACK TRANSACTION;"); }
 
 }  // namespace dagsfm_amd

@@ -6,6 +6,7 @@
 #ifndef DAGSFM_AMD_HOST_DATABASE_H_
 #define DAGSFM_AMD_HOST_DATABASE_H_
 
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -60,6 +61,7 @@ class Database {
 
   void BeginTransaction() const;
   void EndTransaction() const;
+  void RollbackTransaction() const;
 
  private:
   void CreateTables() const;
@@ -71,13 +73,20 @@ class Database {
 // RAII transaction like DatabaseTransaction, database.h:306-318
 class DatabaseTransaction {
  public:
-  explicit DatabaseTransaction(Database* database) : database_(database) { database_->BeginTransaction(); }
-  // END failing while another exception unwinds must not terminate the process: errors surface through Commit(),
-  // the destructor only makes sure the transaction is closed and swallows what it cannot report.
+  explicit DatabaseTransaction(Database* database) : database_(database), exceptions_(std::uncaught_exceptions()) {
+    database_->BeginTransaction();
+  }
+  // Leaving the scope normally commits, like the reference's destructor (database.h:306-318).  Leaving it because
+  // an exception unwinds ROLLS BACK: the reference aborts the process where this code throws, so it never commits
+  // half a block; neither does this.  END / ROLLBACK failing inside a destructor is swallowed (errors surface through
+  // Commit()).
   ~DatabaseTransaction() noexcept {
     if (!done_) {
       try {
-        database_->EndTransaction();
+        if (std::uncaught_exceptions() > exceptions_)
+          database_->RollbackTransaction();
+        else
+          database_->EndTransaction();
       } catch (...) {
       }
     }
@@ -86,9 +95,14 @@ class DatabaseTransaction {
     done_ = true;
     database_->EndTransaction();
   }
+  void Rollback() {
+    done_ = true;
+    database_->RollbackTransaction();
+  }
 
  private:
   Database* database_;
+  int exceptions_;
   bool done_ = false;
 };
 

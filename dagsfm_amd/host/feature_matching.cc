@@ -27,6 +27,15 @@ void FeatureMatcherCache::Setup() {  // matching.cc:221-243
   for (image_pair_t id : database_->ReadPairIds(true)) have_inliers_.insert(id);
 }
 
+void FeatureMatcherCache::RollbackTransaction(bool transaction_open) {
+  std::lock_guard<std::recursive_mutex> lock(mutex_);
+  if (transaction_open) database_->RollbackTransaction();
+  have_matches_.clear();
+  have_inliers_.clear();
+  for (image_pair_t id : database_->ReadPairIds(false)) have_matches_.insert(id);
+  for (image_pair_t id : database_->ReadPairIds(true)) have_inliers_.insert(id);
+}
+
 std::vector<image_t> FeatureMatcherCache::GetImageIds() const {
   std::vector<image_t> ids;
   ids.reserve(images_cache_.size());
@@ -128,7 +137,13 @@ bool ExhaustiveFeatureMatcher::Run() {
         matcher_.Match(image_pairs);
       } else {
         DatabaseTransaction database_transaction(&database_);
-        matcher_.Match(image_pairs);
+        try {
+          matcher_.Match(image_pairs);
+        } catch (...) {
+          database_transaction.Rollback();   // nothing of a failed block is committed ...
+          cache_.RollbackTransaction(false);  // ... and the cache's pair-id sets follow the database
+          throw;
+        }
         database_transaction.Commit();
       }
     }

@@ -122,6 +122,10 @@ class FeatureMatcherCache {
     std::lock_guard<std::recursive_mutex> lock(mutex_);
     database_->EndTransaction();
   }
+  // After a failed batch: drops the open transaction's rows (if one is open) and re-reads which pairs the database
+  // holds, so that ExistsMatches / ExistsInlierMatches answer for the database again (not in the reference, whose
+  // CHECKs abort the process instead of unwinding).
+  void RollbackTransaction(bool transaction_open);
 
  private:
   const size_t cache_size_;

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
@@ -48,7 +49,16 @@ class SiftFeatureMatcherT {
     if (!options_.Check()) throw std::invalid_argument("SiftMatchingOptions::Check failed");  // CHECK(options_.Check()), matching.cc:614
   }
   ~SiftFeatureMatcherT() {
-    if (writer_.joinable()) writer_.join();  // errors of a never-flushed write-back are lost with the object
+    if (writer_.joinable()) writer_.join();
+    if (writer_error_) {  // never Flush()ed: a destructor cannot throw, so at least say it (the rows were rolled back)
+      try {
+        std::rethrow_exception(writer_error_);
+      } catch (const std::exception& e) {
+        std::fprintf(stderr, "dagsfm_amd::SiftFeatureMatcher: asynchronous write-back failed and was rolled back: %s\n", e.what());
+      } catch (...) {
+        std::fprintf(stderr, "dagsfm_amd::SiftFeatureMatcher: asynchronous write-back failed and was rolled back\n");
+      }
+    }
     for (dsm_ctx* c : ctxs_) dsm_ctx_destroy(c);
   }
   SiftFeatureMatcherT(const SiftFeatureMatcherT&) = delete;
@@ -110,9 +120,13 @@ class SiftFeatureMatcherT {
     if (!database_ || !cache_ || !is_setup_) throw std::logic_error("SiftFeatureMatcher::Match before Setup");  // CHECKs :751-753
     if (image_pairs.empty()) return;
 
-    // ---- dedupe, resume semantics (matching.cc:763-813)
+    // ---- dedupe, resume semantics (matching.cc:763-813).  The reference deletes the stale rows right here and
+    // CHECK-aborts on any later failure; this class reports device failures as exceptions, so a row must not vanish
+    // before its replacement exists: the deletes are only RECORDED here and applied next to the new rows (write()
+    // below), i.e. after the device results are on the host and inside the same transaction.
     std::unordered_set<uint64_t> seen;
     PairList to_match, to_verify_only;
+    std::vector<char> stale_inliers_match, stale_inliers_verify;  // the pair has a two_view_geometries row to replace
     std::vector<typename Traits::FeatureMatches> existing;
     {
       const auto lock = Traits::LockBatch(cache_);  // one acquisition for the whole list where the cache offers it
@@ -123,13 +137,13 @@ class SiftFeatureMatcherT {
         const bool exists_matches = cache_->ExistsMatches(pr.first, pr.second);
         const bool exists_inlier_matches = cache_->ExistsInlierMatches(pr.first, pr.second);
         if (exists_matches && exists_inlier_matches) continue;
-        if (exists_inlier_matches) cache_->DeleteInlierMatches(pr.first, pr.second);
         if (exists_matches) {
           existing.push_back(cache_->GetMatches(pr.first, pr.second));
-          cache_->DeleteMatches(pr.first, pr.second);
           to_verify_only.push_back(pr);
+          stale_inliers_verify.push_back(exists_inlier_matches ? 1 : 0);
         } else {
           to_match.push_back(pr);
+          stale_inliers_match.push_back(exists_inlier_matches ? 1 : 0);
         }
       }
     }
@@ -149,8 +163,8 @@ class SiftFeatureMatcherT {
     to.max_num_trials = static_cast<uint64_t>(options_.max_num_trials);
     to.min_inlier_ratio = options_.min_inlier_ratio;
     to.multiple_models = options_.multiple_models ? 1 : 0;  // multiple_ignore_watermark stays at its default (true)
-    Run(to_match, nullptr, mo, to);
-    Run(to_verify_only, &existing, mo, to);
+    Run(to_match, nullptr, stale_inliers_match, mo, to);
+    Run(to_verify_only, &existing, stale_inliers_verify, mo, to);
   }
 
  private:
@@ -207,8 +221,8 @@ class SiftFeatureMatcherT {
     if (rc != DSM_OK) sh->error = std::string("result fetch failed: ") + dsm_last_error(ctx);
   }
 
-  void Run(const PairList& prs, const std::vector<typename Traits::FeatureMatches>* given, const dsm_match_options& mo,
-           const dsm_two_view_options& to) {
+  void Run(const PairList& prs, const std::vector<typename Traits::FeatureMatches>* given, const std::vector<char>& stale_inliers,
+           const dsm_match_options& mo, const dsm_two_view_options& to) {
     if (prs.empty()) return;
     const uint32_t np = static_cast<uint32_t>(prs.size());
     // Contiguous blocks of the list, one per device, cut by cost (descriptor-matrix size + a per-pair term for
@@ -265,14 +279,18 @@ class SiftFeatureMatcherT {
     // ---- write results (matching.cc:819-836), on this thread or handed to the write-back thread
     const int min_num_inliers = options_.min_num_inliers;
     typename Traits::Cache* cache = cache_;
-    auto write = [cache, min_num_inliers, np, prs, moff = std::move(moff), m = std::move(m), tv = std::move(tv),
-                  ioff = std::move(ioff), im = std::move(im)]() {
+    const bool replace_matches = given != nullptr;  // resume path: the pair's `matches` row exists and is rewritten
+    auto write = [cache, min_num_inliers, np, prs, stale_inliers, replace_matches, moff = std::move(moff), m = std::move(m),
+                  tv = std::move(tv), ioff = std::move(ioff), im = std::move(im)]() {
       for (uint32_t i = 0; i < np; ++i) {
+        if (stale_inliers[i]) cache->DeleteInlierMatches(prs[i].first, prs[i].second);  // matching.cc:797-799
+        if (replace_matches) cache->DeleteMatches(prs[i].first, prs[i].second);         // matching.cc:806-808
         size_t nm = moff[i + 1] - moff[i];
         if (nm < static_cast<size_t>(min_num_inliers)) nm = 0;  // matching.cc:824-826
         const typename Traits::FeatureMatches matches = Traits::MakeMatches(m.data() + 2 * moff[i], nm);
-        // stays TwoViewGeometry() when the device post-filter zeroed the pair (matching.cc:828-831)
-        const bool keep = tv[i].num_inliers >= static_cast<uint32_t>(min_num_inliers) && tv[i].num_inliers > 0;
+        // TwoViewGeometry() when the pair fails the post-filter (matching.cc:828-831: `< min_num_inliers` only, so with
+        // min_num_inliers = 0 an estimated geometry without inliers -- e.g. DEGENERATE -- is kept, as in the reference)
+        const bool keep = tv[i].num_inliers >= static_cast<uint32_t>(min_num_inliers);
         const typename Traits::TwoViewGeometry t =
             Traits::MakeTwoViewGeometry(keep ? &tv[i] : nullptr, im.data() + 2 * ioff[i], keep ? ioff[i + 1] - ioff[i] : 0);
         cache->WriteMatches(prs[i].first, prs[i].second, matches);
@@ -290,12 +308,21 @@ class SiftFeatureMatcherT {
         }
         Flush();  // one write-back in flight
         writer_ = std::thread([this, cache, write = std::move(write)]() {
+          bool open = false;
           try {
             cache->BeginTransaction();
+            open = true;
             write();
+            open = false;
             cache->EndTransaction();
           } catch (...) {
             writer_error_ = std::current_exception();
+            // close the transaction without its rows and make the cache say what the database says again: the batch's
+            // pairs were marked as present above and must not be skipped by a later Match()
+            try {
+              cache->RollbackTransaction(open);
+            } catch (...) {
+            }
           }
         });
         return;

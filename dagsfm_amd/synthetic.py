@@ -199,3 +199,26 @@ def vocabulary(scene, num_words, seed=0):
     proj = np.ascontiguousarray(q[:64].astype(np.float32))
     thr = (words.astype(np.float32) @ proj.T + rng.normal(scale=8.0, size=(num_words, 64))).astype(np.float32)
     return words, proj, np.ascontiguousarray(thr)
+
+
+def knn_pairs(scene, n_images, k, seed):
+    """Candidate-pair graph standing in for the vocabulary-tree retrieval of configs[3]: the K
+    nearest images of every image by camera-centre distance (seeded scene => deterministic), deduplicated to id1 < id2
+    and sorted -- the order VocabTreeFeatureMatcher hands its pairs to Match() in (by query image)."""
+    centres = np.empty((n_images, 3))
+    for i in range(n_images):
+        R, t = scene.pose(i)
+        centres[i] = -R.T @ t
+    k = min(k, n_images - 1)
+    pairs = set()
+    blk = 1024
+    for s in range(0, n_images, blk):
+        d = ((centres[s:s + blk, None, :] - centres[None, :, :]) ** 2).sum(-1)
+        d[np.arange(d.shape[0]), np.arange(s, s + d.shape[0])] = np.inf
+        nn = np.argpartition(d, k - 1, axis=1)[:, :k]
+        for r in range(nn.shape[0]):
+            i = s + r
+            for j in nn[r]:
+                pairs.add((min(i, int(j)), max(i, int(j))))
+    out = np.array(sorted(pairs), dtype=np.uint32).reshape(-1, 2)
+    return out

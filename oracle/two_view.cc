@@ -45,6 +45,11 @@
 
 #include "../include/dagsfm_mi355x.h"
 #include "linalg.h"
+// atan / sin / cos / tan of the camera models: the correctly rounded values, computed by the same plain-double code as
+// on the device (dagsfm_amd/csrc/exact_trig.h; tests/test_exact_trig.py checks it against this host's libm)
+#define DSM_XT static inline
+#define DSM_XT_CONST static const
+#include "../dagsfm_amd/csrc/exact_trig.h"
 
 namespace oracle {
 
@@ -685,7 +690,7 @@ static void Distortion(int id, const double* e, double u, double v, double* du, 
       const double k1 = e[0], k2 = e[1], k3 = e[2], k4 = e[3];
       const double r = std::sqrt(u * u + v * v);
       if (r > eps) {
-        const double theta = std::atan(r);
+        const double theta = dsm_atan(r);
         const double theta2 = theta * theta;
         const double theta4 = theta2 * theta2;
         const double theta6 = theta4 * theta2;
@@ -714,7 +719,7 @@ static void Distortion(int id, const double* e, double u, double v, double* du, 
       const double k = e[0];
       const double r = std::sqrt(u * u + v * v);
       if (r > eps) {
-        const double theta = std::atan(r);
+        const double theta = dsm_atan(r);
         const double theta2 = theta * theta;
         const double thetad = theta * (1.0 + k * theta2);
         *du = u * thetad / r - u;
@@ -729,7 +734,7 @@ static void Distortion(int id, const double* e, double u, double v, double* du, 
       const double k1 = e[0], k2 = e[1];
       const double r = std::sqrt(u * u + v * v);
       if (r > eps) {
-        const double theta = std::atan(r);
+        const double theta = dsm_atan(r);
         const double theta2 = theta * theta;
         const double theta4 = theta2 * theta2;
         const double thetad = theta * (1.0 + k1 * theta2 + k2 * theta4);
@@ -801,11 +806,11 @@ static void FOVUndistortion(const double* e, double u, double v, double* du, dou
   if (omega2 < kEpsilon) {
     factor = (omega2 * radius2) / 3.0 - omega2 / 12.0 + 1.0;
   } else if (radius2 < kEpsilon) {
-    factor = (omega * (omega * omega * radius2 + 3.0)) / (6.0 * std::tan(omega / 2.0));
+    factor = (omega * (omega * omega * radius2 + 3.0)) / (6.0 * dsm_tan(omega / 2.0));
   } else {
     const double radius = std::sqrt(radius2);
-    const double numerator = std::tan(radius * omega);
-    factor = numerator / (radius * 2.0 * std::tan(omega / 2.0));
+    const double numerator = dsm_tan(radius * omega);
+    factor = numerator / (radius * 2.0 * dsm_tan(omega / 2.0));
   }
   *du = u * factor;
   *dv = v * factor;
@@ -830,9 +835,9 @@ static Vec2 ImageToWorld(const dsm_camera& cam, const Vec2& p) {
     IterativeUndistortion(id, &cam.params[4], &w.x, &w.y);
     if (id == 10) {  // ThinPrismFisheyeCameraModel::ImageToWorld, :1434-1456
       const double theta = std::sqrt(w.x * w.x + w.y * w.y);
-      const double theta_cos_theta = theta * std::cos(theta);
+      const double theta_cos_theta = theta * dsm_cos(theta);
       if (theta_cos_theta > std::numeric_limits<double>::epsilon()) {
-        const double scale = std::sin(theta) / theta_cos_theta;
+        const double scale = dsm_sin(theta) / theta_cos_theta;
         w.x *= scale;
         w.y *= scale;
       }
@@ -1367,6 +1372,12 @@ static std::vector<Vec2> ToVec2(const double* p, int n) {
 }
 
 extern "C" {
+
+// exact_trig.h on the host, for tests/test_exact_trig.py: kind 0 atan, 1 sin, 2 cos, 3 tan
+void oracle_exact_trig(int kind, const double* x, int n, double* out) {
+  for (int i = 0; i < n; ++i)
+    out[i] = kind == 0 ? dsm_atan(x[i]) : kind == 1 ? dsm_sin(x[i]) : kind == 2 ? dsm_cos(x[i]) : dsm_tan(x[i]);
+}
 
 // Steps 3 / 4 of the 5-point solver alone, for tests/test_fivept_reference_order.py (layouts of Eigen's .data()).
 void oracle_fivept_build_A(const double* e_colmajor_9x4, double* a_colmajor_10x20) {

@@ -309,3 +309,43 @@ def test_exhaustive_matcher_several_device_contexts(tmp_path):
             assert (m[pid] == base_m[pid]).all()
             assert t[pid]["config"] == base_t[pid]["config"] and (t[pid]["inliers"] == base_t[pid]["inliers"]).all()
             assert t[pid]["F"] == base_t[pid]["F"] and t[pid]["E"] == base_t[pid]["E"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("async_write", [False, True])
+def test_failed_device_call_leaves_existing_rows_alone(tmp_path, async_write, monkeypatch):
+    """Match() used to delete the stale rows of resume-path pairs BEFORE any device work; a device failure
+    (reported as an exception, where the reference CHECK-aborts) then committed the deletes and the putative matches
+    were gone.  Now the deletes travel with the new rows.  Set-up: a finished database, one two_view_geometries row
+    removed (so that pair is on the resume path: its `matches` row would be deleted and rewritten), and a camera
+    model id the device rejects -- the run must fail and every row must still be there."""
+    if async_write:
+        monkeypatch.setenv("DSM_ASYNC_WRITE_BACK", "1")
+    from dagsfm_amd import synthetic
+    n_img = 4
+    scene = synthetic.Scene(n_img, 512, seed=44, n_pool=1400)
+    ims = [scene.image(i) for i in range(n_img)]
+    path = str(tmp_path / "database.db")
+    dbutil.create(path, [(im[0], im[1]) for im in ims], prior=True)
+    subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5"])
+    before = dbutil.read_results(path)
+    pid = dbutil.pair_id(1, 2)
+    assert len(before[0][pid]) > 15
+    con = sqlite3.connect(path)
+    con.execute("DELETE FROM two_view_geometries WHERE pair_id = ?", (pid,))
+    con.execute("UPDATE cameras SET model = 99")
+    con.commit()
+    con.close()
+    r = subprocess.run([CLI, "--database_path", path, "--random_seed", "5"], capture_output=True, text=True)
+    assert r.returncode != 0 and "camera model" in (r.stderr + r.stdout)
+    after = dbutil.read_results(path)
+    assert set(after[0]) == set(before[0]) and all((after[0][k] == before[0][k]).all() for k in before[0])
+    assert set(after[1]) == set(before[1]) - {pid}
+    # and with the camera repaired the pair is verified from its stored matches, as if nothing had happened
+    con = sqlite3.connect(path)
+    con.execute("UPDATE cameras SET model = 0")
+    con.commit()
+    con.close()
+    subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5"])
+    again = dbutil.read_results(path)
+    assert (again[1][pid]["inliers"] == before[1][pid]["inliers"]).all() and again[1][pid]["F"] == before[1][pid]["F"]

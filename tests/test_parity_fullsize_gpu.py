@@ -52,18 +52,28 @@ def _oracle_verify(oracle, ims, cams, pairs, matches, opts, user_seed):
         return list(ex.map(one, range(len(pairs))))
 
 
-def _compare_stage(dsm, oracle, ims, cams, pairs, opts, user_seed, ref_matches=None, stage_filter=True):
+_ORACLE_CACHE = {}   # the four LO schedules of the fixture compare against the same oracle results
+
+
+def _compare_stage(dsm, oracle, ims, cams, pairs, opts, user_seed, ref_matches=None, stage_filter=True, cache_key=None):
     dsm.set_images([im[0] for im in ims], [im[1] for im in ims], cams)
     dsm.match_pairs(pairs)
     dsm.verify_pairs(opts, user_seed=user_seed, stage_filter=stage_filter)
     offs, m = dsm.matches()
     tvgs = dsm.two_view_geometries()
     ioffs, im = dsm.inlier_matches()
-    if ref_matches is None:
-        ref_matches = _oracle_matches(oracle, ims, pairs)
+    if cache_key is not None and cache_key in _ORACLE_CACHE:
+        ref_matches, refs = _ORACLE_CACHE[cache_key]
+    else:
+        if ref_matches is None:
+            ref_matches = _oracle_matches(oracle, ims, pairs)
+        refs = None
     for k in range(len(pairs)):
         assert (m[int(offs[k]):int(offs[k + 1])] == ref_matches[k]).all(), ("matches", tuple(pairs[k]))
-    refs = _oracle_verify(oracle, ims, cams, pairs, ref_matches, opts, user_seed)
+    if refs is None:
+        refs = _oracle_verify(oracle, ims, cams, pairs, ref_matches, opts, user_seed)
+    if cache_key is not None:
+        _ORACLE_CACHE[cache_key] = (ref_matches, refs)
     configs, n_ok = {}, 0
     for k, (ref, ref_inl) in enumerate(refs):
         got, got_inl = tvgs[k], im[int(ioffs[k]):int(ioffs[k + 1])]
@@ -152,3 +162,50 @@ def test_planar_and_panoramic_configurations(dsm, oracle):
     ims = [so.image(i) for i in range(3)]
     _, refs, configs, n_ok = _compare_stage(dsm, oracle, ims, cams, pairs, opts, 6)
     assert configs.get(5, 0) >= 2, configs
+
+
+def test_config5_8192_features_with_fixed_4096_trials(dsm, oracle):
+    """BASELINE configs[4] as written (missing 2): 8 192 features per image, calibrated E + F + H with
+    min_num_trials = max_num_trials = 4 096 per family -- the image size and the RANSAC schedule TOGETHER."""
+    scene = synthetic.Scene(3, 8192, seed=21)
+    ims = [scene.image(i) for i in range(3)]
+    cams = [capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, 1) for _ in range(3)]
+    pairs = synthetic.exhaustive_pairs(3)
+    opts = capi.default_two_view_options(min_num_trials=4096, max_num_trials=4096, confidence=0.999999, min_inlier_ratio=0.01)
+    ref_matches, refs, configs, n_ok = _compare_stage(dsm, oracle, ims, cams, pairs, opts, 12, cache_key="config5")
+    assert n_ok == 3 and min(len(x) for x in ref_matches) > 300
+    for ref, _ in refs:
+        assert list(ref.num_trials)[:3] == [4096, 4096, 4096], list(ref.num_trials)
+
+
+def test_knn_candidate_pair_list_and_its_shards(dsm, oracle):
+    """BASELINE configs[3] pair list (missing 2): a kNN candidate graph -- sparse, images repeated, not
+    exhaustive, sorted by query image as VocabTreeFeatureMatcher hands its pairs to Match() (matching.cc:749-839
+    runs whatever list it is given) -- through dsm_match_pairs / dsm_verify_pairs against the oracle; then the way
+    bench.py --shard-of runs one rank's share: a contiguous slice of the list over ONLY the images it touches,
+    re-indexed (bench.py: `remap`), which must give the results of the same pairs under their new ids."""
+    n_img = 48
+    scene = synthetic.Scene(n_img, 512, seed=9)
+    ims = [scene.image(i) for i in range(n_img)]
+    cams = [capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, 1) for _ in range(n_img)]
+    pairs = synthetic.knn_pairs(scene, n_img, 8, 9)
+    assert len(pairs) >= 200 and len(np.unique(pairs)) >= 40
+    assert len(pairs) < n_img * (n_img - 1) // 2 // 3                      # sparse
+    assert (pairs[:, 0] < pairs[:, 1]).all()
+    opts = capi.default_two_view_options()
+    ref_matches, refs, configs, n_ok = _compare_stage(dsm, oracle, ims, cams, pairs, opts, 5, cache_key="knn")
+    assert n_ok >= 100, (n_ok, configs)
+    # one shard of four, the way bench.py builds it
+    from dagsfm_amd import sharding
+    for r in (1, 3):
+        part = sharding.shard(pairs, r, 4)
+        used = np.unique(part)
+        remap = np.full(n_img, -1, dtype=np.int64)
+        remap[used] = np.arange(len(used))
+        sub_pairs = remap[part.astype(np.int64)].astype(np.uint32)
+        sub_ims = [ims[int(i)] for i in used]
+        sub_cams = [cams[int(i)] for i in used]
+        lo, hi = sharding.shard_bounds(len(pairs), 4)[r:r + 2]
+        _, _, _, n_sub = _compare_stage(dsm, oracle, sub_ims, sub_cams, sub_pairs, opts, 5, ref_matches=ref_matches[lo:hi],
+                                        cache_key=("knn-shard", r))
+        assert n_sub >= 20
