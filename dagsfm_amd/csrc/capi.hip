@@ -133,7 +133,7 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
                     &ctx->d_g_inl, &ctx->d_g_inl_off, &ctx->d_mm_matches[0], &ctx->d_mm_matches[1], &ctx->d_mm_off[0],
                     &ctx->d_mm_off[1], &ctx->d_mm_counts, &ctx->d_mm_state, &ctx->d_mm_first, &ctx->d_mm_acc, &ctx->d_mm_keep,
                     &ctx->d_mm_total, &ctx->d_order, &ctx->d_dpairs2, &ctx->d_ecnt, &ctx->d_eoff, &ctx->d_etotal, &ctx->d_entries,
-                    &ctx->d_out2, &ctx->d_lo_inl};
+                    &ctx->d_out2, &ctx->d_ms, &ctx->d_out2s, &ctx->d_lo_inl};
   for (VerifyLane& L : ctx->lanes) {
     for (DevBuf* b : {&L.samples, &L.draws_end, &L.nmodels, &L.vcounts, &L.vsums, &L.models, &L.ework, &L.active, &L.vscratch, &L.lo_queue,
                       &L.lo_work, &L.lo_models, &L.lo_slots, &L.lo_ework})
@@ -275,7 +275,7 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
   HIPCHK(ctx, hipMemsetAsync(ctx->d_offsets.p, 0, 8, st));
 
   // Chunk the pair list so that the K1 output scratch stays below a fixed budget.
-  uint64_t budget_rows = (6ull << 30) / 4;
+  uint64_t budget_rows = (8ull << 30) / 8;  // two int32 per row: the result and K1's second-best value for K1b
   if (const char* e = getenv("DSM_MATCH_CHUNK_ROWS")) budget_rows = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // test hook
   std::vector<uint2> dpairs, dpairs2;
   std::vector<uint64_t> doff;
@@ -322,6 +322,7 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
     HIPCHK(ctx, ctx->d_doutoff.reserve(std::max<uint32_t>(nc, 1) * 8));
     HIPCHK(ctx, ctx->d_pair_dir.reserve(std::max<uint32_t>(nc, 1) * sizeof(uint4)));
     HIPCHK(ctx, ctx->d_m.reserve(std::max<uint64_t>(off, 1) * 4));
+    HIPCHK(ctx, ctx->d_ms.reserve(std::max<uint64_t>(off, 1) * 4));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_dpairs.p, dpairs.data(), nc * sizeof(uint2), hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_order.p, order.data(), nc * 4, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_doutoff.p, doff.data(), nc * 8, hipMemcpyHostToDevice, st));
@@ -338,6 +339,7 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
     k1.max_ratio = (float)options->max_ratio;        // narrowed as at sift.cc:164-166
     k1.max_distance = (float)options->max_distance;
     k1.out = ctx->d_m.as<int32_t>();
+    k1.out_s = ctx->d_ms.as<int32_t>();
     k1.order = ctx->d_order.as<uint32_t>();
     k1.entries = nullptr;
     k1.e_off = nullptr;
@@ -401,6 +403,7 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
       HIPCHK(ctx, hipStreamSynchronize(st));
       HIPCHK(ctx, ctx->d_entries.reserve(std::max<uint64_t>(etotal, 1) * 8));
       HIPCHK(ctx, ctx->d_out2.reserve(std::max<uint64_t>(etotal, 1) * 4));
+      HIPCHK(ctx, ctx->d_out2s.reserve(std::max<uint64_t>(etotal, 1) * 4));
       k2.matches = ctx->d_entries.as<uint32_t>();
       launch_k2(k2, nc, true, st);
       HIPCHK(ctx, hipGetLastError());
@@ -414,6 +417,7 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
       g.e_off = ctx->d_eoff.as<uint64_t>();
       g.e_cnt = ctx->d_ecnt.as<uint32_t>();
       g.out = ctx->d_out2.as<int32_t>();
+      g.out_s = ctx->d_out2s.as<int32_t>();
       HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 3], st));
       if (etotal) {
         launch_k1(g, nc, max_rb, st);  // a pair has at most rows(a) entries

@@ -95,7 +95,7 @@ struct dsm_ctx {
   double k1_ms = 0.0;
   double k1b_ms = 0.0;  // k1_resolve_index
   double k1g_ms = 0.0;  // k1_best_rows<GATHER> (pass 2 of the cross-check)
-  DevBuf d_order, d_dpairs2, d_ecnt, d_eoff, d_etotal, d_entries, d_out2;
+  DevBuf d_order, d_dpairs2, d_ecnt, d_eoff, d_etotal, d_entries, d_out2, d_ms, d_out2s;
   uint32_t k1_launches = 0;
   std::vector<hipEvent_t> ev;
 

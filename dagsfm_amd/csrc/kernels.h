@@ -18,7 +18,8 @@ struct K1Params {
   const float* lut;           // acosf(min(d / 2^18, 1)), d = 0..262144, built on the host
   float max_ratio;
   float max_distance;
-  int32_t* out;               // per row: matched column index or -1 (between K1 and K1b: the 32-column tile)
+  int32_t* out;               // per row: matched column index or -1 (between K1 and K1b: tile * 4 + column set)
+  int32_t* out_s;             // per flagged row, between K1 and K1b: K1's second-best dot product (a lower bound)
   // gathered pass (pass 2 of the cross-check); entries == nullptr: plain pass over an image's rows
   const uint32_t* order;      // optional: blockIdx.x -> directed pair (launch order, sorted by column image)
   const uint2* entries;       // one-way matches (i1, i2) of all pairs; entry k of pair d = row i2 of image dpairs[d].x

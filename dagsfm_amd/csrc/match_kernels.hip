@@ -85,48 +85,49 @@ __global__ __launch_bounds__(256) void k0_prepare(const uint8_t* __restrict__ in
 }
 
 // ------------------------------------------------------------------------------------ K1
-// One quarter (4 of the 16 accumulator registers = 4 columns) of a tile's top-2 update for the lane's
-// row, as ONE asm block so that it can be placed between two MFMAs as a unit:
-//   second = max(second, med3(best, x, y));  best = max3(best, x, y)      for two pairs (x, y)
-// Quarter 0 leaves the tile's incoming best in `ob`; quarter 3 records the tile index when the best
-// strictly increased during the tile.
+// The top-2 update of a finished 32x32 tile for the lane's row (its 16 accumulator registers = 16 columns), in
+// four pieces of three VALU instructions, each ONE asm block so that it can be placed between two MFMAs as a unit:
+//   t = max of the 16 values (v_max3 chain);  u = max(t, second);  second = min(u, best);  best = max(u, best)
+// i.e. (best, second) become the two largest of {best, second, t}: the running pair is the top-2 of the TILE MAXIMA
+// of the lane's 16-column sets.  `best` is exact.  `second` misses exactly one candidate -- the second largest value
+// INSIDE the set that holds the best -- and k1_resolve_index, which re-reads that set anyway to find the column,
+// adds it (rows are flagged with this `second`, which is <= the true one: a superset of the rows that pass the ratio
+// test, sift.cc:148-155; the final test runs there).  12 VALU per tile where the exact top-2 tree needed 22: the
+// VALU issue port, not the matrix pipe, was what limited this kernel (2 waves per SIMD x (4 MFMA + 22 VALU) issue
+// slots per 2 x 128 cycles of matrix-pipe time).
+// Piece 3 records the tile index when the best strictly increased during the tile (the reference's best_i2 is the
+// lowest column attaining the maximum).
 template <int Q>
-__device__ __forceinline__ void k1_epilogue_quarter(const v16i& a, int& best, int& second, int& ob, int& btile,
-                                                    int tile) {
-  int t0, t1;
+__device__ __forceinline__ void k1_epilogue_quarter(const v16i& a, int& best, int& second, int& t, int& btile, int tile) {
   if constexpr (Q == 0) {
-    int nb;
     asm volatile(
-        "v_med3_i32 %[t0], %[b], %[a0], %[a1]\n\t"
-        "v_max3_i32 %[nb], %[b], %[a0], %[a1]\n\t"
-        "v_med3_i32 %[t1], %[nb], %[a2], %[a3]\n\t"
-        "v_max3_i32 %[nb], %[nb], %[a2], %[a3]\n\t"
-        "v_max3_i32 %[s], %[s], %[t0], %[t1]"
-        : [nb] "=&v"(nb), [s] "+v"(second), [t0] "=&v"(t0), [t1] "=&v"(t1)
-        : [b] "v"(best), [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]));
-    ob = best;
-    best = nb;
-  } else if constexpr (Q == 3) {
+        "v_max3_i32 %[t], %[a0], %[a1], %[a2]\n\t"
+        "v_max3_i32 %[t], %[t], %[a3], %[a4]\n\t"
+        "v_max3_i32 %[t], %[t], %[a5], %[a6]"
+        : [t] "=&v"(t)
+        : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [a4] "v"(a[4]), [a5] "v"(a[5]), [a6] "v"(a[6]));
+  } else if constexpr (Q == 1) {
     asm volatile(
-        "v_med3_i32 %[t0], %[b], %[a0], %[a1]\n\t"
-        "v_max3_i32 %[b], %[b], %[a0], %[a1]\n\t"
-        "v_med3_i32 %[t1], %[b], %[a2], %[a3]\n\t"
-        "v_max3_i32 %[b], %[b], %[a2], %[a3]\n\t"
-        "v_max3_i32 %[s], %[s], %[t0], %[t1]\n\t"
-        "v_cmp_gt_i32 vcc, %[b], %[ob]\n\t"
-        "v_cndmask_b32 %[bt], %[bt], %[tile], vcc"
-        : [b] "+v"(best), [s] "+v"(second), [bt] "+v"(btile), [t0] "=&v"(t0), [t1] "=&v"(t1)
-        : [ob] "v"(ob), [tile] "v"(tile), [a0] "v"(a[12]), [a1] "v"(a[13]), [a2] "v"(a[14]), [a3] "v"(a[15])
-        : "vcc");
+        "v_max3_i32 %[t], %[t], %[a0], %[a1]\n\t"
+        "v_max3_i32 %[t], %[t], %[a2], %[a3]\n\t"
+        "v_max3_i32 %[t], %[t], %[a4], %[a5]"
+        : [t] "+v"(t)
+        : [a0] "v"(a[7]), [a1] "v"(a[8]), [a2] "v"(a[9]), [a3] "v"(a[10]), [a4] "v"(a[11]), [a5] "v"(a[12]));
+  } else if constexpr (Q == 2) {
+    asm volatile(
+        "v_max3_i32 %[t], %[t], %[a0], %[a1]\n\t"
+        "v_max3_i32 %[t], %[t], %[a2], %[s]\n\t"
+        "v_min_i32 %[s], %[t], %[b]"
+        : [t] "+v"(t), [s] "+v"(second)
+        : [b] "v"(best), [a0] "v"(a[13]), [a1] "v"(a[14]), [a2] "v"(a[15]));
   } else {
     asm volatile(
-        "v_med3_i32 %[t0], %[b], %[a0], %[a1]\n\t"
-        "v_max3_i32 %[b], %[b], %[a0], %[a1]\n\t"
-        "v_med3_i32 %[t1], %[b], %[a2], %[a3]\n\t"
-        "v_max3_i32 %[b], %[b], %[a2], %[a3]\n\t"
-        "v_max3_i32 %[s], %[s], %[t0], %[t1]"
-        : [b] "+v"(best), [s] "+v"(second), [t0] "=&v"(t0), [t1] "=&v"(t1)
-        : [a0] "v"(a[4 * Q]), [a1] "v"(a[4 * Q + 1]), [a2] "v"(a[4 * Q + 2]), [a3] "v"(a[4 * Q + 3]));
+        "v_cmp_gt_i32 vcc, %[t], %[b]\n\t"
+        "v_cndmask_b32 %[bt], %[bt], %[tile], vcc\n\t"
+        "v_max_i32 %[b], %[t], %[b]"
+        : [b] "+v"(best), [bt] "+v"(btile)
+        : [t] "v"(t), [tile] "v"(tile)
+        : "vcc");
   }
 }
 
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void k1_best_rows(const K1Params p) {
       // one epilogue quarter of tile j>>2: the VALU works on finished accumulators while the matrix pipe
       // runs the next chain, and no epilogue reads an accumulator right behind the MFMA that writes it.
       v16i acc[3];
-      int ob[4];
+      int tmax;  // the tile maximum in the making (one tile's epilogue is in flight at a time)
       int tile_v[2];  // the step's two tile indices, one VGPR each (v_cndmask takes no second SGPR)
       asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(tile_v[0]), "=v"(tile_v[1]) : "s"(2 * s), "s"(2 * s + 1));
 #define K1_MFMA(K, KS)                                                                                 \
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void k1_best_rows(const K1Params p) {
 #define K1_EPI(E)                                                                                        \
   {                                                                                                      \
     constexpr int ek = (E) >> 2, eq = (E)&3, ert = ek & 3;                                               \
-    k1_epilogue_quarter<eq>(acc[ek % 3], best[ert], second[ert], ob[ert], btile[ert], tile_v[ek >> 2]);      \
+    k1_epilogue_quarter<eq>(acc[ek % 3], best[ert], second[ert], tmax, btile[ert], tile_v[ek >> 2]);          \
   }
       static_for<0, 4>([&](auto KS) { K1_MFMA(0, KS.value); });
       __builtin_amdgcn_sched_barrier(0);
@@ -287,37 +288,50 @@ __global__ __launch_bounds__(256, 2) void k1_best_rows(const K1Params p) {
   }
 
   if (!active) return;
-  int32_t* out = p.out + (GATHER ? p.e_off[d] : p.d_out_off[d]) + rb * 512u + wave * 128;
+  const uint64_t out0 = (GATHER ? p.e_off[d] : p.d_out_off[d]) + rb * 512u + wave * 128;
+  int32_t* out = p.out + out0;
+  int32_t* out_s = p.out_s + out0;
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
-    // the two halves of the wave hold disjoint columns of the same row
+    // the two halves of the wave hold disjoint 16-column sets of the same row
     const int oB = __shfl_xor(best[rt], 32);
     const int oS = __shfl_xor(second[rt], 32);
     const int oT = __shfl_xor(btile[rt], 32);
     const int B = max(best[rt], oB);
     const int S = max(min(best[rt], oB), max(second[rt], oS));
+    // where the lowest column with the best value lives: a tile, and the half-wave's 16-column set of it (2 = both
+    // sets of the same tile reach it: the lowest column could be in either)
     const bool take = (oB > best[rt]) || (oB == best[rt] && oT < btile[rt]);
+    const bool both = oB == best[rt] && oT == btile[rt];
     const int T = take ? oT : btile[rt];
+    const int set = both ? 2 : ((take ? 1 : 0) ^ half);
     const int best_dot = B + rterm_i[rt];
-    const int second_dot = S + rterm_i[rt];
+    const int second_dot = S + rterm_i[rt];  // <= the true second best (see k1_epilogue_quarter)
     int res = -1;
     if (best_dot > 0) {  // best_i2 != -1, sift.cc:136
       const float bn = p.lut[min(best_dot, 262144)];
       if (!(bn > p.max_distance)) {  // sift.cc:144
         const float sn = p.lut[min(second_dot, 262144)];
         const float rhs = __fmul_rn(p.max_ratio, sn);
-        if (!(bn >= rhs)) res = T;  // sift.cc:153; K1b turns the tile into the column
+        if (!(bn >= rhs)) res = T * 4 + set;  // sift.cc:153 with second <= true second; K1b completes the test
       }
     }
-    if (half == (rt & 1) && valid[rt]) out[rt * 32 + l31] = res;
+    if (half == (rt & 1) && valid[rt]) {
+      out[rt * 32 + l31] = res;
+      if (res >= 0) out_s[rt * 32 + l31] = second_dot;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------ K1b
-// out[row] holds a tile index for the rows that passed the thresholds: replace it by the lowest
-// column of that tile with the largest dot product (= the row's best value, reached in this tile).
-// One workgroup per directed pair (the 32-column tiles it reads all belong to ONE image b, which stays
-// in L2); a wave takes 64 rows at a time and resolves its flagged rows one after the other.
+// out[row] = tile * 4 + set for the rows K1 flagged (best value exact, `second` possibly too small): the best value
+// was first reached in that 32-column tile, in the 16-column set of half-wave `set` (columns 8q + 4*set + e; set 2 =
+// both).  This kernel re-reads those columns -- 2 KB instead of the 4 KB tile -- and
+//   * finds the LOWEST column that attains the best value (the reference's best_i2, strict `>` ascending scan),
+//   * finds the second largest value inside the set, the one candidate K1's `second` lacks, and
+//   * applies the ratio test of sift.cc:148-155 with the completed second best: column index or -1.
+// One workgroup per directed pair (the columns it reads all belong to ONE image b, which stays in L2); a wave takes
+// 64 rows at a time and resolves its flagged rows four at a time.
 template <bool GATHER>
 __global__ __launch_bounds__(256) void k1_resolve_index(const K1Params p) {
   const uint32_t d = blockIdx.x;
@@ -326,21 +340,26 @@ __global__ __launch_bounds__(256) void k1_resolve_index(const K1Params p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const uint32_t b_row0 = p.img_row0[ab.y];
+  const uint32_t a_img0 = p.img_row0[ab.x];
   const int8_t* bimg = p.desc + (size_t)b_row0 * 128;
   const int32_t* rt_b = p.rterm + b_row0;
   const uint2* ent = GATHER ? p.entries + p.e_off[d] : nullptr;
+  const int g = lane >> 3;  // 8 lanes share one dot product: column group g, 16-byte chunk lane & 7
   for (uint32_t row_w = wave * 64u; row_w < a_rows; row_w += 256u) {  // first row of this wave's chunk
-    int32_t* out = p.out + (GATHER ? p.e_off[d] : p.d_out_off[d]) + row_w;
-    const int8_t* arow = p.desc + (size_t)(p.img_row0[ab.x] + (GATHER ? 0u : row_w)) * 128;
+    const uint64_t o0 = (GATHER ? p.e_off[d] : p.d_out_off[d]) + row_w;
+    int32_t* out = p.out + o0;
+    const int32_t* out_s = p.out_s + o0;
     const bool in_range = !GATHER || row_w + (uint32_t)lane < a_rows;
     const int t = in_range ? out[lane] : -1;
-    const uint32_t my_row = GATHER ? (in_range ? ent[row_w + lane].y : 0u) : (uint32_t)lane;  // row inside the image (relative to arow)
+    const int s_appr = t >= 0 ? out_s[lane] : 0;
+    const uint32_t my_row = GATHER ? (in_range ? ent[row_w + lane].y : 0u) : row_w + (uint32_t)lane;  // row inside image a
     unsigned long long mask = __ballot(t >= 0);
-    // four flagged rows per trip: their loads (row descriptor, 4 KB tile, column terms) are issued together, so a trip
-    // pays one memory round trip instead of four (a wave resolves ~100 rows one after the other)
+    // four flagged rows per trip: their loads (row descriptor, column sets, column terms) are issued together, so a
+    // trip pays one memory round trip instead of four (a wave resolves ~100 rows one after the other)
     constexpr int RU = 4;
     while (mask) {
-      int rr_l[RU], r_l[RU], tile_l[RU];
+      int r_l[RU], tile_l[RU], set_l[RU], sap_l[RU];
+      uint32_t grow_l[RU];
       bool on[RU];
 #pragma unroll
       for (int u = 0; u < RU; ++u) {
@@ -348,42 +367,64 @@ __global__ __launch_bounds__(256) void k1_resolve_index(const K1Params p) {
         const int r = on[u] ? (__ffsll((long long)mask) - 1) : 0;
         if (on[u]) mask &= mask - 1;
         r_l[u] = r;
-        tile_l[u] = on[u] ? __builtin_amdgcn_readlane(t, r) : 0;
-        rr_l[u] = GATHER ? __builtin_amdgcn_readlane((int)my_row, r) : r;
+        const int code = on[u] ? __builtin_amdgcn_readlane(t, r) : 0;
+        tile_l[u] = code >> 2;
+        set_l[u] = code & 3;
+        sap_l[u] = __builtin_amdgcn_readlane(s_appr, r);
+        grow_l[u] = a_img0 + (uint32_t)__builtin_amdgcn_readlane((int)my_row, r);
       }
-      // the tile's 32 columns are 4 KB of contiguous memory: four fully coalesced 1-KB loads, lane =
-      // (column i*8 + (lane>>3), 16-byte chunk lane&7) -- eight lanes share one dot product
+      // a set's 16 columns are four runs of four consecutive columns (512 B each): load i covers the eight columns
+      // 8*(2i + (g>>2)) + 4*set + (g&3); both sets (a tie between the half-waves): four loads of eight consecutive columns
       v4i x[RU], y[RU][4];
-      int ct[RU][4];
+      int ct[RU][4], col[RU][4], rti[RU];
 #pragma unroll
       for (int u = 0; u < RU; ++u) {
-        x[u] = *reinterpret_cast<const v4i*>(arow + (size_t)(uint32_t)rr_l[u] * 128 + (lane & 7) * 16);
-        const int8_t* tbase = bimg + (size_t)tile_l[u] * 4096 + lane * 16;
-        const int32_t* tterm = rt_b + tile_l[u] * 32 + (lane >> 3);
+        x[u] = *reinterpret_cast<const v4i*>(p.desc + (size_t)grow_l[u] * 128 + (lane & 7) * 16);
+        rti[u] = p.rterm[grow_l[u]];
+        const bool both = set_l[u] == 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          y[u][i] = *reinterpret_cast<const v4i*>(tbase + i * 1024);
-          ct[u][i] = tterm[i * 8];
+          col[u][i] = both ? i * 8 + g : 8 * (2 * (i & 1) + (g >> 2)) + 4 * set_l[u] + (g & 3);
+          if (i < 2 || both) {  // wave-uniform
+            const int c = tile_l[u] * 32 + col[u][i];
+            y[u][i] = *reinterpret_cast<const v4i*>(bimg + (size_t)c * 128 + (lane & 7) * 16);
+            ct[u][i] = rt_b[c];
+          }
         }
       }
 #pragma unroll
       for (int u = 0; u < RU; ++u) {
-        int key = INT32_MIN;
+        const bool both = set_l[u] == 2;
+        int k1 = INT32_MIN, k2 = INT32_MIN;  // the two largest keys (value << 5 | 31 - column: distinct per column)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          int acc = 0;
+          if (i < 2 || both) {
+            int acc = 0;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_sdot4(x[u][e], y[u][i][e], acc, false);
-          acc += __shfl_xor(acc, 1);
-          acc += __shfl_xor(acc, 2);
-          acc += __shfl_xor(acc, 4);
-          const int col = i * 8 + (lane >> 3);
-          key = max(key, (int)((uint32_t)(acc + ct[u][i]) << 5) | (31 - col));  // |S + rterm(j)| <= 2^22
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_sdot4(x[u][e], y[u][i][e], acc, false);
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            acc += __shfl_xor(acc, 4);
+            const int key = (int)((uint32_t)(acc + ct[u][i]) << 5) | (31 - col[u][i]);  // |S + rterm(j)| <= 2^22
+            k2 = max(k2, min(k1, key));
+            k1 = max(k1, key);
+          }
         }
-        key = max(key, __shfl_xor(key, 8));
-        key = max(key, __shfl_xor(key, 16));
-        key = max(key, __shfl_xor(key, 32));
-        if (lane == 0 && on[u]) out[r_l[u]] = tile_l[u] * 32 + (31 - (key & 31));
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+          const int o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o);
+          k2 = max(min(k1, o1), max(k2, o2));
+          k1 = max(k1, o1);
+        }
+        if (lane == 0 && on[u]) {
+          const int bias = rti[u] + (1 << 21);
+          const int best_dot = (k1 >> 5) + bias;
+          const int second_dot = max(sap_l[u], (k2 >> 5) + bias);
+          const float bn = p.lut[min(best_dot, 262144)];
+          const float sn = p.lut[min(second_dot, 262144)];
+          const float rhs = __fmul_rn(p.max_ratio, sn);
+          out[r_l[u]] = (bn >= rhs) ? -1 : tile_l[u] * 32 + (31 - (k1 & 31));  // sift.cc:153
+        }
       }
     }
   }
