@@ -183,7 +183,11 @@ class Context:
     def sync(self):
         self._chk(lib().dsm_sync(self._h))
 
-    def set_images(self, descriptors, keypoints=None, cameras=None):
+    def append_images(self, descriptors, keypoints=None, cameras=None):
+        """dsm_append_images: adds images behind the resident ones (indices continue), uploading only the new rows."""
+        self.set_images(descriptors, keypoints, cameras, _append=True)
+
+    def set_images(self, descriptors, keypoints=None, cameras=None, _append=False):
         """descriptors: list of (n_i,128) uint8; keypoints: list of (n_i,>=2) float32; cameras: list of Camera."""
         n = len(descriptors)
         descs = [np.ascontiguousarray(d, dtype=np.uint8).reshape(-1, 128) for d in descriptors]
@@ -203,7 +207,9 @@ class Context:
         cptr = None
         if cameras is not None:
             cptr = (Camera * max(n, 1))(*cameras)
-        self._chk(lib().dsm_set_images(self._h, n, nf.ctypes.data_as(u32p), dptr, kptr, stride, cptr))
+        fn = lib().dsm_append_images if _append else lib().dsm_set_images
+        fn.argtypes = lib().dsm_set_images.argtypes
+        self._chk(fn(self._h, n, nf.ctypes.data_as(u32p), dptr, kptr, stride, cptr))
         self._keep = (descs, kps)
 
     def match_pairs(self, pairs, options=None):
@@ -211,6 +217,20 @@ class Context:
         p = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
         self.n_pairs = p.shape[0]
         self._chk(lib().dsm_match_pairs(self._h, self.n_pairs, p.ctypes.data_as(u32p), ctypes.byref(options)))
+
+    def set_matches(self, pairs, matches_per_pair):
+        """dsm_set_matches: installs given FeatureMatches for the pair list (the verify-only / resume path of
+        SiftFeatureMatcher::Match, matching.cc:806-812) instead of running the matcher."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        off = np.zeros(len(pairs) + 1, dtype=np.uint64)
+        for k, m in enumerate(matches_per_pair):
+            off[k + 1] = off[k] + len(m)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(m, dtype=np.uint32).reshape(-1, 2) for m in matches_per_pair] +
+                                                   [np.zeros((1, 2), np.uint32)]), dtype=np.uint32)
+        lib().dsm_set_matches.argtypes = [ctypes.c_void_p, ctypes.c_uint32, u32p, ctypes.POINTER(ctypes.c_uint64), u32p]
+        self._chk(lib().dsm_set_matches(self._h, len(pairs), pairs.ctypes.data_as(u32p),
+                                        off.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), flat.ctypes.data_as(u32p)))
+        self.n_pairs = len(pairs)
 
     def match_counts(self):
         c = np.zeros(max(self.n_pairs, 1), dtype=np.uint32)

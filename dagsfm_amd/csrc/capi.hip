@@ -175,75 +175,109 @@ int dsm_sync(dsm_ctx* ctx) {
   return DSM_OK;
 }
 
-int dsm_set_images(dsm_ctx* ctx, uint32_t n_images, const uint32_t* n_feats, const uint8_t* const* desc,
-                   const float* const* kp_xy, uint32_t kp_stride, const dsm_camera* cameras) {
+// dsm_set_images (append = false: the resident set is replaced) and dsm_append_images (append = true: the images
+// already on the device stay where they are, the new ones get the next indices and only THEIR rows cross PCIe).
+static int upload_images(dsm_ctx* ctx, bool append, uint32_t n_new, const uint32_t* n_feats, const uint8_t* const* desc,
+                         const float* const* kp_xy, uint32_t kp_stride, const dsm_camera* cameras) {
   if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
-  if (n_images && (!n_feats || !desc)) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "null image arrays");
+  if (n_new && (!n_feats || !desc)) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "null image arrays");
   if (kp_xy && kp_stride < 2) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "kp_stride must be >= 2");
   if (cameras)  // Camera::SetModelId CHECKs ExistsCameraModelWithId (camera.cc:52); never a silent default
-    for (uint32_t i = 0; i < n_images; ++i)
+    for (uint32_t i = 0; i < n_new; ++i)
       if (!cam_model_exists(cameras[i].model_id)) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "camera model id does not exist (0..10)");
+  const uint32_t n_old = append ? ctx->n_images : 0u;
+  const uint64_t rows_old = append ? ctx->total_rows : 0ull;
+  if (append && n_old) {
+    if ((kp_xy != nullptr) != ctx->have_kp) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "appended images must carry keypoints iff the resident ones do");
+    if ((cameras != nullptr) != !ctx->cameras.empty()) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "appended images must carry cameras iff the resident ones do");
+  }
+  std::vector<uint32_t> row0(n_new), rows(n_new);
+  uint64_t total = rows_old;
+  for (uint32_t i = 0; i < n_new; ++i) {
+    if (n_feats[i] > 0 && !desc[i]) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "null descriptor pointer");
+    if (kp_xy && n_feats[i] > 0 && !kp_xy[i]) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "null keypoint pointer");
+    const uint64_t r = ((uint64_t)n_feats[i] + 255) / 256 * 256;
+    if (total + r > 0xffffff00ull) return fail(ctx, DSM_ERR_OUT_OF_RANGE, "too many feature rows for one context");
+    row0[i] = (uint32_t)total;
+    rows[i] = (uint32_t)r;
+    total += r;
+  }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->matched = false;
   ctx->verified = false;
   dsm_retrieval_invalidate(ctx);
+  const uint32_t n_images = n_old + n_new;
+  const uint64_t rows_new = total - rows_old;
+  // device buffers first (an allocation failure leaves the resident set as it was)
+  if (append) {
+    HIPCHK(ctx, ctx->d_desc.grow(std::max<uint64_t>(total, 1) * 128, rows_old * 128, ctx->stream));
+    HIPCHK(ctx, ctx->d_rterm.grow(std::max<uint64_t>(total, 1) * 4, rows_old * 4, ctx->stream));
+    HIPCHK(ctx, ctx->d_img_row0.grow(std::max<uint32_t>(n_images, 1) * 4, (size_t)n_old * 4, ctx->stream));
+    HIPCHK(ctx, ctx->d_img_rows.grow(std::max<uint32_t>(n_images, 1) * 4, (size_t)n_old * 4, ctx->stream));
+    if (kp_xy && total) HIPCHK(ctx, ctx->d_kp.grow(total * 16, rows_old * 16, ctx->stream));
+  } else {  // replacing: free first, no second copy of the old set in memory
+    HIPCHK(ctx, ctx->d_desc.reserve(std::max<uint64_t>(total, 1) * 128));
+    HIPCHK(ctx, ctx->d_rterm.reserve(std::max<uint64_t>(total, 1) * 4));
+    HIPCHK(ctx, ctx->d_img_row0.reserve(std::max<uint32_t>(n_images, 1) * 4));
+    HIPCHK(ctx, ctx->d_img_rows.reserve(std::max<uint32_t>(n_images, 1) * 4));
+    if (kp_xy && total) HIPCHK(ctx, ctx->d_kp.reserve(total * 16));
+  }
+  if (!append) {
+    ctx->nfeat.clear();
+    ctx->row0.clear();
+    ctx->rows.clear();
+    ctx->cameras.clear();
+  }
   ctx->n_images = n_images;
-  ctx->nfeat.assign(n_feats, n_feats + n_images);
-  ctx->row0.resize(n_images);
-  ctx->rows.resize(n_images);
-  uint64_t total = 0;
-  for (uint32_t i = 0; i < n_images; ++i) {
-    if (n_feats[i] > 0 && !desc[i]) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "null descriptor pointer");
-    const uint64_t r = ((uint64_t)n_feats[i] + 255) / 256 * 256;
-    if (total + r > 0xffffff00ull) return fail(ctx, DSM_ERR_OUT_OF_RANGE, "too many feature rows for one context");
-    ctx->row0[i] = (uint32_t)total;
-    ctx->rows[i] = (uint32_t)r;
-    total += r;
-  }
+  ctx->nfeat.insert(ctx->nfeat.end(), n_feats, n_feats + n_new);
+  ctx->row0.insert(ctx->row0.end(), row0.begin(), row0.end());
+  ctx->rows.insert(ctx->rows.end(), rows.begin(), rows.end());
   ctx->total_rows = total;
-  ctx->cameras.clear();
-  if (cameras) ctx->cameras.assign(cameras, cameras + n_images);
+  if (cameras) ctx->cameras.insert(ctx->cameras.end(), cameras, cameras + n_new);
   ctx->have_kp = kp_xy != nullptr;
-
-  HIPCHK(ctx, ctx->d_desc.reserve(std::max<uint64_t>(total, 1) * 128));
-  HIPCHK(ctx, ctx->d_rterm.reserve(std::max<uint64_t>(total, 1) * 4));
-  HIPCHK(ctx, ctx->d_img_row0.reserve(std::max<uint32_t>(n_images, 1) * 4));
-  HIPCHK(ctx, ctx->d_img_rows.reserve(std::max<uint32_t>(n_images, 1) * 4));
-  if (n_images) {
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_img_row0.p, ctx->row0.data(), n_images * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_img_rows.p, ctx->rows.data(), n_images * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (n_new) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_img_row0.as<uint32_t>() + n_old, row0.data(), (size_t)n_new * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_img_rows.as<uint32_t>() + n_old, rows.data(), (size_t)n_new * 4, hipMemcpyHostToDevice, ctx->stream));
   }
-  if (total) {
-    // stage the padded u8 image in a temporary device buffer, convert in place with K0
+  if (rows_new) {
+    // stage the padded u8 rows of the new images in a temporary device buffer, convert with K0
     DevBuf tmp;
-    HIPCHK(ctx, tmp.reserve(total * 128));
-    HIPCHK(ctx, hipMemsetAsync(tmp.p, 0, total * 128, ctx->stream));
-    for (uint32_t i = 0; i < n_images; ++i) {
+    HIPCHK(ctx, tmp.reserve(rows_new * 128));
+    HIPCHK(ctx, hipMemsetAsync(tmp.p, 0, rows_new * 128, ctx->stream));
+    for (uint32_t i = 0; i < n_new; ++i) {
       if (!n_feats[i]) continue;
-      HIPCHK(ctx, hipMemcpyAsync(tmp.as<uint8_t>() + (uint64_t)ctx->row0[i] * 128, desc[i], (uint64_t)n_feats[i] * 128,
+      HIPCHK(ctx, hipMemcpyAsync(tmp.as<uint8_t>() + ((uint64_t)row0[i] - rows_old) * 128, desc[i], (uint64_t)n_feats[i] * 128,
                                  hipMemcpyHostToDevice, ctx->stream));
     }
-    launch_k0(tmp.as<uint8_t>(), ctx->d_desc.as<int8_t>(), ctx->d_rterm.as<int32_t>(), total, ctx->stream);
+    launch_k0(tmp.as<uint8_t>(), ctx->d_desc.as<int8_t>() + rows_old * 128, ctx->d_rterm.as<int32_t>() + rows_old, rows_new, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     tmp.release();
   }
-  if (kp_xy && total) {
-    std::vector<double> kp(total * 2, 0.0);
-    for (uint32_t i = 0; i < n_images; ++i) {
+  if (kp_xy && rows_new) {
+    std::vector<double> kp(rows_new * 2, 0.0);
+    for (uint32_t i = 0; i < n_new; ++i) {
       if (!n_feats[i]) continue;
-      if (!kp_xy[i]) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "null keypoint pointer");
-      double* dst = kp.data() + (uint64_t)ctx->row0[i] * 2;
+      double* dst = kp.data() + ((uint64_t)row0[i] - rows_old) * 2;
       for (uint32_t k = 0; k < n_feats[i]; ++k) {
         dst[2 * k + 0] = (double)kp_xy[i][(uint64_t)k * kp_stride + 0];
         dst[2 * k + 1] = (double)kp_xy[i][(uint64_t)k * kp_stride + 1];
       }
     }
-    HIPCHK(ctx, ctx->d_kp.reserve(total * 16));
-    HIPCHK(ctx, hipMemcpy(ctx->d_kp.p, kp.data(), total * 16, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_kp.as<double>() + rows_old * 2, kp.data(), rows_new * 16, hipMemcpyHostToDevice));
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return DSM_OK;
+}
+
+int dsm_set_images(dsm_ctx* ctx, uint32_t n_images, const uint32_t* n_feats, const uint8_t* const* desc,
+                   const float* const* kp_xy, uint32_t kp_stride, const dsm_camera* cameras) {
+  return upload_images(ctx, false, n_images, n_feats, desc, kp_xy, kp_stride, cameras);
+}
+
+int dsm_append_images(dsm_ctx* ctx, uint32_t n_images, const uint32_t* n_feats, const uint8_t* const* desc,
+                      const float* const* kp_xy, uint32_t kp_stride, const dsm_camera* cameras) {
+  return upload_images(ctx, true, n_images, n_feats, desc, kp_xy, kp_stride, cameras);
 }
 
 int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const dsm_match_options* options) {
@@ -575,28 +609,24 @@ static uint32_t ransac_ctor_max_trials(const dsm_two_view_options* o, double min
 
 static const int kMinSamples[4] = {5, 7, 4, 1};
 
-// makes sure the ComputeNumTrials tables for the given match counts (E/F/H) and for every inlier
-// count up to n_max (translation) exist on the device
+// makes sure the ComputeNumTrials tables of the E / F / H estimators exist on the device for the given match counts
+// (3 x (N + 1) entries per distinct count N; the translation estimator's tables are built on demand, below)
 static int ensure_nt_tables(dsm_ctx* ctx, const dsm_two_view_options* o, const std::vector<uint32_t>& counts, uint32_t n_max) {
   if (ctx->nt_confidence != o->confidence) {
     ctx->nt_confidence = o->confidence;
     ctx->nt_table.clear();
     ctx->nt_off.clear();
+    ctx->nt_table_t.clear();
     ctx->nt_off_t.clear();
-    ctx->nt_dirty = true;
+    ctx->nt_dirty = ctx->nt_dirty_t = true;
   }
   if (ctx->nt_off.size() < (size_t)n_max + 1) {
     ctx->nt_off.resize((size_t)n_max + 1, 0);
     ctx->nt_dirty = true;
   }
-  const size_t old_t = ctx->nt_off_t.size();
-  if (old_t < (size_t)n_max + 1) {
+  if (ctx->nt_off_t.size() < (size_t)n_max + 1) {
     ctx->nt_off_t.resize((size_t)n_max + 1, 0);
-    for (size_t N = old_t; N <= n_max; ++N) {
-      ctx->nt_off_t[N] = ctx->nt_table.size();
-      for (size_t k = 0; k <= N; ++k) ctx->nt_table.push_back(host_num_trials(k, N, o->confidence, kMinSamples[3]));
-    }
-    ctx->nt_dirty = true;
+    ctx->nt_dirty_t = true;
   }
   for (uint32_t N : counts) {
     if (N > n_max || ctx->nt_off[N] != 0) continue;
@@ -610,11 +640,31 @@ static int ensure_nt_tables(dsm_ctx* ctx, const dsm_two_view_options* o, const s
     for (size_t i = 0; i < off.size(); ++i) off[i] = ctx->nt_off[i] ? ctx->nt_off[i] - 1 : 0;
     HIPCHK(ctx, ctx->d_nt_table.reserve(std::max<size_t>(ctx->nt_table.size(), 1) * 4));
     HIPCHK(ctx, ctx->d_nt_off.reserve(off.size() * 8));
-    HIPCHK(ctx, ctx->d_nt_off_t.reserve(ctx->nt_off_t.size() * 8));
     HIPCHK(ctx, hipMemcpy(ctx->d_nt_table.p, ctx->nt_table.data(), ctx->nt_table.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->d_nt_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(ctx->d_nt_off_t.p, ctx->nt_off_t.data(), ctx->nt_off_t.size() * 8, hipMemcpyHostToDevice));
     ctx->nt_dirty = false;
+  }
+  return DSM_OK;
+}
+
+// The translation estimator's tables (TwoViewGeometry::DetectWatermark, two_view_geometry.cc:541-549: RANSAC over the
+// INLIER points, so the sample count is an inlier count nobody knows before the run): only for the counts in `totals`,
+// N + 1 entries each.  Round 2 tabulated every N up to the largest match count up front -- O(n^2) entries, 134 MB at
+// 8 192 matches, GBs at the reference's max_num_matches -- although a watermark suspect is rare.  Uploads when
+// anything changed (or nothing has been uploaded yet: the kernels read nt_off_t[N] == 0 as "not built").
+static int ensure_nt_tables_t(dsm_ctx* ctx, const dsm_two_view_options* o, const std::vector<uint32_t>& totals) {
+  for (uint32_t N : totals) {
+    if (N >= ctx->nt_off_t.size() || ctx->nt_off_t[N] != 0) continue;
+    ctx->nt_off_t[N] = ctx->nt_table_t.size() + 1;
+    for (size_t k = 0; k <= N; ++k) ctx->nt_table_t.push_back(host_num_trials(k, N, o->confidence, kMinSamples[3]));
+    ctx->nt_dirty_t = true;
+  }
+  if (ctx->nt_dirty_t) {
+    HIPCHK(ctx, ctx->d_nt_table_t.reserve(std::max<size_t>(ctx->nt_table_t.size(), 1) * 4));
+    HIPCHK(ctx, ctx->d_nt_off_t.reserve(std::max<size_t>(ctx->nt_off_t.size(), 1) * 8));
+    HIPCHK(ctx, hipMemcpy(ctx->d_nt_table_t.p, ctx->nt_table_t.data(), ctx->nt_table_t.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_nt_off_t.p, ctx->nt_off_t.data(), ctx->nt_off_t.size() * 8, hipMemcpyHostToDevice));
+    ctx->nt_dirty_t = false;
   }
   return DSM_OK;
 }
@@ -749,7 +799,12 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   uint32_t n_max = 1;
   for (uint32_t c : counts) n_max = std::max(n_max, c);
   int rc = ensure_nt_tables(ctx, o, counts, n_max);
+  if (rc == DSM_OK) rc = ensure_nt_tables_t(ctx, o, {});
   if (rc != DSM_OK) return rc;
+  HIPCHK(ctx, ctx->d_wm_redo.reserve(std::max<uint32_t>(n_pairs, 1) * 4));
+  HIPCHK(ctx, ctx->d_wm_total.reserve(std::max<uint32_t>(n_pairs, 1) * 4));
+  HIPCHK(ctx, ctx->d_wm_count.reserve(4));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_wm_count.p, 0, 4, st));
   HIPCHK(ctx, ctx->d_tvg.reserve(std::max<uint32_t>(n_pairs, 1) * sizeof(dsm_two_view_geometry)));
   HIPCHK(ctx, ctx->d_inl.reserve(std::max<uint64_t>(total_matches, 1) * 8));
   HIPCHK(ctx, ctx->d_inl_counts.reserve(std::max<uint32_t>(n_pairs, 1) * 4));
@@ -782,6 +837,12 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.nt_table = ctx->d_nt_table.as<uint32_t>();
   vp.nt_off = ctx->d_nt_off.as<uint64_t>();
   vp.nt_off_t = ctx->d_nt_off_t.as<uint64_t>();
+  vp.nt_table_t = ctx->d_nt_table_t.as<uint32_t>();
+  vp.wm_redo = ctx->d_wm_redo.as<uint32_t>();
+  vp.wm_total = ctx->d_wm_total.as<uint32_t>();
+  vp.wm_count = ctx->d_wm_count.as<uint32_t>();
+  vp.final_list = nullptr;
+  vp.n_final = 0;
   vp.max_trials[0] = ransac_ctor_max_trials(o, o->min_inlier_ratio, kMinSamples[0]);
   vp.max_trials[1] = ransac_ctor_max_trials(o, o->min_inlier_ratio, kMinSamples[1]);
   vp.max_trials[2] = ransac_ctor_max_trials(o, o->min_inlier_ratio, kMinSamples[2]);
@@ -833,7 +894,6 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     HIPCHK(ctx, hipEventRecord(ctx->vev0, st));
     launch_verify(vp, n_blocks, st);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(ctx->vev1, st));
   } else {
     // phase-split pipeline: per family, rounds of sample -> solve+score -> replay until no pair is active
     VerifyPlan plan;
@@ -850,7 +910,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
       }
       if (bmax_out) *bmax_out = bmax;
       if (bm_out) *bm_out = bm;
-      return (uint64_t)bmax * (7 * 4 + 4 + 4) + bm * (4 + 8 + 72) + (uint64_t)b[0] * 200 * 8 + (LO_WORK_DOUBLES + 90 + 90 + 200) * 8 + 8;
+      return (uint64_t)bmax * (7 * 4 + 4 + 4) + bm * (4 + 8 + 72) + (uint64_t)b[0] * 200 * 8 + (LO_WORK_DOUBLES + 90 + 90 + 200) * 8 + 12;
     };
     // Lanes: the pair list is dealt out in chunks to up to DSM_VERIFY_MAX_LANES lanes that run concurrently (own
     // stream, own host thread, own scratch; see VerifyLane).  A pair's three families cannot overlap -- F starts from
@@ -930,27 +990,58 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     vp.lo_inl = ctx->d_lo_inl.as<uint32_t>();
     vp.fam_state = ctx->d_fam_state.as<FamState>();
     vp.sidx_g = ctx->d_sidx.as<uint32_t>();
+    // The lane scratch was sized from what hipMemGetInfo reported a moment ago; other contexts of this process (bench
+    // --contexts, several host threads) may have taken that memory since.  An allocation failure here is not an
+    // error: release the lanes' scratch, halve the chunks, try again (a chunk of one pair always fits or nothing does).
+    for (;;) {
+      auto reserve_lanes = [&]() -> hipError_t {
+#define LRES(call)                          \
+  do {                                      \
+    const hipError_t e_ = (call);           \
+    if (e_ != hipSuccess) return e_;        \
+  } while (0)
+        for (uint32_t li = 0; li < n_lanes; ++li) {
+          VerifyLane& L = ctx->lanes[li];
+          const uint32_t chunk = plan.chunk[li];
+          const uint32_t lane_blocks = std::min<uint32_t>(chunk, (uint32_t)dev_cus * 16u);
+          if (!L.stream) LRES(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+          if (!L.done) LRES(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+          if (!L.host_ctr) LRES(hipHostMalloc(reinterpret_cast<void**>(&L.host_ctr), 128, hipHostMallocDefault));
+          LRES(L.active.reserve(128));
+          LRES(L.vscratch.reserve(std::max<size_t>(1, (size_t)lane_blocks * verify_scratch_bytes_per_block(n_max))));
+          LRES(L.samples.reserve((size_t)chunk * plan.bmax * 7 * 4));
+          LRES(L.draws_end.reserve((size_t)chunk * plan.bmax * 4));
+          LRES(L.nmodels.reserve((size_t)chunk * plan.bmax * 4));
+          LRES(L.vcounts.reserve((size_t)chunk * bm_max * 4));
+          LRES(L.vsums.reserve((size_t)chunk * bm_max * 8));
+          LRES(L.models.reserve((size_t)chunk * bm_max * 72));
+          LRES(L.ework.reserve((size_t)chunk * plan.batch[0] * 200 * 8));
+          LRES(L.lo_queue.reserve((size_t)chunk * 3 * 4));  // two alternating queues + the general-kernel list
+          LRES(L.lo_work.reserve((size_t)chunk * LO_WORK_DOUBLES * 8));
+          LRES(L.lo_models.reserve((size_t)chunk * 90 * 8));
+          LRES(L.lo_slots.reserve((size_t)chunk * 90 * 8));
+          LRES(L.lo_ework.reserve((size_t)chunk * 200 * 8));
+        }
+#undef LRES
+        return hipSuccess;
+      };
+      const hipError_t e = reserve_lanes();
+      if (e == hipSuccess) break;
+      (void)hipGetLastError();
+      uint32_t largest = 0;
+      for (uint32_t li = 0; li < n_lanes; ++li) largest = std::max(largest, plan.chunk[li]);
+      if (e != hipErrorOutOfMemory || largest <= 1) {
+        ctx->err = std::string("verification scratch: ") + hipGetErrorString(e);
+        return DSM_ERR_HIP;
+      }
+      for (VerifyLane& L : ctx->lanes)
+        for (DevBuf* b : {&L.samples, &L.draws_end, &L.nmodels, &L.vcounts, &L.vsums, &L.models, &L.ework, &L.vscratch, &L.lo_queue, &L.lo_work,
+                          &L.lo_models, &L.lo_slots, &L.lo_ework})
+          b->release();
+      for (uint32_t li = 0; li < n_lanes; ++li) plan.chunk[li] = std::max<uint32_t>(1, plan.chunk[li] / 2);
+    }
     for (uint32_t li = 0; li < n_lanes; ++li) {
       VerifyLane& L = ctx->lanes[li];
-      const uint32_t chunk = plan.chunk[li];
-      const uint32_t lane_blocks = std::min<uint32_t>(chunk, (uint32_t)dev_cus * 16u);
-      if (!L.stream) HIPCHK(ctx, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-      if (!L.done) HIPCHK(ctx, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
-      if (!L.host_ctr) HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&L.host_ctr), 128, hipHostMallocDefault));
-      HIPCHK(ctx, L.active.reserve(128));
-      HIPCHK(ctx, L.vscratch.reserve(std::max<size_t>(1, (size_t)lane_blocks * verify_scratch_bytes_per_block(n_max))));
-      HIPCHK(ctx, L.samples.reserve((size_t)chunk * plan.bmax * 7 * 4));
-      HIPCHK(ctx, L.draws_end.reserve((size_t)chunk * plan.bmax * 4));
-      HIPCHK(ctx, L.nmodels.reserve((size_t)chunk * plan.bmax * 4));
-      HIPCHK(ctx, L.vcounts.reserve((size_t)chunk * bm_max * 4));
-      HIPCHK(ctx, L.vsums.reserve((size_t)chunk * bm_max * 8));
-      HIPCHK(ctx, L.models.reserve((size_t)chunk * bm_max * 72));
-      HIPCHK(ctx, L.ework.reserve((size_t)chunk * plan.batch[0] * 200 * 8));
-      HIPCHK(ctx, L.lo_queue.reserve((size_t)chunk * 3 * 4));  // two alternating queues + the general-kernel list
-      HIPCHK(ctx, L.lo_work.reserve((size_t)chunk * LO_WORK_DOUBLES * 8));
-      HIPCHK(ctx, L.lo_models.reserve((size_t)chunk * 90 * 8));
-      HIPCHK(ctx, L.lo_slots.reserve((size_t)chunk * 90 * 8));
-      HIPCHK(ctx, L.lo_ework.reserve((size_t)chunk * 200 * 8));
       L.rc = DSM_OK;
       L.err.clear();
       for (int f = 0; f < 3; ++f) L.rounds[f] = L.lo_iters[f] = 0;
@@ -984,7 +1075,6 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
       }
       HIPCHK(ctx, hipStreamWaitEvent(st, L.done, 0));
     }
-    HIPCHK(ctx, hipEventRecord(ctx->vev1, st));
     for (int f = 0; f < 3; ++f) {
       ctx->verify_rounds[f] = ctx->verify_lo_iters[f] = 0;
       for (uint32_t li = 0; li < n_lanes; ++li) {
@@ -1016,6 +1106,35 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
               ctx->verify_rounds[0], ctx->verify_rounds[1], ctx->verify_rounds[2], dbg[1], dbg[3], dbg[5], dbg[2], dbg[4], dbg[6]);
     }
   }
+  // Pairs whose watermark test waited for a translation table (k_verify_final): build the tables of their inlier
+  // counts, visit exactly those pairs again.  Normally none.
+  {
+    uint32_t n_redo = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&n_redo, ctx->d_wm_count.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (n_redo) {
+      std::vector<uint32_t> totals(n_redo);
+      HIPCHK(ctx, hipMemcpy(totals.data(), ctx->d_wm_total.p, (size_t)n_redo * 4, hipMemcpyDeviceToHost));
+      rc = ensure_nt_tables_t(ctx, o, totals);
+      if (rc != DSM_OK) return rc;
+      vp.nt_table_t = ctx->d_nt_table_t.as<uint32_t>();
+      vp.nt_off_t = ctx->d_nt_off_t.as<uint64_t>();
+      vp.final_list = ctx->d_wm_redo.as<uint32_t>();
+      vp.n_final = n_redo;
+      vp.pair0 = 0;
+      vp.n_chunk = n_pairs;
+      vp.active_count = nullptr;
+      // the lanes are done: the per-block work area of lane 0 (legacy schedule: the context's) is free
+      DevBuf& sb = legacy ? ctx->d_vscratch : ctx->lanes[0].vscratch;
+      const size_t per_block = std::max<size_t>(1, verify_scratch_bytes_per_block(n_max));
+      const uint32_t nb = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_redo, sb.cap / per_block));
+      vp.scratch = sb.as<double>();
+      HIPCHK(ctx, hipMemsetAsync(ctx->d_wm_count.p, 0, 4, st));
+      launch_vp_final(vp, nb, st);
+      HIPCHK(ctx, hipGetLastError());
+    }
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->vev1, st));
   // compact inlier matches in list order
   HIPCHK(ctx, hipMemsetAsync(ctx->d_inl_total.p, 0, 8, st));
   launch_scan(ctx->d_inl_counts.as<uint32_t>(), ctx->d_inl_off.as<uint64_t>(), n_pairs, ctx->d_inl_total.as<uint64_t>(), st);

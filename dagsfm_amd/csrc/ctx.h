@@ -104,6 +104,7 @@ struct dsm_ctx {
   DevBuf d_cams, d_pairs_dev, d_seeds, d_tvg, d_inl, d_inl_counts, d_inl_off, d_inl_compact, d_vscratch, d_inl_total;
   DevBuf d_nt_table, d_nt_off, d_nt_off_t, d_pair_state, d_pts_px, d_pts_norm, d_reports, d_masks;
   DevBuf d_fam_state, d_sidx, d_lo_inl;
+  DevBuf d_nt_table_t, d_wm_redo, d_wm_total, d_wm_count;
   VerifyLane lanes[DSM_VERIFY_MAX_LANES];
   uint32_t verify_lanes = 1;  // lanes of the last call
   uint32_t verify_lo_iters[3] = {0, 0, 0};
@@ -115,9 +116,11 @@ struct dsm_ctx {
   double verify_ms = 0.0;
   // cache of the tabulated RANSAC::ComputeNumTrials (host libm), keyed by confidence
   double nt_confidence = -1.0;
-  std::vector<uint32_t> nt_table;        // all tables back to back
-  std::vector<uint64_t> nt_off, nt_off_t;  // per N (0 = absent; offsets are stored +1)
-  bool nt_dirty = true;
+  std::vector<uint32_t> nt_table;        // E / F / H tables of the match counts seen so far, back to back
+  std::vector<uint64_t> nt_off;          // per N (0 = absent; offsets are stored +1)
+  std::vector<uint32_t> nt_table_t;      // translation tables of the inlier counts that needed one (built on demand)
+  std::vector<uint64_t> nt_off_t;        // per N (0 = absent; offsets are stored +1)
+  bool nt_dirty = true, nt_dirty_t = true;
   hipEvent_t vev0 = nullptr, vev1 = nullptr;
 
   dsm_ctx* leaf = nullptr;  // private context of the one-shot leaf entry points

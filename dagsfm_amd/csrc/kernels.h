@@ -108,7 +108,15 @@ struct VerifyParams {
   const uint32_t* seeds;       // per pair PRNG seed
   const uint32_t* nt_table;    // tabulated RANSAC::ComputeNumTrials (host libm)
   const uint64_t* nt_off;      // [n_max+1]: offset of the E/F/H tables (3 x (N+1)) for N matches
-  const uint64_t* nt_off_t;    // [n_max+1]: offset of the translation table (N+1) for N inliers
+  const uint32_t* nt_table_t;  // translation tables (DetectWatermark's RANSAC), built on demand: see wm_redo
+  const uint64_t* nt_off_t;    // [n_max+1]: offset + 1 of the translation table (N+1 entries) for N inliers, 0 = not built
+  // a pair whose watermark test needs a translation table that does not exist yet is recorded here and left alone;
+  // the host builds the tables and runs k_verify_final again over exactly those pairs (final_list)
+  uint32_t* wm_redo;           // [n_pairs] pair indices
+  uint32_t* wm_total;          // [n_pairs] their inlier counts (= the table they need)
+  uint32_t* wm_count;
+  const uint32_t* final_list;  // != nullptr: k_verify_final processes pairs final_list[0 .. n_final)
+  uint32_t n_final;
   uint32_t max_trials[4];      // RANSAC ctor's max_num_trials per family (E, F, H, T)
   uint32_t first_batch[3];     // trials speculated in a pair's first round (<= batch; later rounds draw what the dynamic stop asks for, up to batch)
   dsm_two_view_geometry* tvg;  // [n_pairs]

@@ -52,7 +52,7 @@ struct RetrievalState {
   DevBuf d_row_img, d_wid, d_sig;                       // per feature row
   DevBuf d_keys, d_keys2, d_vals, d_vals2, d_tmp;        // sort scratch
   DevBuf d_file_start, d_e_img, d_e_sig, d_nimg, d_idf;  // inverted files
-  DevBuf d_img_start, d_normc, d_qnorm;
+  DevBuf d_img_start, d_normc, d_qnorm, d_nfeat, d_wcounts;  // d_nfeat: feature counts of the images (query kernels); d_wcounts: entries per word (index)
   DevBuf d_acc, d_first, d_skeys, d_skeys2, d_svals, d_svals2, d_seg, d_out_cnt, d_out_idx, d_out_score;
   std::vector<uint32_t> img_valid_start;  // prefix sums of the feature counts
   double index_ms = 0.0, query_ms = 0.0;
@@ -409,7 +409,7 @@ void dsm_retrieval_destroy(dsm_ctx* ctx) {
   if (!r) return;
   DevBuf* bufs[] = {&r->d_words, &r->d_cw, &r->d_projT, &r->d_thr, &r->d_lut, &r->d_row_img, &r->d_wid, &r->d_sig, &r->d_keys,
                     &r->d_keys2, &r->d_vals, &r->d_vals2, &r->d_tmp, &r->d_file_start, &r->d_e_img, &r->d_e_sig, &r->d_nimg,
-                    &r->d_idf, &r->d_img_start, &r->d_normc, &r->d_qnorm, &r->d_acc, &r->d_first, &r->d_skeys, &r->d_skeys2,
+                    &r->d_idf, &r->d_img_start, &r->d_normc, &r->d_qnorm, &r->d_nfeat, &r->d_wcounts, &r->d_acc, &r->d_first, &r->d_skeys, &r->d_skeys2,
                     &r->d_svals, &r->d_svals2, &r->d_seg, &r->d_out_cnt, &r->d_out_idx, &r->d_out_score};
   for (DevBuf* b : bufs) b->release();
   if (r->ev0) (void)hipEventDestroy(r->ev0);
@@ -689,7 +689,7 @@ int dsm_retrieval_index(dsm_ctx* ctx) {
   // counts per word -> file_start (exclusive scan); entries sorted by word, stable = (image, feature) order inside a
   // file: InvertedFile::SortEntries sorts by image id (inverted_file.h:223-230)
   std::vector<uint32_t> counts((size_t)W + 1, 0), starts((size_t)W + 2, 0);
-  DevBuf d_counts;
+  DevBuf& d_counts = r->d_wcounts;  // owned by the state: no leak on the early returns below
   RCHK(ctx, d_counts.reserve(((size_t)W + 1) * 4));
   RCHK(ctx, hipMemsetAsync(d_counts.p, 0, ((size_t)W + 1) * 4, st));
   if (rows) {
@@ -707,7 +707,6 @@ int dsm_retrieval_index(dsm_ctx* ctx) {
   }
   RCHK(ctx, hipMemcpyAsync(counts.data(), d_counts.p, ((size_t)W + 1) * 4, hipMemcpyDeviceToHost, st));
   RCHK(ctx, hipStreamSynchronize(st));
-  d_counts.release();
   for (uint32_t w = 0; w <= W; ++w) starts[w + 1] = starts[w] + counts[w];
   RCHK(ctx, hipMemcpyAsync(r->d_file_start.p, starts.data(), ((size_t)W + 2) * 4, hipMemcpyHostToDevice, st));
   if (n_entries) {
@@ -769,7 +768,7 @@ int dsm_retrieval_query(dsm_ctx* ctx, uint32_t num_neighbors, uint32_t max_num_i
   if (NI == 0) return DSM_OK;
   const int k = (int)num_neighbors;
   RCHK(ctx, hipEventRecord(r->ev0, st));
-  DevBuf d_nfeat;
+  DevBuf& d_nfeat = r->d_nfeat;  // owned by the state: released with it on every exit path
   RCHK(ctx, d_nfeat.reserve((size_t)NI * 4));
   RCHK(ctx, hipMemcpyAsync(d_nfeat.p, ctx->nfeat.data(), (size_t)NI * 4, hipMemcpyHostToDevice, st));
   RCHK(ctx, r->d_qnorm.reserve((size_t)NI * 4));
@@ -826,7 +825,6 @@ int dsm_retrieval_query(dsm_ctx* ctx, uint32_t num_neighbors, uint32_t max_num_i
   RCHK(ctx, hipMemcpy(counts, r->d_out_cnt.p, (size_t)NI * 4, hipMemcpyDefault));
   RCHK(ctx, hipMemcpy(image_idx, r->d_out_idx.p, (size_t)NI * max_num_images * 4, hipMemcpyDefault));
   RCHK(ctx, hipMemcpy(scores, r->d_out_score.p, (size_t)NI * max_num_images * 4, hipMemcpyDefault));
-  d_nfeat.release();
   return DSM_OK;
 }
 

@@ -1096,13 +1096,17 @@ __global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p
   for (;;) {
     wv_sync();
     uint32_t pl;
-    if (p.active_count != nullptr) {  // pipeline: pairs handed out dynamically (work counter [17])
+    if (p.final_list != nullptr) {  // second visit of the pairs that waited for a translation table
+      if (pl_static >= p.n_final) break;
+      pl = p.final_list[pl_static] - p.pair0;
+      pl_static += gridDim.x;
+    } else if (p.active_count != nullptr) {  // pipeline: pairs handed out dynamically (work counter [17])
       pl = grab_item(wgrab, p.active_count + 17, &s_next, threadIdx.x, grain);
     } else {
       pl = pl_static;
       pl_static += gridDim.x;
     }
-    if (pl >= p.n_chunk) break;
+    if (p.final_list == nullptr && pl >= p.n_chunk) break;
     const uint32_t pi = p.pair0 + pl;
     const uint32_t im1 = p.pairs[2 * pi], im2 = p.pairs[2 * pi + 1];
     const uint64_t moff = p.match_off[pi];
@@ -1273,6 +1277,19 @@ __global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p
           }
           const double border_ratio = (double)in_border / (double)num_inliers;
           if (!(border_ratio < o.watermark_min_inlier_ratio)) {
+            // RANSAC::ComputeNumTrials of the translation estimator is tabulated per sample count like the others,
+            // but only for the inlier counts that ever get here (a watermark suspect is rare).  No table yet: note
+            // the pair and leave it untouched -- nothing has been drawn from its generator, everything written so
+            // far is rewritten identically -- the host builds the table and sends the pair through this kernel again.
+            const uint64_t toff = p.nt_off_t[total];
+            if (toff == 0) {
+              if (lane == 0) {
+                const uint32_t slot = atomicAdd(p.wm_count, 1u);
+                p.wm_redo[slot] = pi;
+                p.wm_total[slot] = (uint32_t)total;
+              }
+              continue;
+            }
             // translation LO-RANSAC over the inlier points (gathered into pts_norm's unused half or ipts)
             double* tp = pts3d_a;  // 4 * total doubles fit: pts3d_a + pts3d_b are contiguous (6n)
             for (int j = lane; j < total; j += 64) {
@@ -1283,7 +1300,7 @@ __global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p
             PairWork wt = w;
             wt.n = total;
             wt.pts = tp;
-            wt.nt_table = p.nt_table + p.nt_off_t[total];
+            wt.nt_table = p.nt_table_t + (toff - 1);
             RansacOpt rt;
             rt.max_error = o.max_error;
             rt.min_num_trials = (uint32_t)o.min_num_trials;

@@ -347,12 +347,13 @@ class SiftFeatureMatcherT {
             }
     }
     if (all_there) return true;
-    std::vector<image_id_t> ids = needed;
-    if (image_ids_.size() + needed.size() <= std::max(max_resident_, needed.size())) {
-      std::unordered_set<image_id_t> in(needed.begin(), needed.end());
-      for (image_id_t id : image_ids_)
-        if (in.insert(id).second) ids.push_back(id);
-    }
+    // Union fits the cache: the resident images stay where they are and only the missing ones are uploaded
+    // (dsm_append_images) -- consecutive blocks of ExhaustiveFeatureMatcher share half of their images.  Otherwise the
+    // set is replaced by what this call needs.
+    const bool append = !image_ids_.empty() && image_ids_.size() + needed.size() <= std::max(max_resident_, needed.size()) + CountResident(needed);
+    std::vector<image_id_t> ids;
+    for (image_id_t id : needed)
+      if (!append || !image_index_.count(id)) ids.push_back(id);
     std::sort(ids.begin(), ids.end());
     const uint32_t n = static_cast<uint32_t>(ids.size());
     std::vector<uint32_t> nfeat(n);
@@ -396,7 +397,10 @@ class SiftFeatureMatcherT {
     std::vector<int> rcs(ctxs_.size(), DSM_OK);
     std::vector<std::thread> th;
     for (size_t d = 0; d < ctxs_.size(); ++d)
-      th.emplace_back([&, d]() { rcs[d] = dsm_set_images(ctxs_[d], n, nfeat.data(), desc.data(), kp.data(), stride, cams.data()); });
+      th.emplace_back([&, d]() {
+        rcs[d] = append ? dsm_append_images(ctxs_[d], n, nfeat.data(), desc.data(), kp.data(), stride, cams.data())
+                        : dsm_set_images(ctxs_[d], n, nfeat.data(), desc.data(), kp.data(), stride, cams.data());
+      });
     for (auto& t : th) t.join();
     Traits::ReleasePins(cache_);
     for (size_t d = 0; d < ctxs_.size(); ++d)
@@ -406,11 +410,22 @@ class SiftFeatureMatcherT {
         image_index_.clear();
         return false;
       }
-    image_ids_ = ids;
-    image_nfeat_ = nfeat;
-    image_index_.clear();
-    for (uint32_t i = 0; i < n; ++i) image_index_[ids[i]] = i;
+    if (!append) {
+      image_ids_.clear();
+      image_nfeat_.clear();
+      image_index_.clear();
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+      image_index_[ids[i]] = static_cast<uint32_t>(image_ids_.size());
+      image_ids_.push_back(ids[i]);
+      image_nfeat_.push_back(nfeat[i]);
+    }
     return true;
+  }
+  size_t CountResident(const std::vector<image_id_t>& ids) const {
+    size_t c = 0;
+    for (image_id_t id : ids) c += image_index_.count(id);
+    return c;
   }
 
   typename Traits::Options options_;

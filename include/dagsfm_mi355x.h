@@ -160,6 +160,17 @@ int dsm_set_images(dsm_ctx* ctx, uint32_t n_images, const uint32_t* n_feats,
                    const uint8_t* const* desc, const float* const* kp_xy,
                    uint32_t kp_stride, const dsm_camera* cameras);
 
+/* Adds `n_images` images to the resident set without touching the ones already there: the new images
+ * get the indices n_resident .. n_resident + n_images - 1 and only their rows are uploaded.  This is
+ * FeatureMatcherCache's incremental behaviour (an LRU that loads what a block of the pair list adds,
+ * src/feature/matching.cc:245-316) for the device-side copy: ExhaustiveFeatureMatcher visits the
+ * database in blocks (matching.cc:870-905) and consecutive blocks share half of their images.
+ * Arguments as dsm_set_images; keypoints / cameras must be given iff the resident images have them.
+ * Invalidates the results of earlier dsm_match_pairs / dsm_verify_pairs calls, like dsm_set_images. */
+int dsm_append_images(dsm_ctx* ctx, uint32_t n_images, const uint32_t* n_feats,
+                      const uint8_t* const* desc, const float* const* kp_xy,
+                      uint32_t kp_stride, const dsm_camera* cameras);
+
 /* Brute-force matches every listed image pair on the device.  Replaces the
  * matcher stage of SiftFeatureMatcher::Match (src/feature/matching.cc:749-839)
  * = MatchSiftFeaturesCPU per pair (src/feature/sift.cc:810-822).

@@ -237,3 +237,38 @@ def test_several_chunks_of_the_pair_list(dsm, oracle, cross, monkeypatch):
             else np.zeros((0, 2), np.uint32)
         assert (m1[int(offs1[k]):int(offs1[k + 1])] == ref).all(), (k, i, j)
     assert int(offs1[-1]) > 300
+
+
+def test_append_images_equals_one_upload(oracle):
+    """dsm_append_images: images added behind the resident ones must behave exactly like images uploaded in one
+    dsm_set_images call -- same indices, same matches, same verification (the host shim appends what a block of
+    ExhaustiveFeatureMatcher's pair list adds instead of uploading the whole set again)."""
+    from dagsfm_amd import synthetic
+    n_img = 7
+    scene = synthetic.Scene(n_img, 700, seed=19, n_pool=2000)
+    ims = [scene.image(i) for i in range(n_img)]
+    cams = [capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, True) for _ in range(n_img)]
+    pairs = synthetic.exhaustive_pairs(n_img)
+    opts = capi.default_two_view_options()
+
+    def run(ctx):
+        ctx.match_pairs(pairs)
+        ctx.verify_pairs(opts, user_seed=3)
+        offs, m = ctx.matches()
+        ioffs, im = ctx.inlier_matches()
+        return np.array(offs), np.array(m), np.array(ioffs), np.array(im), [bytes(t) for t in ctx.two_view_geometries()]
+    whole = capi.Context(0)
+    whole.set_images([im[0] for im in ims], [im[1] for im in ims], cams)
+    ref = run(whole)
+    parts = capi.Context(0)
+    parts.set_images([im[0] for im in ims[:3]], [im[1] for im in ims[:3]], cams[:3])
+    parts.match_pairs(synthetic.exhaustive_pairs(3))   # results of an earlier call are simply invalidated
+    parts.append_images([im[0] for im in ims[3:4]], [im[1] for im in ims[3:4]], cams[3:4])
+    parts.append_images([im[0] for im in ims[4:]], [im[1] for im in ims[4:]], cams[4:])
+    got = run(parts)
+    for a, b in zip(ref[:4], got[:4]):
+        assert a.shape == b.shape and (a == b).all()
+    assert ref[4] == got[4]
+    # keypoints / cameras must come with the appended images iff the resident ones have them
+    with pytest.raises(capi.DsmError):
+        parts.append_images([ims[0][0]])

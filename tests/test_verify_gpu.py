@@ -108,6 +108,55 @@ def test_watermark_configuration(dsm, oracle):
     assert (got_inl == ref_inl).all()
 
 
+@pytest.mark.parametrize("schedule", ["default", "legacy", "lanes", "chunks"])
+def test_watermark_suspects_among_ordinary_pairs(dsm, oracle, schedule, monkeypatch):
+    """The translation estimator's ComputeNumTrials tables are built on demand (round 3; round 2 tabulated every sample
+    count up front, O(n^2) entries): k_verify_final parks a pair whose watermark test needs a table that does not exist,
+    the host builds it and sends exactly those pairs through the kernel again.  Here: a pair list through the stage
+    calls in which some pairs are watermark suspects with DIFFERENT inlier counts (several tables, one second visit),
+    twice on the same context (the second call finds its tables), on every schedule."""
+    if schedule == "legacy":
+        monkeypatch.setenv("DSM_VERIFY_LEGACY", "1")
+    if schedule == "lanes":
+        monkeypatch.setenv("DSM_VERIFY_LANES", "2")
+    if schedule == "chunks":
+        monkeypatch.setenv("DSM_VERIFY_CHUNK_PAIRS", "3")
+    rng = np.random.default_rng(12)
+    n_img, nk = 8, 400
+    camu = capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, False)
+    scene = synthetic.Scene(n_img, nk, seed=71, n_pool=900)
+    ims = [scene.image(i) for i in range(n_img)]
+    kps = [im[1].astype(np.float64).copy() for im in ims]
+    pairs = synthetic.exhaustive_pairs(n_img)
+    matches = [oracle.match_sift_features_cpu(ims[int(i)][0], ims[int(j)][0]) for i, j in pairs]
+    # watermark suspects: replace the keypoints the matches of three pairs refer to by a border cluster that moves
+    # by a pure translation (disjoint images, so that no other pair of the list is disturbed: pairs (0,1) (2,3) (4,5))
+    wm_pairs = [k for k, (i, j) in enumerate(pairs) if (int(i), int(j)) in ((0, 1), (2, 3), (4, 5))]
+    for q, k in enumerate(wm_pairs):
+        i, j = int(pairs[k][0]), int(pairs[k][1])
+        n = 60 + 25 * q
+        idx = np.arange(n)
+        kps[i][idx] = np.c_[rng.uniform(5, 60, n), rng.uniform(5, 700, n)]
+        kps[j][idx] = kps[i][idx] + np.array([3.0, -2.0]) + rng.normal(scale=0.2, size=(n, 2))
+        matches[k] = np.stack([idx, idx], axis=1).astype(np.uint32)
+    opts = capi.default_two_view_options()
+    dsm.set_images([im[0] for im in ims], [k.astype(np.float32) for k in kps], [camu] * n_img)
+    kps = [k.astype(np.float32).astype(np.float64) for k in kps]
+    for rep in range(2):
+        dsm.set_matches(pairs, matches)
+        dsm.verify_pairs(opts, user_seed=4, stage_filter=False)
+        tvgs = dsm.two_view_geometries()
+        ioffs, im = dsm.inlier_matches()
+        n_wm = 0
+        for k, (i, j) in enumerate(pairs):
+            ref, ref_inl = oracle.estimate_two_view_geometry(camu, kps[int(i)], camu, kps[int(j)], matches[k], opts,
+                                                             capi.pair_seed(int(i), int(j), 4))
+            tvg_equal(tvgs[k], ref, (rep, int(i), int(j)))
+            assert (im[int(ioffs[k]):int(ioffs[k + 1])] == ref_inl).all()
+            n_wm += ref.config == 7
+        assert n_wm == 3
+
+
 @pytest.mark.parametrize("prior,sampler_serial,legacy", [(0, False, False), (1, False, False), (1, True, False), (1, False, True),
                                                          (1, False, "inline_lo"), (0, False, "inline_lo"), (1, False, "chunks"),
                                                          (1, False, "batched_lo"), (0, False, "batched_lo"),
