@@ -49,7 +49,12 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--pairs", default="exhaustive", help="exhaustive | knn:K (K pseudo-neighbours per image from a seeded "
                                                           "kNN over the camera centres, id1<id2 dedupe; SURVEY 8d config 4)")
-    ap.add_argument("--shard-of", type=int, default=1, help="run only the first 1/S of the pair list: one GPU's shard of an S-GPU config")
+    ap.add_argument("--shard-of", type=int, default=1, help="run only one 1/S of the pair list: one GPU's shard of an S-GPU config")
+    ap.add_argument("--shard-index", type=int, default=0, help="which of the --shard-of shards (0-based): tools/shard_sweep.py runs them all")
+    ap.add_argument("--outlier-frac", type=float, default=0.2,
+                    help="share of an image's features that are not observations of the scene: a putative match is geometrically "
+                         "right with (1 - f)^2; 0.2 = the headline's 0.64 inlier ratio, 0.5 = a 0.25 ratio (RANSAC needs ~13x the trials)")
+    ap.add_argument("--dump-graph", default="", help="rank 0 saves the assembled match graph of the last step to this .npz (tests)")
     ap.add_argument("--max-pairs", type=int, default=0, help="truncate the (sharded) pair list (bounded runs of the big configs)")
     ap.add_argument("--fixed-trials", type=int, default=0,
                     help="T > 0: min_num_trials = max_num_trials = T, confidence 0.999999, min_inlier_ratio 0.01 -- exactly T "
@@ -166,7 +171,7 @@ def main():
 
     verify = not args.no_verify
     calibrated = not args.uncalibrated
-    scene = synthetic.Scene(args.images, args.feats, seed=args.seed)
+    scene = synthetic.Scene(args.images, args.feats, seed=args.seed, outlier_frac=args.outlier_frac)
     if args.pairs == "exhaustive":
         pairs = synthetic.exhaustive_pairs(args.images)
         pairs_desc = "exhaustive"
@@ -177,7 +182,9 @@ def main():
         raise SystemExit("--pairs must be exhaustive or knn:K")
     n_full = len(pairs)
     if args.shard_of > 1:
-        pairs = sharding.shard(pairs, 0, args.shard_of)
+        if not 0 <= args.shard_index < args.shard_of:
+            raise SystemExit("--shard-index must be in [0, --shard-of)")
+        pairs = sharding.shard(pairs, args.shard_index, args.shard_of)
     if args.max_pairs and len(pairs) > args.max_pairs:
         pairs = pairs[:args.max_pairs]
     # only the images the (sharded / truncated) list touches are generated and made resident
@@ -186,8 +193,10 @@ def main():
     remap[used] = np.arange(len(used))
     images = [scene.image(int(i)) for i in used]
     pairs = remap[pairs.astype(np.int64)].astype(np.uint32)
-    bounds = sharding.shard_bounds(len(pairs), world)
-    my_pairs = sharding.shard(pairs, rank, world)
+    # cut by cost (N1 * N2 + a per-pair term), like the C++ shim cuts between the devices of gpu_index
+    costs = sharding.pair_costs(pairs, [len(im[0]) for im in images])
+    bounds = sharding.shard_bounds(len(pairs), world, costs)
+    my_pairs = pairs[bounds[rank]:bounds[rank + 1]]
 
     n_ctx = max(1, args.contexts)
     ctxs = [capi.Context(dev_index) for _ in range(n_ctx)]
@@ -283,6 +292,10 @@ def main():
         res["score_flops"] = float(((tail.to(torch.float64) * w).sum(dim=1) * head[:, 2].to(torch.float64)).sum().item())
         res["inliers"] = int(graph.inlier_matches.shape[0])
 
+    if rank == 0 and args.dump_graph:
+        np.savez(args.dump_graph, match_counts=graph.match_counts.cpu().numpy(), matches=graph.matches.cpu().numpy(),
+                 **({"tvg": graph.tvg.cpu().numpy(), "inlier_counts": graph.inlier_counts.cpu().numpy(),
+                     "inlier_matches": graph.inlier_matches.cpu().numpy()} if verify else {}))
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         value = n_pairs * args.steps / dt
@@ -306,11 +319,15 @@ def main():
         pass2_s = 1e-3 * k1g_ms / launches
         pairs_per_launch = len(my_pairs) * args.steps / launches
         achieved = ops_per_pair * pairs_per_launch / (pass1_s + pass2_s) if pass1_s > 0 else 0.0
-        traffic = None
+        traffic, traffic_file = None, None
         try:  # HBM bytes per K1 launch from the committed PMC collection (tools/collect_pmc.py), same workload only
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_k1_pmc.json")))
-            if pmc.get("images") == args.images and pmc.get("feats") == args.feats and pmc.get("pairs") == n_pairs and world == 1:
-                traffic = pmc.get("k1_traffic_bytes_per_launch")
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_k1_pmc*.json"))):
+                pmc = json.load(open(f))
+                if pmc.get("images") == args.images and pmc.get("feats") == args.feats and pmc.get("pairs") == n_pairs and world == 1 \
+                        and args.pairs == "exhaustive" and args.shard_of == 1:
+                    traffic = pmc.get("k1_traffic_bytes_per_launch")
+                    traffic_file = os.path.basename(f)
         except Exception:
             traffic = None
         fam = ("calibrated: E+F+H + relative pose" if calibrated else "uncalibrated: F+H")
@@ -318,7 +335,7 @@ def main():
             fam += ", fixed %d trials/family" % args.fixed_trials
         shard_note = ""
         if args.shard_of > 1 or args.max_pairs:
-            shard_note = " [shard 1/%d of %d pairs%s]" % (args.shard_of, n_full, ", truncated" if args.max_pairs else "")
+            shard_note = " [shard %d of %d of %d pairs%s]" % (args.shard_index + 1, args.shard_of, n_full, ", truncated" if args.max_pairs else "")
         out = {
             "metric": ("verified image-pairs/sec (+ RANSAC hypotheses/sec) at %d feats/image" % args.feats) if verify else
                       "matched image-pairs/sec at %d feats/image (matching only, --no-verify)" % args.feats,
@@ -332,6 +349,7 @@ def main():
                 "pairs": n_pairs, "images_resident": len(images), "total_matches": res["matches"],
                 "total_inlier_matches": res["inliers"], "pairs_with_geometry": res["verified"],
                 "hypotheses_per_step": res["models"],
+                "putative_match_inlier_ratio": round((1.0 - args.outlier_frac) ** 2, 4),
                 "contexts_per_gpu": n_ctx,
                 "parallelism": "pair-sharded x%d + %s all-gather of the match graph" % (world, "gloo (debug, oversubscribed)" if args.oversubscribe else "RCCL")},
             "hypotheses_per_s": res["models"] * args.steps / dt if verify else None,
@@ -342,8 +360,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": int8_peak / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / int8_peak, "traffic": traffic,
                          "traffic_note": "HBM bytes per launch of both passes, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read "
-                                         "correction) + WRITE_SIZE in separate passes (profiles/r02_k1_pmc.json); null when not "
-                                         "collected for this workload",
+                                         "correction) + WRITE_SIZE in separate passes (profiles/%s); null when not "
+                                         "collected for this workload" % (traffic_file or "r03_k1_pmc*.json"),
                          "kernel": "k1_best_rows (pass 1 over all rows + gathered pass 2 of the cross-check)",
                          "avg_launch_ms": 1e3 * (pass1_s + pass2_s), "avg_launch_ms_pass1": 1e3 * pass1_s,
                          "avg_launch_ms_pass2": 1e3 * pass2_s, "launches": k1_launches, "peak_source": peaks_note,

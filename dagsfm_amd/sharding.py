@@ -10,13 +10,34 @@ reference's DatabaseInfo merge over rpclib (src/map_reduce/distributed_task_mana
 import numpy as np
 
 
-def shard_bounds(n_pairs, world_size):
-    """Contiguous block of the pair list per rank (pairs cost the same at fixed feature count)."""
-    return np.linspace(0, n_pairs, world_size + 1).astype(np.int64)
+PAIR_COST_FIXED = 4096.0 * 1024.0   # the per-pair term (verification) in units of descriptor-matrix elements
 
 
-def shard(pairs, rank, world_size):
-    b = shard_bounds(len(pairs), world_size)
+def pair_costs(pairs, n_feats):
+    """Cost model of a pair: N1 * N2 (the distance matrix, K1) + a fixed term for the verification -- the same cut
+    the C++ host shim makes between the devices of gpu_index (host/sift_feature_matcher_impl.h, Run())."""
+    nf = np.asarray(n_feats, dtype=np.float64)
+    p = np.asarray(pairs).reshape(-1, 2).astype(np.int64)
+    return nf[p[:, 0]] * nf[p[:, 1]] + PAIR_COST_FIXED
+
+
+def shard_bounds(n_pairs, world_size, costs=None):
+    """Contiguous block of the pair list per rank.  Without `costs` the blocks have equal pair counts (pairs cost the
+    same at a fixed feature count); with per-pair `costs` (pair_costs) the cuts equalise the summed cost instead --
+    images of different sizes, e.g. a kNN candidate list over a heterogeneous collection."""
+    if costs is None or n_pairs == 0:
+        return np.linspace(0, n_pairs, world_size + 1).astype(np.int64)
+    cum = np.concatenate([[0.0], np.cumsum(np.asarray(costs, dtype=np.float64))])
+    assert len(cum) == n_pairs + 1
+    b = np.zeros(world_size + 1, dtype=np.int64)
+    b[-1] = n_pairs
+    for r in range(1, world_size):
+        b[r] = int(np.searchsorted(cum, cum[-1] * r / world_size, side="left"))
+    return np.maximum.accumulate(np.minimum(b, n_pairs))
+
+
+def shard(pairs, rank, world_size, costs=None):
+    b = shard_bounds(len(pairs), world_size, costs)
     return pairs[b[rank]:b[rank + 1]]
 
 
@@ -40,6 +61,38 @@ def all_gather_ragged(dist, local, world_size):
     sizes_h = sizes.cpu().numpy()
     mx = max(int(sizes_h.max()), 1)
     return sizes_h, all_gather_fixed(dist, local, mx, world_size)
+
+
+# padding a rank's rows up to the longest rank's is free while the shards are balanced (one collective instead of one
+# per rank); beyond this ratio of longest to mean the exact-size exchange moves fewer bytes than the padding wastes
+RAGGED_PAD_LIMIT = 1.25
+
+
+def all_gather_rows(dist, local, rank, world_size):
+    """All ranks' variable-length rows concatenated in rank order, exact sizes on the wire when the shards are skewed:
+    the sizes are all-gathered first; balanced shards (longest <= RAGGED_PAD_LIMIT x mean) then take ONE max-padded
+    all-gather, skewed ones (a kNN candidate list cut by pair count over images of very different sizes) one broadcast
+    per rank of exactly that rank's rows."""
+    import torch
+    sizes = torch.zeros(world_size, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device))
+    sizes_h = sizes.cpu().numpy()
+    total, mx = int(sizes_h.sum()), int(sizes_h.max())
+    if total == 0:
+        return local[:0]
+    if mx * world_size <= RAGGED_PAD_LIMIT * total:
+        return assemble_ragged(sizes_h, all_gather_fixed(dist, local, max(mx, 1), world_size))
+    out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    at = 0
+    for r in range(world_size):
+        n = int(sizes_h[r])
+        if n:
+            part = out[at:at + n]
+            if r == rank:
+                part.copy_(local)
+            dist.broadcast(part, src=r)
+        at += n
+    return out
 
 
 def assemble_ragged(sizes, gathered):
@@ -88,8 +141,7 @@ def gather_match_graph(dist, source, rank, world_size, bounds, verify):
     def gather_rows(rows):
         if world_size == 1:
             return rows
-        sizes, allr = all_gather_ragged(dist, rows, world_size)
-        return assemble_ragged(sizes, allr)
+        return all_gather_rows(dist, rows, rank, world_size)
 
     offs = source.match_offsets()
     assert offs.shape[0] == n_mine + 1

@@ -68,6 +68,53 @@ def test_shard_and_gather_two_ranks():
         assert rows.shape == ref_rows.shape and (rows == ref_rows).all()
 
 
+def _skew_worker(rank, world, port, q):
+    from dagsfm_amd import sharding
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    out = []
+    for sizes in ((5, 400), (0, 7), (300, 290), (0, 0)):   # skewed -> per-rank broadcasts; balanced -> one padded all-gather
+        n = sizes[rank]
+        local = torch.arange(n * 2, dtype=torch.int32).reshape(n, 2) + 1000 * rank
+        out.append(sharding.all_gather_rows(dist, local, rank, world).numpy().copy())
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_rows_exact_sizes_when_skewed():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_skew_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outs in res:
+        for sizes, got in zip(((5, 400), (0, 7), (300, 290), (0, 0)), outs):
+            ref = np.concatenate([np.arange(n * 2, dtype=np.int32).reshape(n, 2) + 1000 * r for r, n in enumerate(sizes)])
+            assert got.shape == ref.shape and (got == ref).all()
+
+
+def test_cost_aware_shard_bounds():
+    from dagsfm_amd import sharding
+    rng = np.random.default_rng(0)
+    nfeat = rng.integers(500, 9000, 60)
+    pairs = np.array([(i, j) for i in range(60) for j in range(i + 1, 60)][::3])
+    costs = sharding.pair_costs(pairs, nfeat)
+    for w in (1, 2, 4, 8):
+        b = sharding.shard_bounds(len(pairs), w, costs)
+        assert b[0] == 0 and b[-1] == len(pairs) and (np.diff(b) >= 0).all()
+        per = np.array([costs[b[r]:b[r + 1]].sum() for r in range(w)])
+        assert per.max() <= costs.sum() / w + costs.max()          # no rank is more than one pair above its share
+        assert (np.concatenate([sharding.shard(pairs, r, w, costs) for r in range(w)]) == pairs).all()
+    # equal costs fall back to (almost) equal counts
+    b = sharding.shard_bounds(1000, 8, np.full(1000, 3.0))
+    assert np.diff(b).max() - np.diff(b).min() <= 1
+
+
 def test_shard_bounds_cover_uneven():
     from dagsfm_amd import sharding
     for n in (0, 1, 7, 8, 9, 124750):
