@@ -133,10 +133,11 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
                     &ctx->d_g_inl, &ctx->d_g_inl_off, &ctx->d_mm_matches[0], &ctx->d_mm_matches[1], &ctx->d_mm_off[0],
                     &ctx->d_mm_off[1], &ctx->d_mm_counts, &ctx->d_mm_state, &ctx->d_mm_first, &ctx->d_mm_acc, &ctx->d_mm_keep,
                     &ctx->d_mm_total, &ctx->d_order, &ctx->d_dpairs2, &ctx->d_ecnt, &ctx->d_eoff, &ctx->d_etotal, &ctx->d_entries,
-                    &ctx->d_out2, &ctx->d_ms, &ctx->d_out2s, &ctx->d_lo_inl};
+                    &ctx->d_out2, &ctx->d_ms, &ctx->d_out2s, &ctx->d_lo_inl, &ctx->d_lo_inl_pool, &ctx->d_nt_table_t, &ctx->d_wm_redo, &ctx->d_wm_total,
+                    &ctx->d_wm_count};
   for (VerifyLane& L : ctx->lanes) {
     for (DevBuf* b : {&L.samples, &L.draws_end, &L.nmodels, &L.vcounts, &L.vsums, &L.models, &L.ework, &L.active, &L.vscratch, &L.lo_queue,
-                      &L.lo_work, &L.lo_models, &L.lo_slots, &L.lo_ework})
+                      &L.lo_work, &L.lo_models, &L.lo_slots, &L.lo_ework, &L.tail_items, &L.tail_n, &L.lo_jobs, &L.job_list})
       b->release();
     if (L.done) (void)hipEventDestroy(L.done);
     if (L.host_ctr) (void)hipHostFree(L.host_ctr);
@@ -678,6 +679,9 @@ struct VerifyPlan {
   int dev_cus = 256;
   bool inline_lo = false;
   uint32_t lo_tail = 0;  // queue length at and below which the batched schedule finishes a round inline
+  uint32_t grid_div = 1;
+  bool tail_items = true;   // the tail of a round (<= lo_tail pairs queued) as an item pass; false: the inline tail of round 2
+  bool item_mode = false;   // item passes from the start of every round (short pair lists)
 };
 
 #define LANECHK(L, call)                                              \
@@ -715,8 +719,10 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
   for (uint64_t c0 = plan.begin[li]; c0 < plan.end[li]; c0 += chunk) {
     vp.pair0 = (uint32_t)c0;
     vp.n_chunk = (uint32_t)std::min<uint64_t>(chunk, plan.end[li] - c0);
-    const uint32_t nb_light = std::min<uint32_t>(vp.n_chunk, (uint32_t)plan.dev_cus * 32u);
-    const uint32_t nb_heavy = std::min<uint32_t>(vp.n_chunk, (uint32_t)plan.dev_cus * 16u);
+    // persistent wave-per-pair grids: sized for the whole chip when a lane has it to itself, for its share when the
+    // lanes are many (DSM_VERIFY_GRID_DIV, experiment: a lane's persistent grid must not starve the short launches of the others)
+    const uint32_t nb_light = std::min<uint32_t>(vp.n_chunk, std::max<uint32_t>(64u, (uint32_t)plan.dev_cus * 32u / plan.grid_div));
+    const uint32_t nb_heavy = std::min<uint32_t>(vp.n_chunk, std::max<uint32_t>(64u, (uint32_t)plan.dev_cus * 16u / plan.grid_div));
     vp.batch = 0;
     launch_vp_prep(vp, nb_light, st);
     LANECHK(L, hipGetLastError());
@@ -743,28 +749,73 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
           vp.lo_queue_g = queues + (size_t)2 * chunk;
           vp.worklist = nullptr;
           vp.n_work = vp.n_chunk;
+          vp.tail_items = L.tail_items.as<TailItem>();
+          vp.tail_n = L.tail_n.as<uint32_t>();
+          vp.lo_jobs = nullptr;  // set only in the copies the item passes launch with
+          // Two ways through a round's local optimisations (verify_kernels.hip, "item passes"):
+          //   chain  k_replay_lo suspends a pair at every step, the batched kernels run for all suspended pairs, the next
+          //          replay resumes them: one iteration per step of the slowest pair, no speculative work
+          //   items  every step a pair can still reach is computed at once (jobs), the replay looks the outcomes up:
+          //          one pass per round, ~2x the local-optimisation work
+          // plan.item_mode: item passes from the start of a round (short lists: every iteration of the chain is
+          // latency-bound there); otherwise the chain, and item passes once <= lo_tail pairs are left in the queue.
+          int mode = 0;
+          bool pass_items = plan.item_mode;
           for (uint32_t cur = 0;; cur ^= 1u) {
+            uint32_t* host_ctr = L.host_ctr;
+            if (pass_items) {
+              LANECHK(L, hipMemsetAsync(actr + 88, 0, 12, st));  // [22], [23]: problems for the general LO kernels; [24]: jobs
+              VerifyParams vj = vp;
+              vj.lo_jobs = L.lo_jobs.as<LoJob>();
+              vj.job_list = L.job_list.as<uint32_t>();
+              vj.lo_inl_pool = ctx->d_lo_inl_pool.as<uint32_t>();
+              vj.lo_queue_g = queues + (size_t)2 * chunk;  // (the general kernels' list: job slots here)
+              launch_vp_items_enum(vj, f, st);
+              LANECHK(L, hipGetLastError());
+              LANECHK(L, hipMemcpyAsync(host_ctr, actr, 128, hipMemcpyDeviceToHost, st));
+              LANECHK(L, hipStreamSynchronize(st));
+              const uint32_t n_jobs = host_ctr[24];
+              if (n_jobs) {
+                vj.worklist = vj.job_list;
+                vj.n_work = n_jobs;
+                launch_vp_items_inliers(vj, f, nb_heavy, st);
+                LANECHK(L, hipGetLastError());
+                LANECHK(L, hipMemcpyAsync(host_ctr, actr, 128, hipMemcpyDeviceToHost, st));
+                LANECHK(L, hipStreamSynchronize(st));
+                LANECHK(L, hipMemsetAsync(actr + 76, 0, 4, st));  // k_lo_prepare's work counter [19]
+                launch_vp_local_opt(vj, f, nb_heavy, host_ctr[22], host_ctr[23], st);
+                LANECHK(L, hipGetLastError());
+                launch_vp_items_outcome(vj, f, nb_heavy, st);
+                LANECHK(L, hipGetLastError());
+              }
+              L.lo_iters[f]++;
+              mode = 2;
+              pass_items = false;
+            }
             uint32_t* cnt_dev = L.active.as<uint32_t>() + 20 + cur;
             LANECHK(L, hipMemsetAsync(cnt_dev, 0, 4, st));
             LANECHK(L, hipMemsetAsync(actr + 64, 0, 4, st));  // work counter [16]
             LANECHK(L, hipMemsetAsync(actr + 88, 0, 8, st));  // [22], [23]: queued problems for the general LO kernels
             vp.lo_queue = queues + (size_t)cur * chunk;
             vp.lo_count = cnt_dev;
-            launch_vp_replay_lo(vp, f, nb_heavy, false, st);
+            launch_vp_replay_lo(vp, f, std::min<uint32_t>(nb_heavy, vp.n_work), mode, st);
             LANECHK(L, hipGetLastError());
-            uint32_t* host_ctr = L.host_ctr;
             LANECHK(L, hipMemcpyAsync(host_ctr, actr, 128, hipMemcpyDeviceToHost, st));
             LANECHK(L, hipStreamSynchronize(st));
             active = host_ctr[0];
             const uint32_t nq = host_ctr[20 + cur];
             if (nq == 0) break;
-            L.lo_iters[f]++;
             vp.worklist = vp.lo_queue;
             vp.n_work = nq;
-            if (nq <= plan.lo_tail && f != 0) {  // not for E: its inline solver does not fit the registers (k_replay_lo<TAIL> note)
-              // the last few suspended pairs finish the round with their local optimisations inline (k_replay_lo<TAIL>)
+            if (mode == 2 || (nq <= plan.lo_tail && plan.tail_items)) {  // the pairs still queued: an item pass over them
+              pass_items = true;
+              continue;
+            }
+            L.lo_iters[f]++;
+            if (nq <= plan.lo_tail && f != 0) {  // DSM_LO_TAIL_MODE=inline (not for E: its inline solver does not fit the registers)
+              // round-2 form of the tail: the wave runs its pair's remaining local optimisations inline, one after the other
               LANECHK(L, hipMemsetAsync(actr + 64, 0, 4, st));  // work counter [16]
-              launch_vp_replay_lo(vp, f, std::min<uint32_t>(nb_heavy, nq), true, st);
+              launch_vp_replay_lo(vp, f, std::min<uint32_t>(nb_heavy, nq), 1, st);
               LANECHK(L, hipGetLastError());
               LANECHK(L, hipMemcpyAsync(host_ctr, actr, 4, hipMemcpyDeviceToHost, st));
               LANECHK(L, hipStreamSynchronize(st));
@@ -884,6 +935,11 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.lo_queue = nullptr;
   vp.lo_count = nullptr;
   vp.lo_work = vp.lo_models = vp.lo_slots = vp.lo_ework = nullptr;
+  vp.tail_items = nullptr;
+  vp.tail_n = nullptr;
+  vp.lo_jobs = nullptr;
+  vp.lo_inl_pool = nullptr;
+  vp.job_list = nullptr;
   const bool legacy = getenv("DSM_VERIFY_LEGACY") != nullptr;  // single-kernel-per-family schedule (debug)
   if (legacy) {
     HIPCHK(ctx, ctx->d_vscratch.reserve(std::max<size_t>(1, (size_t)n_blocks * verify_scratch_bytes_per_block(n_max))));
@@ -974,19 +1030,30 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     }
     plan.n_lanes = n_lanes;
     plan.dev_cus = dev_cus;
+    // persistent grids sized for a lane's share of the chip: two lanes 362.5 vs 366.3 ms at config 2, 193.5 vs 205.1 on its half
+    plan.grid_div = n_lanes;
+    if (const char* e = getenv("DSM_VERIFY_GRID_DIV")) plan.grid_div = (uint32_t)std::max(1, atoi(e));
     // Local optimisation: batched kernels (k_replay_lo + k_lo_*) or inline in the replay (k_replay).  The batched form
     // wins on throughput (config 2, 124 750 pairs: 416 vs 702 ms) but every LO iteration costs a kernel round trip; it
     // hands the last <= lo_tail queued pairs of a round (F, H) to an inline finish, which keeps it ahead or level down
     // to ~1 000 pairs (7 140 pairs: 42 vs 50 ms; 4 950: 34.5 vs 36.4; 1 225: 9.5 vs 9.3).  The inline form remains for
     // lists shorter than lo_tail, where the batched one would only add a launch.
     // DSM_VERIFY_INLINE_LO=1 / =0 forces one or the other (tests cover both).
-    plan.inline_lo = n_pairs < 2048u;
+    plan.inline_lo = n_pairs < 256u;  // (round 2: below 2 048; with item passes the batched kernels are ahead from ~1 000 pairs on: 1 225 pairs 14.7 vs 19.8 ms)
     if (const char* e = getenv("DSM_VERIFY_INLINE_LO")) plan.inline_lo = atoi(e) != 0;
-    plan.lo_tail = 2048;  // measured: 0 / 128 / 512 / 2048 / 8192 -> 415 / 412 / 412 / 408 / 411 ms at config 2, 74.8 / 72.7 / 70.5 / 69.5 / 75.3 ms on its 1/8 shard
+    // queue length at which the chain hands the rest of a round to an item pass.  Measured (round 3, item-pass tail): 2 048 /
+    // 4 096 / 8 192 / 16 384 / 32 768 -> 370.6 / 373.2 / 366.3 / 373.1 / 375.9 ms at config 2, 61.7 / 61.0 / 57.5 / 57.8 / 57.7 ms on its 1/8 shard
+    plan.lo_tail = 8192;
     if (const char* e = getenv("DSM_LO_TAIL")) plan.lo_tail = (uint32_t)std::max(0, atoi(e));
+    if (const char* e = getenv("DSM_LO_TAIL_MODE")) plan.tail_items = strcmp(e, "inline") != 0;
+    // item passes from the start of every round for short lists: 4 950 pairs 24.3 vs 28.5 ms, 15 593 pairs (1/8 of config 2)
+    // 55.8 vs 57.5, 31 187 pairs level, 124 750 pairs 395 vs 366 (the speculative half of the items is throughput there)
+    plan.item_mode = n_pairs <= 24000u;
+    if (const char* e = getenv("DSM_VERIFY_ITEM_MODE")) plan.item_mode = atoi(e) != 0;
     HIPCHK(ctx, ctx->d_fam_state.reserve(std::max<size_t>(n_pairs, 1) * 3 * sizeof(FamState)));
     HIPCHK(ctx, ctx->d_sidx.reserve(tm * 4));
     HIPCHK(ctx, ctx->d_lo_inl.reserve(tm * 4));
+    HIPCHK(ctx, ctx->d_lo_inl_pool.reserve(tm * TAIL_KMAX * 4));  // inlier lists of the item passes' jobs
     vp.lo_inl = ctx->d_lo_inl.as<uint32_t>();
     vp.fam_state = ctx->d_fam_state.as<FamState>();
     vp.sidx_g = ctx->d_sidx.as<uint32_t>();
@@ -1016,11 +1083,18 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
           LRES(L.vsums.reserve((size_t)chunk * bm_max * 8));
           LRES(L.models.reserve((size_t)chunk * bm_max * 72));
           LRES(L.ework.reserve((size_t)chunk * plan.batch[0] * 200 * 8));
-          LRES(L.lo_queue.reserve((size_t)chunk * 3 * 4));  // two alternating queues + the general-kernel list
-          LRES(L.lo_work.reserve((size_t)chunk * LO_WORK_DOUBLES * 8));
-          LRES(L.lo_models.reserve((size_t)chunk * 90 * 8));
-          LRES(L.lo_slots.reserve((size_t)chunk * 90 * 8));
-          LRES(L.lo_ework.reserve((size_t)chunk * 200 * 8));
+          LRES(L.lo_queue.reserve(((size_t)chunk * 2 + std::max<size_t>(chunk, (size_t)(plan.item_mode ? chunk : std::min<uint32_t>(chunk, std::max<uint32_t>(plan.lo_tail, 1))) * TAIL_KMAX)) * 4));  // two alternating queues + the general-kernel list (pairs or job slots)
+          // item passes: over the whole chunk (item_mode) or over a queue of <= lo_tail pairs
+          const size_t item_pairs = plan.item_mode ? chunk : std::min<uint32_t>(chunk, std::max<uint32_t>(plan.lo_tail, 1));
+          const size_t slots = std::max<size_t>(chunk, item_pairs * TAIL_KMAX);  // records of the batched LO kernels: per pair or per job
+          LRES(L.tail_items.reserve(item_pairs * TAIL_KMAX * sizeof(TailItem)));
+          LRES(L.tail_n.reserve(item_pairs * 4));
+          LRES(L.lo_jobs.reserve(item_pairs * TAIL_KMAX * sizeof(LoJob)));
+          LRES(L.job_list.reserve(item_pairs * TAIL_KMAX * 4));
+          LRES(L.lo_work.reserve(slots * LO_WORK_DOUBLES * 8));
+          LRES(L.lo_models.reserve(slots * 90 * 8));
+          LRES(L.lo_slots.reserve(slots * 90 * 8));
+          LRES(L.lo_ework.reserve(slots * 200 * 8));
         }
 #undef LRES
         return hipSuccess;
@@ -1036,7 +1110,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
       }
       for (VerifyLane& L : ctx->lanes)
         for (DevBuf* b : {&L.samples, &L.draws_end, &L.nmodels, &L.vcounts, &L.vsums, &L.models, &L.ework, &L.vscratch, &L.lo_queue, &L.lo_work,
-                          &L.lo_models, &L.lo_slots, &L.lo_ework})
+                          &L.lo_models, &L.lo_slots, &L.lo_ework, &L.tail_items, &L.tail_n, &L.lo_jobs, &L.job_list})
           b->release();
       for (uint32_t li = 0; li < n_lanes; ++li) plan.chunk[li] = std::max<uint32_t>(1, plan.chunk[li] / 2);
     }

@@ -65,6 +65,7 @@ struct VerifyLane {
   hipEvent_t done = nullptr;
   DevBuf samples, draws_end, nmodels, vcounts, vsums, models, ework, active, vscratch;
   DevBuf lo_queue, lo_work, lo_models, lo_slots, lo_ework;  // batched local optimisation
+  DevBuf tail_items, tail_n, lo_jobs, job_list;             // item passes (TailItem, LoJob)
   uint32_t rounds[3] = {0, 0, 0}, lo_iters[3] = {0, 0, 0};
   uint32_t dbg[32] = {0};
   uint32_t* host_ctr = nullptr;  // pinned read-back target of the lane's counters
@@ -104,7 +105,7 @@ struct dsm_ctx {
   DevBuf d_cams, d_pairs_dev, d_seeds, d_tvg, d_inl, d_inl_counts, d_inl_off, d_inl_compact, d_vscratch, d_inl_total;
   DevBuf d_nt_table, d_nt_off, d_nt_off_t, d_pair_state, d_pts_px, d_pts_norm, d_reports, d_masks;
   DevBuf d_fam_state, d_sidx, d_lo_inl;
-  DevBuf d_nt_table_t, d_wm_redo, d_wm_total, d_wm_count;
+  DevBuf d_nt_table_t, d_wm_redo, d_wm_total, d_wm_count, d_lo_inl_pool;
   VerifyLane lanes[DSM_VERIFY_MAX_LANES];
   uint32_t verify_lanes = 1;  // lanes of the last call
   uint32_t verify_lo_iters[3] = {0, 0, 0};

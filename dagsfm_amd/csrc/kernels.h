@@ -96,6 +96,26 @@ struct FamState {
 };
 #define LO_WORK_DOUBLES 176  // per pair: W[81] V[81] n1[3] n2[3] scale dsz, padded
 
+// The tail of a round (few pairs left in the local-optimisation queue): every local optimisation a pair can still
+// reach in this round is computed AT ONCE, one wave per (pair, candidate model), instead of one after the other.
+// The outcome of LORANSAC's optimisation step (loransac.h:160-178) depends on the candidate model alone -- the model
+// has just become the best one, its inliers are the input, the local models are compared with it in order -- so it
+// can be computed before the sequential scan knows whether the step will be taken.  An item is that outcome.
+#define TAIL_KMAX 8  // candidates per pair and tail iteration (a pair with more is simply queued once more)
+struct LoJob {
+  uint32_t pl;          // pair (chunk-local)
+  uint32_t ninl;        // inliers of the candidate model = size of the local estimator's input
+  uint32_t pending;     // 1: the step the pair is suspended at -- its inliers are the pair's lo_inl list
+  uint32_t nm;          // local models produced
+};
+struct TailItem {
+  uint32_t t, m;        // trial of the current batch, model of that trial
+  uint32_t nlo;         // local models the optimisation produced (they count as scored models)
+  uint32_t out_n;       // support after the step: inliers ...
+  double out_sum;       // ... residual sum ...
+  double out_model[9];  // ... and model (the candidate itself when no local model beat it)
+};
+
 // Two-view verification: one 64-lane workgroup per image pair (grid-stride over the pair list).
 struct VerifyParams {
   const uint32_t* pairs;       // [n_pairs][2] image indices
@@ -154,6 +174,12 @@ struct VerifyParams {
   // local optimisation as batched kernels: k_replay_lo suspends a pair at every LO, the LO runs for all suspended
   // pairs at once (k_lo_prepare: wave per pair; k_lo_jacobi: 16-lane group per pair; E: the flat 5-point kernels)
   uint32_t* lo_inl;            // [total] ordered inlier indices of the pair's pending LO (at match offsets)
+  TailItem* tail_items;        // [n_work][TAIL_KMAX] (see TailItem)
+  uint32_t* tail_n;            // [n_work] items of every pair of the pass
+  // item passes: the batched local-optimisation kernels work on JOBS (one per item) instead of queued pairs
+  struct LoJob* lo_jobs;       // != nullptr: work index -> job (worklist, if given, maps the launch index to the job index)
+  uint32_t* lo_inl_pool;       // inlier lists of the items: item k of pair pi at (match_off[pi] * TAIL_KMAX + k * n)
+  uint32_t* job_list;          // compact list of the jobs of a pass (k_items_enum)
   const uint32_t* worklist;    // k_replay_lo / LO kernels: chunk-local pair indices to process (nullptr: all pairs)
   uint32_t n_work;
   uint32_t* lo_queue_g;        // k_replay_lo: the queued pairs that need the general LO kernels (count at active_count[22])
@@ -174,7 +200,10 @@ void launch_vp_sample(const VerifyParams& p, int fam, uint32_t n_blocks, hipStre
 void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st);
 void launch_vp_replay(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st);
 void launch_vp_final(const VerifyParams& p, uint32_t n_blocks, hipStream_t st);
-void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, bool tail, hipStream_t st);
+void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, int mode, hipStream_t st);  // mode: 0 suspend, 1 inline tail, 2 item lookup
+void launch_vp_items_enum(const VerifyParams& p, int fam, hipStream_t st);
+void launch_vp_items_inliers(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st);
+void launch_vp_items_outcome(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st);
 // over p.worklist / p.n_work; n_wave_prepare / n_small_jacobi: how many of the queued problems need the general kernels
 // (k_lo_prepare: not register-preparable; k_lo_jacobi: smaller than 9 x 9), counted by k_replay_lo at [22] / [23]
 void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint32_t n_wave_prepare, uint32_t n_small_jacobi, hipStream_t st);

@@ -2195,8 +2195,13 @@ __host__ __device__ inline bool lo_prepare_in_registers(int ninl) {
 // (TAIL at one wave per SIMD: at four, 128 VGPRs, the inlined local optimisation spills 127 - 717 VGPRs and 66 - 102 SGPRs,
 // and hipcc 7.2 then corrupts an SGPR tuple spilled through VGPR lanes -- the uniform best_model[4..7] of the H family
 // came back wrong on 34 of 124 750 pairs; with 512 VGPRs nothing is spilled to memory.  The tail is latency-bound anyway.)
-template <int FAM, bool TAIL>
-__global__ __launch_bounds__(64, (TAIL ? 1 : 4)) void k_replay_lo(const VerifyParams p) {
+// MODE 2 (LOOKUP): the tail of a round, parallel form: k_tail_enum listed the local optimisations the pair can still reach
+// and k_tail_lo computed their outcomes (TailItem); this scan takes the outcome where k_replay would run the
+// optimisation.  A step that is not among the pair's items (more than TAIL_KMAX candidates) suspends the pair as in mode 0.
+template <int FAM, int MODE>
+__global__ __launch_bounds__(64, (MODE == 1 ? 1 : 4)) void k_replay_lo(const VerifyParams p) {
+  constexpr bool TAIL = MODE == 1;
+  constexpr bool LOOKUP = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   VSmem* sm = reinterpret_cast<VSmem*>(smem_raw);
   typedef Fam<FAM> F;
@@ -2260,6 +2265,14 @@ __global__ __launch_bounds__(64, (TAIL ? 1 : 4)) void k_replay_lo(const VerifyPa
         nlo = fam_local<FAM>(w, (int)fs->lo_ninl);  // the inlier list is still in lo_inl; models -> sm->lo_models
       else
         nlo = (int)fs->lo_nm;
+      if constexpr (LOOKUP) {  // item 0 of the pair is the pending step
+        const TailItem& it = p.tail_items[(size_t)widx * TAIL_KMAX];
+        num_models += it.nlo;
+        best_n = it.out_n;
+        best_sum = it.out_sum;
+        for (int k = 0; k < 9; ++k) best_model[k] = it.out_model[k];
+        nlo = 0;
+      }
       const double* glom = p.lo_models + (size_t)pl * 90;
       for (int l = 0; l < nlo; ++l) {
         num_models += 1;
@@ -2315,6 +2328,29 @@ __global__ __launch_bounds__(64, (TAIL ? 1 : 4)) void k_replay_lo(const VerifyPa
             for (int k = 0; k < 9; ++k) best_model[k] = M[k];
             if (cnt > (uint32_t)F::K && cnt >= (uint32_t)F::LO_MIN) {
               if (p.stats && lane == 0) atomicAdd(p.active_count + 2 + FAM * 2, 1u);
+              bool looked_up = false;
+              if constexpr (LOOKUP) {
+                const uint32_t ni = p.tail_n[widx];
+                for (uint32_t k = 0; k < ni; ++k) {  // (a pending item 0 is the model the pair was suspended at: it cannot come again)
+                  const TailItem& it = p.tail_items[(size_t)widx * TAIL_KMAX + k];
+                  if (it.t == (uint32_t)t && it.m == (uint32_t)m) {
+                    num_models += it.nlo;
+                    best_n = it.out_n;
+                    best_sum = it.out_sum;
+                    for (int q = 0; q < 9; ++q) best_model[q] = it.out_model[q];
+                    looked_up = true;
+                    break;
+                  }
+                }
+              }
+              if (looked_up) {
+                dyn_max = w.nt_table[best_n];
+                if (trial_abs >= dyn_max && trial_abs >= min_trials) {
+                  abort = true;
+                  break;
+                }
+                continue;
+              }
               if constexpr (FAM != FAM_E) {  // the residuals of the new best model, for the compaction
                 score_model<FAM>(w, M, max_residual, true);
                 wv_sync();
@@ -2424,6 +2460,288 @@ __global__ __launch_bounds__(64, (TAIL ? 1 : 4)) void k_replay_lo(const VerifyPa
   }
 }
 
+// ------------------------------------------------------------------------------------ item passes
+// The chain of k_replay_lo costs one iteration of launches per local-optimisation step of the SLOWEST pair (14 - 16 per
+// round at the benchmark shape), and every iteration its full serial latency (~1 ms for the E family: tall QR, 9 x 9
+// Jacobi, 5-point solver, each a serial computation per problem) however few problems it carries.  That is the price
+// of a short pair list -- one GPU's share of an 8-GPU job spends a third of its verification time there -- and of the
+// last iterations of any list.  But the outcome of a local-optimisation step is a function of the candidate model
+// alone (TailItem), so all steps a pair can still reach in the round are independent work:
+//   k_items_enum     wave per pair: (item 0 = the step the pair is suspended at, if it is;) then every later model of
+//                    the batch that could still become the best one -- a model with at least as many inliers as every
+//                    minimal-sample model before it.  The true best support is never smaller than that running
+//                    maximum, so the steps the sequential scan will really take are among the items; the scan cannot
+//                    go past the first trial at or beyond the stopping threshold of that maximum (ComputeNumTrials
+//                    is non-increasing in the inlier count), so the list ends there.  Every item becomes a job.
+//   k_items_inliers  wave per job: the candidate's residuals and ordered inlier list (the local estimator's input).
+//   k_lo_*           the batched local-optimisation kernels, over the jobs (lo_ref).
+//   k_items_outcome  wave per job: the local models scored in order against the candidate -> the item's outcome.
+//   k_replay_lo<FAM, 2>  the sequential scan; takes the outcome where it would otherwise suspend.
+// One pass finishes the round of every pair with at most TAIL_KMAX candidate steps; the others are queued once more.
+template <int FAM>
+__global__ __launch_bounds__(64) void k_items_enum(const VerifyParams p) {
+  typedef Fam<FAM> F;
+  constexpr int MAXM = F::MAXM;
+  const int lane = threadIdx.x;
+  for (uint32_t widx = blockIdx.x; widx < p.n_work; widx += gridDim.x) {
+    const uint32_t pl = p.worklist ? p.worklist[widx] : widx;
+    const uint32_t pi = p.pair0 + pl;
+    const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
+    if (!fs->active) {
+      if (lane == 0) p.tail_n[widx] = 0;
+      continue;
+    }
+    TailItem* items = p.tail_items + (size_t)widx * TAIL_KMAX;
+    const int n = (int)(p.match_off[pi + 1] - p.match_off[pi]);
+    const uint32_t* nt = p.nt_table + p.nt_off[n] + (size_t)FAM * (size_t)(n + 1);
+    const uint32_t min_trials = (uint32_t)p.opt.min_num_trials;
+    const uint32_t T0 = fs->rep.num_trials;
+    const int nb = (int)fs->nb;
+    const bool pending = fs->lo_wait != 0;
+    // where the scan stands: a suspended pair right behind the model it is suspended at, a fresh one at the start
+    const int t0 = (int)fs->t_pos;
+    const int m_next = (int)fs->m_pos;
+    const int32_t* nmod = p.nmodels + (size_t)pl * p.batch;
+    const int32_t* cnts = p.counts + (size_t)pl * p.batch * MAXM;
+    uint32_t n_items = 0;
+    if (pending) {
+      if (lane == 0) {
+        items[0].t = (uint32_t)t0;
+        items[0].m = (uint32_t)(m_next - 1);
+      }
+      n_items = 1;
+    }
+    int rm = (int)fs->rep.num_inliers;  // the best support so far (for a suspended pair: of the model it is suspended at)
+    bool stop = false;
+    for (int tb = t0; tb < nb && !stop && n_items < TAIL_KMAX; tb += 64) {
+      const int tt = tb + lane;
+      int nm = 0, c[MAXM], mfirst = 0;
+      if (tt < nb) {
+        nm = nmod[tt];
+        mfirst = tt == t0 ? m_next : 0;
+      }
+      int tmax = -1;
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        c[m] = (m < nm && m >= mfirst) ? cnts[(size_t)tt * MAXM + m] : -1;
+        tmax = max(tmax, c[m]);
+      }
+      // running maximum before this lane's trial (exclusive prefix maximum over the lanes, seeded with rm)
+      int incl = tmax;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl = max(incl, v);
+      }
+      int ex = __shfl_up(incl, 1);
+      ex = lane == 0 ? rm : max(ex, rm);
+      // the scan stops at the first trial with a model at or beyond the threshold of the maximum so far
+      const uint32_t thr = max(nt[ex], min_trials);
+      const bool stops_here = nm > 0 && (T0 + (uint32_t)tt) >= thr;
+      const unsigned long long sb = __ballot(stops_here);
+      const int last = sb ? (__ffsll((long long)sb) - 1) : 63;  // lanes beyond are never reached
+      if (sb) stop = true;
+      int r = ex, ncand = 0;
+      unsigned cmask = 0;
+      if (lane <= last) {
+#pragma unroll
+        for (int m = 0; m < MAXM; ++m) {
+          if (c[m] >= 0) {
+            if (c[m] >= r && c[m] > F::K && c[m] >= F::LO_MIN) {
+              cmask |= 1u << m;
+              ncand += 1;
+            }
+            r = max(r, c[m]);
+          }
+        }
+      }
+      int pos = ncand;  // inclusive prefix sum
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(pos, o);
+        if (lane >= o) pos += v;
+      }
+      const int total = __shfl(pos, 63);
+      int at = (int)n_items + pos - ncand;
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        if ((cmask >> m) & 1u) {
+          if (at < TAIL_KMAX) {
+            items[at].t = (uint32_t)tt;
+            items[at].m = (uint32_t)m;
+          }
+          at += 1;
+        }
+      }
+      n_items = min((uint32_t)TAIL_KMAX, n_items + (uint32_t)total);
+      rm = max(rm, __shfl(incl, last));
+    }
+    // the jobs of this pair: job index = item slot (widx * TAIL_KMAX + k), listed compactly for the kernels that follow
+    uint32_t base = 0;
+    if (lane == 0) {
+      p.tail_n[widx] = n_items;
+      if (n_items) base = atomicAdd(p.active_count + 24, n_items);
+    }
+    base = __shfl(base, 0);
+    if ((uint32_t)lane < n_items) {
+      const uint32_t slot = widx * TAIL_KMAX + (uint32_t)lane;
+      LoJob* j = p.lo_jobs + slot;
+      j->pl = pl;
+      j->ninl = pending && lane == 0 ? fs->lo_ninl : 0u;
+      j->pending = pending && lane == 0 ? 1u : 0u;
+      j->nm = 0;
+      p.job_list[base + (uint32_t)lane] = slot;
+    }
+  }
+}
+
+// per-wave set-up shared by the two item kernels below
+template <int FAM>
+DSM_DEV PairWork item_pair_work(const VerifyParams& p, const WgScratch& ws, VSmem* sm, uint32_t pi, int lane, double* max_residual) {
+  const uint64_t moff = p.match_off[pi];
+  const dsm_camera& cam1 = p.cams[p.pairs[2 * pi]];
+  const dsm_camera& cam2 = p.cams[p.pairs[2 * pi + 1]];
+  PairWork w;
+  w.n = (int)(p.match_off[pi + 1] - moff);
+  w.resid = ws.resid;
+  w.inl = ws.inl;
+  w.tall = ws.tall;
+  w.models = nullptr;
+  w.sm = sm;
+  w.lane = lane;
+  w.pts = (FAM == FAM_E ? p.pts_norm : p.pts_px) + 4 * moff;
+  w.nt_table = nullptr;
+  double max_error = p.opt.max_error;
+  if (FAM == FAM_E)
+    max_error = (image_to_world_threshold(cam1, p.opt.max_error) + image_to_world_threshold(cam2, p.opt.max_error)) / 2;
+  *max_residual = max_error * max_error;
+  return w;
+}
+
+// wave per job: the ordered inlier list of the candidate model (loransac.h:160-163) into the job's slice of the pool,
+// its size into the job; the few problems the register kernels do not take are listed for the general ones, as
+// k_replay_lo does when it suspends a pair.
+template <int FAM>
+__global__ __launch_bounds__(64, 4) void k_items_inliers(const VerifyParams p) {
+  typedef Fam<FAM> F;
+  const int lane = threadIdx.x;
+  const WgScratch ws = wg_scratch(p);
+  for (uint32_t ji = blockIdx.x; ji < p.n_work; ji += gridDim.x) {
+    wv_sync();
+    const uint32_t slot = p.job_list[ji];
+    LoJob* j = p.lo_jobs + slot;
+    const uint32_t pi = p.pair0 + j->pl;
+    int ninl;
+    if (j->pending) {
+      ninl = (int)j->ninl;
+    } else {
+      double max_residual;
+      PairWork w = item_pair_work<FAM>(p, ws, nullptr, pi, lane, &max_residual);
+      const TailItem& it = p.tail_items[slot];
+      const double* M = p.models + (((size_t)j->pl * p.batch + it.t) * F::MAXM + it.m) * 9;
+      double Mr[9];
+      for (int q = 0; q < 9; ++q) Mr[q] = M[q];
+      score_model<FAM>(w, Mr, max_residual, true);
+      wv_sync();
+      const uint64_t moff = p.match_off[pi];
+      w.inl = reinterpret_cast<int*>(p.lo_inl_pool + moff * TAIL_KMAX + (uint64_t)(slot % TAIL_KMAX) * (uint64_t)w.n);
+      ninl = compact_inliers(w, max_residual);
+      if (lane == 0) j->ninl = (uint32_t)ninl;
+    }
+    if (lane == 0) {
+      if (!(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) p.lo_queue_g[atomicAdd(p.active_count + 22, 1u)] = slot;
+      if ((FAM == FAM_H ? 2 * ninl : ninl) < 9) atomicAdd(p.active_count + 23, 1u);
+    }
+  }
+}
+
+// wave per job: the candidate's support, then its local models in order (loransac.h:166-178) -> the item's outcome
+template <int FAM>
+__global__ __launch_bounds__(64, 4) void k_items_outcome(const VerifyParams p) {
+  typedef Fam<FAM> F;
+  const int lane = threadIdx.x;
+  const WgScratch ws = wg_scratch(p);
+  for (uint32_t ji = blockIdx.x; ji < p.n_work; ji += gridDim.x) {
+    wv_sync();
+    const uint32_t slot = p.job_list[ji];
+    const LoJob* j = p.lo_jobs + slot;
+    const uint32_t pi = p.pair0 + j->pl;
+    const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
+    TailItem* it = p.tail_items + slot;
+    double max_residual;
+    PairWork w = item_pair_work<FAM>(p, ws, nullptr, pi, lane, &max_residual);
+    uint32_t best_n;
+    double best_sum, best_model[9];
+    if (j->pending) {  // the candidate is the pair's current best
+      best_n = fs->rep.num_inliers;
+      best_sum = fs->rep.residual_sum;
+      for (int q = 0; q < 9; ++q) best_model[q] = fs->rep.model[q];
+    } else {
+      const uint32_t t = it->t, m = it->m;
+      const double* M = p.models + (((size_t)j->pl * p.batch + t) * F::MAXM + m) * 9;
+      for (int q = 0; q < 9; ++q) best_model[q] = M[q];
+      if constexpr (FAM == FAM_E) {
+        best_sum = score_and_sum<FAM>(w, best_model, max_residual, &best_n);
+      } else {
+        best_n = (uint32_t)p.counts[((size_t)j->pl * p.batch + t) * F::MAXM + m];
+        best_sum = p.sums[((size_t)j->pl * p.batch + t) * F::MAXM + m];  // k_score's in-order sum
+      }
+    }
+    const int nlo = (int)j->nm;
+    const double* glom = p.lo_models + (size_t)slot * 90;
+    for (int l = 0; l < nlo; ++l) {
+      double ML[9];
+      for (int q = 0; q < 9; ++q) ML[q] = glom[l * 9 + q];
+      uint32_t lc;
+      const double lsum = score_and_sum<FAM>(w, ML, max_residual, &lc);
+      if (lc > best_n || (lc == best_n && lsum < best_sum)) {
+        best_n = lc;
+        best_sum = lsum;
+        for (int q = 0; q < 9; ++q) best_model[q] = ML[q];
+      }
+    }
+    if (lane == 0) {
+      it->nlo = (uint32_t)nlo;
+      it->out_n = best_n;
+      it->out_sum = best_sum;
+      for (int q = 0; q < 9; ++q) it->out_model[q] = best_model[q];
+    }
+  }
+}
+
+// What a batched local-optimisation kernel works on: a queued pair (chain of k_replay_lo: per-pair buffers, slot = the
+// pair) or a job of an item pass (slot = the job; LoJob).
+struct LoRef {
+  uint32_t pl, slot;
+  int ninl;
+  const int* inl;
+  uint32_t* nm;
+};
+template <int FAM>
+DSM_DEV LoRef lo_ref(const VerifyParams& p, uint32_t widx) {
+  LoRef r;
+  const uint32_t w = p.worklist ? p.worklist[widx] : widx;
+  if (p.lo_jobs != nullptr) {
+    LoJob* j = p.lo_jobs + w;
+    const uint32_t pi = p.pair0 + j->pl;
+    const uint64_t moff = p.match_off[pi];
+    const uint64_t n = p.match_off[pi + 1] - moff;
+    r.pl = j->pl;
+    r.slot = w;
+    r.ninl = (int)j->ninl;
+    r.inl = reinterpret_cast<const int*>(j->pending ? p.lo_inl + moff : p.lo_inl_pool + moff * TAIL_KMAX + (uint64_t)(w % TAIL_KMAX) * n);
+    r.nm = &j->nm;
+  } else {
+    FamState* fs = p.fam_state + (size_t)(p.pair0 + w) * 3 + FAM;
+    r.pl = w;
+    r.slot = w;
+    r.ninl = (int)fs->lo_ninl;
+    r.inl = reinterpret_cast<const int*>(p.lo_inl + p.match_off[p.pair0 + w]);
+    r.nm = &fs->lo_nm;
+  }
+  return r;
+}
+
 // LO step 1 with the constraint matrix in registers (wr_colpiv_qr9): a wave per queued pair, lane l owns rows l,
 // l + 64, ...; the pair's inlier points are loaded once and serve the in-order normalisation sums (the four / two
 // independent chains of CenterAndNormalizeImagePoints advance together) and the rows.  Same operations as k_lo_prepare.
@@ -2434,15 +2752,14 @@ __global__ __launch_bounds__(64) void k_lo_prepare_reg(const VerifyParams p) {
   const int lane = threadIdx.x;
   const uint32_t widx = blockIdx.x;
   if (widx >= p.n_work) return;
-  const uint32_t pl = p.worklist[widx];
-  const uint32_t pi = p.pair0 + pl;
-  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
-  const int ninl = (int)fs->lo_ninl;
+  const LoRef ref = lo_ref<FAM>(p, widx);
+  const uint32_t pi = p.pair0 + ref.pl;
+  const int ninl = ref.ninl;
   if (!lo_prepare_in_registers<FAM>(ninl)) return;
   const uint64_t moff = p.match_off[pi];
   const double* pts = (FAM == FAM_E ? p.pts_norm : p.pts_px) + 4 * moff;
-  const int* inl = reinterpret_cast<const int*>(p.lo_inl + moff);
-  double* out = p.lo_work + (size_t)pl * LO_WORK_DOUBLES;
+  const int* inl = ref.inl;
+  double* out = p.lo_work + (size_t)ref.slot * LO_WORK_DOUBLES;
   const int m = FAM == FAM_H ? 2 * ninl : ninl;
   double px[PPL][4];
 #pragma unroll
@@ -2626,15 +2943,14 @@ __global__ __launch_bounds__(64, 2) void k_lo_prepare(const VerifyParams p) {  /
     wv_sync();
     const uint32_t widx = grab_item(wgrab, p.active_count + 19, &s_next, lane, grain);
     if (widx >= p.n_work) break;
-    const uint32_t pl = p.worklist[widx];
-    const uint32_t pi = p.pair0 + pl;
-    const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
+    const LoRef ref = lo_ref<FAM>(p, widx);
+    const uint32_t pi = p.pair0 + ref.pl;
     const uint64_t moff = p.match_off[pi];
     const double* pts = (FAM == FAM_E ? p.pts_norm : p.pts_px) + 4 * moff;
-    const int* inl = reinterpret_cast<const int*>(p.lo_inl + moff);
-    const int ninl = (int)fs->lo_ninl;
+    const int* inl = ref.inl;
+    const int ninl = ref.ninl;
     if (p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl)) continue;  // k_lo_prepare_reg's
-    double* out = p.lo_work + (size_t)pl * LO_WORK_DOUBLES;
+    double* out = p.lo_work + (size_t)ref.slot * LO_WORK_DOUBLES;
     double n1[3] = {0, 0, 0}, n2[3] = {0, 0, 0};
     auto idx = [inl](int i) { return inl[i]; };
     int m;
@@ -2715,8 +3031,8 @@ __global__ __launch_bounds__(64) void k_lo_jacobi(const VerifyParams p) {
   const int g = lane / LOJ_G, gl = lane % LOJ_G;
   const uint32_t widx = blockIdx.x * (uint32_t)(64 / LOJ_G) + (uint32_t)g;
   if (widx >= p.n_work) return;
-  const uint32_t pl = p.worklist[widx];
-  const double* in = p.lo_work + (size_t)pl * LO_WORK_DOUBLES;
+  const uint32_t slot = lo_ref<FAM>(p, widx).slot;
+  const double* in = p.lo_work + (size_t)slot * LO_WORK_DOUBLES;
   grp_vd W = lds + g * LOJ_GROUP_DOUBLES;
   grp_vd V = W + 81;
   grp_vd sv = V + 81;
@@ -2728,7 +3044,7 @@ __global__ __launch_bounds__(64) void k_lo_jacobi(const VerifyParams p) {
     V[e] = in[81 + e];
   }
   grp_jacobi_sweeps<LOJ_G>(W, V, dsz, scale, sv, gl);
-  double* outV = p.lo_work + (size_t)pl * LO_WORK_DOUBLES + 81;  // sorted right factor back to the pair's record
+  double* outV = p.lo_work + (size_t)slot * LO_WORK_DOUBLES + 81;  // sorted right factor back to the record
   for (int e = gl; e < 81; e += LOJ_G) outV[e] = V[e];
 }
 
@@ -2737,8 +3053,8 @@ __global__ __launch_bounds__(64) void k_lo_jacobi(const VerifyParams p) {
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_lo_jacobi_reg(const VerifyParams p) {
   const uint32_t widx = blockIdx.x * 64u + threadIdx.x;
   if (widx >= p.n_work) return;
-  const uint32_t pl = p.worklist[widx];
-  double* rec = p.lo_work + (size_t)pl * LO_WORK_DOUBLES;
+  const uint32_t slot = p.worklist ? p.worklist[widx] : widx;  // the pair (chain) or the job (item pass): lo_ref's slot
+  double* rec = p.lo_work + (size_t)slot * LO_WORK_DOUBLES;
   if ((int)rec[169] != 9) return;
   double W[81], V[81], sv[9];
 #pragma unroll
@@ -2757,9 +3073,8 @@ template <int FAM>
 __global__ __launch_bounds__(64) void k_lo_finish(const VerifyParams p) {
   const uint32_t widx = blockIdx.x * 64u + threadIdx.x;
   if (widx >= p.n_work) return;
-  const uint32_t pl = p.worklist[widx];
-  const uint32_t pi = p.pair0 + pl;
-  const double* in = p.lo_work + (size_t)pl * LO_WORK_DOUBLES;
+  const LoRef ref = lo_ref<FAM>(p, widx);
+  const double* in = p.lo_work + (size_t)ref.slot * LO_WORK_DOUBLES;
   double nv[9], n1[3], n2[3], model[9];
   for (int k = 0; k < 9; ++k) nv[k] = in[81 + 8 * 9 + k];
   for (int k = 0; k < 3; ++k) {
@@ -2770,9 +3085,9 @@ __global__ __launch_bounds__(64) void k_lo_finish(const VerifyParams p) {
     eight_point_finish(nv, n1, n2, model);
   else
     homography_finish(nv, n1, n2, model);
-  double* om = p.lo_models + (size_t)pl * 90;
+  double* om = p.lo_models + (size_t)ref.slot * 90;
   for (int k = 0; k < 9; ++k) om[k] = model[k];
-  p.fam_state[(size_t)pi * 3 + FAM].lo_nm = 1;
+  *ref.nm = 1;
 }
 
 // LO step 3 (E only), lane per queued pair: the 5-point solver from the null-space basis on, the same device
@@ -2780,14 +3095,14 @@ __global__ __launch_bounds__(64) void k_lo_finish(const VerifyParams p) {
 __global__ __launch_bounds__(64, 2) void k_lo_e_build(const VerifyParams p) {
   const uint32_t widx = blockIdx.x * 64u + threadIdx.x;
   if (widx >= p.n_work) return;
-  const uint32_t pl = p.worklist[widx];
+  const uint32_t sl = p.worklist ? p.worklist[widx] : widx;  // lo_ref's slot
   double Eb[36];
-  const double* V = p.lo_work + (size_t)pl * LO_WORK_DOUBLES + 81;
-  double* slot = p.lo_slots + (size_t)pl * 90;
+  const double* V = p.lo_work + (size_t)sl * LO_WORK_DOUBLES + 81;
+  double* slot = p.lo_slots + (size_t)sl * 90;
   for (int r = 0; r < 9; ++r)
     for (int c = 0; c < 4; ++c) Eb[r * 4 + c] = V[(5 + c) * 9 + r];  // Eb[r*4 + c] = V(r, 5 + c), essential_matrix.cc:72-74
   for (int k = 0; k < 36; ++k) slot[EPOLY_EB + k] = Eb[k];
-  five_point_build_A<1>(Eb, p.lo_ework + (size_t)pl * 200);
+  five_point_build_A<1>(Eb, p.lo_ework + (size_t)sl * 200);
 }
 __global__ __launch_bounds__(64) void k_lo_e_lu(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -2795,31 +3110,57 @@ __global__ __launch_bounds__(64) void k_lo_e_lu(const VerifyParams p) {
   unsigned char* idx = smem_raw + 100 * 64 * 8 + threadIdx.x;
   const uint32_t widx = blockIdx.x * 64u + threadIdx.x;
   if (widx >= p.n_work) return;
-  const uint32_t pl = p.worklist[widx];
-  e_lu_body(p.lo_ework + (size_t)pl * 200, p.lo_slots + (size_t)pl * 90, Al, idx);
+  const uint32_t sl = p.worklist ? p.worklist[widx] : widx;  // lo_ref's slot
+  e_lu_body(p.lo_ework + (size_t)sl * 200, p.lo_slots + (size_t)sl * 90, Al, idx);
 }
 __global__ __launch_bounds__(64) void k_lo_e_roots_models(const VerifyParams p) {
   const uint32_t widx = blockIdx.x * 64u + threadIdx.x;
   if (widx >= p.n_work) return;
-  const uint32_t pl = p.worklist[widx];
-  const uint32_t pi = p.pair0 + pl;
-  double* slot = p.lo_slots + (size_t)pl * 90;
+  const LoRef ref = lo_ref<FAM_E>(p, widx);
+  double* slot = p.lo_slots + (size_t)ref.slot * 90;
   const int code = e_roots_body(slot);
-  const int nm = e_models_body(slot, code, p.lo_models + (size_t)pl * 90);
-  p.fam_state[(size_t)pi * 3 + FAM_E].lo_nm = (uint32_t)nm;
+  const int nm = e_models_body(slot, code, p.lo_models + (size_t)ref.slot * 90);
+  *ref.nm = (uint32_t)nm;
 }
 
-void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, bool tail, hipStream_t st) {
+void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, int mode, hipStream_t st) {
   if (!p.n_work || !n_blocks) return;
   const size_t smem = ((offsetof(VSmem, gen) + 15) / 16) * 16;
-  if (tail) {  // F and H only: the E instance would still spill 134 VGPRs at 512 (its 16-lane 5-point finish is inlined)
-    if (fam == FAM_F) hipLaunchKernelGGL((k_replay_lo<FAM_F, true>), dim3(n_blocks), dim3(64), smem, st, p);
-    if (fam == FAM_H) hipLaunchKernelGGL((k_replay_lo<FAM_H, true>), dim3(n_blocks), dim3(64), smem, st, p);
+  if (mode == 1) {  // F and H only: the E instance would still spill 134 VGPRs at 512 (its 16-lane 5-point finish is inlined)
+    if (fam == FAM_F) hipLaunchKernelGGL((k_replay_lo<FAM_F, 1>), dim3(n_blocks), dim3(64), smem, st, p);
+    if (fam == FAM_H) hipLaunchKernelGGL((k_replay_lo<FAM_H, 1>), dim3(n_blocks), dim3(64), smem, st, p);
+  } else if (mode == 2) {
+    if (fam == FAM_E) hipLaunchKernelGGL((k_replay_lo<FAM_E, 2>), dim3(n_blocks), dim3(64), smem, st, p);
+    if (fam == FAM_F) hipLaunchKernelGGL((k_replay_lo<FAM_F, 2>), dim3(n_blocks), dim3(64), smem, st, p);
+    if (fam == FAM_H) hipLaunchKernelGGL((k_replay_lo<FAM_H, 2>), dim3(n_blocks), dim3(64), smem, st, p);
   } else {
-    if (fam == FAM_E) hipLaunchKernelGGL((k_replay_lo<FAM_E, false>), dim3(n_blocks), dim3(64), smem, st, p);
-    if (fam == FAM_F) hipLaunchKernelGGL((k_replay_lo<FAM_F, false>), dim3(n_blocks), dim3(64), smem, st, p);
-    if (fam == FAM_H) hipLaunchKernelGGL((k_replay_lo<FAM_H, false>), dim3(n_blocks), dim3(64), smem, st, p);
+    if (fam == FAM_E) hipLaunchKernelGGL((k_replay_lo<FAM_E, 0>), dim3(n_blocks), dim3(64), smem, st, p);
+    if (fam == FAM_F) hipLaunchKernelGGL((k_replay_lo<FAM_F, 0>), dim3(n_blocks), dim3(64), smem, st, p);
+    if (fam == FAM_H) hipLaunchKernelGGL((k_replay_lo<FAM_H, 0>), dim3(n_blocks), dim3(64), smem, st, p);
   }
+}
+// item pass, step by step (the host reads the job count between enum and the rest)
+void launch_vp_items_enum(const VerifyParams& p, int fam, hipStream_t st) {
+  if (!p.n_work) return;
+  const uint32_t ne = p.n_work < 8192u ? p.n_work : 8192u;
+  if (fam == FAM_E) hipLaunchKernelGGL(k_items_enum<FAM_E>, dim3(ne), dim3(64), 0, st, p);
+  if (fam == FAM_F) hipLaunchKernelGGL(k_items_enum<FAM_F>, dim3(ne), dim3(64), 0, st, p);
+  if (fam == FAM_H) hipLaunchKernelGGL(k_items_enum<FAM_H>, dim3(ne), dim3(64), 0, st, p);
+}
+// p.n_work = number of jobs, p.job_list their slots
+void launch_vp_items_inliers(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st) {
+  if (!p.n_work || !n_blocks) return;
+  const uint32_t nb = p.n_work < n_blocks ? p.n_work : n_blocks;
+  if (fam == FAM_E) hipLaunchKernelGGL(k_items_inliers<FAM_E>, dim3(nb), dim3(64), 0, st, p);
+  if (fam == FAM_F) hipLaunchKernelGGL(k_items_inliers<FAM_F>, dim3(nb), dim3(64), 0, st, p);
+  if (fam == FAM_H) hipLaunchKernelGGL(k_items_inliers<FAM_H>, dim3(nb), dim3(64), 0, st, p);
+}
+void launch_vp_items_outcome(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st) {
+  if (!p.n_work || !n_blocks) return;
+  const uint32_t nb = p.n_work < n_blocks ? p.n_work : n_blocks;
+  if (fam == FAM_E) hipLaunchKernelGGL(k_items_outcome<FAM_E>, dim3(nb), dim3(64), 0, st, p);
+  if (fam == FAM_F) hipLaunchKernelGGL(k_items_outcome<FAM_F>, dim3(nb), dim3(64), 0, st, p);
+  if (fam == FAM_H) hipLaunchKernelGGL(k_items_outcome<FAM_H>, dim3(nb), dim3(64), 0, st, p);
 }
 void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint32_t n_wave_prepare, uint32_t n_small_jacobi,
                          hipStream_t st) {

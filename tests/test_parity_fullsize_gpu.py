@@ -17,7 +17,7 @@ from tests.test_verify_gpu import tvg_equal
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["batched_lo", "batched_tail", "batched_tail_all", "inline_lo"])
+@pytest.fixture(autouse=True, params=["batched_lo", "batched_tail", "batched_tail_all", "batched_tail_inline", "item_mode", "inline_lo"])
 def lo_schedule(request, monkeypatch):
     """The schedules of the local optimisation: the batched kernels that long pair lists (bench.py) run -- pure
     (DSM_LO_TAIL=0: every queued pair goes through k_lo_prepare* / k_lo_jacobi*) and with the inline tail (a queue of
@@ -26,7 +26,12 @@ def lo_schedule(request, monkeypatch):
     monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "1" if request.param == "inline_lo" else "0")
     # batched_tail_all: every pair goes to the inline finish right after its first suspension (the configuration that
     # exposed a register-spill miscompile of k_replay_lo<TAIL> in round 2: tools/bisect_schedules.py)
-    monkeypatch.setenv("DSM_LO_TAIL", {"batched_tail": "4", "batched_tail_all": "100000"}.get(request.param, "0"))
+    # The tail itself has two forms: an item pass (k_items_* + the batched kernels over jobs + the lookup replay: the product path, round 3) and
+    # the inline finish of round 2 (batched_tail_inline: DSM_LO_TAIL_MODE=inline).
+    monkeypatch.setenv("DSM_LO_TAIL", {"batched_tail": "4", "batched_tail_all": "100000", "batched_tail_inline": "100000"}.get(request.param, "0"))
+    monkeypatch.setenv("DSM_LO_TAIL_MODE", "inline" if request.param == "batched_tail_inline" else "items")
+    # item_mode: every round as item passes from the start (what short pair lists get by default)
+    monkeypatch.setenv("DSM_VERIFY_ITEM_MODE", "1" if request.param == "item_mode" else "0")
     return request.param
 
 

@@ -162,7 +162,9 @@ def test_watermark_suspects_among_ordinary_pairs(dsm, oracle, schedule, monkeypa
                                                          (1, False, "batched_lo"), (0, False, "batched_lo"),
                                                          (1, False, "lanes"), (0, False, "lanes_inline"),
                                                          (1, False, "batched_tail"), (0, False, "batched_tail"),
-                                                         (1, False, "batched_tail_all"), (0, False, "batched_tail_all")])
+                                                         (1, False, "batched_tail_all"), (0, False, "batched_tail_all"),
+                                                         (1, False, "batched_tail_inline"), (0, False, "batched_tail_inline"),
+                                                         (1, False, "item_mode"), (0, False, "item_mode")])
 def test_stage_match_and_verify_many_pairs(dsm, oracle, prior, sampler_serial, legacy, monkeypatch):
     """dsm_match_pairs + dsm_verify_pairs over an exhaustive pair list == oracle matcher + oracle verifier
     with SiftFeatureMatcher::Match's post-filter (matching.cc:824-831).  sampler_serial forces the sampler's
@@ -172,7 +174,9 @@ def test_stage_match_and_verify_many_pairs(dsm, oracle, prior, sampler_serial, l
         monkeypatch.setenv("DSM_SAMPLER_SERIAL", "1")
     # DSM_LO_TAIL: queue length at which the batched schedule finishes a round inline (default 2 048 = always on lists
     # this short); 0 keeps every local optimisation in the batched kernels, "batched_tail" mixes the two
-    monkeypatch.setenv("DSM_LO_TAIL", {"batched_tail": "6", "batched_tail_all": "100000"}.get(legacy, "0"))
+    monkeypatch.setenv("DSM_LO_TAIL", {"batched_tail": "6", "batched_tail_all": "100000", "batched_tail_inline": "100000"}.get(legacy, "0"))
+    monkeypatch.setenv("DSM_LO_TAIL_MODE", "inline" if legacy == "batched_tail_inline" else "items")  # the tail as an item pass (default) or inline
+    monkeypatch.setenv("DSM_VERIFY_ITEM_MODE", "1" if legacy == "item_mode" else "0")  # every round as item passes from the start
     if legacy == "chunks":  # several chunks of the pair list (one chunk is the rule on a 288 GB device)
         monkeypatch.setenv("DSM_VERIFY_CHUNK_PAIRS", "5")
         monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "0")
@@ -180,7 +184,7 @@ def test_stage_match_and_verify_many_pairs(dsm, oracle, prior, sampler_serial, l
         monkeypatch.setenv("DSM_VERIFY_LANES", "3")
         monkeypatch.setenv("DSM_VERIFY_CHUNK_PAIRS", "4")
         monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "0" if legacy == "lanes" else "1")
-    elif legacy in ("batched_lo", "batched_tail", "batched_tail_all"):  # the schedule long pair lists get (short ones default to the inline form)
+    elif legacy in ("batched_lo", "batched_tail", "batched_tail_all", "batched_tail_inline", "item_mode"):  # the schedule long pair lists get (short ones default to the inline form)
         monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "0")
     elif legacy == "inline_lo":  # phase-split pipeline with the local optimisation inline in the replay (round-1 schedule)
         monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "1")

@@ -3,7 +3,9 @@
 produce byte-identical TwoViewGeometry records and inlier matches on the whole workload:
   batched   phase-split pipeline, local optimisation as batched kernels (k_replay_lo + k_lo_*; what bench.py runs)
   inline    phase-split pipeline, local optimisation inline in the wave-per-pair replay (DSM_VERIFY_INLINE_LO=1)
-  no_tail   the batched schedule without the inline finish of short queues (DSM_LO_TAIL=0)
+  no_tail   the batched schedule without a tail: every local optimisation through the batched kernels (DSM_LO_TAIL=0)
+  tail_inline  the tail of a round as round 2 ran it: inline in k_replay_lo<1>, F and H only (DSM_LO_TAIL_MODE=inline;
+            the default since round 3 computes the tail's local optimisations as parallel items, k_tail_enum / k_tail_lo)
   final_2waves  k_verify_final compiled for two waves per SIMD (register spills; DSM_FINAL_WAVES=2)
   one_lane  the batched schedule on a single lane (DSM_VERIFY_LANES=1; the default deals the list out to two lanes)
   legacy    one k_ransac kernel per family, lane-0 sampler, per-lane scratch solvers (DSM_VERIFY_LEGACY=1; --legacy)
@@ -26,6 +28,9 @@ def run(ctx, opts, schedule):
     os.environ.pop("DSM_VERIFY_LEGACY", None)
     os.environ.pop("DSM_VERIFY_LANES", None)
     os.environ.pop("DSM_LO_TAIL", None)
+    os.environ.pop("DSM_LO_TAIL_MODE", None)
+    if schedule == "tail_inline":
+        os.environ["DSM_LO_TAIL_MODE"] = "inline"
     os.environ.pop("DSM_FINAL_WAVES", None)
     if schedule == "final_2waves":
         os.environ["DSM_FINAL_WAVES"] = "2"
@@ -61,7 +66,7 @@ def main():
     opts = capi.default_two_view_options()
     r0 = run(ctx, opts, "batched")
     ok = True
-    for name in ["one_lane", "no_tail", "final_2waves", "inline"] + (["legacy"] if a.legacy else []):
+    for name in ["one_lane", "no_tail", "tail_inline", "final_2waves", "inline"] + (["legacy"] if a.legacy else []):
         r1 = run(ctx, opts, name)
         same = (r0[0] == r1[0]).all() and (r0[1] == r1[1]).all() and (r0[2] == r1[2]).all()
         # num_trials / num_models are the last 32 bytes of the record
