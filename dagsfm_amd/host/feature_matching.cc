@@ -2,6 +2,7 @@
 #include "feature_matching.h"
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -153,12 +154,87 @@ bool ExhaustiveFeatureMatcher::Run() {
 }
 
 // ---------------------------------------------------------------------------------------- retrieval
+bool VocabularyFile::ReadReferenceLayout(const std::string& path) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;
+  std::fseek(f, 0, SEEK_END);
+  const long fsize = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  std::vector<uint8_t> buf(fsize > 0 ? static_cast<size_t>(fsize) : 0);
+  const bool read_ok = !buf.empty() && std::fread(buf.data(), 1, buf.size(), f) == buf.size();
+  std::fclose(f);
+  if (!read_ok || buf.size() < 16) return false;
+  uint64_t rows = 0, cols = 0;
+  std::memcpy(&rows, buf.data(), 8);
+  std::memcpy(&cols, buf.data() + 8, 8);
+  if (cols != 128 || rows == 0 || rows > 0x7fffffffull || 16 + rows * cols > buf.size()) return false;
+  const size_t words_end = 16 + static_cast<size_t>(rows * cols);
+  // parse the inverted index from `at`; true when it ends exactly at the end of the file
+  auto parse = [&](size_t at, std::vector<float>* proj, std::vector<float>* thr) -> bool {
+    const size_t proj_bytes = 64 * 128 * 4;
+    if (at + 8 + proj_bytes > buf.size()) return false;
+    if (proj) std::memcpy(proj->data(), buf.data() + at + 8, proj_bytes);
+    size_t pos = at + 8 + proj_bytes;
+    for (uint64_t w = 0; w < rows; ++w) {
+      if (pos + 1 + 4 + 64 * 4 + 4 > buf.size()) return false;
+      if (thr) std::memcpy(thr->data() + w * 64, buf.data() + pos + 5, 64 * 4);
+      uint32_t n_entries = 0;
+      std::memcpy(&n_entries, buf.data() + pos + 5 + 256, 4);
+      pos += 1 + 4 + 256 + 4;
+      const uint64_t entry_bytes = static_cast<uint64_t>(n_entries) * 32;  // int32 image, int32 feature, 4 f32 geometry, u64 signature
+      if (entry_bytes > buf.size() - pos) return false;
+      pos += static_cast<size_t>(entry_bytes);
+    }
+    if (pos + 4 > buf.size()) return false;
+    int32_t num_images = 0;
+    std::memcpy(&num_images, buf.data() + pos, 4);
+    if (num_images < 0) return false;
+    return pos + 4 + static_cast<uint64_t>(num_images) * 8 == buf.size();
+  };
+  const int32_t key[2] = {static_cast<int32_t>(rows), 64};
+  for (size_t at = words_end; at + 8 <= buf.size(); ++at) {
+    if (std::memcmp(buf.data() + at, key, 8) != 0) continue;
+    if (!parse(at, nullptr, nullptr)) continue;
+    num_words = static_cast<uint32_t>(rows);
+    words.assign(buf.begin() + 16, buf.begin() + words_end);
+    projection.resize(64 * 128);
+    thresholds.resize(static_cast<size_t>(rows) * 64);
+    return parse(at, &projection, &thresholds);
+  }
+  return false;
+}
+
+std::vector<uint32_t> TopScaleFeatureOrder(const FeatureKeypoints& keypoints, size_t num_features) {
+  std::vector<uint32_t> order;
+  if (keypoints.size() <= num_features || num_features == 0) {
+    order.resize(keypoints.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = static_cast<uint32_t>(i);
+    return order;
+  }
+  std::vector<std::pair<size_t, float>> scales;
+  scales.reserve(keypoints.size());
+  for (size_t i = 0; i < keypoints.size(); ++i) {
+    const FeatureKeypoint& k = keypoints[i];  // FeatureKeypoint::ComputeScale, src/feature/types.cc:84-94
+    const float sx = std::sqrt(k.a11 * k.a11 + k.a21 * k.a21), sy = std::sqrt(k.a12 * k.a12 + k.a22 * k.a22);
+    scales.emplace_back(i, (sx + sy) / 2.0f);
+  }
+  std::partial_sort(scales.begin(), scales.begin() + num_features, scales.end(),
+                    [](const std::pair<size_t, float> scale1, const std::pair<size_t, float> scale2) { return scale1.second > scale2.second; });
+  order.resize(num_features);
+  for (size_t i = 0; i < num_features; ++i) order[i] = static_cast<uint32_t>(scales[i].first);
+  return order;
+}
+
 bool VocabularyFile::Read(const std::string& path) {
   FILE* f = std::fopen(path.c_str(), "rb");
   if (!f) return false;
   char magic[8];
   uint32_t hdr[2];
-  bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "DSMVOC1", 8) == 0 && std::fread(hdr, 4, 2, f) == 2 && hdr[0] > 0;
+  if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, "DSMVOC1", 8) != 0) {  // not this library's flat file: the reference's layout
+    std::fclose(f);
+    return ReadReferenceLayout(path);
+  }
+  bool ok = std::fread(hdr, 4, 2, f) == 2 && hdr[0] > 0;
   if (ok) {
     num_words = hdr[0];
     words.resize(static_cast<size_t>(num_words) * 128);
@@ -190,7 +266,7 @@ bool VocabSimilarityGraph::Run() {
   image_pairs_.clear();
   scores_.clear();
   if (!options_.Check()) {
-    last_error_ = "VocabSimilaritySearchOptions::Check failed (spatial verification and max_num_features are not built)";
+    last_error_ = "VocabSimilaritySearchOptions::Check failed (num_images > 0, a vocabulary path; spatial re-ranking is not built)";
     return false;
   }
   VocabularyFile voc;
@@ -214,8 +290,16 @@ bool VocabSimilarityGraph::Run() {
   std::vector<const uint8_t*> desc(n);
   for (uint32_t i = 0; i < n; ++i) {
     const FeatureDescriptors& d = cache_.GetDescriptors(ids[i]);
-    copies[i] = d.data;
-    nfeat[i] = static_cast<uint32_t>(d.rows);
+    if (options_.max_num_features > 0 && d.rows > static_cast<size_t>(options_.max_num_features)) {
+      // similarity_graph.cpp:77-79, 137-141: index and query only the features of largest scale, in that order
+      const std::vector<uint32_t> order = TopScaleFeatureOrder(cache_.GetKeypoints(ids[i]), static_cast<size_t>(options_.max_num_features));
+      copies[i].resize(order.size() * 128);
+      for (size_t k = 0; k < order.size(); ++k) std::memcpy(copies[i].data() + k * 128, d.data.data() + static_cast<size_t>(order[k]) * 128, 128);
+      nfeat[i] = static_cast<uint32_t>(order.size());
+    } else {
+      copies[i] = d.data;
+      nfeat[i] = static_cast<uint32_t>(d.rows);
+    }
     desc[i] = copies[i].data();
     cache_.ReleasePins();
   }
@@ -375,13 +459,31 @@ uint64_t dsm_host_image_pair_to_pair_id(uint32_t a, uint32_t b) { return Databas
 
 // VocabSimilarityGraph::Run over database_path with the vocabulary file; writes up to `capacity` pairs (image ids) and
 // their scores.  Returns the number of pairs, or < 0 on error.
+int64_t dsm_host_vocab_candidate_pairs2(const char* database_path, const char* vocab_path, int num_images, int num_nearest_neighbors,
+                                        int max_num_features, uint32_t* pairs, float* scores, uint64_t capacity);
 int64_t dsm_host_vocab_candidate_pairs(const char* database_path, const char* vocab_path, int num_images, int num_nearest_neighbors,
                                        uint32_t* pairs, float* scores, uint64_t capacity) {
+  return dsm_host_vocab_candidate_pairs2(database_path, vocab_path, num_images, num_nearest_neighbors, -1, pairs, scores, capacity);
+}
+// the vocabulary of a file in either layout, for the tests: returns num_words (0: unreadable); arrays may be null
+uint32_t dsm_host_read_vocabulary(const char* path, uint8_t* words, float* projection, float* thresholds, uint32_t capacity_words) {
+  VocabularyFile v;
+  if (!v.Read(path)) return 0;
+  if (v.num_words <= capacity_words) {
+    if (words) std::memcpy(words, v.words.data(), v.words.size());
+    if (projection) std::memcpy(projection, v.projection.data(), v.projection.size() * 4);
+    if (thresholds) std::memcpy(thresholds, v.thresholds.data(), v.thresholds.size() * 4);
+  }
+  return v.num_words;
+}
+int64_t dsm_host_vocab_candidate_pairs2(const char* database_path, const char* vocab_path, int num_images, int num_nearest_neighbors,
+                                        int max_num_features, uint32_t* pairs, float* scores, uint64_t capacity) {
   try {
     Database db(database_path);
     VocabSimilaritySearchOptions o;
     o.num_images = num_images;
     o.num_nearest_neighbors = num_nearest_neighbors;
+    o.max_num_features = max_num_features;
     o.vocab_tree_path = vocab_path;
     VocabSimilarityGraph g(o, db);
     if (!g.Run()) {

@@ -240,22 +240,37 @@ struct VocabSimilaritySearchOptions {  // similarity_graph.h:52-76
   int num_images = 100;
   int num_nearest_neighbors = 5;
   int num_checks = 256;                   // FLANN search effort in the reference; the search is exact here
-  int num_images_after_verification = 0;  // spatial verification is not built (0 = off is the reference's default)
-  int max_num_features = -1;
+  int num_images_after_verification = 0;  // spatial re-ranking (vote_and_verify.cc) is not built: 0 = off is the reference's default
+  int max_num_features = -1;              // > 0: index and query only the features of largest scale (ExtractTopScaleFeatures)
   int num_threads = 8;
   std::string vocab_tree_path;
-  bool Check() const { return num_images > 0 && !vocab_tree_path.empty() && num_images_after_verification == 0 && max_num_features <= 0; }
+  bool Check() const { return num_images > 0 && !vocab_tree_path.empty() && num_images_after_verification == 0; }
 };
 
-// The vocabulary as this library reads it (a flat file; INTEGRATION.md shows how to write it from a VisualIndex):
-//   "DSMVOC1\0", uint32 num_words, uint32 reserved, words u8 [W][128], projection f32 [64][128], thresholds f32 [W][64]
+// The vocabulary.  Read() takes either layout:
+//   * the reference's own vocabulary-tree file, as VisualIndex<>::Write leaves it (retrieval/visual_index.h:586-614):
+//       uint64 rows, uint64 cols (= 128), the visual words u8 [rows][cols];
+//       FLANN's serialised search index (third-party layout, not needed: the word search is exact here);
+//       the inverted index (inverted_index.h:342-381): int32 num_words, int32 64, the projection f32 [64][128], then
+//       per word (inverted_file.h:375-392) u8 status, f32 idf, f32 thresholds[64], uint32 entries x 32 B, and at the
+//       end int32 num_images x (int32 id, f32 constant).
+//     The FLANN blob carries no length, so the inverted index is located by its header -- (num_words, 64) -- at the
+//     one offset from which the rest of the file parses to exactly its end.
+//   * a flat file of this library (Write()): "DSMVOC1\0", uint32 num_words, uint32 reserved, words u8 [W][128],
+//     projection f32 [64][128], thresholds f32 [W][64]
 struct VocabularyFile {
   uint32_t num_words = 0;
   std::vector<uint8_t> words;
   std::vector<float> projection, thresholds;
   bool Read(const std::string& path);
+  bool ReadReferenceLayout(const std::string& path);
   bool Write(const std::string& path) const;
 };
+
+// ExtractTopScaleFeatures (src/feature/utils.cc:79-113): the indices of the num_features keypoints of largest scale, in
+// the order the reference leaves them (std::partial_sort on (index, scale) by descending scale -- the same library
+// call, so ties fall the same way); every index in order when there are no more than num_features.
+std::vector<uint32_t> TopScaleFeatureOrder(const FeatureKeypoints& keypoints, size_t num_features);
 
 class VocabSimilarityGraph {
  public:

@@ -133,3 +133,106 @@ def test_host_vocab_similarity_graph_over_database(tmp_path, dsm):
     assert n == len(exp_pairs)
     assert [tuple(x) for x in pairs[:n]] == exp_pairs
     assert (scores[:n] == np.array(exp_scores, np.float32)).all()
+
+
+def _write_reference_vocabulary(path, words, projection, thresholds, rng, with_entries=False):
+    """A vocabulary-tree file in the reference's own layout (VisualIndex<>::Write, retrieval/visual_index.h:586-614):
+    words, an opaque FLANN blob (random bytes here -- the reader must find the inverted index without understanding it),
+    the inverted index (inverted_index.h:383-420 / inverted_file.h:394-411)."""
+    import struct
+    w = np.ascontiguousarray(words, np.uint8)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<QQ", w.shape[0], 128))
+        f.write(w.tobytes())
+        blob = rng.integers(0, 256, int(rng.integers(1000, 5000)), dtype=np.uint8).tobytes()
+        # plant the index header's byte pattern inside the blob: the reader must not be fooled by it
+        blob = blob[:100] + struct.pack("<ii", w.shape[0], 64) + blob[100:]
+        f.write(blob)
+        f.write(struct.pack("<ii", w.shape[0], 64))
+        f.write(np.ascontiguousarray(projection, np.float32).tobytes())
+        n_img = 0
+        for k in range(w.shape[0]):
+            f.write(struct.pack("<Bf", 3, 0.25 * k))
+            f.write(np.ascontiguousarray(thresholds[k], np.float32).tobytes())
+            ne = int(rng.integers(0, 3)) if with_entries else 0
+            f.write(struct.pack("<I", ne))
+            for _ in range(ne):
+                f.write(struct.pack("<iiffffQ", 7, 3, 1.0, 2.0, 3.0, 0.5, 0xDEADBEEF))
+                n_img = 1
+        f.write(struct.pack("<i", n_img))
+        for _ in range(n_img):
+            f.write(struct.pack("<if", 7, 1.5))
+
+
+@pytest.mark.parametrize("with_entries", [False, True])
+def test_reads_the_references_vocabulary_file_layout(tmp_path, with_entries):
+    """VERDICT r02 (missing 1): the reference's vocabulary file is read as it is (the FLANN blob skipped), no converter."""
+    import ctypes
+    import os
+    rng = np.random.default_rng(3)
+    words, proj, thr = _scene(2, 64, 96)[2]
+    path = str(tmp_path / "vocab_tree.bin")
+    _write_reference_vocabulary(path, words, proj, thr, rng, with_entries)
+    L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dagsfm_amd", "libdagsfm_host.so"))
+    L.dsm_host_read_vocabulary.restype = ctypes.c_uint32
+    L.dsm_host_read_vocabulary.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    w2 = np.zeros_like(np.ascontiguousarray(words, np.uint8))
+    p2 = np.zeros((64, 128), np.float32)
+    t2 = np.zeros((len(words), 64), np.float32)
+    assert L.dsm_host_read_vocabulary(path.encode(), w2.ctypes.data, p2.ctypes.data, t2.ctypes.data, len(words)) == len(words)
+    assert (w2 == words).all() and (p2 == proj).all() and (t2 == thr).all()
+    # a truncated file is refused, not misread
+    open(path, "r+b").truncate(os.path.getsize(path) - 3)
+    assert L.dsm_host_read_vocabulary(path.encode(), None, None, None, 0) == 0
+
+
+@pytest.mark.gpu
+def test_host_vocab_similarity_graph_max_num_features(tmp_path, dsm):
+    """VocabTreeMatching.max_num_features (similarity_graph.cpp:77-79, 137-141): every image is indexed and queried with
+    its max_num_features features of largest scale only, in ExtractTopScaleFeatures' order; the vocabulary comes from a
+    file in the reference's layout."""
+    import ctypes
+    import os
+    import sqlite3
+    from tests import dbutil
+    n_img, keep = 8, 120
+    scene, ims, voc = _scene(n_img, 300, 512)
+    rng = np.random.default_rng(8)
+    path = str(tmp_path / "database.db")
+    dbutil.create(path, [(im[0], im[1]) for im in ims])
+    # distinct keypoint scales (a11 = a22 = s, a12 = a21 = 0 -> ComputeScale = s): the top-scale order is then unique
+    con = sqlite3.connect(path)
+    orders = []
+    for i, im in enumerate(ims):
+        n = len(im[0])
+        s = rng.permutation(n).astype(np.float32) + 1.0
+        k = np.zeros((n, 6), np.float32)
+        k[:, :2] = im[1]
+        k[:, 2] = s
+        k[:, 5] = s
+        con.execute("UPDATE keypoints SET data = ? WHERE image_id = ?", (k.tobytes(), i + 1))
+        orders.append(np.argsort(-s)[:keep])
+    con.commit()
+    con.close()
+    L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dagsfm_amd", "libdagsfm_host.so"))
+    L.dsm_host_vocab_candidate_pairs2.restype = ctypes.c_int64
+    L.dsm_host_vocab_candidate_pairs2.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_uint64]
+    vpath = str(tmp_path / "vocab_tree.bin")
+    _write_reference_vocabulary(vpath, *voc, rng)
+    pairs = np.zeros((1000, 2), np.uint32)
+    scores = np.zeros(1000, np.float32)
+    n = L.dsm_host_vocab_candidate_pairs2(path.encode(), vpath.encode(), 4, 5, keep, pairs.ctypes.data, scores.ctypes.data, 1000)
+    assert n > 0
+    dsm.set_images([im[0][o] for im, o in zip(ims, orders)])
+    dsm.retrieval_set_vocabulary(*voc)
+    dsm.retrieval_index()
+    res = dsm.retrieval_query(n_img, 5, 4)
+    exp_pairs, exp_scores = [], []
+    for q, (ids, sc) in enumerate(res):
+        for d, s in zip(ids, sc):
+            if q < int(d):
+                exp_pairs.append((q + 1, int(d) + 1))
+                exp_scores.append(np.float32(s) * np.float32(1e3))
+    assert n == len(exp_pairs) and [tuple(x) for x in pairs[:n]] == exp_pairs
+    assert (scores[:n] == np.array(exp_scores, np.float32)).all()
