@@ -390,10 +390,17 @@ DSM_DEV int homography_four_point_reg(const double* xs, double* models) {
       if (v > scale) scale = v;
     }
   if (scale == 0.0) scale = 1.0;
+  // m / scale (JacobiSVD's m_scaledMatrix): an exactly rounded division per entry -- a third of this solver's
+  // instructions when done for all 72.  24 entries are structural zeros (0 / scale = 0) and the eight -1 entries share
+  // one quotient: 41 divisions, same values.
+  const double neg_inv = -1.0 / scale;
 #pragma unroll
-  for (int c = 0; c < 8; ++c)
-#pragma unroll
-    for (int r = 0; r < 9; ++r) a[c][r] /= scale;
+  for (int i = 0; i < 4; ++i) {
+    a[i][0] /= scale; a[i][1] /= scale; a[i][2] = neg_inv;
+    a[i][6] /= scale; a[i][7] /= scale; a[i][8] /= scale;
+    a[4 + i][3] /= scale; a[4 + i][4] /= scale; a[4 + i][5] = neg_inv;
+    a[4 + i][6] /= scale; a[4 + i][7] /= scale; a[4 + i][8] /= scale;
+  }
   double nu[8], nd[8], hco[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
