@@ -134,7 +134,7 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
                     &ctx->d_mm_off[1], &ctx->d_mm_counts, &ctx->d_mm_state, &ctx->d_mm_first, &ctx->d_mm_acc, &ctx->d_mm_keep,
                     &ctx->d_mm_total, &ctx->d_order, &ctx->d_dpairs2, &ctx->d_ecnt, &ctx->d_eoff, &ctx->d_etotal, &ctx->d_entries,
                     &ctx->d_out2, &ctx->d_ms, &ctx->d_out2s, &ctx->d_lo_inl, &ctx->d_lo_inl_pool, &ctx->d_nt_table_t, &ctx->d_wm_redo, &ctx->d_wm_total,
-                    &ctx->d_wm_count};
+                    &ctx->d_wm_count, &ctx->d_pose_jobs};
   for (VerifyLane& L : ctx->lanes) {
     for (DevBuf* b : {&L.samples, &L.draws_end, &L.nmodels, &L.vcounts, &L.vsums, &L.models, &L.ework, &L.active, &L.vscratch, &L.lo_queue,
                       &L.lo_work, &L.lo_models, &L.lo_slots, &L.lo_ework, &L.tail_items, &L.tail_n, &L.lo_jobs, &L.job_list})
@@ -855,6 +855,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   HIPCHK(ctx, ctx->d_wm_redo.reserve(std::max<uint32_t>(n_pairs, 1) * 4));
   HIPCHK(ctx, ctx->d_wm_total.reserve(std::max<uint32_t>(n_pairs, 1) * 4));
   HIPCHK(ctx, ctx->d_wm_count.reserve(4));
+  HIPCHK(ctx, ctx->d_pose_jobs.reserve(std::max<uint32_t>(n_pairs, 1) * sizeof(PoseJob)));
   HIPCHK(ctx, hipMemsetAsync(ctx->d_wm_count.p, 0, 4, st));
   HIPCHK(ctx, ctx->d_tvg.reserve(std::max<uint32_t>(n_pairs, 1) * sizeof(dsm_two_view_geometry)));
   HIPCHK(ctx, ctx->d_inl.reserve(std::max<uint64_t>(total_matches, 1) * 8));
@@ -894,6 +895,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.wm_count = ctx->d_wm_count.as<uint32_t>();
   vp.final_list = nullptr;
   vp.n_final = 0;
+  vp.pose_jobs = ctx->d_pose_jobs.as<PoseJob>();
   vp.max_trials[0] = ransac_ctor_max_trials(o, o->min_inlier_ratio, kMinSamples[0]);
   vp.max_trials[1] = ransac_ctor_max_trials(o, o->min_inlier_ratio, kMinSamples[1]);
   vp.max_trials[2] = ransac_ctor_max_trials(o, o->min_inlier_ratio, kMinSamples[2]);

@@ -105,7 +105,7 @@ struct dsm_ctx {
   DevBuf d_cams, d_pairs_dev, d_seeds, d_tvg, d_inl, d_inl_counts, d_inl_off, d_inl_compact, d_vscratch, d_inl_total;
   DevBuf d_nt_table, d_nt_off, d_nt_off_t, d_pair_state, d_pts_px, d_pts_norm, d_reports, d_masks;
   DevBuf d_fam_state, d_sidx, d_lo_inl;
-  DevBuf d_nt_table_t, d_wm_redo, d_wm_total, d_wm_count, d_lo_inl_pool;
+  DevBuf d_nt_table_t, d_wm_redo, d_wm_total, d_wm_count, d_lo_inl_pool, d_pose_jobs;
   VerifyLane lanes[DSM_VERIFY_MAX_LANES];
   uint32_t verify_lanes = 1;  // lanes of the last call
   uint32_t verify_lo_iters[3] = {0, 0, 0};

@@ -102,6 +102,17 @@ struct FamState {
 // has just become the best one, its inliers are the input, the local models are compared with it in order -- so it
 // can be computed before the sequential scan knows whether the step will be taken.  An item is that outcome.
 #define TAIL_KMAX 8  // candidates per pair and tail iteration (a pair with more is simply queued once more)
+// EstimateWithRelativePose (two_view_geometry.cc:232-290) leaves k_verify_final as a job: the candidate poses of the pair
+// (the four (R, t) of DecomposeEssentialMatrix, or the solutions of the homography decomposition); k_final_pose checks
+// them, a wave per (pair, candidate); k_final_finish picks the winner.
+struct PoseJob {
+  int32_t ncmb;        // candidates (0: the pair has no pose step)
+  int32_t ni;          // inlier points (compacted to the front of the pair's pts_norm rows)
+  double Rc[4 * 9];
+  double tc[4 * 3];
+  int32_t cnt[4];      // k_final_pose: points in front of both cameras, per candidate
+  double med[4];       // k_final_pose: median triangulation angle of those points, per candidate
+};
 struct LoJob {
   uint32_t pl;          // pair (chunk-local)
   uint32_t ninl;        // inliers of the candidate model = size of the local estimator's input
@@ -135,7 +146,8 @@ struct VerifyParams {
   uint32_t* wm_redo;           // [n_pairs] pair indices
   uint32_t* wm_total;          // [n_pairs] their inlier counts (= the table they need)
   uint32_t* wm_count;
-  const uint32_t* final_list;  // != nullptr: k_verify_final processes pairs final_list[0 .. n_final)
+  const uint32_t* final_list;  // != nullptr: k_verify_final / k_final_pose / k_final_finish process pairs final_list[0 .. n_final)
+  PoseJob* pose_jobs;          // [n_pairs]
   uint32_t n_final;
   uint32_t max_trials[4];      // RANSAC ctor's max_num_trials per family (E, F, H, T)
   uint32_t first_batch[3];     // trials speculated in a pair's first round (<= batch; later rounds draw what the dynamic stop asks for, up to batch)

@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(64) void k_verify_prep(const VerifyParams p) {
 }
 
 template <int FAM>
-__global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : 4)) void k_ransac(const VerifyParams p) {
+__global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : (FAM == FAM_F ? 3 : 4))) void k_ransac(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   VSmem* sm = reinterpret_cast<VSmem*>(smem_raw);
   uint32_t* sidx = reinterpret_cast<uint32_t*>(smem_raw + ((sizeof(VSmem) + 15) / 16) * 16);
@@ -1085,9 +1085,7 @@ __global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p
   const WgScratch ws = wg_scratch(p);
   double* resid = ws.resid;
   int* inl = ws.inl;
-  double* ipts = ws.ipts;
   double* pts3d_a = ws.pts3d_a;
-  double* pts3d_b = ws.pts3d_b;
 
   __shared__ uint32_t s_next;
   WorkGrab wgrab;
@@ -1127,6 +1125,7 @@ __global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p
     uint32_t num_inliers = 0;
     bool have_mask = false;
     bool gen_loaded = false;
+    bool pose_pending = false;  // the pair has a pose job: k_final_pose / k_final_finish complete the record
 
     const bool calibrated = cam1.has_prior_focal_length && cam2.has_prior_focal_length;
     if ((uint64_t)n < o.min_num_inliers) {
@@ -1287,6 +1286,7 @@ __global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p
                 const uint32_t slot = atomicAdd(p.wm_count, 1u);
                 p.wm_redo[slot] = pi;
                 p.wm_total[slot] = (uint32_t)total;
+                p.pose_jobs[pi].ncmb = 0;  // nothing for k_final_pose / k_final_finish until the pair comes back
               }
               continue;
             }
@@ -1325,19 +1325,28 @@ __global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p
         }
       }
 
-      // EstimateWithRelativePose, two_view_geometry.cc:232-290 (skipped for DEGENERATE: SURVEY.md H8)
-      if (calibrated && have_mask && config != DSM_CONFIG_DEGENERATE && config != DSM_CONFIG_UNDEFINED) {
+      // EstimateWithRelativePose, two_view_geometry.cc:232-290 (skipped for DEGENERATE: SURVEY.md H8, and for a pair the
+      // stage's post-filter is about to discard).  Here only the candidate poses; checking them (triangulating every
+      // inlier per candidate) is k_final_pose's work, at an occupancy this kernel cannot have.
+      if (calibrated && have_mask && config != DSM_CONFIG_DEGENERATE && config != DSM_CONFIG_UNDEFINED &&
+          !(p.stage_filter && (uint64_t)num_inliers < o.min_num_inliers)) {
         const int ni = (int)num_inliers;
-        for (int j = lane; j < ni; j += 64) {  // inlier_points{1,2}_N, in inlier order
-          const double* q = pts_norm + 4 * (size_t)inl[j];
-          ipts[4 * j + 0] = q[0]; ipts[4 * j + 1] = q[1]; ipts[4 * j + 2] = q[2]; ipts[4 * j + 3] = q[3];
+        // inlier_points{1,2}_N, in inlier order: compacted to the front of the pair's own pts_norm rows (inl[j] >= j,
+        // a chunk is read completely before it is written; nothing reads pts_norm after this kernel)
+        double* ipts_g = p.pts_norm + 4 * moff;
+        for (int b0 = 0; b0 < ni; b0 += 64) {
+          const int j = b0 + lane;
+          double q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+          if (j < ni) {
+            const double* q = pts_norm + 4 * (size_t)inl[j];
+            q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+          }
+          wv_sync();
+          if (j < ni) {
+            ipts_g[4 * j + 0] = q0; ipts_g[4 * j + 1] = q1; ipts_g[4 * j + 2] = q2; ipts_g[4 * j + 3] = q3;
+          }
+          wv_sync();
         }
-        wv_sync();
-        double Rbest[9];
-        for (int k = 0; k < 9; ++k) Rbest[k] = 0.0;
-        int nbest = 0;
-        double* pbest = pts3d_a;
-        double* pcur = pts3d_b;
         double Rc[4 * 9], tc[4 * 3];
         int ncmb;
         if (config == DSM_CONFIG_CALIBRATED || config == DSM_CONFIG_UNCALIBRATED) {
@@ -1375,7 +1384,6 @@ __global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p
             tc[1 * 3 + k] = t0[k];
             tc[2 * 3 + k] = -t0[k];
             tc[3 * 3 + k] = -t0[k];
-            tvec[k] = t0[k];
           }
           ncmb = 4;
         } else {
@@ -1385,82 +1393,17 @@ __global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p
           calibration_matrix(cam2, K2);
           ncmb = decompose_homography(Hm, K1, K2, Rc, tc);
         }
-        for (int c = 0; c < ncmb; ++c) {
-          const int cnt = check_cheirality(Rc + c * 9, tc + c * 3, ipts, ni, pcur, lane);
-          if (cnt >= nbest) {
-            for (int k = 0; k < 9; ++k) Rbest[k] = Rc[c * 9 + k];
-            for (int k = 0; k < 3; ++k) tvec[k] = tc[c * 3 + k];
-            nbest = cnt;
-            double* tsw = pbest;
-            pbest = pcur;
-            pcur = tsw;
-          }
+        if (lane == 0) {
+          PoseJob* job = p.pose_jobs + pi;
+          job->ncmb = ncmb;
+          job->ni = ni;
+          for (int k = 0; k < 36; ++k) job->Rc[k] = Rc[k];
+          for (int k = 0; k < 12; ++k) job->tc[k] = tc[k];
         }
-        rotation_to_quaternion(Rbest, qvec);
-        if (nbest == 0) {
-          tri_angle = 0;
-        } else {
-          // Median(CalculateTriangulationAnglesWithPM), triangulation.cc:183-218, math.h:211-229
-          double c2[3];
-          for (int i = 0; i < 3; ++i) c2[i] = -(Rbest[0 * 3 + i] * tvec[0] + Rbest[1 * 3 + i] * tvec[1] + Rbest[2 * 3 + i] * tvec[2]);
-          const double c1[3] = {-(1.0 * 0.0 + 0.0 * 0.0 + 0.0 * 0.0), -(0.0 * 0.0 + 1.0 * 0.0 + 0.0 * 0.0), -(0.0 * 0.0 + 0.0 * 0.0 + 1.0 * 0.0)};
-          double baseline2 = 0;
-          for (int i = 0; i < 3; ++i) baseline2 += (c1[i] - c2[i]) * (c1[i] - c2[i]);
-          double* ang = resid;
-          for (int j = lane; j < nbest; j += 64) {
-            const double* X = pbest + 3 * (size_t)j;
-            double r1 = 0, r2 = 0;
-            for (int k = 0; k < 3; ++k) {
-              r1 += (X[k] - c1[k]) * (X[k] - c1[k]);
-              r2 += (X[k] - c2[k]) * (X[k] - c2[k]);
-            }
-            const double ray1 = sqrt(r1), ray2 = sqrt(r2);
-            const double angle = fabs(acos((ray1 * ray1 + ray2 * ray2 - baseline2) / (2 * ray1 * ray2)));
-            ang[j] = isnan(angle) ? 0.0 : (angle < M_PI - angle ? angle : M_PI - angle);
-          }
-          wv_sync();
-          // median by rank counting: element of rank mid (and mid-1 for even sizes)
-          const int mid = nbest / 2;
-          double lo_v = 0.0, hi_v = 0.0;
-          int have = 0;
-          for (int b0 = 0; b0 < nbest; b0 += 64) {
-            const int j = b0 + lane;
-            bool is_mid = false, is_lo = false;
-            double a = 0.0;
-            if (j < nbest) {
-              a = ang[j];
-              int rank = 0;
-              for (int k = 0; k < nbest; ++k) {
-                const double b = ang[k];
-                rank += (b < a) || (b == a && k < j);
-              }
-              is_mid = rank == mid;
-              is_lo = rank == mid - 1;
-            }
-            const unsigned long long bm = __ballot(is_mid), bl = __ballot(is_lo);
-            if (bm) {
-              hi_v = __shfl(a, __ffsll((long long)bm) - 1);
-              have |= 1;
-            }
-            if (bl) {
-              lo_v = __shfl(a, __ffsll((long long)bl) - 1);
-              have |= 2;
-            }
-          }
-          tri_angle = (nbest % 2 == 0) ? (hi_v + lo_v) / 2.0 : hi_v;
-          (void)have;
-        }
-        if (config == DSM_CONFIG_PLANAR_OR_PANORAMIC) {
-          const double tn = sqrt(tvec[0] * tvec[0] + tvec[1] * tvec[1] + tvec[2] * tvec[2]);
-          if (tn == 0) {
-            config = DSM_CONFIG_PANORAMIC;
-            tri_angle = 0;
-          } else {
-            config = DSM_CONFIG_PLANAR;
-          }
-        }
+        pose_pending = true;
       }
     }
+    if (!pose_pending && lane == 0) p.pose_jobs[pi].ncmb = 0;
 
     if (p.keep_generator && gen_loaded) {  // EstimateMultiple: the next pass continues this stream
       wv_sync();
@@ -1497,9 +1440,134 @@ __global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p
   }
 }
 
+#ifndef K_FINAL_POSE_WAVES
+#define K_FINAL_POSE_WAVES 3
+#endif
+// EstimateWithRelativePose, the part that costs: for every candidate pose CheckCheirality (pose.cc:225-247) --
+// every inlier triangulated, a 4 x 4 SVD per point -- and, of the points in front of both cameras, the median
+// triangulation angle (triangulation.cc:183-218, math.h:211-229).  A wave per (pair, candidate) at three waves per SIMD;
+// inside k_verify_final (one wave per SIMD, 512 VGPRs of decision tree around it) the same loops ran latency-bound.
+// The median is computed for every candidate although only the winner's is used: it is cheap next to the SVDs and
+// saves a second pass over the winner's points.
+__global__ __launch_bounds__(64, K_FINAL_POSE_WAVES) void k_final_pose(const VerifyParams p) {
+  const int lane = threadIdx.x;
+  const WgScratch ws = wg_scratch(p);
+  double* pts3d = ws.pts3d_a;
+  // the angles of a candidate's points: read cnt times each by the rank counting below -- from LDS when they fit
+  // (a broadcast ds_read instead of a global load per comparison), from the work area otherwise
+  constexpr int kAngLds = 1024;
+  __shared__ double s_ang[kAngLds];
+  const uint32_t n_items = (p.final_list ? p.n_final : p.n_chunk) * 4u;
+  for (uint32_t idx = blockIdx.x; idx < n_items; idx += gridDim.x) {
+    const uint32_t pi = p.final_list ? p.final_list[idx >> 2] : p.pair0 + (idx >> 2);
+    const int c = (int)(idx & 3u);
+    PoseJob* job = p.pose_jobs + pi;
+    if (c >= job->ncmb) continue;
+    wv_sync();
+    const uint64_t moff = p.match_off[pi];
+    const double* ipts = p.pts_norm + 4 * moff;
+    double R[9], t[3];
+    for (int k = 0; k < 9; ++k) R[k] = job->Rc[c * 9 + k];
+    for (int k = 0; k < 3; ++k) t[k] = job->tc[c * 3 + k];
+    const int cnt = check_cheirality(R, t, ipts, job->ni, pts3d, lane);
+    double med = 0.0;
+    if (cnt > 0) {
+      // Median(CalculateTriangulationAnglesWithPM), triangulation.cc:183-218, math.h:211-229
+      double c2[3];
+      for (int i = 0; i < 3; ++i) c2[i] = -(R[0 * 3 + i] * t[0] + R[1 * 3 + i] * t[1] + R[2 * 3 + i] * t[2]);
+      const double c1[3] = {-(1.0 * 0.0 + 0.0 * 0.0 + 0.0 * 0.0), -(0.0 * 0.0 + 1.0 * 0.0 + 0.0 * 0.0), -(0.0 * 0.0 + 0.0 * 0.0 + 1.0 * 0.0)};
+      double baseline2 = 0;
+      for (int i = 0; i < 3; ++i) baseline2 += (c1[i] - c2[i]) * (c1[i] - c2[i]);
+      // (two instantiations, not a selected pointer: that would compile to flat loads)
+      auto median_of_angles = [&](double* ang) {
+        for (int j = lane; j < cnt; j += 64) {
+          const double* X = pts3d + 3 * (size_t)j;
+          double r1 = 0, r2 = 0;
+          for (int k = 0; k < 3; ++k) {
+            r1 += (X[k] - c1[k]) * (X[k] - c1[k]);
+            r2 += (X[k] - c2[k]) * (X[k] - c2[k]);
+          }
+          const double ray1 = sqrt(r1), ray2 = sqrt(r2);
+          const double angle = fabs(acos((ray1 * ray1 + ray2 * ray2 - baseline2) / (2 * ray1 * ray2)));
+          ang[j] = isnan(angle) ? 0.0 : (angle < M_PI - angle ? angle : M_PI - angle);
+        }
+        wv_sync();
+        // median by rank counting: element of rank mid (and mid-1 for even sizes)
+        const int mid = cnt / 2;
+        double lo_v = 0.0, hi_v = 0.0;
+        for (int b0 = 0; b0 < cnt; b0 += 64) {
+          const int j = b0 + lane;
+          bool is_mid = false, is_lo = false;
+          double a = 0.0;
+          if (j < cnt) {
+            a = ang[j];
+            int rank = 0;
+            for (int k = 0; k < cnt; ++k) {
+              const double b = ang[k];
+              rank += (b < a) || (b == a && k < j);
+            }
+            is_mid = rank == mid;
+            is_lo = rank == mid - 1;
+          }
+          const unsigned long long bm = __ballot(is_mid), bl = __ballot(is_lo);
+          if (bm) hi_v = __shfl(a, __ffsll((long long)bm) - 1);
+          if (bl) lo_v = __shfl(a, __ffsll((long long)bl) - 1);
+        }
+        return (cnt % 2 == 0) ? (hi_v + lo_v) / 2.0 : hi_v;
+      };
+      med = cnt <= kAngLds ? median_of_angles(s_ang) : median_of_angles(ws.resid);
+    }
+    if (lane == 0) {
+      job->cnt[c] = cnt;
+      job->med[c] = med;
+    }
+  }
+}
+
+// The winner among the candidates (pose.cc:80-105: the last one with the most points in front of both cameras),
+// its quaternion, the median angle, PLANAR vs PANORAMIC (two_view_geometry.cc:266-279).  A lane per pair.
+__global__ __launch_bounds__(64) void k_final_finish(const VerifyParams p) {
+  const uint32_t n_items = p.final_list ? p.n_final : p.n_chunk;
+  const uint32_t idx = blockIdx.x * 64u + threadIdx.x;
+  if (idx >= n_items) return;
+  const uint32_t pi = p.final_list ? p.final_list[idx] : p.pair0 + idx;
+  const PoseJob* job = p.pose_jobs + pi;
+  if (job->ncmb <= 0) return;
+  dsm_two_view_geometry* out = p.tvg + pi;
+  double Rbest[9], tvec[3] = {0, 0, 0};
+  for (int k = 0; k < 9; ++k) Rbest[k] = 0.0;
+  int nbest = 0, cbest = -1;
+  for (int c = 0; c < job->ncmb; ++c) {
+    if (job->cnt[c] >= nbest) {
+      for (int k = 0; k < 9; ++k) Rbest[k] = job->Rc[c * 9 + k];
+      for (int k = 0; k < 3; ++k) tvec[k] = job->tc[c * 3 + k];
+      nbest = job->cnt[c];
+      cbest = c;
+    }
+  }
+  double qvec[4];
+  rotation_to_quaternion(Rbest, qvec);
+  double tri_angle = (nbest == 0 || cbest < 0) ? 0.0 : job->med[cbest];
+  int config = out->config;
+  if (config == DSM_CONFIG_PLANAR_OR_PANORAMIC) {
+    const double tn = sqrt(tvec[0] * tvec[0] + tvec[1] * tvec[1] + tvec[2] * tvec[2]);
+    if (tn == 0) {
+      config = DSM_CONFIG_PANORAMIC;
+      tri_angle = 0;
+    } else {
+      config = DSM_CONFIG_PLANAR;
+    }
+  }
+  out->config = config;
+  for (int k = 0; k < 4; ++k) out->qvec[k] = qvec[k];
+  for (int k = 0; k < 3; ++k) out->tvec[k] = tvec[k];
+  out->tri_angle = tri_angle;
+}
+
 size_t verify_scratch_bytes_per_block(uint32_t n_max) { return verify_scratch_doubles(n_max) * sizeof(double); }
 size_t verify_smem_bytes(uint32_t n_max) { return ((sizeof(VSmem) + 15) / 16) * 16 + (size_t)(n_max > 0 ? n_max : 1) * 4; }
 
+static void launch_final_pose_finish(const VerifyParams& p, uint32_t n_blocks, hipStream_t st);
 void launch_verify(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
   if (p.n_pairs == 0 || n_blocks == 0) return;
   const size_t smem = verify_smem_bytes(p.n_max);
@@ -1508,6 +1576,7 @@ void launch_verify(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
   hipLaunchKernelGGL(k_ransac<FAM_F>, dim3(n_blocks), dim3(64), smem, st, p);
   hipLaunchKernelGGL(k_ransac<FAM_H>, dim3(n_blocks), dim3(64), smem, st, p);
   hipLaunchKernelGGL(k_verify_final<2>, dim3(n_blocks), dim3(64), smem, st, p);
+  launch_final_pose_finish(p, n_blocks, st);
 }
 
 // ------------------------------------------------------------------------------------ phase-split pipeline
@@ -1662,7 +1731,6 @@ __global__ __launch_bounds__(64, 8) void k_score(const VerifyParams p) {
     for (int e = lane; e < 4 * n; e += 64) spts[e] = gpts[e];
     __syncthreads();
   }
-  const double* pts = in_lds ? spts : gpts;
   const double max_residual = p.opt.max_error * p.opt.max_error;
   if (t >= nb || m >= p.nmodels[(size_t)pl * p.batch + t]) return;
   const double* gm = p.models + ((size_t)pl * p.batch + t) * F::MAXM * 9 + m * 9;
@@ -1670,13 +1738,27 @@ __global__ __launch_bounds__(64, 8) void k_score(const VerifyParams p) {
   for (int k = 0; k < 9; ++k) M[k] = gm[k];
   // InlierSupportMeasurer::Evaluate (support_measurement.cc:43-48): the lane walks the correspondences in index
   // order, so its running sum IS the in-order residual_sum that decides ties between equal inlier counts
+  // (two loops, not one over a selected pointer: a pointer that may be LDS or global compiles to flat loads with a
+  // full wait per point; apart, the staged points are ds_read_b128 broadcasts and the loop is unrolled over four points)
   int cnt = 0;
   double sum = 0;
-  for (int i = 0; i < n; ++i) {
-    const double r = fam_residual<FAM>(M, pts + (size_t)i * 4);
-    if (r <= max_residual) {
-      cnt += 1;
-      sum += r;
+  if (in_lds) {
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) {
+      const double r = fam_residual<FAM>(M, spts + (size_t)i * 4);
+      if (r <= max_residual) {
+        cnt += 1;
+        sum += r;
+      }
+    }
+  } else {
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) {
+      const double r = fam_residual<FAM>(M, gpts + (size_t)i * 4);
+      if (r <= max_residual) {
+        cnt += 1;
+        sum += r;
+      }
     }
   }
   p.counts[((size_t)pl * p.batch + t) * F::MAXM + m] = cnt;
@@ -1903,7 +1985,6 @@ __global__ __launch_bounds__(64, 8) void k_models_score_e(const VerifyParams p) 
   const bool in_lds = n <= VP_LDS_PTS;
   if (in_lds)
     for (int e = lane; e < 4 * n; e += 64) spts[e] = gpts[e];
-  const double* pts = in_lds ? spts : gpts;
   const dsm_camera& cam1 = p.cams[p.pairs[2 * pi]];
   const dsm_camera& cam2 = p.cams[p.pairs[2 * pi + 1]];
   const double max_error =
@@ -1922,7 +2003,11 @@ __global__ __launch_bounds__(64, 8) void k_models_score_e(const VerifyParams p) 
       double M[9];
       for (int k = 0; k < 9; ++k) M[k] = Mg[k];
       int cnt = 0;
-      for (int i = lane; i < n; i += 64) cnt += (fam_residual<FAM_E>(M, pts + (size_t)i * 4) <= max_residual) ? 1 : 0;
+      if (in_lds) {  // (apart: a pointer that may be LDS or global compiles to flat loads)
+        for (int i = lane; i < n; i += 64) cnt += (fam_residual<FAM_E>(M, spts + (size_t)i * 4) <= max_residual) ? 1 : 0;
+      } else {
+        for (int i = lane; i < n; i += 64) cnt += (fam_residual<FAM_E>(M, gpts + (size_t)i * 4) <= max_residual) ? 1 : 0;
+      }
       for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
       if (lane == 0) counts[tt * 10 + m] = cnt;
     }
@@ -3252,6 +3337,13 @@ void launch_vp_replay(const VerifyParams& p, int fam, uint32_t n_blocks, hipStre
   if (fam == FAM_F) hipLaunchKernelGGL(k_replay<FAM_F>, dim3(n_blocks), dim3(64), smem, st, p);
   if (fam == FAM_H) hipLaunchKernelGGL(k_replay<FAM_H>, dim3(n_blocks), dim3(64), smem, st, p);
 }
+static void launch_final_pose_finish(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
+  const uint32_t n = p.final_list ? p.n_final : p.n_chunk;
+  if (!n) return;
+  const uint32_t items = n * 4u;
+  hipLaunchKernelGGL(k_final_pose, dim3(items < n_blocks ? items : n_blocks), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(k_final_finish, dim3((n + 63) / 64), dim3(64), 0, st, p);
+}
 void launch_vp_final(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
   if (!p.n_pairs || !n_blocks) return;
   const char* fw = getenv("DSM_FINAL_WAVES");
@@ -3259,6 +3351,7 @@ void launch_vp_final(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_verify_final<2>, dim3(n_blocks), dim3(64), verify_smem_bytes(p.n_max), st, p);
   else
     hipLaunchKernelGGL(k_verify_final<1>, dim3(n_blocks), dim3(64), verify_smem_bytes(p.n_max), st, p);
+  launch_final_pose_finish(p, n_blocks, st);
 }
 
 void debug_read_prof(unsigned long long* out16) {
