@@ -958,6 +958,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     for (int f = 0; f < 3; ++f) {
       plan.batch[f] = vp_batch(f, vp.max_trials[f], (uint32_t)std::min<uint64_t>(o->min_num_trials, 0xffffffffull));
       vp.first_batch[f] = plan.batch[f];
+      // (measured, round 3: smaller first rounds cost more in extra rounds than they save in unused hypotheses -- E 56 / 48 / 32: +10 / +19 / +24 ms, F 96: +5 ms)
     }
     auto per_pair_bytes = [&](const uint32_t* b, uint32_t* bmax_out, uint64_t* bm_out) {
       uint32_t bmax = 0;
