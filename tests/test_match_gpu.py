@@ -272,3 +272,46 @@ def test_append_images_equals_one_upload(oracle):
     # keypoints / cameras must come with the appended images iff the resident ones have them
     with pytest.raises(capi.DsmError):
         parts.append_images([ims[0][0]])
+
+
+@pytest.mark.parametrize("cross", [0, 1])
+def test_second_best_in_the_same_column_set_as_the_best(dsm, oracle, cross):
+    """Round 3's K1 keeps the top-2 of the TILE MAXIMA of a lane's 16-column sets: `second` misses the second largest value
+    inside the set that holds the best, and K1b adds it before the ratio test.  Rows whose runner-up sits (a) in the very
+    set of the best column, (b) in the other half-wave's set of the same 32-column tile, (c) in another tile -- close
+    enough to the best that the ratio test REJECTS the row only if the true second best is used; plus exact duplicates
+    of the best in the same set (a duplicate is the second best, sift.cc:126-132) and runner-ups at LOWER columns."""
+    rng = np.random.default_rng(42)
+    n1, n2 = 96, 700
+    d1 = rand_sift(rng, n1)
+    d2 = rand_sift(rng, n2)
+
+    def near(x, k):   # k bytes nudged by one: a neighbour at a small, growing distance
+        y = x.astype(np.int32).copy()
+        idx = rng.choice(128, k, replace=False)
+        y[idx] += np.where(y[idx] < 200, 1, -1)
+        return np.clip(y, 0, 255).astype(np.uint8)
+    # column sets of a tile: half h holds columns 8q + 4h + e (q, e = 0..3)
+    same_set = lambda c: (c & ~31) + 8 * ((((c & 31) >> 3) + 1) % 4) + (c & 7)          # another q, same half, same e
+    other_half = lambda c: c ^ 4
+    cases = []
+    for r in range(0, 90, 3):
+        c0 = int(rng.integers(0, n2 - 64))
+        kind = r // 3 % 5
+        c1 = {0: same_set(c0), 1: other_half(c0), 2: (c0 + 64) % n2, 3: same_set(c0), 4: other_half(c0)}[kind]
+        if kind >= 3 and c1 > c0:
+            c0, c1 = c1, c0                                   # runner-up (or duplicate) at the LOWER column
+        d2[c0] = near(d1[r], 6)
+        d2[c1] = d2[c0] if kind == 3 else near(d1[r], 9)      # kind 3: an exact duplicate of the best
+        cases.append((r, c0, c1, kind))
+    for ratio, dist in [(0.8, 0.7), (0.95, 0.7), (0.6, 1.0)]:
+        o = capi.default_match_options(max_ratio=ratio, max_distance=dist, cross_check=cross)
+        ref = oracle.match_sift_features_cpu(d1, d2, ratio, dist, bool(cross))
+        check_equal(dsm.match_sift_features(d1, d2, o), ref)
+        # and the other direction (the planted columns are rows of image a there)
+        check_equal(dsm.match_sift_features(d2, d1, o), oracle.match_sift_features_cpu(d2, d1, ratio, dist, bool(cross)))
+    # the construction does what it says: with the default ratio most planted rows are rejected although their best
+    # column is an almost exact copy
+    ref = oracle.match_sift_features_cpu(d1, d2, 0.8, 0.7, False)
+    planted = {r for r, _, _, _ in cases}
+    assert len(planted - set(ref[:, 0].tolist())) >= 20
