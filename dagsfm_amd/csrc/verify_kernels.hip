@@ -151,6 +151,7 @@ DSM_DEV void mt_skip_wave(MtState* s, uint32_t target, int lane) {
 struct WvSampler {
   uint32_t raw[640];  // tempered outputs not yet consumed (<= 6 left over + one regenerated block)
   uint32_t jb[640];   // swap partners of the draws of one block
+  uint64_t plain[10];  // per 64 trials of the block: the trials whose swaps are independent of each other
 };
 
 // RandomSampler::Sample x nb (src/optim/random_sampler.cc:43-62) for K-element samples out of n, by the wave:
@@ -203,66 +204,75 @@ DSM_DEV void wv_draw_samples(MtState* gen, WvSampler* ws, uint32_t* sidx, uint32
       serial = true;
       break;
     }
-    if (lane == 0) {
-      // The first K_ entries of the index array are touched by every trial: they live in registers (h[]) for the
-      // block.  A trial's K_ partner reads are independent unless two draws name the same partner or a partner lies
-      // inside the head; those (rare) trials take the one-swap-at-a-time form.  Either way the state after the trial
-      // is that of K_ sequential swaps.
-      uint32_t h[K_], jn[K_];
+    // Which trials are "plain" -- every partner outside the head (j >= K_) and no partner named twice -- depends on the
+    // draws alone, not on the index array: decided for the whole block by a lane per trial, as ballot masks.  The
+    // generator position after each trial goes out on the same occasion.
+    for (int c = 0; c < nt; c += 64) {
+      const int tt = c + lane;
+      bool plain = false;
+      if (tt < nt) {
+        uint32_t j[K_];
 #pragma unroll
-      for (int i = 0; i < K_; ++i) h[i] = sidx[i];
+        for (int i = 0; i < K_; ++i) j[i] = ws->jb[tt * K_ + i];
+        plain = true;
 #pragma unroll
-      for (int i = 0; i < K_; ++i) jn[i] = ws->jb[i];
-      for (int tt = 0; tt < nt; ++tt) {
-        uint32_t j[K_], v[K_];
-        bool plain = true;
-#pragma unroll
-        for (int i = 0; i < K_; ++i) {
-          j[i] = jn[i];
-          plain = plain && j[i] >= (uint32_t)K_;
-        }
-#pragma unroll
-        for (int i = 0; i < K_; ++i) v[i] = sidx[j[i]];  // j < n always; a value read here is only used if plain
-        if (tt + 1 < nt) {
-#pragma unroll
-          for (int i = 0; i < K_; ++i) jn[i] = ws->jb[(tt + 1) * K_ + i];
-        }
+        for (int i = 0; i < K_; ++i) plain = plain && j[i] >= (uint32_t)K_;
 #pragma unroll
         for (int i = 1; i < K_; ++i) {
 #pragma unroll
           for (int i2 = 0; i2 < i; ++i2) plain = plain && j[i] != j[i2];
         }
-        if (plain) {
-#pragma unroll
-          for (int i = 0; i < K_; ++i) {
-            sidx[j[i]] = h[i];
-            h[i] = v[i];
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < K_; ++i) {
-            if (j[i] >= (uint32_t)K_) {
-              const uint32_t a = h[i];
-              h[i] = sidx[j[i]];
-              sidx[j[i]] = a;
-            } else {
-#pragma unroll
-              for (int jj = i + 1; jj < K_; ++jj) {  // j >= i by construction; j == i is a swap with itself
-                if (j[i] == (uint32_t)jj) {
-                  const uint32_t a = h[i];
-                  h[i] = h[jj];
-                  h[jj] = a;
-                }
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < K_; ++i) smp[(size_t)(t + tt) * 7 + i] = h[i];
         if (de) de[t + tt] = calls + (uint32_t)(tt + 1) * K_;
       }
+      const uint64_t m = __ballot(plain);
+      if (lane == 0) ws->plain[c >> 6] = m;
+    }
+    wv_sync();
+    // The swaps are a sequential chain through the index array, but only from trial to trial: the K_ swaps of a plain
+    // trial are independent, so lane i makes draw i -- one partner read, one write of the head entry it replaces, the
+    // head entry itself in a register (h).  A trial then costs one LDS round trip instead of K_ times the single lane's
+    // instruction stream (measured, lane 0 alone: ~1 200 cycles per 7-point trial).  The LDS queue of a wave is in
+    // order, so the next trial's read sees this trial's write.  A trial that is not plain (a few per cent: ~K_^2 / n)
+    // takes the one-swap-at-a-time form on lane 0 with the head back in the array.  Either way the state after the
+    // trial is that of K_ sequential swaps.
+    {
+      const bool mine = lane < K_;
+      uint32_t h = mine ? sidx[lane] : 0u;
+      uint32_t jn = mine ? ws->jb[lane] : 0u;
+      for (int c = 0; c < nt; c += 64) {
+        const uint64_t pm = ws->plain[c >> 6];
+        const uint32_t pm_lo = __builtin_amdgcn_readfirstlane((uint32_t)pm), pm_hi = __builtin_amdgcn_readfirstlane((uint32_t)(pm >> 32));
+        const int lim = nt - c < 64 ? nt - c : 64;
+        for (int u = 0; u < lim; ++u) {
+          const int tt = c + u;
+          const uint32_t j = jn;
+          if (mine && tt + 1 < nt) jn = ws->jb[(tt + 1) * K_ + lane];
+          const bool plain = (((u < 32) ? (pm_lo >> u) : (pm_hi >> (u - 32))) & 1u) != 0u;
+          if (plain) {
+            if (mine) {
+              const uint32_t v = sidx[j];
+              sidx[j] = h;
+              h = v;
+            }
+          } else {
+            if (mine) sidx[lane] = h;
+            wv_sync();
+            if (lane == 0) {
 #pragma unroll
-      for (int i = 0; i < K_; ++i) sidx[i] = h[i];
+              for (int i = 0; i < K_; ++i) {
+                const uint32_t ji = ws->jb[tt * K_ + i];
+                const uint32_t a = sidx[i];
+                sidx[i] = sidx[ji];
+                sidx[ji] = a;
+              }
+            }
+            wv_sync();
+            if (mine) h = sidx[lane];
+          }
+          if (mine) smp[(size_t)(t + tt) * 7 + lane] = h;
+        }
+      }
+      if (mine) sidx[lane] = h;
     }
     pos += nd;
     have -= nd;
