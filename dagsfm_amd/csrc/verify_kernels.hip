@@ -1028,6 +1028,10 @@ __global__ __launch_bounds__(64) void k_verify_prep(const VerifyParams p) {
       fs.nb = 0;
       fs.t_pos = fs.m_pos = fs.lo_wait = fs.lo_ninl = fs.lo_nm = fs.pad = 0;
       p.fam_state[(size_t)pi * 3 + lane] = fs;
+      // a family that never runs (fewer matches than its minimal sample, E without prior focal lengths) must still
+      // hand k_verify_final the report LORANSAC::Estimate returns at once (loransac.h:97-103), not what an earlier call
+      // left in this pair's slot
+      p.reports[(size_t)pi * 3 + lane] = fs.rep;
     }
     wv_sync();
   }
@@ -1165,6 +1169,9 @@ __global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p
       ntr[2] = H_rep.num_trials;
       nmo[2] = H_rep.num_models;
       // the generator continues where the H family stopped (watermark RANSAC, :547-549)
+      // (generator_load consumes the "resume from the snapshot" mark an early stop of the H family leaves; a pair that is
+      // parked below for its translation table comes through here a second time and must find the mark again)
+      const uint32_t snap_mark = p.pair_state[(size_t)pi * PAIR_STATE_WORDS + PS_USE_SNAP];
       generator_load(&sm->gen, p.pair_state + (size_t)pi * PAIR_STATE_WORDS, lane);
       gen_loaded = true;
 
@@ -1297,6 +1304,7 @@ __global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p
                 p.wm_redo[slot] = pi;
                 p.wm_total[slot] = (uint32_t)total;
                 p.pose_jobs[pi].ncmb = 0;  // nothing for k_final_pose / k_final_finish until the pair comes back
+                p.pair_state[(size_t)pi * PAIR_STATE_WORDS + PS_USE_SNAP] = snap_mark;
               }
               continue;
             }
@@ -3467,8 +3475,16 @@ __global__ __launch_bounds__(64) void k_multi_accumulate(const MultiParams p) {
       cnt += (uint32_t)__popcll(__ballot(keep));
     }
     if (lane == 0) {
-      p.next_count[pi] = cnt;
-      atomicAdd(p.active, 1u);
+      if (cnt == (uint32_t)n) {
+        // not DEGENERATE, yet no match removed (min_num_inliers = 0, F failed, H succeeded, inliers from F's empty
+        // mask): the reference would repeat the pass on the same matches indefinitely; the pair ends here, like in the
+        // oracle (oracle/two_view.cc, EstimateMultiple)
+        ms->done = 1;
+        p.next_count[pi] = 0;
+      } else {
+        p.next_count[pi] = cnt;
+        atomicAdd(p.active, 1u);
+      }
     }
   }
 }

@@ -1428,7 +1428,12 @@ void oracle_estimate_two_view_geometry(const dsm_camera* camera1, const double* 
           next.push_back(remaining[i]);
           next.push_back(remaining[i + 1]);
         }
+      // A pass that is not DEGENERATE yet removes no match (reachable with min_num_inliers = 0: F fails on fewer than
+      // 7 matches, H succeeds, the inlier list comes from F's empty mask) would be repeated on the same matches for as
+      // long as the PRNG keeps H succeeding -- in practice forever.  Oracle and product both stop after recording it.
+      const bool no_progress = next.size() == remaining.size();
       remaining.swap(next);
+      if (no_progress) break;
     }
     if (found.empty()) {
       tv.config = DSM_CONFIG_DEGENERATE;

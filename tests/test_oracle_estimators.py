@@ -290,3 +290,19 @@ def test_estimate_multiple_two_motions(oracle):
     # both structures contribute
     first = inl[:, 0] < len(a1)
     assert first.sum() >= 15 and (~first).sum() >= 15
+
+
+def test_estimate_multiple_ends_when_a_pass_removes_nothing(oracle):
+    """min_num_inliers = 0 and fewer than 7 matches: F fails, H succeeds, the inlier list (taken from F's empty mask) is
+    empty -- a pass that is not DEGENERATE and removes no match.  The reference's loop (two_view_geometry.cc:128-167)
+    would repeat it; the oracle (and the product, tests/test_verify_gpu.py) record the geometry once and stop."""
+    from dagsfm_amd import capi
+    rng = np.random.default_rng(5)
+    camu = capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, False)
+    opts = capi.default_two_view_options(min_num_inliers=0, multiple_models=1, multiple_ignore_watermark=0)
+    p1 = rng.uniform(100, 900, (5, 2))
+    p2 = p1 * 1.01 + np.array([4.0, -2.0])
+    m = np.stack([np.arange(5), np.arange(5)], axis=1).astype(np.uint32)
+    ref, inl = oracle.estimate_two_view_geometry(camu, p1, camu, p2, m, opts, 3)
+    assert ref.config == 6 and ref.num_inliers == 0 and len(inl) == 0
+    assert ref.num_trials[2] > 0 and ref.num_trials[1] == 0
