@@ -982,7 +982,19 @@ __global__ __launch_bounds__(64) void k_verify_prep(const VerifyParams p) {
     const uint32_t im1 = p.pairs[2 * pi], im2 = p.pairs[2 * pi + 1];
     const uint64_t moff = p.match_off[pi];
     const int n = (int)(p.match_off[pi + 1] - moff);
-    if ((uint64_t)n < p.opt.min_num_inliers) continue;
+    if ((uint64_t)n < p.opt.min_num_inliers) {
+      // DEGENERATE at once (two_view_geometry.cc:298-301): no family runs.  Its states must say so -- the buffer may
+      // have just grown over memory that holds anything (found by tools/fuzz_stage.py: a pair list longer than any
+      // before it on the context, k_sample taking garbage for an active pair)
+      if (p.fam_state != nullptr && lane < 3) {
+        FamState fs;
+        memset(&fs, 0, sizeof(fs));
+        fs.rep.residual_sum = DBL_MAX;
+        p.fam_state[(size_t)pi * 3 + lane] = fs;
+        p.reports[(size_t)pi * 3 + lane] = fs.rep;
+      }
+      continue;
+    }
     const uint32_t* matches = p.matches + 2 * moff;
     const dsm_camera cam1 = p.cams[im1], cam2 = p.cams[im2];
     const bool calibrated = cam1.has_prior_focal_length && cam2.has_prior_focal_length;

@@ -460,3 +460,18 @@ def test_estimate_multiple_ends_when_a_pass_removes_nothing(dsm, oracle):
         tvg_equal(got, ref, ("no progress", n))
         assert (got_inl == ref_inl).all()
         assert ref.config != 1 and ref.num_inliers == 0
+
+
+def test_differential_fuzz_stage_calls(dsm):
+    """tools/fuzz_stage.py as a regression test: 30 small seeded scenes through set_images -> match_pairs -> verify_pairs
+    -> guided_match_pairs on ONE context, matches / records / guided inlier lists / post-filter against the oracle.
+    Seed 1 is the sequence that found (round 3) a hang: scene 11 is the first pair list longer than any before it, most
+    of its pairs have fewer matches than min_num_inliers, and k_verify_prep left the family states of such pairs
+    unwritten -- in the freshly grown buffer k_sample took whatever was there for an active pair."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_stage
+    msgs = []
+    total, bad, stats = fuzz_stage.run_fuzz(dsm, 30, 1, min(32, os.cpu_count() or 4), log=msgs.append)
+    assert bad == 0, "\n".join(msgs)
+    assert total > 200 and stats["guided"] > 30
