@@ -20,7 +20,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dagsfm_amd import capi, synthetic  # noqa: E402
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from fuzz_verify import CAMS, rec_diff  # noqa: E402
+from fuzz_verify import CAMS, poison_device_memory, rec_diff  # noqa: E402
 
 _O = None
 
@@ -48,7 +48,7 @@ def _oracle_pair(a):
     return m, bytes(ref), inl, g
 
 
-def run_fuzz(ctx, n_scenes, seed, workers, log=print):
+def run_fuzz(ctx, n_scenes, seed, workers, log=print, poison=False):
     bad = total = 0
     stats = dict(guided=0, kept=0)
     with Pool(workers, initializer=_init) as pool:
@@ -74,6 +74,8 @@ def run_fuzz(ctx, n_scenes, seed, workers, log=print):
                        min_inlier_ratio=float(rng.choice([0.1, 0.25])), detect_watermark=int(rng.random() < 0.8))
             guided = bool(rng.random() < 0.6)
             user_seed = int(rng.integers(0, 1000))
+            if poison and s % 4 == 0:
+                poison_device_memory(256)
             t0 = time.perf_counter()
             ctx.set_images([im[0] for im in ims], [im[1] for im in ims], [_cam(cs)] * n_img)
             mo = capi.default_match_options(**mkw)
@@ -130,9 +132,10 @@ def main():
     ap.add_argument("--scenes", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--workers", type=int, default=min(64, os.cpu_count() or 8))
+    ap.add_argument("--poison", action="store_true", help="fill freed device memory with 0xFF every fourth scene")
     args = ap.parse_args()
     ctx = capi.Context(0)
-    total, bad, stats = run_fuzz(ctx, args.scenes, args.seed, args.workers, log=lambda s: print(s, flush=True))
+    total, bad, stats = run_fuzz(ctx, args.scenes, args.seed, args.workers, log=lambda s: print(s, flush=True), poison=args.poison)
     print("FUZZ RESULT: %d pairs (%d kept, %d with a guided list), %d mismatches" % (total, stats["kept"], stats["guided"], bad))
     return 1 if bad else 0
 

@@ -179,8 +179,23 @@ def rec_diff(g, r):
     return None
 
 
-def run_fuzz(ctx, batches, pairs_per_batch, seed, workers, log=print, first_batch=0):
-    """Returns (pairs checked, mismatches, {config: count})."""
+def poison_device_memory(megabytes=768):
+    """Leaves 0xFF in device memory the allocator is about to hand out again: a second context uploads all-0xFF descriptors
+    and keypoints and is closed.  Buffers the product grows afterwards land (in practice) on these pages, so a kernel that
+    reads what it never wrote sees NaNs, huge counters and 'active' flags instead of the zeros of fresh pages."""
+    c = capi.Context(0)
+    rows = 1 << 16
+    n = max(1, megabytes * (1 << 20) // (rows * (128 + 8)))
+    d = np.full((rows, 128), 255, np.uint8)
+    k = np.full((rows, 2), np.float32(np.nan))
+    c.set_images([d] * n, [k] * n, [capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, True)] * n)
+    c.sync()
+    c.close()
+
+
+def run_fuzz(ctx, batches, pairs_per_batch, seed, workers, log=print, first_batch=0, grow=False, poison=False):
+    """Returns (pairs checked, mismatches, {config: count}).  grow: batch b has (b + 1) x pairs_per_batch pairs, so every
+    call outgrows the buffers of the one before; poison: poison_device_memory() before every call."""
     bad = 0
     total = 0
     configs = {}
@@ -189,7 +204,10 @@ def run_fuzz(ctx, batches, pairs_per_batch, seed, workers, log=print, first_batc
             rng = np.random.default_rng([seed, b])
             okw = make_options(rng, np.random.default_rng([seed, b, 7]))  # (second stream: fields added later leave the earlier draws alone)
             user_seed = int(rng.integers(0, 1000))
-            probs = pool.map(make_pair, [int(s) for s in rng.integers(0, 2**31, pairs_per_batch)], chunksize=16)
+            n_here = pairs_per_batch * (b - first_batch + 1) if grow else pairs_per_batch
+            probs = pool.map(make_pair, [int(s) for s in rng.integers(0, 2**31, n_here)], chunksize=16)
+            if poison:
+                poison_device_memory()
             descs, kps, cams, pairs, matches = [], [], [], [], []
             for k, (c1, c2, kp1, kp2, m, kind) in enumerate(probs):
                 for c, kp in ((c1, kp1), (c2, kp2)):
@@ -236,9 +254,12 @@ def main():
     ap.add_argument("--pairs", type=int, default=1500)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--workers", type=int, default=min(96, os.cpu_count() or 8))
+    ap.add_argument("--grow", action="store_true", help="batch b has (b + 1) x --pairs pairs")
+    ap.add_argument("--poison", action="store_true", help="fill freed device memory with 0xFF before every call")
     args = ap.parse_args()
     ctx = capi.Context(0)
-    total, bad, configs = run_fuzz(ctx, args.batches, args.pairs, args.seed, args.workers, log=lambda m: print(m, flush=True))
+    total, bad, configs = run_fuzz(ctx, args.batches, args.pairs, args.seed, args.workers, log=lambda m: print(m, flush=True),
+                                   grow=args.grow, poison=args.poison)
     print("configurations seen (oracle): %s" % dict(sorted(configs.items())))
     print("FUZZ RESULT: %d pairs, %d mismatches" % (total, bad))
     return 1 if bad else 0
