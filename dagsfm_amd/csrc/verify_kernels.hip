@@ -1097,11 +1097,10 @@ __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : (FAM == FAM_F ? 3 : 4))) vo
   }
 }
 
-// WAVES = waves per SIMD the register allocation aims at.  2 (256 VGPRs): 102 VGPRs spilled next to 80 spilled SGPRs -- the
-// pattern that broke k_replay_lo<TAIL>; 1 (512 VGPRs): nothing spilled.  The spill-free instance is the product path: on
-// its own it is slower (41 vs 29 ms per step on one lane) but with the two verification lanes overlapping the step time
-// is the same (418 vs 417 ms).  DSM_FINAL_WAVES=2 selects the other; tools/check_schedules.py compares the two on all
-// 124 750 pairs of config 2 (byte-identical).
+// WAVES = waves per SIMD the register allocation aims at.  Since the candidate poses moved out (k_final_pose), both
+// instances need 254 VGPRs; <2> spills 12 of them and runs two waves per SIMD, <1> spills none and runs one.  <2> is the
+// product path: verification of config 2 349 -> 341 ms (profiles/r03_check_schedules.txt); DSM_FINAL_WAVES=1 selects the
+// other, and tools/check_schedules.py compares the two on all 124 750 pairs of config 2 (byte-identical).
 template <int WAVES>
 __global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -3377,10 +3376,10 @@ static void launch_final_pose_finish(const VerifyParams& p, uint32_t n_blocks, h
 void launch_vp_final(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
   if (!p.n_pairs || !n_blocks) return;
   const char* fw = getenv("DSM_FINAL_WAVES");
-  if (fw && atoi(fw) == 2)
-    hipLaunchKernelGGL(k_verify_final<2>, dim3(n_blocks), dim3(64), verify_smem_bytes(p.n_max), st, p);
-  else
+  if (fw && atoi(fw) == 1)
     hipLaunchKernelGGL(k_verify_final<1>, dim3(n_blocks), dim3(64), verify_smem_bytes(p.n_max), st, p);
+  else
+    hipLaunchKernelGGL(k_verify_final<2>, dim3(n_blocks), dim3(64), verify_smem_bytes(p.n_max), st, p);
   launch_final_pose_finish(p, n_blocks, st);
 }
 

@@ -6,7 +6,7 @@ produce byte-identical TwoViewGeometry records and inlier matches on the whole w
   no_tail   the batched schedule without a tail: every local optimisation through the batched kernels (DSM_LO_TAIL=0)
   tail_inline  the tail of a round as round 2 ran it: inline in k_replay_lo<1>, F and H only (DSM_LO_TAIL_MODE=inline;
             the default since round 3 computes the tail's local optimisations as parallel items, k_tail_enum / k_tail_lo)
-  final_2waves  k_verify_final compiled for two waves per SIMD (register spills; DSM_FINAL_WAVES=2)
+  final_1wave   k_verify_final compiled for one wave per SIMD (no register spill; DSM_FINAL_WAVES=1)
   one_lane  the batched schedule on a single lane (DSM_VERIFY_LANES=1; the default deals the list out to two lanes)
   legacy    one k_ransac kernel per family, lane-0 sampler, per-lane scratch solvers (DSM_VERIFY_LEGACY=1; --legacy)
 This exercises the paths too rare for the oracle-sized tests (a Lemire rejection in the sampler happens for a few
@@ -32,8 +32,8 @@ def run(ctx, opts, schedule):
     if schedule == "tail_inline":
         os.environ["DSM_LO_TAIL_MODE"] = "inline"
     os.environ.pop("DSM_FINAL_WAVES", None)
-    if schedule == "final_2waves":
-        os.environ["DSM_FINAL_WAVES"] = "2"
+    if schedule == "final_1wave":
+        os.environ["DSM_FINAL_WAVES"] = "1"
     if schedule == "no_tail":
         os.environ["DSM_LO_TAIL"] = "0"
     if schedule == "one_lane":
@@ -66,7 +66,7 @@ def main():
     opts = capi.default_two_view_options()
     r0 = run(ctx, opts, "batched")
     ok = True
-    for name in ["one_lane", "no_tail", "tail_inline", "final_2waves", "inline"] + (["legacy"] if a.legacy else []):
+    for name in ["one_lane", "no_tail", "tail_inline", "final_1wave", "inline"] + (["legacy"] if a.legacy else []):
         r1 = run(ctx, opts, name)
         same = (r0[0] == r1[0]).all() and (r0[1] == r1[1]).all() and (r0[2] == r1[2]).all()
         # num_trials / num_models are the last 32 bytes of the record
