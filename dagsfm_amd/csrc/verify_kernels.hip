@@ -156,8 +156,8 @@ struct WvSampler {
 
 // RandomSampler::Sample x nb (src/optim/random_sampler.cc:43-62) for K-element samples out of n, by the wave:
 // draw d of a trial picks j = uniform_int_distribution(i, n-1) and swaps sidx[i] <-> sidx[j].  The generator
-// outputs of a whole block are tempered and mapped through Lemire's multiply-shift by all lanes; only the
-// swaps -- a true sequential chain through the index array -- are left to lane 0.  A draw that Lemire's
+// outputs of a whole block are tempered and mapped through Lemire's multiply-shift by all lanes; the swaps are a
+// sequential chain through the index array only from trial to trial, so lane i makes draw i of a trial (below).  A draw that Lemire's
 // method would reject (probability (2^32 mod range) / 2^32, ~6e-8 at 256 matches) shifts every later draw:
 // the first block that contains one, and everything after it, is replayed serially with the same
 // semantics as uniform_u32 above.  smp: [nb][7] samples; de (optional): generator calls after each trial.
@@ -1612,7 +1612,7 @@ void launch_verify(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
 // Same LO-RANSAC, different schedule: the sequential part of loransac.h:91-233 is only (a) drawing the
 // samples and (b) comparing supports in trial order; solving and scoring the speculated trials is flat
 // data-parallel work.  Per family and round:
-//   k_sample        wave per pair, lane 0 draws `batch` minimal samples (light kernel, high occupancy)
+//   k_sample        wave per pair: `batch` minimal samples, a lane per draw of a trial (light kernel, high occupancy)
 //   k_solve/k_score lane per hypothesis (per model) over ALL pairs x trials: minimal solve, inlier counts
 //   k_replay        wave per pair: scans the counts in trial order (ballot-skipping the trials that can change
 //                   nothing), re-scores candidates with the in-order residual_sum, runs the local

@@ -47,6 +47,9 @@ def rot(rng, mag):
     return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
 
 
+BIG = False  # --big: hundreds to thousands of matches per pair (many rounds, batch growth, points beyond the LDS staging)
+
+
 def make_pair(seed):
     """One problem: (cam1, cam2, kp1 float32 [n1,2], kp2, matches uint32 [m,2], kind)."""
     rng = np.random.default_rng(seed)
@@ -57,6 +60,8 @@ def make_pair(seed):
     if rng.random() < 0.7:
         prior2 = prior1
     n = int(rng.choice([0, 3, 6, 8, 14, 15, 16, 25, 40, 80, 150, 300], p=[.02, .02, .03, .03, .05, .05, .05, .15, .2, .2, .15, .05]))
+    if BIG:
+        n = int(rng.choice([300, 600, 1200, 1600, 2500]))
     if kind == "tiny":
         n = int(rng.integers(0, 12))
     noise = float(rng.choice([0.0, 0.3, 1.0, 2.5]))
@@ -254,9 +259,12 @@ def main():
     ap.add_argument("--pairs", type=int, default=1500)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--workers", type=int, default=min(96, os.cpu_count() or 8))
+    ap.add_argument("--big", action="store_true", help="300 .. 2 500 matches per pair")
     ap.add_argument("--grow", action="store_true", help="batch b has (b + 1) x --pairs pairs")
     ap.add_argument("--poison", action="store_true", help="fill freed device memory with 0xFF before every call")
     args = ap.parse_args()
+    global BIG
+    BIG = args.big  # (set before the pool forks)
     ctx = capi.Context(0)
     total, bad, configs = run_fuzz(ctx, args.batches, args.pairs, args.seed, args.workers, log=lambda m: print(m, flush=True),
                                    grow=args.grow, poison=args.poison)
