@@ -344,6 +344,31 @@ class Context:
         self._chk(lib().dsm_retrieval_query(self._h, num_neighbors, max_num_images, cnt.ctypes.data, idx.ctypes.data, sc.ctypes.data))
         return [(idx[q, :cnt[q]].copy(), sc[q, :cnt[q]].copy()) for q in range(n_images)]
 
+    def retrieval_matches(self, query_result, num_neighbors=5, max_num_images=100):
+        """dsm_retrieval_matches + dsm_get_retrieval_matches for the retrieved lists of retrieval_query: (offsets [n+1] uint64,
+        tuples [total, 5] uint32 = query feature, image, database feature, word << 8 | Hamming distance, entry position)."""
+        n = len(query_result)
+        cnt = np.array([len(r[0]) for r in query_result], np.uint32)
+        idx = np.zeros((n, max_num_images), np.uint32)
+        for q, r in enumerate(query_result):
+            idx[q, :len(r[0])] = r[0]
+        offs = np.zeros(n + 1, np.uint64)
+        L = lib()
+        L.dsm_retrieval_matches.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.dsm_get_retrieval_matches.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+        self._chk(L.dsm_retrieval_matches(self._h, num_neighbors, max_num_images, cnt.ctypes.data, idx.ctypes.data, offs.ctypes.data))
+        total = int(offs[-1])
+        tup = np.zeros((max(total, 1), 5), np.uint32)
+        self._chk(L.dsm_get_retrieval_matches(self._h, tup.ctypes.data, total))
+        return offs, tup[:total]
+
+    def retrieval_idf(self, num_words):
+        out = np.zeros(num_words, np.float32)
+        L = lib()
+        L.dsm_get_retrieval_idf.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+        self._chk(L.dsm_get_retrieval_idf(self._h, out.ctypes.data, num_words))
+        return out
+
     def retrieval_debug_word_ids(self, image, n_feats, k):
         out = np.zeros((max(n_feats, 1), k), np.int32)
         self._chk(lib().dsm_retrieval_debug_word_ids(self._h, image, k, out.ctypes.data))

@@ -51,7 +51,10 @@ struct RetrievalState {
   DevBuf d_words, d_cw, d_projT, d_thr, d_lut;
   DevBuf d_row_img, d_wid, d_sig;                       // per feature row
   DevBuf d_keys, d_keys2, d_vals, d_vals2, d_tmp;        // sort scratch
-  DevBuf d_file_start, d_e_img, d_e_sig, d_nimg, d_idf;  // inverted files
+  DevBuf d_file_start, d_e_img, d_e_sig, d_e_row, d_nimg, d_idf;  // inverted files (d_e_row: the entry's feature row, spatial verification)
+  DevBuf d_m_counts, d_m_off, d_m_tuples, d_m_cnt_in, d_m_idx_in;  // dsm_retrieval_matches
+  uint64_t m_total = 0;
+  std::vector<float> idf_host;
   DevBuf d_img_start, d_normc, d_qnorm, d_nfeat, d_wcounts;  // d_nfeat: feature counts of the images (query kernels); d_wcounts: entries per word (index)
   DevBuf d_acc, d_first, d_skeys, d_skeys2, d_svals, d_svals2, d_seg, d_out_cnt, d_out_idx, d_out_score;
   std::vector<uint32_t> img_valid_start;  // prefix sums of the feature counts
@@ -198,12 +201,13 @@ __global__ void k_index_keys(const int32_t* __restrict__ wid, uint64_t n_rows, u
   atomicAdd(counts + key, 1u);
 }
 __global__ void k_gather_entries(const uint32_t* __restrict__ rows_sorted, uint64_t n_entries, const int32_t* __restrict__ row_img,
-                                 const uint64_t* __restrict__ sig, int32_t* e_img, uint64_t* e_sig) {
+                                 const uint64_t* __restrict__ sig, int32_t* e_img, uint64_t* e_sig, uint32_t* e_row) {
   const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_entries) return;
   const uint32_t r = rows_sorted[p];
   e_img[p] = row_img[r];
   e_sig[p] = sig[(uint64_t)r * RK_MAX];
+  e_row[p] = r;
 }
 // distinct images per inverted file (its entries are sorted by image): InvertedFile::GetImageIds(...).size()
 __global__ void k_word_image_counts(const uint32_t* __restrict__ keys_sorted, const int32_t* __restrict__ e_img, uint64_t n_entries,
@@ -357,6 +361,72 @@ __global__ __launch_bounds__(64) void k_vocab_score(const int32_t* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------ matches for spatial verification
+// VisualIndex::Query with geometries, visual_index.h:295-346: for every query feature and each of its words, the entries of
+// the word's inverted file that belong to one of the query's retrieved images (InvertedIndex::FindMatches) and lie within
+// kMaxHammingDistance.  One wave per query image; the retrieved images are a bitmap in LDS.  Tuples (query feature, image,
+// database feature, word << 8 | Hamming distance, entry position) in (feature, neighbour, entry) order; WRITE = false only
+// counts.  A database feature sits in ONE inverted file (IndexOptions::num_neighbors = 1) and a query feature's words are
+// distinct, so the reference's "keep the best weight per database feature" (:331-336) never has two candidates.
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_vocab_matches(const int32_t* __restrict__ wid, const uint64_t* __restrict__ sig,
+                                                      const uint32_t* __restrict__ img_row0, const uint32_t* __restrict__ img_nfeat,
+                                                      uint32_t n_images, int k, const uint32_t* __restrict__ file_start,
+                                                      const int32_t* __restrict__ e_img, const uint64_t* __restrict__ e_sig,
+                                                      const uint32_t* __restrict__ e_row, const uint32_t* __restrict__ top_counts,
+                                                      const uint32_t* __restrict__ top_idx, uint32_t max_num_images,
+                                                      uint32_t* m_counts, const uint64_t* __restrict__ m_off, uint32_t* tuples) {
+  extern __shared__ uint32_t s_member[];  // (n_images + 31) / 32 words
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  if (q >= n_images) return;
+  const uint32_t words = (n_images + 31u) / 32u;
+  for (uint32_t w = lane; w < words; w += 64) s_member[w] = 0u;
+  __syncthreads();
+  const uint32_t nt = top_counts[q] < max_num_images ? top_counts[q] : max_num_images;
+  for (uint32_t t = lane; t < nt; t += 64) {
+    const uint32_t d = top_idx[(size_t)q * max_num_images + t];
+    if (d < n_images) atomicOr(&s_member[d >> 5], 1u << (d & 31u));
+  }
+  __syncthreads();
+  const uint32_t nf = img_nfeat[q];
+  uint32_t total = 0;
+  uint32_t* out = WRITE ? tuples + (size_t)m_off[q] * 5 : nullptr;
+  for (uint32_t i = 0; i < nf; ++i) {
+    const uint64_t r = (uint64_t)img_row0[q] + i;
+    for (int n = 0; n < k; ++n) {
+      const int w = wid[r * RK_MAX + n];
+      if (w == RK_INVALID) continue;
+      const uint32_t s = file_start[w], e = file_start[w + 1];
+      if (s == e) continue;
+      const uint64_t bq = sig[r * RK_MAX + n];
+      for (uint32_t base = s; base < e; base += 64) {
+        const uint32_t p = base + lane;
+        bool hit = false;
+        int img = 0, h = 0;
+        if (p < e) {
+          img = e_img[p];
+          if ((s_member[(uint32_t)img >> 5] >> ((uint32_t)img & 31u)) & 1u) {
+            h = __popcll(bq ^ e_sig[p]);
+            hit = h <= 24;  // HammingDistWeightFunctor::kMaxHammingDistance (utils.h:54)
+          }
+        }
+        const unsigned long long bal = __ballot(hit);
+        if (WRITE && hit) {
+          uint32_t* o = out + (size_t)(total + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))) * 5;
+          o[0] = i;
+          o[1] = (uint32_t)img;
+          o[2] = e_row[p] - img_row0[img];
+          o[3] = ((uint32_t)w << 8) | (uint32_t)h;
+          o[4] = p;
+        }
+        total += (uint32_t)__popcll(bal);
+      }
+    }
+  }
+  if (!WRITE && lane == 0) m_counts[q] = total;
+}
+
 // keys for the descending sort: ~score bits (scores are >= 0), then first-seen item; untouched images go last
 __global__ void k_score_keys(const float* __restrict__ acc, const uint32_t* __restrict__ first, uint32_t q0, uint32_t n_queries,
                              uint32_t n_images, const float* __restrict__ qnorm, const float* __restrict__ normc, uint64_t* keys,
@@ -408,7 +478,7 @@ void dsm_retrieval_destroy(dsm_ctx* ctx) {
   RetrievalState* r = ctx->retrieval;
   if (!r) return;
   DevBuf* bufs[] = {&r->d_words, &r->d_cw, &r->d_projT, &r->d_thr, &r->d_lut, &r->d_row_img, &r->d_wid, &r->d_sig, &r->d_keys,
-                    &r->d_keys2, &r->d_vals, &r->d_vals2, &r->d_tmp, &r->d_file_start, &r->d_e_img, &r->d_e_sig, &r->d_nimg,
+                    &r->d_keys2, &r->d_vals, &r->d_vals2, &r->d_tmp, &r->d_file_start, &r->d_e_img, &r->d_e_sig, &r->d_e_row, &r->d_m_counts, &r->d_m_off, &r->d_m_tuples, &r->d_m_cnt_in, &r->d_m_idx_in, &r->d_nimg,
                     &r->d_idf, &r->d_img_start, &r->d_normc, &r->d_qnorm, &r->d_nfeat, &r->d_wcounts, &r->d_acc, &r->d_first, &r->d_skeys, &r->d_skeys2,
                     &r->d_svals, &r->d_svals2, &r->d_seg, &r->d_out_cnt, &r->d_out_idx, &r->d_out_score};
   for (DevBuf* b : bufs) b->release();
@@ -683,6 +753,7 @@ int dsm_retrieval_index(dsm_ctx* ctx) {
   RCHK(ctx, r->d_idf.reserve(((size_t)W + 1) * 4));
   RCHK(ctx, r->d_e_img.reserve(rows1 * 4));
   RCHK(ctx, r->d_e_sig.reserve(rows1 * 8));
+  RCHK(ctx, r->d_e_row.reserve(rows1 * 4));
   RCHK(ctx, r->d_img_start.reserve(((size_t)NI + 1) * 4));
   RCHK(ctx, r->d_normc.reserve(std::max<uint32_t>(NI, 1) * 4));
   RCHK(ctx, hipMemsetAsync(r->d_nimg.p, 0, ((size_t)W + 1) * 4, st));
@@ -711,7 +782,7 @@ int dsm_retrieval_index(dsm_ctx* ctx) {
   RCHK(ctx, hipMemcpyAsync(r->d_file_start.p, starts.data(), ((size_t)W + 2) * 4, hipMemcpyHostToDevice, st));
   if (n_entries) {
     hipLaunchKernelGGL(k_gather_entries, dim3((uint32_t)((n_entries + 255) / 256)), dim3(256), 0, st, r->d_vals2.as<uint32_t>(), n_entries,
-                       r->d_row_img.as<int32_t>(), r->d_sig.as<uint64_t>(), r->d_e_img.as<int32_t>(), r->d_e_sig.as<uint64_t>());
+                       r->d_row_img.as<int32_t>(), r->d_sig.as<uint64_t>(), r->d_e_img.as<int32_t>(), r->d_e_sig.as<uint64_t>(), r->d_e_row.as<uint32_t>());
     hipLaunchKernelGGL(k_word_image_counts, dim3((uint32_t)((n_entries + 255) / 256)), dim3(256), 0, st, r->d_keys2.as<uint32_t>(),
                        r->d_e_img.as<int32_t>(), n_entries, r->d_nimg.as<uint32_t>());
     RCHK(ctx, hipGetLastError());
@@ -726,6 +797,7 @@ int dsm_retrieval_index(dsm_ctx* ctx) {
   for (uint32_t w = 0; w < W; ++w)
     if (nimg[w]) idf[w] = (float)log((double)num_total_images / (double)nimg[w]);
   RCHK(ctx, hipMemcpyAsync(r->d_idf.p, idf.data(), ((size_t)W + 1) * 4, hipMemcpyHostToDevice, st));
+  r->idf_host.assign(idf.begin(), idf.begin() + W);
   RCHK(ctx, hipMemcpyAsync(r->d_img_start.p, r->img_valid_start.data(), ((size_t)NI + 1) * 4, hipMemcpyHostToDevice, st));
   // per image: its entries in word order = the word-sorted list stably re-sorted by image
   if (n_entries) {
@@ -825,6 +897,79 @@ int dsm_retrieval_query(dsm_ctx* ctx, uint32_t num_neighbors, uint32_t max_num_i
   RCHK(ctx, hipMemcpy(counts, r->d_out_cnt.p, (size_t)NI * 4, hipMemcpyDefault));
   RCHK(ctx, hipMemcpy(image_idx, r->d_out_idx.p, (size_t)NI * max_num_images * 4, hipMemcpyDefault));
   RCHK(ctx, hipMemcpy(scores, r->d_out_score.p, (size_t)NI * max_num_images * 4, hipMemcpyDefault));
+  return DSM_OK;
+}
+
+int dsm_retrieval_matches(dsm_ctx* ctx, uint32_t num_neighbors, uint32_t max_num_images, const uint32_t* counts, const uint32_t* image_idx,
+                          uint64_t* offsets) {
+  if (!ctx || !counts || !image_idx || !offsets) return DSM_ERR_INVALID_ARGUMENT;
+  RetrievalState* r = ctx->retrieval;
+  if (!r || !r->indexed) return dsm_fail(ctx, DSM_ERR_NOT_READY, "dsm_retrieval_index has not run");
+  if (num_neighbors == 0 || num_neighbors > RK_MAX) return dsm_fail(ctx, DSM_ERR_INVALID_ARGUMENT, "num_neighbors must be 1..8");
+  if (max_num_images == 0) return dsm_fail(ctx, DSM_ERR_INVALID_ARGUMENT, "max_num_images must be > 0");
+  const uint32_t NI = ctx->n_images;
+  offsets[0] = 0;
+  r->m_total = 0;
+  if (NI == 0) return DSM_OK;
+  const size_t smem = ((size_t)NI + 31) / 32 * 4;
+  if (smem > 60000) return dsm_fail(ctx, DSM_ERR_OUT_OF_RANGE, "dsm_retrieval_matches: more than 480 000 resident images");
+  if (r->num_words >= (1u << 24)) return dsm_fail(ctx, DSM_ERR_OUT_OF_RANGE, "dsm_retrieval_matches: more than 2^24 visual words");
+  RCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  RCHK(ctx, r->d_nfeat.reserve((size_t)NI * 4));
+  RCHK(ctx, hipMemcpyAsync(r->d_nfeat.p, ctx->nfeat.data(), (size_t)NI * 4, hipMemcpyHostToDevice, st));
+  RCHK(ctx, r->d_m_cnt_in.reserve((size_t)NI * 4));
+  RCHK(ctx, r->d_m_idx_in.reserve((size_t)NI * max_num_images * 4));
+  RCHK(ctx, hipMemcpyAsync(r->d_m_cnt_in.p, counts, (size_t)NI * 4, hipMemcpyDefault, st));
+  RCHK(ctx, hipMemcpyAsync(r->d_m_idx_in.p, image_idx, (size_t)NI * max_num_images * 4, hipMemcpyDefault, st));
+  RCHK(ctx, r->d_m_counts.reserve((size_t)NI * 4));
+  RCHK(ctx, r->d_m_off.reserve(((size_t)NI + 1) * 8));
+  auto launch = [&](bool write) {
+    if (write)
+      hipLaunchKernelGGL(k_vocab_matches<true>, dim3(NI), dim3(64), smem, st, r->d_wid.as<int32_t>(), r->d_sig.as<uint64_t>(),
+                         ctx->d_img_row0.as<uint32_t>(), r->d_nfeat.as<uint32_t>(), NI, (int)num_neighbors, r->d_file_start.as<uint32_t>(),
+                         r->d_e_img.as<int32_t>(), r->d_e_sig.as<uint64_t>(), r->d_e_row.as<uint32_t>(), r->d_m_cnt_in.as<uint32_t>(),
+                         r->d_m_idx_in.as<uint32_t>(), max_num_images, r->d_m_counts.as<uint32_t>(), r->d_m_off.as<uint64_t>(),
+                         r->d_m_tuples.as<uint32_t>());
+    else
+      hipLaunchKernelGGL(k_vocab_matches<false>, dim3(NI), dim3(64), smem, st, r->d_wid.as<int32_t>(), r->d_sig.as<uint64_t>(),
+                         ctx->d_img_row0.as<uint32_t>(), r->d_nfeat.as<uint32_t>(), NI, (int)num_neighbors, r->d_file_start.as<uint32_t>(),
+                         r->d_e_img.as<int32_t>(), r->d_e_sig.as<uint64_t>(), r->d_e_row.as<uint32_t>(), r->d_m_cnt_in.as<uint32_t>(),
+                         r->d_m_idx_in.as<uint32_t>(), max_num_images, r->d_m_counts.as<uint32_t>(), r->d_m_off.as<uint64_t>(),
+                         (uint32_t*)nullptr);
+  };
+  launch(false);
+  RCHK(ctx, hipGetLastError());
+  std::vector<uint32_t> mc(NI);
+  RCHK(ctx, hipMemcpyAsync(mc.data(), r->d_m_counts.p, (size_t)NI * 4, hipMemcpyDeviceToHost, st));
+  RCHK(ctx, hipStreamSynchronize(st));
+  for (uint32_t q = 0; q < NI; ++q) offsets[q + 1] = offsets[q] + mc[q];
+  r->m_total = offsets[NI];
+  RCHK(ctx, hipMemcpyAsync(r->d_m_off.p, offsets, ((size_t)NI + 1) * 8, hipMemcpyHostToDevice, st));
+  RCHK(ctx, r->d_m_tuples.reserve(std::max<uint64_t>(r->m_total, 1) * 20));
+  launch(true);
+  RCHK(ctx, hipGetLastError());
+  RCHK(ctx, hipStreamSynchronize(st));
+  return DSM_OK;
+}
+
+int dsm_get_retrieval_matches(dsm_ctx* ctx, uint32_t* tuples, uint64_t capacity) {
+  if (!ctx || !ctx->retrieval) return DSM_ERR_INVALID_ARGUMENT;
+  RetrievalState* r = ctx->retrieval;
+  if (capacity < r->m_total) return dsm_fail(ctx, DSM_ERR_OUT_OF_RANGE, "dsm_get_retrieval_matches: capacity below the total of dsm_retrieval_matches");
+  if (r->m_total == 0) return DSM_OK;
+  if (!tuples) return DSM_ERR_INVALID_ARGUMENT;
+  RCHK(ctx, hipSetDevice(ctx->device));
+  RCHK(ctx, hipMemcpy(tuples, r->d_m_tuples.p, (size_t)r->m_total * 20, hipMemcpyDefault));
+  return DSM_OK;
+}
+
+int dsm_get_retrieval_idf(dsm_ctx* ctx, float* idf, uint32_t capacity) {
+  if (!ctx || !ctx->retrieval || !idf) return DSM_ERR_INVALID_ARGUMENT;
+  RetrievalState* r = ctx->retrieval;
+  if (!r->indexed) return dsm_fail(ctx, DSM_ERR_NOT_READY, "dsm_retrieval_index has not run");
+  if (capacity < r->num_words) return dsm_fail(ctx, DSM_ERR_OUT_OF_RANGE, "dsm_get_retrieval_idf: capacity below the number of visual words");
+  std::memcpy(idf, r->idf_host.data(), (size_t)r->num_words * 4);
   return DSM_OK;
 }
 

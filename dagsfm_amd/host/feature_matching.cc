@@ -1,5 +1,6 @@
 // feature_matching.cc -- see feature_matching.h.
 #include "feature_matching.h"
+#include "spatial_verification.h"
 
 #include <chrono>
 #include <cmath>
@@ -266,7 +267,7 @@ bool VocabSimilarityGraph::Run() {
   image_pairs_.clear();
   scores_.clear();
   if (!options_.Check()) {
-    last_error_ = "VocabSimilaritySearchOptions::Check failed (num_images > 0, a vocabulary path; spatial re-ranking is not built)";
+    last_error_ = "VocabSimilaritySearchOptions::Check failed (num_images > 0, a vocabulary path)";
     return false;
   }
   VocabularyFile voc;
@@ -288,17 +289,27 @@ bool VocabSimilarityGraph::Run() {
   std::vector<std::vector<uint8_t>> copies(n);
   std::vector<uint32_t> nfeat(n);
   std::vector<const uint8_t*> desc(n);
+  const bool verify = options_.num_images_after_verification > 0;
+  std::vector<std::vector<FeatureGeometry>> geometries(verify ? n : 0);  // of the features as indexed, for the spatial re-ranking
   for (uint32_t i = 0; i < n; ++i) {
     const FeatureDescriptors& d = cache_.GetDescriptors(ids[i]);
     if (options_.max_num_features > 0 && d.rows > static_cast<size_t>(options_.max_num_features)) {
       // similarity_graph.cpp:77-79, 137-141: index and query only the features of largest scale, in that order
-      const std::vector<uint32_t> order = TopScaleFeatureOrder(cache_.GetKeypoints(ids[i]), static_cast<size_t>(options_.max_num_features));
+      const FeatureKeypoints& kps = cache_.GetKeypoints(ids[i]);
+      const std::vector<uint32_t> order = TopScaleFeatureOrder(kps, static_cast<size_t>(options_.max_num_features));
       copies[i].resize(order.size() * 128);
       for (size_t k = 0; k < order.size(); ++k) std::memcpy(copies[i].data() + k * 128, d.data.data() + static_cast<size_t>(order[k]) * 128, 128);
       nfeat[i] = static_cast<uint32_t>(order.size());
+      if (verify)
+        for (size_t k = 0; k < order.size(); ++k) geometries[i].push_back(GeometryOfKeypoint(kps[order[k]]));
     } else {
       copies[i] = d.data;
       nfeat[i] = static_cast<uint32_t>(d.rows);
+      if (verify) {
+        const FeatureKeypoints& kps = cache_.GetKeypoints(ids[i]);
+        for (size_t k = 0; k < d.rows && k < kps.size(); ++k) geometries[i].push_back(GeometryOfKeypoint(kps[k]));
+        geometries[i].resize(d.rows);
+      }
     }
     desc[i] = copies[i].data();
     cache_.ReleasePins();
@@ -317,6 +328,42 @@ bool VocabSimilarityGraph::Run() {
   if (rc == DSM_OK) rc = dsm_retrieval_index(ctx);
   if (rc == DSM_OK)
     rc = dsm_retrieval_query(ctx, static_cast<uint32_t>(options_.num_nearest_neighbors), max_images, counts.data(), idx.data(), sc.data());
+  // spatial verification of the retrieved images and re-ranking (VisualIndex::Query with geometries, visual_index.h:259-500):
+  // the device lists, per query, the database features that share a word with a query feature within the Hamming
+  // threshold; the 1-to-1 assignment and VoteAndVerify of each retrieved image run here (spatial_verification.cc)
+  if (rc == DSM_OK && verify) {
+    std::vector<uint64_t> offsets(static_cast<size_t>(n) + 1, 0);
+    rc = dsm_retrieval_matches(ctx, static_cast<uint32_t>(options_.num_nearest_neighbors), max_images, counts.data(), idx.data(), offsets.data());
+    std::vector<uint32_t> tuples(static_cast<size_t>(offsets[n]) * 5 + 1);
+    std::vector<float> idf(voc.num_words);
+    if (rc == DSM_OK) rc = dsm_get_retrieval_matches(ctx, tuples.data(), offsets[n]);
+    if (rc == DSM_OK) rc = dsm_get_retrieval_idf(ctx, idf.data(), voc.num_words);
+    if (rc == DSM_OK) {
+      float lut[65];  // HammingDistWeightFunctor<64, 16>, retrieval/utils.h:47-78
+      for (int h = 0; h <= 64; ++h) {
+        const float hamming_dist = static_cast<float>(h);
+        lut[h] = hamming_dist <= 24 ? std::exp(-hamming_dist * hamming_dist / (16.0f * 16.0f)) : 0.0f;
+      }
+      std::vector<RetrievalCandidate> candidates;
+      for (uint32_t q = 0; q < n; ++q) {
+        candidates.clear();
+        for (uint64_t m = offsets[q]; m < offsets[q + 1]; ++m) {
+          const uint32_t* t = tuples.data() + m * 5;
+          RetrievalCandidate c;
+          c.query_feature = t[0];
+          c.image = t[1];
+          c.database_feature = t[2];
+          c.entry_position = t[4];
+          const float idf_weight = idf[t[3] >> 8];
+          c.weight = lut[t[3] & 255u] * (idf_weight * idf_weight);
+          c.database_geometry = geometries[c.image][c.database_feature];
+          candidates.push_back(c);
+        }
+        counts[q] = SpatialRerank(geometries[q], candidates, options_.num_images_after_verification, counts[q],
+                                  idx.data() + static_cast<size_t>(q) * max_images, sc.data() + static_cast<size_t>(q) * max_images);
+      }
+    }
+  }
   if (rc != DSM_OK) last_error_ = dsm_last_error(ctx);
   dsm_ctx_destroy(ctx);
   if (rc != DSM_OK) return false;
@@ -476,14 +523,67 @@ uint32_t dsm_host_read_vocabulary(const char* path, uint8_t* words, float* proje
   }
   return v.num_words;
 }
+int64_t dsm_host_vocab_candidate_pairs3(const char* database_path, const char* vocab_path, int num_images, int num_nearest_neighbors,
+                                        int max_num_features, int num_images_after_verification, uint32_t* pairs, float* scores,
+                                        uint64_t capacity);
 int64_t dsm_host_vocab_candidate_pairs2(const char* database_path, const char* vocab_path, int num_images, int num_nearest_neighbors,
                                         int max_num_features, uint32_t* pairs, float* scores, uint64_t capacity) {
+  return dsm_host_vocab_candidate_pairs3(database_path, vocab_path, num_images, num_nearest_neighbors, max_num_features, 0, pairs, scores,
+                                         capacity);
+}
+// leaf hooks of the spatial re-ranking for tests/test_retrieval.py (geometries: [n][4] = x, y, scale, orientation)
+int dsm_host_sv_vote_and_verify(uint32_t n, const float* g1, const float* g2) {
+  std::vector<GeometryMatch> m(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    m[i].query.x = g1[4 * i]; m[i].query.y = g1[4 * i + 1]; m[i].query.scale = g1[4 * i + 2]; m[i].query.orientation = g1[4 * i + 3];
+    m[i].database.x = g2[4 * i]; m[i].database.y = g2[4 * i + 1]; m[i].database.scale = g2[4 * i + 2]; m[i].database.orientation = g2[4 * i + 3];
+  }
+  return VoteAndVerify(VoteAndVerifyOptions(), m);
+}
+// HammingDistWeightFunctor<64, 16>()(h), retrieval/utils.h:47-78
+float dsm_host_sv_hamming_weight(uint32_t h) {
+  const float hamming_dist = static_cast<float>(h);
+  return hamming_dist <= 24 ? std::exp(-hamming_dist * hamming_dist / (16.0f * 16.0f)) : 0.0f;
+}
+void dsm_host_sv_estimate_affine(const double* x1, const double* x2, uint32_t n, double* A6) { EstimateAffineTransform(x1, x2, n, A6); }
+void dsm_host_sv_keypoint_geometry(const float* kp6, uint32_t n, float* out4) {  // kp6: x, y, a11, a12, a21, a22
+  for (uint32_t i = 0; i < n; ++i) {
+    FeatureKeypoint k;
+    k.x = kp6[6 * i]; k.y = kp6[6 * i + 1]; k.a11 = kp6[6 * i + 2]; k.a12 = kp6[6 * i + 3]; k.a21 = kp6[6 * i + 4]; k.a22 = kp6[6 * i + 5];
+    const FeatureGeometry g = GeometryOfKeypoint(k);
+    out4[4 * i] = g.x; out4[4 * i + 1] = g.y; out4[4 * i + 2] = g.scale; out4[4 * i + 3] = g.orientation;
+  }
+}
+// SpatialRerank of one query from flat arrays: candidates as 5 uint32 (dsm_get_retrieval_matches) + weight + geometry
+uint32_t dsm_host_spatial_rerank(uint32_t n_query_features, const float* query_geom, uint64_t n_candidates, const uint32_t* tuples,
+                                 const float* weights, const float* database_geom, int num_images_after_verification, uint32_t count,
+                                 uint32_t* image_idx, float* scores) {
+  std::vector<FeatureGeometry> qg(n_query_features);
+  for (uint32_t i = 0; i < n_query_features; ++i) {
+    qg[i].x = query_geom[4 * i]; qg[i].y = query_geom[4 * i + 1]; qg[i].scale = query_geom[4 * i + 2]; qg[i].orientation = query_geom[4 * i + 3];
+  }
+  std::vector<RetrievalCandidate> c(n_candidates);
+  for (uint64_t m = 0; m < n_candidates; ++m) {
+    c[m].query_feature = tuples[5 * m];
+    c[m].image = tuples[5 * m + 1];
+    c[m].database_feature = tuples[5 * m + 2];
+    c[m].entry_position = tuples[5 * m + 4];
+    c[m].weight = weights[m];
+    c[m].database_geometry.x = database_geom[4 * m]; c[m].database_geometry.y = database_geom[4 * m + 1];
+    c[m].database_geometry.scale = database_geom[4 * m + 2]; c[m].database_geometry.orientation = database_geom[4 * m + 3];
+  }
+  return SpatialRerank(qg, c, num_images_after_verification, count, image_idx, scores);
+}
+int64_t dsm_host_vocab_candidate_pairs3(const char* database_path, const char* vocab_path, int num_images, int num_nearest_neighbors,
+                                        int max_num_features, int num_images_after_verification, uint32_t* pairs, float* scores,
+                                        uint64_t capacity) {
   try {
     Database db(database_path);
     VocabSimilaritySearchOptions o;
     o.num_images = num_images;
     o.num_nearest_neighbors = num_nearest_neighbors;
     o.max_num_features = max_num_features;
+    o.num_images_after_verification = num_images_after_verification;
     o.vocab_tree_path = vocab_path;
     VocabSimilarityGraph g(o, db);
     if (!g.Run()) {

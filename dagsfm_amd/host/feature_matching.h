@@ -240,11 +240,11 @@ struct VocabSimilaritySearchOptions {  // similarity_graph.h:52-76
   int num_images = 100;
   int num_nearest_neighbors = 5;
   int num_checks = 256;                   // FLANN search effort in the reference; the search is exact here
-  int num_images_after_verification = 0;  // spatial re-ranking (vote_and_verify.cc) is not built: 0 = off is the reference's default
+  int num_images_after_verification = 0;  // > 0: spatial re-ranking of the retrieved images (spatial_verification.h); 0 = off is the reference's default
   int max_num_features = -1;              // > 0: index and query only the features of largest scale (ExtractTopScaleFeatures)
   int num_threads = 8;
   std::string vocab_tree_path;
-  bool Check() const { return num_images > 0 && !vocab_tree_path.empty() && num_images_after_verification == 0; }
+  bool Check() const { return num_images > 0 && !vocab_tree_path.empty() && num_images_after_verification >= 0; }
 };
 
 // The vocabulary.  Read() takes either layout:

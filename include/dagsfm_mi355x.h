@@ -298,6 +298,20 @@ int dsm_retrieval_index(dsm_ctx* ctx);
  * num_neighbors: QueryOptions::num_neighbors (VocabSimilaritySearchOptions::num_nearest_neighbors, default 5, max 8). */
 int dsm_retrieval_query(dsm_ctx* ctx, uint32_t num_neighbors, uint32_t max_num_images, uint32_t* counts,
                         uint32_t* image_idx, float* scores);
+/* The input of the spatial re-ranking (VisualIndex::Query with geometries, visual_index.h:295-346; QueryOptions::
+ * num_images_after_verification > 0): for every resident image as the query and its retrieved images (counts / image_idx as
+ * dsm_retrieval_query returned them, same max_num_images), the database features that fall into one of the query feature's
+ * words, belong to a retrieved image and lie within HammingDistWeightFunctor::kMaxHammingDistance (InvertedIndex::
+ * FindMatches + the Hamming test).  offsets[q] .. offsets[q + 1] (n_images + 1 entries) index the tuples of query q;
+ * dsm_get_retrieval_matches copies them: 5 uint32 each = query feature, image, database feature, (word << 8) | Hamming
+ * distance, position of the entry in the inverted files (the order the reference's pointer comparison has inside one
+ * file), in (query feature, neighbour, entry) order.  The 1-to-1 assignment and VoteAndVerify (vote_and_verify.cc) run on
+ * the host (dagsfm_amd/host/spatial_verification.cc): they are sequential per image and use the host's float libm. */
+int dsm_retrieval_matches(dsm_ctx* ctx, uint32_t num_neighbors, uint32_t max_num_images, const uint32_t* counts,
+                          const uint32_t* image_idx, uint64_t* offsets);
+int dsm_get_retrieval_matches(dsm_ctx* ctx, uint32_t* tuples, uint64_t capacity);
+/* InvertedFile::IDFWeight of every visual word (inverted_file.h:260-271) after dsm_retrieval_index. */
+int dsm_get_retrieval_idf(dsm_ctx* ctx, float* idf, uint32_t capacity);
 /* Test hook: the k nearest visual words (ascending distance, ties to the lower id) of every feature of one image. */
 int dsm_retrieval_debug_word_ids(dsm_ctx* ctx, uint32_t image, uint32_t k, int32_t* out);
 /* Device time (HIP events) of the last dsm_retrieval_index / dsm_retrieval_query. */

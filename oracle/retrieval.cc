@@ -33,17 +33,24 @@
 #include <limits>
 #include <unordered_map>
 #include <unordered_set>
+#include <map>
+#include <set>
 #include <vector>
+
+#include "spatial_verification.h"
 
 namespace {
 
 const int kDescDim = 128, kEmbeddingDim = 64;
 const int kInvalidWordId = std::numeric_limits<int>::max();
 
+using oracle_sv::FeatureGeometry;
+
 struct Entry {  // InvertedFileEntry, inverted_file_entry.h:44-62 (the geometry is only used by spatial verification)
   int image_id;
   int feature_idx;
   uint64_t descriptor;
+  FeatureGeometry geometry;
 };
 
 // HammingDistWeightFunctor<64, 16>, utils.h:47-78
@@ -188,7 +195,10 @@ void oracle_retrieval_find_word_ids(void* h, const uint8_t* desc, uint32_t n, ui
 }
 
 // VisualIndex::Add with IndexOptions::num_neighbors = 1 (visual_index.h:62-73, 201-243)
-void oracle_retrieval_add(void* h, int image_id, const uint8_t* desc, uint32_t n) {
+void oracle_retrieval_add_geom(void* h, int image_id, const uint8_t* desc, uint32_t n, const float* geom);
+void oracle_retrieval_add(void* h, int image_id, const uint8_t* desc, uint32_t n) { oracle_retrieval_add_geom(h, image_id, desc, n, nullptr); }
+// geom: [n][4] = x, y, FeatureKeypoint::ComputeScale(), ComputeOrientation() (visual_index.h:229-233), or null
+void oracle_retrieval_add_geom(void* h, int image_id, const uint8_t* desc, uint32_t n, const float* geom) {
   Index& ix = *static_cast<Index*>(h);
   if (n == 0) return;
   std::vector<int> ids;
@@ -202,6 +212,12 @@ void oracle_retrieval_add(void* h, int image_id, const uint8_t* desc, uint32_t n
     e.image_id = image_id;
     e.feature_idx = static_cast<int>(i);
     e.descriptor = Binarize(ix.files[word_id], proj);
+    if (geom) {
+      e.geometry.x = geom[4 * i + 0];
+      e.geometry.y = geom[4 * i + 1];
+      e.geometry.scale = geom[4 * i + 2];
+      e.geometry.orientation = geom[4 * i + 3];
+    }
     ix.files[word_id].entries.push_back(e);
   }
 }
@@ -230,13 +246,13 @@ void oracle_retrieval_prepare(void* h) {
     ix.normalization_constants[s.first] = s.second > 0.0 ? static_cast<float>(1.0 / std::sqrt(s.second)) : 0.0f;
 }
 
-// VisualIndex::QueryAndFindWordIds (visual_index.h:664-693) with num_images_after_verification = 0.
-// Returns the number of image scores written (<= capacity): ids / scores in retrieval order.
-uint32_t oracle_retrieval_query(void* h, const uint8_t* desc, uint32_t n, uint32_t num_neighbors, int32_t max_num_images,
-                                int32_t* out_ids, float* out_scores, uint32_t capacity) {
-  Index& ix = *static_cast<Index*>(h);
-  if (n == 0) return 0;
-  std::vector<int> word_ids;  // (i, nn) row-major here
+// VisualIndex::QueryAndFindWordIds (visual_index.h:664-693): image_scores in retrieval order, word_ids (i, nn) row-major.
+static void QueryAndFindWordIds(Index& ix, const uint8_t* desc, uint32_t n, uint32_t num_neighbors, int32_t max_num_images,
+                                std::vector<ImageScore>* out_scores, std::vector<int>* out_word_ids) {
+  out_scores->clear();
+  out_word_ids->clear();
+  if (n == 0) return;
+  std::vector<int>& word_ids = *out_word_ids;
   FindWordIds(ix, desc, static_cast<int>(n), static_cast<int>(num_neighbors), &word_ids);
   // InvertedIndex::ComputeSelfSimilarity (inverted_index.h:327-339): linear index over the COLUMN-major Eigen::MatrixXi
   double self_similarity_d = 0.0;
@@ -275,12 +291,206 @@ uint32_t oracle_retrieval_query(void* h, const uint8_t* desc, uint32_t n, uint32
   if (max_num_images >= 0) num_images = std::min<size_t>(image_scores.size(), static_cast<size_t>(max_num_images));
   std::stable_sort(image_scores.begin(), image_scores.end(), SortFunc);  // partial_sort + resize, ties: see the header
   image_scores.resize(num_images);
+  *out_scores = image_scores;
+}
+
+// Returns the number of image scores written (<= capacity): ids / scores in retrieval order (num_images_after_verification = 0).
+uint32_t oracle_retrieval_query(void* h, const uint8_t* desc, uint32_t n, uint32_t num_neighbors, int32_t max_num_images,
+                                int32_t* out_ids, float* out_scores, uint32_t capacity) {
+  Index& ix = *static_cast<Index*>(h);
+  std::vector<ImageScore> image_scores;
+  std::vector<int> word_ids;
+  QueryAndFindWordIds(ix, desc, n, num_neighbors, max_num_images, &image_scores, &word_ids);
   const uint32_t m = static_cast<uint32_t>(std::min<size_t>(image_scores.size(), capacity));
   for (uint32_t k = 0; k < m; ++k) {
     out_ids[k] = image_scores[k].image_id;
     out_scores[k] = image_scores[k].score;
   }
   return m;
+}
+
+// VisualIndex::Query with geometries (visual_index.h:259-500): retrieval, then spatial verification of the retrieved
+// images and re-ranking.  geom: [n][4] = x, y, ComputeScale(), ComputeOrientation() of the query keypoints.
+// Orders the reference leaves to pointer values / hash tables (oracle/spatial_verification.h lists those of
+// VoteAndVerify): a feature's candidate matches are sorted by descending weight, equal weights by descending query
+// feature index, then by descending position of the database entry (word id, position inside the word's file) -- the
+// reference compares the entries' ADDRESSES there, which is this order inside one inverted file and allocator-dependent
+// across files; images of equal final score keep their retrieval order.
+uint32_t oracle_retrieval_query_verified(void* h, const uint8_t* desc, const float* geom, uint32_t n, uint32_t num_neighbors,
+                                         int32_t max_num_images, int32_t num_images_after_verification, int32_t* out_ids,
+                                         float* out_scores, uint32_t capacity) {
+  Index& ix = *static_cast<Index*>(h);
+  std::vector<ImageScore> image_scores;
+  std::vector<int> word_ids;
+  QueryAndFindWordIds(ix, desc, n, num_neighbors, max_num_images, &image_scores, &word_ids);
+  if (num_images_after_verification > 0 && n > 0) {
+    std::unordered_set<int> image_ids;
+    for (const ImageScore& s : image_scores) image_ids.insert(s.image_id);
+    struct M {  // (dist, (query entry, db entry)) with the addresses replaced by what orders them
+      float dist;
+      int query_idx;
+      int word_id;
+      int pos;  // position of the db entry inside its inverted file
+      int db_feature_idx;
+    };
+    auto greater = [](const M& a, const M& b) {  // std::greater<std::pair<float, std::pair<ptr, ptr>>>
+      if (a.dist != b.dist) return a.dist > b.dist;
+      if (a.query_idx != b.query_idx) return a.query_idx > b.query_idx;
+      if (a.word_id != b.word_id) return a.word_id > b.word_id;
+      return a.pos > b.pos;
+    };
+    std::map<int, std::map<int, std::vector<M>>> query_to_db_matches, db_to_query_matches;
+    float proj[kEmbeddingDim];
+    for (uint32_t i = 0; i < n; ++i) {
+      Project(ix, desc + static_cast<size_t>(i) * kDescDim, proj);
+      // per db feature the best weight over this query feature's words (visual_index.h:311-346)
+      std::map<int, std::map<int, M>> image_matches;
+      for (uint32_t j = 0; j < num_neighbors; ++j) {
+        const int word_id = word_ids[static_cast<size_t>(i) * num_neighbors + j];
+        if (word_id == kInvalidWordId) continue;
+        const InvertedFile& f = ix.files[word_id];
+        const uint64_t query_descriptor = Binarize(f, proj);
+        const float idf_weight = f.idf_weight;
+        const float squared_idf_weight = idf_weight * idf_weight;
+        for (size_t p = 0; p < f.entries.size(); ++p) {  // InvertedIndex::FindMatches, inverted_index.h:306-317
+          const Entry& e = f.entries[p];
+          if (!image_ids.count(e.image_id)) continue;
+          const size_t hamming_dist = static_cast<size_t>(__builtin_popcountll(query_descriptor ^ e.descriptor));
+          if (hamming_dist <= HammingWeights::kMaxHammingDistance) {
+            const float dist = ix.weights.lut[hamming_dist] * squared_idf_weight;
+            auto& feature_matches = image_matches[e.image_id];
+            const auto it = feature_matches.find(e.feature_idx);
+            if (it == feature_matches.end() || it->second.dist < dist)
+              feature_matches[e.feature_idx] = M{dist, static_cast<int>(i), word_id, static_cast<int>(p), e.feature_idx};
+          }
+        }
+      }
+      for (const auto& fm : image_matches)
+        for (const auto& m : fm.second) {
+          query_to_db_matches[fm.first][static_cast<int>(i)].push_back(m.second);
+          db_to_query_matches[fm.first][m.first].push_back(m.second);
+        }
+    }
+    auto geometry_of = [&](const M& m) { return ix.files[m.word_id].entries[m.pos].geometry; };
+    for (ImageScore& image_score : image_scores) {
+      auto& query_matches = query_to_db_matches[image_score.image_id];
+      auto& db_matches = db_to_query_matches[image_score.image_id];
+      if (query_matches.empty()) continue;
+      // 1-to-1 matching (visual_index.h:386-478).  The Fibonacci heaps order (-num_available_matches, feature_idx)
+      // pairs; a std::set with erase + insert for `increase` has the same top().  An entry whose handle is gone stays
+      // in the heap until it is popped (the reference never removes it either).
+      typedef std::pair<int, int> HeapItem;
+      std::set<HeapItem> query_heap, db_heap;
+      std::map<int, HeapItem> query_handles, db_handles;
+      for (auto& md : query_matches) {
+        std::sort(md.second.begin(), md.second.end(), greater);
+        const HeapItem it(-static_cast<int>(md.second.size()), md.first);
+        query_heap.insert(it);
+        query_handles[md.first] = it;
+      }
+      for (auto& md : db_matches) {
+        std::sort(md.second.begin(), md.second.end(), greater);
+        const HeapItem it(-static_cast<int>(md.second.size()), md.first);
+        db_heap.insert(it);
+        db_handles[md.first] = it;
+      }
+      std::vector<oracle_sv::FeatureGeometryMatch> matches;
+      HeapItem db_top = *db_heap.rbegin();
+      HeapItem query_top = *query_heap.rbegin();
+      while (!db_heap.empty() && !query_heap.empty()) {
+        const bool use_query = (query_top.first >= db_top.first) && !query_heap.empty();
+        auto& heap1 = use_query ? query_heap : db_heap;
+        auto& heap2 = use_query ? db_heap : query_heap;
+        auto& handles1 = use_query ? query_handles : db_handles;
+        auto& handles2 = use_query ? db_handles : query_handles;
+        auto& matches1 = use_query ? query_matches : db_matches;
+        auto& matches2 = use_query ? db_matches : query_matches;
+        const int idx1 = heap1.rbegin()->second;
+        heap1.erase(std::prev(heap1.end()));
+        if (handles1.count(idx1) > 0) {
+          handles1.erase(idx1);
+          bool match_found = false;
+          for (const M& entry2 : matches1[idx1]) {
+            const int idx2 = use_query ? entry2.db_feature_idx : entry2.query_idx;
+            if (handles2.count(idx2) > 0) {
+              if (!match_found) {
+                match_found = true;
+                oracle_sv::FeatureGeometryMatch match;
+                match.geometry1.x = geom[4 * entry2.query_idx + 0];
+                match.geometry1.y = geom[4 * entry2.query_idx + 1];
+                match.geometry1.scale = geom[4 * entry2.query_idx + 2];
+                match.geometry1.orientation = geom[4 * entry2.query_idx + 3];
+                match.geometries2.push_back(geometry_of(entry2));
+                matches.push_back(match);
+                handles2.erase(idx2);
+                for (const M& entry1 : matches2[idx2]) {
+                  const int other_idx1 = use_query ? entry1.query_idx : entry1.db_feature_idx;
+                  const auto hit = handles1.find(other_idx1);
+                  if (hit != handles1.end()) {
+                    heap1.erase(hit->second);
+                    hit->second.first += 1;
+                    heap1.insert(hit->second);
+                  }
+                }
+              } else {
+                const auto hit = handles2.find(idx2);
+                heap2.erase(hit->second);
+                hit->second.first += 1;
+                heap2.insert(hit->second);
+              }
+            }
+          }
+        }
+        if (!query_heap.empty()) query_top = *query_heap.rbegin();
+        if (!db_heap.empty()) db_top = *db_heap.rbegin();
+      }
+      const oracle_sv::VoteAndVerifyOptions vote_and_verify_options;
+      image_score.score += oracle_sv::VoteAndVerify(vote_and_verify_options, matches);
+    }
+    const size_t num_images = std::min<size_t>(image_scores.size(), static_cast<size_t>(num_images_after_verification));
+    std::stable_sort(image_scores.begin(), image_scores.end(), [](const ImageScore& a, const ImageScore& b) { return a.score > b.score; });
+    image_scores.resize(num_images);
+  }
+  const uint32_t m = static_cast<uint32_t>(std::min<size_t>(image_scores.size(), capacity));
+  for (uint32_t k = 0; k < m; ++k) {
+    out_ids[k] = image_scores[k].image_id;
+    out_scores[k] = image_scores[k].score;
+  }
+  return m;
+}
+
+// leaf hooks for tests/test_retrieval.py (the reference's geometry_test.cc / affine_transform_test.cc literals)
+void oracle_sv_transform_from_match(const float* g1, const float* g2, float* out4) {
+  oracle_sv::FeatureGeometry a, b;
+  a.x = g1[0]; a.y = g1[1]; a.scale = g1[2]; a.orientation = g1[3];
+  b.x = g2[0]; b.y = g2[1]; b.scale = g2[2]; b.orientation = g2[3];
+  const auto t = oracle_sv::TransformFromMatch(a, b);
+  out4[0] = t.scale; out4[1] = t.angle; out4[2] = t.tx; out4[3] = t.ty;
+}
+void oracle_sv_estimate_affine(const double* x1, const double* x2, uint32_t n, double* A6) {
+  oracle_sv::EstimateAffine(std::vector<double>(x1, x1 + 2 * n), std::vector<double>(x2, x2 + 2 * n), A6);
+}
+// FeatureKeypoint::ComputeScale / ComputeOrientation (feature/types.cc:84-98) of keypoints x, y, a11, a12, a21, a22:
+// the geometry VisualIndex::Add / Query store (visual_index.h:229-233, 303-307)
+void oracle_sv_keypoint_geometry(const float* kp6, uint32_t n, float* out4) {
+  for (uint32_t i = 0; i < n; ++i) {
+    const float a11 = kp6[6 * i + 2], a12 = kp6[6 * i + 3], a21 = kp6[6 * i + 4], a22 = kp6[6 * i + 5];
+    out4[4 * i] = kp6[6 * i];
+    out4[4 * i + 1] = kp6[6 * i + 1];
+    out4[4 * i + 2] = (std::sqrt(a11 * a11 + a21 * a21) + std::sqrt(a12 * a12 + a22 * a22)) / 2.0f;
+    out4[4 * i + 3] = std::atan2(a21, a11);
+  }
+}
+int oracle_sv_vote_and_verify(uint32_t n, const float* g1, const float* g2) {
+  std::vector<oracle_sv::FeatureGeometryMatch> matches(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    matches[i].geometry1.x = g1[4 * i]; matches[i].geometry1.y = g1[4 * i + 1];
+    matches[i].geometry1.scale = g1[4 * i + 2]; matches[i].geometry1.orientation = g1[4 * i + 3];
+    oracle_sv::FeatureGeometry b;
+    b.x = g2[4 * i]; b.y = g2[4 * i + 1]; b.scale = g2[4 * i + 2]; b.orientation = g2[4 * i + 3];
+    matches[i].geometries2.push_back(b);
+  }
+  return oracle_sv::VoteAndVerify(oracle_sv::VoteAndVerifyOptions(), matches);
 }
 
 }  // extern "C"

@@ -37,11 +37,16 @@ def create(path, images, focal=800.0, width=1000, height=750, prior=True, kp_col
     for i, (desc, kp) in enumerate(images):
         iid = i + 1
         con.execute("INSERT INTO images(image_id, name, camera_id) VALUES (?, ?, ?)", (iid, "img%04d.jpg" % iid, 1))
+        kp = np.asarray(kp, dtype=np.float32)
+        kp = kp.reshape(len(kp), -1) if len(kp) else np.zeros((0, kp_cols), np.float32)
         k = np.zeros((len(kp), kp_cols), dtype=np.float32)
-        k[:, :2] = kp
-        if kp_cols == 6:
-            k[:, 2] = 1.0
-            k[:, 5] = 1.0
+        if kp.shape[1] == kp_cols:  # x, y and the affine shape a11, a12, a21, a22 as given
+            k[:] = kp
+        else:
+            k[:, :2] = kp[:, :2]
+            if kp_cols == 6:
+                k[:, 2] = 1.0
+                k[:, 5] = 1.0
         con.execute("INSERT INTO keypoints VALUES (?, ?, ?, ?)", (iid, k.shape[0], kp_cols, k.tobytes()))
         d = np.ascontiguousarray(desc, dtype=np.uint8)
         con.execute("INSERT INTO descriptors VALUES (?, ?, ?, ?)", (iid, d.shape[0], 128, d.tobytes()))

@@ -313,3 +313,81 @@ class RetrievalOracle:
         sc = np.zeros(capacity, np.float32)
         n = self.L.oracle_retrieval_query(self.h, d.ctypes.data, len(d), num_neighbors, max_num_images, ids.ctypes.data, sc.ctypes.data, capacity)
         return ids[:n].copy(), sc[:n].copy()
+
+
+def _retrieval_oracle_add_geom(self, image_id, desc, geom):
+    """VisualIndex::Add with the features' geometry (x, y, scale, orientation) kept in the entries."""
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 128)
+    g = np.ascontiguousarray(geom, np.float32).reshape(-1, 4)
+    assert len(g) == len(d)
+    self.L.oracle_retrieval_add_geom.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    self.L.oracle_retrieval_add_geom(self.h, image_id, d.ctypes.data, len(d), g.ctypes.data)
+
+
+def _retrieval_oracle_query_verified(self, desc, geom, num_neighbors=5, max_num_images=-1, num_images_after_verification=0, capacity=100000):
+    """VisualIndex::Query with geometries: retrieval + spatial verification + re-ranking (visual_index.h:259-500)."""
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 128)
+    g = np.ascontiguousarray(geom, np.float32).reshape(-1, 4)
+    ids = np.zeros(capacity, np.int32)
+    sc = np.zeros(capacity, np.float32)
+    self.L.oracle_retrieval_query_verified.restype = ctypes.c_uint32
+    self.L.oracle_retrieval_query_verified.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    n = self.L.oracle_retrieval_query_verified(self.h, d.ctypes.data, g.ctypes.data, len(d), num_neighbors, max_num_images,
+                                               num_images_after_verification, ids.ctypes.data, sc.ctypes.data, capacity)
+    return ids[:n].copy(), sc[:n].copy()
+
+
+RetrievalOracle.add_geom = _retrieval_oracle_add_geom
+RetrievalOracle.query_verified = _retrieval_oracle_query_verified
+
+
+def keypoint_geometry(kp):
+    """(x, y, FeatureKeypoint::ComputeScale(), ComputeOrientation()) of keypoints with 2 (x, y), 4 (x, y, scale,
+    orientation) or 6 (x, y, a11, a12, a21, a22) columns (feature/types.cc:42-98), computed by the oracle in C++ float
+    (numpy's float32 arctan2 is not glibc's atan2f to the last bit)."""
+    k = np.ascontiguousarray(kp, np.float32)
+    if len(k) == 0:
+        return np.zeros((0, 4), np.float32)
+    k = k.reshape(len(k), -1)
+    n = len(k)
+    k6 = np.zeros((n, 6), np.float32)
+    k6[:, :2] = k[:, :2]
+    if k.shape[1] == 2:
+        k6[:, 2], k6[:, 5] = 1.0, 1.0
+    elif k.shape[1] == 4:  # FeatureKeypoint(x, y, scale, orientation), types.cc:50-58 -- only used with exact inputs in the tests
+        s, o = k[:, 2], k[:, 3]
+        k6[:, 2], k6[:, 3], k6[:, 4], k6[:, 5] = s * np.cos(o), -s * np.sin(o), s * np.sin(o), s * np.cos(o)
+    else:
+        k6[:, 2:] = k[:, 2:6]
+    out = np.zeros((n, 4), np.float32)
+    L = load().lib
+    L.oracle_sv_keypoint_geometry.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    L.oracle_sv_keypoint_geometry(k6.ctypes.data, n, out.ctypes.data)
+    return out
+
+
+def sv_transform_from_match(g1, g2):
+    L = load().lib
+    a, b = np.ascontiguousarray(g1, np.float32), np.ascontiguousarray(g2, np.float32)
+    out = np.zeros(4, np.float32)
+    L.oracle_sv_transform_from_match.argtypes = [ctypes.c_void_p] * 3
+    L.oracle_sv_transform_from_match(a.ctypes.data, b.ctypes.data, out.ctypes.data)
+    return out
+
+
+def sv_estimate_affine(x1, x2):
+    L = load().lib
+    a, b = np.ascontiguousarray(x1, np.float64).reshape(-1, 2), np.ascontiguousarray(x2, np.float64).reshape(-1, 2)
+    out = np.zeros(6, np.float64)
+    L.oracle_sv_estimate_affine.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    L.oracle_sv_estimate_affine(a.ctypes.data, b.ctypes.data, len(a), out.ctypes.data)
+    return out.reshape(2, 3)
+
+
+def sv_vote_and_verify(g1, g2):
+    L = load().lib
+    a, b = np.ascontiguousarray(g1, np.float32).reshape(-1, 4), np.ascontiguousarray(g2, np.float32).reshape(-1, 4)
+    L.oracle_sv_vote_and_verify.restype = ctypes.c_int
+    L.oracle_sv_vote_and_verify.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    return int(L.oracle_sv_vote_and_verify(len(a), a.ctypes.data, b.ctypes.data))

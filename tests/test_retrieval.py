@@ -236,3 +236,205 @@ def test_host_vocab_similarity_graph_max_num_features(tmp_path, dsm):
                 exp_scores.append(np.float32(s) * np.float32(1e3))
     assert n == len(exp_pairs) and [tuple(x) for x in pairs[:n]] == exp_pairs
     assert (scores[:n] == np.array(exp_scores, np.float32)).all()
+
+
+# ------------------------------------------------------------------------------------------- spatial re-ranking
+# QueryOptions::num_images_after_verification > 0: VisualIndex::Query with geometries (visual_index.h:259-500) +
+# VoteAndVerify (vote_and_verify.cc).  Oracle: oracle/spatial_verification.h + oracle_retrieval_query_verified; product:
+# dsm_retrieval_matches on the device, dagsfm_amd/host/spatial_verification.cc on the host.
+def _host_lib():
+    import ctypes
+    import os
+    H = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dagsfm_amd", "libdagsfm_host.so"))
+    H.dsm_host_sv_vote_and_verify.restype = ctypes.c_int
+    H.dsm_host_sv_vote_and_verify.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    H.dsm_host_sv_estimate_affine.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    H.dsm_host_sv_keypoint_geometry.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    H.dsm_host_sv_hamming_weight.restype = ctypes.c_float
+    H.dsm_host_sv_hamming_weight.argtypes = [ctypes.c_uint32]
+    H.dsm_host_spatial_rerank.restype = ctypes.c_uint32
+    H.dsm_host_spatial_rerank.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    H.dsm_host_vocab_candidate_pairs3.restype = ctypes.c_int64
+    H.dsm_host_vocab_candidate_pairs3.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+    return H
+
+
+def _host_rerank(H, qgeom, tup, idf, geoms, naf, ids, scores):
+    lut = np.array([H.dsm_host_sv_hamming_weight(h) for h in range(65)], np.float32)
+    w = np.ascontiguousarray((lut[tup[:, 3] & 255] * (idf[tup[:, 3] >> 8] * idf[tup[:, 3] >> 8]).astype(np.float32)).astype(np.float32))
+    dbg = np.array([geoms[int(t[1])][int(t[2])] for t in tup], np.float32).reshape(-1, 4)
+    ids = np.ascontiguousarray(ids, np.uint32).copy()
+    sc = np.ascontiguousarray(scores, np.float32).copy()
+    qg = np.ascontiguousarray(qgeom, np.float32)
+    tup = np.ascontiguousarray(tup, np.uint32)
+    n = H.dsm_host_spatial_rerank(len(qg), qg.ctypes.data, len(tup), tup.ctypes.data, w.ctypes.data, dbg.ctypes.data, naf, len(ids),
+                                  ids.ctypes.data, sc.ctypes.data)
+    return ids[:n], sc[:n]
+
+
+def test_spatial_leaves_like_the_reference_tests():
+    """retrieval/geometry_test.cc:43-135 (TransformFromMatch: identity, translation, scale, orientation) and
+    estimators/affine_transform_test.cc:40-67 on the oracle; then the product's host implementation against the oracle,
+    bit for bit: the least-squares affine map (degenerate inputs included), FeatureKeypoint's scale / orientation, and
+    VoteAndVerify over random similarity scenes with outliers, zero scales (inf / NaN paths) and single positions."""
+    for x in range(3):
+        for y in range(3):
+            for s in range(1, 5):
+                for o in range(3):
+                    assert np.allclose(oracle_lib.sv_transform_from_match([x, y, s, o], [x, y, s, o]), [1, 0, 0, 0], atol=1e-6)
+            assert np.allclose(oracle_lib.sv_transform_from_match([0, 0, 1, 0], [x, y, 1, 0]), [1, 0, x, y], atol=1e-6)
+    for s in range(1, 5):
+        assert np.allclose(oracle_lib.sv_transform_from_match([0, 0, 1, 0], [0, 0, s, 0]), [s, 0, 0, 0])
+    for o in range(3):
+        assert np.allclose(oracle_lib.sv_transform_from_match([0, 0, 1, 0], [0, 0, 1, o]), [1, o, 0, 0])
+    for x in np.arange(0, 1, 0.1):
+        A = np.array([[x, 0.2, 0.3], [30, 0.2, 0.1]])
+        src = np.array([[x, 0], [1, 0], [2, 1]], float)
+        dst = (A @ np.c_[src, np.ones(3)].T).T
+        Ae = oracle_lib.sv_estimate_affine(src, dst)
+        assert (((dst - (Ae @ np.c_[src, np.ones(3)].T).T) ** 2).sum(1) < 1e-6).all()
+    H = _host_lib()
+    rng = np.random.default_rng(0)
+    for n in (3, 4, 5, 9, 10, 40, 300):
+        for rep in range(4):
+            x1 = np.ascontiguousarray(rng.uniform(0, 1000, (n, 2)))
+            x2 = (rng.normal(size=(2, 3)) * [1, 1, 50] @ np.c_[x1, np.ones(n)].T).T + rng.normal(scale=rng.choice([0, 1.0]), size=(n, 2))
+            if rep == 3:
+                x2[:] = x2[0]
+            x2 = np.ascontiguousarray(x2)
+            b = np.zeros(6)
+            H.dsm_host_sv_estimate_affine(x1.ctypes.data, x2.ctypes.data, n, b.ctypes.data)
+            a = oracle_lib.sv_estimate_affine(x1, x2).ravel()
+            assert ((a == b) | (np.isnan(a) & np.isnan(b))).all(), (n, rep)
+    kp = np.c_[rng.uniform(0, 100, (50, 2)), rng.normal(size=(50, 4))].astype(np.float32)
+    g = np.zeros((50, 4), np.float32)
+    H.dsm_host_sv_keypoint_geometry(kp.ctypes.data, 50, g.ctypes.data)
+    assert (g == oracle_lib.keypoint_geometry(kp)).all()
+    n_pos = 0
+    for trial in range(150):
+        n = int(rng.choice([0, 2, 3, 5, 20, 100, 400]))
+        g1 = np.c_[rng.uniform(0, 1000, n), rng.uniform(0, 750, n), rng.uniform(0.5, 8, n), rng.uniform(-3.2, 3.2, n)].astype(np.float32)
+        ang, sc = rng.uniform(-3, 3), rng.uniform(0.3, 3)
+        R = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+        xy2 = (sc * (R @ g1[:, :2].T)).T + rng.uniform(-300, 300, 2) + rng.normal(scale=rng.choice([0, 2, 20]), size=(n, 2))
+        g2 = np.c_[xy2, g1[:, 2] * sc * rng.uniform(0.8, 1.25, n), g1[:, 3] + ang + rng.normal(scale=0.1, size=n)].astype(np.float32)
+        k = int(rng.uniform(0, 1) * n)
+        if k:
+            g2[rng.choice(n, k, replace=False), :2] = rng.uniform(0, 1000, (k, 2))
+        if trial % 17 == 0 and n:
+            g2[:, 2] = 0
+        if trial % 19 == 0 and n:
+            g1[:, :2] = g1[0, :2]
+        a = oracle_lib.sv_vote_and_verify(g1, g2)
+        g1c, g2c = np.ascontiguousarray(g1), np.ascontiguousarray(g2)
+        assert a == H.dsm_host_sv_vote_and_verify(n, g1c.ctypes.data, g2c.ctypes.data), trial
+        n_pos += a > 0
+    assert n_pos > 40
+    # a consistent similarity between 200 features is found whole; random positions are not
+    n = 200
+    g1 = np.c_[rng.uniform(0, 1000, n), rng.uniform(0, 750, n), rng.uniform(1, 5, n), rng.uniform(-3, 3, n)].astype(np.float32)
+    R = np.array([[np.cos(0.3), -np.sin(0.3)], [np.sin(0.3), np.cos(0.3)]])
+    g2 = np.c_[(1.4 * (R @ g1[:, :2].T)).T + [50, -20], g1[:, 2] * 1.4, g1[:, 3] + 0.3].astype(np.float32)
+    assert oracle_lib.sv_vote_and_verify(g1, g2) > 150
+    g2[:, :2] = rng.uniform(0, 1000, (n, 2))
+    assert oracle_lib.sv_vote_and_verify(g1, g2) < 30
+    assert oracle_lib.sv_vote_and_verify(g1[:2], g2[:2]) == 0
+
+
+def _spatial_case(rng, n_img, feats, n_words):
+    scene = synthetic.Scene(n_img, feats, seed=int(rng.integers(0, 2**31)), n_pool=int(feats * 1.5))
+    voc = synthetic.vocabulary(scene, n_words, seed=3)
+    ims = [scene.image(i) for i in range(n_img)]
+    descs = [im[0] for im in ims]
+    kps = []
+    for im in ims:  # keypoints with an affine shape (6 columns), like the database holds for SIFT features
+        n = len(im[0])
+        s, o = rng.uniform(1, 6, n), rng.uniform(-3.1, 3.1, n)
+        kps.append(np.c_[im[1][:, 0], im[1][:, 1], s * np.cos(o), -s * np.sin(o), s * np.sin(o), s * np.cos(o)].astype(np.float32))
+    if n_img > 3:
+        descs[2], kps[2] = descs[2][:0], kps[2][:0]
+    return voc, descs, kps
+
+
+def test_host_spatial_rerank_equals_oracle():
+    """The host half of the product (1-to-1 assignment with its own bookkeeping, VoteAndVerify, re-ranking) against
+    oracle_retrieval_query_verified, with the device's candidate tuples restated in numpy (tests/retrieval_emulation.py):
+    image lists and scores bit-identical, for 1 / 3 / 5 neighbours, short and long retrieval lists, an empty image."""
+    from tests import retrieval_emulation
+    H = _host_lib()
+    rng = np.random.default_rng(1)
+    total = changed = 0
+    for case in range(8):
+        n_img, feats, n_words = int(rng.choice([3, 6, 10])), int(rng.choice([40, 120])), int(rng.choice([8, 64, 300]))
+        k, max_images, naf = int(rng.choice([1, 3, 5])), int(rng.choice([2, 5, 100])), int(rng.choice([1, 3, 100]))
+        voc, descs, kps = _spatial_case(rng, n_img, feats, n_words)
+        geoms = [oracle_lib.keypoint_geometry(k_) for k_ in kps]
+        orc = oracle_lib.RetrievalOracle(*voc)
+        for i, d in enumerate(descs):
+            orc.add_geom(i, d, geoms[i])
+        orc.prepare()
+        tuples, idf = retrieval_emulation.emulate(voc[0], voc[1], voc[2], descs, k, orc)
+        for q in range(n_img):
+            ids0, sc0 = orc.query(descs[q], k, max_images)
+            ref_ids, ref_sc = orc.query_verified(descs[q], geoms[q], k, max_images, naf)
+            if len(descs[q]) == 0:
+                assert len(ref_ids) == 0
+                continue
+            got_ids, got_sc = _host_rerank(H, geoms[q], tuples(q, ids0), idf, geoms, naf, ids0, sc0)
+            assert list(got_ids) == list(ref_ids) and (got_sc == ref_sc).all(), (case, q)
+            assert len(ref_ids) == min(len(ids0), naf)
+            total += 1
+            changed += list(ref_ids) != list(ids0[:len(ref_ids)])
+    assert total > 30 and changed > 5
+
+
+@pytest.mark.gpu
+def test_device_retrieval_matches_and_reranked_database_run(tmp_path, dsm):
+    """(1) dsm_retrieval_matches / dsm_get_retrieval_matches / dsm_get_retrieval_idf against the numpy restatement:
+    offsets, the tuples in their order, the IDF weights.  (2) VocabSimilarityGraph::Run over a database.db with
+    num_images_after_verification > 0 (host shim + device) against the oracle's verified queries: pairs and scores."""
+    import ctypes
+    from tests import dbutil, retrieval_emulation
+    rng = np.random.default_rng(2)
+    n_img, feats, n_words, k, max_images, naf = 9, 200, 128, 5, 6, 4
+    voc, descs, kps = _spatial_case(rng, n_img, feats, n_words)
+    geoms = [oracle_lib.keypoint_geometry(k_) for k_ in kps]
+    orc = oracle_lib.RetrievalOracle(*voc)
+    for i, d in enumerate(descs):
+        orc.add_geom(i, d, geoms[i])
+    orc.prepare()
+    dsm.set_images(descs)
+    dsm.retrieval_set_vocabulary(*voc)
+    dsm.retrieval_index()
+    res = dsm.retrieval_query(n_img, num_neighbors=k, max_num_images=max_images)
+    offs, tup = dsm.retrieval_matches(res, num_neighbors=k, max_num_images=max_images)
+    tuples, idf = retrieval_emulation.emulate(voc[0], voc[1], voc[2], descs, k, orc)
+    assert (dsm.retrieval_idf(n_words) == idf).all()
+    for q in range(n_img):
+        exp = tuples(q, res[q][0])
+        got = tup[int(offs[q]):int(offs[q + 1])]
+        assert got.shape == exp.shape and (got == exp).all(), q
+    assert offs[-1] > 500
+    # (2) through the database
+    path = str(tmp_path / "database.db")
+    dbutil.create(path, [(d, kp) for d, kp in zip(descs, kps)], prior=True, kp_cols=6)
+    vpath = str(tmp_path / "vocab.bin")
+    H = _host_lib()
+    H.dsm_host_write_vocabulary.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    w, p, t = [np.ascontiguousarray(a) for a in voc]
+    assert H.dsm_host_write_vocabulary(vpath.encode(), n_words, w.ctypes.data, p.ctypes.data, t.ctypes.data) == 0
+    pairs = np.zeros((1000, 2), np.uint32)
+    scores = np.zeros(1000, np.float32)
+    n = H.dsm_host_vocab_candidate_pairs3(path.encode(), vpath.encode(), max_images, k, -1, naf, pairs.ctypes.data, scores.ctypes.data, 1000)
+    exp_pairs, exp_scores = [], []
+    for q in range(n_img):
+        ids, sc = orc.query_verified(descs[q], geoms[q], k, max_images, naf)
+        for i, s in zip(ids, sc):
+            if q < int(i):
+                exp_pairs.append((q + 1, int(i) + 1))
+                exp_scores.append(np.float32(s) * np.float32(1e3))
+    assert n == len(exp_pairs) and n > 5
+    assert [tuple(x) for x in pairs[:n]] == exp_pairs
+    assert (scores[:n] == np.array(exp_scores, np.float32)).all()
