@@ -15,6 +15,9 @@
 //   InvertedFile::ScoreFeature       inverted_file.h:297-361   ConvertToBinaryDescriptor :248-257
 //   HammingDistWeightFunctor         src/retrieval/utils.h:47-78
 //   InvertedIndex::ComputeSelfSimilarity inverted_index.h:327-339
+//   VisualIndex::Query with geometries (spatial re-ranking)  visual_index.h:259-500: InvertedIndex::FindMatches
+//                                    (inverted_index.h:306-317), the 1-to-1 assignment, VoteAndVerify
+//                                    (oracle/spatial_verification.h), the re-ranking
 //
 // Third-party arithmetic that is NOT restated, and what stands in its place (DESIGN.md "Retrieval"):
 //   * FindWordIds (visual_index.h:695-738) asks FLANN's AutotunedIndex (lib/FLANN, randomised kd-trees / k-means

@@ -3,7 +3,8 @@
 oracle/retrieval.cc on ONE context: many small seeded collections with awkward shapes -- vocabularies of 1 .. 3 000
 words with duplicated words (equal distances), images with 0, 1, a few or a few hundred features, duplicated images
 (equal scores), words nobody uses, 1 .. 8 neighbours, max_num_images from 1 to more than there are images -- image lists
-and scores must be bit-identical, as must the word assignment.
+and scores must be bit-identical, as must the word assignment and the spatially re-ranked lists (device candidate tuples +
+the host shim's vote-and-verify against the oracle's verified query).
 
   python tools/fuzz_retrieval.py [--cases 60] [--seed 1]
 
@@ -20,6 +21,8 @@ from dagsfm_amd import capi, synthetic  # noqa: E402
 
 def run_fuzz(ctx, n_cases, seed, log=print):
     from tests import oracle_lib
+    from tests.test_retrieval import _host_lib, _host_rerank
+    H = _host_lib()
     bad = total = 0
     for c in range(n_cases):
         rng = np.random.default_rng([seed, c])
@@ -50,12 +53,29 @@ def run_fuzz(ctx, n_cases, seed, log=print):
         ctx.retrieval_set_vocabulary(words, proj, thr)
         ctx.retrieval_index()
         res = ctx.retrieval_query(n_img, num_neighbors=k, max_num_images=max_images)
+        # keypoint geometry for the spatial re-ranking: random affine shapes
+        geoms = []
+        for d in descs:
+            n = len(d)
+            s_, o_ = rng.uniform(1, 6, n), rng.uniform(-3.1, 3.1, n)
+            geoms.append(oracle_lib.keypoint_geometry(np.c_[rng.uniform(0, 1000, n), rng.uniform(0, 750, n), s_ * np.cos(o_), -s_ * np.sin(o_),
+                                                            s_ * np.sin(o_), s_ * np.cos(o_)].astype(np.float32)))
         orc = oracle_lib.RetrievalOracle(words, proj, thr)
         for i, d in enumerate(descs):
-            orc.add(i, d)
+            orc.add_geom(i, d, geoms[i])
         orc.prepare()
+        naf = int(rng.choice([1, 2, 5, 100]))
+        offs, tup = ctx.retrieval_matches(res, num_neighbors=k, max_num_images=max_images)
+        idf = ctx.retrieval_idf(n_words)
         nb = 0
         for q, d in enumerate(descs):
+            if len(d):  # the re-ranked list: device tuples + host shim against the oracle's verified query
+                ref_ids, ref_sc = orc.query_verified(d, geoms[q], k, max_images, naf)
+                got_ids, got_sc = _host_rerank(H, geoms[q], tup[int(offs[q]):int(offs[q + 1])], idf, geoms, naf, res[q][0], res[q][1])
+                if list(got_ids) != list(ref_ids) or not (got_sc == ref_sc).all():
+                    nb += 1
+                    if nb <= 3:
+                        log("MISMATCH case %d query %d (re-ranked): %s %s vs %s %s" % (c, q, list(got_ids)[:6], list(got_sc)[:3], list(ref_ids)[:6], list(ref_sc)[:3]))
             ids, sc = orc.query(d, k, max_images)
             if list(res[q][0]) != list(ids) or not (np.asarray(res[q][1]) == sc).all():
                 nb += 1
