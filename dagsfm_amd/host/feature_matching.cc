@@ -344,24 +344,33 @@ bool VocabSimilarityGraph::Run() {
         const float hamming_dist = static_cast<float>(h);
         lut[h] = hamming_dist <= 24 ? std::exp(-hamming_dist * hamming_dist / (16.0f * 16.0f)) : 0.0f;
       }
-      std::vector<RetrievalCandidate> candidates;
-      for (uint32_t q = 0; q < n; ++q) {
-        candidates.clear();
-        for (uint64_t m = offsets[q]; m < offsets[q + 1]; ++m) {
-          const uint32_t* t = tuples.data() + m * 5;
-          RetrievalCandidate c;
-          c.query_feature = t[0];
-          c.image = t[1];
-          c.database_feature = t[2];
-          c.entry_position = t[4];
-          const float idf_weight = idf[t[3] >> 8];
-          c.weight = lut[t[3] & 255u] * (idf_weight * idf_weight);
-          c.database_geometry = geometries[c.image][c.database_feature];
-          candidates.push_back(c);
+      // one query is independent of the next (the reference verifies on its retrieval thread pool, similarity_graph.cpp:
+      // 116-160): options_.num_threads workers take the queries in turn
+      auto rerank_range = [&](uint32_t first, uint32_t step) {
+        std::vector<RetrievalCandidate> candidates;
+        for (uint32_t q = first; q < n; q += step) {
+          candidates.clear();
+          for (uint64_t m = offsets[q]; m < offsets[q + 1]; ++m) {
+            const uint32_t* t = tuples.data() + m * 5;
+            RetrievalCandidate c;
+            c.query_feature = t[0];
+            c.image = t[1];
+            c.database_feature = t[2];
+            c.entry_position = t[4];
+            const float idf_weight = idf[t[3] >> 8];
+            c.weight = lut[t[3] & 255u] * (idf_weight * idf_weight);
+            c.database_geometry = geometries[c.image][c.database_feature];
+            candidates.push_back(c);
+          }
+          counts[q] = SpatialRerank(geometries[q], candidates, options_.num_images_after_verification, counts[q],
+                                    idx.data() + static_cast<size_t>(q) * max_images, sc.data() + static_cast<size_t>(q) * max_images);
         }
-        counts[q] = SpatialRerank(geometries[q], candidates, options_.num_images_after_verification, counts[q],
-                                  idx.data() + static_cast<size_t>(q) * max_images, sc.data() + static_cast<size_t>(q) * max_images);
-      }
+      };
+      const uint32_t workers = std::max<uint32_t>(1, std::min<uint32_t>(n, static_cast<uint32_t>(std::max(1, options_.num_threads))));
+      std::vector<std::thread> pool;
+      for (uint32_t w = 1; w < workers; ++w) pool.emplace_back(rerank_range, w, workers);
+      rerank_range(0, workers);
+      for (std::thread& t : pool) t.join();
     }
   }
   if (rc != DSM_OK) last_error_ = dsm_last_error(ctx);
