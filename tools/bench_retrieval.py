@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--num-images", type=int, default=100)
     ap.add_argument("--neighbors", type=int, default=5)
     ap.add_argument("--cpu-images", type=int, default=0, help="time the CPU oracle's word assignment on this many images (0 = skip)")
+    ap.add_argument("--verify", type=int, default=0, help="num_images_after_verification: also time the spatial re-ranking")
     a = ap.parse_args()
     scene = synthetic.Scene(a.images, a.feats, seed=0)
     ims = [scene.image(i) for i in range(a.images)]
@@ -55,6 +56,50 @@ def main():
            "images_per_query": a.num_images, "index_s": t1 - t0, "query_s": t2 - t1, "index_device_ms": t_index,
            "query_device_ms": t_query, "candidate_pairs": len(pairs), "queries_retrieving_themselves_first": self_first,
            "word_assignment_int8_ops_per_image": 2.0 * 128 * a.feats * a.words}
+    if a.verify > 0:
+        # spatial re-ranking (QueryOptions::num_images_after_verification): candidate tuples on the device, then the host
+        # shim's SpatialRerank per query (called here one query after the other through its C export; the shim itself
+        # spreads the queries over VocabSimilaritySearchOptions::num_threads workers).  Feature shapes that are consistent
+        # between the views of a scene point: scale = the point's own x the image's zoom, orientation = the point's + the
+        # image's roll.
+        import ctypes
+        from tests.test_retrieval import _host_lib
+        H = _host_lib()
+        rng = np.random.default_rng(5)
+        base_s, base_o = rng.uniform(1.5, 6.0, scene.n_pool), rng.uniform(-3.0, 3.0, scene.n_pool)
+        geoms = []
+        for im in ims:
+            n = len(im[0])
+            pid = np.asarray(im[3])
+            zoom, roll = rng.uniform(0.7, 1.4), rng.uniform(-0.4, 0.4)
+            sc_ = np.where(pid >= 0, base_s[np.maximum(pid, 0)] * zoom, rng.uniform(1.5, 6.0, n))
+            or_ = np.where(pid >= 0, base_o[np.maximum(pid, 0)] + roll, rng.uniform(-3.0, 3.0, n))
+            geoms.append(np.c_[im[1][:, 0], im[1][:, 1], sc_, or_].astype(np.float32))
+        row0 = np.concatenate([[0], np.cumsum([len(g) for g in geoms])])
+        gall = np.ascontiguousarray(np.concatenate(geoms))
+        ni = min(a.num_images, a.images)
+        t3 = time.perf_counter()
+        offs, tup = ctx.retrieval_matches(res, num_neighbors=a.neighbors, max_num_images=ni)
+        t4 = time.perf_counter()
+        idf = ctx.retrieval_idf(a.words)
+        lut = np.array([H.dsm_host_sv_hamming_weight(h) for h in range(65)], np.float32)
+        w_all = np.ascontiguousarray((lut[tup[:, 3] & 255] * (idf[tup[:, 3] >> 8] * idf[tup[:, 3] >> 8]).astype(np.float32)).astype(np.float32))
+        dbg_all = np.ascontiguousarray(gall[row0[tup[:, 1]] + tup[:, 2]])
+        t_host = 0.0
+        changed = 0
+        for q in range(a.images):
+            lo, hi = int(offs[q]), int(offs[q + 1])
+            ids = np.ascontiguousarray(res[q][0], np.uint32).copy()
+            scq = np.ascontiguousarray(res[q][1], np.float32).copy()
+            tq, wq, dq = tup[lo:hi], w_all[lo:hi], dbg_all[lo:hi]
+            t5 = time.perf_counter()
+            n_after = H.dsm_host_spatial_rerank(len(geoms[q]), geoms[q].ctypes.data, hi - lo, tq.ctypes.data, wq.ctypes.data, dq.ctypes.data,
+                                                a.verify, len(ids), ids.ctypes.data, scq.ctypes.data)
+            t_host += time.perf_counter() - t5
+            changed += list(ids[:n_after]) != list(res[q][0][:n_after])
+        out["spatial_reranking"] = {"num_images_after_verification": a.verify, "candidate_tuples": int(offs[-1]),
+                                    "device_matches_s": t4 - t3, "host_rerank_s_one_thread": t_host,
+                                    "queries_reordered": changed, "images_verified_per_s_one_thread": a.images * ni / max(t_host, 1e-9)}
     if a.cpu_images > 0:
         from tests import oracle_lib
         orc = oracle_lib.RetrievalOracle(*voc)
