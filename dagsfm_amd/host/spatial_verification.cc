@@ -336,8 +336,9 @@ float AreaUnder(const FeatureGeometry& g, const float A[4]) {  // N = A^T (I / s
   return 1.0f / std::sqrt(4.0f * n00 * n11 - bsum * bsum);
 }
 
-bool IsInlier(const GeometryMatch& m, const BothWays& w, float max_transfer_error, float max_scale_error) {
-  const float moved = AreaUnder(m.query, w.bwd), measured = AreaOf(m.database);
+// `measured` = AreaOf(m.database): the same for every hypothesis, so the caller computes it once per match
+bool IsInlier(const GeometryMatch& m, float measured, const BothWays& w, float max_transfer_error, float max_scale_error) {
+  const float moved = AreaUnder(m.query, w.bwd);
   const float scale_error = moved > measured ? moved / measured : measured / moved;
   if (!(scale_error <= max_scale_error)) return false;
   const float ax = (m.database.x - (w.fwd[0] * m.query.x + w.fwd[1] * m.query.y)) - w.fwd_t[0];
@@ -348,10 +349,11 @@ bool IsInlier(const GeometryMatch& m, const BothWays& w, float max_transfer_erro
   return (e1 + e2) <= max_transfer_error;
 }
 
-std::vector<int> InliersOf(const std::vector<GeometryMatch>& matches, const BothWays& w, float max_transfer_error, float max_scale_error) {
+std::vector<int> InliersOf(const std::vector<GeometryMatch>& matches, const std::vector<float>& measured, const BothWays& w,
+                           float max_transfer_error, float max_scale_error) {
   std::vector<int> idx;
   for (size_t i = 0; i < matches.size(); ++i)
-    if (IsInlier(matches[i], w, max_transfer_error, max_scale_error)) idx.push_back(static_cast<int>(i));
+    if (IsInlier(matches[i], measured[i], w, max_transfer_error, max_scale_error)) idx.push_back(static_cast<int>(i));
   return idx;
 }
 
@@ -399,11 +401,19 @@ int VoteAndVerify(const VoteAndVerifyOptions& o, const std::vector<GeometryMatch
   auto key_of = [&](int na, int ns, int nx, int ny) {
     return static_cast<uint64_t>(static_cast<int64_t>(na + o.num_angle_bins * (ns + o.num_scale_bins * (nx + o.num_trans_bins * ny))));
   };
-  std::map<uint64_t, Votes> level[kLevels];
+  // The reference keeps one hash map of bins per level.  Here: the votes in match order, and per level the indices of the
+  // votes stably sorted by the level's key -- a run of equal keys is a bin, and inside a run the votes are still in match
+  // order, which is the order the reference adds them up in (float sums).
   struct Cell {
     int na, ns, nx, ny;
   };
-  std::map<uint64_t, Cell> finest;
+  struct Vote {
+    uint64_t key[kLevels];
+    Cell cell;
+    Similarity T;
+  };
+  std::vector<Vote> votes;
+  votes.reserve(matches.size());
   for (const GeometryMatch& m : matches) {
     const Similarity T = SimilarityOfMatch(m.query, m.database);
     if (std::abs(T.tx) > max_trans || std::abs(T.ty) > max_trans) continue;
@@ -413,47 +423,78 @@ int VoteAndVerify(const VoteAndVerifyOptions& o, const std::vector<GeometryMatch
     const float y = (T.ty + max_trans) * trans_norm;
     const float s = (log_scale + max_log_scale) * scale_norm;
     const float a = (T.angle + M_PI) * angle_norm;
-    Cell c;
-    c.nx = std::min(TruncateToInt(x * o.num_trans_bins), o.num_trans_bins - 1);
-    c.ny = std::min(TruncateToInt(y * o.num_trans_bins), o.num_trans_bins - 1);
-    c.ns = std::min(TruncateToInt(s * o.num_scale_bins), o.num_scale_bins - 1);
-    c.na = std::min(TruncateToInt(a * o.num_angle_bins), o.num_angle_bins - 1);
-    finest[key_of(c.na, c.ns, c.nx, c.ny)] = c;
-    for (int l = 0; l < kLevels; ++l) {
-      Votes& v = level[l][key_of(c.na >> l, c.ns >> l, c.nx >> l, c.ny >> l)];
-      v.count += 1;
-      v.sum.scale += T.scale;
-      v.sum.angle += T.angle;
-      v.sum.tx += T.tx;
-      v.sum.ty += T.ty;
+    Vote v;
+    v.cell.nx = std::min(TruncateToInt(x * o.num_trans_bins), o.num_trans_bins - 1);
+    v.cell.ny = std::min(TruncateToInt(y * o.num_trans_bins), o.num_trans_bins - 1);
+    v.cell.ns = std::min(TruncateToInt(s * o.num_scale_bins), o.num_scale_bins - 1);
+    v.cell.na = std::min(TruncateToInt(a * o.num_angle_bins), o.num_angle_bins - 1);
+    for (int l = 0; l < kLevels; ++l) v.key[l] = key_of(v.cell.na >> l, v.cell.ns >> l, v.cell.nx >> l, v.cell.ny >> l);
+    v.T = T;
+    votes.push_back(v);
+  }
+  std::vector<uint64_t> bin_key[kLevels];
+  std::vector<uint32_t> bin_count[kLevels];
+  std::vector<Votes> finest_bin;   // level 0: count and sums
+  std::vector<Cell> finest_cell;   // the cell of the LAST vote of the bin (coords[index] is overwritten by every vote)
+  std::vector<uint32_t> by_key(votes.size());
+  for (int l = 0; l < kLevels; ++l) {
+    for (uint32_t i = 0; i < by_key.size(); ++i) by_key[i] = i;
+    std::stable_sort(by_key.begin(), by_key.end(), [&](uint32_t i, uint32_t j) { return votes[i].key[l] < votes[j].key[l]; });
+    for (size_t i = 0; i < by_key.size();) {
+      size_t j = i;
+      Votes bin;
+      while (j < by_key.size() && votes[by_key[j]].key[l] == votes[by_key[i]].key[l]) {
+        if (l == 0) {
+          const Similarity& T = votes[by_key[j]].T;
+          bin.sum.scale += T.scale;
+          bin.sum.angle += T.angle;
+          bin.sum.tx += T.tx;
+          bin.sum.ty += T.ty;
+        }
+        ++j;
+      }
+      bin.count = j - i;
+      bin_key[l].push_back(votes[by_key[i]].key[l]);
+      bin_count[l].push_back(static_cast<uint32_t>(j - i));
+      if (l == 0) {
+        finest_bin.push_back(bin);
+        finest_cell.push_back(votes[by_key[j - 1]].cell);
+      }
+      i = j;
     }
   }
+  auto count_at = [&](int l, uint64_t key) -> size_t {
+    const auto it = std::lower_bound(bin_key[l].begin(), bin_key[l].end(), key);
+    return it != bin_key[l].end() && *it == key ? bin_count[l][it - bin_key[l].begin()] : 0;
+  };
   // multi-resolution score of every occupied finest cell; candidates by descending score, equal scores by ascending key
   struct Scored {
-    uint64_t key;
+    uint32_t bin;  // index into finest_bin (ascending key)
     float score;
   };
   std::vector<Scored> scored;
-  for (const auto& kv : level[0]) {
-    if (kv.second.count < static_cast<size_t>(o.min_num_votes)) continue;
-    const Cell c = finest.at(kv.first);
-    float score = kv.second.count;
+  for (uint32_t b = 0; b < finest_bin.size(); ++b) {
+    if (finest_bin[b].count < static_cast<size_t>(o.min_num_votes)) continue;
+    const Cell c = finest_cell[b];
+    float score = finest_bin[b].count;
     float weight = 0.5f;
     for (int l = 1; l < kLevels; ++l) {
-      score += level[l][key_of(c.na >> l, c.ns >> l, c.nx >> l, c.ny >> l)].count * weight;
+      score += count_at(l, key_of(c.na >> l, c.ns >> l, c.nx >> l, c.ny >> l)) * weight;
       weight *= 0.5f;
     }
-    scored.push_back(Scored{kv.first, score});
+    scored.push_back(Scored{b, score});
   }
   std::stable_sort(scored.begin(), scored.end(), [](const Scored& a, const Scored& b) { return a.score > b.score; });
   const size_t num_candidates = std::min(static_cast<size_t>(o.num_transformations), scored.size());
 
   const float max_transfer_error = o.max_transfer_error, max_scale_error = o.max_scale_error;
+  std::vector<float> measured(matches.size());
+  for (size_t i = 0; i < matches.size(); ++i) measured[i] = AreaOf(matches[i].database);
   size_t max_num_trials = std::numeric_limits<size_t>::max();
   size_t best_count = 0;
   BothWays best;
   for (size_t i = 0; i < num_candidates && i < max_num_trials; ++i) {
-    const Votes& v = level[0].at(scored[i].key);
+    const Votes& v = finest_bin[scored[i].bin];
     const float inv = 1.0f / static_cast<float>(v.count);
     Similarity mean = v.sum;
     mean.scale *= inv;
@@ -461,7 +502,7 @@ int VoteAndVerify(const VoteAndVerifyOptions& o, const std::vector<GeometryMatch
     mean.tx *= inv;
     mean.ty *= inv;
     const BothWays w = BothWaysOf(mean);
-    std::vector<int> inl = InliersOf(matches, w, max_transfer_error, max_scale_error);
+    std::vector<int> inl = InliersOf(matches, measured, w, max_transfer_error, max_scale_error);
     if (inl.size() < best_count || inl.size() < 3) continue;
     best_count = inl.size();
     best = w;
@@ -498,7 +539,7 @@ int VoteAndVerify(const VoteAndVerifyOptions& o, const std::vector<GeometryMatch
     local.bwd[2] = static_cast<float>(cof(0, 1) * invdet);
     local.bwd[3] = static_cast<float>(cof(1, 1) * invdet);
     local.bwd_t[1] = static_cast<float>(cof(2, 1) * invdet);
-    inl = InliersOf(matches, local, max_transfer_error, max_scale_error);
+    inl = InliersOf(matches, measured, local, max_transfer_error, max_scale_error);
     if (inl.size() > best_count) {
       best_count = inl.size();
       best = local;
@@ -511,8 +552,9 @@ int VoteAndVerify(const VoteAndVerifyOptions& o, const std::vector<GeometryMatch
   const int kGrid = 64;
   std::vector<std::pair<float, float>> at;
   float min_x = std::numeric_limits<float>::max(), min_y = std::numeric_limits<float>::max(), max_x = 0, max_y = 0;
-  for (const GeometryMatch& m : matches) {
-    if (!IsInlier(m, best, max_transfer_error, max_scale_error)) continue;
+  for (size_t i = 0; i < matches.size(); ++i) {
+    const GeometryMatch& m = matches[i];
+    if (!IsInlier(m, measured[i], best, max_transfer_error, max_scale_error)) continue;
     at.emplace_back(m.query.x, m.query.y);
     min_x = std::min(min_x, m.query.x);
     min_y = std::min(min_y, m.query.y);
@@ -534,79 +576,157 @@ int VoteAndVerify(const VoteAndVerifyOptions& o, const std::vector<GeometryMatch
   return occupied;
 }
 
+namespace {
+
+// The free features of one side during the 1-to-1 assignment: the reference keeps them in a heap ordered by (-open
+// candidates, feature index) and always takes the top -- the feature with the FEWEST open candidates, the LARGER index
+// among equals.  Here: one bitmap of local ids per open-candidate count (local ids ascend with the feature index, so the
+// highest set bit of the first non-empty bitmap is the top), which makes "one candidate fewer" a bit moved to the next
+// bitmap instead of an erase + insert in an ordered set.
+class FreeFeatures {
+ public:
+  FreeFeatures(const std::vector<uint32_t>& open_counts) : open_(open_counts.begin(), open_counts.end()), words_((open_counts.size() + 63) / 64) {
+    uint32_t most = 0;
+    for (uint32_t c : open_counts) most = std::max(most, c);
+    bits_.assign(static_cast<size_t>(most + 1) * words_, 0);
+    for (uint32_t id = 0; id < open_counts.size(); ++id) Set(open_counts[id], id);
+    free_ = open_counts.size();
+  }
+  bool Empty() const { return free_ == 0; }
+  bool IsFree(uint32_t id) const { return open_[id] >= 0; }
+  // open candidates of the top feature; Top() must not be called when Empty()
+  uint32_t TopOpen() {
+    while (!AnyAt(lowest_)) ++lowest_;
+    return lowest_;
+  }
+  uint32_t Top() {
+    const uint32_t c = TopOpen();
+    for (size_t w = words_; w-- > 0;) {
+      const uint64_t x = bits_[c * words_ + w];
+      if (x) return static_cast<uint32_t>(w * 64 + 63 - __builtin_clzll(x));
+    }
+    return 0;
+  }
+  void Take(uint32_t id) {  // leaves the free set for good
+    Clear(static_cast<uint32_t>(open_[id]), id);
+    open_[id] = -1;
+    --free_;
+  }
+  void OneCandidateFewer(uint32_t id) {
+    const uint32_t c = static_cast<uint32_t>(open_[id]);
+    Clear(c, id);
+    Set(c - 1, id);
+    open_[id] = static_cast<int>(c - 1);
+    if (c - 1 < lowest_) lowest_ = c - 1;
+  }
+
+ private:
+  bool AnyAt(uint32_t c) const {
+    for (size_t w = 0; w < words_; ++w)
+      if (bits_[c * words_ + w]) return true;
+    return false;
+  }
+  void Set(uint32_t c, uint32_t id) { bits_[c * words_ + id / 64] |= 1ull << (id % 64); }
+  void Clear(uint32_t c, uint32_t id) { bits_[c * words_ + id / 64] &= ~(1ull << (id % 64)); }
+  std::vector<int> open_;  // open candidates of a free feature, -1 once taken
+  size_t words_;
+  std::vector<uint64_t> bits_;
+  uint32_t lowest_ = 0;
+  size_t free_ = 0;
+};
+
+}  // namespace
+
 uint32_t SpatialRerank(const std::vector<FeatureGeometry>& query_geometries, const std::vector<RetrievalCandidate>& candidates,
                        int num_images_after_verification, uint32_t count, uint32_t* image_idx, float* scores) {
   if (num_images_after_verification <= 0) return count;
-  // candidates per retrieved image
-  std::map<uint32_t, std::vector<const RetrievalCandidate*>> by_image;
-  for (const RetrievalCandidate& c : candidates) by_image[c.image].push_back(&c);
-  auto stronger = [](const RetrievalCandidate* a, const RetrievalCandidate* b) {
-    if (a->weight != b->weight) return a->weight > b->weight;
-    if (a->query_feature != b->query_feature) return a->query_feature > b->query_feature;
-    return a->entry_position > b->entry_position;
+  // candidates grouped by retrieved image
+  std::vector<uint32_t> by_image(candidates.size());
+  for (uint32_t i = 0; i < by_image.size(); ++i) by_image[i] = i;
+  std::stable_sort(by_image.begin(), by_image.end(), [&](uint32_t a, uint32_t b) { return candidates[a].image < candidates[b].image; });
+  auto stronger = [&](uint32_t a, uint32_t b) {  // the order of a feature's candidate list (spatial_verification.h)
+    const RetrievalCandidate &x = candidates[a], &y = candidates[b];
+    if (x.weight != y.weight) return x.weight > y.weight;
+    if (x.query_feature != y.query_feature) return x.query_feature > y.query_feature;
+    return x.entry_position > y.entry_position;
   };
+  std::vector<uint32_t> qfeat, dfeat, qlist, dlist, qstart, dstart, qid, did;
   for (uint32_t k = 0; k < count; ++k) {
-    const auto found = by_image.find(image_idx[k]);
-    if (found == by_image.end()) continue;
-    // each side's features with their candidate lists, strongest first
-    std::map<uint32_t, std::vector<const RetrievalCandidate*>> of_query, of_database;
-    for (const RetrievalCandidate* c : found->second) {
-      of_query[c->query_feature].push_back(c);
-      of_database[c->database_feature].push_back(c);
+    const auto lo = std::lower_bound(by_image.begin(), by_image.end(), image_idx[k],
+                                     [&](uint32_t a, uint32_t image) { return candidates[a].image < image; });
+    auto hi = lo;
+    while (hi != by_image.end() && candidates[*hi].image == image_idx[k]) ++hi;
+    if (lo == hi) continue;
+    const uint32_t nc = static_cast<uint32_t>(hi - lo);
+    // local ids of the features on either side, ascending with the feature index
+    qfeat.clear();
+    dfeat.clear();
+    for (auto it = lo; it != hi; ++it) {
+      qfeat.push_back(candidates[*it].query_feature);
+      dfeat.push_back(candidates[*it].database_feature);
     }
-    // features still free, ordered by (fewest open candidates first, then the larger index): the top of the
-    // reference's heaps.  A feature leaves its set when it is taken or assigned.
-    typedef std::pair<int, uint32_t> Key;  // (-open candidates, feature)
-    std::set<Key> free_query, free_database;
-    std::map<uint32_t, int> open_query, open_database;
-    for (auto& kv : of_query) {
-      std::sort(kv.second.begin(), kv.second.end(), stronger);
-      open_query[kv.first] = -static_cast<int>(kv.second.size());
-      free_query.insert(Key(open_query[kv.first], kv.first));
+    std::sort(qfeat.begin(), qfeat.end());
+    qfeat.erase(std::unique(qfeat.begin(), qfeat.end()), qfeat.end());
+    std::sort(dfeat.begin(), dfeat.end());
+    dfeat.erase(std::unique(dfeat.begin(), dfeat.end()), dfeat.end());
+    qid.resize(nc);
+    did.resize(nc);
+    for (uint32_t c = 0; c < nc; ++c) {
+      qid[c] = static_cast<uint32_t>(std::lower_bound(qfeat.begin(), qfeat.end(), candidates[lo[c]].query_feature) - qfeat.begin());
+      did[c] = static_cast<uint32_t>(std::lower_bound(dfeat.begin(), dfeat.end(), candidates[lo[c]].database_feature) - dfeat.begin());
     }
-    for (auto& kv : of_database) {
-      std::sort(kv.second.begin(), kv.second.end(), stronger);
-      open_database[kv.first] = -static_cast<int>(kv.second.size());
-      free_database.insert(Key(open_database[kv.first], kv.first));
-    }
+    // each feature's candidates (positions c in [0, nc)), strongest first, as CSR lists
+    auto build_lists = [&](const std::vector<uint32_t>& id, size_t n_ids, std::vector<uint32_t>* list, std::vector<uint32_t>* start) {
+      list->resize(nc);
+      for (uint32_t c = 0; c < nc; ++c) (*list)[c] = c;
+      std::sort(list->begin(), list->end(), [&](uint32_t a, uint32_t b) {
+        if (id[a] != id[b]) return id[a] < id[b];
+        return stronger(lo[a], lo[b]);
+      });
+      start->assign(n_ids + 1, 0);
+      for (uint32_t c = 0; c < nc; ++c) (*start)[id[c] + 1] += 1;
+      for (size_t i = 0; i < n_ids; ++i) (*start)[i + 1] += (*start)[i];
+    };
+    build_lists(qid, qfeat.size(), &qlist, &qstart);
+    build_lists(did, dfeat.size(), &dlist, &dstart);
+    std::vector<uint32_t> qopen(qfeat.size()), dopen(dfeat.size());
+    for (size_t i = 0; i < qfeat.size(); ++i) qopen[i] = qstart[i + 1] - qstart[i];
+    for (size_t i = 0; i < dfeat.size(); ++i) dopen[i] = dstart[i + 1] - dstart[i];
+    FreeFeatures free_query(qopen), free_database(dopen);
     std::vector<GeometryMatch> matches;
-    while (!free_query.empty() && !free_database.empty()) {
-      const bool from_query = free_query.rbegin()->first >= free_database.rbegin()->first;
-      std::set<Key>& mine = from_query ? free_query : free_database;
-      std::set<Key>& theirs = from_query ? free_database : free_query;
-      std::map<uint32_t, int>& my_open = from_query ? open_query : open_database;
-      std::map<uint32_t, int>& their_open = from_query ? open_database : open_query;
-      const uint32_t me = mine.rbegin()->second;
-      mine.erase(std::prev(mine.end()));
-      my_open.erase(me);
+    while (!free_query.Empty() && !free_database.Empty()) {
+      // (-open, index) of the query top >= that of the database top  <=>  not more open candidates
+      const bool from_query = free_query.TopOpen() <= free_database.TopOpen();
+      FreeFeatures& mine = from_query ? free_query : free_database;
+      FreeFeatures& theirs = from_query ? free_database : free_query;
+      const std::vector<uint32_t>& my_list = from_query ? qlist : dlist;
+      const std::vector<uint32_t>& my_start = from_query ? qstart : dstart;
+      const std::vector<uint32_t>& their_list = from_query ? dlist : qlist;
+      const std::vector<uint32_t>& their_start = from_query ? dstart : qstart;
+      const std::vector<uint32_t>& their_id = from_query ? did : qid;
+      const std::vector<uint32_t>& my_id = from_query ? qid : did;
+      const uint32_t me = mine.Top();
+      mine.Take(me);
       bool assigned = false;
-      const std::vector<const RetrievalCandidate*>& my_list = from_query ? of_query[me] : of_database[me];
-      for (const RetrievalCandidate* c : my_list) {
-        const uint32_t other = from_query ? c->database_feature : c->query_feature;
-        const auto open = their_open.find(other);
-        if (open == their_open.end()) continue;  // already assigned or taken
+      for (uint32_t p = my_start[me]; p < my_start[me + 1]; ++p) {
+        const uint32_t c = my_list[p];
+        const uint32_t other = their_id[c];
+        if (!theirs.IsFree(other)) continue;  // already assigned or taken
         if (!assigned) {
           assigned = true;
+          const RetrievalCandidate& cand = candidates[lo[c]];
           GeometryMatch m;
-          m.query = query_geometries[c->query_feature];
-          m.database = c->database_geometry;
+          m.query = query_geometries[cand.query_feature];
+          m.database = cand.database_geometry;
           matches.push_back(m);
-          theirs.erase(Key(open->second, other));
-          their_open.erase(open);
+          theirs.Take(other);
           // everybody on my side who also pointed at `other` has one candidate fewer
-          const std::vector<const RetrievalCandidate*>& rivals = from_query ? of_database[other] : of_query[other];
-          for (const RetrievalCandidate* r : rivals) {
-            const uint32_t rival = from_query ? r->query_feature : r->database_feature;
-            const auto ro = my_open.find(rival);
-            if (ro == my_open.end()) continue;
-            mine.erase(Key(ro->second, rival));
-            ro->second += 1;
-            mine.insert(Key(ro->second, rival));
+          for (uint32_t r = their_start[other]; r < their_start[other + 1]; ++r) {
+            const uint32_t rival = my_id[their_list[r]];
+            if (mine.IsFree(rival)) mine.OneCandidateFewer(rival);
           }
         } else {  // a candidate I no longer need: it loses me
-          theirs.erase(Key(open->second, other));
-          open->second += 1;
-          theirs.insert(Key(open->second, other));
+          theirs.OneCandidateFewer(other);
         }
       }
     }
