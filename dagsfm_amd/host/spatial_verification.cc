@@ -326,8 +326,14 @@ BothWays BothWaysOf(const Similarity& t) {
 
 float AreaOf(const FeatureGeometry& g) { return 1.0f / std::sqrt(4.0f / (g.scale * g.scale * g.scale * g.scale)); }
 
-float AreaUnder(const FeatureGeometry& g, const float A[4]) {  // N = A^T (I / scale^2) A, 1 / sqrt(4 N00 N11 - (N10 + N01)^2)
-  const float d = 1.0f / (g.scale * g.scale), z = 0.0f / (g.scale * g.scale);
+// What IsInlier needs of a match that does not depend on the hypothesis, computed once per match: the database feature's
+// own area and the two distinct entries of Identity / scale^2 (1 / s^2 and 0 / s^2 -- the latter is 0 unless the scale is
+// 0, inf or NaN, and is kept as the expression it is in the reference)
+struct MatchConstants {
+  float measured, d, z;
+};
+
+float AreaUnder(float d, float z, const float A[4]) {  // N = A^T (I / scale^2) A, 1 / sqrt(4 N00 N11 - (N10 + N01)^2)
   const float t00 = A[0] * d + A[2] * z, t01 = A[0] * z + A[2] * d;
   const float t10 = A[1] * d + A[3] * z, t11 = A[1] * z + A[3] * d;
   const float n00 = t00 * A[0] + t01 * A[2], n01 = t00 * A[1] + t01 * A[3];
@@ -336,9 +342,9 @@ float AreaUnder(const FeatureGeometry& g, const float A[4]) {  // N = A^T (I / s
   return 1.0f / std::sqrt(4.0f * n00 * n11 - bsum * bsum);
 }
 
-// `measured` = AreaOf(m.database): the same for every hypothesis, so the caller computes it once per match
-bool IsInlier(const GeometryMatch& m, float measured, const BothWays& w, float max_transfer_error, float max_scale_error) {
-  const float moved = AreaUnder(m.query, w.bwd);
+bool IsInlier(const GeometryMatch& m, const MatchConstants& k, const BothWays& w, float max_transfer_error, float max_scale_error) {
+  const float measured = k.measured;
+  const float moved = AreaUnder(k.d, k.z, w.bwd);
   const float scale_error = moved > measured ? moved / measured : measured / moved;
   if (!(scale_error <= max_scale_error)) return false;
   const float ax = (m.database.x - (w.fwd[0] * m.query.x + w.fwd[1] * m.query.y)) - w.fwd_t[0];
@@ -349,7 +355,7 @@ bool IsInlier(const GeometryMatch& m, float measured, const BothWays& w, float m
   return (e1 + e2) <= max_transfer_error;
 }
 
-std::vector<int> InliersOf(const std::vector<GeometryMatch>& matches, const std::vector<float>& measured, const BothWays& w,
+std::vector<int> InliersOf(const std::vector<GeometryMatch>& matches, const std::vector<MatchConstants>& measured, const BothWays& w,
                            float max_transfer_error, float max_scale_error) {
   std::vector<int> idx;
   for (size_t i = 0; i < matches.size(); ++i)
@@ -488,8 +494,11 @@ int VoteAndVerify(const VoteAndVerifyOptions& o, const std::vector<GeometryMatch
   const size_t num_candidates = std::min(static_cast<size_t>(o.num_transformations), scored.size());
 
   const float max_transfer_error = o.max_transfer_error, max_scale_error = o.max_scale_error;
-  std::vector<float> measured(matches.size());
-  for (size_t i = 0; i < matches.size(); ++i) measured[i] = AreaOf(matches[i].database);
+  std::vector<MatchConstants> measured(matches.size());
+  for (size_t i = 0; i < matches.size(); ++i) {
+    const float s2 = matches[i].query.scale * matches[i].query.scale;
+    measured[i] = MatchConstants{AreaOf(matches[i].database), 1.0f / s2, 0.0f / s2};
+  }
   size_t max_num_trials = std::numeric_limits<size_t>::max();
   size_t best_count = 0;
   BothWays best;
