@@ -5,8 +5,9 @@
 //   TwoWayTransform, VotingBin, ComputeScaleError, ComputeTransferError, ComputeInliers, ComputeEffectiveInlierCount,
 //   VoteAndVerify                                            src/retrieval/vote_and_verify.cc:46-418
 //   the 1-to-1 assignment and the re-ranking of VisualIndex::Query    src/retrieval/visual_index.h:366-500
-// Where the reference's result depends on a hash table's iteration order, on pointer values or on Eigen's reduction
-// order, the order is the one oracle/spatial_verification.h and oracle/retrieval.cc define;
+// Where the reference's result depends on pointer values or on Eigen's reduction order, the order is the one
+// oracle/spatial_verification.h and oracle/retrieval.cc define; where it depends on std::unordered_map's iteration order
+// (the voting bins) the same container is fed the same insertions;
 // tests/test_retrieval.py compares the two implementations bit for bit.  Everything here is float / double arithmetic in
 // the reference's own expression order (-ffp-contract=off).
 #include "spatial_verification.h"
@@ -18,6 +19,7 @@
 #include <limits>
 #include <map>
 #include <set>
+#include <unordered_map>
 #include <utility>
 
 namespace dagsfm_amd {
@@ -473,13 +475,19 @@ int VoteAndVerify(const VoteAndVerifyOptions& o, const std::vector<GeometryMatch
     const auto it = std::lower_bound(bin_key[l].begin(), bin_key[l].end(), key);
     return it != bin_key[l].end() && *it == key ? bin_count[l][it - bin_key[l].begin()] : 0;
   };
-  // multi-resolution score of every occupied finest cell; candidates by descending score, equal scores by ascending key
+  // multi-resolution score of every occupied finest cell.  The reference walks its std::unordered_map of bins and
+  // std::partial_sort's what it finds by score, so which of several equally scored bins are among the 30 candidates, and in
+  // which order, is whatever libstdc++'s hash table and heap-select make of the sequence of insertions.  The same
+  // containers, fed the same sequence (the finest key of every vote, in match order), give the same order here.
   struct Scored {
-    uint32_t bin;  // index into finest_bin (ascending key)
+    uint32_t bin;  // index into finest_bin
     float score;
   };
+  std::unordered_map<size_t, uint32_t> walk_order;
+  for (const Vote& v : votes) walk_order[static_cast<size_t>(v.key[0])] += 1;
   std::vector<Scored> scored;
-  for (uint32_t b = 0; b < finest_bin.size(); ++b) {
+  for (const auto& kv : walk_order) {
+    const uint32_t b = static_cast<uint32_t>(std::lower_bound(bin_key[0].begin(), bin_key[0].end(), static_cast<uint64_t>(kv.first)) - bin_key[0].begin());
     if (finest_bin[b].count < static_cast<size_t>(o.min_num_votes)) continue;
     const Cell c = finest_cell[b];
     float score = finest_bin[b].count;
@@ -490,8 +498,8 @@ int VoteAndVerify(const VoteAndVerifyOptions& o, const std::vector<GeometryMatch
     }
     scored.push_back(Scored{b, score});
   }
-  std::stable_sort(scored.begin(), scored.end(), [](const Scored& a, const Scored& b) { return a.score > b.score; });
   const size_t num_candidates = std::min(static_cast<size_t>(o.num_transformations), scored.size());
+  std::partial_sort(scored.begin(), scored.begin() + num_candidates, scored.end(), [](const Scored& a, const Scored& b) { return a.score > b.score; });
 
   const float max_transfer_error = o.max_transfer_error, max_scale_error = o.max_scale_error;
   std::vector<MatchConstants> measured(matches.size());

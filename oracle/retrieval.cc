@@ -484,7 +484,9 @@ void oracle_sv_keypoint_geometry(const float* kp6, uint32_t n, float* out4) {
     out4[4 * i + 3] = std::atan2(a21, a11);
   }
 }
-int oracle_sv_vote_and_verify(uint32_t n, const float* g1, const float* g2) {
+int oracle_sv_vote_and_verify_order(uint32_t n, const float* g1, const float* g2, int platform_order);
+int oracle_sv_vote_and_verify(uint32_t n, const float* g1, const float* g2) { return oracle_sv_vote_and_verify_order(n, g1, g2, 1); }
+int oracle_sv_vote_and_verify_order(uint32_t n, const float* g1, const float* g2, int platform_order) {
   std::vector<oracle_sv::FeatureGeometryMatch> matches(n);
   for (uint32_t i = 0; i < n; ++i) {
     matches[i].geometry1.x = g1[4 * i]; matches[i].geometry1.y = g1[4 * i + 1];
@@ -493,7 +495,7 @@ int oracle_sv_vote_and_verify(uint32_t n, const float* g1, const float* g2) {
     b.x = g2[4 * i]; b.y = g2[4 * i + 1]; b.scale = g2[4 * i + 2]; b.orientation = g2[4 * i + 3];
     matches[i].geometries2.push_back(b);
   }
-  return oracle_sv::VoteAndVerify(oracle_sv::VoteAndVerifyOptions(), matches);
+  return oracle_sv::VoteAndVerify(oracle_sv::VoteAndVerifyOptions(), matches, platform_order != 0);
 }
 
 }  // extern "C"

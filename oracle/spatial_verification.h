@@ -9,8 +9,10 @@
 // PARITY UNPINNED for VoteAndVerify: the reference holds no test vector for it (there is no vote_and_verify_test.cc),
 // Eigen is absent here, and its result depends on things the C++ standard leaves open.  What stands in their place:
 //   * the reference walks `std::unordered_map` bins and `std::partial_sort`s them by score: bins of equal score come
-//     out in an order that depends on the hash table's history.  Here: descending score, equal scores by ascending bin
-//     index.
+//     out in an order that depends on the hash table's history and on the library.  Here: the same containers fed the
+//     same sequence of insertions, i.e. the order of THIS toolchain's libstdc++ (GCC 11) -- like the PRNG mapping of
+//     std::uniform_int_distribution in the two-view oracle.  (An order of our own -- equal scores by ascending bin index --
+//     changes the result of 26 of 3 000 random scenes, mostly by one or two effective inliers.)
 //   * Eigen's fixed-size float products (Matrix2f * Vector2f, A^T * M * A) are written out coefficient by coefficient,
 //     sums left to right; the least-squares solve (JacobiSVD of the 2N x 6 system, ColPivHouseholderQR preconditioner,
 //     solve() = V * S^-1 * U^T b over the numerical rank) uses oracle/linalg.h, dot products left to right.
@@ -26,6 +28,7 @@
 #include <cstdint>
 #include <limits>
 #include <map>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -248,8 +251,12 @@ struct VotingBin {  // vote_and_verify.cc:75-101
   }
 };
 
-// VoteAndVerify, vote_and_verify.cc:208-418
-inline int VoteAndVerify(const VoteAndVerifyOptions& options, const std::vector<FeatureGeometryMatch>& matches) {
+// VoteAndVerify, vote_and_verify.cc:208-418.  platform_order = true (the definition, and what the product implements): the
+// candidate bins in the order THIS platform's libstdc++ gives the reference's own containers -- std::unordered_map<size_t,
+// ...> iteration order, std::partial_sort'ed by score; false: descending score, equal scores by ascending bin index -- kept
+// to measure how often the choice matters (tests/test_retrieval.py::test_bin_order_of_the_platform).
+inline int VoteAndVerify(const VoteAndVerifyOptions& options, const std::vector<FeatureGeometryMatch>& matches,
+                         bool platform_order = true) {
   if (matches.size() < 3) return 0;  // AffineTransformEstimator::kMinNumSamples
   const float max_trans = options.max_image_size;
   const float kMaxScale = 10.0f;
@@ -261,6 +268,7 @@ inline int VoteAndVerify(const VoteAndVerifyOptions& options, const std::vector<
   const int kNumLevels = 6;
   std::map<uint64_t, VotingBin> bins[kNumLevels];
   std::map<uint64_t, int> coords_a, coords_s, coords_x, coords_y;
+  std::unordered_map<size_t, int> platform_bins0;  // the keys of bins[0] inserted as the reference inserts them
   for (const auto& match : matches) {
     for (const auto& geometry2 : match.geometries2) {
       const auto T = TransformFromMatch(match.geometry1, geometry2);
@@ -284,6 +292,7 @@ inline int VoteAndVerify(const VoteAndVerifyOptions& options, const std::vector<
           coords_x[index] = n_x;
           coords_y[index] = n_y;
         }
+        if (level == 0) platform_bins0[static_cast<size_t>(index)] += 1;
         bins[level][index].Vote(T);
         n_x >>= 1;
         n_y >>= 1;
@@ -319,6 +328,18 @@ inline int VoteAndVerify(const VoteAndVerifyOptions& options, const std::vector<
   std::vector<size_t> order(bin_scores.size());
   for (size_t i = 0; i < order.size(); ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return bin_scores[a].second > bin_scores[b].second; });
+  if (platform_order) {
+    std::map<uint64_t, size_t> position;  // key -> index into bin_scores / bin_keys
+    for (size_t i = 0; i < bin_keys.size(); ++i) position[bin_keys[i]] = i;
+    std::vector<std::pair<size_t, float>> walk;  // (index, score) in the hash table's iteration order
+    for (const auto& kv : platform_bins0) {
+      const auto it = position.find(static_cast<uint64_t>(kv.first));
+      if (it != position.end()) walk.emplace_back(it->second, bin_scores[it->second].second);
+    }
+    std::partial_sort(walk.begin(), walk.begin() + num_transformations, walk.end(),
+                      [](const std::pair<size_t, float>& a, const std::pair<size_t, float>& b) { return a.second > b.second; });
+    for (size_t i = 0; i < num_transformations; ++i) order[i] = walk[i].first;
+  }
 
   size_t max_num_trials = std::numeric_limits<size_t>::max();
   size_t best_num_inliers = 0;

@@ -385,9 +385,11 @@ def sv_estimate_affine(x1, x2):
     return out.reshape(2, 3)
 
 
-def sv_vote_and_verify(g1, g2):
+def sv_vote_and_verify(g1, g2, platform_order=True):
+    """VoteAndVerify of 1-to-1 matches; platform_order=False: equal bin scores by ascending bin index instead of libstdc++'s
+    hash-table order (only for measuring how often that matters)."""
     L = load().lib
     a, b = np.ascontiguousarray(g1, np.float32).reshape(-1, 4), np.ascontiguousarray(g2, np.float32).reshape(-1, 4)
-    L.oracle_sv_vote_and_verify.restype = ctypes.c_int
-    L.oracle_sv_vote_and_verify.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
-    return int(L.oracle_sv_vote_and_verify(len(a), a.ctypes.data, b.ctypes.data))
+    L.oracle_sv_vote_and_verify_order.restype = ctypes.c_int
+    L.oracle_sv_vote_and_verify_order.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    return int(L.oracle_sv_vote_and_verify_order(len(a), a.ctypes.data, b.ctypes.data, 1 if platform_order else 0))
