@@ -749,11 +749,16 @@ uint32_t SpatialRerank(const std::vector<FeatureGeometry>& query_geometries, con
     }
     scores[k] += VoteAndVerify(VoteAndVerifyOptions(), matches);
   }
-  // re-rank: descending score, equal scores in retrieval order
+  // re-rank (visual_index.h:486-499): the reference's own std::sort / std::partial_sort calls on the same sequence, so
+  // equal scores fall the same way
   std::vector<uint32_t> order(count);
   for (uint32_t k = 0; k < count; ++k) order[k] = k;
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return scores[a] > scores[b]; });
   const uint32_t kept = std::min<uint32_t>(count, static_cast<uint32_t>(num_images_after_verification));
+  auto better = [&](uint32_t a, uint32_t b) { return scores[a] > scores[b]; };
+  if (kept == count)
+    std::sort(order.begin(), order.end(), better);
+  else
+    std::partial_sort(order.begin(), order.begin() + kept, order.end(), better);
   std::vector<uint32_t> new_idx(kept);
   std::vector<float> new_scores(kept);
   for (uint32_t k = 0; k < kept; ++k) {

@@ -318,7 +318,7 @@ uint32_t oracle_retrieval_query(void* h, const uint8_t* desc, uint32_t n, uint32
 // VoteAndVerify): a feature's candidate matches are sorted by descending weight, equal weights by descending query
 // feature index, then by descending position of the database entry (word id, position inside the word's file) -- the
 // reference compares the entries' ADDRESSES there, which is this order inside one inverted file and allocator-dependent
-// across files; images of equal final score keep their retrieval order.
+// across files; the final re-ranking uses the same std::sort / std::partial_sort calls as the reference.
 uint32_t oracle_retrieval_query_verified(void* h, const uint8_t* desc, const float* geom, uint32_t n, uint32_t num_neighbors,
                                          int32_t max_num_images, int32_t num_images_after_verification, int32_t* out_ids,
                                          float* out_scores, uint32_t capacity) {
@@ -450,9 +450,15 @@ uint32_t oracle_retrieval_query_verified(void* h, const uint8_t* desc, const flo
       const oracle_sv::VoteAndVerifyOptions vote_and_verify_options;
       image_score.score += oracle_sv::VoteAndVerify(vote_and_verify_options, matches);
     }
+    // visual_index.h:486-499, with the library's own (unstable) sorts: equal scores fall as libstdc++ lets them
     const size_t num_images = std::min<size_t>(image_scores.size(), static_cast<size_t>(num_images_after_verification));
-    std::stable_sort(image_scores.begin(), image_scores.end(), [](const ImageScore& a, const ImageScore& b) { return a.score > b.score; });
-    image_scores.resize(num_images);
+    auto SortFunc = [](const ImageScore& a, const ImageScore& b) { return a.score > b.score; };
+    if (num_images == image_scores.size()) {
+      std::sort(image_scores.begin(), image_scores.end(), SortFunc);
+    } else {
+      std::partial_sort(image_scores.begin(), image_scores.begin() + num_images, image_scores.end(), SortFunc);
+      image_scores.resize(num_images);
+    }
   }
   const uint32_t m = static_cast<uint32_t>(std::min<size_t>(image_scores.size(), capacity));
   for (uint32_t k = 0; k < m; ++k) {
