@@ -468,6 +468,12 @@ uint32_t oracle_retrieval_query_verified(void* h, const uint8_t* desc, const flo
   return m;
 }
 
+// HammingDistWeightFunctor<64, 16>()(h), for the test that pins it to the reference's own header (oracle/_ref/libmisc_ref.so)
+float oracle_retrieval_hamming_weight(uint32_t h) {
+  static const HammingWeights w;
+  return h <= static_cast<uint32_t>(kEmbeddingDim) ? w.lut[h] : 0.0f;
+}
+
 // leaf hooks for tests/test_retrieval.py (the reference's geometry_test.cc / affine_transform_test.cc literals)
 void oracle_sv_transform_from_match(const float* g1, const float* g2, float* out4) {
   oracle_sv::FeatureGeometry a, b;

@@ -1466,6 +1466,22 @@ void oracle_estimate_two_view_geometry(const dsm_camera* camera1, const double* 
     std::memcpy(inlier_matches_out, tv.inlier_matches.data(), tv.inlier_matches.size() * sizeof(uint32_t));
 }
 
+// InlierSupportMeasurer::Evaluate / Compare (support_measurement.cc:36-62) for tests/test_oracle_estimators.py, which pins
+// them to the reference's own file compiled where it lies (oracle/_ref/libmisc_ref.so)
+void oracle_inlier_support(const double* residuals, uint64_t n, double max_residual, uint64_t* num_inliers, double* residual_sum) {
+  const Support s = EvaluateSupport(std::vector<double>(residuals, residuals + n), max_residual);
+  *num_inliers = s.num_inliers;
+  *residual_sum = s.residual_sum;
+}
+int oracle_inlier_support_compare(uint64_t num_inliers1, double residual_sum1, uint64_t num_inliers2, double residual_sum2) {
+  Support a, b;
+  a.num_inliers = num_inliers1;
+  a.residual_sum = residual_sum1;
+  b.num_inliers = num_inliers2;
+  b.residual_sum = residual_sum2;
+  return CompareSupport(a, b) ? 1 : 0;
+}
+
 uint64_t oracle_compute_num_trials(uint64_t num_inliers, uint64_t num_samples, double confidence, int min_samples) {
   return ComputeNumTrials(num_inliers, num_samples, confidence, min_samples);
 }

@@ -306,3 +306,46 @@ def test_estimate_multiple_ends_when_a_pass_removes_nothing(oracle):
     ref, inl = oracle.estimate_two_view_geometry(camu, p1, camu, p2, m, opts, 3)
     assert ref.config == 6 and ref.num_inliers == 0 and len(inl) == 0
     assert ref.num_trials[2] > 0 and ref.num_trials[1] == 0
+
+
+def _misc_ref():
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libmisc_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libmisc_ref.so is built only where /root/reference exists (make -C oracle ref)")
+    return ctypes.CDLL(path)
+
+
+def test_support_measurer_equals_the_references_own_file(oracle):
+    """InlierSupportMeasurer::Evaluate / Compare: the oracle's restatement against /root/reference/src/optim/
+    support_measurement.cc itself (plain standard C++, compiled where it lies into oracle/_ref/libmisc_ref.so) -- counts and
+    residual sums bit for bit on random residual vectors (empty, all in, all out, values at the threshold), and every
+    Compare outcome including equal counts with equal / different sums."""
+    import ctypes
+    R = _misc_ref()
+    L = oracle.lib
+    for lib in (R, L):
+        pre = "ref_" if lib is R else "oracle_"
+        getattr(lib, pre + "inlier_support").argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+        getattr(lib, pre + "inlier_support_compare").restype = ctypes.c_int
+        getattr(lib, pre + "inlier_support_compare").argtypes = [ctypes.c_uint64, ctypes.c_double, ctypes.c_uint64, ctypes.c_double]
+    rng = np.random.default_rng(0)
+    supports = []
+    for trial in range(300):
+        n = int(rng.choice([0, 1, 7, 100, 1000]))
+        r = np.ascontiguousarray(rng.exponential(4.0, n) ** rng.choice([1, 2]))
+        thr = float(rng.choice([0.0, 1.0, 4.0, 16.0, 1e9]))
+        if n and trial % 5 == 0:
+            r[rng.integers(n)] = thr  # exactly at the threshold: an inlier (<=)
+        out = []
+        for lib, pre in ((R, "ref_"), (L, "oracle_")):
+            cnt, s = ctypes.c_uint64(0), ctypes.c_double(0)
+            getattr(lib, pre + "inlier_support")(r.ctypes.data, n, thr, ctypes.byref(cnt), ctypes.byref(s))
+            out.append((cnt.value, s.value))
+        assert out[0] == out[1], (trial, out)
+        supports.append(out[0])
+    supports += [(5, 1.0), (5, 1.0), (5, 2.0), (6, 9.0), (0, np.finfo(np.float64).max)]
+    for a in supports[::7] + supports[-5:]:
+        for b in supports[::11] + supports[-5:]:
+            assert R.ref_inlier_support_compare(a[0], a[1], b[0], b[1]) == L.oracle_inlier_support_compare(a[0], a[1], b[0], b[1])

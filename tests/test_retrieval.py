@@ -461,3 +461,27 @@ def test_bin_order_of_the_platform():
         n_cases += 1
         n_diff += oracle_lib.sv_vote_and_verify(g1, g2, True) != oracle_lib.sv_vote_and_verify(g1, g2, False)
     assert n_diff <= 0.05 * n_cases
+
+
+def test_hamming_weights_equal_the_references_own_header():
+    """HammingDistWeightFunctor<64> (retrieval/utils.h:47-78, a plain standard C++ header compiled where it lies into
+    oracle/_ref/libmisc_ref.so): the oracle's table and the host shim's weights are the same 65 floats, and the cut-off is
+    the 24 the kernels use."""
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libmisc_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libmisc_ref.so is built only where /root/reference exists (make -C oracle ref)")
+    R = ctypes.CDLL(path)
+    R.ref_hamming_weight.restype = ctypes.c_float
+    R.ref_hamming_weight.argtypes = [ctypes.c_uint32]
+    R.ref_max_hamming_distance.restype = ctypes.c_uint32
+    L = oracle_lib.load().lib
+    L.oracle_retrieval_hamming_weight.restype = ctypes.c_float
+    L.oracle_retrieval_hamming_weight.argtypes = [ctypes.c_uint32]
+    H = _host_lib()
+    assert R.ref_max_hamming_distance() == 24
+    for h in range(65):
+        ref = np.float32(R.ref_hamming_weight(h))
+        assert np.float32(L.oracle_retrieval_hamming_weight(h)) == ref and np.float32(H.dsm_host_sv_hamming_weight(h)) == ref, h
+        assert (ref > 0) == (h <= 24)
