@@ -406,8 +406,12 @@ int VoteAndVerify(const VoteAndVerifyOptions& o, const std::vector<GeometryMatch
   const float scale_norm = 1.0f / (2.0f * max_log_scale);
   const float angle_norm = 1.0f / (2.0f * M_PI);
   const int kLevels = 6;
+  // n_a + num_angle_bins * (n_s + num_scale_bins * (n_x + num_trans_bins * n_y)) as the reference's int expression, with
+  // the two's-complement wrap x86 gives it when a coordinate is INT_MIN (a NaN transformation passes the range tests)
   auto key_of = [&](int na, int ns, int nx, int ny) {
-    return static_cast<uint64_t>(static_cast<int64_t>(na + o.num_angle_bins * (ns + o.num_scale_bins * (nx + o.num_trans_bins * ny))));
+    const uint32_t k = static_cast<uint32_t>(na) + static_cast<uint32_t>(o.num_angle_bins) *
+        (static_cast<uint32_t>(ns) + static_cast<uint32_t>(o.num_scale_bins) * (static_cast<uint32_t>(nx) + static_cast<uint32_t>(o.num_trans_bins) * static_cast<uint32_t>(ny)));
+    return static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(k)));
   };
   // The reference keeps one hash map of bins per level.  Here: the votes in match order, and per level the indices of the
   // votes stably sorted by the level's key -- a run of equal keys is a bin, and inside a run the votes are still in match

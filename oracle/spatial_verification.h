@@ -251,6 +251,18 @@ struct VotingBin {  // vote_and_verify.cc:75-101
   }
 };
 
+// n_a + num_angle_bins * (n_s + num_scale_bins * (n_x + num_trans_bins * n_y)), vote_and_verify.cc:271-274: an int
+// expression in the reference; a NaN transformation passes the range tests and arrives here with INT_MIN coordinates, where
+// the int arithmetic overflows (undefined in C++, a two's-complement wrap on x86 -- which is what this computes).
+inline uint64_t BinIndex(const VoteAndVerifyOptions& options, int n_a, int n_s, int n_x, int n_y) {
+  const uint32_t k = static_cast<uint32_t>(n_a) +
+                     static_cast<uint32_t>(options.num_angle_bins) *
+                         (static_cast<uint32_t>(n_s) +
+                          static_cast<uint32_t>(options.num_scale_bins) *
+                              (static_cast<uint32_t>(n_x) + static_cast<uint32_t>(options.num_trans_bins) * static_cast<uint32_t>(n_y)));
+  return static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(k)));
+}
+
 // VoteAndVerify, vote_and_verify.cc:208-418.  platform_order = true (the definition, and what the product implements): the
 // candidate bins in the order THIS platform's libstdc++ gives the reference's own containers -- std::unordered_map<size_t,
 // ...> iteration order, std::partial_sort'ed by score; false: descending score, equal scores by ascending bin index -- kept
@@ -284,8 +296,7 @@ inline int VoteAndVerify(const VoteAndVerifyOptions& options, const std::vector<
       int n_s = std::min(FloatToInt(s * options.num_scale_bins), static_cast<int>(options.num_scale_bins - 1));
       int n_a = std::min(FloatToInt(a * options.num_angle_bins), static_cast<int>(options.num_angle_bins - 1));
       for (int level = 0; level < kNumLevels; ++level) {
-        const uint64_t index = static_cast<uint64_t>(static_cast<int64_t>(
-            n_a + options.num_angle_bins * (n_s + options.num_scale_bins * (n_x + options.num_trans_bins * n_y))));
+        const uint64_t index = BinIndex(options, n_a, n_s, n_x, n_y);
         if (level == 0) {
           coords_a[index] = n_a;
           coords_s[index] = n_s;
@@ -314,8 +325,7 @@ inline int VoteAndVerify(const VoteAndVerifyOptions& options, const std::vector<
         n_y >>= 1;
         n_s >>= 1;
         n_a >>= 1;
-        const uint64_t index = static_cast<uint64_t>(static_cast<int64_t>(
-            n_a + options.num_angle_bins * (n_s + options.num_scale_bins * (n_x + options.num_trans_bins * n_y))));
+        const uint64_t index = BinIndex(options, n_a, n_s, n_x, n_y);
         score += bins[level][index].num_votes * level_weight;
         level_weight *= 0.5f;
       }

@@ -332,6 +332,20 @@ def test_spatial_leaves_like_the_reference_tests():
         assert a == H.dsm_host_sv_vote_and_verify(n, g1c.ctypes.data, g2c.ctypes.data), trial
         n_pos += a > 0
     assert n_pos > 40
+    # special values anywhere (zero / huge / infinite / NaN coordinates, scales, orientations): NaN transformations pass the
+    # range tests of the vote and arrive at the bin index as INT_MIN coordinates; both sides wrap like x86 does
+    specials = np.array([0.0, -0.0, 1e-30, 1e30, np.inf, -np.inf, np.nan, 1.0, -1.0], np.float32)
+    for trial in range(400):
+        n = int(rng.integers(0, 40))
+        g1 = (rng.uniform(0, 1000, (n, 4))).astype(np.float32)
+        g2 = (rng.uniform(0, 1000, (n, 4))).astype(np.float32)
+        for g in (g1, g2):
+            mask = rng.random((n, 4)) < 0.2
+            g[mask] = specials[rng.integers(0, len(specials), int(mask.sum()))]
+        same = rng.random(n) < 0.3
+        g2[same] = g1[same]
+        g1c, g2c = np.ascontiguousarray(g1), np.ascontiguousarray(g2)
+        assert oracle_lib.sv_vote_and_verify(g1, g2) == H.dsm_host_sv_vote_and_verify(n, g1c.ctypes.data, g2c.ctypes.data), trial
     # a consistent similarity between 200 features is found whole; random positions are not
     n = 200
     g1 = np.c_[rng.uniform(0, 1000, n), rng.uniform(0, 750, n), rng.uniform(1, 5, n), rng.uniform(-3, 3, n)].astype(np.float32)
