@@ -246,8 +246,14 @@ FeatureKeypoints Database::ReadKeypoints(image_t image_id) const {
   sqlite3_bind_int64(st.s, 1, image_id);
   FeatureKeypoints kps;
   if (st.Step() != SQLITE_ROW) return kps;
-  const size_t rows = static_cast<size_t>(sqlite3_column_int64(st.s, 0));
-  const size_t cols = static_cast<size_t>(sqlite3_column_int64(st.s, 1));
+  // (the reference CHECKs the blob size against rows x cols, database.cc:60-88 -> BlobToMatrix; here a malformed row is an
+  // exception the caller reports, never a read past the blob)
+  const sqlite3_int64 rows64 = sqlite3_column_int64(st.s, 0), cols64 = sqlite3_column_int64(st.s, 1);
+  const size_t nb = static_cast<size_t>(sqlite3_column_bytes(st.s, 2));
+  if (rows64 < 0 || (cols64 != 2 && cols64 != 4 && cols64 != 6) || static_cast<uint64_t>(rows64) * static_cast<uint64_t>(cols64) * 4 != nb)
+    throw std::runtime_error("keypoints of image " + std::to_string(image_id) + ": blob size does not match rows x cols (2, 4 or 6 float columns)");
+  const size_t rows = static_cast<size_t>(rows64);
+  const size_t cols = static_cast<size_t>(cols64);
   const float* d = static_cast<const float*>(sqlite3_column_blob(st.s, 2));
   kps.resize(rows);
   for (size_t i = 0; i < rows; ++i) {
@@ -278,16 +284,24 @@ FeatureDescriptors Database::ReadDescriptors(image_t image_id) const {
   sqlite3_bind_int64(st.s, 1, image_id);
   FeatureDescriptors d;
   if (st.Step() != SQLITE_ROW) return d;
-  d.rows = static_cast<size_t>(sqlite3_column_int64(st.s, 0));
-  d.cols = static_cast<size_t>(sqlite3_column_int64(st.s, 1));
+  const sqlite3_int64 rows64 = sqlite3_column_int64(st.s, 0), cols64 = sqlite3_column_int64(st.s, 1);
   const size_t nb = static_cast<size_t>(sqlite3_column_bytes(st.s, 2));
+  if (rows64 < 0 || cols64 != 128 || static_cast<uint64_t>(rows64) * 128u != nb)  // FeatureDescriptors: rows x 128 uint8
+    throw std::runtime_error("descriptors of image " + std::to_string(image_id) + ": blob size does not match rows x 128");
+  d.rows = static_cast<size_t>(rows64);
+  d.cols = static_cast<size_t>(cols64);
   d.data.resize(nb);
   if (nb) std::memcpy(d.data.data(), sqlite3_column_blob(st.s, 2), nb);
   return d;
 }
 
 static FeatureMatches MatchesFromBlob(sqlite3_stmt* s, int col_rows, int col_data) {
-  const size_t rows = static_cast<size_t>(sqlite3_column_int64(s, col_rows));
+  const sqlite3_int64 rows64 = sqlite3_column_int64(s, col_rows);
+  const size_t nb = static_cast<size_t>(sqlite3_column_bytes(s, col_data));
+  const sqlite3_int64 cols64 = sqlite3_column_int64(s, col_rows + 1);  // (rows, cols, data are adjacent columns of both tables)
+  if (rows64 < 0 || cols64 != 2 || static_cast<uint64_t>(rows64) * 8u != nb)  // rows x 2 uint32 (FeatureMatchesFromBlob, database.cc:103-122)
+    throw std::runtime_error("matches blob: size does not match rows x 2 uint32");
+  const size_t rows = static_cast<size_t>(rows64);
   FeatureMatches m(rows);
   const uint32_t* d = static_cast<const uint32_t*>(sqlite3_column_blob(s, col_data));
   for (size_t i = 0; i < rows; ++i) {

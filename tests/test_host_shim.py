@@ -349,3 +349,40 @@ def test_failed_device_call_leaves_existing_rows_alone(tmp_path, async_write, mo
     subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5"])
     again = dbutil.read_results(path)
     assert (again[1][pid]["inliers"] == before[1][pid]["inliers"]).all() and again[1][pid]["F"] == before[1][pid]["F"]
+
+
+def test_malformed_blobs_are_errors_not_overreads(tmp_path):
+    """keypoints / descriptors / matches rows whose `rows` x `cols` do not match the blob (the reference CHECK-aborts in
+    BlobToMatrix / FeatureMatchesFromBlob, database.cc:60-122, 103-122): the shim reports an error; found reading past the
+    blob by an AddressSanitizer run over mutated databases."""
+    L = host()
+    L.dsm_host_cache_lru_probe.restype = ctypes.c_int
+    L.dsm_host_cache_lru_probe.argtypes = [ctypes.c_char_p, ctypes.c_uint32, u32p, ctypes.c_uint32, ctypes.c_uint32]
+    rng = np.random.default_rng(0)
+    ims = [(rng.integers(0, 256, (n, 128)).astype(np.uint8), rng.uniform(0, 100, (n, 2)).astype(np.float32)) for n in (5, 0, 17)]
+    ids = (ctypes.c_uint32 * 3)(1, 2, 3)
+    good = str(tmp_path / "good.db")
+    dbutil.create(good, ims)
+    assert L.dsm_host_cache_lru_probe(good.encode(), 2, ids, 3, 2) >= 0
+    for k, sql in enumerate(["UPDATE keypoints SET rows = 1000 WHERE image_id = 1", "UPDATE keypoints SET cols = 3 WHERE image_id = 3",
+                             "UPDATE keypoints SET rows = -5 WHERE image_id = 1", "UPDATE descriptors SET rows = 999 WHERE image_id = 3",
+                             "UPDATE descriptors SET cols = 64 WHERE image_id = 3", "UPDATE descriptors SET data = NULL WHERE image_id = 1"]):
+        path = str(tmp_path / ("bad%d.db" % k))
+        dbutil.create(path, ims)
+        con = sqlite3.connect(path)
+        con.execute(sql)
+        con.commit()
+        con.close()
+        assert L.dsm_host_cache_lru_probe(path.encode(), 2, ids, 3, 2) < 0, sql
+    # a matches row that claims 50 rows over 24 bytes
+    path = str(tmp_path / "badm.db")
+    dbutil.create(path, ims)
+    con = sqlite3.connect(path)
+    con.execute("INSERT INTO matches VALUES (?, ?, ?, ?)", (dbutil.pair_id(1, 3), 50, 2, b"x" * 24))
+    con.commit()
+    con.close()
+    m, inl = np.zeros((256, 2), np.uint32), np.zeros((256, 2), np.uint32)
+    nm, ni, cfg = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_int(0)
+    q, t = np.zeros(4), np.zeros(3)
+    assert L.dsm_host_db_read_pair(path.encode(), 1, 3, m.ctypes.data_as(u32p), ctypes.byref(nm), ctypes.byref(cfg), q.ctypes.data_as(f64p),
+                                   t.ctypes.data_as(f64p), inl.ctypes.data_as(u32p), ctypes.byref(ni), 256) != 0
