@@ -218,6 +218,12 @@ std::vector<Camera> Database::ReadAllCameras() const {
     c.width = static_cast<size_t>(sqlite3_column_int64(st.s, 2));
     c.height = static_cast<size_t>(sqlite3_column_int64(st.s, 3));
     const size_t nb = static_cast<size_t>(sqlite3_column_bytes(st.s, 4));
+    // (the reference copies num_params_bytes into num_params_bytes / 8 doubles and then CHECKs Camera::VerifyParams,
+    // database.cc ReadCameraRow; here an odd blob or a parameter count that is not the model's is an exception)
+    static const size_t kNumParams[11] = {3, 4, 4, 5, 8, 8, 12, 5, 4, 5, 12};  // camera_models.h:187-349, ids 0 .. 10
+    if (nb % sizeof(double) != 0 || (c.model_id >= 0 && c.model_id <= 10 && nb / sizeof(double) != kNumParams[c.model_id]))
+      throw std::runtime_error("camera " + std::to_string(c.camera_id) + ": the params blob does not hold the parameters of camera model " +
+                               std::to_string(c.model_id));
     c.params.resize(nb / sizeof(double));
     if (nb) std::memcpy(c.params.data(), sqlite3_column_blob(st.s, 4), nb);
     c.prior_focal_length = sqlite3_column_int64(st.s, 5) != 0;

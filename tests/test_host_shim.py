@@ -366,7 +366,9 @@ def test_malformed_blobs_are_errors_not_overreads(tmp_path):
     assert L.dsm_host_cache_lru_probe(good.encode(), 2, ids, 3, 2) >= 0
     for k, sql in enumerate(["UPDATE keypoints SET rows = 1000 WHERE image_id = 1", "UPDATE keypoints SET cols = 3 WHERE image_id = 3",
                              "UPDATE keypoints SET rows = -5 WHERE image_id = 1", "UPDATE descriptors SET rows = 999 WHERE image_id = 3",
-                             "UPDATE descriptors SET cols = 64 WHERE image_id = 3", "UPDATE descriptors SET data = NULL WHERE image_id = 1"]):
+                             "UPDATE descriptors SET cols = 64 WHERE image_id = 3", "UPDATE descriptors SET data = NULL WHERE image_id = 1",
+                             "UPDATE cameras SET params = x'00112233445566778899aabbcc'",   # 13 bytes: not whole doubles
+                             "UPDATE cameras SET model = 4"]):                                # OPENCV wants 8 parameters, the row has 3
         path = str(tmp_path / ("bad%d.db" % k))
         dbutil.create(path, ims)
         con = sqlite3.connect(path)
