@@ -236,6 +236,13 @@ bool VocabularyFile::Read(const std::string& path) {
     return ReadReferenceLayout(path);
   }
   bool ok = std::fread(hdr, 4, 2, f) == 2 && hdr[0] > 0;
+  if (ok) {  // the header's word count must be what the file holds: nothing is allocated on the word of a damaged file
+    const long at = std::ftell(f);
+    ok = at >= 0 && std::fseek(f, 0, SEEK_END) == 0;
+    const long end = ok ? std::ftell(f) : -1;
+    ok = ok && end >= at && static_cast<uint64_t>(end - at) == static_cast<uint64_t>(hdr[0]) * (128 + 64 * 4) + 64ull * 128 * 4 &&
+         std::fseek(f, at, SEEK_SET) == 0;
+  }
   if (ok) {
     num_words = hdr[0];
     words.resize(static_cast<size_t>(num_words) * 128);
