@@ -5,6 +5,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -196,3 +197,26 @@ def test_gather_match_graph_two_ranks_equals_single_process():
         for rank, got in res:
             for a, b in zip(got, ref):
                 assert a.shape == b.shape and (a == b).all(), rank
+
+
+@pytest.mark.parametrize("world,n_images", [(4, 3), (8, 4), (4, 9)])
+def test_gather_match_graph_more_ranks_and_empty_shards(world, n_images):
+    """4 and 8 ranks (the driver's scaling runs), including more ranks than pairs: a rank with an empty shard takes part in
+    every collective with zero rows, and the assembled graph still equals the single-process one."""
+    from dagsfm_amd import sharding, synthetic
+    pairs = synthetic.exhaustive_pairs(n_images).astype(np.int64)
+    ref = _graph_to_numpy(sharding.gather_match_graph(None, _StubSource(pairs, True), 0, 1, sharding.shard_bounds(len(pairs), 1), True))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graph_worker, args=(r, world, port, n_images, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in res) == list(range(world))
+    for rank, got in res:
+        for a, b in zip(got, ref):
+            assert a.shape == b.shape and (a == b).all(), rank
