@@ -67,6 +67,12 @@ def parse_args():
                     help="dsm contexts per GPU: the rank's share of the pair list is cut into that many contiguous parts, each "
                          "matched + verified by its own context / stream / host thread (the latency-bound tails of one part's "
                          "RANSAC rounds overlap with the bulk kernels of another)")
+    ap.add_argument("--force-collectives", nargs="?", const="auto", default="", choices=["", "auto", "padded", "broadcast"],
+                    help="one rank only: form a 1-rank RCCL process group and send the results through the same all-gather / "
+                         "broadcast calls the N-rank exchange makes (the part of the RCCL path a one-GPU box can run); the "
+                         "line then carries the measured exchange time")
+    ap.add_argument("--no-second-regime", action="store_true",
+                    help="skip the low-inlier-ratio side measurement (extra.low_inlier_regime) after the timed region")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="debug: all ranks on device 0 over gloo (exercises the multi-rank path on a 1-GPU box)")
     return ap.parse_args()
@@ -168,6 +174,11 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
         assert dist.get_world_size() == world
+    elif args.force_collectives:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1, device_id=dev)
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    force = {"": None, "auto": True}.get(args.force_collectives, args.force_collectives)
 
     verify = not args.no_verify
     calibrated = not args.uncalibrated
@@ -241,6 +252,8 @@ def main():
         if verify:
             ctxs[k].verify_pairs(topts, user_seed=user_seed, stage_filter=True)
 
+    gather_s = [0.0]  # fetch of this rank's results into torch tensors + the exchange (RCCL all-gather / broadcast)
+
     def step():
         if n_ctx == 1:
             run_part(0)
@@ -250,13 +263,18 @@ def main():
                 t.start()
             for t in th:
                 t.join()
-        return sharding.gather_match_graph(dist, gsource, rank, world, bounds, verify)
+        tg = time.perf_counter()
+        g = sharding.gather_match_graph(dist, gsource, rank, world, bounds, verify, force_collectives=force)
+        torch.cuda.synchronize()
+        gather_s[0] += time.perf_counter() - tg
+        return g
 
     for _ in range(args.warmup):
         step()
     k1_ms, k1_launches, kv_ms, k1b_ms, k1g_ms = 0.0, 0, 0.0, 0.0, 0.0
     graph = None
     barrier()
+    gather_s[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         graph = step()
@@ -322,7 +340,7 @@ def main():
         traffic, traffic_file = None, None
         try:  # HBM bytes per K1 launch from the committed PMC collection (tools/collect_pmc.py), same workload only
             import glob
-            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_k1_pmc*.json"))):
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[34]_k1_pmc*.json"))):
                 pmc = json.load(open(f))
                 if pmc.get("images") == args.images and pmc.get("feats") == args.feats and pmc.get("pairs") == n_pairs and world == 1 \
                         and args.pairs == "exhaustive" and args.shard_of == 1:
@@ -361,7 +379,7 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / int8_peak, "traffic": traffic,
                          "traffic_note": "HBM bytes per launch of both passes, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read "
                                          "correction) + WRITE_SIZE in separate passes (profiles/%s); null when not "
-                                         "collected for this workload" % (traffic_file or "r03_k1_pmc*.json"),
+                                         "collected for this workload" % (traffic_file or "r0*_k1_pmc*.json"),
                          "kernel": "k1_best_rows (pass 1 over all rows + gathered pass 2 of the cross-check)",
                          "avg_launch_ms": 1e3 * (pass1_s + pass2_s), "avg_launch_ms_pass1": 1e3 * pass1_s,
                          "avg_launch_ms_pass2": 1e3 * pass2_s, "launches": k1_launches, "peak_source": peaks_note,
@@ -370,6 +388,25 @@ def main():
                                  "(SURVEY.md 8d) over the HIP-event time of BOTH k1_best_rows launches; pass 2 recomputes only "
                                  "the rows matches12 points at (~7 % of the matrix at this shape)"},
         }
+        # ---- the exchange: fetch of the rank's results into torch tensors + all-gather / broadcast of the match graph
+        result_bytes = 16 * n_pairs + 8 * res["matches"] + (ctypes.sizeof(capi.TwoViewGeometry) * n_pairs + 8 * res["inliers"] if verify else 0)
+        out["exchange"] = {"gather_ms_per_step": 1e3 * gather_s[0] / args.steps, "bytes_per_step": result_bytes,
+                           "backend": (dist.get_backend() if dist.is_initialized() else "none (single rank, no collective)"),
+                           "forced_on_one_rank": bool(world == 1 and force),
+                           "note": "device-to-device fetch through the C-ABI getters + the collectives of sharding.gather_match_graph "
+                                   "(rank 0's wall time, inside the timed region)"}
+        # executed matrix-pipe work: SQ_INSTS_VALU_MFMA_I8 (x 65 536 ops per 32x32x32 instruction) of both passes from the
+        # committed PMC collection of the same workload, over THIS run's HIP-event time
+        try:
+            if traffic_file is not None and pass1_s > 0:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))
+                mi = pmc.get("SQ_INSTS_VALU_MFMA_I8", {})
+                if "pass1" in mi:
+                    insts = mi["pass1"]["mean_per_dispatch"] + mi.get("pass2", {}).get("mean_per_dispatch", 0.0)
+                    out["roofline"]["executed_frac"] = insts * 65536.0 / (pass1_s + pass2_s) / int8_peak
+                    out["roofline"]["executed_note"] = "SQ_INSTS_VALU_MFMA_I8 of both passes (profiles/%s) x 65 536 int8 ops over this run's launch time" % traffic_file
+        except Exception:
+            pass
         if pass1_s > 0 and res["matches"] >= 0:
             # what the matrix pipe executed: pass 1 = the whole matrix; pass 2 = gathered rows in 128-row wave units
             out["roofline"]["frac_pass1_only"] = ops_per_pair * pairs_per_launch / pass1_s / int8_peak
@@ -379,6 +416,46 @@ def main():
                                       "frac": ach / fp64_peak, "traffic": None,
                                       "note": "algorithmic inlier-scoring flops only (33 / 20 / 5 per model x correspondence), "
                                               "per GPU, over the HIP-event time of all verification kernels"}
+            try:  # executed FP64 instruction rates per kernel from the committed counter collection (tools/collect_pmc.py --verify)
+                vf = os.path.join(ROOT, "profiles", "r04_verify_pmc.json")
+                if os.path.exists(vf) and world == 1 and args.images == 500 and args.feats == 4096 and args.pairs == "exhaustive" \
+                        and calibrated and args.shard_of == 1 and not args.fixed_trials:
+                    vp = json.load(open(vf))
+                    out["roofline_verify"]["executed"] = vp.get("summary")
+                    out["roofline_verify"]["executed_note"] = "profiles/r04_verify_pmc.json: per-kernel FP64 VALU instructions x 64 lanes (ADD/MUL = 1, FMA = 2 flops) over the kernels' own durations, one lane"
+            except Exception:
+                pass
+        # ---- second regime: the same pipeline where real collections live -- half of every image's
+        # features are not observations of the scene, a putative match is right with 0.25 instead of 0.64, RANSAC needs ~13x
+        # the trials.  150 images x the same feature count, after the timed region; never part of `value`.
+        if world == 1 and verify and not args.no_second_regime and args.shard_of == 1 and not args.max_pairs and args.images >= 150 \
+                and args.pairs == "exhaustive" and not args.fixed_trials and args.outlier_frac < 0.5:
+            try:
+                n2 = 150
+                scene2 = synthetic.Scene(n2, args.feats, seed=args.seed, outlier_frac=0.5)
+                im2 = [scene2.image(i) for i in range(n2)]
+                cams2 = cams[:n2]
+                pairs2 = synthetic.exhaustive_pairs(n2)
+                ctx.set_images([im[0] for im in im2], [im[1] for im in im2], cams2)
+                t_steps, kv2 = [], 0.0
+                for it in range(3):  # one warm-up + two timed steps
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                    ctx.match_pairs(pairs2, opts)
+                    ctx.verify_pairs(topts, user_seed=user_seed, stage_filter=True)
+                    ctx.sync()
+                    if it:
+                        t_steps.append(time.perf_counter() - ts)
+                        kv2 += ctx.verify_kernel_time()
+                tv2 = ctx.two_view_geometries()
+                out["extra"] = {"low_inlier_regime": {
+                    "pairs_per_s": len(pairs2) * len(t_steps) / sum(t_steps), "verify_us_per_pair": 1e3 * kv2 / len(t_steps) / len(pairs2),
+                    "ms_per_step": 1e3 * sum(t_steps) / len(t_steps), "pairs": int(len(pairs2)),
+                    "pairs_with_geometry": int(sum(1 for t in tv2 if t.config > 1)),
+                    "workload": "%d images x %d feats, exhaustive, outlier_frac 0.5 (putative inlier ratio 0.25), %s; 2 steps after "
+                                "the timed region, not part of value" % (n2, args.feats, fam)}}
+            except Exception as e:  # the side measurement must never cost the headline line
+                out["extra"] = {"low_inlier_regime": {"error": repr(e)}}
         if world == 1 and args.cpu_seconds > 0:
             from tests import oracle_lib
             cores = min(host_cores(), 256)
@@ -393,6 +470,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -155,20 +155,54 @@ def default_two_view_options(**kw):
     return o
 
 
+# the keys dsm_set_debug_option knows (DESIGN.md "Tuning / debugging hooks")
+DEBUG_OPTION_KEYS = ("DSM_MATCH_CHUNK_ROWS", "DSM_K1_DOT4", "DSM_VERIFY_DEBUG", "DSM_SAMPLER_SERIAL", "DSM_LO_PREPARE_WAVE",
+                     "DSM_LO_JACOBI_GROUPS", "DSM_ROOTS_LDS", "DSM_FINAL_WAVES", "DSM_VERIFY_LEGACY", "DSM_VERIFY_LANES",
+                     "DSM_VERIFY_FIXED_BATCH", "DSM_VERIFY_LANE_SPLIT", "DSM_VERIFY_CHUNK_PAIRS", "DSM_VERIFY_GRID_DIV",
+                     "DSM_VERIFY_INLINE_LO", "DSM_LO_TAIL", "DSM_LO_TAIL_MODE", "DSM_VERIFY_ITEM_MODE", "DSM_DEBUG_SAMPLER_MODE",
+                     "DSM_VOCAB_ASSIGN_VALU", "DSM_VERIFY_HOST_LOOP")
+
+
 class Context:
     """One context = one GPU (SiftFeatureMatcher + FeatureMatcherCache of the reference)."""
 
     def __init__(self, device=0):
-        self._h = ctypes.c_void_p()
-        rc = lib().dsm_ctx_create(device, ctypes.byref(self._h))
+        self._handle = ctypes.c_void_p()
+        self._debug = {}
+        rc = lib().dsm_ctx_create(device, ctypes.byref(self._handle))
         if rc != 0:
             raise DsmError("dsm_ctx_create failed (%d): %s" % (rc, lib().dsm_last_error(None).decode()))
         self.n_pairs = 0
 
+    @property
+    def _h(self):
+        """The context handle.  The library itself never reads the environment (dsm_set_debug_option is the only way in);
+        this TEST / TOOL binding forwards the DSM_* debug variables of the process to the context before every call, so
+        that `DSM_VERIFY_LANES=1 python tools/...` and monkeypatch.setenv in the tests keep working."""
+        if self._handle:
+            for key in DEBUG_OPTION_KEYS:
+                want = os.environ.get(key)
+                if self._debug.get(key) != want:
+                    self.set_debug_option(key, want)
+        return self._handle
+
+    def set_debug_option(self, key, value):
+        """dsm_set_debug_option: a scheduling / cross-check switch of this context (None removes it)."""
+        L = lib()
+        L.dsm_set_debug_option.restype = ctypes.c_int
+        L.dsm_set_debug_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
+        rc = L.dsm_set_debug_option(self._handle, key.encode(), None if value is None else str(value).encode())
+        if rc != 0:
+            raise DsmError("dsm_set_debug_option(%s) failed (%d)" % (key, rc))
+        if value is None:
+            self._debug.pop(key, None)
+        else:
+            self._debug[key] = str(value)
+
     def close(self):
-        if self._h:
-            lib().dsm_ctx_destroy(self._h)
-            self._h = ctypes.c_void_p()
+        if self._handle:
+            lib().dsm_ctx_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
 
     def __del__(self):
         try:

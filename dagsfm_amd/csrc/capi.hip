@@ -176,6 +176,23 @@ int dsm_sync(dsm_ctx* ctx) {
   return DSM_OK;
 }
 
+int dsm_set_debug_option(dsm_ctx* ctx, const char* key, const char* value) {
+  static const char* const kKnown[] = {
+      "DSM_MATCH_CHUNK_ROWS", "DSM_K1_DOT4", "DSM_VERIFY_DEBUG", "DSM_SAMPLER_SERIAL", "DSM_LO_PREPARE_WAVE", "DSM_LO_JACOBI_GROUPS",
+      "DSM_ROOTS_LDS", "DSM_FINAL_WAVES", "DSM_VERIFY_LEGACY", "DSM_VERIFY_LANES", "DSM_VERIFY_FIXED_BATCH", "DSM_VERIFY_LANE_SPLIT",
+      "DSM_VERIFY_CHUNK_PAIRS", "DSM_VERIFY_GRID_DIV", "DSM_VERIFY_INLINE_LO", "DSM_LO_TAIL", "DSM_LO_TAIL_MODE", "DSM_VERIFY_ITEM_MODE",
+      "DSM_DEBUG_SAMPLER_MODE", "DSM_VOCAB_ASSIGN_VALU", "DSM_VERIFY_HOST_LOOP"};
+  if (!ctx || !key) return DSM_ERR_INVALID_ARGUMENT;
+  bool known = false;
+  for (const char* k : kKnown) known = known || strcmp(k, key) == 0;
+  if (!known) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "dsm_set_debug_option: unknown key");
+  if (value)
+    ctx->debug_options[key] = value;
+  else
+    ctx->debug_options.erase(key);
+  return DSM_OK;
+}
+
 // dsm_set_images (append = false: the resident set is replaced) and dsm_append_images (append = true: the images
 // already on the device stay where they are, the new ones get the next indices and only THEIR rows cross PCIe).
 static int upload_images(dsm_ctx* ctx, bool append, uint32_t n_new, const uint32_t* n_feats, const uint8_t* const* desc,
@@ -311,7 +328,7 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
 
   // Chunk the pair list so that the K1 output scratch stays below a fixed budget.
   uint64_t budget_rows = (8ull << 30) / 8;  // two int32 per row: the result and K1's second-best value for K1b
-  if (const char* e = getenv("DSM_MATCH_CHUNK_ROWS")) budget_rows = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // test hook
+  if (const char* e = ctx->dbg("DSM_MATCH_CHUNK_ROWS")) budget_rows = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // test hook
   std::vector<uint2> dpairs, dpairs2;
   std::vector<uint64_t> doff;
   std::vector<uint4> pdir;
@@ -385,7 +402,7 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
       ctx->ev.push_back(e);
     }
     // DSM_K1_DOT4=1: the LDS-tiled v_dot4 variant of pass 1 (comparison runs only, profiles/r02_k1_variants.md)
-    const bool k1_dot4 = getenv("DSM_K1_DOT4") != nullptr;
+    const bool k1_dot4 = ctx->dbg("DSM_K1_DOT4") != nullptr;
     HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used], st));
     if (k1_dot4)
       launch_k1_dot4(k1, nc, max_rb, st);
@@ -566,6 +583,7 @@ int dsm_match_sift_features(dsm_ctx* ctx, const dsm_match_options* options, cons
     if (rc != DSM_OK) return fail(ctx, rc, dsm_last_error(nullptr));
   }
   dsm_ctx* lf = ctx->leaf;
+  lf->debug_options = ctx->debug_options;
   const uint32_t nf[2] = {n1, n2};
   const uint8_t* dp[2] = {desc1, desc2};
   int rc = dsm_set_images(lf, 2, nf, dp, nullptr, 0, nullptr);
@@ -835,7 +853,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
     launch_vp_final(vp, nb_heavy, st);
     LANECHK(L, hipGetLastError());
   }
-  if (getenv("DSM_VERIFY_DEBUG")) LANECHK(L, hipMemcpyAsync(L.dbg, actr, 128, hipMemcpyDeviceToHost, st));
+  if (ctx->dbg("DSM_VERIFY_DEBUG")) LANECHK(L, hipMemcpyAsync(L.dbg, actr, 128, hipMemcpyDeviceToHost, st));
   LANECHK(L, hipEventRecord(L.done, st));
   LANECHK(L, hipStreamSynchronize(st));
 }
@@ -907,7 +925,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.n_pairs = n_pairs;
   vp.n_max = n_max;
   vp.stage_filter = stage_filter;
-  vp.sampler_serial = getenv("DSM_SAMPLER_SERIAL") ? 1 : 0;
+  vp.sampler_serial = ctx->dbg("DSM_SAMPLER_SERIAL") ? 1 : 0;
   vp.reseed = reseed ? 1 : 0;
   vp.keep_generator = keep_generator ? 1 : 0;
   if (!ctx->vev0) {
@@ -924,8 +942,11 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.counts = nullptr;
   vp.sums = nullptr;
   vp.first_batch[0] = vp.first_batch[1] = vp.first_batch[2] = 0;
-  vp.stats = getenv("DSM_VERIFY_DEBUG") ? 1 : 0;
-  vp.lo_reg_prepare = getenv("DSM_LO_PREPARE_WAVE") ? 0 : 1;  // =1: the round-2 kernel (matrix in global scratch) for every problem
+  vp.stats = ctx->dbg("DSM_VERIFY_DEBUG") ? 1 : 0;
+  vp.lo_reg_prepare = ctx->dbg("DSM_LO_PREPARE_WAVE") ? 0 : 1;
+  vp.dbg_jacobi_groups = ctx->dbg("DSM_LO_JACOBI_GROUPS") ? 1 : 0;  // the 8-lane-group Jacobi kernel for every problem (round-2 form)
+  vp.dbg_roots_lds = ctx->dbg("DSM_ROOTS_LDS") ? 1 : 0;              // k_roots_e_lds instead of the register form
+  vp.dbg_final_waves = ctx->dbg("DSM_FINAL_WAVES") ? atoi(ctx->dbg("DSM_FINAL_WAVES")) : 0;  // =1: the round-2 kernel (matrix in global scratch) for every problem
   vp.models = nullptr;
   vp.e_work = nullptr;
   vp.sidx_g = nullptr;
@@ -942,7 +963,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.lo_jobs = nullptr;
   vp.lo_inl_pool = nullptr;
   vp.job_list = nullptr;
-  const bool legacy = getenv("DSM_VERIFY_LEGACY") != nullptr;  // single-kernel-per-family schedule (debug)
+  const bool legacy = ctx->dbg("DSM_VERIFY_LEGACY") != nullptr;  // single-kernel-per-family schedule (debug)
   if (legacy) {
     HIPCHK(ctx, ctx->d_vscratch.reserve(std::max<size_t>(1, (size_t)n_blocks * verify_scratch_bytes_per_block(n_max))));
     vp.scratch = ctx->d_vscratch.as<double>();
@@ -976,7 +997,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     // the generator state E ends with -- but different pairs can, and the replay / local-optimisation launches of
     // one lane are latency chains that leave most of the chip idle.
     uint32_t n_lanes = n_pairs >= 4096 ? 2 : 1;
-    if (const char* e = getenv("DSM_VERIFY_LANES")) n_lanes = (uint32_t)std::max(1, std::min(DSM_VERIFY_MAX_LANES, atoi(e)));
+    if (const char* e = ctx->dbg("DSM_VERIFY_LANES")) n_lanes = (uint32_t)std::max(1, std::min(DSM_VERIFY_MAX_LANES, atoi(e)));
     n_lanes = std::max<uint32_t>(1, std::min<uint32_t>(n_lanes, n_pairs));
     // Scratch of the speculated trials: as much of the pair list per chunk as memory allows (every chunk pays the
     // latency tail of its sequential rounds, so fewer chunks are faster): up to 40 % of what is free now, at
@@ -997,7 +1018,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     // ~60 / ~150 trials at a 64 % inlier ratio), every later round what its dynamic stop still asks for.  At a 25 %
     // ratio that is thousands of trials (E 5 400, F 10 000: measured), i.e. a hundred rounds of 64 -- so the buffers
     // grow (E up to 512, F up to 1 024 trials per round) as long as the whole list still fits a quarter of the budget.
-    if (!getenv("DSM_VERIFY_FIXED_BATCH")) {
+    if (!ctx->dbg("DSM_VERIFY_FIXED_BATCH")) {
       for (bool grew = true; grew;) {
         grew = false;
         for (int f = 1; f >= 0; --f) {
@@ -1018,8 +1039,8 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     // Equal shares (measured: giving the first lane 0.6 - 0.8 of the list to push the lanes out of phase is 1 - 2 %
     // slower than 0.5; three lanes are slower than two).  DSM_VERIFY_LANE_SPLIT = share of the first lane.
     double first_share = 1.0 / n_lanes;
-    if (const char* e = getenv("DSM_VERIFY_LANE_SPLIT")) first_share = std::min(0.95, std::max(0.05, atof(e)));
-    const char* cp = getenv("DSM_VERIFY_CHUNK_PAIRS");  // test hook: force several chunks on a small pair list
+    if (const char* e = ctx->dbg("DSM_VERIFY_LANE_SPLIT")) first_share = std::min(0.95, std::max(0.05, atof(e)));
+    const char* cp = ctx->dbg("DSM_VERIFY_CHUNK_PAIRS");  // test hook: force several chunks on a small pair list
     uint32_t at = 0;
     for (uint32_t li = 0; li < n_lanes; ++li) {
       uint32_t cnt = (li == 0 && n_lanes > 1) ? (uint32_t)(n_pairs * first_share + 0.5) : (n_pairs - at) / (n_lanes - li);
@@ -1035,7 +1056,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     plan.dev_cus = dev_cus;
     // persistent grids sized for a lane's share of the chip: two lanes 362.5 vs 366.3 ms at config 2, 193.5 vs 205.1 on its half
     plan.grid_div = n_lanes;
-    if (const char* e = getenv("DSM_VERIFY_GRID_DIV")) plan.grid_div = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = ctx->dbg("DSM_VERIFY_GRID_DIV")) plan.grid_div = (uint32_t)std::max(1, atoi(e));
     // Local optimisation: batched kernels (k_replay_lo + k_lo_*) or inline in the replay (k_replay).  The batched form
     // wins on throughput (config 2, 124 750 pairs: 416 vs 702 ms) but every LO iteration costs a kernel round trip; it
     // hands the last <= lo_tail queued pairs of a round (F, H) to an inline finish, which keeps it ahead or level down
@@ -1043,16 +1064,16 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     // lists shorter than lo_tail, where the batched one would only add a launch.
     // DSM_VERIFY_INLINE_LO=1 / =0 forces one or the other (tests cover both).
     plan.inline_lo = n_pairs < 256u;  // (round 2: below 2 048; with item passes the batched kernels are ahead from ~1 000 pairs on: 1 225 pairs 14.7 vs 19.8 ms)
-    if (const char* e = getenv("DSM_VERIFY_INLINE_LO")) plan.inline_lo = atoi(e) != 0;
+    if (const char* e = ctx->dbg("DSM_VERIFY_INLINE_LO")) plan.inline_lo = atoi(e) != 0;
     // queue length at which the chain hands the rest of a round to an item pass.  Measured (round 3, item-pass tail): 2 048 /
     // 4 096 / 8 192 / 16 384 / 32 768 -> 370.6 / 373.2 / 366.3 / 373.1 / 375.9 ms at config 2, 61.7 / 61.0 / 57.5 / 57.8 / 57.7 ms on its 1/8 shard
     plan.lo_tail = 8192;
-    if (const char* e = getenv("DSM_LO_TAIL")) plan.lo_tail = (uint32_t)std::max(0, atoi(e));
-    if (const char* e = getenv("DSM_LO_TAIL_MODE")) plan.tail_items = strcmp(e, "inline") != 0;
+    if (const char* e = ctx->dbg("DSM_LO_TAIL")) plan.lo_tail = (uint32_t)std::max(0, atoi(e));
+    if (const char* e = ctx->dbg("DSM_LO_TAIL_MODE")) plan.tail_items = strcmp(e, "inline") != 0;
     // item passes from the start of every round for short lists: 4 950 pairs 24.3 vs 28.5 ms, 15 593 pairs (1/8 of config 2)
     // 55.8 vs 57.5, 31 187 pairs level, 124 750 pairs 395 vs 366 (the speculative half of the items is throughput there)
     plan.item_mode = n_pairs <= 24000u;
-    if (const char* e = getenv("DSM_VERIFY_ITEM_MODE")) plan.item_mode = atoi(e) != 0;
+    if (const char* e = ctx->dbg("DSM_VERIFY_ITEM_MODE")) plan.item_mode = atoi(e) != 0;
     HIPCHK(ctx, ctx->d_fam_state.reserve(std::max<size_t>(n_pairs, 1) * 3 * sizeof(FamState)));
     HIPCHK(ctx, ctx->d_sidx.reserve(tm * 4));
     HIPCHK(ctx, ctx->d_lo_inl.reserve(tm * 4));
@@ -1159,7 +1180,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
         ctx->verify_lo_iters[f] = std::max(ctx->verify_lo_iters[f], ctx->lanes[li].lo_iters[f]);
       }
     }
-    if (getenv("DSM_VERIFY_DEBUG")) {
+    if (ctx->dbg("DSM_VERIFY_DEBUG")) {
       uint32_t dbg[32] = {0};
       unsigned long long cyc[3] = {0, 0, 0};
       for (uint32_t li = 0; li < n_lanes; ++li) {
@@ -1592,6 +1613,7 @@ int dsm_estimate_two_view_geometry(dsm_ctx* ctx, const dsm_camera* camera1, cons
     if (rc != DSM_OK) return fail(ctx, rc, dsm_last_error(nullptr));
   }
   dsm_ctx* lf = ctx->leaf;
+  lf->debug_options = ctx->debug_options;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   DevBuf kp, row0, cams, pr, off, mt, sd;
   const uint32_t rows0[2] = {0, n1};
@@ -1651,7 +1673,7 @@ int dsm_debug_sample_sequence(dsm_ctx* ctx, uint32_t seed, uint32_t k, uint32_t 
   HIPCHK(ctx, idx.reserve((size_t)total * 4));
   HIPCHK(ctx, tmp7.reserve((size_t)n_draws * 7 * 4 + 4));
   // 1 (default): the wave sampler of the product path; 0: lane-0 reference loop; 2: the sampler's serial replay path
-  const char* mode_env = getenv("DSM_DEBUG_SAMPLER_MODE");
+  const char* mode_env = ctx->dbg("DSM_DEBUG_SAMPLER_MODE");
   int mode = mode_env ? atoi(mode_env) : 1;
   if (!(k == 1 || k == 4 || k == 5 || k == 7)) mode = 0;
   launch_debug_samples(seed, k, total, n_draws, o.as<uint32_t>(), idx.as<uint32_t>(), tmp7.as<uint32_t>(), mode, ctx->stream);

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -125,6 +126,14 @@ struct dsm_ctx {
   hipEvent_t vev0 = nullptr, vev1 = nullptr;
 
   dsm_ctx* leaf = nullptr;  // private context of the one-shot leaf entry points
+
+  // dsm_set_debug_option: scheduling / cross-check switches of THIS context (none changes a result).  The library never
+  // reads the process environment: a host application's environment cannot change schedules.
+  std::map<std::string, std::string> debug_options;
+  const char* dbg(const char* key) const {
+    const auto it = debug_options.find(key);
+    return it == debug_options.end() ? nullptr : it->second.c_str();
+  }
 
   struct RetrievalState* retrieval = nullptr;  // vocabulary-tree retrieval (retrieval.hip), created on first use
 };

@@ -162,7 +162,11 @@ DSM_XT dd cos_kernel(dd r) {  // 1 - r^2/2! + ... + r^28/28!
 
 // x = k * pi/2 + r with |r| <= pi/4 (+ a little).  pi/2 is split into 33 + 33 + 33 + 53 bits: k * part is exact
 // for |k| < 2^20, and x - k * p0 is exact (Sterbenz) -- the cancellation costs no accuracy.  |x| < 2^20 * pi/2 is the
-// supported range (beyond it the reduction loses accuracy gracefully; angles of a camera model are < pi).
+// supported range; beyond it (garbage camera parameters: angles of a camera model are < pi) sin / cos / tan return NaN
+// on the device and in the oracle alike -- the cast of k to an integer below would be undefined from |x| ~ 1.4e19 on,
+// and "loses accuracy" is not a contract two builds can share.
+#define DSM_XT_MAX_ARG 1647099.0  /* < 2^20 * pi/2 */
+DSM_XT bool trig_arg_supported(double x) { return (x < 0.0 ? -x : x) <= DSM_XT_MAX_ARG; }
 DSM_XT dd reduce_pio2(double x, int* quadrant) {
   double kd = x * kTwoOverPi;
   kd = (kd >= 0.0) ? (double)(long long)(kd + 0.5) : -(double)(long long)(0.5 - kd);
@@ -181,6 +185,7 @@ DSM_XT dd reduce_pio2(double x, int* quadrant) {
 DSM_XT double dsm_sin(double x) {
   using namespace dsm_xt;
   if (!(x == x) || x - x != 0.0) return x - x;  // NaN, inf
+  if (!dsm_xt::trig_arg_supported(x)) return __builtin_nan("");  // outside the supported range: NaN in both builds
   int q;
   const dd r = reduce_pio2(x, &q);
   const dd v = (q & 1) ? cos_kernel(r) : sin_kernel(r);
@@ -190,6 +195,7 @@ DSM_XT double dsm_sin(double x) {
 DSM_XT double dsm_cos(double x) {
   using namespace dsm_xt;
   if (!(x == x) || x - x != 0.0) return x - x;
+  if (!dsm_xt::trig_arg_supported(x)) return __builtin_nan("");  // outside the supported range: NaN in both builds
   int q;
   const dd r = reduce_pio2(x, &q);
   const dd v = (q & 1) ? sin_kernel(r) : cos_kernel(r);
@@ -198,6 +204,7 @@ DSM_XT double dsm_cos(double x) {
 DSM_XT double dsm_tan(double x) {
   using namespace dsm_xt;
   if (!(x == x) || x - x != 0.0) return x - x;
+  if (!dsm_xt::trig_arg_supported(x)) return __builtin_nan("");  // outside the supported range: NaN in both builds
   if (x == 0.0) return x;
   int q;
   const dd r = reduce_pio2(x, &q);

@@ -657,7 +657,7 @@ static int retrieval_assign(dsm_ctx* ctx, uint32_t k) {
   RCHK(ctx, r->d_wid.reserve(std::max<uint64_t>(rows, 1) * RK_MAX * 4));
   RCHK(ctx, r->d_sig.reserve(std::max<uint64_t>(rows, 1) * RK_MAX * 8));
   if (rows) {
-    if (getenv("DSM_VOCAB_ASSIGN_VALU"))  // the LDS-tiled v_dot4 form (comparison / cross-check)
+    if (ctx->dbg("DSM_VOCAB_ASSIGN_VALU"))  // the LDS-tiled v_dot4 form (comparison / cross-check)
       hipLaunchKernelGGL(k_vocab_assign, dim3((uint32_t)((rows + 511) / 512)), dim3(256), 0, st, ctx->d_desc.as<int8_t>(),
                          r->d_row_img.as<int32_t>(), rows, r->d_words.as<int8_t>(), r->d_cw.as<int32_t>(), r->num_words, r->words_padded, (int)k,
                          r->d_wid.as<int32_t>());

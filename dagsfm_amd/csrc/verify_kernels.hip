@@ -3280,7 +3280,7 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint
                          hipStream_t st) {
   if (!p.n_work || !n_blocks) return;
   const dim3 g4((p.n_work + 64 / LOJ_G - 1) / (64 / LOJ_G)), g64((p.n_work + 63) / 64);
-  const bool reg_jacobi = getenv("DSM_LO_JACOBI_GROUPS") == nullptr;  // =1: the 8-lane-group kernel for every problem (round-2 form)
+  const bool reg_jacobi = !p.dbg_jacobi_groups;  // =1: the 8-lane-group kernel for every problem (round-2 form)
   const bool reg_prepare = p.lo_reg_prepare && n_wave_prepare < p.n_work;
   // the general kernels work through k_replay_lo's list of the problems that need them (a handful per iteration: the
   // first local optimisations of a pair have 6 - 9 inliers), not through the whole queue
@@ -3343,7 +3343,7 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
   if (fam == FAM_E) {
     hipLaunchKernelGGL(k_solve_e_build, grid, dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_solve_e_lu, grid, dim3(64), ELU_SMEM, st, p);
-    const bool roots_lds = getenv("DSM_ROOTS_LDS") != nullptr;
+    const bool roots_lds = p.dbg_roots_lds != 0;
     if (roots_lds)
       hipLaunchKernelGGL(k_roots_e_lds, grid, dim3(64), 100 * 64 * sizeof(double), st, p);
     else
@@ -3375,8 +3375,7 @@ static void launch_final_pose_finish(const VerifyParams& p, uint32_t n_blocks, h
 }
 void launch_vp_final(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
   if (!p.n_pairs || !n_blocks) return;
-  const char* fw = getenv("DSM_FINAL_WAVES");
-  if (fw && atoi(fw) == 1)
+  if (p.dbg_final_waves == 1)
     hipLaunchKernelGGL(k_verify_final<1>, dim3(n_blocks), dim3(64), verify_smem_bytes(p.n_max), st, p);
   else
     hipLaunchKernelGGL(k_verify_final<2>, dim3(n_blocks), dim3(64), verify_smem_bytes(p.n_max), st, p);

@@ -292,6 +292,9 @@ FeatureDescriptors Database::ReadDescriptors(image_t image_id) const {
   if (st.Step() != SQLITE_ROW) return d;
   const sqlite3_int64 rows64 = sqlite3_column_int64(st.s, 0), cols64 = sqlite3_column_int64(st.s, 1);
   const size_t nb = static_cast<size_t>(sqlite3_column_bytes(st.s, 2));
+  // an image without features may be stored as a 0 x 0 (or 0 x anything) matrix with an empty blob: the reference's
+  // ReadDynamicMatrixBlob only CHECKs rows * cols * size == num_bytes (database.cc:60-77) and returns it
+  if (rows64 == 0 && nb == 0 && cols64 >= 0) return d;
   if (rows64 < 0 || cols64 != 128 || static_cast<uint64_t>(rows64) * 128u != nb)  // FeatureDescriptors: rows x 128 uint8
     throw std::runtime_error("descriptors of image " + std::to_string(image_id) + ": blob size does not match rows x 128");
   d.rows = static_cast<size_t>(rows64);
@@ -459,6 +462,10 @@ void Database::DeleteInlierMatches(image_t a, image_t b) const {
 
 void Database::BeginTransaction() const { Exec("BEGIN TRANSACTION;"); }
 void Database::EndTransaction() const { Exec("END TRANSACTION;"); }
-void Database::RollbackTransaction() const { Exec("ROLLBACK TRANSACTION;"); }
+void Database::RollbackTransaction() const {
+  // nothing to roll back outside a transaction (sqlite would answer "cannot rollback - no transaction is active")
+  if (database_ != nullptr && sqlite3_get_autocommit(database_)) return;
+  Exec("ROLLBACK TRANSACTION;");
+}
 
 }  // namespace dagsfm_amd

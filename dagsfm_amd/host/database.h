@@ -93,7 +93,17 @@ class DatabaseTransaction {
   }
   void Commit() {
     done_ = true;
-    database_->EndTransaction();
+    try {
+      database_->EndTransaction();
+    } catch (...) {
+      // a COMMIT that failed (SQLITE_BUSY, SQLITE_FULL) leaves the transaction open: close it without its rows, so that
+      // the next BeginTransaction does not fail with "cannot start a transaction within a transaction"
+      try {
+        database_->RollbackTransaction();
+      } catch (...) {
+      }
+      throw;
+    }
   }
   void Rollback() {
     done_ = true;

@@ -4,15 +4,20 @@
 #include <iostream>
 #include <string>
 
-extern "C" int dsm_host_exhaustive_matcher_ex(const char* database_path, int block_size, int use_prior_defaults,
-                                              unsigned random_seed, double max_ratio, double max_distance, int cross_check,
-                                              int min_num_inliers, int guided_matching, int multiple_models);
+extern "C" int dsm_host_exhaustive_matcher_ex2(const char* database_path, int block_size, int use_prior_defaults,
+                                               unsigned random_seed, double max_ratio, double max_distance, int cross_check,
+                                               int min_num_inliers, int guided_matching, int multiple_models,
+                                               const char* gpu_index, int async_write_back);
 
 int main(int argc, char** argv) {
   std::string db;
   int block = 1000;  // the reference's default of 50 bounds its host cache; here a large block amortises the per-call costs
   unsigned seed = 0;
   int guided = 0, multiple = 0;
+  std::string gpu_index = "-1";  // all visible devices
+  // this executable's own switch for the tests / tools (the libraries read no environment): DSM_ASYNC_WRITE_BACK=1 is
+  // --SiftMatching.async_write_back 1
+  int async_write_back = std::getenv("DSM_ASYNC_WRITE_BACK") != nullptr ? 1 : 0;
   for (int i = 1; i + 1 < argc; i += 2) {
     const std::string k = argv[i];
     if (k == "--database_path") db = argv[i + 1];
@@ -20,12 +25,14 @@ int main(int argc, char** argv) {
     else if (k == "--random_seed") seed = static_cast<unsigned>(std::strtoul(argv[i + 1], nullptr, 10));
     else if (k == "--SiftMatching.guided_matching") guided = std::atoi(argv[i + 1]);
     else if (k == "--SiftMatching.multiple_models") multiple = std::atoi(argv[i + 1]);
-    else if (k == "--SiftMatching.gpu_index") setenv("DSM_GPU_INDEX", argv[i + 1], 1);  // "-1" (default): all visible devices
+    else if (k == "--SiftMatching.gpu_index") gpu_index = argv[i + 1];
+    else if (k == "--SiftMatching.async_write_back") async_write_back = std::atoi(argv[i + 1]);
   }
   if (db.empty()) {
     std::cerr << "usage: dsm_exhaustive_matcher --database_path database.db [--ExhaustiveMatching.block_size 1000] [--random_seed 0]"
-                 " [--SiftMatching.guided_matching 0] [--SiftMatching.multiple_models 0] [--SiftMatching.gpu_index -1]\n";
+                 " [--SiftMatching.guided_matching 0] [--SiftMatching.multiple_models 0] [--SiftMatching.gpu_index -1]"
+                 " [--SiftMatching.async_write_back 0]\n";
     return 64;
   }
-  return dsm_host_exhaustive_matcher_ex(db.c_str(), block, 1, seed, 0, 0, 1, 15, guided, multiple);
+  return dsm_host_exhaustive_matcher_ex2(db.c_str(), block, 1, seed, 0, 0, 1, 15, guided, multiple, gpu_index.c_str(), async_write_back);
 }

@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <cstring>
 #include <iostream>
+#include <mutex>
+#include <thread>
 #include <stdexcept>
 #include <unordered_set>
 
@@ -142,8 +144,14 @@ bool ExhaustiveFeatureMatcher::Run() {
         try {
           matcher_.Match(image_pairs);
         } catch (...) {
-          database_transaction.Rollback();   // nothing of a failed block is committed ...
-          cache_.RollbackTransaction(false);  // ... and the cache's pair-id sets follow the database
+          try {
+            database_transaction.Rollback();  // nothing of a failed block is committed ...
+          } catch (...) {  // (a failing ROLLBACK must neither hide the original error nor skip the cache)
+          }
+          try {
+            cache_.RollbackTransaction(false);  // ... and the cache's pair-id sets follow the database
+          } catch (...) {
+          }
           throw;
         }
         database_transaction.Commit();
@@ -300,7 +308,20 @@ bool VocabSimilarityGraph::Run() {
   std::vector<std::vector<FeatureGeometry>> geometries(verify ? n : 0);  // of the features as indexed, for the spatial re-ranking
   for (uint32_t i = 0; i < n; ++i) {
     const FeatureDescriptors& d = cache_.GetDescriptors(ids[i]);
-    if (options_.max_num_features > 0 && d.rows > static_cast<size_t>(options_.max_num_features)) {
+    const bool top_scale = options_.max_num_features > 0 && d.rows > static_cast<size_t>(options_.max_num_features);
+    if (top_scale || verify) {
+      // ExtractTopScaleFeatures CHECK_EQs the two tables (src/feature/utils.cc:84); the indices of the keypoints address
+      // rows of the descriptor blob below, and the geometries must belong to the indexed rows
+      const size_t num_kps = cache_.GetKeypoints(ids[i]).size();
+      if (num_kps != d.rows) {
+        last_error_ = "image " + std::to_string(ids[i]) + ": " + std::to_string(num_kps) + " keypoints but " +
+                      std::to_string(d.rows) + " descriptors";
+        cache_.ReleasePins();
+        dsm_ctx_destroy(ctx);
+        return false;
+      }
+    }
+    if (top_scale) {
       // similarity_graph.cpp:77-79, 137-141: index and query only the features of largest scale, in that order
       const FeatureKeypoints& kps = cache_.GetKeypoints(ids[i]);
       const std::vector<uint32_t> order = TopScaleFeatureOrder(kps, static_cast<size_t>(options_.max_num_features));
@@ -314,8 +335,7 @@ bool VocabSimilarityGraph::Run() {
       nfeat[i] = static_cast<uint32_t>(d.rows);
       if (verify) {
         const FeatureKeypoints& kps = cache_.GetKeypoints(ids[i]);
-        for (size_t k = 0; k < d.rows && k < kps.size(); ++k) geometries[i].push_back(GeometryOfKeypoint(kps[k]));
-        geometries[i].resize(d.rows);
+        for (size_t k = 0; k < d.rows; ++k) geometries[i].push_back(GeometryOfKeypoint(kps[k]));
       }
     }
     desc[i] = copies[i].data();
@@ -341,11 +361,20 @@ bool VocabSimilarityGraph::Run() {
   if (rc == DSM_OK && verify) {
     std::vector<uint64_t> offsets(static_cast<size_t>(n) + 1, 0);
     rc = dsm_retrieval_matches(ctx, static_cast<uint32_t>(options_.num_nearest_neighbors), max_images, counts.data(), idx.data(), offsets.data());
-    std::vector<uint32_t> tuples(static_cast<size_t>(offsets[n]) * 5 + 1);
-    std::vector<float> idf(voc.num_words);
-    if (rc == DSM_OK) rc = dsm_get_retrieval_matches(ctx, tuples.data(), offsets[n]);
-    if (rc == DSM_OK) rc = dsm_get_retrieval_idf(ctx, idf.data(), voc.num_words);
+    std::vector<uint32_t> tuples;
+    std::vector<float> idf;
+    std::string host_error;  // what a worker could not do (allocation, a tuple outside the indexed features)
     if (rc == DSM_OK) {
+      try {
+        tuples.resize(static_cast<size_t>(offsets[n]) * 5 + 1);
+        idf.resize(voc.num_words);
+      } catch (const std::exception& e) {
+        host_error = std::string("spatial re-ranking: ") + e.what();
+      }
+    }
+    if (rc == DSM_OK && host_error.empty()) rc = dsm_get_retrieval_matches(ctx, tuples.data(), offsets[n]);
+    if (rc == DSM_OK && host_error.empty()) rc = dsm_get_retrieval_idf(ctx, idf.data(), voc.num_words);
+    if (rc == DSM_OK && host_error.empty()) {
       float lut[65];  // HammingDistWeightFunctor<64, 16>, retrieval/utils.h:47-78
       for (int h = 0; h <= 64; ++h) {
         const float hamming_dist = static_cast<float>(h);
@@ -353,12 +382,16 @@ bool VocabSimilarityGraph::Run() {
       }
       // one query is independent of the next (the reference verifies on its retrieval thread pool, similarity_graph.cpp:
       // 116-160): options_.num_threads workers take the queries in turn
+      std::mutex error_mutex;
       auto rerank_range = [&](uint32_t first, uint32_t step) {
+       try {
         std::vector<RetrievalCandidate> candidates;
         for (uint32_t q = first; q < n; q += step) {
           candidates.clear();
           for (uint64_t m = offsets[q]; m < offsets[q + 1]; ++m) {
             const uint32_t* t = tuples.data() + m * 5;
+            if (t[1] >= n || t[2] >= geometries[t[1]].size() || t[0] >= geometries[q].size() || (t[3] >> 8) >= idf.size())
+              throw std::runtime_error("candidate tuple outside the indexed features");
             RetrievalCandidate c;
             c.query_feature = t[0];
             c.image = t[1];
@@ -372,12 +405,21 @@ bool VocabSimilarityGraph::Run() {
           counts[q] = SpatialRerank(geometries[q], candidates, options_.num_images_after_verification, counts[q],
                                     idx.data() + static_cast<size_t>(q) * max_images, sc.data() + static_cast<size_t>(q) * max_images);
         }
+       } catch (const std::exception& e) {  // a worker thread must not std::terminate the host process
+        std::lock_guard<std::mutex> lock(error_mutex);
+        if (host_error.empty()) host_error = std::string("spatial re-ranking: ") + e.what();
+       }
       };
       const uint32_t workers = std::max<uint32_t>(1, std::min<uint32_t>(n, static_cast<uint32_t>(std::max(1, options_.num_threads))));
       std::vector<std::thread> pool;
       for (uint32_t w = 1; w < workers; ++w) pool.emplace_back(rerank_range, w, workers);
       rerank_range(0, workers);
       for (std::thread& t : pool) t.join();
+    }
+    if (!host_error.empty()) {
+      last_error_ = host_error;
+      dsm_ctx_destroy(ctx);
+      return false;
     }
   }
   if (rc != DSM_OK) last_error_ = dsm_last_error(ctx);
@@ -403,9 +445,11 @@ using namespace dagsfm_amd;
 extern "C" {
 
 // Runs ExhaustiveFeatureMatcher over database_path.  Returns 0 on success.
-int dsm_host_exhaustive_matcher_ex(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,
-                                   double max_ratio, double max_distance, int cross_check, int min_num_inliers,
-                                   int guided_matching, int multiple_models) {
+// gpu_index: SiftMatchingOptions::gpu_index ("-1" or null: all devices); async_write_back: this repository's extension.
+// Nothing here reads the process environment: the CLI parses its own flags (exhaustive_matcher_main.cc).
+int dsm_host_exhaustive_matcher_ex2(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,
+                                    double max_ratio, double max_distance, int cross_check, int min_num_inliers,
+                                    int guided_matching, int multiple_models, const char* gpu_index, int async_write_back) {
   try {
     ExhaustiveMatchingOptions eo;
     eo.block_size = block_size;
@@ -418,8 +462,8 @@ int dsm_host_exhaustive_matcher_ex(const char* database_path, int block_size, in
     }
     mo.guided_matching = guided_matching != 0;
     mo.multiple_models = multiple_models != 0;
-    mo.async_write_back = std::getenv("DSM_ASYNC_WRITE_BACK") != nullptr;  // CLI / tests: overlap SQLite with the device
-    if (const char* g = std::getenv("DSM_GPU_INDEX")) mo.gpu_index = g;    // SiftMatchingOptions::gpu_index ("-1": all devices)
+    mo.async_write_back = async_write_back != 0;  // overlap SQLite with the device
+    if (gpu_index && *gpu_index) mo.gpu_index = gpu_index;
     mo.random_seed = random_seed;
     ExhaustiveFeatureMatcher m(eo, mo, database_path);
     return m.Run() ? 0 : 2;
@@ -427,6 +471,13 @@ int dsm_host_exhaustive_matcher_ex(const char* database_path, int block_size, in
     std::cerr << "ERROR: " << e.what() << std::endl;
     return 1;
   }
+}
+
+int dsm_host_exhaustive_matcher_ex(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,
+                                   double max_ratio, double max_distance, int cross_check, int min_num_inliers,
+                                   int guided_matching, int multiple_models) {
+  return dsm_host_exhaustive_matcher_ex2(database_path, block_size, use_prior_defaults, random_seed, max_ratio, max_distance, cross_check,
+                                         min_num_inliers, guided_matching, multiple_models, nullptr, 0);
 }
 
 int dsm_host_exhaustive_matcher(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,

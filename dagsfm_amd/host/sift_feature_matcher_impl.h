@@ -26,9 +26,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <unordered_map>
 #include <unordered_set>
 #include <utility>
@@ -277,11 +279,36 @@ class SiftFeatureMatcherT {
       std::copy(sh.im.begin(), sh.im.begin() + 2 * sh.ioff[sh.end - sh.begin], im.begin() + 2 * ioff[sh.begin]);
     }
     // ---- write results (matching.cc:819-836), on this thread or handed to the write-back thread
-    const int min_num_inliers = options_.min_num_inliers;
-    typename Traits::Cache* cache = cache_;
-    const bool replace_matches = given != nullptr;  // resume path: the pair's `matches` row exists and is rewritten
-    auto write = [cache, min_num_inliers, np, prs, stale_inliers, replace_matches, moff = std::move(moff), m = std::move(m),
-                  tv = std::move(tv), ioff = std::move(ioff), im = std::move(im)]() {
+    std::shared_ptr<WriteBatch> batch = std::make_shared<WriteBatch>();
+    batch->cache = cache_;
+    batch->min_num_inliers = options_.min_num_inliers;
+    batch->replace_matches = given != nullptr;  // resume path: the pair's `matches` row exists and is rewritten
+    batch->prs = prs;
+    batch->stale_inliers = stale_inliers;
+    batch->moff.swap(moff);
+    batch->m.swap(m);
+    batch->tv.swap(tv);
+    batch->ioff.swap(ioff);
+    batch->im.swap(im);
+    if (WriteBackAsync(batch, std::integral_constant<bool, Traits::kAsyncWriteBack>())) return;
+    batch->Write();
+  }
+
+  // The rows of one Run(): what the write-back needs, owned by whoever writes them (this thread or the writer thread).
+  // (A struct behind a shared_ptr instead of a lambda with init-captures: the reference builds with -std=c++11,
+  // /root/reference/src/CMakeLists.txt:37, and this header compiles with its flags.)
+  struct WriteBatch {
+    typename Traits::Cache* cache;
+    int min_num_inliers;
+    bool replace_matches;
+    PairList prs;
+    std::vector<char> stale_inliers;
+    std::vector<uint64_t> moff, ioff;
+    std::vector<uint32_t> m, im;
+    std::vector<dsm_two_view_geometry> tv;
+
+    void Write() const {
+      const uint32_t np = static_cast<uint32_t>(prs.size());
       for (uint32_t i = 0; i < np; ++i) {
         if (stale_inliers[i]) cache->DeleteInlierMatches(prs[i].first, prs[i].second);  // matching.cc:797-799
         if (replace_matches) cache->DeleteMatches(prs[i].first, prs[i].second);         // matching.cc:806-808
@@ -296,39 +323,44 @@ class SiftFeatureMatcherT {
         cache->WriteMatches(prs[i].first, prs[i].second, matches);
         cache->WriteTwoViewGeometry(prs[i].first, prs[i].second, t);
       }
-    };
-    if constexpr (Traits::kAsyncWriteBack) {
-      if (Traits::AsyncWriteBack(options_)) {
-        {
-          // the rows are on their way: later Match() calls must skip these pairs.  Marked only now, with the device
-          // results on the host -- a failed device call above leaves the cache saying what the database says.
-          const auto lock = Traits::LockBatch(cache_);
-          (void)lock;
-          for (const auto& pr : prs) cache_->MarkPending(pr.first, pr.second);
-        }
-        Flush();  // one write-back in flight
-        writer_ = std::thread([this, cache, write = std::move(write)]() {
-          bool open = false;
-          try {
-            cache->BeginTransaction();
-            open = true;
-            write();
-            open = false;
-            cache->EndTransaction();
-          } catch (...) {
-            writer_error_ = std::current_exception();
-            // close the transaction without its rows and make the cache say what the database says again: the batch's
-            // pairs were marked as present above and must not be skipped by a later Match()
-            try {
-              cache->RollbackTransaction(open);
-            } catch (...) {
-            }
-          }
-        });
-        return;
-      }
     }
-    write();
+  };
+
+  // host projects without this repository's asynchronous write-back extension (the reference's own Options / Cache)
+  bool WriteBackAsync(const std::shared_ptr<WriteBatch>&, std::false_type) { return false; }
+
+  // SiftMatchingOptions::async_write_back: hands the batch to the writer thread; false when the option is off
+  bool WriteBackAsync(const std::shared_ptr<WriteBatch>& batch, std::true_type) {
+    if (!Traits::AsyncWriteBack(options_)) return false;
+    {
+      // the rows are on their way: later Match() calls must skip these pairs.  Marked only now, with the device
+      // results on the host -- a failed device call above leaves the cache saying what the database says.
+      const auto lock = Traits::LockBatch(cache_);
+      (void)lock;
+      for (const auto& pr : batch->prs) cache_->MarkPending(pr.first, pr.second);
+    }
+    Flush();  // one write-back in flight
+    SiftFeatureMatcherT* const self = this;
+    writer_ = std::thread([self, batch]() {
+      typename Traits::Cache* const cache = batch->cache;
+      bool open = false;
+      try {
+        cache->BeginTransaction();
+        open = true;
+        batch->Write();
+        cache->EndTransaction();  // a failing COMMIT (SQLITE_BUSY, SQLITE_FULL) leaves the transaction open:
+        open = false;             // only a COMMIT that returned has closed it
+      } catch (...) {
+        self->writer_error_ = std::current_exception();
+        // close the transaction without its rows and make the cache say what the database says again: the batch's
+        // pairs were marked as present above and must not be skipped by a later Match()
+        try {
+          cache->RollbackTransaction(open);
+        } catch (...) {
+        }
+      }
+    });
+    return true;
   }
 
   // Makes the images the pair lists refer to resident on every device (replicated: SURVEY 8e); keeps what is

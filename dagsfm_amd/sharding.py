@@ -68,11 +68,11 @@ def all_gather_ragged(dist, local, world_size):
 RAGGED_PAD_LIMIT = 1.25
 
 
-def all_gather_rows(dist, local, rank, world_size):
+def all_gather_rows(dist, local, rank, world_size, exchange=None):
     """All ranks' variable-length rows concatenated in rank order, exact sizes on the wire when the shards are skewed:
     the sizes are all-gathered first; balanced shards (longest <= RAGGED_PAD_LIMIT x mean) then take ONE max-padded
     all-gather, skewed ones (a kNN candidate list cut by pair count over images of very different sizes) one broadcast
-    per rank of exactly that rank's rows."""
+    per rank of exactly that rank's rows.  `exchange` = "padded" / "broadcast" forces one of the two (tests)."""
     import torch
     sizes = torch.zeros(world_size, dtype=torch.int64, device=local.device)
     dist.all_gather_into_tensor(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device))
@@ -80,7 +80,7 @@ def all_gather_rows(dist, local, rank, world_size):
     total, mx = int(sizes_h.sum()), int(sizes_h.max())
     if total == 0:
         return local[:0]
-    if mx * world_size <= RAGGED_PAD_LIMIT * total:
+    if exchange == "padded" or (exchange is None and mx * world_size <= RAGGED_PAD_LIMIT * total):
         return assemble_ragged(sizes_h, all_gather_fixed(dist, local, max(mx, 1), world_size))
     out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     at = 0
@@ -114,8 +114,13 @@ class MatchGraph:
         self.inlier_matches = inlier_matches  # [sum, 2] int32 or None
 
 
-def gather_match_graph(dist, source, rank, world_size, bounds, verify):
+def gather_match_graph(dist, source, rank, world_size, bounds, verify, force_collectives=None):
     """Assembles the match graph of the whole pair list on every rank from the per-rank shards.
+
+    force_collectives ("padded" / "broadcast" / True = the exchange the sizes pick): a single rank ALSO goes through
+    every collective (all_gather_into_tensor of the int64 counts, the uint8 records and the int32 rows; the per-rank
+    broadcast) instead of returning its own tensors -- what a one-GPU box can run of the RCCL path (bench.py
+    --force-collectives, tests/test_rccl_single_rank_gpu.py).
 
     `source` is this rank's result holder (bench.py / the CLI wrap a dsm_ctx in it; the CPU test uses a stub) with
       match_offsets() -> [n+1] int64        matches(total) -> [total, 2] int32
@@ -131,24 +136,27 @@ def gather_match_graph(dist, source, rank, world_size, bounds, verify):
     def counts_of(offs):
         return (offs[1:] - offs[:-1]).reshape(-1, 1)
 
+    exchange = force_collectives if isinstance(force_collectives, str) else None
+    alone = world_size == 1 and not force_collectives
+
     def gather_counts(offs):
         c = counts_of(offs)
-        if world_size == 1:
+        if alone:
             return c.reshape(-1)
         allc = all_gather_fixed(dist, c, maxp, world_size)
         return torch.cat([allc[r * maxp:r * maxp + int(bounds[r + 1] - bounds[r])] for r in range(world_size)]).reshape(-1)
 
     def gather_rows(rows):
-        if world_size == 1:
+        if alone:
             return rows
-        return all_gather_rows(dist, rows, rank, world_size)
+        return all_gather_rows(dist, rows, rank, world_size, exchange)
 
     offs = source.match_offsets()
     assert offs.shape[0] == n_mine + 1
     g = MatchGraph(gather_counts(offs), gather_rows(source.matches(int(offs[-1].item()))))
     if verify:
         tv = source.two_view_geometries()
-        if world_size > 1:
+        if not alone:
             allt = all_gather_fixed(dist, tv, maxp, world_size)
             tv = torch.cat([allt[r * maxp:r * maxp + int(bounds[r + 1] - bounds[r])] for r in range(world_size)])
         g.tvg = tv

@@ -130,6 +130,12 @@ void dsm_ctx_destroy(dsm_ctx* ctx);
 const char* dsm_last_error(const dsm_ctx* ctx);
 /* Blocks until all work queued by this context has finished. */
 int dsm_sync(dsm_ctx* ctx);
+/* Scheduling / cross-check switches of one context, for tests and profiling: `key` is one of the names DESIGN.md lists
+ * under "Tuning / debugging hooks" (e.g. "DSM_VERIFY_LANES"), `value` its setting; value == NULL removes the key.  None
+ * of them changes a result (tools/check_schedules.py).  The library never reads the process environment, so a host
+ * application's environment cannot change schedules; the reference has no analogue (its options all travel in
+ * SiftMatchingOptions, src/feature/sift.h:139-195).  DSM_ERR_INVALID_ARGUMENT for an unknown key. */
+int dsm_set_debug_option(dsm_ctx* ctx, const char* key, const char* value);
 
 /* What the device reports about itself (hipDeviceProp_t): used by bench.py to derive the roofline peaks from
  * the hardware instead of hard-coding them. */

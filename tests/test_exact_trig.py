@@ -28,7 +28,7 @@ def _args(kind, rng, n):
         return np.concatenate([rng.uniform(0, 4, n), 10.0 ** rng.uniform(-12, 12, n // 2), -rng.uniform(0, 30, n // 4),
                                [1.0, 0.125, 0.5, 0.0625, 1e-9, 1e19, 2.0 ** 53, 1e300]])
     return np.concatenate([rng.uniform(0, 3.2, n), rng.uniform(-20, 20, n // 2), 10.0 ** rng.uniform(-12, 0, n // 4),
-                           rng.uniform(0, 1e5, n // 4), [math.pi / 2, math.pi, 3 * math.pi / 2, math.pi / 4, 1e-300]])
+                           rng.uniform(0, 1e5, n // 4), [math.pi / 2, math.pi, 3 * math.pi / 2, math.pi / 4, 1e-300, 1647099.0, -1647099.0]])
 
 
 @pytest.mark.parametrize("kind", range(4))
@@ -59,3 +59,12 @@ def test_special_values(oracle):
     for kind in range(1, 4):
         assert np.isnan(_run(oracle, kind, [np.inf, np.nan])).all()
     assert np.isnan(_run(oracle, 0, [np.nan])).all()
+
+
+def test_arguments_beyond_the_supported_range_are_nan(oracle):
+    # |x| <= 1 647 099 (< 2^20 pi/2) is the range of the exact argument reduction; beyond it sin / cos / tan are NaN in the
+    # oracle and on the device alike (the integer cast of the quadrant is undefined from ~1.4e19 on)
+    for kind in range(1, 4):
+        assert np.isnan(_run(oracle, kind, [1647099.5, -1647100.0, 1e7, 1.4e19, -1e300, 1.7e308])).all()
+        assert np.isfinite(_run(oracle, kind, [1647099.0, -1647099.0])).all()
+    assert np.isfinite(_run(oracle, 0, [1e19, 1e300, -1.7e308])).all()  # atan has no reduction by pi/2

@@ -364,6 +364,17 @@ def test_malformed_blobs_are_errors_not_overreads(tmp_path):
     good = str(tmp_path / "good.db")
     dbutil.create(good, ims)
     assert L.dsm_host_cache_lru_probe(good.encode(), 2, ids, 3, 2) >= 0
+    # an image without features stored as a 0 x 0 matrix with an empty (or NULL) blob is NOT malformed: the reference's
+    # ReadDynamicMatrixBlob accepts it (database.cc:60-77 only CHECKs rows * cols * size == num_bytes); ADVICE r03
+    for k, sql in enumerate(["UPDATE descriptors SET rows = 0, cols = 0, data = x'' WHERE image_id = 2",
+                             "UPDATE descriptors SET rows = 0, cols = 0, data = NULL WHERE image_id = 2"]):
+        path = str(tmp_path / ("empty%d.db" % k))
+        dbutil.create(path, ims)
+        con = sqlite3.connect(path)
+        con.execute(sql)
+        con.commit()
+        con.close()
+        assert L.dsm_host_cache_lru_probe(path.encode(), 2, ids, 3, 2) >= 0, sql
     for k, sql in enumerate(["UPDATE keypoints SET rows = 1000 WHERE image_id = 1", "UPDATE keypoints SET cols = 3 WHERE image_id = 3",
                              "UPDATE keypoints SET rows = -5 WHERE image_id = 1", "UPDATE descriptors SET rows = 999 WHERE image_id = 3",
                              "UPDATE descriptors SET cols = 64 WHERE image_id = 3", "UPDATE descriptors SET data = NULL WHERE image_id = 1",

@@ -238,6 +238,38 @@ def test_host_vocab_similarity_graph_max_num_features(tmp_path, dsm):
     assert (scores[:n] == np.array(exp_scores, np.float32)).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("delta", [-3, 5])
+def test_vocab_similarity_graph_rejects_keypoint_descriptor_mismatch(tmp_path, delta):
+    """a database whose keypoints row has more (heap over-read) or fewer (features silently dropped) rows than
+    its descriptors row -- the reference CHECK_EQs the two in ExtractTopScaleFeatures (src/feature/utils.cc:84); the shim
+    reports an error, with max_num_features and with the spatial re-ranking's geometries alike."""
+    import ctypes
+    import os
+    import sqlite3
+    from tests import dbutil
+    scene, ims, voc = _scene(4, 200, 64)
+    rng = np.random.default_rng(3)
+    path = str(tmp_path / "database.db")
+    dbutil.create(path, [(im[0], im[1]) for im in ims])
+    n = len(ims[2][0]) + delta
+    con = sqlite3.connect(path)
+    con.execute("UPDATE keypoints SET rows = ?, data = ? WHERE image_id = 3", (n, np.ones((n, 6), np.float32).tobytes()))
+    con.commit()
+    con.close()
+    L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dagsfm_amd", "libdagsfm_host.so"))
+    L.dsm_host_vocab_candidate_pairs2.restype = ctypes.c_int64
+    L.dsm_host_vocab_candidate_pairs2.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_uint64]
+    vpath = str(tmp_path / "vocab_tree.bin")
+    _write_reference_vocabulary(vpath, *voc, rng)
+    pairs = np.zeros((100, 2), np.uint32)
+    scores = np.zeros(100, np.float32)
+    assert L.dsm_host_vocab_candidate_pairs2(path.encode(), vpath.encode(), 3, 5, 50, pairs.ctypes.data, scores.ctypes.data, 100) < 0
+    # without max_num_features and without re-ranking the keypoints are never read: the run goes through
+    assert L.dsm_host_vocab_candidate_pairs2(path.encode(), vpath.encode(), 3, 5, 0, pairs.ctypes.data, scores.ctypes.data, 100) > 0
+
+
 # ------------------------------------------------------------------------------------------- spatial re-ranking
 # QueryOptions::num_images_after_verification > 0: VisualIndex::Query with geometries (visual_index.h:259-500) +
 # VoteAndVerify (vote_and_verify.cc).  Oracle: oracle/spatial_verification.h + oracle_retrieval_query_verified; product:

@@ -220,3 +220,29 @@ def test_gather_match_graph_more_ranks_and_empty_shards(world, n_images):
     for rank, got in res:
         for a, b in zip(got, ref):
             assert a.shape == b.shape and (a == b).all(), rank
+
+
+def _single_rank_forced(port, q):
+    from dagsfm_amd import sharding, synthetic
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    pairs = synthetic.exhaustive_pairs(7).astype(np.int64)
+    bounds = sharding.shard_bounds(len(pairs), 1)
+    out = [_graph_to_numpy(sharding.gather_match_graph(dist, _StubSource(pairs, True), 0, 1, bounds, True, force_collectives=f))
+           for f in (None, True, "padded", "broadcast")]
+    q.put(out)
+    dist.destroy_process_group()
+
+
+def test_single_rank_forced_through_the_collectives():
+    """force_collectives: a lone rank takes the same all_gather_into_tensor / broadcast calls the N-rank exchange makes (what
+    tests/test_rccl_single_rank_gpu.py runs over RCCL on the one GPU of the test box); the graph must not change."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_rank_forced, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    for got in out[1:]:
+        for a, b in zip(got, out[0]):
+            assert a.shape == b.shape and (a == b).all()

@@ -20,13 +20,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(ROOT, "gpurun_out", "pmc")
 os.makedirs(out_dir, exist_ok=True)
 argv = sys.argv[1:]
+verify_mode = "--verify" in argv  # every kernel of the step by name (the verification kernels), executed-instruction counters
 util = "--util" in argv
 util1 = "--util1" in argv  # only the MFMA / VALU instruction and busy counters
 tag_out = None
 if "--out" in argv:
     tag_out = argv[argv.index("--out") + 1]
     del argv[argv.index("--out"):argv.index("--out") + 2]
-argv = [a for a in argv if a not in ("--util", "--util1")]
+argv = [a for a in argv if a not in ("--util", "--util1", "--verify")]
 bench_args = argv or ["--steps", "1", "--warmup", "0", "--cpu-seconds", "0"]
 res = {"bench_args": bench_args}
 env = dict(os.environ, TMPDIR="/tmp")
@@ -40,11 +41,74 @@ if util:
                ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS")]
 
 
+if verify_mode:
+    # SQ counters only (<= 8 per pass).  FP64 instruction classes: the verification is built with -ffp-contract=off, so its
+    # arithmetic is ADD_F64 / MUL_F64 (1 flop per lane), FMA_F64 appears only inside the division / square-root expansions,
+    # TRANS_F64 is v_rcp / v_rsq / v_sqrt_f64 (quarter rate).
+    passes = [("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CU_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAVES", "SQ_THREAD_CYCLES_VALU"),
+              ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_SALU",
+               "SQ_INSTS_VALU_INT32"),
+              ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM",
+               "SQ_ACTIVE_INST_ANY")]
+
+
 def kname(row):
     n = row.get("Kernel_Name", "")
+    if verify_mode:
+        n = n.replace("void ", "").split("(")[0].strip()
+        return n if n and not n.startswith("k1_") and not n.startswith("__amd") else None
     if "k1_best_rows" not in n:
         return None
     return "pass2" if "<true>" in n else "pass1"
+
+
+def summarize_verify(res):
+    """Per kernel: time, VALU issue utilisation, the FP64 instruction mix and the executed FP64 rate against the vector peak
+    (256 CUs x 4 SIMDs x 16 lanes x clock: one wave64 FP64 instruction = 4 cycles of a SIMD; an FMA counts 2 flops)."""
+    def tot(counter, k):  # summed over the dispatches of the step
+        v = res.get(counter, {}).get(k)
+        return v["mean_per_dispatch"] * v["dispatches"] if v else 0.0
+    cus, clk = 256, 2.4e9
+    issue_peak = cus * 4 * clk / 4.0        # wave64 VALU instructions per second, whole chip
+    fp64_peak = cus * 4 * 16 * 2 * clk      # 78.6 TFLOP/s
+    names = sorted(res.get("SQ_INSTS_VALU", {}).keys())
+    dur = {}
+    for k, v in res.get("duration_ms_SQ_INSTS_VALU", {}).items():
+        dur[k] = sum(v)
+    rows = {}
+    for k in names:
+        ms = dur.get(k, 0.0)
+        if ms <= 0:
+            continue
+        valu = tot("SQ_INSTS_VALU", k)
+        f64 = {c: tot("SQ_INSTS_VALU_" + c + "_F64", k) for c in ("ADD", "MUL", "FMA", "TRANS")}
+        f64_insts = sum(f64.values())
+        flops = 64.0 * (f64["ADD"] + f64["MUL"] + 2.0 * f64["FMA"] + f64["TRANS"])
+        busy_cu = tot("SQ_BUSY_CU_CYCLES", k)
+        wave_cyc = tot("SQ_WAVE_CYCLES", k)
+        rows[k] = {
+            "ms_per_step": ms, "dispatches": res["SQ_INSTS_VALU"][k]["dispatches"],
+            "valu_insts": valu, "fp64_insts": f64_insts, "fp64_mix": f64,
+            "fp64_share_of_valu": f64_insts / valu if valu else None,
+            "valu_issue_util": valu / (ms * 1e-3) / issue_peak,                  # of the nameplate clock
+            "executed_fp64_tflops": flops / (ms * 1e-3) / 1e12,
+            "executed_frac": flops / (ms * 1e-3) / fp64_peak,
+            "lane_util": (tot("SQ_THREAD_CYCLES_VALU", k) / (64.0 * tot("SQ_ACTIVE_INST_VALU", k))) if tot("SQ_ACTIVE_INST_VALU", k) else None,
+            "clock_ghz_while_busy": busy_cu / cus / (ms * 1e-3) / 1e9 if busy_cu else None,
+            "waves_per_simd_avg": wave_cyc / (4.0 * busy_cu) if busy_cu else None,
+            "wait_inst_any_share": tot("SQ_WAIT_INST_ANY", k) / wave_cyc if wave_cyc else None,
+            "lds_insts": tot("SQ_INSTS_LDS", k), "lds_bank_conflict_cycles": tot("SQ_LDS_BANK_CONFLICT", k),
+            "salu_insts": tot("SQ_INSTS_SALU", k), "vmem_insts": tot("SQ_INSTS_VMEM", k),
+        }
+    total_ms = sum(r["ms_per_step"] for r in rows.values())
+    total_flops = sum(r["executed_fp64_tflops"] * r["ms_per_step"] for r in rows.values())
+    res["summary"] = {"kernels": dict(sorted(rows.items(), key=lambda kv: -kv[1]["ms_per_step"])),
+                      "all_kernels_ms_per_step": total_ms,
+                      "executed_fp64_tflops_over_all": total_flops / total_ms if total_ms else None,
+                      "executed_frac_over_all": total_flops / total_ms * 1e12 / fp64_peak if total_ms else None,
+                      "peaks": {"fp64_vector_tflops": fp64_peak / 1e12, "valu_wave_insts_per_s": issue_peak},
+                      "note": "durations and counters of ONE step under counter collection (kernels serialised, one lane: "
+                              "DSM_VERIFY_LANES=1); SQ counters summed over all CUs"}
 
 
 for counters in passes:
@@ -95,7 +159,9 @@ if util and "SQ_VALU_MFMA_BUSY_CYCLES" in res and "SQ_BUSY_CU_CYCLES" in res:
                                                         (4.0 * res["SQ_BUSY_CU_CYCLES"][k]["mean_per_dispatch"]))
         except Exception:
             pass
-print(json.dumps(res))
-json.dump(res, open(os.path.join(out_dir, "k1_pmc.json"), "w"), indent=1)
+if verify_mode:
+    summarize_verify(res)
+print(json.dumps(res if not verify_mode else res.get("summary")))
+json.dump(res, open(os.path.join(out_dir, "k1_pmc.json" if not verify_mode else "verify_pmc.json"), "w"), indent=1)
 if tag_out:
     json.dump(res, open(tag_out, "w"), indent=1)
