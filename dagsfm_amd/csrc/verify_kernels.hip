@@ -1738,6 +1738,24 @@ __global__ __launch_bounds__(64, 2) void k_solve(const VerifyParams p) {
     if (k < nm * 9) gm[k] = mloc[k];
 }
 
+// if (r <= max_residual) { cnt += 1; sum += r; } -- InlierSupportMeasurer::Evaluate's loop body (support_measurement.cc:43-48)
+// -- under the execution mask instead of as selected values: the compiler's form is a compare, an add and three or four
+// v_cndmask per point (5.5 VALU of the 35 a homography residual costs); masked, the same compare and the same two adds are
+// 3 VALU and two scalar instructions.  Same IEEE operations on the same values.  s_and_saveexec_b64 writes SCC: it is in
+// the clobber list (without it the compiler keeps the loop's s_cmp result across the block).
+DSM_DEV void count_inlier(double r, double max_residual, double& sum, int& cnt) {
+  unsigned long long saved_exec;
+  asm volatile(
+      "v_cmp_le_f64 vcc, %[r], %[mx]\n\t"
+      "s_and_saveexec_b64 %[sv], vcc\n\t"
+      "v_add_f64 %[sum], %[sum], %[r]\n\t"
+      "v_add_u32 %[cnt], 1, %[cnt]\n\t"
+      "s_mov_b64 exec, %[sv]"
+      : [sum] "+v"(sum), [cnt] "+v"(cnt), [sv] "=&s"(saved_exec)
+      : [r] "v"(r), [mx] "v"(max_residual)
+      : "vcc", "scc");
+}
+
 template <int FAM>
 __global__ __launch_bounds__(64, 8) void k_score(const VerifyParams p) {
   typedef Fam<FAM> F;
@@ -1772,23 +1790,27 @@ __global__ __launch_bounds__(64, 8) void k_score(const VerifyParams p) {
   int cnt = 0;
   double sum = 0;
   if (in_lds) {
-#pragma unroll 4
-    for (int i = 0; i < n; ++i) {
-      const double r = fam_residual<FAM>(M, spts + (size_t)i * 4);
-      if (r <= max_residual) {
-        cnt += 1;
-        sum += r;
-      }
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {  // four points per trip by hand: a loop with inline assembly is not unrolled for us
+      const double r0 = fam_residual<FAM>(M, spts + (size_t)i * 4), r1 = fam_residual<FAM>(M, spts + (size_t)(i + 1) * 4);
+      const double r2 = fam_residual<FAM>(M, spts + (size_t)(i + 2) * 4), r3 = fam_residual<FAM>(M, spts + (size_t)(i + 3) * 4);
+      count_inlier(r0, max_residual, sum, cnt);
+      count_inlier(r1, max_residual, sum, cnt);
+      count_inlier(r2, max_residual, sum, cnt);
+      count_inlier(r3, max_residual, sum, cnt);
     }
+    for (; i < n; ++i) count_inlier(fam_residual<FAM>(M, spts + (size_t)i * 4), max_residual, sum, cnt);
   } else {
-#pragma unroll 4
-    for (int i = 0; i < n; ++i) {
-      const double r = fam_residual<FAM>(M, gpts + (size_t)i * 4);
-      if (r <= max_residual) {
-        cnt += 1;
-        sum += r;
-      }
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {  // four points per trip by hand: a loop with inline assembly is not unrolled for us
+      const double r0 = fam_residual<FAM>(M, gpts + (size_t)i * 4), r1 = fam_residual<FAM>(M, gpts + (size_t)(i + 1) * 4);
+      const double r2 = fam_residual<FAM>(M, gpts + (size_t)(i + 2) * 4), r3 = fam_residual<FAM>(M, gpts + (size_t)(i + 3) * 4);
+      count_inlier(r0, max_residual, sum, cnt);
+      count_inlier(r1, max_residual, sum, cnt);
+      count_inlier(r2, max_residual, sum, cnt);
+      count_inlier(r3, max_residual, sum, cnt);
     }
+    for (; i < n; ++i) count_inlier(fam_residual<FAM>(M, gpts + (size_t)i * 4), max_residual, sum, cnt);
   }
   p.counts[((size_t)pl * p.batch + t) * F::MAXM + m] = cnt;
   p.sums[((size_t)pl * p.batch + t) * F::MAXM + m] = sum;
