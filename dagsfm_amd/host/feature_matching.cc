@@ -1,5 +1,6 @@
 // feature_matching.cc -- see feature_matching.h.
 #include "feature_matching.h"
+#include "flann_index.h"
 #include "spatial_verification.h"
 
 #include <chrono>
@@ -200,15 +201,31 @@ bool VocabularyFile::ReadReferenceLayout(const std::string& path) {
     if (num_images < 0) return false;
     return pos + 4 + static_cast<uint64_t>(num_images) * 8 == buf.size();
   };
-  const int32_t key[2] = {static_cast<int32_t>(rows), 64};
-  for (size_t at = words_end; at + 8 <= buf.size(); ++at) {
-    if (std::memcmp(buf.data() + at, key, 8) != 0) continue;
-    if (!parse(at, nullptr, nullptr)) continue;
+  auto accept = [&](size_t at) -> bool {
     num_words = static_cast<uint32_t>(rows);
     words.assign(buf.begin() + 16, buf.begin() + words_end);
     projection.resize(64 * 128);
     thresholds.resize(static_cast<size_t>(rows) * 64);
+    index_begin = words_end;
+    index_end = at;
+    flann_blob.assign(buf.begin() + words_end, buf.begin() + at);
     return parse(at, &projection, &thresholds);
+  };
+  const int32_t key[2] = {static_cast<int32_t>(rows), 64};
+  // The middle section is what flann::AutotunedIndex::saveIndex wrote (visual_index.h:600-607): two FLANN archives back to
+  // back -- the autotuned index's own record, then the index it chose (lib/FLANN/algorithms/autotuned_index.h:209-217) --
+  // each framed as header, first compressed block, (size, block)*, 0 (lib/FLANN/util/serialization.h:412-479).  Walking
+  // that framing lands on the byte loadIndex stops at (:564-574), which is where the reference reads the inverted index.
+  size_t at = words_end;
+  flann_framed = FlannSkipArchive(buf.data(), buf.size(), &at) && FlannSkipArchive(buf.data(), buf.size(), &at);
+  if (flann_framed)
+    return at + 8 <= buf.size() && std::memcmp(buf.data() + at, key, 8) == 0 && parse(at, nullptr, nullptr) && accept(at);
+  // not FLANN's v1.1 framing (a blob this reader cannot walk): the inverted index is located by its header --
+  // (num_words, 64) -- at the one offset from which the rest of the file parses to exactly its end
+  for (at = words_end; at + 8 <= buf.size(); ++at) {
+    if (std::memcmp(buf.data() + at, key, 8) != 0) continue;
+    if (!parse(at, nullptr, nullptr)) continue;
+    return accept(at);
   }
   return false;
 }
@@ -588,6 +605,33 @@ uint32_t dsm_host_read_vocabulary(const char* path, uint8_t* words, float* proje
     if (projection) std::memcpy(projection, v.projection.data(), v.projection.size() * 4);
     if (thresholds) std::memcpy(thresholds, v.thresholds.data(), v.thresholds.size() * 4);
   }
+  return v.num_words;
+}
+// FlannIndex (flann_index.h) over the FLANN section of a vocabulary file in the reference's layout, for
+// tests/test_retrieval_flann.py: the k nearest words of n descriptors as the reference's own search returns them.
+// Returns the algorithm the file's index uses (0 linear, 1 kd-trees, 2 k-means), < 0 on error.
+int dsm_host_flann_find_word_ids(const char* vocab_path, const uint8_t* descriptors, uint32_t n, uint32_t k, int num_checks, int num_threads,
+                                 int32_t* out_ids, float* out_dists, uint64_t* end_offset) {
+  VocabularyFile v;
+  if (!v.ReadReferenceLayout(vocab_path) || !v.flann_framed) return -1;
+  FlannIndex index;
+  size_t at = 0;
+  if (!index.Load(v.flann_blob.data(), v.flann_blob.size(), &at, v.words.data(), v.num_words)) {
+    std::cerr << "ERROR: " << index.error() << std::endl;
+    return -2;
+  }
+  if (end_offset) *end_offset = v.index_begin + at;
+  if (n && !index.FindWordIds(descriptors, n, k, num_checks, num_threads, out_ids, out_dists)) return -3;
+  return index.algorithm();
+}
+// where ReadReferenceLayout found the FLANN index of a vocabulary file in the reference's layout: begin / end offsets,
+// *framed = 1 when it walked FLANN's archive framing (0: located the inverted index by its header).  Returns num_words.
+uint32_t dsm_host_vocabulary_index_range(const char* path, uint64_t* begin, uint64_t* end, int* framed) {
+  VocabularyFile v;
+  if (!v.ReadReferenceLayout(path)) return 0;
+  if (begin) *begin = v.index_begin;
+  if (end) *end = v.index_end;
+  if (framed) *framed = v.flann_framed ? 1 : 0;
   return v.num_words;
 }
 int64_t dsm_host_vocab_candidate_pairs3(const char* database_path, const char* vocab_path, int num_images, int num_nearest_neighbors,

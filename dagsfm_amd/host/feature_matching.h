@@ -262,6 +262,11 @@ struct VocabularyFile {
   uint32_t num_words = 0;
   std::vector<uint8_t> words;
   std::vector<float> projection, thresholds;
+  // reference layout only: the byte range of the serialised FLANN index between the words and the inverted index, and
+  // whether it carries FLANN's v1.1 archive framing (then index_end is the offset flann's loadIndex stops at)
+  uint64_t index_begin = 0, index_end = 0;
+  bool flann_framed = false;
+  std::vector<uint8_t> flann_blob;  // the bytes of that range (what FlannIndex::Load parses for word_search = flann)
   bool Read(const std::string& path);
   bool ReadReferenceLayout(const std::string& path);
   bool Write(const std::string& path) const;

@@ -23,7 +23,26 @@
 #include <type_traits>
 #include <vector>
 
+#include <algorithm>
+#include <cassert>
+#include <cstdlib>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <typeinfo>
+
+// flann_ref_build_forced below needs AutotunedIndex's private state (bestParams_, bestIndex_): the test wants the
+// reference's OWN serialisation of a kd-tree / k-means index over a small vocabulary, and the autotuner -- which decides
+// by wall-clock timings -- picks linear search for anything small enough to be a unit test.
+#define private public
+#define protected public
 #include "FLANN/flann.hpp"
+#undef private
+#undef protected
 
 namespace {
 
@@ -69,6 +88,40 @@ void* flann_ref_build(const uint8_t* words, uint32_t num_words, float target_pre
   index_params["target_precision"] = target_precision;
   r->index = new AutoIndex(index_params);
   r->index->buildIndex(r->matrix);
+  return r;
+}
+
+// The autotuner's decision replaced by a given one, everything else as AutotunedIndex::buildIndex() does it
+// (autotuned_index.h:135-155): algorithm 1 = randomised kd-trees (p1 = trees), 2 = hierarchical k-means (p1 = branching,
+// p2 = iterations, centers_init random, cb_index 0.2 -- the grid optimizeKMeans / optimizeKDTree explore), 0 = linear.
+// saveIndex then writes exactly what it writes after a tuned build that chose these parameters.
+void* flann_ref_build_forced(const uint8_t* words, uint32_t num_words, int algorithm, int p1, int p2, int autotuned_checks) {
+  RefIndex* r = new RefIndex();
+  r->words.assign(words, words + static_cast<size_t>(num_words) * 128);
+  r->matrix = flann::Matrix<uint8_t>(r->words.data(), num_words, 128);
+  flann::AutotunedIndexParams index_params;
+  r->index = new AutoIndex(r->matrix, index_params);
+  flann::IndexParams best;
+  if (algorithm == 1) {
+    best["algorithm"] = flann::FLANN_INDEX_KDTREE;
+    best["trees"] = p1;
+  } else if (algorithm == 2) {
+    best["algorithm"] = flann::FLANN_INDEX_KMEANS;
+    best["centers_init"] = flann::FLANN_CENTERS_RANDOM;
+    best["iterations"] = p2;
+    best["branching"] = p1;
+    best["cb_index"] = 0.2f;
+  } else {
+    best["algorithm"] = flann::FLANN_INDEX_LINEAR;
+  }
+  r->index->bestParams_ = best;
+  const flann::flann_algorithm_t index_type = flann::get_param<flann::flann_algorithm_t>(best, "algorithm");
+  r->index->bestIndex_ = flann::create_index_by_type<Dist>(index_type, r->matrix, best, Dist());
+  r->index->bestIndex_->buildIndex();
+  r->index->bestSearchParams_.checks = autotuned_checks;
+  r->index->speedup_ = 1.0f;
+  r->index->bestParams_["search_params"] = r->index->bestSearchParams_;
+  r->index->bestParams_["speedup"] = r->index->speedup_;
   return r;
 }
 
