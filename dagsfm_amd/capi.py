@@ -367,6 +367,18 @@ class Context:
                        thresholds=self._voc[2].ctypes.data)
         self._chk(lib().dsm_retrieval_set_vocabulary(self._h, ctypes.byref(v)))
 
+    def retrieval_set_word_ids(self, index_ids, query_ids):
+        """dsm_retrieval_set_word_ids: the caller's word ids (the reference's FLANN answer) instead of the device's exact
+        search; index_ids [features], query_ids [features, k].  (None, None): exact search again."""
+        L = lib()
+        L.dsm_retrieval_set_word_ids.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        if index_ids is None:
+            self._chk(L.dsm_retrieval_set_word_ids(self._h, None, 0, None))
+            return
+        a = np.ascontiguousarray(index_ids, np.int32).reshape(-1)
+        b = np.ascontiguousarray(query_ids, np.int32).reshape(len(a), -1)
+        self._chk(L.dsm_retrieval_set_word_ids(self._h, a.ctypes.data, b.shape[1], b.ctypes.data))
+
     def retrieval_index(self):
         self._chk(lib().dsm_retrieval_index(self._h))
 

@@ -48,6 +48,13 @@ struct RetrievalState {
   uint32_t num_words = 0, words_padded = 0;
   bool have_vocab = false, indexed = false;
   uint32_t k_assigned = 0;  // neighbours currently held in d_wid / d_sig
+  // dsm_retrieval_set_word_ids: word ids searched by the caller (the host shim's FLANN-compatible search) instead of the
+  // device's exact search.  The reference searches twice -- 1 neighbour when it indexes a feature, num_neighbors when it
+  // queries -- and an approximate search's first of five need not be its one of one, so both lists are kept.
+  std::vector<int32_t> host_index_ids, host_query_ids;  // [features] / [features][host_k_query], images back to back
+  uint32_t host_k_query = 0;
+  bool host_ids = false;
+  int host_loaded = 0;  // which list d_wid / d_sig hold: 1 index, 2 query
   DevBuf d_words, d_cw, d_projT, d_thr, d_lut;
   DevBuf d_row_img, d_wid, d_sig;                       // per feature row
   DevBuf d_keys, d_keys2, d_vals, d_vals2, d_tmp;        // sort scratch
@@ -472,6 +479,7 @@ void dsm_retrieval_invalidate(dsm_ctx* ctx) {  // the resident images changed
   if (!ctx->retrieval) return;
   ctx->retrieval->indexed = false;
   ctx->retrieval->k_assigned = 0;
+  ctx->retrieval->host_loaded = 0;
 }
 
 void dsm_retrieval_destroy(dsm_ctx* ctx) {
@@ -640,10 +648,48 @@ __global__ __launch_bounds__(256, 2) void k_vocab_assign_mfma(const int8_t* __re
 }
 
 // words of every feature of every resident image (k nearest), signatures for them
-static int retrieval_assign(dsm_ctx* ctx, uint32_t k) {
+enum { ASSIGN_FOR_INDEX = 1, ASSIGN_FOR_QUERY = 2 };
+static int retrieval_assign(dsm_ctx* ctx, uint32_t k, int purpose) {
   RetrievalState* r = ctx->retrieval;
   hipStream_t st = ctx->stream;
   const uint64_t rows = ctx->total_rows;
+  if (r->host_ids) {
+    // the caller's word ids: scattered into the padded row layout, signatures computed for exactly those words
+    if (r->host_loaded == purpose && r->d_wid.p) return DSM_OK;
+    uint64_t n_feat = 0;
+    for (uint32_t i = 0; i < ctx->n_images; ++i) n_feat += ctx->nfeat[i];
+    if (n_feat != r->host_index_ids.size()) return dsm_fail(ctx, DSM_ERR_NOT_READY, "dsm_retrieval_set_word_ids: the resident images changed since the ids were set");
+    const uint32_t kk = purpose == ASSIGN_FOR_INDEX ? 1u : r->host_k_query;
+    std::vector<int32_t> wid(std::max<uint64_t>(rows, 1) * RK_MAX, RK_INVALID);
+    r->img_valid_start.assign(ctx->n_images + 1, 0);
+    uint64_t at = 0;
+    for (uint32_t i = 0; i < ctx->n_images; ++i) {
+      for (uint32_t f = 0; f < ctx->nfeat[i]; ++f, ++at) {
+        int32_t* o = wid.data() + ((uint64_t)ctx->row0[i] + f) * RK_MAX;
+        if (purpose == ASSIGN_FOR_INDEX)
+          o[0] = r->host_index_ids[at];
+        else
+          for (uint32_t q = 0; q < kk; ++q) o[q] = r->host_query_ids[at * kk + q];
+      }
+      r->img_valid_start[i + 1] = r->img_valid_start[i] + ctx->nfeat[i];
+    }
+    std::vector<int32_t> row_img(std::max<uint64_t>(rows, 1), -1);  // row -> image (padding rows: -1), as below
+    for (uint32_t i = 0; i < ctx->n_images; ++i)
+      for (uint32_t f = 0; f < ctx->nfeat[i]; ++f) row_img[(uint64_t)ctx->row0[i] + f] = (int32_t)i;
+    RCHK(ctx, r->d_row_img.reserve(row_img.size() * 4));
+    RCHK(ctx, hipMemcpy(r->d_row_img.p, row_img.data(), row_img.size() * 4, hipMemcpyHostToDevice));
+    RCHK(ctx, r->d_wid.reserve(wid.size() * 4));
+    RCHK(ctx, r->d_sig.reserve(wid.size() * 8));
+    RCHK(ctx, hipMemcpy(r->d_wid.p, wid.data(), wid.size() * 4, hipMemcpyHostToDevice));
+    if (rows) {
+      hipLaunchKernelGGL(k_vocab_signature, dim3(2048), dim3(256), 0, st, ctx->d_desc.as<int8_t>(), rows, r->d_projT.as<float>(),
+                         r->d_thr.as<float>(), r->d_wid.as<int32_t>(), (int)kk, r->d_sig.as<uint64_t>());
+      RCHK(ctx, hipGetLastError());
+    }
+    r->k_assigned = kk;
+    r->host_loaded = purpose;
+    return DSM_OK;
+  }
   if (r->k_assigned >= k && r->d_wid.p) return DSM_OK;
   // row -> image (padding rows: -1)
   std::vector<int32_t> row_img(std::max<uint64_t>(rows, 1), -1);
@@ -730,6 +776,34 @@ int dsm_retrieval_set_vocabulary(dsm_ctx* ctx, const dsm_vocabulary* v) {
   return DSM_OK;
 }
 
+int dsm_retrieval_set_word_ids(dsm_ctx* ctx, const int32_t* index_ids, uint32_t k_query, const int32_t* query_ids) {
+  if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
+  RetrievalState* r = ctx->retrieval;
+  if (!r || !r->have_vocab) return dsm_fail(ctx, DSM_ERR_NOT_READY, "dsm_retrieval_set_vocabulary has not run");
+  r->indexed = false;
+  r->k_assigned = 0;
+  r->host_loaded = 0;
+  if (!index_ids && !query_ids) {  // back to the device's exact search
+    r->host_ids = false;
+    r->host_index_ids.clear();
+    r->host_query_ids.clear();
+    return DSM_OK;
+  }
+  if (!index_ids || !query_ids || k_query == 0 || k_query > RK_MAX) return dsm_fail(ctx, DSM_ERR_INVALID_ARGUMENT, "word id lists / k_query (1..8)");
+  uint64_t n_feat = 0;
+  for (uint32_t i = 0; i < ctx->n_images; ++i) n_feat += ctx->nfeat[i];
+  for (uint64_t i = 0; i < n_feat; ++i)  // (a 1-neighbour search over >= 1 words always returns a word: every feature is indexed)
+    if (index_ids[i] < 0 || (uint32_t)index_ids[i] >= r->num_words) return dsm_fail(ctx, DSM_ERR_OUT_OF_RANGE, "word id outside the vocabulary");
+  for (uint64_t i = 0; i < n_feat * k_query; ++i)
+    if (query_ids[i] != RK_INVALID && (query_ids[i] < 0 || (uint32_t)query_ids[i] >= r->num_words))
+      return dsm_fail(ctx, DSM_ERR_OUT_OF_RANGE, "word id outside the vocabulary");
+  r->host_index_ids.assign(index_ids, index_ids + n_feat);
+  r->host_query_ids.assign(query_ids, query_ids + n_feat * k_query);
+  r->host_k_query = k_query;
+  r->host_ids = true;
+  return DSM_OK;
+}
+
 int dsm_retrieval_index(dsm_ctx* ctx) {
   if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
   RetrievalState* r = ctx->retrieval;
@@ -740,7 +814,8 @@ int dsm_retrieval_index(dsm_ctx* ctx) {
   const uint32_t W = r->num_words, NI = ctx->n_images;
   RCHK(ctx, hipEventRecord(r->ev0, st));
   r->k_assigned = 0;  // the resident images may have changed
-  int rc = retrieval_assign(ctx, RK_MAX);
+  r->host_loaded = 0;
+  int rc = retrieval_assign(ctx, RK_MAX, ASSIGN_FOR_INDEX);
   if (rc != DSM_OK) return rc;
   const uint64_t n_entries = r->img_valid_start[NI];  // one entry per feature (IndexOptions::num_neighbors = 1)
   const uint64_t rows1 = std::max<uint64_t>(rows, 1);
@@ -839,6 +914,11 @@ int dsm_retrieval_query(dsm_ctx* ctx, uint32_t num_neighbors, uint32_t max_num_i
   const uint32_t NI = ctx->n_images;
   if (NI == 0) return DSM_OK;
   const int k = (int)num_neighbors;
+  if (r->host_ids) {
+    if (num_neighbors != r->host_k_query) return dsm_fail(ctx, DSM_ERR_INVALID_ARGUMENT, "num_neighbors differs from the k of dsm_retrieval_set_word_ids");
+    const int rca = retrieval_assign(ctx, num_neighbors, ASSIGN_FOR_QUERY);
+    if (rca != DSM_OK) return rca;
+  }
   RCHK(ctx, hipEventRecord(r->ev0, st));
   DevBuf& d_nfeat = r->d_nfeat;  // owned by the state: released with it on every exit path
   RCHK(ctx, d_nfeat.reserve((size_t)NI * 4));
@@ -911,6 +991,12 @@ int dsm_retrieval_matches(dsm_ctx* ctx, uint32_t num_neighbors, uint32_t max_num
   offsets[0] = 0;
   r->m_total = 0;
   if (NI == 0) return DSM_OK;
+  if (r->host_ids) {
+    if (num_neighbors != r->host_k_query) return dsm_fail(ctx, DSM_ERR_INVALID_ARGUMENT, "num_neighbors differs from the k of dsm_retrieval_set_word_ids");
+    RCHK(ctx, hipSetDevice(ctx->device));
+    const int rca = retrieval_assign(ctx, num_neighbors, ASSIGN_FOR_QUERY);
+    if (rca != DSM_OK) return rca;
+  }
   const size_t smem = ((size_t)NI + 31) / 32 * 4;
   if (smem > 60000) return dsm_fail(ctx, DSM_ERR_OUT_OF_RANGE, "dsm_retrieval_matches: more than 480 000 resident images");
   if (r->num_words >= (1u << 24)) return dsm_fail(ctx, DSM_ERR_OUT_OF_RANGE, "dsm_retrieval_matches: more than 2^24 visual words");
@@ -980,7 +1066,8 @@ int dsm_retrieval_debug_word_ids(dsm_ctx* ctx, uint32_t image, uint32_t k, int32
   if (image >= ctx->n_images || k == 0 || k > RK_MAX) return dsm_fail(ctx, DSM_ERR_OUT_OF_RANGE, "image / k out of range");
   RCHK(ctx, hipSetDevice(ctx->device));
   r->k_assigned = 0;
-  int rc = retrieval_assign(ctx, RK_MAX);
+  r->host_loaded = 0;
+  int rc = retrieval_assign(ctx, RK_MAX, ASSIGN_FOR_QUERY);
   if (rc != DSM_OK) return rc;
   RCHK(ctx, hipStreamSynchronize(ctx->stream));
   std::vector<int32_t> all((size_t)ctx->nfeat[image] * RK_MAX);

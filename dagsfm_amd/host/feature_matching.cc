@@ -369,6 +369,35 @@ bool VocabSimilarityGraph::Run() {
   std::vector<float> sc(static_cast<size_t>(n) * max_images);
   int rc = dsm_set_images(ctx, n, nfeat.data(), desc.data(), nullptr, 0, nullptr);
   if (rc == DSM_OK) rc = dsm_retrieval_set_vocabulary(ctx, &v);
+  if (rc == DSM_OK && options_.word_search == VocabSimilaritySearchOptions::kFlann) {
+    // the reference's own word ids: FindWordIds with 1 neighbour for VisualIndex::Add (IndexOptions::num_neighbors,
+    // visual_index.h:62-73, 201-243; IndexImagesInVisualIndex passes the same num_checks, similarity_graph.cpp:56-85) and
+    // with num_nearest_neighbors for the query, over the index loaded from the vocabulary file
+    FlannIndex flann;
+    size_t at = 0;
+    if (!voc.flann_framed || !flann.Load(voc.flann_blob.data(), voc.flann_blob.size(), &at, voc.words.data(), voc.num_words)) {
+      last_error_ = "word_search = flann: " + (voc.flann_framed ? flann.error() : std::string("the vocabulary file carries no FLANN index"));
+      dsm_ctx_destroy(ctx);
+      return false;
+    }
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; ++i) total += nfeat[i];
+    const uint32_t kq = static_cast<uint32_t>(options_.num_nearest_neighbors);
+    std::vector<int32_t> index_ids(std::max<uint64_t>(total, 1)), query_ids(std::max<uint64_t>(total, 1) * kq);
+    uint64_t f0 = 0;
+    bool ok = kq >= 1;
+    for (uint32_t i = 0; ok && i < n; ++i) {
+      ok = flann.FindWordIds(desc[i], nfeat[i], 1, options_.num_checks, options_.num_threads, index_ids.data() + f0, nullptr) &&
+           flann.FindWordIds(desc[i], nfeat[i], kq, options_.num_checks, options_.num_threads, query_ids.data() + f0 * kq, nullptr);
+      f0 += nfeat[i];
+    }
+    if (!ok) {
+      last_error_ = "word_search = flann: the search refused num_nearest_neighbors / num_checks";
+      dsm_ctx_destroy(ctx);
+      return false;
+    }
+    rc = dsm_retrieval_set_word_ids(ctx, index_ids.data(), kq, query_ids.data());
+  }
   if (rc == DSM_OK) rc = dsm_retrieval_index(ctx);
   if (rc == DSM_OK)
     rc = dsm_retrieval_query(ctx, static_cast<uint32_t>(options_.num_nearest_neighbors), max_images, counts.data(), idx.data(), sc.data());
@@ -685,9 +714,19 @@ uint32_t dsm_host_spatial_rerank(uint32_t n_query_features, const float* query_g
   }
   return SpatialRerank(qg, c, num_images_after_verification, count, image_idx, scores);
 }
+int64_t dsm_host_vocab_candidate_pairs4(const char* database_path, const char* vocab_path, int num_images, int num_nearest_neighbors,
+                                        int max_num_features, int num_images_after_verification, int word_search_flann, int num_checks,
+                                        uint32_t* pairs, float* scores, uint64_t capacity);
 int64_t dsm_host_vocab_candidate_pairs3(const char* database_path, const char* vocab_path, int num_images, int num_nearest_neighbors,
                                         int max_num_features, int num_images_after_verification, uint32_t* pairs, float* scores,
                                         uint64_t capacity) {
+  return dsm_host_vocab_candidate_pairs4(database_path, vocab_path, num_images, num_nearest_neighbors, max_num_features,
+                                         num_images_after_verification, 0, 256, pairs, scores, capacity);
+}
+// word_search_flann != 0: VocabSimilaritySearchOptions::word_search = kFlann with `num_checks`
+int64_t dsm_host_vocab_candidate_pairs4(const char* database_path, const char* vocab_path, int num_images, int num_nearest_neighbors,
+                                        int max_num_features, int num_images_after_verification, int word_search_flann, int num_checks,
+                                        uint32_t* pairs, float* scores, uint64_t capacity) {
   try {
     Database db(database_path);
     VocabSimilaritySearchOptions o;
@@ -696,6 +735,8 @@ int64_t dsm_host_vocab_candidate_pairs3(const char* database_path, const char* v
     o.max_num_features = max_num_features;
     o.num_images_after_verification = num_images_after_verification;
     o.vocab_tree_path = vocab_path;
+    o.word_search = word_search_flann ? VocabSimilaritySearchOptions::kFlann : VocabSimilaritySearchOptions::kExact;
+    o.num_checks = num_checks;
     VocabSimilarityGraph g(o, db);
     if (!g.Run()) {
       std::cerr << "ERROR: " << g.LastError() << std::endl;

@@ -239,7 +239,13 @@ class ExhaustiveFeatureMatcher {
 struct VocabSimilaritySearchOptions {  // similarity_graph.h:52-76
   int num_images = 100;
   int num_nearest_neighbors = 5;
-  int num_checks = 256;                   // FLANN search effort in the reference; the search is exact here
+  int num_checks = 256;                   // FLANN search effort (QueryOptions::num_checks); only word_search = kFlann consults it
+  // How a feature's visual words are found.  kExact (default): the true nearest words, searched on the device.  kFlann: the
+  // reference's own answer -- the approximate search of the flann::AutotunedIndex stored in the vocabulary file
+  // (visual_index.h:695-738), restated on the host (flann_index.h) bit for bit; needs a vocabulary file in the reference's
+  // layout (this library's flat file carries no index).
+  enum WordSearch { kExact = 0, kFlann = 1 };
+  WordSearch word_search = kExact;
   int num_images_after_verification = 0;  // > 0: spatial re-ranking of the retrieved images (spatial_verification.h); 0 = off is the reference's default
   int max_num_features = -1;              // > 0: index and query only the features of largest scale (ExtractTopScaleFeatures)
   int num_threads = 8;

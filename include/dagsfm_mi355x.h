@@ -295,6 +295,14 @@ typedef struct dsm_vocabulary {
   const float* thresholds; /* [num_words][64] per-word embedding thresholds, InvertedFile::thresholds_ */
 } dsm_vocabulary;
 int dsm_retrieval_set_vocabulary(dsm_ctx* ctx, const dsm_vocabulary* vocabulary);
+/* The reference's OWN word ids instead of the device's exact nearest words: VisualIndex::FindWordIds (visual_index.h:
+ * 695-738) asks the flann::AutotunedIndex loaded from the vocabulary file for APPROXIMATE neighbours, once with 1
+ * neighbour when a feature is indexed (VisualIndex::Add, :201-243) and once with QueryOptions::num_neighbors when it is
+ * queried (:664-693).  The host shim restates that search (dagsfm_amd/host/flann_index.cc, bit for bit against the
+ * reference's FLANN) and hands the ids over here: index_ids [features] and query_ids [features][k_query] for the
+ * features of all resident images back to back, kInvalidWordId (INT_MAX) where FLANN returned fewer.  Later
+ * dsm_retrieval_index / _query / _matches use them (num_neighbors must equal k_query); both NULL: exact search again. */
+int dsm_retrieval_set_word_ids(dsm_ctx* ctx, const int32_t* index_ids, uint32_t k_query, const int32_t* query_ids);
 /* VisualIndex::Add (IndexOptions::num_neighbors = 1) for every resident image in list order, then Prepare()
  * (visual_index.h:201-243, 501-505): inverted files sorted by image, IDF weights, normalisation constants. */
 int dsm_retrieval_index(dsm_ctx* ctx);

@@ -21,9 +21,12 @@
 //
 // Third-party arithmetic that is NOT restated, and what stands in its place (DESIGN.md "Retrieval"):
 //   * FindWordIds (visual_index.h:695-738) asks FLANN's AutotunedIndex (lib/FLANN, randomised kd-trees / k-means
-//     tree, `num_checks` leaves) for APPROXIMATE nearest visual words.  Its answer depends on FLANN's random seeds and
-//     is not reproducible; here the search is EXACT: the num_neighbors words with the smallest squared L2 distance
-//     (integer arithmetic), ties to the lower word id, in ascending distance as FLANN returns them.
+//     tree, `num_checks` leaves) for APPROXIMATE nearest visual words.  By default the search here is EXACT: the
+//     num_neighbors words with the smallest squared L2 distance (integer arithmetic), ties to the lower word id, in
+//     ascending distance as FLANN returns them -- what the device's default search returns.  The reference's own
+//     answer is a function of the index stored in the vocabulary file; oracle_retrieval_set_word_search plugs the
+//     reference's FLANN itself (compiled from /root/reference/lib/FLANN into oracle/_ref/libflann_ref.so) into
+//     every Add / Query, which is what the product's word_search = flann mode is checked against.
 //   * `proj_matrix_ * descriptor.cast<float>()` is an Eigen float matrix-vector product whose summation order depends
 //     on Eigen's vectorisation; here each of the 64 sums runs over the 128 dimensions left to right in float
 //     (one rounding per multiply and per add).
@@ -80,7 +83,12 @@ struct InvertedFile {
   float idf_weight = 0.0f;
 };
 
+// VisualIndex::FindWordIds as a callback: ids[i * k + n], kInvalidWordId where the search returned fewer than k words
+typedef void (*WordSearchFn)(void* user, const uint8_t* desc, uint32_t n_desc, uint32_t k, int32_t* out_ids);
+
 struct Index {
+  WordSearchFn word_search = nullptr;  // oracle_retrieval_set_word_search: the reference's own FLANN (oracle/_ref/libflann_ref.so)
+  void* word_search_user = nullptr;
   int num_words = 0;
   std::vector<uint8_t> words;  // [W][128]
   std::vector<float> proj;     // [64][128] row-major
@@ -92,6 +100,10 @@ struct Index {
 // exact stand-in for VisualIndex::FindWordIds (see the header): ids[i*k + n], ascending distance, ties to the lower id
 void FindWordIds(const Index& ix, const uint8_t* desc, int n_desc, int k, std::vector<int>* ids) {
   ids->assign(static_cast<size_t>(n_desc) * k, kInvalidWordId);
+  if (ix.word_search) {  // the search the reference itself runs, plugged in by the test (see the header)
+    if (n_desc > 0) ix.word_search(ix.word_search_user, desc, static_cast<uint32_t>(n_desc), static_cast<uint32_t>(k), ids->data());
+    return;
+  }
   std::vector<std::pair<int64_t, int>> best(k);
   for (int i = 0; i < n_desc; ++i) {
     const uint8_t* d = desc + static_cast<size_t>(i) * kDescDim;
@@ -189,6 +201,15 @@ void* oracle_retrieval_create(const OracleVocabulary* v) {
   return ix;
 }
 void oracle_retrieval_destroy(void* h) { delete static_cast<Index*>(h); }
+
+// Replaces the exact word search by a caller-supplied one for every later Add / Query of this index -- the tests pass
+// flann_ref_find_word_ids of oracle/_ref/libflann_ref.so (the reference's own flann::AutotunedIndex::knnSearch over the
+// index loaded from the vocabulary file, oracle/ref_flann_shim.cpp) with its handle as `user`.  fn == NULL: exact again.
+void oracle_retrieval_set_word_search(void* h, WordSearchFn fn, void* user) {
+  Index* ix = static_cast<Index*>(h);
+  ix->word_search = fn;
+  ix->word_search_user = user;
+}
 
 // exact nearest words (test hook for the device's word assignment)
 void oracle_retrieval_find_word_ids(void* h, const uint8_t* desc, uint32_t n, uint32_t k, int32_t* out) {

@@ -338,6 +338,22 @@ def _retrieval_oracle_query_verified(self, desc, geom, num_neighbors=5, max_num_
     return ids[:n].copy(), sc[:n].copy()
 
 
+def _retrieval_oracle_use_flann(self, flann_index, num_checks=256):
+    """Every later Add / Query asks the reference's own FLANN (tests/flann_ref.Index: libflann_ref.so, compiled from
+    /root/reference/lib/FLANN) for its word ids instead of the exact search -- a plain C function pointer, no Python in the
+    loop.  None restores the exact search."""
+    from tests import flann_ref
+    self.L.oracle_retrieval_set_word_search.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    if flann_index is None:
+        self.L.oracle_retrieval_set_word_search(self.h, None, None)
+        return
+    flann_ref.load().flann_ref_set_search(flann_index.h, num_checks, 1)
+    fn = ctypes.cast(flann_ref.load().flann_ref_find_word_ids, ctypes.c_void_p)
+    self._flann = flann_index
+    self.L.oracle_retrieval_set_word_search(self.h, fn, flann_index.h)
+
+
+RetrievalOracle.use_flann = _retrieval_oracle_use_flann
 RetrievalOracle.add_geom = _retrieval_oracle_add_geom
 RetrievalOracle.query_verified = _retrieval_oracle_query_verified
 

@@ -172,3 +172,76 @@ def test_damaged_flann_sections_are_refused(tmp_path):
         else:
             assert ((ids >= 0) & ((ids < len(exp["words"])) | (ids == 2147483647))).all()
     assert n_bad > 20
+
+
+# ------------------------------------------------------------------------------------------- the product's word_search = flann
+def _flann_scene(tmp_path, rng, n_img, feats, n_words, algo, p1, p2):
+    from dagsfm_amd import synthetic
+    scene = synthetic.Scene(n_img, feats, seed=17)
+    ims = [scene.image(i) for i in range(n_img)]
+    desc = np.concatenate([im[0] for im in ims])
+    words = desc[rng.choice(len(desc), n_words, replace=False)].copy()
+    proj = rng.standard_normal((64, 128)).astype(np.float32)
+    # per-word thresholds around the projected words themselves, so that signatures are not all alike
+    thr = (proj @ words.astype(np.float32).T).T.astype(np.float32)
+    ix = flann_ref.Index.build_forced(words, algo, p1, p2, autotuned_checks=32, seed=9)
+    path = str(tmp_path / "vocab_tree.bin")
+    begin, end = flann_ref.write_reference_vocabulary(path, words, proj, thr, ix)
+    ix.close()
+    return ims, words, proj, thr, path, begin
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo,p1,p2", [(flann_ref.KDTREE, 4, 0), (flann_ref.KMEANS, 8, 3)])
+def test_word_search_flann_equals_the_oracle_over_the_references_flann(tmp_path, dsm, algo, p1, p2):
+    """VocabSimilarityGraph::Run with word_search = flann over a database.db and a vocabulary file carrying a REAL FLANN
+    tree: the candidate pairs and scores equal the oracle's whose every word search is the reference's own
+    flann::AutotunedIndex::knnSearch over the loaded index (oracle_retrieval_set_word_search <- libflann_ref.so) -- and
+    differ from the exact-search run, which is the point of the mode."""
+    _need_ref()
+    from tests import dbutil, oracle_lib
+    rng = np.random.default_rng(77 + algo)
+    n_img, feats, n_words, k, max_images, checks = 10, 400, 1500, 5, 6, 24
+    ims, words, proj, thr, vpath, begin = _flann_scene(tmp_path, rng, n_img, feats, n_words, algo, p1, p2)
+    dpath = str(tmp_path / "database.db")
+    dbutil.create(dpath, [(im[0], im[1]) for im in ims])
+    L = _host()
+    L.dsm_host_vocab_candidate_pairs4.restype = ctypes.c_int64
+    L.dsm_host_vocab_candidate_pairs4.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+    res = {}
+    for mode in (1, 0):
+        pairs = np.zeros((1000, 2), np.uint32)
+        scores = np.zeros(1000, np.float32)
+        n = L.dsm_host_vocab_candidate_pairs4(dpath.encode(), vpath.encode(), max_images, k, -1, 0, mode, checks, pairs.ctypes.data,
+                                              scores.ctypes.data, 1000)
+        assert n > 0
+        res[mode] = ([tuple(x) for x in pairs[:n]], scores[:n].copy())
+    ref = flann_ref.Index.load(words, vpath, begin)
+    orc = oracle_lib.RetrievalOracle(words, proj, thr)
+    orc.use_flann(ref, checks)
+    for i, im in enumerate(ims):
+        orc.add(i, im[0])
+    orc.prepare()
+    exp_pairs, exp_scores = [], []
+    for q, im in enumerate(ims):
+        ids, sc = orc.query(im[0], k, max_images)
+        for d, s in zip(ids, sc):
+            if q < int(d):
+                exp_pairs.append((q + 1, int(d) + 1))
+                exp_scores.append(np.float32(s) * np.float32(1e3))
+    assert res[1][0] == exp_pairs and (res[1][1] == np.array(exp_scores, np.float32)).all()
+    # the approximate search at 24 checks is not the exact one: the two modes score differently
+    assert res[0][0] != res[1][0] or not np.array_equal(res[0][1], res[1][1])
+    # and the device entry point itself, fed the reference's ids directly
+    dsm.set_images([im[0] for im in ims])
+    dsm.retrieval_set_vocabulary(words, proj, thr)
+    alld = np.concatenate([im[0] for im in ims])
+    dsm.retrieval_set_word_ids(ref.knn(alld, 1, num_checks=checks), ref.knn(alld, k, num_checks=checks))
+    dsm.retrieval_index()
+    got = dsm.retrieval_query(n_img, k, max_images)
+    dsm.retrieval_set_word_ids(None, None)
+    for q, im in enumerate(ims):
+        ids, sc = orc.query(im[0], k, max_images)
+        assert list(got[q][0]) == list(ids) and (got[q][1] == sc).all()
+    ref.close()
