@@ -462,6 +462,8 @@ void Database::DeleteInlierMatches(image_t a, image_t b) const {
 
 void Database::BeginTransaction() const { Exec("BEGIN TRANSACTION;"); }
 void Database::EndTransaction() const { Exec("END TRANSACTION;"); }
+void Database::SetBulkLoadJournal(bool in_memory) const { Exec(in_memory ? "PRAGMA journal_mode=MEMORY;" : "PRAGMA journal_mode=WAL;"); }
+
 void Database::RollbackTransaction() const {
   // nothing to roll back outside a transaction (sqlite would answer "cannot rollback - no transaction is active")
   if (database_ != nullptr && sqlite3_get_autocommit(database_)) return;

@@ -62,6 +62,12 @@ class Database {
   void BeginTransaction() const;
   void EndTransaction() const;
   void RollbackTransaction() const;
+  // Bulk-load setting for a run that only APPENDS rows (extension; measured in tools/sqlite_ceiling.py): the rollback journal
+  // in memory instead of the write-ahead log, so that every page of the new rows is written once instead of twice (WAL +
+  // checkpoint).  ROLLBACK keeps working; a process that dies inside the transaction can leave the file damaged where WAL
+  // would not (synchronous=OFF, the reference's own setting, already gives up the power-loss case).  false restores WAL,
+  // the mode the reference's Database::Open sets (database.cc:267-276).  No other connection may be open.
+  void SetBulkLoadJournal(bool in_memory) const;
 
  private:
   void CreateTables() const;

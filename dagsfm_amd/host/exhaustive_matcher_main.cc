@@ -13,7 +13,7 @@ int main(int argc, char** argv) {
   std::string db;
   int block = 1000;  // the reference's default of 50 bounds its host cache; here a large block amortises the per-call costs
   unsigned seed = 0;
-  int guided = 0, multiple = 0;
+  int guided = 0, multiple = 0, timing = 0, bulk = 0;
   std::string gpu_index = "-1";  // all visible devices
   // this executable's own switch for the tests / tools (the libraries read no environment): DSM_ASYNC_WRITE_BACK=1 is
   // --SiftMatching.async_write_back 1
@@ -27,12 +27,14 @@ int main(int argc, char** argv) {
     else if (k == "--SiftMatching.multiple_models") multiple = std::atoi(argv[i + 1]);
     else if (k == "--SiftMatching.gpu_index") gpu_index = argv[i + 1];
     else if (k == "--SiftMatching.async_write_back") async_write_back = std::atoi(argv[i + 1]);
+    else if (k == "--timing") timing = std::atoi(argv[i + 1]);
+    else if (k == "--SiftMatching.bulk_load_journal") bulk = std::atoi(argv[i + 1]);
   }
   if (db.empty()) {
     std::cerr << "usage: dsm_exhaustive_matcher --database_path database.db [--ExhaustiveMatching.block_size 1000] [--random_seed 0]"
                  " [--SiftMatching.guided_matching 0] [--SiftMatching.multiple_models 0] [--SiftMatching.gpu_index -1]"
-                 " [--SiftMatching.async_write_back 0]\n";
+                 " [--SiftMatching.async_write_back 0] [--SiftMatching.bulk_load_journal 0] [--timing 0]\n";
     return 64;
   }
-  return dsm_host_exhaustive_matcher_ex2(db.c_str(), block, 1, seed, 0, 0, 1, 15, guided, multiple, gpu_index.c_str(), async_write_back);
+  return dsm_host_exhaustive_matcher_ex2(db.c_str(), block, 1, seed, 0, 0, 1, 15, guided, multiple, gpu_index.c_str(), (async_write_back ? 1 : 0) | (timing ? 2 : 0) | (bulk ? 4 : 0));
 }

@@ -118,6 +118,19 @@ bool ExhaustiveFeatureMatcher::Run() {
     std::cerr << "ERROR: " << matcher_.LastError() << std::endl;
     return false;
   }
+  const auto t_run = std::chrono::steady_clock::now();
+  struct JournalGuard {  // WAL again however Run() ends
+    const Database* db;
+    ~JournalGuard() {
+      if (db) {
+        try {
+          db->SetBulkLoadJournal(false);
+        } catch (...) {
+        }
+      }
+    }
+  } journal_guard{match_options_.bulk_load_journal ? &database_ : nullptr};
+  if (match_options_.bulk_load_journal) database_.SetBulkLoadJournal(true);
   cache_.Setup();
   const std::vector<image_t> image_ids = cache_.GetImageIds();
   const size_t block_size = static_cast<size_t>(options_.block_size);
@@ -160,6 +173,7 @@ bool ExhaustiveFeatureMatcher::Run() {
     }
   }
   matcher_.Flush();
+  run_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run).count();
   return true;
 }
 
@@ -496,6 +510,9 @@ extern "C" {
 int dsm_host_exhaustive_matcher_ex2(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,
                                     double max_ratio, double max_distance, int cross_check, int min_num_inliers,
                                     int guided_matching, int multiple_models, const char* gpu_index, int async_write_back) {
+  const bool print_timing = async_write_back & 2;  // bit 1 of the flag word: print the stage timers
+  const bool bulk_load_journal = async_write_back & 4;  // bit 2: SiftMatchingOptions::bulk_load_journal
+  async_write_back &= 1;
   try {
     ExhaustiveMatchingOptions eo;
     eo.block_size = block_size;
@@ -509,10 +526,20 @@ int dsm_host_exhaustive_matcher_ex2(const char* database_path, int block_size, i
     mo.guided_matching = guided_matching != 0;
     mo.multiple_models = multiple_models != 0;
     mo.async_write_back = async_write_back != 0;  // overlap SQLite with the device
+    mo.bulk_load_journal = bulk_load_journal;
     if (gpu_index && *gpu_index) mo.gpu_index = gpu_index;
     mo.random_seed = random_seed;
     ExhaustiveFeatureMatcher m(eo, mo, database_path);
-    return m.Run() ? 0 : 2;
+    const bool ok = m.Run();
+    if (ok && print_timing) {  // the CLI's --timing 1: one line on stderr, what tools/bench_cli.py keeps
+      const SiftFeatureMatcher::Timings t = m.MatcherTimings();
+      std::fprintf(stderr, "[dsm_exhaustive_matcher] pairs %llu  run %.3f s  =  features from database.db -> device %.3f s  +  device (match + verify + fetch) "
+                           "%.3f s  +  SQLite write-back %.3f s%s  +  other %.3f s\n",
+                   static_cast<unsigned long long>(t.pairs), m.run_seconds, t.resident_s, t.device_s, t.write_s,
+                   mo.async_write_back ? " (on the write-back thread: overlaps the device time)" : "",
+                   m.run_seconds - t.resident_s - t.device_s - (mo.async_write_back ? 0.0 : t.write_s));
+    }
+    return ok ? 0 : 2;
   } catch (const std::exception& e) {
     std::cerr << "ERROR: " << e.what() << std::endl;
     return 1;

@@ -223,6 +223,9 @@ class ExhaustiveFeatureMatcher {
   ExhaustiveFeatureMatcher(const ExhaustiveMatchingOptions& options, const SiftMatchingOptions& match_options,
                            const std::string& database_path);
   bool Run();
+  // where Run()'s wall time went: SiftFeatureMatcher's stage timers + Run()'s own total
+  SiftFeatureMatcher::Timings MatcherTimings() const { return matcher_.GetTimings(); }
+  double run_seconds = 0.0;
 
  private:
   ExhaustiveMatchingOptions options_;

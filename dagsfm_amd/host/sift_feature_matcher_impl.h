@@ -21,6 +21,7 @@
 #define DAGSFM_AMD_HOST_SIFT_FEATURE_MATCHER_IMPL_H_
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -112,6 +113,15 @@ class SiftFeatureMatcherT {
     }
   }
 
+  // Where a run's wall time went (seconds, summed over all Match() calls of this object): reading features from the cache /
+  // database and making them resident on the devices; the device calls (matching, verification, fetch of the results); the
+  // write-back into the `matches` / `two_view_geometries` tables -- on the caller's thread, or on the write-back thread
+  // (then it overlaps the next call's device work and is NOT part of the caller's wall time).
+  struct Timings {
+    double resident_s, device_s, write_s;
+    uint64_t pairs;
+  };
+  Timings GetTimings() const { return timings_; }
   const std::string& LastError() const { return last_error_; }
   size_t NumDevices() const { return ctxs_.size(); }
   size_t NumResidentImages() const { return image_ids_.size(); }
@@ -149,7 +159,12 @@ class SiftFeatureMatcherT {
         }
       }
     }
-    if (!EnsureResident(to_match, to_verify_only)) throw std::runtime_error(last_error_);
+    {
+      const Clock::time_point t0 = Clock::now();
+      const bool resident = EnsureResident(to_match, to_verify_only);
+      timings_.resident_s += Seconds(t0);
+      if (!resident) throw std::runtime_error(last_error_);
+    }
     dsm_match_options mo;
     dsm_default_match_options(&mo);
     mo.max_ratio = options_.max_ratio;
@@ -246,6 +261,7 @@ class SiftFeatureMatcherT {
       shares[d].end = at;
     }
     shares[nd - 1].end = np;
+    const Clock::time_point t_device = Clock::now();
     if (nd == 1) {
       RunShare(ctxs_[0], prs, given, mo, to, &shares[0]);
     } else {
@@ -253,6 +269,8 @@ class SiftFeatureMatcherT {
       for (size_t d = 0; d < nd; ++d) th.emplace_back([&, d]() { RunShare(ctxs_[d], prs, given, mo, to, &shares[d]); });
       for (auto& t : th) t.join();
     }
+    timings_.device_s += Seconds(t_device);
+    timings_.pairs += np;
     for (const Share& sh : shares)
       if (!sh.error.empty()) throw std::runtime_error(sh.error);
     // merge the shares in list order
@@ -291,8 +309,13 @@ class SiftFeatureMatcherT {
     batch->ioff.swap(ioff);
     batch->im.swap(im);
     if (WriteBackAsync(batch, std::integral_constant<bool, Traits::kAsyncWriteBack>())) return;
+    const Clock::time_point t_write = Clock::now();
     batch->Write();
+    timings_.write_s += Seconds(t_write);
   }
+
+  typedef std::chrono::steady_clock Clock;
+  static double Seconds(const Clock::time_point& since) { return std::chrono::duration<double>(Clock::now() - since).count(); }
 
   // The rows of one Run(): what the write-back needs, owned by whoever writes them (this thread or the writer thread).
   // (A struct behind a shared_ptr instead of a lambda with init-captures: the reference builds with -std=c++11,
@@ -345,11 +368,13 @@ class SiftFeatureMatcherT {
       typename Traits::Cache* const cache = batch->cache;
       bool open = false;
       try {
+        const Clock::time_point t_write = Clock::now();
         cache->BeginTransaction();
         open = true;
         batch->Write();
         cache->EndTransaction();  // a failing COMMIT (SQLITE_BUSY, SQLITE_FULL) leaves the transaction open:
         open = false;             // only a COMMIT that returned has closed it
+        self->timings_.write_s += Seconds(t_write);  // (one write-back in flight: Flush() joins before the next starts)
       } catch (...) {
         self->writer_error_ = std::current_exception();
         // close the transaction without its rows and make the cache say what the database says again: the batch's
@@ -471,6 +496,7 @@ class SiftFeatureMatcherT {
   std::vector<uint32_t> image_nfeat_;
   std::unordered_map<image_id_t, uint32_t> image_index_;  // image_id -> device image index
   std::string last_error_;
+  Timings timings_ = Timings();
   std::thread writer_;  // at most one write-back in flight
   std::exception_ptr writer_error_;
 };

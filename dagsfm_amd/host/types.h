@@ -86,6 +86,8 @@ struct SiftMatchingOptions {  // feature/sift.h:116-165, same names and defaults
   // and the rows are written by a background thread, overlapping SQLite with the next block's device work; the
   // writer owns the transaction, so the caller must not hold one; Flush() / the destructor waits for it.
   bool async_write_back = false;
+  // extension: Database::SetBulkLoadJournal(true) for the run (ExhaustiveFeatureMatcher::Run restores WAL at its end)
+  bool bulk_load_journal = false;
   // not in the reference: seed of the per-pair PRNG schedule (the reference seeds from the clock)
   uint32_t random_seed = 0;
   bool Check() const;  // feature/sift.cc:236-250

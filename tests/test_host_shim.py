@@ -399,3 +399,33 @@ def test_malformed_blobs_are_errors_not_overreads(tmp_path):
     q, t = np.zeros(4), np.zeros(3)
     assert L.dsm_host_db_read_pair(path.encode(), 1, 3, m.ctypes.data_as(u32p), ctypes.byref(nm), ctypes.byref(cfg), q.ctypes.data_as(f64p),
                                    t.ctypes.data_as(f64p), inl.ctypes.data_as(u32p), ctypes.byref(ni), 256) != 0
+
+
+@pytest.mark.gpu
+def test_bulk_load_journal_writes_the_same_rows_and_restores_wal(tmp_path):
+    """SiftMatchingOptions::bulk_load_journal (extension, tools/sqlite_ceiling.py): the run appends its rows under an in-memory
+    rollback journal instead of the WAL; the rows are the blocking run's, and the file is back in WAL mode afterwards -- the
+    mode the reference's Database::Open sets (database.cc:267-276)."""
+    from dagsfm_amd import synthetic
+    n_img = 6
+    scene = synthetic.Scene(n_img, 512, seed=36, n_pool=1400)
+    ims = [scene.image(i) for i in range(n_img)]
+    res = []
+    for k, flags in enumerate([[], ["--SiftMatching.bulk_load_journal", "1"], ["--SiftMatching.bulk_load_journal", "1", "--SiftMatching.async_write_back", "1"]]):
+        path = str(tmp_path / ("database%d.db" % k))
+        dbutil.create(path, [(im[0], im[1]) for im in ims], prior=True)
+        r = subprocess.run([CLI, "--database_path", path, "--ExhaustiveMatching.block_size", "3", "--random_seed", "4", "--timing", "1"] + flags,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "SQLite write-back" in r.stderr
+        con = sqlite3.connect(path)
+        assert con.execute("PRAGMA journal_mode").fetchone()[0] == "wal"
+        con.close()
+        res.append(dbutil.read_results(path))
+    base_m, base_t = res[0]
+    assert len(base_m) == n_img * (n_img - 1) // 2
+    for m, t in res[1:]:
+        assert m.keys() == base_m.keys() and t.keys() == base_t.keys()
+        for pid in base_m:
+            assert (m[pid] == base_m[pid]).all() and t[pid]["config"] == base_t[pid]["config"] and (t[pid]["inliers"] == base_t[pid]["inliers"]).all()
+            assert t[pid]["F"] == base_t[pid]["F"] and t[pid]["E"] == base_t[pid]["E"]
