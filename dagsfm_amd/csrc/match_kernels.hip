@@ -131,6 +131,9 @@ __device__ __forceinline__ void k1_epilogue_quarter(const v16i& a, int& best, in
   }
 }
 
+#ifndef K1_LDS_DMA
+#define K1_LDS_DMA 0  // 1: B tiles staged by global_load_lds_dwordx4 (A/B'd in round 4)
+#endif
 // LDS image of a 64-column B tile: column c occupies 128 B; its eight 16-B chunks are
 // XOR-swizzled with (c>>1)&7 so that the 16-lane ds_read_b128 groups are conflict free.
 __device__ __forceinline__ int lds_off(int col, int chunk) {
@@ -198,8 +201,31 @@ __global__ __launch_bounds__(256, 2) void k1_best_rows(const K1Params p) {
   const int32_t* rt_b = p.rterm + b_row0;
   const uint32_t nsteps = b_cols >> 6;
 
-  v4i stage[2];
   int cstage = 0;
+#if K1_LDS_DMA
+  // B tiles go global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no ds_write).  The DMA writes a wave's
+  // 64 x 16 B linearly at a wave-uniform LDS base, so the XOR swizzle of lds_off moves to the SOURCE: LDS slot L (column
+  // L >> 3, chunk position L & 7) receives the column's chunk (L & 7) ^ ((L >> 4) & 7) -- the same involution the reads
+  // apply; the eight chunks of a column are one 128-B line, so the permutation costs no coalescing.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  int src_off[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int L = tid + 256 * u;
+    src_off[u] = ((L & ~7) | ((L & 7) ^ ((L >> 4) & 7))) * 16;
+  }
+  auto stage_tile = [&](const int8_t* src, int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + src_off[u]),
+                                       (__attribute__((address_space(3))) void*)(&sB[buf][(wave_u * 64 + 256 * u) * 16]), 16, 0, 0);
+  };
+  stage_tile(bimg, 0);
+  cstage = rt_b[tid & 63];
+  if (tid < 64) sC[0][tid] = cstage + (1 << 21);
+  __syncthreads();  // (its fence waits for the DMA: vmcnt(0))
+#else
+  v4i stage[2];
   // prologue: step 0
 #pragma unroll
   for (int u = 0; u < 2; ++u) stage[u] = *reinterpret_cast<const v4i*>(bimg + (size_t)(tid + 256 * u) * 16);
@@ -211,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void k1_best_rows(const K1Params p) {
   }
   if (tid < 64) sC[0][tid] = cstage + (1 << 21);
   __syncthreads();
+#endif
   // make sure nothing issued before the loop is still pending at its head: hipcc's waitcnt pass would
   // otherwise keep a conservative vmcnt wait at the top of every iteration (right behind the prefetch)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -221,8 +248,12 @@ __global__ __launch_bounds__(256, 2) void k1_best_rows(const K1Params p) {
     // prefetch of the next B step (global -> registers); consumed at the end of the step
     if (more) {
       const int8_t* src = bimg + (size_t)(s + 1) * 64 * 128;
+#if K1_LDS_DMA
+      stage_tile(src, cur ^ 1);  // the buffer of the previous step: every wave left it at the barrier that ended that step
+#else
 #pragma unroll
       for (int u = 0; u < 2; ++u) stage[u] = *reinterpret_cast<const v4i*>(src + (size_t)(tid + 256 * u) * 16);
+#endif
       cstage = rt_b[(s + 1) * 64 + (tid & 63)];
     }
     if (active) {
@@ -277,11 +308,13 @@ __global__ __launch_bounds__(256, 2) void k1_best_rows(const K1Params p) {
 #undef K1_EPI
     }
     if (more) {
+#if !K1_LDS_DMA
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int q = tid + 256 * u;
         *reinterpret_cast<v4i*>(&sB[cur ^ 1][lds_off(q >> 3, q & 7)]) = stage[u];
       }
+#endif
       if (tid < 64) sC[cur ^ 1][tid] = cstage + (1 << 21);
     }
     __syncthreads();
