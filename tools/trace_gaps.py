@@ -13,7 +13,10 @@ starts = [s for s, e, n in ev if "k1_best_rows<false>" in n or "k1_best_rows<(bo
 t0 = starts[-1]
 ev = [x for x in ev if x[0] >= t0]
 first_verify = min(s for s, e, n in ev if "k_verify_prep" in n)
-ver = [x for x in ev if x[0] >= first_verify]
+# the verification ends with its last k_final_finish / k_compact_inliers; what follows (result fetches, torch kernels of the
+# statistics, the next step) is not part of it
+last_final = max(e for s, e, n in ev if s >= first_verify and ("k_final_finish" in n or "k_compact_inliers" in n))
+ver = [x for x in ev if x[0] >= first_verify and x[0] <= last_final]
 t1 = max(e for s, e, n in ver)
 busy_end = first_verify
 gaps = []
