@@ -1756,6 +1756,42 @@ DSM_DEV void count_inlier(double r, double max_residual, double& sum, int& cnt) 
       : "vcc", "scc");
 }
 
+// InlierSupportMeasurer::Evaluate (support_measurement.cc:43-48) of ONE model by one lane: inlier count and the in-order
+// residual_sum over the pair's correspondences (staged in LDS when they fit: spts; otherwise gpts)
+template <int FAM>
+DSM_DEV void exact_support(const double* M, int n, bool in_lds, const double* spts, const double* gpts, double max_residual, int& cnt,
+                           double& sum) {
+  // InlierSupportMeasurer::Evaluate (support_measurement.cc:43-48): the lane walks the correspondences in index
+  // order, so its running sum IS the in-order residual_sum that decides ties between equal inlier counts
+  // (two loops, not one over a selected pointer: a pointer that may be LDS or global compiles to flat loads with a
+  // full wait per point; apart, the staged points are ds_read_b128 broadcasts and the loop is unrolled over four points)
+  cnt = 0;
+  sum = 0;
+  if (in_lds) {
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {  // four points per trip by hand: a loop with inline assembly is not unrolled for us
+      const double r0 = fam_residual<FAM>(M, spts + (size_t)i * 4), r1 = fam_residual<FAM>(M, spts + (size_t)(i + 1) * 4);
+      const double r2 = fam_residual<FAM>(M, spts + (size_t)(i + 2) * 4), r3 = fam_residual<FAM>(M, spts + (size_t)(i + 3) * 4);
+      count_inlier(r0, max_residual, sum, cnt);
+      count_inlier(r1, max_residual, sum, cnt);
+      count_inlier(r2, max_residual, sum, cnt);
+      count_inlier(r3, max_residual, sum, cnt);
+    }
+    for (; i < n; ++i) count_inlier(fam_residual<FAM>(M, spts + (size_t)i * 4), max_residual, sum, cnt);
+  } else {
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {  // four points per trip by hand: a loop with inline assembly is not unrolled for us
+      const double r0 = fam_residual<FAM>(M, gpts + (size_t)i * 4), r1 = fam_residual<FAM>(M, gpts + (size_t)(i + 1) * 4);
+      const double r2 = fam_residual<FAM>(M, gpts + (size_t)(i + 2) * 4), r3 = fam_residual<FAM>(M, gpts + (size_t)(i + 3) * 4);
+      count_inlier(r0, max_residual, sum, cnt);
+      count_inlier(r1, max_residual, sum, cnt);
+      count_inlier(r2, max_residual, sum, cnt);
+      count_inlier(r3, max_residual, sum, cnt);
+    }
+    for (; i < n; ++i) count_inlier(fam_residual<FAM>(M, gpts + (size_t)i * 4), max_residual, sum, cnt);
+  }
+}
+
 template <int FAM>
 __global__ __launch_bounds__(64, 8) void k_score(const VerifyParams p) {
   typedef Fam<FAM> F;
@@ -1783,37 +1819,238 @@ __global__ __launch_bounds__(64, 8) void k_score(const VerifyParams p) {
   const double* gm = p.models + ((size_t)pl * p.batch + t) * F::MAXM * 9 + m * 9;
   double M[9];
   for (int k = 0; k < 9; ++k) M[k] = gm[k];
-  // InlierSupportMeasurer::Evaluate (support_measurement.cc:43-48): the lane walks the correspondences in index
-  // order, so its running sum IS the in-order residual_sum that decides ties between equal inlier counts
-  // (two loops, not one over a selected pointer: a pointer that may be LDS or global compiles to flat loads with a
-  // full wait per point; apart, the staged points are ds_read_b128 broadcasts and the loop is unrolled over four points)
   int cnt = 0;
   double sum = 0;
-  if (in_lds) {
-    int i = 0;
-    for (; i + 4 <= n; i += 4) {  // four points per trip by hand: a loop with inline assembly is not unrolled for us
-      const double r0 = fam_residual<FAM>(M, spts + (size_t)i * 4), r1 = fam_residual<FAM>(M, spts + (size_t)(i + 1) * 4);
-      const double r2 = fam_residual<FAM>(M, spts + (size_t)(i + 2) * 4), r3 = fam_residual<FAM>(M, spts + (size_t)(i + 3) * 4);
-      count_inlier(r0, max_residual, sum, cnt);
-      count_inlier(r1, max_residual, sum, cnt);
-      count_inlier(r2, max_residual, sum, cnt);
-      count_inlier(r3, max_residual, sum, cnt);
-    }
-    for (; i < n; ++i) count_inlier(fam_residual<FAM>(M, spts + (size_t)i * 4), max_residual, sum, cnt);
-  } else {
-    int i = 0;
-    for (; i + 4 <= n; i += 4) {  // four points per trip by hand: a loop with inline assembly is not unrolled for us
-      const double r0 = fam_residual<FAM>(M, gpts + (size_t)i * 4), r1 = fam_residual<FAM>(M, gpts + (size_t)(i + 1) * 4);
-      const double r2 = fam_residual<FAM>(M, gpts + (size_t)(i + 2) * 4), r3 = fam_residual<FAM>(M, gpts + (size_t)(i + 3) * 4);
-      count_inlier(r0, max_residual, sum, cnt);
-      count_inlier(r1, max_residual, sum, cnt);
-      count_inlier(r2, max_residual, sum, cnt);
-      count_inlier(r3, max_residual, sum, cnt);
-    }
-    for (; i < n; ++i) count_inlier(fam_residual<FAM>(M, gpts + (size_t)i * 4), max_residual, sum, cnt);
-  }
+  exact_support<FAM>(M, n, in_lds, spts, gpts, max_residual, cnt, sum);
   p.counts[((size_t)pl * p.batch + t) * F::MAXM + m] = cnt;
   p.sums[((size_t)pl * p.batch + t) * F::MAXM + m] = sum;
+}
+
+// ------------------------------------------------------------------------------------ k_score as bound + exact (round 4)
+// LO-RANSAC only ever LOOKS at the support of a trial that can still beat the best support so far (loransac.h:150-158:
+// `if (support_measurer.Compare(support, best_support))`): a model whose inlier count is below a count some EARLIER model
+// (or an earlier round's best) has reached cannot change anything, whatever its exact count and sum are -- and on a
+// non-planar pair that is all but a few dozen of the 1 765 homographies.  So the scoring runs in two steps:
+//   k_prescore    every (trial, model) slot: a LOWER and an UPPER bound of its inlier count from a division-free test in
+//                 fused arithmetic (18 VALU per homography residual instead of 36 + a quarter-rate v_rcp_f64), each point
+//                 classified "surely inlier" / "surely outlier" / "uncertain" with margins derived below;
+//   k_score_needed  per pair: the running maximum of the LOWER bounds in trial order (starting from the best count of the
+//                 earlier rounds); a slot whose UPPER bound reaches it is scored EXACTLY (exact_support: the reference's own
+//                 operations, count and in-order sum), every other slot is written as support (0, 0) -- fewer inliers than
+//                 the best support at that point of the scan, which is all the replay ever asks of it.
+// The bounds are rigorous, not heuristic (u = 2^-53; all comparisons are false on NaN, which makes a point uncertain):
+//   H (homography_matrix.cc:94-131): with A_k = |H_k0| max|s_0| + |H_k1| max|s_1| + |H_k2|, the reference's pd_k (3 roundings)
+//     and the fused pd_k here (2) both lie within E_k = 4u A_k of the exact value.  A point is classified only if
+//     |pd_2| >= P_min = max(2^34 E_2, 2^26 max(E_0, E_1), 2^-400): then pd_2 is known to 2^-34 relative and pd_0 / pd_2 to
+//     2^-26 px + 2^-34 |pd_0 / pd_2|, so with coordinates below 2^14 px the reference's dd_k and e_k / pd_2 here
+//     (e_k = d_k pd_2 - pd_k) both lie within a = 2^-20 (1 + 2^-5) px + 2^-33 |dd_k| of the exact difference, and
+//     sqrt(r) is pinned to 2.8e-6 px + 3e-10 relative on either side: L = e_0^2 + e_1^2 <= T pd_2^2 (1 - 2^-12) implies
+//     r_ref <= T and L >= T pd_2^2 (1 + 2^-12) implies r_ref > T for every T >= 2^-6 (margin >= 2.6x).
+//   F (utils.cc:87-131): g = F x1, h = F^T x2 (first two rows), C = x2^T F x1.  With B_k / Bt_j the sums of absolute terms
+//     over the pair's coordinate maxima, every g_k, h_j is within 4u B of exact, C within E_C = 8u (max|x2_0| B_0 +
+//     max|x2_1| B_1 + B_2), D = g_0^2 + g_1^2 + h_0^2 + h_1^2 within 2 sqrt(D) E_D + 4u D, E_D = 4u (B_0 + B_1 + Bt_0 + Bt_1).
+//     A point is classified only if D >= D_min = max((2^26 E_D)^2, (2^16 E_C)^2 / T): D is then known to 2^-25 relative and
+//     |C| to 2^-16 sqrt(T D), so C^2 <= T D (1 - 2^-12) implies r_ref <= T and C^2 >= T D (1 + 2^-12) implies r_ref > T
+//     (needed: delta >= 2^-14 (1 + 2^-10); margin 4x).
+//   Magnitudes outside [2^-400, 2^300] (or coordinates beyond 2^14, or T outside [2^-6, 2^40]) switch the classification
+//   off for the model: every point uncertain, upper bound n, lower bound 0 -- the slot is then simply scored exactly.
+// DSM_SCORE_PREFILTER=0 (dsm_set_debug_option) runs the plain k_score instead: an independent schedule of the same results
+// (tools/check_schedules.py, tests).
+struct PreBounds {
+  double c0, c1;   // H: P_min, unused;  F: D_min, unused   (NaN = classification off)
+  double t_lo, t_hi;
+};
+#define PRESCORE_DELTA 0x1p-12
+#define PRESCORE_CU 0x1p-51 /* 4u */
+
+template <int FAM>
+DSM_DEV PreBounds prescore_bounds(const double* M, const double mx[4], double T) {
+  PreBounds b;
+  b.t_lo = T * (1.0 - PRESCORE_DELTA);
+  b.t_hi = T * (1.0 + PRESCORE_DELTA);
+  b.c1 = 0.0;
+  const double nan = __builtin_nan("");
+  const bool t_ok = (T >= 0x1p-6) && (T <= 0x1p40);
+  const bool x_ok = (mx[0] <= 0x1p14) && (mx[1] <= 0x1p14) && (mx[2] <= 0x1p14) && (mx[3] <= 0x1p14);
+  if (FAM == FAM_H) {
+    const double A0 = fabs(M[0]) * mx[0] + fabs(M[1]) * mx[1] + fabs(M[2]);
+    const double A1 = fabs(M[3]) * mx[0] + fabs(M[4]) * mx[1] + fabs(M[5]);
+    const double A2 = fabs(M[6]) * mx[0] + fabs(M[7]) * mx[1] + fabs(M[8]);
+    const double E01 = PRESCORE_CU * fmax(A0, A1), E2 = PRESCORE_CU * A2;
+    const double pmin = fmax(fmax(0x1p34 * E2, 0x1p26 * E01), 0x1p-400);
+    b.c0 = (t_ok && x_ok && pmin <= 0x1p300) ? pmin : nan;
+  } else {
+    const double B0 = fabs(M[0]) * mx[0] + fabs(M[1]) * mx[1] + fabs(M[2]);
+    const double B1 = fabs(M[3]) * mx[0] + fabs(M[4]) * mx[1] + fabs(M[5]);
+    const double B2 = fabs(M[6]) * mx[0] + fabs(M[7]) * mx[1] + fabs(M[8]);
+    const double Bt0 = fabs(M[0]) * mx[2] + fabs(M[3]) * mx[3] + fabs(M[6]);
+    const double Bt1 = fabs(M[1]) * mx[2] + fabs(M[4]) * mx[3] + fabs(M[7]);
+    const double ED = PRESCORE_CU * (B0 + B1 + Bt0 + Bt1);
+    const double EC = 2.0 * PRESCORE_CU * (mx[2] * B0 + mx[3] * B1 + B2);
+    const double d1 = 0x1p26 * ED, d2 = 0x1p16 * EC;
+    const double dmin = fmax(fmax(d1 * d1, d2 * d2 / T) * (1.0 + 0x1p-10), 0x1p-600);
+    b.c0 = (t_ok && x_ok && ED <= 0x1p170 && EC <= 0x1p170 && dmin <= 0x1p400) ? dmin : nan;
+  }
+  return b;
+}
+
+// one correspondence: bit 0 = surely an inlier of the reference's test, bit 1 = surely an outlier (neither: uncertain)
+template <int FAM>
+DSM_DEV void prescore_point(const double* M, const PreBounds& b, const double* q, int& lb, int& sure_out) {
+  if (FAM == FAM_H) {
+    const double s0 = q[0], s1 = q[1], d0 = q[2], d1 = q[3];
+    const double pd0 = __builtin_fma(M[0], s0, __builtin_fma(M[1], s1, M[2]));
+    const double pd1 = __builtin_fma(M[3], s0, __builtin_fma(M[4], s1, M[5]));
+    const double pd2 = __builtin_fma(M[6], s0, __builtin_fma(M[7], s1, M[8]));
+    const double e0 = __builtin_fma(d0, pd2, -pd0);
+    const double e1 = __builtin_fma(d1, pd2, -pd1);
+    const double L = __builtin_fma(e0, e0, e1 * e1);
+    const double q2 = pd2 * pd2;
+    const bool ok = fabs(pd2) >= b.c0;
+    lb += (ok && (L <= b.t_lo * q2)) ? 1 : 0;
+    sure_out += (ok && (L >= b.t_hi * q2)) ? 1 : 0;
+  } else {
+    const double x10 = q[0], x11 = q[1], x20 = q[2], x21 = q[3];
+    const double g0 = __builtin_fma(M[0], x10, __builtin_fma(M[1], x11, M[2]));
+    const double g1 = __builtin_fma(M[3], x10, __builtin_fma(M[4], x11, M[5]));
+    const double g2 = __builtin_fma(M[6], x10, __builtin_fma(M[7], x11, M[8]));
+    const double h0 = __builtin_fma(M[0], x20, __builtin_fma(M[3], x21, M[6]));
+    const double h1 = __builtin_fma(M[1], x20, __builtin_fma(M[4], x21, M[7]));
+    const double C = __builtin_fma(x20, g0, __builtin_fma(x21, g1, g2));
+    const double num = C * C;
+    const double D = __builtin_fma(g0, g0, __builtin_fma(g1, g1, __builtin_fma(h0, h0, h1 * h1)));
+    const bool ok = D >= b.c0;
+    lb += (ok && (num <= b.t_lo * D)) ? 1 : 0;
+    sure_out += (ok && (num >= b.t_hi * D)) ? 1 : 0;
+  }
+}
+
+// stages the pair's points in LDS (when they fit) and returns max |coordinate| per column (x1, y1, x2, y2) to every lane
+DSM_DEV void stage_points_with_maxima(const double* gpts, int n, bool in_lds, double* spts, int lane, double mx[4]) {
+  double m = 0.0;  // this lane only ever sees column (lane & 3): e = lane + 64 k
+  for (int e = lane; e < 4 * n; e += 64) {
+    const double v = gpts[e];
+    if (in_lds) spts[e] = v;
+    m = fmax(m, fabs(v));
+  }
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) m = fmax(m, __shfl_xor(m, o));
+#pragma unroll
+  for (int c = 0; c < 4; ++c) mx[c] = __shfl(m, c);
+  if (in_lds) __syncthreads();
+}
+
+template <int FAM>
+__global__ __launch_bounds__(64, 8) void k_prescore(const VerifyParams p) {
+  typedef Fam<FAM> F;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* spts = reinterpret_cast<double*>(smem_raw);  // min(n_max, VP_LDS_PTS) x 4 doubles
+  const uint32_t pl = blockIdx.x;
+  const uint32_t pi = p.pair0 + pl;
+  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
+  if (!fs->active) return;
+  const int lane = threadIdx.x;
+  const int nb = (int)fs->nb;
+  const int slot = blockIdx.y * 64 + lane;  // (trial, model) = (slot / MAXM, slot % MAXM)
+  if ((int)(blockIdx.y * 64) / F::MAXM >= nb) return;
+  const int t = slot / F::MAXM, m = slot - t * F::MAXM;
+  const uint64_t moff = p.match_off[pi];
+  const int n = (int)(p.match_off[pi + 1] - moff);
+  const double* gpts = p.pts_px + 4 * moff;
+  const bool in_lds = n <= VP_LDS_PTS;
+  double mx[4];
+  stage_points_with_maxima(gpts, n, in_lds, spts, lane, mx);
+  const double T = p.opt.max_error * p.opt.max_error;
+  if (t >= nb) return;
+  // bounds of the slot: counts[] = upper bound (-1: no model in this slot), the low word of sums[] = lower bound
+  int32_t* ub_out = p.counts + ((size_t)pl * p.batch + t) * F::MAXM + m;
+  int32_t* lb_out = reinterpret_cast<int32_t*>(p.sums + ((size_t)pl * p.batch + t) * F::MAXM + m);
+  if (m >= p.nmodels[(size_t)pl * p.batch + t]) {
+    *ub_out = -1;
+    *lb_out = 0;
+    return;
+  }
+  const double* gm = p.models + ((size_t)pl * p.batch + t) * F::MAXM * 9 + m * 9;
+  double M[9];
+  for (int k = 0; k < 9; ++k) M[k] = gm[k];
+  const PreBounds b = prescore_bounds<FAM>(M, mx, T);
+  int lb = 0, sure_out = 0;
+  if (in_lds) {
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) prescore_point<FAM>(M, b, spts + (size_t)i * 4, lb, sure_out);
+  } else {
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) prescore_point<FAM>(M, b, gpts + (size_t)i * 4, lb, sure_out);
+  }
+  *ub_out = n - sure_out;
+  *lb_out = lb;
+}
+
+// dynamic LDS: the points (as k_score) + the list of the slots to score exactly (uint16 each, batch * MAXM of them)
+template <int FAM>
+__global__ __launch_bounds__(64, 8) void k_score_needed(const VerifyParams p) {
+  typedef Fam<FAM> F;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* spts = reinterpret_cast<double*>(smem_raw);
+  const int lane = threadIdx.x;
+  for (uint32_t pl = blockIdx.x; pl < p.n_chunk; pl += gridDim.x) {
+    const uint32_t pi = p.pair0 + pl;
+    const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
+    if (!fs->active) continue;
+    const int nb = (int)fs->nb;
+    const uint64_t moff = p.match_off[pi];
+    const int n = (int)(p.match_off[pi + 1] - moff);
+    const double* gpts = p.pts_px + 4 * moff;
+    const bool in_lds = n <= VP_LDS_PTS;
+    uint16_t* list = reinterpret_cast<uint16_t*>(spts + (size_t)(in_lds ? n : 0) * 4);
+    __syncthreads();  // the previous pair's readers are done with the LDS
+    if (in_lds)
+      for (int e = lane; e < 4 * n; e += 64) spts[e] = gpts[e];
+    int32_t* counts = p.counts + (size_t)pl * p.batch * F::MAXM;
+    double* sums = p.sums + (size_t)pl * p.batch * F::MAXM;
+    const int n_slots = nb * F::MAXM;
+    int carry = (int)fs->rep.num_inliers;  // the best count of the earlier rounds (0 in the first)
+    int n_list = 0;
+    for (int base = 0; base < n_slots; base += 64) {
+      const int slot = base + lane;
+      const bool in_range = slot < n_slots;
+      const int ub = in_range ? counts[slot] : -1;
+      const int lb = (in_range && ub >= 0) ? reinterpret_cast<const int32_t*>(sums + slot)[0] : 0;
+      int incl = lb;  // inclusive running maximum of the lower bounds along the wave
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl = max(incl, v);
+      }
+      int excl = __shfl_up(incl, 1);
+      if (lane == 0) excl = 0;
+      const int before = max(carry, excl);  // what some earlier model has surely reached
+      const bool needed = ub >= 0 && ub >= before;
+      const unsigned long long mask = __ballot(needed);
+      if (needed) list[n_list + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)slot;
+      if (in_range && ub >= 0 && !needed) {  // cannot change anything: fewer inliers than the best support at that point
+        counts[slot] = 0;
+        sums[slot] = 0.0;
+      }
+      n_list += __popcll(mask);
+      carry = max(carry, __shfl(incl, 63));
+    }
+    __syncthreads();  // points and list visible
+    const double max_residual = p.opt.max_error * p.opt.max_error;
+    for (int base = 0; base < n_list; base += 64) {
+      if (base + lane < n_list) {
+        const int slot = list[base + lane];
+        const double* gm = p.models + (size_t)pl * p.batch * F::MAXM * 9 + (size_t)slot * 9;
+        double M[9];
+        for (int k = 0; k < 9; ++k) M[k] = gm[k];
+        int cnt;
+        double sum;
+        exact_support<FAM>(M, n, in_lds, spts, gpts, max_residual, cnt, sum);
+        counts[slot] = cnt;
+        sums[slot] = sum;
+      }
+    }
+  }
 }
 
 // E family: the minimal solve is split in two kernels.  One lane per hypothesis keeps ~5 KB of matrices in
@@ -3372,13 +3609,28 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
       hipLaunchKernelGGL(k_roots_e, grid, dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_models_score_e, grid, dim3(64), smem, st, p);
   }
+  // scoring: bound + exact (k_prescore, k_score_needed) unless DSM_SCORE_PREFILTER=0; the slot list of k_score_needed must
+  // fit 16-bit indices and, with the points, the LDS
+  const uint32_t nb_needed = p.n_chunk < 256u * 32u ? p.n_chunk : 256u * 32u;
   if (fam == FAM_F) {
     hipLaunchKernelGGL(k_solve<FAM_F>, grid, dim3(64), 0, st, p);
-    hipLaunchKernelGGL(k_score<FAM_F>, dim3(p.n_chunk, (p.batch * 3 + 63) / 64), dim3(64), smem, st, p);
+    const size_t smem2 = smem + (size_t)p.batch * 3 * 2;
+    if (p.score_prefilter && p.batch * 3 <= 65535 && smem2 <= 64 * 1024) {
+      hipLaunchKernelGGL(k_prescore<FAM_F>, dim3(p.n_chunk, (p.batch * 3 + 63) / 64), dim3(64), smem, st, p);
+      hipLaunchKernelGGL(k_score_needed<FAM_F>, dim3(nb_needed), dim3(64), smem2, st, p);
+    } else {
+      hipLaunchKernelGGL(k_score<FAM_F>, dim3(p.n_chunk, (p.batch * 3 + 63) / 64), dim3(64), smem, st, p);
+    }
   }
   if (fam == FAM_H) {
     hipLaunchKernelGGL(k_solve<FAM_H>, grid, dim3(64), 0, st, p);
-    hipLaunchKernelGGL(k_score<FAM_H>, grid, dim3(64), smem, st, p);
+    const size_t smem2 = smem + (size_t)p.batch * 2;
+    if (p.score_prefilter && p.batch <= 65535 && smem2 <= 64 * 1024) {
+      hipLaunchKernelGGL(k_prescore<FAM_H>, grid, dim3(64), smem, st, p);
+      hipLaunchKernelGGL(k_score_needed<FAM_H>, dim3(nb_needed), dim3(64), smem2, st, p);
+    } else {
+      hipLaunchKernelGGL(k_score<FAM_H>, grid, dim3(64), smem, st, p);
+    }
   }
 }
 void launch_vp_replay(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st) {

@@ -7,6 +7,7 @@ produce byte-identical TwoViewGeometry records and inlier matches on the whole w
   tail_inline  the tail of a round as round 2 ran it: inline in k_replay_lo<1>, F and H only (DSM_LO_TAIL_MODE=inline;
             the default since round 3 computes the tail's local optimisations as parallel items, k_tail_enum / k_tail_lo)
   final_1wave   k_verify_final compiled for one wave per SIMD (no register spill; DSM_FINAL_WAVES=1)
+  no_prefilter  F / H scoring by the plain k_score instead of bound + exact (DSM_SCORE_PREFILTER=0; round 4)
   one_lane  the batched schedule on a single lane (DSM_VERIFY_LANES=1; the default deals the list out to two lanes)
   legacy    one k_ransac kernel per family, lane-0 sampler, per-lane scratch solvers (DSM_VERIFY_LEGACY=1; --legacy)
 This exercises the paths too rare for the oracle-sized tests (a Lemire rejection in the sampler happens for a few
@@ -31,6 +32,9 @@ def run(ctx, opts, schedule):
     os.environ.pop("DSM_LO_TAIL_MODE", None)
     if schedule == "tail_inline":
         os.environ["DSM_LO_TAIL_MODE"] = "inline"
+    os.environ.pop("DSM_SCORE_PREFILTER", None)
+    if schedule == "no_prefilter":
+        os.environ["DSM_SCORE_PREFILTER"] = "0"
     os.environ.pop("DSM_FINAL_WAVES", None)
     if schedule == "final_1wave":
         os.environ["DSM_FINAL_WAVES"] = "1"
@@ -54,9 +58,10 @@ def main():
     ap.add_argument("--images", type=int, default=500)
     ap.add_argument("--feats", type=int, default=4096)
     ap.add_argument("--legacy", action="store_true", help="also run the (slow) single-kernel-per-family schedule")
+    ap.add_argument("--outlier-frac", type=float, default=0.2, help="0.5: the 0.25-inlier-ratio regime (thousands of trials per pair)")
     ap.add_argument("--uncalibrated", action="store_true", help="cameras without a focal-length prior: the F + H path of the decision tree")
     a = ap.parse_args()
-    scene = synthetic.Scene(a.images, a.feats, seed=0)
+    scene = synthetic.Scene(a.images, a.feats, seed=0, outlier_frac=a.outlier_frac)
     ims = [scene.image(i) for i in range(a.images)]
     pairs = synthetic.exhaustive_pairs(a.images)
     ctx = capi.Context(0)
@@ -66,7 +71,7 @@ def main():
     opts = capi.default_two_view_options()
     r0 = run(ctx, opts, "batched")
     ok = True
-    for name in ["one_lane", "no_tail", "tail_inline", "final_1wave", "inline"] + (["legacy"] if a.legacy else []):
+    for name in ["no_prefilter", "one_lane", "no_tail", "tail_inline", "final_1wave", "inline"] + (["legacy"] if a.legacy else []):
         r1 = run(ctx, opts, name)
         same = (r0[0] == r1[0]).all() and (r0[1] == r1[1]).all() and (r0[2] == r1[2]).all()
         # num_trials / num_models are the last 32 bytes of the record
