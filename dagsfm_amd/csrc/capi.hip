@@ -747,8 +747,17 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
     for (int f = 0; f < 3; ++f) {
       vp.batch = plan.batch[f];
       for (uint32_t round = 0; round < 100000; ++round) {
-        LANECHK(L, hipMemsetAsync(actr, 0, 4, st));
-        LANECHK(L, hipMemsetAsync(actr + 72, 0, 4, st));  // k_sample's work counter
+        // counters of the lane (uint32 at actr): [0] pairs still active after the round, [16] replay work counter, [17]
+        // k_verify_final's, [18] k_sample's, [19] k_lo_prepare's, [20] / [21] lengths of the two alternating queues, [22] /
+        // [23] problems for the general LO kernels, [24] jobs of an item pass.  Every launch below finds its counters zeroed;
+        // counters that are dead at that point are zeroed along with them, so that each phase costs ONE fill, not one per
+        // counter (a fill is a kernel launch: 33 of them made 0.7 ms of the 8.7 ms a 1 225-pair list takes)
+        if (vp.stats) {  // DSM_VERIFY_DEBUG keeps its statistics in [1] - [13] across the rounds
+          LANECHK(L, hipMemsetAsync(actr, 0, 4, st));
+          LANECHK(L, hipMemsetAsync(actr + 64, 0, 36, st));
+        } else {
+          LANECHK(L, hipMemsetAsync(actr, 0, 100, st));  // round start: [0] and [18] are live, the rest is dead here
+        }
         launch_vp_sample(vp, f, nb_light, st);
         launch_vp_solve_score(vp, f, st);
         uint32_t active = 0;
@@ -782,12 +791,14 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
           for (uint32_t cur = 0;; cur ^= 1u) {
             uint32_t* host_ctr = L.host_ctr;
             if (pass_items) {
-              LANECHK(L, hipMemsetAsync(actr + 88, 0, 12, st));  // [22], [23]: problems for the general LO kernels; [24]: jobs
+              // [22], [23]: problems for the general LO kernels; [24]: jobs; [19]: k_lo_prepare's work counter (used after
+              // the two read-backs below); [20], [21]: the queue lengths, already read by the host
               VerifyParams vj = vp;
               vj.lo_jobs = L.lo_jobs.as<LoJob>();
               vj.job_list = L.job_list.as<uint32_t>();
               vj.lo_inl_pool = ctx->d_lo_inl_pool.as<uint32_t>();
               vj.lo_queue_g = queues + (size_t)2 * chunk;  // (the general kernels' list: job slots here)
+              LANECHK(L, hipMemsetAsync(actr + 76, 0, 24, st));
               launch_vp_items_enum(vj, f, st);
               LANECHK(L, hipGetLastError());
               LANECHK(L, hipMemcpyAsync(host_ctr, actr, 128, hipMemcpyDeviceToHost, st));
@@ -800,8 +811,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
                 LANECHK(L, hipGetLastError());
                 LANECHK(L, hipMemcpyAsync(host_ctr, actr, 128, hipMemcpyDeviceToHost, st));
                 LANECHK(L, hipStreamSynchronize(st));
-                LANECHK(L, hipMemsetAsync(actr + 76, 0, 4, st));  // k_lo_prepare's work counter [19]
-                launch_vp_local_opt(vj, f, nb_heavy, host_ctr[22], host_ctr[23], st);
+                launch_vp_local_opt(vj, f, nb_heavy, host_ctr[22], host_ctr[23], st);  // ([19] zeroed above)
                 LANECHK(L, hipGetLastError());
                 launch_vp_items_outcome(vj, f, nb_heavy, st);
                 LANECHK(L, hipGetLastError());
@@ -811,9 +821,9 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
               pass_items = false;
             }
             uint32_t* cnt_dev = L.active.as<uint32_t>() + 20 + cur;
-            LANECHK(L, hipMemsetAsync(cnt_dev, 0, 4, st));
-            LANECHK(L, hipMemsetAsync(actr + 64, 0, 4, st));  // work counter [16]
-            LANECHK(L, hipMemsetAsync(actr + 88, 0, 8, st));  // [22], [23]: queued problems for the general LO kernels
+            // this queue's length [20 + cur], the work counter [16], [22] / [23]: queued problems for the general LO kernels;
+            // [17] - [19], the other queue's length (read by the host after the launch that filled it) and [24] are dead here
+            LANECHK(L, hipMemsetAsync(actr + 64, 0, 36, st));
             vp.lo_queue = queues + (size_t)cur * chunk;
             vp.lo_count = cnt_dev;
             launch_vp_replay_lo(vp, f, std::min<uint32_t>(nb_heavy, vp.n_work), mode, st);

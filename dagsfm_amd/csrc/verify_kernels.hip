@@ -1870,7 +1870,8 @@ DSM_DEV PreBounds prescore_bounds(const double* M, const double mx[4], double T)
   b.t_hi = T * (1.0 + PRESCORE_DELTA);
   b.c1 = 0.0;
   const double nan = __builtin_nan("");
-  const bool t_ok = (T >= 0x1p-6) && (T <= 0x1p40);
+  // (H's margins are absolute, in pixels: T must not be tiny; the Sampson test is scale-free -- E's T is ~1e-5)
+  const bool t_ok = (T >= (FAM == FAM_H ? 0x1p-6 : 0x1p-200)) && (T <= 0x1p40);
   const bool x_ok = (mx[0] <= 0x1p14) && (mx[1] <= 0x1p14) && (mx[2] <= 0x1p14) && (mx[3] <= 0x1p14);
   if (FAM == FAM_H) {
     const double A0 = fabs(M[0]) * mx[0] + fabs(M[1]) * mx[1] + fabs(M[2]);
@@ -1957,33 +1958,42 @@ __global__ __launch_bounds__(64, 8) void k_prescore(const VerifyParams p) {
   const uint64_t moff = p.match_off[pi];
   const int n = (int)(p.match_off[pi + 1] - moff);
   const double* gpts = p.pts_px + 4 * moff;
+  // (measured, round 4: the points of a pair that fits the LDS by SCALAR loads instead -- wave-uniform addresses, no LDS
+  // traffic -- are slower: k_prescore<H> 48.4 vs 37.2 ms; the scalar cache does not hold the 8 KB of every resident pair)
   const bool in_lds = n <= VP_LDS_PTS;
-  double mx[4];
-  stage_points_with_maxima(gpts, n, in_lds, spts, lane, mx);
   const double T = p.opt.max_error * p.opt.max_error;
-  if (t >= nb) return;
   // bounds of the slot: counts[] = upper bound (-1: no model in this slot), the low word of sums[] = lower bound
-  int32_t* ub_out = p.counts + ((size_t)pl * p.batch + t) * F::MAXM + m;
-  int32_t* lb_out = reinterpret_cast<int32_t*>(p.sums + ((size_t)pl * p.batch + t) * F::MAXM + m);
-  if (m >= p.nmodels[(size_t)pl * p.batch + t]) {
-    *ub_out = -1;
-    *lb_out = 0;
-    return;
-  }
-  const double* gm = p.models + ((size_t)pl * p.batch + t) * F::MAXM * 9 + m * 9;
+  const bool has_slot = t < nb;
+  const bool has_model = has_slot && m < p.nmodels[(size_t)pl * p.batch + (has_slot ? t : 0)];
+  const double* gm = p.models + ((size_t)pl * p.batch + (has_slot ? t : 0)) * F::MAXM * 9 + m * 9;
   double M[9];
-  for (int k = 0; k < 9; ++k) M[k] = gm[k];
-  const PreBounds b = prescore_bounds<FAM>(M, mx, T);
-  int lb = 0, sure_out = 0;
+  for (int k = 0; k < 9; ++k) M[k] = has_model ? gm[k] : 0.0;
+  int lb = 0, sure_out = n + 1;
+  // two separate paths (not one loop over a selected pointer, and no barrier on the way to the global-memory loop: its
+  // loads have wave-uniform addresses and nothing may have been stored before them, so they can be scalar loads)
   if (in_lds) {
+    double mx[4];
+    stage_points_with_maxima(gpts, n, true, spts, lane, mx);
+    if (has_model) {
+      const PreBounds b = prescore_bounds<FAM>(M, mx, T);
+      sure_out = 0;
 #pragma unroll 4
-    for (int i = 0; i < n; ++i) prescore_point<FAM>(M, b, spts + (size_t)i * 4, lb, sure_out);
+      for (int i = 0; i < n; ++i) prescore_point<FAM>(M, b, spts + (size_t)i * 4, lb, sure_out);
+    }
   } else {
+    double mx[4];
+    stage_points_with_maxima(gpts, n, false, nullptr, lane, mx);
+    if (has_model) {
+      const PreBounds b = prescore_bounds<FAM>(M, mx, T);
+      sure_out = 0;
 #pragma unroll 4
-    for (int i = 0; i < n; ++i) prescore_point<FAM>(M, b, gpts + (size_t)i * 4, lb, sure_out);
+      for (int i = 0; i < n; ++i) prescore_point<FAM>(M, b, gpts + (size_t)i * 4, lb, sure_out);
+    }
   }
-  *ub_out = n - sure_out;
-  *lb_out = lb;
+  if (has_slot) {
+    p.counts[((size_t)pl * p.batch + t) * F::MAXM + m] = n - sure_out;  // -1: no model in this slot
+    reinterpret_cast<int32_t*>(p.sums + ((size_t)pl * p.batch + t) * F::MAXM + m)[0] = lb;
+  }
 }
 
 // dynamic LDS: the points (as k_score) + the list of the slots to score exactly (uint16 each, batch * MAXM of them)
@@ -2271,8 +2281,19 @@ __global__ __launch_bounds__(64, 8) void k_models_score_e(const VerifyParams p) 
   const int n = (int)(p.match_off[pi + 1] - moff);
   const double* gpts = p.pts_norm + 4 * moff;
   const bool in_lds = n <= VP_LDS_PTS;
-  if (in_lds)
-    for (int e = lane; e < 4 * n; e += 64) spts[e] = gpts[e];
+  double mx[4];  // max |coordinate| of the pair's points (the bound step's margins, see k_prescore)
+  {
+    double mm = 0.0;
+    for (int e = lane; e < 4 * n; e += 64) {
+      const double v = gpts[e];
+      if (in_lds) spts[e] = v;
+      mm = fmax(mm, fabs(v));
+    }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) mm = fmax(mm, __shfl_xor(mm, o));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mx[c] = __shfl(mm, c);
+  }
   const dsm_camera& cam1 = p.cams[p.pairs[2 * pi]];
   const dsm_camera& cam2 = p.cams[p.pairs[2 * pi + 1]];
   const double max_error =
@@ -2284,12 +2305,31 @@ __global__ __launch_bounds__(64, 8) void k_models_score_e(const VerifyParams p) 
   LSEC_BEGIN();
   int32_t* counts = p.counts + ((size_t)pl * p.batch + t0) * 10;
   const int ntr = (nb - t0) < 64 ? (nb - t0) : 64;
+  // bound + exact as for F and H (k_prescore), fused here because the decision is wave-uniform: a model whose UPPER bound
+  // is below a count that an earlier model of this block (or an earlier round's best) has reached cannot change
+  // anything in the replay; it is written as 0 inliers and its exact count is never taken.  n < 65 536 for the packing.
+  const bool prefilter = p.score_prefilter != 0 && n < 65536;
+  int run_max = (int)fs->rep.num_inliers;
   for (int tt = 0; tt < ntr; ++tt) {
     const int nmt = __builtin_amdgcn_readlane(nm, tt);
     for (int m = 0; m < nmt; ++m) {
       const double* Mg = slots + (size_t)tt * 90 + m * 9;
       double M[9];
       for (int k = 0; k < 9; ++k) M[k] = Mg[k];
+      if (prefilter) {
+        const PreBounds b = prescore_bounds<FAM_E>(M, mx, max_residual);
+        int lb = 0, so = 0;
+        if (in_lds) {
+          for (int i = lane; i < n; i += 64) prescore_point<FAM_E>(M, b, spts + (size_t)i * 4, lb, so);
+        } else {
+          for (int i = lane; i < n; i += 64) prescore_point<FAM_E>(M, b, gpts + (size_t)i * 4, lb, so);
+        }
+        for (int o = 32; o > 0; o >>= 1) so += __shfl_xor(so, o);
+        if (n - so < run_max) {  // wave-uniform
+          if (lane == 0) counts[tt * 10 + m] = 0;
+          continue;
+        }
+      }
       int cnt = 0;
       if (in_lds) {  // (apart: a pointer that may be LDS or global compiles to flat loads)
         for (int i = lane; i < n; i += 64) cnt += (fam_residual<FAM_E>(M, spts + (size_t)i * 4) <= max_residual) ? 1 : 0;
@@ -2298,6 +2338,7 @@ __global__ __launch_bounds__(64, 8) void k_models_score_e(const VerifyParams p) 
       }
       for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
       if (lane == 0) counts[tt * 10 + m] = cnt;
+      run_max = max(run_max, cnt);
     }
   }
   LSEC_END(13);
