@@ -475,3 +475,29 @@ def test_differential_fuzz_stage_calls(dsm):
     total, bad, stats = fuzz_stage.run_fuzz(dsm, 30, 1, min(32, os.cpu_count() or 4), log=msgs.append)
     assert bad == 0, "\n".join(msgs)
     assert total > 200 and stats["guided"] > 30
+
+
+@pytest.mark.parametrize("prefilter", ["1", "0"])
+def test_bound_and_exact_scoring_regimes(dsm, oracle, prefilter, monkeypatch):
+    """Round 4: F / H / E scoring as bound + exact (k_prescore, k_score_needed).  The bounds switch
+    themselves off where their margins do not hold -- a threshold below 2^-6 px^2, coordinates beyond 2^14 px -- and every
+    regime must equal the oracle, with the plain k_score (DSM_SCORE_PREFILTER=0) as well: thresholds from 0.1 px to 60 px,
+    keypoints scaled by 40 (40 000 px wide images), calibrated and not, a planar scene (most homographies are near-ties)."""
+    monkeypatch.setenv("DSM_SCORE_PREFILTER", prefilter)
+    cases = []
+    for planar in (False, True):
+        scene = synthetic.Scene(3, 1024, seed=21 + planar, planar=planar)
+        for scale, max_error in ((1.0, 0.1), (1.0, 0.3), (1.0, 4.0), (1.0, 60.0), (40.0, 160.0), (40.0, 8.0)):
+            p1, p2, m = _scene_pair(scene, 0, 1 + planar, oracle)
+            cases.append((planar, scale, max_error, p1 * scale, p2 * scale, m))
+    n_geo = 0
+    for planar, scale, max_error, p1, p2, m in cases:
+        for prior in (0, 1):
+            cam = capi.simple_pinhole(800.0 * scale, 500.0 * scale, 375.0 * scale, int(1000 * scale), int(750 * scale), prior)
+            opts = capi.default_two_view_options(max_error=max_error)
+            ref, ref_inl = oracle.estimate_two_view_geometry(cam, p1, cam, p2, m, opts, 13)
+            got, got_inl = dsm.estimate_two_view_geometry(cam, p1, cam, p2, m, opts, 13)
+            tvg_equal(got, ref, (planar, scale, max_error, prior))
+            assert (got_inl == ref_inl).all()
+            n_geo += ref.config > 1
+    assert n_geo >= 12
