@@ -13,7 +13,7 @@ const size_t kBlockBytes = 1024 * 64;  // BLOCK_BYTES, util/serialization.h:374
 // LZ4_COMPRESSBOUND(BLOCK_BYTES): LoadArchive::loadBlock refuses larger blocks (serialization.h:677-681)
 const uint64_t kMaxCompressedBlock = kBlockBytes + kBlockBytes / 255 + 16;
 const int kVecLen = 128;
-const int kMaxTreeDepth = 100000;  // recursion guard for damaged files (a k-d tree over n points is at most n deep)
+const int kMaxTreeDepth = 4096;  // recursion guard of the loader (FLANN splits at the mean / by cluster: real trees are tens of levels deep; a damaged file must not overflow the stack)
 
 // One LZ4 block (the format of ext/lz4.c's LZ4_decompress_safe_continue): sequences of token, literal run, 2-byte
 // little-endian match offset, match length; the last sequence ends after its literals.  Matches may reach back into

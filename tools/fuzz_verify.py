@@ -130,7 +130,7 @@ def make_pair(seed):
 
 
 def make_options(rng, rng2):
-    kw = dict(max_error=float(rng.choice([0.7, 2.0, 4.0, 9.0])),
+    kw = dict(max_error=float(rng.choice([0.1, 0.7, 2.0, 4.0, 9.0, 40.0])),  # 0.1: below the H bound step's range (T < 2^-6)
               confidence=float(rng.choice([0.9, 0.99, 0.999, 0.9999])),
               max_num_trials=int(rng.choice([50, 400, 2000, 10000])),
               min_inlier_ratio=float(rng.choice([0.1, 0.25, 0.5])),
