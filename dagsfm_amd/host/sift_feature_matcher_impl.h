@@ -41,6 +41,24 @@
 
 namespace dagsfm_amd {
 
+// A result buffer that is NOT zero-filled on allocation (std::vector<uint32_t>(n) writes every page once before the device
+// copy writes it again: the matches of config 2 are 460 MB per call) and moves without copying.
+struct RawU32Buffer {
+  std::unique_ptr<uint32_t[]> p;
+  size_t n;
+  RawU32Buffer() : n(0) {}
+  void Allocate(size_t count) {
+    p.reset(new uint32_t[count]);
+    n = count;
+  }
+  uint32_t* data() { return p.get(); }
+  const uint32_t* data() const { return p.get(); }
+  void swap(RawU32Buffer& o) {
+    p.swap(o.p);
+    std::swap(n, o.n);
+  }
+};
+
 template <typename Traits>
 class SiftFeatureMatcherT {
  public:
@@ -189,7 +207,7 @@ class SiftFeatureMatcherT {
   struct Share {
     uint32_t begin = 0, end = 0;
     std::vector<uint64_t> moff, ioff;
-    std::vector<uint32_t> m, im;
+    RawU32Buffer m, im;
     std::vector<dsm_two_view_geometry> tv;
     std::string error;
   };
@@ -228,12 +246,12 @@ class SiftFeatureMatcherT {
     sh->moff.assign(np + 1, 0);
     sh->ioff.assign(np + 1, 0);
     rc = dsm_get_matches(ctx, sh->moff.data(), nullptr, 0);
-    sh->m.assign(2 * std::max<uint64_t>(sh->moff[np], 1), 0);
+    sh->m.Allocate(2 * std::max<uint64_t>(sh->moff[np], 1));
     if (rc == DSM_OK) rc = dsm_get_matches(ctx, nullptr, sh->m.data(), sh->moff[np]);
     sh->tv.resize(np);
     if (rc == DSM_OK) rc = dsm_get_two_view_geometries(ctx, sh->tv.data());
     if (rc == DSM_OK) rc = dsm_get_inlier_matches(ctx, sh->ioff.data(), nullptr, 0);
-    sh->im.assign(2 * std::max<uint64_t>(sh->ioff[np], 1), 0);
+    sh->im.Allocate(2 * std::max<uint64_t>(sh->ioff[np], 1));
     if (rc == DSM_OK) rc = dsm_get_inlier_matches(ctx, nullptr, sh->im.data(), sh->ioff[np]);
     if (rc != DSM_OK) sh->error = std::string("result fetch failed: ") + dsm_last_error(ctx);
   }
@@ -273,28 +291,41 @@ class SiftFeatureMatcherT {
     timings_.pairs += np;
     for (const Share& sh : shares)
       if (!sh.error.empty()) throw std::runtime_error(sh.error);
-    // merge the shares in list order
-    std::vector<uint64_t> moff(np + 1, 0), ioff(np + 1, 0);
-    std::vector<dsm_two_view_geometry> tv(np);
-    uint64_t mt = 0, it = 0;
-    for (const Share& sh : shares) {
-      for (uint32_t i = sh.begin; i < sh.end; ++i) {
-        moff[i] = mt + sh.moff[i - sh.begin];
-        ioff[i] = it + sh.ioff[i - sh.begin];
-        tv[i] = sh.tv[i - sh.begin];
+    // merge the shares in list order (one device: its buffers ARE the result, nothing is copied)
+    std::vector<uint64_t> moff, ioff;
+    std::vector<dsm_two_view_geometry> tv;
+    RawU32Buffer m, im;
+    if (nd == 1) {
+      moff.swap(shares[0].moff);
+      ioff.swap(shares[0].ioff);
+      tv.swap(shares[0].tv);
+      m.swap(shares[0].m);
+      im.swap(shares[0].im);
+    } else {
+      moff.assign(np + 1, 0);
+      ioff.assign(np + 1, 0);
+      tv.resize(np);
+      uint64_t mt = 0, it = 0;
+      for (const Share& sh : shares) {
+        for (uint32_t i = sh.begin; i < sh.end; ++i) {
+          moff[i] = mt + sh.moff[i - sh.begin];
+          ioff[i] = it + sh.ioff[i - sh.begin];
+          tv[i] = sh.tv[i - sh.begin];
+        }
+        if (sh.end > sh.begin) {
+          mt += sh.moff[sh.end - sh.begin];
+          it += sh.ioff[sh.end - sh.begin];
+        }
       }
-      if (sh.end > sh.begin) {
-        mt += sh.moff[sh.end - sh.begin];
-        it += sh.ioff[sh.end - sh.begin];
+      moff[np] = mt;
+      ioff[np] = it;
+      m.Allocate(2 * std::max<uint64_t>(mt, 1));
+      im.Allocate(2 * std::max<uint64_t>(it, 1));
+      for (const Share& sh : shares) {
+        if (sh.end == sh.begin) continue;
+        std::copy(sh.m.data(), sh.m.data() + 2 * sh.moff[sh.end - sh.begin], m.data() + 2 * moff[sh.begin]);
+        std::copy(sh.im.data(), sh.im.data() + 2 * sh.ioff[sh.end - sh.begin], im.data() + 2 * ioff[sh.begin]);
       }
-    }
-    moff[np] = mt;
-    ioff[np] = it;
-    std::vector<uint32_t> m(2 * std::max<uint64_t>(mt, 1)), im(2 * std::max<uint64_t>(it, 1));
-    for (const Share& sh : shares) {
-      if (sh.end == sh.begin) continue;
-      std::copy(sh.m.begin(), sh.m.begin() + 2 * sh.moff[sh.end - sh.begin], m.begin() + 2 * moff[sh.begin]);
-      std::copy(sh.im.begin(), sh.im.begin() + 2 * sh.ioff[sh.end - sh.begin], im.begin() + 2 * ioff[sh.begin]);
     }
     // ---- write results (matching.cc:819-836), on this thread or handed to the write-back thread
     std::shared_ptr<WriteBatch> batch = std::make_shared<WriteBatch>();
@@ -327,7 +358,7 @@ class SiftFeatureMatcherT {
     PairList prs;
     std::vector<char> stale_inliers;
     std::vector<uint64_t> moff, ioff;
-    std::vector<uint32_t> m, im;
+    RawU32Buffer m, im;
     std::vector<dsm_two_view_geometry> tv;
 
     void Write() const {
