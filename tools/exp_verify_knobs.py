@@ -35,7 +35,10 @@ def main():
     combos = [dict(), dict(DSM_VERIFY_LANES="1"), dict(DSM_VERIFY_LANES="3"), dict(DSM_VERIFY_LANES="4"),
               dict(DSM_VERIFY_LANES="2", DSM_VERIFY_GRID_DIV="2"), dict(DSM_VERIFY_LANES="3", DSM_VERIFY_GRID_DIV="3"),
               dict(DSM_VERIFY_LANES="4", DSM_VERIFY_GRID_DIV="4"), dict(DSM_VERIFY_LANES="4", DSM_VERIFY_GRID_DIV="2"),
-              dict(DSM_LO_TAIL="512"), dict(DSM_LO_TAIL="8192"), dict(DSM_VERIFY_LANES="4", DSM_VERIFY_GRID_DIV="4", DSM_LO_TAIL="512")]
+              dict(DSM_LO_TAIL="512"), dict(DSM_LO_TAIL="4096"), dict(DSM_LO_TAIL="16384"), dict(DSM_LO_TAIL="32768"),
+              dict(DSM_VERIFY_LANES="2", DSM_VERIFY_LANE_SPLIT="0.6"), dict(DSM_VERIFY_LANES="2", DSM_VERIFY_LANE_SPLIT="0.7"),
+              dict(DSM_VERIFY_ITEM_MODE="1"), dict(DSM_VERIFY_ITEM_MODE="0"), dict(DSM_VERIFY_LANES="3", DSM_VERIFY_GRID_DIV="2"),
+              dict(DSM_VERIFY_LANES="4", DSM_VERIFY_GRID_DIV="4", DSM_LO_TAIL="512")]
     keys = sorted({k for c in combos for k in c})
     for name, pl in (("1/8 shard", sharding.shard(pairs, 0, 8)), ("whole list", pairs)):
         ctx.match_pairs(pl)
