@@ -367,6 +367,14 @@ class Context:
                        thresholds=self._voc[2].ctypes.data)
         self._chk(lib().dsm_retrieval_set_vocabulary(self._h, ctypes.byref(v)))
 
+    def debug_verify_counters(self):
+        """dsm_debug_verify_counters: 16 statistics counters of the last verify call (DSM_VERIFY_DEBUG / DSM_SCORE_PREFILTER=check)."""
+        out = np.zeros(16, np.uint32)
+        L = lib()
+        L.dsm_debug_verify_counters.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(L.dsm_debug_verify_counters(self._h, out.ctypes.data))
+        return out
+
     def retrieval_set_word_ids(self, index_ids, query_ids):
         """dsm_retrieval_set_word_ids: the caller's word ids (the reference's FLANN answer) instead of the device's exact
         search; index_ids [features], query_ids [features, k].  (None, None): exact search again."""

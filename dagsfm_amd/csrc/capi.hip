@@ -863,7 +863,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
     launch_vp_final(vp, nb_heavy, st);
     LANECHK(L, hipGetLastError());
   }
-  if (ctx->dbg("DSM_VERIFY_DEBUG")) LANECHK(L, hipMemcpyAsync(L.dbg, actr, 128, hipMemcpyDeviceToHost, st));
+  if (vp.stats) LANECHK(L, hipMemcpyAsync(L.dbg, actr, 128, hipMemcpyDeviceToHost, st));
   LANECHK(L, hipEventRecord(L.done, st));
   LANECHK(L, hipStreamSynchronize(st));
 }
@@ -957,7 +957,14 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.dbg_jacobi_groups = ctx->dbg("DSM_LO_JACOBI_GROUPS") ? 1 : 0;  // the 8-lane-group Jacobi kernel for every problem (round-2 form)
   vp.dbg_roots_lds = ctx->dbg("DSM_ROOTS_LDS") ? 1 : 0;              // k_roots_e_lds instead of the register form
   vp.dbg_final_waves = ctx->dbg("DSM_FINAL_WAVES") ? atoi(ctx->dbg("DSM_FINAL_WAVES")) : 0;
-  vp.score_prefilter = ctx->dbg("DSM_SCORE_PREFILTER") ? atoi(ctx->dbg("DSM_SCORE_PREFILTER")) : 1;  // =1: the round-2 kernel (matrix in global scratch) for every problem
+  vp.score_prefilter = ctx->dbg("DSM_SCORE_PREFILTER") ? atoi(ctx->dbg("DSM_SCORE_PREFILTER")) : 1;
+  // "check": every slot is scored exactly AND held against its bounds (counters [14] violations, [15] slots the filter
+  // would have skipped; dsm_debug_verify_counters); the statistics counters stay alive across the rounds
+  const bool prefilter_check = ctx->dbg("DSM_SCORE_PREFILTER") && strcmp(ctx->dbg("DSM_SCORE_PREFILTER"), "check") == 0;
+  if (prefilter_check) {
+    vp.score_prefilter = 5;
+    vp.stats = 1;
+  }  // =1: the round-2 kernel (matrix in global scratch) for every problem
   vp.models = nullptr;
   vp.e_work = nullptr;
   vp.sidx_g = nullptr;
@@ -1674,6 +1681,14 @@ int dsm_estimate_two_view_geometry(dsm_ctx* ctx, const dsm_camera* camera1, cons
   DevBuf* bufs[] = {&kp, &row0, &cams, &pr, &off, &mt, &sd};
   for (DevBuf* b : bufs) b->release();
   return rc;
+}
+
+int dsm_debug_verify_counters(dsm_ctx* ctx, uint32_t* out16) {
+  if (!ctx || !out16) return DSM_ERR_INVALID_ARGUMENT;
+  for (int k = 0; k < 16; ++k) out16[k] = 0;
+  for (uint32_t li = 0; li < ctx->verify_lanes && li < DSM_VERIFY_MAX_LANES; ++li)
+    for (int k = 0; k < 16; ++k) out16[k] += ctx->lanes[li].dbg[k];
+  return DSM_OK;
 }
 
 int dsm_debug_sample_sequence(dsm_ctx* ctx, uint32_t seed, uint32_t k, uint32_t total, uint32_t n_draws, uint32_t* out) {

@@ -2035,7 +2035,12 @@ __global__ __launch_bounds__(64, 8) void k_score_needed(const VerifyParams p) {
       int excl = __shfl_up(incl, 1);
       if (lane == 0) excl = 0;
       const int before = max(carry, excl);  // what some earlier model has surely reached
-      const bool needed = ub >= 0 && ub >= before;
+      const bool skippable = ub >= 0 && ub < before;
+      // bit 2 of score_prefilter (DSM_SCORE_PREFILTER=check): every slot is scored exactly and its bounds are CHECKED
+      // against the exact count below; [15] counts the slots the filter would have skipped
+      const bool check = (p.score_prefilter & 4) != 0;
+      if (check && skippable) atomicAdd(p.active_count + 15, 1u);
+      const bool needed = ub >= 0 && (ub >= before || check);
       const unsigned long long mask = __ballot(needed);
       if (needed) list[n_list + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)slot;
       if (in_range && ub >= 0 && !needed) {  // cannot change anything: fewer inliers than the best support at that point
@@ -2056,6 +2061,10 @@ __global__ __launch_bounds__(64, 8) void k_score_needed(const VerifyParams p) {
         int cnt;
         double sum;
         exact_support<FAM>(M, n, in_lds, spts, gpts, max_residual, cnt, sum);
+        if (p.score_prefilter & 4) {  // lower bound <= exact count <= upper bound, or the margins of k_prescore are wrong
+          const int ub = counts[slot], lb = reinterpret_cast<const int32_t*>(sums + slot)[0];
+          if (cnt < lb || cnt > ub) atomicAdd(p.active_count + 14, 1u);
+        }
         counts[slot] = cnt;
         sums[slot] = sum;
       }
@@ -2265,6 +2274,7 @@ __global__ __launch_bounds__(64) void k_roots_e_lds(const VerifyParams p) {
 // the inlier counts of ALL models of the block's 64 hypotheses (built by k_roots_e) with the lanes spread over the
 // correspondences (a hypothesis has 0..10 models: scoring them
 // lane-per-hypothesis would run every lane as long as the one with the most models).
+template <bool CHECK>  // CHECK: DSM_SCORE_PREFILTER=check -- exact counts for every model, held against the bound step's bounds
 __global__ __launch_bounds__(64, 8) void k_models_score_e(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* spts = reinterpret_cast<double*>(smem_raw);  // min(n_max, VP_LDS_PTS) x 4 doubles
@@ -2316,6 +2326,7 @@ __global__ __launch_bounds__(64, 8) void k_models_score_e(const VerifyParams p) 
       const double* Mg = slots + (size_t)tt * 90 + m * 9;
       double M[9];
       for (int k = 0; k < 9; ++k) M[k] = Mg[k];
+      int ub_chk = n, lb_chk = 0;
       if (prefilter) {
         const PreBounds b = prescore_bounds<FAM_E>(M, mx, max_residual);
         int lb = 0, so = 0;
@@ -2325,9 +2336,18 @@ __global__ __launch_bounds__(64, 8) void k_models_score_e(const VerifyParams p) 
           for (int i = lane; i < n; i += 64) prescore_point<FAM_E>(M, b, gpts + (size_t)i * 4, lb, so);
         }
         for (int o = 32; o > 0; o >>= 1) so += __shfl_xor(so, o);
+        if constexpr (CHECK) {
+          for (int o = 32; o > 0; o >>= 1) lb += __shfl_xor(lb, o);
+          ub_chk = n - so;
+          lb_chk = lb;
+        }
         if (n - so < run_max) {  // wave-uniform
-          if (lane == 0) counts[tt * 10 + m] = 0;
-          continue;
+          if constexpr (!CHECK) {
+            if (lane == 0) counts[tt * 10 + m] = 0;
+            continue;
+          } else {
+            if (lane == 0) atomicAdd(p.active_count + 15, 1u);  // would have been skipped
+          }
         }
       }
       int cnt = 0;
@@ -2338,6 +2358,9 @@ __global__ __launch_bounds__(64, 8) void k_models_score_e(const VerifyParams p) 
       }
       for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
       if (lane == 0) counts[tt * 10 + m] = cnt;
+      if constexpr (CHECK) {
+        if (lane == 0 && (cnt < lb_chk || cnt > ub_chk)) atomicAdd(p.active_count + 14, 1u);
+      }
       run_max = max(run_max, cnt);
     }
   }
@@ -3648,7 +3671,10 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
       hipLaunchKernelGGL(k_roots_e_lds, grid, dim3(64), 100 * 64 * sizeof(double), st, p);
     else
       hipLaunchKernelGGL(k_roots_e, grid, dim3(64), 0, st, p);
-    hipLaunchKernelGGL(k_models_score_e, grid, dim3(64), smem, st, p);
+    if (p.score_prefilter & 4)
+      hipLaunchKernelGGL(k_models_score_e<true>, grid, dim3(64), smem, st, p);
+    else
+      hipLaunchKernelGGL(k_models_score_e<false>, grid, dim3(64), smem, st, p);
   }
   // scoring: bound + exact (k_prescore, k_score_needed) unless DSM_SCORE_PREFILTER=0; the slot list of k_score_needed must
   // fit 16-bit indices and, with the points, the LDS

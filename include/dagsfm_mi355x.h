@@ -278,6 +278,12 @@ int dsm_estimate_two_view_geometry(dsm_ctx* ctx, const dsm_camera* camera1, cons
 int dsm_debug_sample_sequence(dsm_ctx* ctx, uint32_t seed, uint32_t k, uint32_t total,
                               uint32_t n_draws, uint32_t* out);
 
+/* Test hook: the statistics counters of the last dsm_verify_pairs call that ran with the debug option DSM_VERIFY_DEBUG or
+ * DSM_SCORE_PREFILTER=check (16 uint32, summed over the lanes): [1..6] candidates / local optimisations per family, [14]
+ * (model, pair) slots whose exact inlier count fell outside the bounds of the scoring's bound step -- must be 0 --, [15] slots
+ * the bound step would have skipped. */
+int dsm_debug_verify_counters(dsm_ctx* ctx, uint32_t* out16);
+
 /* Test hook: Camera::ImageToWorld (src/base/camera.cc:210-214) of n pixel points (x, y) on the device. */
 int dsm_debug_image_to_world(dsm_ctx* ctx, const dsm_camera* camera, uint32_t n, const double* xy, double* out_uv);
 

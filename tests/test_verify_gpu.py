@@ -501,3 +501,58 @@ def test_bound_and_exact_scoring_regimes(dsm, oracle, prefilter, monkeypatch):
             assert (got_inl == ref_inl).all()
             n_geo += ref.config > 1
     assert n_geo >= 12
+
+
+def test_scoring_bounds_hold_on_every_slot(oracle, monkeypatch):
+    """DSM_SCORE_PREFILTER=check: every (model, pair) slot is scored exactly AND its exact count is held against the bound
+    step's [lower, upper] -- a violated bound that happened not to change a decision would go unnoticed by
+    the parity tests; this counts them.  Scenes: general and planar, 0.64 and 0.25 inlier ratios, calibrated and not, a tight
+    and a loose threshold; plus the fuzz generator's structures (collinear, repeated, pure outliers, all camera models).
+    Counter [14] (violations) must be 0 and [15] (slots the filter skips) must be most of them on an ordinary scene."""
+    import importlib.util
+    import sys
+    monkeypatch.setenv("DSM_SCORE_PREFILTER", "check")
+    ctx = capi.Context(0)
+    skipped_ordinary = None
+    for planar, outlier_frac, prior, max_error in ((False, 0.2, 1, 4.0), (True, 0.2, 1, 4.0), (False, 0.5, 1, 4.0), (False, 0.2, 0, 1.0),
+                                                  (False, 0.2, 1, 12.0)):
+        n_img = 7
+        scene = synthetic.Scene(n_img, 1536, seed=31, planar=planar, outlier_frac=outlier_frac)
+        ims = [scene.image(i) for i in range(n_img)]
+        cams = [capi.simple_pinhole(scene.focal, scene.width / 2.0, scene.height / 2.0, scene.width, scene.height, prior) for _ in range(n_img)]
+        ctx.set_images([im[0] for im in ims], [im[1] for im in ims], cams)
+        pairs = synthetic.exhaustive_pairs(n_img)
+        ctx.match_pairs(pairs)
+        ctx.verify_pairs(capi.default_two_view_options(max_error=max_error), user_seed=3, stage_filter=True)
+        c = ctx.debug_verify_counters()
+        assert c[14] == 0, (planar, outlier_frac, prior, max_error, int(c[14]))
+        if not planar and outlier_frac == 0.2 and prior == 1 and max_error == 4.0:
+            skipped_ordinary = int(c[15])
+        # and the results of the checking schedule are the oracle's
+        tv = ctx.two_view_geometries()
+        offs, m = ctx.matches()
+        i, j = pairs[0]
+        ref, _ = oracle.estimate_two_view_geometry(cams[i], ims[i][1].astype(np.float64), cams[j], ims[j][1].astype(np.float64),
+                                                   m[int(offs[0]):int(offs[1])], capi.default_two_view_options(max_error=max_error),
+                                                   capi.pair_seed(int(i), int(j), 3))
+        tvg_equal(tv[0], ref, (planar, outlier_frac, prior, max_error))
+    assert skipped_ordinary is not None and skipped_ordinary > 21 * 1000  # > 1 000 of ~2 000+ slots per pair are never scored exactly
+    # the fuzz generator's pairs (tools/fuzz_verify.py): every structure, every camera model, through the stage calls
+    spec = importlib.util.spec_from_file_location("fuzz_verify", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_verify.py"))
+    fz = importlib.util.module_from_spec(spec)
+    sys.modules["fuzz_verify"] = fz
+    spec.loader.exec_module(fz)
+    problems = [fz.make_pair(9000 + k) for k in range(300)]
+    descs, kps, cams, pairs, matches = [], [], [], [], []
+    for k, (c1, c2, kp1, kp2, mt, kind) in enumerate(problems):
+        for c, kp in ((c1, kp1), (c2, kp2)):
+            descs.append(np.zeros((len(kp), 128), np.uint8))
+            kps.append(kp)
+            cams.append(capi.camera(c[0], c[1], fz.W, fz.H, c[2]))
+        pairs.append((2 * k, 2 * k + 1))
+        matches.append(mt)
+    ctx.set_images(descs, kps, cams)
+    ctx.set_matches(np.array(pairs, np.uint32), matches)
+    for max_error in (4.0, 0.7):
+        ctx.verify_pairs(capi.default_two_view_options(max_error=max_error), user_seed=1, stage_filter=False)
+        assert ctx.debug_verify_counters()[14] == 0
