@@ -316,8 +316,17 @@ struct H4Step {
     } else {
       double b = sqrt(c0 * c0 + tail_sq);
       if (c0 >= 0.0) b = -b;
+      const SharedDivisor hd = shared_divisor(c0 - b);  // (verify_linalg.h: the same quotients, the reciprocal formed once)
+      double mn = 0x1p1000;
 #pragma unroll
-      for (int i = K + 1; i < 9; ++i) a[K][i] = a[K][i] / (c0 - b);
+      for (int i = K + 1; i < 9; ++i) mn = fmin(mn, fabs(a[K][i]));
+      if (div_shared_group_ok(hd, mn)) {
+#pragma unroll
+        for (int i = K + 1; i < 9; ++i) a[K][i] = div_shared_fast(a[K][i], hd);
+      } else {
+#pragma unroll
+        for (int i = K + 1; i < 9; ++i) a[K][i] = a[K][i] / (c0 - b);
+      }
       tau = (b - c0) / b;
       beta = b;
     }
@@ -394,12 +403,27 @@ DSM_DEV int homography_four_point_reg(const double* xs, double* models) {
   // instructions when done for all 72.  24 entries are structural zeros (0 / scale = 0) and the eight -1 entries share
   // one quotient: 41 divisions, same values.
   const double neg_inv = -1.0 / scale;
+  const SharedDivisor sd = shared_divisor(scale);  // (and the 40 remaining quotients share the refined reciprocal)
+  double mn = 0x1p1000;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    a[i][0] /= scale; a[i][1] /= scale; a[i][2] = neg_inv;
-    a[i][6] /= scale; a[i][7] /= scale; a[i][8] /= scale;
-    a[4 + i][3] /= scale; a[4 + i][4] /= scale; a[4 + i][5] = neg_inv;
-    a[4 + i][6] /= scale; a[4 + i][7] /= scale; a[4 + i][8] /= scale;
+  for (int i = 0; i < 8; ++i) {
+    const int o = i < 4 ? 0 : 3;
+    mn = fmin(mn, fmin(fmin(fabs(a[i][o]), fabs(a[i][o + 1])), fmin(fmin(fabs(a[i][6]), fabs(a[i][7])), fabs(a[i][8]))));
+  }
+  if (div_shared_group_ok(sd, mn)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int o = i < 4 ? 0 : 3;
+      a[i][o] = div_shared_fast(a[i][o], sd); a[i][o + 1] = div_shared_fast(a[i][o + 1], sd); a[i][o + 2] = neg_inv;
+      a[i][6] = div_shared_fast(a[i][6], sd); a[i][7] = div_shared_fast(a[i][7], sd); a[i][8] = div_shared_fast(a[i][8], sd);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int o = i < 4 ? 0 : 3;
+      a[i][o] /= scale; a[i][o + 1] /= scale; a[i][o + 2] = neg_inv;
+      a[i][6] /= scale; a[i][7] /= scale; a[i][8] /= scale;
+    }
   }
   double nu[8], nd[8], hco[8];
 #pragma unroll

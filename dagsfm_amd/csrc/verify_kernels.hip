@@ -3334,6 +3334,8 @@ __global__ __launch_bounds__(64) void k_lo_prepare_reg(const VerifyParams p) {
   }
   double scale = mxl;
   if (scale == 0.0) scale = 1.0;
+  // (the rows of an E / F design matrix end in an exact 1 and an H row carries three exact zeros: no group guard passes;
+  // the plain divisions stay)
 #pragma unroll
   for (int r = 0; r < RPL; ++r) {
     if (lane + 64 * r < m) {

@@ -30,6 +30,46 @@
 #define DSM_DEV __device__ __forceinline__
 #define DSM_DEVN __device__ __noinline__
 
+// ====================================================================== several quotients with one denominator
+// x / d for many x and one d (JacobiSVD's m / scale over a whole matrix; a Householder tail over c0 - beta): the correctly
+// rounded quotient, computed by the hardware's OWN division sequence with the part that depends on d alone done once.
+// hipcc expands an FP64 division into v_div_scale (x2), v_rcp_f64, four refinement FMAs of the reciprocal, one multiply,
+// one residual FMA, v_div_fmas and v_div_fixup -- 11 VALU, one of them quarter rate.  When no operand needs scaling
+// (v_div_scale returns its input, VCC = 0, so v_div_fmas is a plain FMA) and no special case applies (v_div_fixup passes
+// the result through), that is: r = refine(refine(rcp(d))); q = x r; e = fma(-d, q, x); result = fma(e, r, q).  The first
+// part is shared_divisor(), the second 3 VALU per quotient in div_shared_fast() -- the SAME instructions on the same
+// values, hence the same bits.  The range in which the sequence needs neither scaling nor fix-up (v_div_scale_f64: numerator
+// exponent above 53, exponent difference below 768, neither 1/d nor x/d denormal) contains |d| in [2^-300, 2^300] with
+// |x| in [2^-600, 2^400]; a group with a numerator outside it (zero, tiny, NaN-free huge) takes the plain divisions.
+struct SharedDivisor {
+  double d, r;
+  bool ok;
+};
+DSM_DEV SharedDivisor shared_divisor(double d) {
+  SharedDivisor s;
+  s.d = d;
+  const double ad = fabs(d);
+  s.ok = (ad >= 0x1p-300) && (ad <= 0x1p300);  // false for NaN
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  s.r = r;
+  return s;
+}
+// the three instructions of one quotient (only inside a group that passed div_shared_group_ok)
+DSM_DEV double div_shared_fast(double x, const SharedDivisor& s) {
+  const double q = x * s.r;
+  const double e = __builtin_fma(-s.d, q, x);
+  return __builtin_fma(e, s.r, q);
+}
+// ONE guard for a whole group of numerators: `min_abs` = the smallest |x| of the group (NaN numerators do not lower it:
+// they give NaN on either path).  The callers' numerators are bounded by the denominator's own construction (|x| <= scale;
+// a Householder tail is bounded by the norm that made c0 - beta), so a finite in-range d implies finite numerators and
+// only the lower end needs looking at.  A per-quotient guard would cost a branch per division and eat the gain.
+DSM_DEV bool div_shared_group_ok(const SharedDivisor& s, double min_abs) { return s.ok && (min_abs >= 0x1p-600); }
+
 // ====================================================================== per-lane routines
 // Column-major storage with leading dimension ld, like Eigen.
 
@@ -243,8 +283,17 @@ DSM_DEV void pr_colpiv_qr9(double (&qr)[9 * M], double (&hco)[M]) {
     } else {
       double b = sqrt(c0 * c0 + tail_sq);
       if (c0 >= 0.0) b = -b;
+      const SharedDivisor hd = shared_divisor(c0 - b);
+      double mn = 0x1p1000;
 #pragma unroll
-      for (int i = k + 1; i < 9; ++i) QRE(i, k) = QRE(i, k) / (c0 - b);
+      for (int i = k + 1; i < 9; ++i) mn = fmin(mn, fabs(QRE(i, k)));
+      if (div_shared_group_ok(hd, mn)) {
+#pragma unroll
+        for (int i = k + 1; i < 9; ++i) QRE(i, k) = div_shared_fast(QRE(i, k), hd);
+      } else {
+#pragma unroll
+        for (int i = k + 1; i < 9; ++i) QRE(i, k) = QRE(i, k) / (c0 - b);
+      }
       tau = (b - c0) / b;
       beta = b;
     }
@@ -316,8 +365,19 @@ DSM_DEV void pr_nullspace_9xm(double (&At)[9 * M], double (&out)[(9 - M) * 9]) {
     if (a > scale) scale = a;
   }
   if (scale == 0.0) scale = 1.0;
+  {
+    const SharedDivisor sd = shared_divisor(scale);
+    double mn = 0x1p1000;
 #pragma unroll
-  for (int i = 0; i < 9 * M; ++i) At[i] /= scale;
+    for (int i = 0; i < 9 * M; ++i) mn = fmin(mn, fabs(At[i]));
+    if (div_shared_group_ok(sd, mn)) {
+#pragma unroll
+      for (int i = 0; i < 9 * M; ++i) At[i] = div_shared_fast(At[i], sd);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 9 * M; ++i) At[i] /= scale;
+    }
+  }
   double hco[M];
   pr_colpiv_qr9<M>(At, hco);
   double q[9];
@@ -826,11 +886,14 @@ DSM_DEV bool pr_hessenberg_eigenvalues(double (&T)[N * N], int n, double (&re)[N
     }
   }
   if (scale < DBL_MIN) return true;
+  {
+    // (a companion matrix is mostly exact zeros: its group never passes the guard; kept as the plain division)
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
+    for (int j = 0; j < N; ++j) {
 #pragma unroll
-    for (int i = 0; i < N; ++i)
-      if (i <= j + 1) RT(i, j) /= scale;
+      for (int i = 0; i < N; ++i)
+        if (i <= j + 1) RT(i, j) /= scale;
+    }
   }
   const int max_iters = 40 * n;
   int iu = n - 1, iter = 0, total_iter = 0;
