@@ -2,6 +2,7 @@
 #include "flann_index.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <limits>
 #include <thread>
@@ -466,7 +467,9 @@ bool FlannIndex::FindWordIds(const uint8_t* descriptors, uint32_t n, uint32_t k,
   if (num_checks < 0 && algorithm_ != kLinear) return false;
   for (size_t i = 0; i < static_cast<size_t>(n) * k; ++i) out_ids[i] = kInvalidWordId;  // word_ids.setConstant(kInvalidWordId)
   if (out_dists) std::fill(out_dists, out_dists + static_cast<size_t>(n) * k, 0.0f);
+  std::atomic<bool> failed(false);  // (a worker must not std::terminate the host process: an allocation failure is reported as `false`)
   auto run = [&](uint32_t begin, uint32_t end) {
+   try {
     ResultSet result(k);
     for (uint32_t i = begin; i < end; ++i) {
       result.Clear();
@@ -477,6 +480,9 @@ bool FlannIndex::FindWordIds(const uint8_t* descriptors, uint32_t n, uint32_t k,
         if (out_dists) out_dists[static_cast<size_t>(i) * k + j] = result.dist_index_[j].dist;
       }
     }
+   } catch (...) {
+    failed = true;  // (only ever set to true: no ordering between the workers is needed)
+   }
   };
   // `cores` threads over the queries (nn_index.h:342-354); every query is searched on its own, so any split gives the
   // reference's answer
@@ -489,7 +495,7 @@ bool FlannIndex::FindWordIds(const uint8_t* descriptors, uint32_t n, uint32_t k,
       pool.emplace_back(run, static_cast<uint32_t>(static_cast<uint64_t>(n) * w / workers), static_cast<uint32_t>(static_cast<uint64_t>(n) * (w + 1) / workers));
     for (std::thread& t : pool) t.join();
   }
-  return true;
+  return !failed;
 }
 
 }  // namespace dagsfm_amd
