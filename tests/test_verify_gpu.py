@@ -556,3 +556,28 @@ def test_scoring_bounds_hold_on_every_slot(oracle, monkeypatch):
     for max_error in (4.0, 0.7):
         ctx.verify_pairs(capi.default_two_view_options(max_error=max_error), user_seed=1, stage_filter=False)
         assert ctx.debug_verify_counters()[14] == 0
+
+
+def test_debug_options_are_per_context_and_checked():
+    """dsm_set_debug_option (round 4): the library reads no environment; a switch belongs to ONE context, an unknown key is an
+    error, NULL removes a key.  (The Python binding forwards DSM_* variables of the process through this call.)"""
+    a, b = capi.Context(0), capi.Context(0)
+    a.set_debug_option("DSM_VERIFY_LANES", "1")
+    assert a._debug.get("DSM_VERIFY_LANES") == "1" and "DSM_VERIFY_LANES" not in b._debug
+    with pytest.raises(capi.DsmError):
+        a.set_debug_option("DSM_NO_SUCH_SWITCH", "1")
+    a.set_debug_option("DSM_VERIFY_LANES", None)
+    assert "DSM_VERIFY_LANES" not in a._debug
+    # the two contexts give the same results whatever one of them was told
+    scene = synthetic.Scene(3, 512, seed=5)
+    ims = [scene.image(i) for i in range(3)]
+    cams = [capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, True) for _ in range(3)]
+    a.set_debug_option("DSM_VERIFY_INLINE_LO", "0")
+    a.set_debug_option("DSM_SCORE_PREFILTER", "0")
+    recs = []
+    for c in (a, b):
+        c.set_images([im[0] for im in ims], [im[1] for im in ims], cams)
+        c.match_pairs(synthetic.exhaustive_pairs(3))
+        c.verify_pairs(capi.default_two_view_options(), user_seed=7, stage_filter=False)
+        recs.append([bytes(t) for t in c.two_view_geometries()])
+    assert recs[0] == recs[1]
