@@ -1895,9 +1895,18 @@ DSM_DEV PreBounds prescore_bounds(const double* M, const double mx[4], double T)
   return b;
 }
 
-// one correspondence: bit 0 = surely an inlier of the reference's test, bit 1 = surely an outlier (neither: uncertain)
+// one correspondence: surely an inlier of the reference's test / surely an outlier (neither: uncertain)
+template <int FAM>
+DSM_DEV void prescore_flags(const double* M, const PreBounds& b, const double* q, bool& sure_in, bool& sure_out);
 template <int FAM>
 DSM_DEV void prescore_point(const double* M, const PreBounds& b, const double* q, int& lb, int& sure_out) {
+  bool in, out;
+  prescore_flags<FAM>(M, b, q, in, out);
+  lb += in ? 1 : 0;
+  sure_out += out ? 1 : 0;
+}
+template <int FAM>
+DSM_DEV void prescore_flags(const double* M, const PreBounds& b, const double* q, bool& sure_in, bool& sure_out) {
   if (FAM == FAM_H) {
     const double s0 = q[0], s1 = q[1], d0 = q[2], d1 = q[3];
     const double pd0 = __builtin_fma(M[0], s0, __builtin_fma(M[1], s1, M[2]));
@@ -1908,8 +1917,8 @@ DSM_DEV void prescore_point(const double* M, const PreBounds& b, const double* q
     const double L = __builtin_fma(e0, e0, e1 * e1);
     const double q2 = pd2 * pd2;
     const bool ok = fabs(pd2) >= b.c0;
-    lb += (ok && (L <= b.t_lo * q2)) ? 1 : 0;
-    sure_out += (ok && (L >= b.t_hi * q2)) ? 1 : 0;
+    sure_in = ok && (L <= b.t_lo * q2);
+    sure_out = ok && (L >= b.t_hi * q2);
   } else {
     const double x10 = q[0], x11 = q[1], x20 = q[2], x21 = q[3];
     const double g0 = __builtin_fma(M[0], x10, __builtin_fma(M[1], x11, M[2]));
@@ -1921,8 +1930,8 @@ DSM_DEV void prescore_point(const double* M, const PreBounds& b, const double* q
     const double num = C * C;
     const double D = __builtin_fma(g0, g0, __builtin_fma(g1, g1, __builtin_fma(h0, h0, h1 * h1)));
     const bool ok = D >= b.c0;
-    lb += (ok && (num <= b.t_lo * D)) ? 1 : 0;
-    sure_out += (ok && (num >= b.t_hi * D)) ? 1 : 0;
+    sure_in = ok && (num <= b.t_lo * D);
+    sure_out = ok && (num >= b.t_hi * D);
   }
 }
 
@@ -2329,15 +2338,25 @@ __global__ __launch_bounds__(64, 8) void k_models_score_e(const VerifyParams p) 
       int ub_chk = n, lb_chk = 0;
       if (prefilter) {
         const PreBounds b = prescore_bounds<FAM_E>(M, mx, max_residual);
-        int lb = 0, so = 0;
-        if (in_lds) {
-          for (int i = lane; i < n; i += 64) prescore_point<FAM_E>(M, b, spts + (size_t)i * 4, lb, so);
+        int lb = 0, so = 0;  // wave totals: a ballot + scalar population count per 64 points instead of per-lane counters + a reduction
+        if (in_lds) {  // (two loops: a pointer that may be LDS or global compiles to flat loads)
+          for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            bool fin = false, fout = false;
+            if (i < n) prescore_flags<FAM_E>(M, b, spts + (size_t)i * 4, fin, fout);
+            so += (int)__popcll(__ballot(fout));
+            if constexpr (CHECK) lb += (int)__popcll(__ballot(fin));
+          }
         } else {
-          for (int i = lane; i < n; i += 64) prescore_point<FAM_E>(M, b, gpts + (size_t)i * 4, lb, so);
+          for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            bool fin = false, fout = false;
+            if (i < n) prescore_flags<FAM_E>(M, b, gpts + (size_t)i * 4, fin, fout);
+            so += (int)__popcll(__ballot(fout));
+            if constexpr (CHECK) lb += (int)__popcll(__ballot(fin));
+          }
         }
-        for (int o = 32; o > 0; o >>= 1) so += __shfl_xor(so, o);
         if constexpr (CHECK) {
-          for (int o = 32; o > 0; o >>= 1) lb += __shfl_xor(lb, o);
           ub_chk = n - so;
           lb_chk = lb;
         }
@@ -2352,11 +2371,16 @@ __global__ __launch_bounds__(64, 8) void k_models_score_e(const VerifyParams p) 
       }
       int cnt = 0;
       if (in_lds) {  // (apart: a pointer that may be LDS or global compiles to flat loads)
-        for (int i = lane; i < n; i += 64) cnt += (fam_residual<FAM_E>(M, spts + (size_t)i * 4) <= max_residual) ? 1 : 0;
+        for (int base = 0; base < n; base += 64) {
+          const int i = base + lane;
+          cnt += (int)__popcll(__ballot(i < n && fam_residual<FAM_E>(M, spts + (size_t)(i < n ? i : 0) * 4) <= max_residual));
+        }
       } else {
-        for (int i = lane; i < n; i += 64) cnt += (fam_residual<FAM_E>(M, gpts + (size_t)i * 4) <= max_residual) ? 1 : 0;
+        for (int base = 0; base < n; base += 64) {
+          const int i = base + lane;
+          cnt += (int)__popcll(__ballot(i < n && fam_residual<FAM_E>(M, gpts + (size_t)(i < n ? i : 0) * 4) <= max_residual));
+        }
       }
-      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
       if (lane == 0) counts[tt * 10 + m] = cnt;
       if constexpr (CHECK) {
         if (lane == 0 && (cnt < lb_chk || cnt > ub_chk)) atomicAdd(p.active_count + 14, 1u);
