@@ -372,6 +372,14 @@ inline SVD jacobi_svd(const Mat& A, bool want_u) {
   return out;
 }
 
+// (tools/sim_roots_lanes.py builds the oracle with -DORACLE_EIG_TRACE to record, per polynomial, the sequence of deflations
+// and Francis steps with their windows -- the input of its model of how 64 lanes of k_roots_e share a wave)
+#ifdef ORACLE_EIG_TRACE
+extern "C" void oracle_eig_trace(int kind, int il, int imm, int iu);
+#define ORACLE_EIG_EVENT(kind, il, imm, iu) oracle_eig_trace(kind, il, imm, iu)
+#else
+#define ORACLE_EIG_EVENT(kind, il, imm, iu) ((void)0)
+#endif
 // ---- EigenSolver (eigenvalues only): Hessenberg + RealSchur (Eigen/src/Eigenvalues) ----------
 // Returns false when the QR iteration does not converge (info() != Success).
 inline bool real_eigenvalues(const Mat& Cin, std::vector<double>* re, std::vector<double>* im) {
@@ -421,11 +429,13 @@ inline bool real_eigenvalues(const Mat& Cin, std::vector<double>* re, std::vecto
         il--;
       }
       if (il == iu) {
+        ORACLE_EIG_EVENT(1, il, il, iu);
         T(iu, iu) = T(iu, iu) + exshift;
         if (iu > 0) T(iu, iu - 1) = 0.0;
         iu--;
         iter = 0;
       } else if (il == iu - 1) {
+        ORACLE_EIG_EVENT(2, il, il, iu);
         // splitOffTwoRows
         const double p = 0.5 * (T(iu - 1, iu - 1) - T(iu, iu));
         const double q = p * p + T(iu, iu - 1) * T(iu - 1, iu);
@@ -508,6 +518,7 @@ inline bool real_eigenvalues(const Mat& Cin, std::vector<double>* re, std::vecto
           const double rhs = v0 * (std::fabs(T(imm - 1, imm - 1)) + std::fabs(Tmm) + std::fabs(T(imm + 1, imm + 1)));
           if (std::fabs(lhs) < DBL_EPSILON * rhs) break;
         }
+        ORACLE_EIG_EVENT(3, il, imm, iu);
         // performFrancisQRStep
         for (int k = imm; k <= iu - 2; ++k) {
           const bool first = (k == imm);
