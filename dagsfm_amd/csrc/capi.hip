@@ -1073,7 +1073,10 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     plan.n_lanes = n_lanes;
     plan.dev_cus = dev_cus;
     // persistent grids sized for a lane's share of the chip: two lanes 362.5 vs 366.3 ms at config 2, 193.5 vs 205.1 on its half
-    plan.grid_div = n_lanes;
+    // -- when the lanes' launches are long.  A short list's launches are tails more than bodies, and a lane then gains more from
+    // waves of its own on every CU than it loses to the other lane's: 15 594 pairs (an eighth of config 2) 46.7 vs 48.3 ms with
+    // whole-chip grids, the whole list 306.0 vs 297.8.
+    plan.grid_div = n_pairs <= 40000u ? 1u : n_lanes;
     if (const char* e = ctx->dbg("DSM_VERIFY_GRID_DIV")) plan.grid_div = (uint32_t)std::max(1, atoi(e));
     // Local optimisation: batched kernels (k_replay_lo + k_lo_*) or inline in the replay (k_replay).  The batched form
     // wins on throughput (config 2, 124 750 pairs: 416 vs 702 ms) but every LO iteration costs a kernel round trip; it

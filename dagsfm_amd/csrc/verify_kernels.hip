@@ -235,27 +235,55 @@ DSM_DEV void wv_draw_samples(MtState* gen, WvSampler* ws, uint32_t* sidx, uint32
     // order, so the next trial's read sees this trial's write.  A trial that is not plain (a few per cent: ~K_^2 / n)
     // takes the one-swap-at-a-time form on lane 0 with the head back in the array.  Either way the state after the
     // trial is that of K_ sequential swaps.
+    // Runs of plain trials go through a loop without a branch in it: the execution mask is set once for the run, an iteration
+    // is two LDS reads (the next trial's partner, the entry that becomes the head), one LDS write and the store of the sample
+    // -- and the write and the store of trial r use the head read in trial r - 1, so the read of trial r is in flight behind
+    // them (the first form of this loop tested the plain bit, saved and restored the mask and waited for its own read in
+    // every trial: ~25 scalar instructions and a full LDS round trip per trial, the scalar unit of the CU was its limit).
     {
       const bool mine = lane < K_;
       uint32_t h = mine ? sidx[lane] : 0u;
       uint32_t jn = mine ? ws->jb[lane] : 0u;
       for (int c = 0; c < nt; c += 64) {
         const uint64_t pm = ws->plain[c >> 6];
-        const uint32_t pm_lo = __builtin_amdgcn_readfirstlane((uint32_t)pm), pm_hi = __builtin_amdgcn_readfirstlane((uint32_t)(pm >> 32));
+        // (the builtin returns int: through uint32_t, or the low word's bit 31 would be sign-extended over the high word)
+        const uint32_t pm_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pm), pm_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pm >> 32));
+        const uint64_t pmu = ((uint64_t)pm_hi << 32) | (uint64_t)pm_lo;
         const int lim = nt - c < 64 ? nt - c : 64;
-        for (int u = 0; u < lim; ++u) {
+        int u = 0;
+        while (u < lim) {
+          const uint64_t not_plain = ~(pmu >> u);  // bit r: trial u + r is not plain (the shifted-in zeros end the run at bit 64 - u)
+          int run = not_plain ? __builtin_ctzll(not_plain) : 64;
+          if (run > lim - u) run = lim - u;
           const int tt = c + u;
-          const uint32_t j = jn;
-          if (mine && tt + 1 < nt) jn = ws->jb[(tt + 1) * K_ + lane];
-          const bool plain = (((u < 32) ? (pm_lo >> u) : (pm_hi >> (u - 32))) & 1u) != 0u;
-          if (plain) {
+          if (run > 0) {
             if (mine) {
-              const uint32_t v = sidx[j];
+              uint32_t* out = smp + (size_t)(t + tt) * 7 + lane;
+              const uint32_t* jp = ws->jb + (tt + 1) * K_ + lane;  // (one trial past the block's last is inside jb[]: read, never used)
+              uint32_t j = jn;
+              jn = *jp;
+              jp += K_;
+              uint32_t v = sidx[j];
               sidx[j] = h;
               h = v;
+              for (int r = 1; r < run; ++r) {
+                j = jn;
+                jn = *jp;
+                jp += K_;
+                v = sidx[j];
+                sidx[j] = h;
+                *out = h;
+                out += 7;
+                h = v;
+              }
+              *out = h;
             }
+            u += run;
           } else {
-            if (mine) sidx[lane] = h;
+            if (mine) {
+              jn = ws->jb[(tt + 1) * K_ + lane];
+              sidx[lane] = h;
+            }
             wv_sync();
             if (lane == 0) {
 #pragma unroll
@@ -267,9 +295,12 @@ DSM_DEV void wv_draw_samples(MtState* gen, WvSampler* ws, uint32_t* sidx, uint32
               }
             }
             wv_sync();
-            if (mine) h = sidx[lane];
+            if (mine) {
+              h = sidx[lane];
+              smp[(size_t)(t + tt) * 7 + lane] = h;
+            }
+            u += 1;
           }
-          if (mine) smp[(size_t)(t + tt) * 7 + lane] = h;
         }
       }
       if (mine) sidx[lane] = h;

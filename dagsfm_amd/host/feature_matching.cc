@@ -114,7 +114,31 @@ ExhaustiveFeatureMatcher::ExhaustiveFeatureMatcher(const ExhaustiveMatchingOptio
 }
 
 bool ExhaustiveFeatureMatcher::Run() {
-  if (!matcher_.Setup()) {
+  // The reference's order is matcher_.Setup(); cache_.Setup() (matching.cc:858-863).  Setup() here creates the device
+  // contexts (HIP runtime start-up, code objects: a few hundred ms of a process that matches 500 images in about one second),
+  // the cache's set-up and the first block's features are SQLite reads: the two run side by side.
+  const auto t_setup = std::chrono::steady_clock::now();
+  bool setup_ok = false;
+  std::thread setup_thread([this, &setup_ok]() { setup_ok = matcher_.Setup(); });
+  struct Joiner {
+    std::thread* t;
+    ~Joiner() {
+      if (t->joinable()) t->join();
+    }
+  } setup_joiner{&setup_thread};
+  cache_.Setup();
+  const std::vector<image_t> image_ids = cache_.GetImageIds();
+  {
+    const size_t first_block = std::min<size_t>({image_ids.size(), static_cast<size_t>(std::max(options_.block_size, 1)), cache_.CacheSize()});
+    for (size_t i = 0; i < first_block; ++i) {  // what the first Match() asks for first; stays cached (LRU), pinned only until here
+      cache_.GetKeypoints(image_ids[i]);
+      cache_.GetDescriptors(image_ids[i]);
+    }
+    cache_.ReleasePins();
+  }
+  setup_thread.join();
+  setup_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup).count();
+  if (!setup_ok) {
     std::cerr << "ERROR: " << matcher_.LastError() << std::endl;
     return false;
   }
@@ -131,8 +155,6 @@ bool ExhaustiveFeatureMatcher::Run() {
     }
   } journal_guard{match_options_.bulk_load_journal ? &database_ : nullptr};
   if (match_options_.bulk_load_journal) database_.SetBulkLoadJournal(true);
-  cache_.Setup();
-  const std::vector<image_t> image_ids = cache_.GetImageIds();
   const size_t block_size = static_cast<size_t>(options_.block_size);
   const size_t num_blocks = (image_ids.size() + block_size - 1) / block_size;
   std::vector<std::pair<image_t, image_t>> image_pairs;
@@ -507,9 +529,11 @@ extern "C" {
 // Runs ExhaustiveFeatureMatcher over database_path.  Returns 0 on success.
 // gpu_index: SiftMatchingOptions::gpu_index ("-1" or null: all devices); async_write_back: this repository's extension.
 // Nothing here reads the process environment: the CLI parses its own flags (exhaustive_matcher_main.cc).
-int dsm_host_exhaustive_matcher_ex2(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,
+// async_slice_pairs: SiftMatchingOptions::async_slice_pairs (< 0: its default).
+int dsm_host_exhaustive_matcher_ex3(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,
                                     double max_ratio, double max_distance, int cross_check, int min_num_inliers,
-                                    int guided_matching, int multiple_models, const char* gpu_index, int async_write_back) {
+                                    int guided_matching, int multiple_models, const char* gpu_index, int async_write_back,
+                                    int async_slice_pairs) {
   const bool print_timing = async_write_back & 2;  // bit 1 of the flag word: print the stage timers
   const bool bulk_load_journal = async_write_back & 4;  // bit 2: SiftMatchingOptions::bulk_load_journal
   async_write_back &= 1;
@@ -527,15 +551,17 @@ int dsm_host_exhaustive_matcher_ex2(const char* database_path, int block_size, i
     mo.multiple_models = multiple_models != 0;
     mo.async_write_back = async_write_back != 0;  // overlap SQLite with the device
     mo.bulk_load_journal = bulk_load_journal;
+    if (async_slice_pairs >= 0) mo.async_slice_pairs = async_slice_pairs;
     if (gpu_index && *gpu_index) mo.gpu_index = gpu_index;
     mo.random_seed = random_seed;
     ExhaustiveFeatureMatcher m(eo, mo, database_path);
     const bool ok = m.Run();
     if (ok && print_timing) {  // the CLI's --timing 1: one line on stderr, what tools/bench_cli.py keeps
       const SiftFeatureMatcher::Timings t = m.MatcherTimings();
-      std::fprintf(stderr, "[dsm_exhaustive_matcher] pairs %llu  run %.3f s  =  features from database.db -> device %.3f s  +  device (match + verify + fetch) "
-                           "%.3f s  +  SQLite write-back %.3f s%s  +  other %.3f s\n",
-                   static_cast<unsigned long long>(t.pairs), m.run_seconds, t.resident_s, t.device_s, t.write_s,
+      std::fprintf(stderr, "[dsm_exhaustive_matcher] set-up (device contexts || cache + first block's features) %.3f s;  "
+                           "pairs %llu  run %.3f s  =  features from database.db -> device %.3f s  +  device (match + verify + fetch) "
+                           "%.3f s (fetch %.3f)  +  SQLite write-back %.3f s%s  +  other %.3f s\n",
+                   m.setup_seconds, static_cast<unsigned long long>(t.pairs), m.run_seconds, t.resident_s, t.device_s, t.fetch_s, t.write_s,
                    mo.async_write_back ? " (on the write-back thread: overlaps the device time)" : "",
                    m.run_seconds - t.resident_s - t.device_s - (mo.async_write_back ? 0.0 : t.write_s));
     }
@@ -544,6 +570,13 @@ int dsm_host_exhaustive_matcher_ex2(const char* database_path, int block_size, i
     std::cerr << "ERROR: " << e.what() << std::endl;
     return 1;
   }
+}
+
+int dsm_host_exhaustive_matcher_ex2(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,
+                                    double max_ratio, double max_distance, int cross_check, int min_num_inliers,
+                                    int guided_matching, int multiple_models, const char* gpu_index, int async_write_back) {
+  return dsm_host_exhaustive_matcher_ex3(database_path, block_size, use_prior_defaults, random_seed, max_ratio, max_distance, cross_check,
+                                         min_num_inliers, guided_matching, multiple_models, gpu_index, async_write_back, -1);
 }
 
 int dsm_host_exhaustive_matcher_ex(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,

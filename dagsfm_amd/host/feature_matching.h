@@ -207,6 +207,7 @@ struct NativeTraits {
   }
   static uint32_t RandomSeed(const Options& o) { return o.random_seed; }
   static bool AsyncWriteBack(const Options& o) { return o.async_write_back; }
+  static size_t AsyncSlicePairs(const Options& o) { return o.async_slice_pairs > 0 ? static_cast<size_t>(o.async_slice_pairs) : 0; }
 };
 
 // SiftFeatureMatcher of this repository's host side: Setup() / Match() / Flush() as documented in
@@ -226,6 +227,7 @@ class ExhaustiveFeatureMatcher {
   // where Run()'s wall time went: SiftFeatureMatcher's stage timers + Run()'s own total
   SiftFeatureMatcher::Timings MatcherTimings() const { return matcher_.GetTimings(); }
   double run_seconds = 0.0;
+  double setup_seconds = 0.0;  // before that: device contexts, cache set-up, the first block's features
 
  private:
   ExhaustiveMatchingOptions options_;

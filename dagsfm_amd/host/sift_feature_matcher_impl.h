@@ -13,7 +13,8 @@
 //   functions  PairId(a, b); CacheSize(cache); ReleasePins(cache); LockBatch(cache) (RAII guard, may be empty);
 //              ToDsmCamera(camera, &out); CameraIdOf(image); KeypointData(kps, &n, &stride_in_floats);
 //              DescriptorData(desc, &rows, &cols); AppendFlat(matches, &flat); MakeMatches(flat, n);
-//              MakeTwoViewGeometry(record or nullptr, inliers, n); RandomSeed(options); AsyncWriteBack(options)
+//              MakeTwoViewGeometry(record or nullptr, inliers, n); RandomSeed(options); AsyncWriteBack(options);
+//              AsyncSlicePairs(options) (only with kAsyncWriteBack)
 //
 // feature_matching.h instantiates it with this repository's own types (NativeTraits); colmap_traits.h with the
 // reference's (compile-checked against tests/colmap_stub, which carries the reference's exact signatures).
@@ -138,6 +139,7 @@ class SiftFeatureMatcherT {
   struct Timings {
     double resident_s, device_s, write_s;
     uint64_t pairs;
+    double fetch_s;  // the part of device_s that copies the results to the host (the slowest device's, per call)
   };
   Timings GetTimings() const { return timings_; }
   const std::string& LastError() const { return last_error_; }
@@ -210,6 +212,7 @@ class SiftFeatureMatcherT {
     RawU32Buffer m, im;
     std::vector<dsm_two_view_geometry> tv;
     std::string error;
+    double fetch_s = 0.0;
   };
 
   void RunShare(dsm_ctx* ctx, const PairList& prs, const std::vector<typename Traits::FeatureMatches>* given,
@@ -243,6 +246,7 @@ class SiftFeatureMatcherT {
       sh->error = std::string("device matching failed: ") + dsm_last_error(ctx);
       return;
     }
+    const Clock::time_point t_fetch = Clock::now();
     sh->moff.assign(np + 1, 0);
     sh->ioff.assign(np + 1, 0);
     rc = dsm_get_matches(ctx, sh->moff.data(), nullptr, 0);
@@ -254,10 +258,39 @@ class SiftFeatureMatcherT {
     sh->im.Allocate(2 * std::max<uint64_t>(sh->ioff[np], 1));
     if (rc == DSM_OK) rc = dsm_get_inlier_matches(ctx, nullptr, sh->im.data(), sh->ioff[np]);
     if (rc != DSM_OK) sh->error = std::string("result fetch failed: ") + dsm_last_error(ctx);
+    sh->fetch_s = Seconds(t_fetch);
   }
+
+  // With the asynchronous write-back a long list goes to the devices slice by slice: the rows of slice k are written
+  // (one transaction of the writer thread per slice) while slice k + 1 is on the devices -- one Match() over a block of
+  // 500 images (124 750 pairs) then overlaps its own write-back instead of only the next block's.  Per-pair seeds and
+  // the matching depend on the pair alone, so the rows are those of the unsliced call.
+  size_t AsyncSlicePairs(std::true_type) const { return Traits::AsyncWriteBack(options_) ? Traits::AsyncSlicePairs(options_) : 0; }
+  size_t AsyncSlicePairs(std::false_type) const { return 0; }
 
   void Run(const PairList& prs, const std::vector<typename Traits::FeatureMatches>* given, const std::vector<char>& stale_inliers,
            const dsm_match_options& mo, const dsm_two_view_options& to) {
+    const size_t slice = AsyncSlicePairs(std::integral_constant<bool, Traits::kAsyncWriteBack>());
+    if (slice == 0 || prs.size() <= slice + slice / 2) {  // (no slice shorter than half the nominal length)
+      RunSlice(prs, given, stale_inliers, mo, to);
+      return;
+    }
+    const size_t n_slices = (prs.size() + slice - 1) / slice;
+    for (size_t k = 0; k < n_slices; ++k) {
+      const size_t b = prs.size() * k / n_slices, e = prs.size() * (k + 1) / n_slices;
+      const PairList part(prs.begin() + b, prs.begin() + e);
+      const std::vector<char> stale(stale_inliers.begin() + b, stale_inliers.begin() + e);
+      if (given) {
+        const std::vector<typename Traits::FeatureMatches> given_part(given->begin() + b, given->begin() + e);
+        RunSlice(part, &given_part, stale, mo, to);
+      } else {
+        RunSlice(part, nullptr, stale, mo, to);
+      }
+    }
+  }
+
+  void RunSlice(const PairList& prs, const std::vector<typename Traits::FeatureMatches>* given, const std::vector<char>& stale_inliers,
+                const dsm_match_options& mo, const dsm_two_view_options& to) {
     if (prs.empty()) return;
     const uint32_t np = static_cast<uint32_t>(prs.size());
     // Contiguous blocks of the list, one per device, cut by cost (descriptor-matrix size + a per-pair term for
@@ -289,6 +322,9 @@ class SiftFeatureMatcherT {
     }
     timings_.device_s += Seconds(t_device);
     timings_.pairs += np;
+    double fetch_s = 0.0;
+    for (const Share& sh : shares) fetch_s = std::max(fetch_s, sh.fetch_s);
+    timings_.fetch_s += fetch_s;
     for (const Share& sh : shares)
       if (!sh.error.empty()) throw std::runtime_error(sh.error);
     // merge the shares in list order (one device: its buffers ARE the result, nothing is copied)

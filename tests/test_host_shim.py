@@ -103,12 +103,18 @@ def test_database_round_trip_and_dagsfm_columns(tmp_path):
     con.close()
 
 
+# "sliced": the asynchronous write-back with a Match() call cut into slices of a few pairs (async_slice_pairs; 32 768 by default,
+# which no test list reaches) -- slice k is written while slice k + 1 is on the device
+_SLICED = ["--SiftMatching.async_write_back", "1", "--SiftMatching.async_slice_pairs", "4"]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("async_write", [False, True])
+@pytest.mark.parametrize("async_write", [False, True, "sliced"])
 def test_exhaustive_matcher_drop_in(tmp_path, oracle, async_write, monkeypatch):
     """colmap exhaustive_matcher equivalent over a synthetic database.db == oracle, incl. resume semantics; also with
     the write-back on a background thread (SiftMatchingOptions::async_write_back, DSM_ASYNC_WRITE_BACK)."""
-    if async_write:
+    extra = _SLICED if async_write == "sliced" else []
+    if async_write is True:
         monkeypatch.setenv("DSM_ASYNC_WRITE_BACK", "1")
     from dagsfm_amd import capi, synthetic
     n_img = 6
@@ -117,7 +123,7 @@ def test_exhaustive_matcher_drop_in(tmp_path, oracle, async_write, monkeypatch):
     path = str(tmp_path / "database.db")
     dbutil.create(path, [(im[0], im[1]) for im in ims], prior=True)
     assert os.path.exists(CLI)
-    subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5"])  # one block: pairs visited as (i, j), i < j
+    subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5"] + extra)  # one block: pairs visited as (i, j), i < j
     matches, tvgs = dbutil.read_results(path)
     assert len(matches) == n_img * (n_img - 1) // 2 == len(tvgs)
     cam = capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, True)
@@ -143,7 +149,7 @@ def test_exhaustive_matcher_drop_in(tmp_path, oracle, async_write, monkeypatch):
     assert n_geo >= 8
     # resume: (1) nothing to do; (2) a deleted two_view_geometries row is re-verified from the stored matches
     before = dbutil.read_results(path)
-    subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5"])
+    subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5"] + extra)
     after = dbutil.read_results(path)
     assert all((before[0][k] == after[0][k]).all() for k in before[0])
     con = sqlite3.connect(path)
@@ -151,7 +157,7 @@ def test_exhaustive_matcher_drop_in(tmp_path, oracle, async_write, monkeypatch):
     con.execute("DELETE FROM two_view_geometries WHERE pair_id = ?", (pid,))
     con.commit()
     con.close()
-    subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5"])
+    subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5"] + extra)
     again = dbutil.read_results(path)
     assert (again[1][pid]["inliers"] == before[1][pid]["inliers"]).all() and again[1][pid]["config"] == before[1][pid]["config"]
     assert again[1][pid]["F"] == before[1][pid]["F"]
@@ -173,11 +179,12 @@ def _visit_order(n, block_size):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("async_write", [False, True])
+@pytest.mark.parametrize("async_write", [False, True, "sliced"])
 def test_exhaustive_matcher_blocks_and_swapped_pairs(tmp_path, oracle, async_write, monkeypatch):
     """block_size < #images: some pairs are visited as (larger id, smaller id); the rows are stored swapped /
     inverted exactly as Database::WriteMatches / WriteTwoViewGeometry do (database.cc:681-751)."""
-    if async_write:  # several Match() calls: the write-back of one block overlaps the device work of the next
+    extra = [_SLICED[0], _SLICED[1], _SLICED[2], "2"] if async_write == "sliced" else []
+    if async_write is True:  # several Match() calls: the write-back of one block overlaps the device work of the next
         monkeypatch.setenv("DSM_ASYNC_WRITE_BACK", "1")
     from dagsfm_amd import capi, synthetic
     n_img = 6
@@ -185,7 +192,7 @@ def test_exhaustive_matcher_blocks_and_swapped_pairs(tmp_path, oracle, async_wri
     ims = [scene.image(i) for i in range(n_img)]
     path = str(tmp_path / "database.db")
     dbutil.create(path, [(im[0], im[1]) for im in ims], prior=True)
-    subprocess.check_call([CLI, "--database_path", path, "--ExhaustiveMatching.block_size", "4", "--random_seed", "9"])
+    subprocess.check_call([CLI, "--database_path", path, "--ExhaustiveMatching.block_size", "4", "--random_seed", "9"] + extra)
     matches, tvgs = dbutil.read_results(path)
     order = _visit_order(n_img, 4)
     assert len({frozenset(p) for p in order}) == len(order) == n_img * (n_img - 1) // 2 == len(matches)
@@ -312,14 +319,15 @@ def test_exhaustive_matcher_several_device_contexts(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("async_write", [False, True])
+@pytest.mark.parametrize("async_write", [False, True, "sliced"])
 def test_failed_device_call_leaves_existing_rows_alone(tmp_path, async_write, monkeypatch):
     """Match() used to delete the stale rows of resume-path pairs BEFORE any device work; a device failure
     (reported as an exception, where the reference CHECK-aborts) then committed the deletes and the putative matches
     were gone.  Now the deletes travel with the new rows.  Set-up: a finished database, one two_view_geometries row
     removed (so that pair is on the resume path: its `matches` row would be deleted and rewritten), and a camera
     model id the device rejects -- the run must fail and every row must still be there."""
-    if async_write:
+    extra = [_SLICED[0], _SLICED[1], _SLICED[2], "2"] if async_write == "sliced" else []
+    if async_write is True:
         monkeypatch.setenv("DSM_ASYNC_WRITE_BACK", "1")
     from dagsfm_amd import synthetic
     n_img = 4
@@ -327,7 +335,7 @@ def test_failed_device_call_leaves_existing_rows_alone(tmp_path, async_write, mo
     ims = [scene.image(i) for i in range(n_img)]
     path = str(tmp_path / "database.db")
     dbutil.create(path, [(im[0], im[1]) for im in ims], prior=True)
-    subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5"])
+    subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5"] + extra)
     before = dbutil.read_results(path)
     pid = dbutil.pair_id(1, 2)
     assert len(before[0][pid]) > 15
@@ -336,7 +344,7 @@ def test_failed_device_call_leaves_existing_rows_alone(tmp_path, async_write, mo
     con.execute("UPDATE cameras SET model = 99")
     con.commit()
     con.close()
-    r = subprocess.run([CLI, "--database_path", path, "--random_seed", "5"], capture_output=True, text=True)
+    r = subprocess.run([CLI, "--database_path", path, "--random_seed", "5"] + extra, capture_output=True, text=True)
     assert r.returncode != 0 and "camera model" in (r.stderr + r.stdout)
     after = dbutil.read_results(path)
     assert set(after[0]) == set(before[0]) and all((after[0][k] == before[0][k]).all() for k in before[0])
@@ -346,7 +354,7 @@ def test_failed_device_call_leaves_existing_rows_alone(tmp_path, async_write, mo
     con.execute("UPDATE cameras SET model = 0")
     con.commit()
     con.close()
-    subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5"])
+    subprocess.check_call([CLI, "--database_path", path, "--random_seed", "5"] + extra)
     again = dbutil.read_results(path)
     assert (again[1][pid]["inliers"] == before[1][pid]["inliers"]).all() and again[1][pid]["F"] == before[1][pid]["F"]
 

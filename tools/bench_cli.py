@@ -30,17 +30,19 @@ def main():
     base = os.path.join(d, "base.db")
     dbutil.create(base, [(im[0], im[1]) for im in ims], prior=True)
     n_pairs = a.images * (a.images - 1) // 2
-    for mode in ("blocking", "async", "blocking+bulk_journal", "async+bulk_journal"):
-        path = os.path.join(d, mode.replace("+", "_") + ".db")
+    for mode in ("blocking", "async", "blocking+bulk_journal", "async+bulk_journal", "async+bulk_journal unsliced"):
+        path = os.path.join(d, mode.replace("+", "_").replace(" ", "_") + ".db")
         shutil.copy(base, path)
         env = dict(os.environ)
         env.pop("DSM_ASYNC_WRITE_BACK", None)
         t0 = time.perf_counter()
         subprocess.check_call([CLI, "--database_path", path, "--random_seed", "1", "--ExhaustiveMatching.block_size",
                                str(a.block_size), "--timing", "1", "--SiftMatching.async_write_back", "1" if "async" in mode else "0",
-                               "--SiftMatching.bulk_load_journal", "1" if "bulk" in mode else "0"], env=env, stderr=sys.stdout)
+                               "--SiftMatching.bulk_load_journal", "1" if "bulk" in mode else "0",
+                               # (async: a Match() over more than 1.5 x 32 768 pairs runs in slices, slice k written while k + 1 computes)
+                               "--SiftMatching.async_slice_pairs", "0" if "unsliced" in mode else "-1"], env=env, stderr=sys.stdout)
         dt = time.perf_counter() - t0
-        print("block_size %d  %-22s %d pairs in %.2f s  (%.0f pairs/s incl. process start, image upload and SQLite)" % (a.block_size, mode, n_pairs, dt, n_pairs / dt), flush=True)
+        print("block_size %d  %-31s %d pairs in %.2f s  (%.0f pairs/s incl. process start, image upload and SQLite)" % (a.block_size, mode, n_pairs, dt, n_pairs / dt), flush=True)
     shutil.rmtree(d)
 
 

@@ -24,6 +24,10 @@ def _im(i):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--combos", default="", help='semicolon-separated "KEY=V KEY=V" settings instead of the built-in list')
+    a = ap.parse_args()
     _init()
     with Pool(48, initializer=_init) as pool:
         ims = pool.map(_im, range(500), chunksize=4)
@@ -39,6 +43,8 @@ def main():
               dict(DSM_VERIFY_LANES="2", DSM_VERIFY_LANE_SPLIT="0.6"), dict(DSM_VERIFY_LANES="2", DSM_VERIFY_LANE_SPLIT="0.7"),
               dict(DSM_VERIFY_ITEM_MODE="1"), dict(DSM_VERIFY_ITEM_MODE="0"), dict(DSM_VERIFY_LANES="3", DSM_VERIFY_GRID_DIV="2"),
               dict(DSM_VERIFY_LANES="4", DSM_VERIFY_GRID_DIV="4", DSM_LO_TAIL="512")]
+    if a.combos:
+        combos = [dict()] + [dict(kv.split("=") for kv in c.split()) for c in a.combos.split(";") if c.strip()]
     keys = sorted({k for c in combos for k in c})
     for name, pl in (("1/8 shard", sharding.shard(pairs, 0, 8)), ("whole list", pairs)):
         ctx.match_pairs(pl)
