@@ -119,7 +119,10 @@ bool ExhaustiveFeatureMatcher::Run() {
   // the cache's set-up and the first block's features are SQLite reads: the two run side by side.
   const auto t_setup = std::chrono::steady_clock::now();
   bool setup_ok = false;
-  std::thread setup_thread([this, &setup_ok]() { setup_ok = matcher_.Setup(); });
+  if (!options_.overlap_setup) setup_ok = matcher_.Setup();
+  std::thread setup_thread([this, &setup_ok]() {
+    if (options_.overlap_setup) setup_ok = matcher_.Setup();
+  });
   struct Joiner {
     std::thread* t;
     ~Joiner() {
@@ -529,17 +532,19 @@ extern "C" {
 // Runs ExhaustiveFeatureMatcher over database_path.  Returns 0 on success.
 // gpu_index: SiftMatchingOptions::gpu_index ("-1" or null: all devices); async_write_back: this repository's extension.
 // Nothing here reads the process environment: the CLI parses its own flags (exhaustive_matcher_main.cc).
-// async_slice_pairs: SiftMatchingOptions::async_slice_pairs (< 0: its default).
+// match_slice_pairs: SiftMatchingOptions::match_slice_pairs (< 0: its default).
 int dsm_host_exhaustive_matcher_ex3(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,
                                     double max_ratio, double max_distance, int cross_check, int min_num_inliers,
                                     int guided_matching, int multiple_models, const char* gpu_index, int async_write_back,
-                                    int async_slice_pairs) {
+                                    int match_slice_pairs) {
   const bool print_timing = async_write_back & 2;  // bit 1 of the flag word: print the stage timers
   const bool bulk_load_journal = async_write_back & 4;  // bit 2: SiftMatchingOptions::bulk_load_journal
+  const bool serial_setup = async_write_back & 8;       // bit 3: ExhaustiveMatchingOptions::overlap_setup = false
   async_write_back &= 1;
   try {
     ExhaustiveMatchingOptions eo;
     eo.block_size = block_size;
+    eo.overlap_setup = !serial_setup;
     SiftMatchingOptions mo;
     if (!use_prior_defaults) {
       mo.max_ratio = max_ratio;
@@ -551,7 +556,7 @@ int dsm_host_exhaustive_matcher_ex3(const char* database_path, int block_size, i
     mo.multiple_models = multiple_models != 0;
     mo.async_write_back = async_write_back != 0;  // overlap SQLite with the device
     mo.bulk_load_journal = bulk_load_journal;
-    if (async_slice_pairs >= 0) mo.async_slice_pairs = async_slice_pairs;
+    if (match_slice_pairs >= 0) mo.match_slice_pairs = match_slice_pairs;
     if (gpu_index && *gpu_index) mo.gpu_index = gpu_index;
     mo.random_seed = random_seed;
     ExhaustiveFeatureMatcher m(eo, mo, database_path);
@@ -560,8 +565,8 @@ int dsm_host_exhaustive_matcher_ex3(const char* database_path, int block_size, i
       const SiftFeatureMatcher::Timings t = m.MatcherTimings();
       std::fprintf(stderr, "[dsm_exhaustive_matcher] set-up (device contexts || cache + first block's features) %.3f s;  "
                            "pairs %llu  run %.3f s  =  features from database.db -> device %.3f s  +  device (match + verify + fetch) "
-                           "%.3f s (fetch %.3f)  +  SQLite write-back %.3f s%s  +  other %.3f s\n",
-                   m.setup_seconds, static_cast<unsigned long long>(t.pairs), m.run_seconds, t.resident_s, t.device_s, t.fetch_s, t.write_s,
+                           "%.3f s (match %.3f, verify %.3f, fetch %.3f)  +  SQLite write-back %.3f s%s  +  other %.3f s\n",
+                   m.setup_seconds, static_cast<unsigned long long>(t.pairs), m.run_seconds, t.resident_s, t.device_s, t.match_s, t.verify_s, t.fetch_s, t.write_s,
                    mo.async_write_back ? " (on the write-back thread: overlaps the device time)" : "",
                    m.run_seconds - t.resident_s - t.device_s - (mo.async_write_back ? 0.0 : t.write_s));
     }

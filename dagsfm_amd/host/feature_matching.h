@@ -33,6 +33,9 @@ namespace dagsfm_amd {
 
 struct ExhaustiveMatchingOptions {  // matching.h:52-60
   int block_size = 50;
+  // extension: Run() creates the device contexts on a second thread while this one reads the cache's tables and the first
+  // block's features (false: one after the other, the reference's order)
+  bool overlap_setup = true;
   bool Check() const { return block_size > 1; }
 };
 
@@ -207,7 +210,7 @@ struct NativeTraits {
   }
   static uint32_t RandomSeed(const Options& o) { return o.random_seed; }
   static bool AsyncWriteBack(const Options& o) { return o.async_write_back; }
-  static size_t AsyncSlicePairs(const Options& o) { return o.async_slice_pairs > 0 ? static_cast<size_t>(o.async_slice_pairs) : 0; }
+  static size_t MatchSlicePairs(const Options& o) { return o.match_slice_pairs > 0 ? static_cast<size_t>(o.match_slice_pairs) : 0; }
 };
 
 // SiftFeatureMatcher of this repository's host side: Setup() / Match() / Flush() as documented in

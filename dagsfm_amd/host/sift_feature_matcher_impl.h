@@ -14,7 +14,7 @@
 //              ToDsmCamera(camera, &out); CameraIdOf(image); KeypointData(kps, &n, &stride_in_floats);
 //              DescriptorData(desc, &rows, &cols); AppendFlat(matches, &flat); MakeMatches(flat, n);
 //              MakeTwoViewGeometry(record or nullptr, inliers, n); RandomSeed(options); AsyncWriteBack(options);
-//              AsyncSlicePairs(options) (only with kAsyncWriteBack)
+//              MatchSlicePairs(options) (only with kAsyncWriteBack: this repository's Options)
 //
 // feature_matching.h instantiates it with this repository's own types (NativeTraits); colmap_traits.h with the
 // reference's (compile-checked against tests/colmap_stub, which carries the reference's exact signatures).
@@ -140,6 +140,7 @@ class SiftFeatureMatcherT {
     double resident_s, device_s, write_s;
     uint64_t pairs;
     double fetch_s;  // the part of device_s that copies the results to the host (the slowest device's, per call)
+    double match_s, verify_s;  // likewise: dsm_match_pairs / dsm_set_matches, dsm_verify_pairs (+ guided matching)
   };
   Timings GetTimings() const { return timings_; }
   const std::string& LastError() const { return last_error_; }
@@ -212,7 +213,7 @@ class SiftFeatureMatcherT {
     RawU32Buffer m, im;
     std::vector<dsm_two_view_geometry> tv;
     std::string error;
-    double fetch_s = 0.0;
+    double fetch_s = 0.0, match_s = 0.0, verify_s = 0.0;
   };
 
   void RunShare(dsm_ctx* ctx, const PairList& prs, const std::vector<typename Traits::FeatureMatches>* given,
@@ -227,6 +228,7 @@ class SiftFeatureMatcherT {
       seeds[i] = dsm_pair_seed(pr.first, pr.second, Traits::RandomSeed(options_));
     }
     int rc;
+    const Clock::time_point t_match = Clock::now();
     if (given) {
       std::vector<uint64_t> off(np + 1, 0);
       std::vector<uint32_t> flat;
@@ -239,6 +241,8 @@ class SiftFeatureMatcherT {
     } else {
       rc = dsm_match_pairs(ctx, np, idx.data(), &mo);
     }
+    sh->match_s = Seconds(t_match);
+    const Clock::time_point t_verify = Clock::now();
     // guided_matching (matching.cc:647-667): verifier -> guided matcher -> output; the post-filter then sees the guided counts
     if (rc == DSM_OK) rc = dsm_verify_pairs(ctx, &to, seeds.data(), 0, options_.guided_matching ? 0 : 1);
     if (rc == DSM_OK && options_.guided_matching) rc = dsm_guided_match_pairs(ctx, &mo, &to, 1);
@@ -246,6 +250,7 @@ class SiftFeatureMatcherT {
       sh->error = std::string("device matching failed: ") + dsm_last_error(ctx);
       return;
     }
+    sh->verify_s = Seconds(t_verify);
     const Clock::time_point t_fetch = Clock::now();
     sh->moff.assign(np + 1, 0);
     sh->ioff.assign(np + 1, 0);
@@ -261,17 +266,20 @@ class SiftFeatureMatcherT {
     sh->fetch_s = Seconds(t_fetch);
   }
 
-  // With the asynchronous write-back a long list goes to the devices slice by slice: the rows of slice k are written
-  // (one transaction of the writer thread per slice) while slice k + 1 is on the devices -- one Match() over a block of
-  // 500 images (124 750 pairs) then overlaps its own write-back instead of only the next block's.  Per-pair seeds and
-  // the matching depend on the pair alone, so the rows are those of the unsliced call.
-  size_t AsyncSlicePairs(std::true_type) const { return Traits::AsyncWriteBack(options_) ? Traits::AsyncSlicePairs(options_) : 0; }
-  size_t AsyncSlicePairs(std::false_type) const { return 0; }
+  // A long list goes to the devices slice by slice (SiftMatchingOptions::match_slice_pairs).  The device scratch of a call is
+  // sized by its pair list -- 38 GiB for 124 750 pairs -- and the FIRST call of a process has to allocate it: 0.1 - 1.2 s,
+  // erratic, measured through the CLI's stage timers; a slice of 32 768 pairs needs a quarter of it and every later slice
+  // re-uses it.  With the asynchronous write-back the rows of slice k are written (one transaction of the writer thread per
+  // slice) while slice k + 1 is on the devices, so one Match() over a block of 500 images overlaps its own write-back instead
+  // of only the next block's; without it they are written by the caller between the slices.  Per-pair seeds and the matching
+  // depend on the pair alone, so the rows are those of the unsliced call.
+  size_t MatchSlicePairs(std::true_type) const { return Traits::MatchSlicePairs(options_); }
+  size_t MatchSlicePairs(std::false_type) const { return 32768; }  // (the reference's Options: the default)
 
   void Run(const PairList& prs, const std::vector<typename Traits::FeatureMatches>* given, const std::vector<char>& stale_inliers,
            const dsm_match_options& mo, const dsm_two_view_options& to) {
-    const size_t slice = AsyncSlicePairs(std::integral_constant<bool, Traits::kAsyncWriteBack>());
-    if (slice == 0 || prs.size() <= slice + slice / 2) {  // (no slice shorter than half the nominal length)
+    const size_t slice = MatchSlicePairs(std::integral_constant<bool, Traits::kAsyncWriteBack>());
+    if (slice == 0 || prs.size() <= slice + slice / 2) {  // (no slice shorter than half the nominal length; 0: never sliced)
       RunSlice(prs, given, stale_inliers, mo, to);
       return;
     }
@@ -322,9 +330,15 @@ class SiftFeatureMatcherT {
     }
     timings_.device_s += Seconds(t_device);
     timings_.pairs += np;
-    double fetch_s = 0.0;
-    for (const Share& sh : shares) fetch_s = std::max(fetch_s, sh.fetch_s);
+    double fetch_s = 0.0, match_s = 0.0, verify_s = 0.0;
+    for (const Share& sh : shares) {
+      fetch_s = std::max(fetch_s, sh.fetch_s);
+      match_s = std::max(match_s, sh.match_s);
+      verify_s = std::max(verify_s, sh.verify_s);
+    }
     timings_.fetch_s += fetch_s;
+    timings_.match_s += match_s;
+    timings_.verify_s += verify_s;
     for (const Share& sh : shares)
       if (!sh.error.empty()) throw std::runtime_error(sh.error);
     // merge the shares in list order (one device: its buffers ARE the result, nothing is copied)

@@ -86,9 +86,10 @@ struct SiftMatchingOptions {  // feature/sift.h:116-165, same names and defaults
   // and the rows are written by a background thread, overlapping SQLite with the next block's device work; the
   // writer owns the transaction, so the caller must not hold one; Flush() / the destructor waits for it.
   bool async_write_back = false;
-  // extension, with async_write_back: a Match() over more pairs than 1.5 x this goes to the devices in slices of about
-  // this many pairs, and slice k's rows are written while slice k + 1 is on the devices (0: never sliced)
-  int async_slice_pairs = 32768;
+  // extension: a Match() over more pairs than 1.5 x this goes to the devices in slices of about this many pairs (0: never
+  // sliced) -- bounded device scratch (the first call of a process allocates it), and with async_write_back slice k's rows are
+  // written while slice k + 1 is on the devices
+  int match_slice_pairs = 32768;
   // extension: Database::SetBulkLoadJournal(true) for the run (ExhaustiveFeatureMatcher::Run restores WAL at its end)
   bool bulk_load_journal = false;
   // not in the reference: seed of the per-pair PRNG schedule (the reference seeds from the clock)

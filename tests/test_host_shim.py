@@ -103,9 +103,10 @@ def test_database_round_trip_and_dagsfm_columns(tmp_path):
     con.close()
 
 
-# "sliced": the asynchronous write-back with a Match() call cut into slices of a few pairs (async_slice_pairs; 32 768 by default,
-# which no test list reaches) -- slice k is written while slice k + 1 is on the device
-_SLICED = ["--SiftMatching.async_write_back", "1", "--SiftMatching.async_slice_pairs", "4"]
+# "sliced": a Match() call cut into slices of a few pairs (match_slice_pairs; 32 768 by default, which no test list reaches), here
+# with the asynchronous write-back -- slice k is written while slice k + 1 is on the device; test_bulk_load_journal_... slices a
+# blocking run
+_SLICED = ["--SiftMatching.async_write_back", "1", "--SiftMatching.match_slice_pairs", "4"]
 
 
 @pytest.mark.gpu
@@ -419,7 +420,8 @@ def test_bulk_load_journal_writes_the_same_rows_and_restores_wal(tmp_path):
     scene = synthetic.Scene(n_img, 512, seed=36, n_pool=1400)
     ims = [scene.image(i) for i in range(n_img)]
     res = []
-    for k, flags in enumerate([[], ["--SiftMatching.bulk_load_journal", "1"], ["--SiftMatching.bulk_load_journal", "1", "--SiftMatching.async_write_back", "1"]]):
+    for k, flags in enumerate([[], ["--SiftMatching.bulk_load_journal", "1"], ["--SiftMatching.bulk_load_journal", "1", "--SiftMatching.async_write_back", "1"],
+                               ["--SiftMatching.match_slice_pairs", "2"]]):  # (the last: a blocking run whose Match() calls go to the device in slices)
         path = str(tmp_path / ("database%d.db" % k))
         dbutil.create(path, [(im[0], im[1]) for im in ims], prior=True)
         r = subprocess.run([CLI, "--database_path", path, "--ExhaustiveMatching.block_size", "3", "--random_seed", "4", "--timing", "1"] + flags,

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--images", type=int, default=400)
     ap.add_argument("--feats", type=int, default=1024)
     ap.add_argument("--block_size", type=int, default=50, help="ExhaustiveMatching.block_size (reference default 50)")
+    ap.add_argument("--modes", default="blocking,async,blocking+bulk_journal,async+bulk_journal,async+bulk_journal unsliced,async+bulk_journal serial_setup",
+                    help="comma-separated; words: async, bulk_journal, unsliced (match_slice_pairs 0), serial_setup (overlap_setup 0)")
     a = ap.parse_args()
     scene = synthetic.Scene(a.images, a.feats, seed=1)
     ims = [scene.image(i) for i in range(a.images)]
@@ -30,7 +32,7 @@ def main():
     base = os.path.join(d, "base.db")
     dbutil.create(base, [(im[0], im[1]) for im in ims], prior=True)
     n_pairs = a.images * (a.images - 1) // 2
-    for mode in ("blocking", "async", "blocking+bulk_journal", "async+bulk_journal", "async+bulk_journal unsliced"):
+    for mode in a.modes.split(","):
         path = os.path.join(d, mode.replace("+", "_").replace(" ", "_") + ".db")
         shutil.copy(base, path)
         env = dict(os.environ)
@@ -40,9 +42,10 @@ def main():
                                str(a.block_size), "--timing", "1", "--SiftMatching.async_write_back", "1" if "async" in mode else "0",
                                "--SiftMatching.bulk_load_journal", "1" if "bulk" in mode else "0",
                                # (async: a Match() over more than 1.5 x 32 768 pairs runs in slices, slice k written while k + 1 computes)
-                               "--SiftMatching.async_slice_pairs", "0" if "unsliced" in mode else "-1"], env=env, stderr=sys.stdout)
+                               "--SiftMatching.match_slice_pairs", "0" if "unsliced" in mode else "-1",
+                               "--ExhaustiveMatching.overlap_setup", "0" if "serial_setup" in mode else "1"], env=env, stderr=sys.stdout)
         dt = time.perf_counter() - t0
-        print("block_size %d  %-31s %d pairs in %.2f s  (%.0f pairs/s incl. process start, image upload and SQLite)" % (a.block_size, mode, n_pairs, dt, n_pairs / dt), flush=True)
+        print("block_size %d  %-35s %d pairs in %.2f s  (%.0f pairs/s incl. process start, image upload and SQLite)" % (a.block_size, mode, n_pairs, dt, n_pairs / dt), flush=True)
     shutil.rmtree(d)
 
 
