@@ -181,7 +181,7 @@ int dsm_set_debug_option(dsm_ctx* ctx, const char* key, const char* value) {
       "DSM_MATCH_CHUNK_ROWS", "DSM_K1_DOT4", "DSM_VERIFY_DEBUG", "DSM_SAMPLER_SERIAL", "DSM_LO_PREPARE_WAVE", "DSM_LO_JACOBI_GROUPS",
       "DSM_ROOTS_LDS", "DSM_FINAL_WAVES", "DSM_VERIFY_LEGACY", "DSM_VERIFY_LANES", "DSM_VERIFY_FIXED_BATCH", "DSM_VERIFY_LANE_SPLIT",
       "DSM_VERIFY_CHUNK_PAIRS", "DSM_VERIFY_GRID_DIV", "DSM_VERIFY_INLINE_LO", "DSM_LO_TAIL", "DSM_LO_TAIL_MODE", "DSM_VERIFY_ITEM_MODE",
-      "DSM_DEBUG_SAMPLER_MODE", "DSM_VOCAB_ASSIGN_VALU", "DSM_VERIFY_HOST_LOOP", "DSM_SCORE_PREFILTER"};
+      "DSM_DEBUG_SAMPLER_MODE", "DSM_VOCAB_ASSIGN_VALU", "DSM_VERIFY_HOST_LOOP", "DSM_SCORE_PREFILTER", "DSM_VERIFY_REPLAY_GRID"};
   if (!ctx || !key) return DSM_ERR_INVALID_ARGUMENT;
   bool known = false;
   for (const char* k : kKnown) known = known || strcmp(k, key) == 0;
@@ -698,6 +698,7 @@ struct VerifyPlan {
   bool inline_lo = false;
   uint32_t lo_tail = 0;  // queue length at and below which the batched schedule finishes a round inline
   uint32_t grid_div = 1;
+  uint32_t replay_grid_mul = 1;
   bool tail_items = true;   // the tail of a round (<= lo_tail pairs queued) as an item pass; false: the inline tail of round 2
   bool item_mode = false;   // item passes from the start of every round (short pair lists)
 };
@@ -741,6 +742,9 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
     // lanes are many (DSM_VERIFY_GRID_DIV, experiment: a lane's persistent grid must not starve the short launches of the others)
     const uint32_t nb_light = std::min<uint32_t>(vp.n_chunk, std::max<uint32_t>(64u, (uint32_t)plan.dev_cus * 32u / plan.grid_div));
     const uint32_t nb_heavy = std::min<uint32_t>(vp.n_chunk, std::max<uint32_t>(64u, (uint32_t)plan.dev_cus * 16u / plan.grid_div));
+    // the replay scans are latency-bound and light (four waves per SIMD fit): their grid may be larger than the heavy kernels'
+    // (a lane's scratch holds dev_cus * 16 workgroups)
+    const uint32_t nb_replay = std::min<uint32_t>(vp.n_chunk, std::min<uint32_t>((uint32_t)plan.dev_cus * 16u, std::max<uint32_t>(64u, (uint32_t)plan.dev_cus * 16u * plan.replay_grid_mul / plan.grid_div)));
     vp.batch = 0;
     launch_vp_prep(vp, nb_light, st);
     LANECHK(L, hipGetLastError());
@@ -826,7 +830,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
             LANECHK(L, hipMemsetAsync(actr + 64, 0, 36, st));
             vp.lo_queue = queues + (size_t)cur * chunk;
             vp.lo_count = cnt_dev;
-            launch_vp_replay_lo(vp, f, std::min<uint32_t>(nb_heavy, vp.n_work), mode, st);
+            launch_vp_replay_lo(vp, f, std::min<uint32_t>(nb_replay, vp.n_work), mode, st);
             LANECHK(L, hipGetLastError());
             LANECHK(L, hipMemcpyAsync(host_ctr, actr, 128, hipMemcpyDeviceToHost, st));
             LANECHK(L, hipStreamSynchronize(st));
@@ -1078,6 +1082,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     // whole-chip grids, the whole list 306.0 vs 297.8.
     plan.grid_div = n_pairs <= 40000u ? 1u : n_lanes;
     if (const char* e = ctx->dbg("DSM_VERIFY_GRID_DIV")) plan.grid_div = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = ctx->dbg("DSM_VERIFY_REPLAY_GRID")) plan.replay_grid_mul = (uint32_t)std::max(1, atoi(e));
     // Local optimisation: batched kernels (k_replay_lo + k_lo_*) or inline in the replay (k_replay).  The batched form
     // wins on throughput (config 2, 124 750 pairs: 416 vs 702 ms) but every LO iteration costs a kernel round trip; it
     // hands the last <= lo_tail queued pairs of a round (F, H) to an inline finish, which keeps it ahead or level down

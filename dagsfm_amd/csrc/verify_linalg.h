@@ -419,7 +419,10 @@ DSM_DEV void dsm_make_jacobi(double x, double y, double z, double* c, double* s)
       t = 1.0 / (tau - w);
     const double sign_t = t > 0.0 ? 1.0 : -1.0;
     const double n = 1.0 / sqrt(t * t + 1.0);
-    *s = -sign_t * (y / fabs(y)) * fabs(t) * n;
+    // y / |y| (Eigen's makeJacobi) is exactly +-1 for a finite y (never zero here: deno >= DBL_MIN): the sign, without the
+    // division sequence; an infinite or NaN y takes the division and its NaN
+    const double y_sign = fabs(y) <= DBL_MAX ? copysign(1.0, y) : y / fabs(y);
+    *s = -sign_t * y_sign * fabs(t) * n;
     *c = n;
   }
 }
@@ -436,8 +439,14 @@ DSM_DEV void dsm_jacobi_2x2(double m00, double m01, double m10, double m11, doub
   } else {
     const double u = t / d;
     const double tmp = sqrt(1.0 + u * u);
-    r1s = 1.0 / tmp;
-    r1c = u / tmp;
+    const SharedDivisor sd = shared_divisor(tmp);  // the two quotients by tmp (see the top of this file)
+    if (div_shared_group_ok(sd, fabs(u))) {
+      r1s = div_shared_fast(1.0, sd);
+      r1c = div_shared_fast(u, sd);
+    } else {
+      r1s = 1.0 / tmp;
+      r1c = u / tmp;
+    }
   }
   const double a0 = r1c * m00 + r1s * m10, a1 = r1c * m01 + r1s * m11;
   const double b1 = -r1s * m01 + r1c * m11;
