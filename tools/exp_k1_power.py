@@ -18,6 +18,13 @@ sets = {
     "uniform random u8": lambda i: rng.integers(0, 256, (n_feat, 128), dtype=np.uint8),
     "all 128 (s8 operand 0)": lambda i: np.full((n_feat, 128), 128, dtype=np.uint8),
     "all 0 (s8 operand -128)": lambda i: np.zeros((n_feat, 128), dtype=np.uint8),
+    # the same SIFT-like bytes (all below 128 in this generator) seen by the multipliers as plain positive int8 operands instead of
+    # as value - 128: does the ENCODING of small magnitudes matter, or only how much the low bits toggle?
+    "synthetic SIFT + 128 (operand = the byte itself)": lambda i: (scene.image(i)[0].astype(np.int32) + 128).clip(0, 255).astype(np.uint8),
+    "uniform 0..127 (operands -128..-1)": lambda i: rng.integers(0, 128, (n_feat, 128), dtype=np.uint8),
+    "uniform 128..255 (operands 0..127)": lambda i: rng.integers(128, 256, (n_feat, 128), dtype=np.uint8),
+    "uniform 0..15 (operands -128..-113)": lambda i: rng.integers(0, 16, (n_feat, 128), dtype=np.uint8),
+    "uniform 128..143 (operands 0..15)": lambda i: rng.integers(128, 144, (n_feat, 128), dtype=np.uint8),
 }
 kp = np.zeros((n_feat, 2), dtype=np.float32)
 cams = [capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, 1) for _ in range(n_img)]
@@ -30,5 +37,5 @@ for name, gen in sets.items():
     ms, n = ctx.match_kernel_time()   # pass-1 launches of the last call
     ms /= max(1, n)
     ops = 2.0 * 128 * n_feat * n_feat * len(pairs)
-    print("%-30s pass 1 %.2f ms  %.2f POP/s  (%.3f of 5.03 POP/s)" % (name, ms, ops / ms / 1e12, ops / ms / 1e12 / 5.033), flush=True)
+    print("%-50s pass 1 %.2f ms  %.2f POP/s  (%.3f of 5.03 POP/s)" % (name, ms, ops / ms / 1e12, ops / ms / 1e12 / 5.033), flush=True)
     del ctx

@@ -18,6 +18,12 @@ rm -rf $out/prof1
 timeout 900 python tools/collect_pmc.py --util --out $out/k1_pmc.json --steps 1 --warmup 0 --cpu-seconds 0 --no-second-regime > $out/k1_pmc_stdout.json 2> $out/k1_pmc.err; tail -c 300 $out/k1_pmc.err
 DSM_VERIFY_LANES=1 timeout 900 python tools/collect_pmc.py --verify --out $out/verify_pmc.json --steps 1 --warmup 0 --cpu-seconds 0 --no-second-regime > $out/verify_pmc_summary.json 2> $out/verify_pmc.err; tail -c 200 $out/verify_pmc.err
 rm -rf gpurun_out/pmc
+timeout 1200 python tools/check_schedules.py --legacy > $out/check_schedules.txt 2>&1
+timeout 600 python tools/check_schedules.py --images 150 --outlier-frac 0.5 --legacy >> $out/check_schedules.txt 2>&1
+timeout 600 python tools/check_schedules.py --images 200 --uncalibrated --legacy >> $out/check_schedules.txt 2>&1; grep -c "identical: True" $out/check_schedules.txt; grep -c "identical: False" $out/check_schedules.txt
+timeout 600 python tools/fuzz_verify.py --batches 4 --pairs 2000 --seed 977 > $out/fuzz_verify.txt 2>&1; tail -1 $out/fuzz_verify.txt
+timeout 900 python tools/bench_cli.py --images 500 --feats 4096 --block_size 500 > $out/bench_cli_500x4096.txt 2>&1
+timeout 900 python tools/bench_cli.py --images 500 --feats 4096 --block_size 125 --modes "blocking,async,blocking+bulk_journal,async+bulk_journal" >> $out/bench_cli_500x4096.txt 2>&1; grep "pairs in" $out/bench_cli_500x4096.txt
 timeout 900 python tools/shard_sweep.py --shards 8 --steps 2 > $out/shard_sweep_config2.txt 2>&1; tail -2 $out/shard_sweep_config2.txt | cut -c1-300
 timeout 300 python bench.py --uncalibrated --steps 3 --warmup 1 --cpu-seconds 0 --no-second-regime > $out/bench_config2_uncalibrated.json 2>/dev/null
 timeout 300 python bench.py --images 50 --feats 1024 --uncalibrated --steps 10 --warmup 2 --cpu-seconds 0 > $out/bench_config1.json 2>/dev/null
