@@ -436,6 +436,7 @@ class SiftFeatureMatcherT {
   // SiftMatchingOptions::async_write_back: hands the batch to the writer thread; false when the option is off
   bool WriteBackAsync(const std::shared_ptr<WriteBatch>& batch, std::true_type) {
     if (!Traits::AsyncWriteBack(options_)) return false;
+    Flush();  // one write-back in flight; rethrows the previous one's error BEFORE this batch is marked (its pairs stay unmarked then)
     {
       // the rows are on their way: later Match() calls must skip these pairs.  Marked only now, with the device
       // results on the host -- a failed device call above leaves the cache saying what the database says.
@@ -443,7 +444,6 @@ class SiftFeatureMatcherT {
       (void)lock;
       for (const auto& pr : batch->prs) cache_->MarkPending(pr.first, pr.second);
     }
-    Flush();  // one write-back in flight
     SiftFeatureMatcherT* const self = this;
     writer_ = std::thread([self, batch]() {
       typename Traits::Cache* const cache = batch->cache;
