@@ -2156,7 +2156,9 @@ __global__ __launch_bounds__(64, 2) void k_solve_e_build(const VerifyParams p) {
 // polynomial are written to it); Al / idx: this lane's column of the lane-interleaved LDS work area.
 // ES: element stride of Ag (see five_point_build_A)
 template <int ES = 1>
-DSM_DEV void e_lu_body(const double* Ag, double* slot, double* Al, unsigned char* idx) {
+DSM_DEV void e_lu_body(double* Ag_rw, double* slot, double* Al, unsigned char* idx) {
+  const double* Ag = Ag_rw;
+  double* Sg = Ag_rw;  // the solution's way out of the registers, see below
 #define LA(i, k) Al[((k) * 10 + (i)) * 64]
   LSEC_BEGIN2();
   for (int r = 0; r < 10; ++r)
@@ -2191,12 +2193,27 @@ DSM_DEV void e_lu_body(const double* Ag, double* slot, double* Al, unsigned char
       for (int i = k + 1; i < 10; ++i) LA(i, j) -= LA(i, k) * akj;
     }
   }
-  double S[60];  // S[(r-4)*10 + c] = solution(r, c), rows 4..9
+  // The rows of a right-hand side follow the pivoting, so its loads can only be issued once the factor is final.  As ONE unrolled
+  // block -- the factor hoisted out of LDS into registers, the 60 solution entries accumulating in registers -- the compiler had no
+  // room to keep loads in flight: the ISA showed each of the hundred loads followed by its own s_waitcnt vmcnt(0), a hundred memory
+  // latencies in a row.  A ROLLED loop over the columns: the next column's ten loads are issued at the top of an iteration and
+  // waited for at the top of the next, and a solved column leaves the registers at once -- into the part of the lane's A that the
+  // elimination no longer needs (rows 0..5 of the left block; the right-hand sides are columns 10..19), from where the solution
+  // comes back in one batch for B(z).
+  int prow[10];
 #pragma unroll
+  for (int i = 0; i < 10; ++i) prow[i] = ((int)idx[i * 64] * 20 + 10) * ES;
+  double bn[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) bn[i] = Ag[prow[i]];
+#pragma unroll 1
   for (int j = 0; j < 10; ++j) {
     double b[10];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) b[i] = Ag[((int)idx[i * 64] * 20 + 10 + j) * ES];
+    for (int i = 0; i < 10; ++i) b[i] = bn[i];
+    const int jn = j < 9 ? j + 1 : 9;  // (the last iteration re-reads its own column: no branch around the loads)
+#pragma unroll
+    for (int i = 0; i < 10; ++i) bn[i] = Ag[prow[i] + jn * ES];
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
       double s = b[i];
@@ -2212,7 +2229,13 @@ DSM_DEV void e_lu_body(const double* Ag, double* slot, double* Al, unsigned char
       b[i] = s / LA(i, i);
     }
 #pragma unroll
-    for (int i = 4; i < 10; ++i) S[(i - 4) * 10 + j] = b[i];
+    for (int i = 4; i < 10; ++i) Sg[((i - 4) * 20 + j) * ES] = b[i];
+  }
+  double S[60];  // S[(r-4)*10 + c] = solution(r, c), rows 4..9
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+#pragma unroll
+    for (int c = 0; c < 10; ++c) S[r * 10 + c] = Sg[(r * 20 + c) * ES];
   }
   LSEC_END2(9);
 #undef LA

@@ -1,13 +1,13 @@
 #!/bin/bash
-# round 4, session L: k_solve_e_lu as half-wave workgroups (six waves per CU instead of three), alternated A/B, then the suite
+# round 4, session L: k_solve_e_lu variants (half-wave workgroups; the right-hand sides in a rolled, prefetching column loop), alternated A/B, then the suite
 out=gpurun_out/r4l
 mkdir -p $out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for rep in 1 2; do for v in elu64 elu32; do
+for rep in 1 2; do for v in head elurolled; do
   echo -n "$v: "; DSM_LIB_PATH=$R/ab/lib_$v.so timeout 400 python bench.py --steps 3 --warmup 1 --cpu-seconds 0 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],1), d['kernel_ms_per_step']['k_verify_pairs'], d['extra']['low_inlier_regime']['ms_per_step'])"
-done; done | tee $out/ab_elu.txt
-for v in elu64 elu32; do
+done; done | tee $out/ab_elu_rolled.txt
+for v in head elurolled; do
 (cd /tmp && DSM_LIB_PATH=$R/ab/lib_$v.so DSM_VERIFY_LANES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_$v -o bench -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-second-regime > /dev/null 2> $R/$out/rocprof_$v.err)
 find $out/prof_$v -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats_1lane_$v.csv
 rm -rf $out/prof_$v
