@@ -1735,6 +1735,38 @@ __global__ __launch_bounds__(64) void k_sample(const VerifyParams p) {
 
 // the pair's correspondences are staged in LDS when they fit
 #define VP_LDS_PTS 1536
+// A pair's correspondences into LDS (and / or the largest |coordinate| per column): EIGHT loads of a lane in flight at a time.
+// As a plain loop the compiler emitted load, s_waitcnt vmcnt(0), ds_write per element -- sixteen memory latencies in a row in front
+// of every 64-slot workgroup of a 256-match pair, as long as the scoring loop that follows them.  (max is exact and order-free.)
+template <bool STORE, bool MAXIMA>
+DSM_DEV double stage_points_batched(const double* gpts, int n4, double* spts, int lane) {
+  constexpr int U = 8;
+  double m = 0.0;  // this lane only ever sees column (lane & 3): e = lane + 64 k
+  int e = lane;
+  for (; e + (U - 1) * 64 < n4; e += U * 64) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = gpts[e + u * 64];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (STORE) spts[e + u * 64] = v[u];
+      if (MAXIMA) m = fmax(m, fabs(v[u]));
+    }
+  }
+  if (n4 > 0) {  // the rest: up to U - 1 further elements of this lane, still issued together (addresses clamped, not branched around)
+    double v[U - 1];
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u) v[u] = gpts[e + u * 64 < n4 ? e + u * 64 : n4 - 1];
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u) {
+      if (e + u * 64 < n4) {
+        if (STORE) spts[e + u * 64] = v[u];
+        if (MAXIMA) m = fmax(m, fabs(v[u]));
+      }
+    }
+  }
+  return m;
+}
 // F and H: solver and inlier counting as two kernels.  k_solve keeps the solver's working set (F: the 9 x 7
 // matrix in lane-interleaved LDS; H: ~220 VGPRs) away from the counting loop, which is pure FP64 VALU work
 // with a 9-double model per lane and wants many resident waves; k_score gives every (trial, model) slot its
@@ -1842,7 +1874,7 @@ __global__ __launch_bounds__(64, 8) void k_score(const VerifyParams p) {
   const double* gpts = p.pts_px + 4 * moff;
   const bool in_lds = n <= VP_LDS_PTS;
   if (in_lds) {
-    for (int e = lane; e < 4 * n; e += 64) spts[e] = gpts[e];
+    (void)stage_points_batched<true, false>(gpts, 4 * n, spts, lane);
     __syncthreads();
   }
   const double max_residual = p.opt.max_error * p.opt.max_error;
@@ -1968,12 +2000,7 @@ DSM_DEV void prescore_flags(const double* M, const PreBounds& b, const double* q
 
 // stages the pair's points in LDS (when they fit) and returns max |coordinate| per column (x1, y1, x2, y2) to every lane
 DSM_DEV void stage_points_with_maxima(const double* gpts, int n, bool in_lds, double* spts, int lane, double mx[4]) {
-  double m = 0.0;  // this lane only ever sees column (lane & 3): e = lane + 64 k
-  for (int e = lane; e < 4 * n; e += 64) {
-    const double v = gpts[e];
-    if (in_lds) spts[e] = v;
-    m = fmax(m, fabs(v));
-  }
+  double m = in_lds ? stage_points_batched<true, true>(gpts, 4 * n, spts, lane) : stage_points_batched<false, true>(gpts, 4 * n, spts, lane);
 #pragma unroll
   for (int o = 4; o < 64; o <<= 1) m = fmax(m, __shfl_xor(m, o));
 #pragma unroll
@@ -2054,8 +2081,7 @@ __global__ __launch_bounds__(64, 8) void k_score_needed(const VerifyParams p) {
     const bool in_lds = n <= VP_LDS_PTS;
     uint16_t* list = reinterpret_cast<uint16_t*>(spts + (size_t)(in_lds ? n : 0) * 4);
     __syncthreads();  // the previous pair's readers are done with the LDS
-    if (in_lds)
-      for (int e = lane; e < 4 * n; e += 64) spts[e] = gpts[e];
+    if (in_lds) (void)stage_points_batched<true, false>(gpts, 4 * n, spts, lane);
     int32_t* counts = p.counts + (size_t)pl * p.batch * F::MAXM;
     double* sums = p.sums + (size_t)pl * p.batch * F::MAXM;
     const int n_slots = nb * F::MAXM;
@@ -2356,12 +2382,7 @@ __global__ __launch_bounds__(64, 8) void k_models_score_e(const VerifyParams p) 
   const bool in_lds = n <= VP_LDS_PTS;
   double mx[4];  // max |coordinate| of the pair's points (the bound step's margins, see k_prescore)
   {
-    double mm = 0.0;
-    for (int e = lane; e < 4 * n; e += 64) {
-      const double v = gpts[e];
-      if (in_lds) spts[e] = v;
-      mm = fmax(mm, fabs(v));
-    }
+    double mm = in_lds ? stage_points_batched<true, true>(gpts, 4 * n, spts, lane) : stage_points_batched<false, true>(gpts, 4 * n, spts, lane);
 #pragma unroll
     for (int o = 4; o < 64; o <<= 1) mm = fmax(mm, __shfl_xor(mm, o));
 #pragma unroll
