@@ -8,6 +8,8 @@ produce byte-identical TwoViewGeometry records and inlier matches on the whole w
             the default since round 3 computes the tail's local optimisations as parallel items, k_tail_enum / k_tail_lo)
   final_1wave   k_verify_final compiled for one wave per SIMD (no register spill; DSM_FINAL_WAVES=1)
   no_prefilter  F / H scoring by the plain k_score instead of bound + exact (DSM_SCORE_PREFILTER=0; round 4)
+  e_fused       the essential family's scoring by the wave-per-hypothesis kernel with the bound step fused in (k_models_score_e,
+                DSM_SCORE_PREFILTER=3) instead of a lane per model (k_prescore_e + k_score_needed<E>)
   one_lane  the batched schedule on a single lane (DSM_VERIFY_LANES=1; the default deals the list out to two lanes)
   legacy    one k_ransac kernel per family, lane-0 sampler, per-lane scratch solvers (DSM_VERIFY_LEGACY=1; --legacy)
 This exercises the paths too rare for the oracle-sized tests (a Lemire rejection in the sampler happens for a few
@@ -35,6 +37,8 @@ def run(ctx, opts, schedule):
     os.environ.pop("DSM_SCORE_PREFILTER", None)
     if schedule == "no_prefilter":
         os.environ["DSM_SCORE_PREFILTER"] = "0"
+    if schedule == "e_fused":
+        os.environ["DSM_SCORE_PREFILTER"] = "3"
     os.environ.pop("DSM_FINAL_WAVES", None)
     if schedule == "final_1wave":
         os.environ["DSM_FINAL_WAVES"] = "1"
@@ -71,7 +75,7 @@ def main():
     opts = capi.default_two_view_options()
     r0 = run(ctx, opts, "batched")
     ok = True
-    for name in ["no_prefilter", "one_lane", "no_tail", "tail_inline", "final_1wave", "inline"] + (["legacy"] if a.legacy else []):
+    for name in ["no_prefilter", "e_fused", "one_lane", "no_tail", "tail_inline", "final_1wave", "inline"] + (["legacy"] if a.legacy else []):
         r1 = run(ctx, opts, name)
         same = (r0[0] == r1[0]).all() and (r0[1] == r1[1]).all() and (r0[2] == r1[2]).all()
         # num_trials / num_models are the last 32 bytes of the record
