@@ -2092,8 +2092,8 @@ __global__ __launch_bounds__(64, 8) void k_score_needed(const VerifyParams p) {
       const int slot = base + lane;
       const bool in_range = slot < n_slots;
       int ub = in_range ? counts[slot] : -1;
-      // (E: k_prescore_e writes the slots that hold a model and nothing else -- a hypothesis has 0..10 of its 10 slots filled)
-      if (FAM == FAM_E && in_range && (slot % F::MAXM) >= nmod[slot / F::MAXM]) ub = -1;
+      // (k_prescore_compact writes the slots that hold a model and nothing else)
+      if (F::MAXM > 1 && in_range && (slot % F::MAXM) >= nmod[slot / F::MAXM]) ub = -1;
       const int lb = (in_range && ub >= 0) ? reinterpret_cast<const int32_t*>(sums + slot)[0] : 0;
       int incl = lb;  // inclusive running maximum of the lower bounds along the wave
 #pragma unroll
@@ -2368,24 +2368,27 @@ __global__ __launch_bounds__(64) void k_roots_e_lds(const VerifyParams p) {
   p.nmodels[(size_t)pl * p.batch + t] = e_models_body(slot, code, slot);
 }
 
-// The bound step for the essential family, a lane per MODEL.  A hypothesis has 0..10 models (4.6 on average), so its ten slots are
-// mostly empty: the workgroup takes 64 consecutive entries of the pair's models in COMPACTED order -- the prefix sums of nmodels[]
-// over the round's trials, computed by every workgroup of the pair (at most 512 trials: eight steps) -- and a lane scores its model
-// against all correspondences exactly like k_prescore does for F and H (points broadcast from LDS, 25 VALU per point and model
-// instead of a wave-wide pass with its reductions per model: k_models_score_e, which stays as DSM_SCORE_PREFILTER=3 / =0).
-// Writes the slot's upper bound into counts[] and its lower bound into the low word of sums[]; k_score_needed<FAM_E> follows.
-__global__ __launch_bounds__(64, 8) void k_prescore_e(const VerifyParams p) {
+// The bound step with a lane per MODEL in compacted order.  A five-point hypothesis has 0..10 models (4.6 on average), a seven-point one
+// 1 or 3 (2.46): a lane per (trial, model) SLOT leaves 54 % / 18 % of the lanes without one.  Here a workgroup takes 64 consecutive
+// entries of the pair's models in COMPACTED order -- the prefix sums of nmodels[] over the round's trials, recomputed by every
+// workgroup of the pair (at most 1 024 trials: sixteen shuffle scans) -- and a lane scores its model against all correspondences
+// exactly like k_prescore (points broadcast from LDS).  For E this replaces k_models_score_e, a wave-wide pass with its reductions per
+// model (kept as DSM_SCORE_PREFILTER=3 / =0, where F takes the slot-per-lane k_prescore).  Writes the slot's upper bound into counts[]
+// and its lower bound into the low word of sums[]; k_score_needed follows and reads which slots hold a model from nmodels[].
+template <int FAM>
+__global__ __launch_bounds__(64, 8) void k_prescore_compact(const VerifyParams p) {
+  typedef Fam<FAM> F;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ uint16_t s_map[64];
   double* spts = reinterpret_cast<double*>(smem_raw);  // min(n_max, VP_LDS_PTS) x 4 doubles
   const uint32_t pl = blockIdx.x;
   const uint32_t pi = p.pair0 + pl;
-  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
+  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
   if (!fs->active) return;
   const int lane = threadIdx.x;
   const int nb = (int)fs->nb;
   const int c0 = (int)blockIdx.y * 64;  // first compacted entry of this workgroup
-  if (c0 >= nb * 10) return;
+  if (c0 >= nb * F::MAXM) return;
   const int32_t* nmod = p.nmodels + (size_t)pl * p.batch;
   int run = 0;
   for (int base = 0; base < nb; base += 64) {
@@ -2401,7 +2404,7 @@ __global__ __launch_bounds__(64, 8) void k_prescore_e(const VerifyParams p) {
     if (off < c0 + 64 && off + nm > c0) {
       for (int m = 0; m < nm; ++m) {
         const int c = off + m - c0;
-        if (c >= 0 && c < 64) s_map[c] = (uint16_t)(t * 10 + m);
+        if (c >= 0 && c < 64) s_map[c] = (uint16_t)(t * F::MAXM + m);
       }
     }
     run += __shfl(incl, 63);
@@ -2411,31 +2414,34 @@ __global__ __launch_bounds__(64, 8) void k_prescore_e(const VerifyParams p) {
   if (c0 >= run) return;  // wave-uniform: no model of the pair is left for this workgroup
   const uint64_t moff = p.match_off[pi];
   const int n = (int)(p.match_off[pi + 1] - moff);
-  const double* gpts = p.pts_norm + 4 * moff;
+  const double* gpts = (FAM == FAM_E ? p.pts_norm : p.pts_px) + 4 * moff;
   const bool in_lds = n <= VP_LDS_PTS;
-  const double max_error = (image_to_world_threshold(p.cams[p.pairs[2 * pi]], p.opt.max_error) +
-                            image_to_world_threshold(p.cams[p.pairs[2 * pi + 1]], p.opt.max_error)) / 2;
-  const double T = max_error * max_error;
+  double T = p.opt.max_error * p.opt.max_error;
+  if (FAM == FAM_E) {
+    const double max_error = (image_to_world_threshold(p.cams[p.pairs[2 * pi]], p.opt.max_error) +
+                              image_to_world_threshold(p.cams[p.pairs[2 * pi + 1]], p.opt.max_error)) / 2;
+    T = max_error * max_error;
+  }
   double mx[4];
   stage_points_with_maxima(gpts, n, in_lds, spts, lane, mx);  // (ends with the barrier that also publishes s_map when in_lds)
   if (!in_lds) __syncthreads();
   const bool has_model = c0 + lane < run;
   const int slot = has_model ? (int)s_map[lane] : 0;
-  const double* gm = p.models + (size_t)pl * p.batch * 90 + (size_t)slot * 9;
+  const double* gm = p.models + ((size_t)pl * p.batch * F::MAXM + (size_t)slot) * 9;
   double M[9];
   for (int k = 0; k < 9; ++k) M[k] = has_model ? gm[k] : 0.0;
   if (!has_model) return;
-  const PreBounds b = prescore_bounds<FAM_E>(M, mx, T);
+  const PreBounds b = prescore_bounds<FAM>(M, mx, T);
   int lb = 0, sure_out = 0;
   if (in_lds) {
 #pragma unroll 4
-    for (int i = 0; i < n; ++i) prescore_point<FAM_E>(M, b, spts + (size_t)i * 4, lb, sure_out);
+    for (int i = 0; i < n; ++i) prescore_point<FAM>(M, b, spts + (size_t)i * 4, lb, sure_out);
   } else {
 #pragma unroll 4
-    for (int i = 0; i < n; ++i) prescore_point<FAM_E>(M, b, gpts + (size_t)i * 4, lb, sure_out);
+    for (int i = 0; i < n; ++i) prescore_point<FAM>(M, b, gpts + (size_t)i * 4, lb, sure_out);
   }
-  p.counts[(size_t)pl * p.batch * 10 + slot] = n - sure_out;
-  reinterpret_cast<int32_t*>(p.sums + (size_t)pl * p.batch * 10 + slot)[0] = lb;
+  p.counts[(size_t)pl * p.batch * F::MAXM + slot] = n - sure_out;
+  reinterpret_cast<int32_t*>(p.sums + (size_t)pl * p.batch * F::MAXM + slot)[0] = lb;
 }
 
 // the inlier counts of ALL models of the block's 64 hypotheses (built by k_roots_e) with the lanes spread over the
@@ -3850,12 +3856,12 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
       hipLaunchKernelGGL(k_roots_e_lds, grid, dim3(64), 100 * 64 * sizeof(double), st, p);
     else
       hipLaunchKernelGGL(k_roots_e, grid, dim3(64), 0, st, p);
-    // scoring: a lane per model (k_prescore_e -> k_score_needed<E>), or the wave-per-hypothesis kernel with the bound step fused in
+    // scoring: a lane per model (k_prescore_compact<E> -> k_score_needed<E>), or the wave-per-hypothesis kernel with the bound step fused in
     // (DSM_SCORE_PREFILTER=3; also what =0 runs, without its bound step)
     const size_t smem2e = smem + (size_t)p.batch * 10 * 2;
     const uint32_t nb_needed_e = p.n_chunk < 256u * 32u ? p.n_chunk : 256u * 32u;
     if ((p.score_prefilter & 1) && !(p.score_prefilter & 2) && p.batch * 10 <= 65535 && smem2e <= 64 * 1024) {  // 1, and 5 = check
-      hipLaunchKernelGGL(k_prescore_e, dim3(p.n_chunk, (p.batch * 10 + 63) / 64), dim3(64), smem, st, p);
+      hipLaunchKernelGGL(k_prescore_compact<FAM_E>, dim3(p.n_chunk, (p.batch * 10 + 63) / 64), dim3(64), smem, st, p);
       hipLaunchKernelGGL(k_score_needed<FAM_E>, dim3(nb_needed_e), dim3(64), smem2e, st, p);
     } else if (p.score_prefilter & 4) {
       hipLaunchKernelGGL(k_models_score_e<true>, grid, dim3(64), smem, st, p);
@@ -3870,7 +3876,10 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
     hipLaunchKernelGGL(k_solve<FAM_F>, grid, dim3(64), 0, st, p);
     const size_t smem2 = smem + (size_t)p.batch * 3 * 2;
     if (p.score_prefilter && p.batch * 3 <= 65535 && smem2 <= 64 * 1024) {
-      hipLaunchKernelGGL(k_prescore<FAM_F>, dim3(p.n_chunk, (p.batch * 3 + 63) / 64), dim3(64), smem, st, p);
+      if (p.score_prefilter & 2)  // DSM_SCORE_PREFILTER=3: a lane per slot
+        hipLaunchKernelGGL(k_prescore<FAM_F>, dim3(p.n_chunk, (p.batch * 3 + 63) / 64), dim3(64), smem, st, p);
+      else
+        hipLaunchKernelGGL(k_prescore_compact<FAM_F>, dim3(p.n_chunk, (p.batch * 3 + 63) / 64), dim3(64), smem, st, p);
       hipLaunchKernelGGL(k_score_needed<FAM_F>, dim3(nb_needed), dim3(64), smem2, st, p);
     } else {
       hipLaunchKernelGGL(k_score<FAM_F>, dim3(p.n_chunk, (p.batch * 3 + 63) / 64), dim3(64), smem, st, p);

@@ -9,7 +9,7 @@ produce byte-identical TwoViewGeometry records and inlier matches on the whole w
   final_1wave   k_verify_final compiled for one wave per SIMD (no register spill; DSM_FINAL_WAVES=1)
   no_prefilter  F / H scoring by the plain k_score instead of bound + exact (DSM_SCORE_PREFILTER=0; round 4)
   e_fused       the essential family's scoring by the wave-per-hypothesis kernel with the bound step fused in (k_models_score_e,
-                DSM_SCORE_PREFILTER=3) instead of a lane per model (k_prescore_e + k_score_needed<E>)
+                DSM_SCORE_PREFILTER=3) instead of a lane per model (k_prescore_compact + k_score_needed; with it F takes the slot-per-lane k_prescore)
   one_lane  the batched schedule on a single lane (DSM_VERIFY_LANES=1; the default deals the list out to two lanes)
   legacy    one k_ransac kernel per family, lane-0 sampler, per-lane scratch solvers (DSM_VERIFY_LEGACY=1; --legacy)
 This exercises the paths too rare for the oracle-sized tests (a Lemire rejection in the sampler happens for a few
