@@ -1896,7 +1896,8 @@ __global__ __launch_bounds__(64, 8) void k_score(const VerifyParams p) {
 // non-planar pair that is all but a few dozen of the 1 765 homographies.  So the scoring runs in two steps:
 //   k_prescore    every (trial, model) slot: a LOWER and an UPPER bound of its inlier count from a division-free test in
 //                 fused arithmetic (18 VALU per homography residual instead of 36 + a quarter-rate v_rcp_f64), each point
-//                 classified "surely inlier" / "surely outlier" / "uncertain" with margins derived below;
+//                 classified "surely inlier" / "surely outlier" / "uncertain" with margins derived below (H: a lane per slot;
+//                 E and F, whose samples have 0..10 / 1 or 3 models: k_prescore_compact, a lane per model in compacted order);
 //   k_score_needed  per pair: the running maximum of the LOWER bounds in trial order (starting from the best count of the
 //                 earlier rounds); a slot whose UPPER bound reaches it is scored EXACTLY (exact_support: the reference's own
 //                 operations, count and in-order sum), every other slot is written as support (0, 0) -- fewer inliers than
@@ -1917,8 +1918,8 @@ __global__ __launch_bounds__(64, 8) void k_score(const VerifyParams p) {
 //     (needed: delta >= 2^-14 (1 + 2^-10); margin 4x).
 //   Magnitudes outside [2^-400, 2^300] (or coordinates beyond 2^14, or T outside [2^-6, 2^40]) switch the classification
 //   off for the model: every point uncertain, upper bound n, lower bound 0 -- the slot is then simply scored exactly.
-// DSM_SCORE_PREFILTER=0 (dsm_set_debug_option) runs the plain k_score instead: an independent schedule of the same results
-// (tools/check_schedules.py, tests).
+// DSM_SCORE_PREFILTER=0 (dsm_set_debug_option) runs the plain k_score / k_models_score_e instead, =3 the slot-per-lane k_prescore
+// for F and the fused k_models_score_e for E: independent schedules of the same results (tools/check_schedules.py, tests).
 struct PreBounds {
   double c0, c1;   // H: P_min, unused;  F: D_min, unused   (NaN = classification off)
   double t_lo, t_hi;
