@@ -160,7 +160,7 @@ DEBUG_OPTION_KEYS = ("DSM_MATCH_CHUNK_ROWS", "DSM_K1_DOT4", "DSM_VERIFY_DEBUG", 
                      "DSM_LO_JACOBI_GROUPS", "DSM_ROOTS_LDS", "DSM_FINAL_WAVES", "DSM_VERIFY_LEGACY", "DSM_VERIFY_LANES",
                      "DSM_VERIFY_FIXED_BATCH", "DSM_VERIFY_LANE_SPLIT", "DSM_VERIFY_CHUNK_PAIRS", "DSM_VERIFY_GRID_DIV",
                      "DSM_VERIFY_INLINE_LO", "DSM_LO_TAIL", "DSM_LO_TAIL_MODE", "DSM_VERIFY_ITEM_MODE", "DSM_DEBUG_SAMPLER_MODE",
-                     "DSM_VOCAB_ASSIGN_VALU", "DSM_VERIFY_HOST_LOOP", "DSM_SCORE_PREFILTER", "DSM_VERIFY_REPLAY_GRID")
+                     "DSM_VOCAB_ASSIGN_VALU", "DSM_VERIFY_HOST_LOOP", "DSM_SCORE_PREFILTER", "DSM_VERIFY_REPLAY_GRID", "DSM_ROOTS_REFILL")
 
 
 class Context:

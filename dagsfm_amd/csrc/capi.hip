@@ -181,7 +181,7 @@ int dsm_set_debug_option(dsm_ctx* ctx, const char* key, const char* value) {
       "DSM_MATCH_CHUNK_ROWS", "DSM_K1_DOT4", "DSM_VERIFY_DEBUG", "DSM_SAMPLER_SERIAL", "DSM_LO_PREPARE_WAVE", "DSM_LO_JACOBI_GROUPS",
       "DSM_ROOTS_LDS", "DSM_FINAL_WAVES", "DSM_VERIFY_LEGACY", "DSM_VERIFY_LANES", "DSM_VERIFY_FIXED_BATCH", "DSM_VERIFY_LANE_SPLIT",
       "DSM_VERIFY_CHUNK_PAIRS", "DSM_VERIFY_GRID_DIV", "DSM_VERIFY_INLINE_LO", "DSM_LO_TAIL", "DSM_LO_TAIL_MODE", "DSM_VERIFY_ITEM_MODE",
-      "DSM_DEBUG_SAMPLER_MODE", "DSM_VOCAB_ASSIGN_VALU", "DSM_VERIFY_HOST_LOOP", "DSM_SCORE_PREFILTER", "DSM_VERIFY_REPLAY_GRID"};
+      "DSM_DEBUG_SAMPLER_MODE", "DSM_VOCAB_ASSIGN_VALU", "DSM_VERIFY_HOST_LOOP", "DSM_SCORE_PREFILTER", "DSM_VERIFY_REPLAY_GRID", "DSM_ROOTS_REFILL"};
   if (!ctx || !key) return DSM_ERR_INVALID_ARGUMENT;
   bool known = false;
   for (const char* k : kKnown) known = known || strcmp(k, key) == 0;
@@ -960,6 +960,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.lo_reg_prepare = ctx->dbg("DSM_LO_PREPARE_WAVE") ? 0 : 1;
   vp.dbg_jacobi_groups = ctx->dbg("DSM_LO_JACOBI_GROUPS") ? 1 : 0;  // the 8-lane-group Jacobi kernel for every problem (round-2 form)
   vp.dbg_roots_lds = ctx->dbg("DSM_ROOTS_LDS") ? 1 : 0;              // k_roots_e_lds instead of the register form
+  vp.dbg_roots_refill = ctx->dbg("DSM_ROOTS_REFILL") ? atoi(ctx->dbg("DSM_ROOTS_REFILL")) : 0;  // experimental: k_roots_e_init / _iter / _finish
   vp.dbg_final_waves = ctx->dbg("DSM_FINAL_WAVES") ? atoi(ctx->dbg("DSM_FINAL_WAVES")) : 0;
   vp.score_prefilter = ctx->dbg("DSM_SCORE_PREFILTER") ? atoi(ctx->dbg("DSM_SCORE_PREFILTER")) : 1;
   // "check": every slot is scored exactly AND held against its bounds (counters [14] violations, [15] slots the filter

@@ -8,6 +8,7 @@ produce byte-identical TwoViewGeometry records and inlier matches on the whole w
             the default since round 3 computes the tail's local optimisations as parallel items, k_tail_enum / k_tail_lo)
   final_1wave   k_verify_final compiled for one wave per SIMD (no register spill; DSM_FINAL_WAVES=1)
   no_prefilter  F / H scoring by the plain k_score instead of bound + exact (DSM_SCORE_PREFILTER=0; round 4)
+  roots_refill  (--experimental) the 5-point roots by k_roots_e_init / _iter / _finish: lane-level refill (DSM_ROOTS_REFILL=1)
   e_fused       the essential family's scoring by the wave-per-hypothesis kernel with the bound step fused in (k_models_score_e,
                 DSM_SCORE_PREFILTER=3) instead of a lane per model (k_prescore_compact + k_score_needed; with it F takes the slot-per-lane k_prescore)
   one_lane  the batched schedule on a single lane (DSM_VERIFY_LANES=1; the default deals the list out to two lanes)
@@ -39,6 +40,9 @@ def run(ctx, opts, schedule):
         os.environ["DSM_SCORE_PREFILTER"] = "0"
     if schedule == "e_fused":
         os.environ["DSM_SCORE_PREFILTER"] = "3"
+    os.environ.pop("DSM_ROOTS_REFILL", None)
+    if schedule == "roots_refill":
+        os.environ["DSM_ROOTS_REFILL"] = "1"
     os.environ.pop("DSM_FINAL_WAVES", None)
     if schedule == "final_1wave":
         os.environ["DSM_FINAL_WAVES"] = "1"
@@ -62,6 +66,8 @@ def main():
     ap.add_argument("--images", type=int, default=500)
     ap.add_argument("--feats", type=int, default=4096)
     ap.add_argument("--legacy", action="store_true", help="also run the (slow) single-kernel-per-family schedule")
+    ap.add_argument("--experimental", action="store_true",
+                    help="also run the schedules that have not been adopted: roots_refill (DSM_ROOTS_REFILL=1: the 5-point roots with lane-level refill)")
     ap.add_argument("--outlier-frac", type=float, default=0.2, help="0.5: the 0.25-inlier-ratio regime (thousands of trials per pair)")
     ap.add_argument("--uncalibrated", action="store_true", help="cameras without a focal-length prior: the F + H path of the decision tree")
     a = ap.parse_args()
@@ -75,7 +81,7 @@ def main():
     opts = capi.default_two_view_options()
     r0 = run(ctx, opts, "batched")
     ok = True
-    for name in ["no_prefilter", "e_fused", "one_lane", "no_tail", "tail_inline", "final_1wave", "inline"] + (["legacy"] if a.legacy else []):
+    for name in (["roots_refill"] if a.experimental else []) + ["no_prefilter", "e_fused", "one_lane", "no_tail", "tail_inline", "final_1wave", "inline"] + (["legacy"] if a.legacy else []):
         r1 = run(ctx, opts, name)
         same = (r0[0] == r1[0]).all() and (r0[1] == r1[1]).all() and (r0[2] == r1[2]).all()
         # num_trials / num_models are the last 32 bytes of the record
