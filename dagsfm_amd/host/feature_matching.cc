@@ -121,7 +121,11 @@ bool ExhaustiveFeatureMatcher::Run() {
   bool setup_ok = false;
   if (!options_.overlap_setup) setup_ok = matcher_.Setup();
   std::thread setup_thread([this, &setup_ok]() {
-    if (options_.overlap_setup) setup_ok = matcher_.Setup();
+    try {  // (an exception must not leave a thread: Setup() reports through its return value, this is for std::bad_alloc and the like)
+      if (options_.overlap_setup) setup_ok = matcher_.Setup();
+    } catch (...) {
+      setup_ok = false;
+    }
   });
   struct Joiner {
     std::thread* t;
