@@ -39,6 +39,84 @@ GUIDE_FP64_VECTOR = 78.6e12
 GUIDE_HBM = 8.0e12
 
 
+LINE_LIMIT = 4096          # the driver reads the last 8 KB of stdout; the line must fit with room to spare
+REQUIRED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def _round_floats(x, sig=6):
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x))
+    if isinstance(x, dict):
+        return {k: _round_floats(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_round_floats(v, sig) for v in x]
+    return x
+
+
+def _drop_notes(x):
+    """The prose (what each figure means) lives in README.md "Measurement" and in the --dump-line file, not on stdout."""
+    if isinstance(x, dict):
+        return {k: _drop_notes(v) for k, v in x.items()
+                if not (k == "note" or k.endswith("_note") or k in ("peak_source", "sample_note"))}
+    return x
+
+
+def format_line(out, dump_path="", limit=LINE_LIMIT):
+    """The ONE stdout line: `out` without its prose and with floats at 6 significant digits.  The long form goes to
+    `dump_path`.  Fails loudly instead of printing a line the driver's 8 KB tail would cut."""
+    if dump_path:
+        with open(dump_path, "w") as f:
+            json.dump(out, f, indent=1)
+            f.write("\n")
+    for k in REQUIRED_KEYS:
+        if k not in out:
+            raise SystemExit("bench.py: result lacks the contract key %r" % k)
+    if "workload" not in out["config"]:
+        raise SystemExit("bench.py: config.workload missing")
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        if k not in out["roofline"]:
+            raise SystemExit("bench.py: roofline.%s missing" % k)
+    line = json.dumps(_round_floats(_drop_notes(out)), separators=(",", ":"))
+    if len(line) >= limit:
+        raise SystemExit("bench.py: the result line is %d bytes (limit %d): move detail to --dump-line" % (len(line), limit))
+    return line
+
+
+def profile_figures(root, images, feats, n_pairs, verify_too):
+    """Figures READ FROM COMMITTED FILES under profiles/ (counter collections of an earlier run of the same workload,
+    tools/collect_pmc.py) -- never measured in this run, so they sit under one `from_profiles` key with their file names."""
+    import glob
+    fp = {}
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "r0[3-9]_k1_pmc*.json"))):
+        try:
+            pmc = json.load(open(f))
+        except Exception:
+            continue
+        if pmc.get("images") == images and pmc.get("feats") == feats and pmc.get("pairs") == n_pairs:
+            mi = pmc.get("SQ_INSTS_VALU_MFMA_I8", {})
+            insts = None
+            if "pass1" in mi:
+                insts = mi["pass1"]["mean_per_dispatch"] + mi.get("pass2", {}).get("mean_per_dispatch", 0.0)
+            fp["k1"] = {"file": "profiles/" + os.path.basename(f), "hbm_bytes_per_launch": pmc.get("k1_traffic_bytes_per_launch"),
+                        "mfma_i8_insts_per_launch": insts}
+    if verify_too:
+        for f in sorted(glob.glob(os.path.join(root, "profiles", "r0[4-9]_verify_pmc.json"))):
+            try:
+                vp = json.load(open(f))
+            except Exception:
+                continue
+            if vp.get("images") == images and vp.get("feats") == feats and vp.get("pairs") == n_pairs:
+                sm = vp.get("summary", {})
+                ks = sorted(sm.get("kernels", {}).items(), key=lambda kv: -kv[1].get("ms_per_step", 0.0))[:5]
+                fp["verify"] = {"file": "profiles/" + os.path.basename(f),
+                                "all_kernels_ms_per_step": sm.get("all_kernels_ms_per_step"),
+                                "executed_fp64_tflops_over_all": sm.get("executed_fp64_tflops_over_all"),
+                                "executed_frac_over_all": sm.get("executed_frac_over_all"),
+                                "top5_ms_execfrac_laneutil": {k: [v.get("ms_per_step"), v.get("executed_frac"), v.get("lane_util")] for k, v in ks}}
+    return fp
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +151,7 @@ def parse_args():
                          "line then carries the measured exchange time")
     ap.add_argument("--no-second-regime", action="store_true",
                     help="skip the low-inlier-ratio side measurement (extra.low_inlier_regime) after the timed region")
+    ap.add_argument("--dump-line", default="", help="rank 0 also writes the long form of the result (with the prose notes) to this file")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="debug: all ranks on device 0 over gloo (exercises the multi-rank path on a 1-GPU box)")
     return ap.parse_args()
@@ -140,9 +219,10 @@ def cpu_baseline(orc, label, build, scene_images, pairs, budget_s, verify, cams,
     dt = time.perf_counter() - t0
     return {"value": state["pairs"] / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "build": build,
             "hypotheses_per_s": state["models"] / dt,
-            "sample": "%d of %d pairs (%s) in %.1f s on %d threads (host has %d usable cores); oracle/ = the reference CPU "
-                      "path restated (MatchSiftFeaturesCPU + TwoViewGeometry::Estimate), %s"
-                      % (state["pairs"], len(pairs), "match only" if not verify else "match + verify", dt, cores, host_cores(), label)}
+            "sample": "%d of %d pairs, evenly spaced (%s), %.1f s on %d threads; oracle/ %s"
+                      % (state["pairs"], len(pairs), "match only" if not verify else "match + verify", dt, cores, build),
+            "sample_note": "host has %d usable cores; oracle/ = the reference CPU path restated (MatchSiftFeaturesCPU + "
+                           "TwoViewGeometry::Estimate), %s" % (host_cores(), label)}
 
 
 def main():
@@ -265,13 +345,13 @@ def main():
                 t.join()
         tg = time.perf_counter()
         g = sharding.gather_match_graph(dist, gsource, rank, world, bounds, verify, force_collectives=force)
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()  # inside the timed region on purpose: a step ends when the assembled graph is complete in HBM
         gather_s[0] += time.perf_counter() - tg
         return g
 
     for _ in range(args.warmup):
         step()
-    k1_ms, k1_launches, kv_ms, k1b_ms, k1g_ms = 0.0, 0, 0.0, 0.0, 0.0
+    k1_ms, k1_launches, kv_ms, k1b_ms, k1g_ms, k1t_ms = 0.0, 0, 0.0, 0.0, 0.0, 0.0
     graph = None
     barrier()
     gather_s[0] = 0.0
@@ -284,6 +364,7 @@ def main():
             k1_launches += nl
             k1b_ms += c.match_resolve_time()
             k1g_ms += c.match_gather_time()
+            k1t_ms += c.match_tail_time()
             if verify:
                 kv_ms += c.verify_kernel_time()
     barrier()
@@ -337,17 +418,12 @@ def main():
         pass2_s = 1e-3 * k1g_ms / launches
         pairs_per_launch = len(my_pairs) * args.steps / launches
         achieved = ops_per_pair * pairs_per_launch / (pass1_s + pass2_s) if pass1_s > 0 else 0.0
-        traffic, traffic_file = None, None
-        try:  # HBM bytes per K1 launch from the committed PMC collection (tools/collect_pmc.py), same workload only
-            import glob
-            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[34]_k1_pmc*.json"))):
-                pmc = json.load(open(f))
-                if pmc.get("images") == args.images and pmc.get("feats") == args.feats and pmc.get("pairs") == n_pairs and world == 1 \
-                        and args.pairs == "exhaustive" and args.shard_of == 1:
-                    traffic = pmc.get("k1_traffic_bytes_per_launch")
-                    traffic_file = os.path.basename(f)
-        except Exception:
-            traffic = None
+        fp = {}
+        if world == 1 and args.pairs == "exhaustive" and args.shard_of == 1 and not args.max_pairs and not args.fixed_trials \
+                and abs(args.outlier_frac - 0.2) < 1e-12:
+            fp = profile_figures(ROOT, args.images, args.feats, n_pairs, verify and calibrated)
+        traffic = fp.get("k1", {}).get("hbm_bytes_per_launch")
+        traffic_file = fp.get("k1", {}).get("file")
         fam = ("calibrated: E+F+H + relative pose" if calibrated else "uncalibrated: F+H")
         if args.fixed_trials:
             fam += ", fixed %d trials/family" % args.fixed_trials
@@ -374,16 +450,18 @@ def main():
             "device": {"name": info.name.decode(), "arch": info.arch.decode(), "compute_units": cus, "clock_mhz": clk / 1e6,
                        "hbm_gb": info.total_memory / 2 ** 30, "ranks_seen_by_process_group": world},
             "kernel_ms_per_step": {"k1_best_rows<pass 1>": k1_ms / args.steps, "k1_best_rows<gathered pass 2>": k1g_ms / args.steps,
-                                   "k1_resolve_index": k1b_ms / args.steps, "k_verify_pairs": kv_ms / args.steps},
+                                   "k1_resolve_index<pass 1>": k1b_ms / args.steps,
+                                   "pass-2 k1_resolve_index + compaction": k1t_ms / args.steps, "k_verify_pairs": kv_ms / args.steps,
+                                   "exchange": 0.0},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": int8_peak / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / int8_peak, "traffic": traffic,
+                         "traffic_file": traffic_file,
                          "traffic_note": "HBM bytes per launch of both passes, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read "
-                                         "correction) + WRITE_SIZE in separate passes (profiles/%s); null when not "
-                                         "collected for this workload" % (traffic_file or "r0*_k1_pmc*.json"),
+                                         "correction) + WRITE_SIZE in separate passes, read from the committed collection "
+                                         "traffic_file (an earlier run of this workload); null when not collected for it",
                          "kernel": "k1_best_rows (pass 1 over all rows + gathered pass 2 of the cross-check)",
                          "avg_launch_ms": 1e3 * (pass1_s + pass2_s), "avg_launch_ms_pass1": 1e3 * pass1_s,
                          "avg_launch_ms_pass2": 1e3 * pass2_s, "launches": k1_launches, "peak_source": peaks_note,
-                         "executed_frac": None,
                          "note": "int8 ops (2 per MAC) counted as flops; algorithmic = ONE 2*128*N1*N2 distance matrix per pair "
                                  "(SURVEY.md 8d) over the HIP-event time of BOTH k1_best_rows launches; pass 2 recomputes only "
                                  "the rows matches12 points at (~7 % of the matrix at this shape)"},
@@ -395,18 +473,7 @@ def main():
                            "forced_on_one_rank": bool(world == 1 and force),
                            "note": "device-to-device fetch through the C-ABI getters + the collectives of sharding.gather_match_graph "
                                    "(rank 0's wall time, inside the timed region)"}
-        # executed matrix-pipe work: SQ_INSTS_VALU_MFMA_I8 (x 65 536 ops per 32x32x32 instruction) of both passes from the
-        # committed PMC collection of the same workload, over THIS run's HIP-event time
-        try:
-            if traffic_file is not None and pass1_s > 0:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))
-                mi = pmc.get("SQ_INSTS_VALU_MFMA_I8", {})
-                if "pass1" in mi:
-                    insts = mi["pass1"]["mean_per_dispatch"] + mi.get("pass2", {}).get("mean_per_dispatch", 0.0)
-                    out["roofline"]["executed_frac"] = insts * 65536.0 / (pass1_s + pass2_s) / int8_peak
-                    out["roofline"]["executed_note"] = "SQ_INSTS_VALU_MFMA_I8 of both passes (profiles/%s) x 65 536 int8 ops over this run's launch time" % traffic_file
-        except Exception:
-            pass
+        out["kernel_ms_per_step"]["exchange"] = out["exchange"]["gather_ms_per_step"]
         if pass1_s > 0 and res["matches"] >= 0:
             # what the matrix pipe executed: pass 1 = the whole matrix; pass 2 = gathered rows in 128-row wave units
             out["roofline"]["frac_pass1_only"] = ops_per_pair * pairs_per_launch / pass1_s / int8_peak
@@ -416,15 +483,12 @@ def main():
                                       "frac": ach / fp64_peak, "traffic": None,
                                       "note": "algorithmic inlier-scoring flops only (33 / 20 / 5 per model x correspondence), "
                                               "per GPU, over the HIP-event time of all verification kernels"}
-            try:  # executed FP64 instruction rates per kernel from the committed counter collection (tools/collect_pmc.py --verify)
-                vf = os.path.join(ROOT, "profiles", "r04_verify_pmc.json")
-                if os.path.exists(vf) and world == 1 and args.images == 500 and args.feats == 4096 and args.pairs == "exhaustive" \
-                        and calibrated and args.shard_of == 1 and not args.fixed_trials:
-                    vp = json.load(open(vf))
-                    out["roofline_verify"]["executed"] = vp.get("summary")
-                    out["roofline_verify"]["executed_note"] = "profiles/r04_verify_pmc.json: per-kernel FP64 VALU instructions x 64 lanes (ADD/MUL = 1, FMA = 2 flops) over the kernels' own durations, one lane"
-            except Exception:
-                pass
+        if fp:
+            # counter figures of an EARLIER run of this workload (files named inside); instruction counts are per launch and
+            # do not depend on the clock, so executed work / this run's launch time is printed next to them
+            if fp.get("k1", {}).get("mfma_i8_insts_per_launch") and pass1_s > 0:
+                fp["k1"]["executed_frac_at_this_runs_time"] = fp["k1"]["mfma_i8_insts_per_launch"] * 65536.0 / (pass1_s + pass2_s) / int8_peak
+            out["from_profiles"] = fp
         # ---- second regime: the same pipeline where real collections live -- half of every image's
         # features are not observations of the scene, a putative match is right with 0.25 instead of 0.64, RANSAC needs ~13x
         # the trials.  150 images x the same feature count, after the timed region; never part of `value`.
@@ -467,7 +531,7 @@ def main():
                 out["cpu_baseline_native"] = cpu_baseline(native, "built -O3 -march=native on this host (labelled second baseline, SURVEY 8d)",
                                                           "-O3 -march=native", images, pairs, args.cpu_seconds - share, verify, cams,
                                                           topts, user_seed, cores)
-        print(json.dumps(out), flush=True)
+        print(format_line(out, args.dump_line), flush=True)
     if world > 1:
         dist.barrier()
     if dist.is_initialized():

@@ -102,6 +102,7 @@ def lib():
         L.dsm_debug_sample_sequence.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, u32p]
         L.dsm_get_device_info.argtypes = [vp, ctypes.POINTER(DeviceInfo)]
         L.dsm_get_match_gather_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+        L.dsm_get_match_tail_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
         L.dsm_retrieval_set_vocabulary.argtypes = [vp, ctypes.POINTER(Vocabulary)]
         L.dsm_retrieval_index.argtypes = [vp]
         L.dsm_retrieval_query.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp]
@@ -452,6 +453,11 @@ class Context:
     def match_gather_time(self):
         ms = ctypes.c_double(0)
         self._chk(lib().dsm_get_match_gather_time(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def match_tail_time(self):
+        ms = ctypes.c_double()
+        self._chk(lib().dsm_get_match_tail_time(self._h, ctypes.byref(ms)))
         return ms.value
 
     def match_resolve_time(self):

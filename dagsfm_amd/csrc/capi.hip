@@ -311,6 +311,7 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
   ctx->pairs.assign(pairs, pairs + (size_t)n_pairs * 2);
   ctx->k1_ms = 0.0;
   ctx->k1b_ms = 0.0;
+  ctx->k1t_ms = 0.0;
   ctx->k1g_ms = 0.0;
   ctx->k1_launches = 0;
   ctx->total_matches = 0;
@@ -396,7 +397,7 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
     k1.entries = nullptr;
     k1.e_off = nullptr;
     k1.e_cnt = nullptr;
-    while (ctx->ev.size() < ev_used + 5) {
+    while (ctx->ev.size() < ev_used + 6) {
       hipEvent_t e;
       HIPCHK(ctx, hipEventCreate(&e));
       ctx->ev.push_back(e);
@@ -499,15 +500,18 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
       launch_k2_entries(ke, nc, true, st);
       HIPCHK(ctx, hipGetLastError());
     }
-    ev_used += 5;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 5], st));
+    ev_used += 6;
     ctx->total_matches = total;
     // the scratch of this chunk is reused by the next one
     HIPCHK(ctx, hipStreamSynchronize(st));
     c0 = c1;
   }
   HIPCHK(ctx, hipStreamSynchronize(st));
-  for (size_t k = 0; k + 4 < ev_used; k += 5) {
+  for (size_t k = 0; k + 5 < ev_used; k += 6) {
     float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[k + 4], ctx->ev[k + 5]));
+    ctx->k1t_ms += ms;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[k], ctx->ev[k + 1]));
     ctx->k1_ms += ms;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[k + 1], ctx->ev[k + 2]));
@@ -541,6 +545,7 @@ int dsm_set_matches(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
   ctx->total_matches = total;
   ctx->k1_ms = 0.0;
   ctx->k1b_ms = 0.0;
+  ctx->k1t_ms = 0.0;
   ctx->k1_launches = 0;
   HIPCHK(ctx, ctx->d_counts.reserve(std::max<uint32_t>(n_pairs, 1) * 4));
   HIPCHK(ctx, ctx->d_offsets.reserve(((size_t)n_pairs + 1) * 8));
@@ -1751,6 +1756,13 @@ int dsm_get_match_gather_time(dsm_ctx* ctx, double* total_ms) {
   if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
   if (!ctx->matched) return fail(ctx, DSM_ERR_NOT_READY, "dsm_match_pairs has not run");
   if (total_ms) *total_ms = ctx->k1g_ms;
+  return DSM_OK;
+}
+
+int dsm_get_match_tail_time(dsm_ctx* ctx, double* total_ms) {
+  if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
+  if (!ctx->matched) return fail(ctx, DSM_ERR_NOT_READY, "dsm_match_pairs has not run");
+  if (total_ms) *total_ms = ctx->k1t_ms;
   return DSM_OK;
 }
 

@@ -96,6 +96,7 @@ struct dsm_ctx {
   uint64_t total_matches = 0;
   double k1_ms = 0.0;
   double k1b_ms = 0.0;  // k1_resolve_index
+  double k1t_ms = 0.0;  // after pass 2: its k1_resolve_index + the compaction of the mutual matches (host wait for the total included)
   double k1g_ms = 0.0;  // k1_best_rows<GATHER> (pass 2 of the cross-check)
   DevBuf d_order, d_dpairs2, d_ecnt, d_eoff, d_etotal, d_entries, d_out2, d_ms, d_out2s;
   uint32_t k1_launches = 0;
