@@ -7,6 +7,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DSM_LIB_PATH: developer override (e.g. the -DDSM_PROFILE_SECTIONS build under dagsfm_amd/prof/)
 LIB_PATH = os.environ.get("DSM_LIB_PATH") or os.path.join(_HERE, "libdagsfm_mi355x.so")
+# the same sources with -DDSM_CHECK_BUILD: the product plus the cross-check schedules (csrc/ctx.h, csrc/Makefile).  Only
+# tools/ and the schedule-parametrised tests load it -- Context(check=True), or any check-only DSM_* variable in the process
+# environment when the context is created; everything else, bench.py and the shim included, runs the product library.
+CHECK_LIB_PATH = os.environ.get("DSM_CHECK_LIB_PATH") or os.path.join(_HERE, "libdagsfm_mi355x_check.so")
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -60,17 +64,17 @@ class Vocabulary(ctypes.Structure):
                 ("projection", ctypes.c_void_p), ("thresholds", ctypes.c_void_p)]
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    """Loads the shared library; raises if it has not been built (no fallback)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def lib(check=False):
+    """Loads the shared library (check=True: the check build); raises if it has not been built (no fallback)."""
+    if check not in _libs:
+        path = CHECK_LIB_PATH if check else LIB_PATH
+        if not os.path.exists(path):
             raise DsmError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "(make -C dagsfm_amd/csrc)" % LIB_PATH)
-        L = ctypes.CDLL(LIB_PATH)
+                           "(make -C dagsfm_amd/csrc)" % path)
+        L = ctypes.CDLL(path)
         vp = ctypes.c_void_p
         L.dsm_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
         L.dsm_ctx_destroy.argtypes = [vp]
@@ -115,8 +119,10 @@ def lib():
         L.dsm_default_match_options.restype = None
         L.dsm_default_two_view_options.argtypes = [ctypes.POINTER(TwoViewOptions)]
         L.dsm_default_two_view_options.restype = None
-        _lib = L
-    return _lib
+        L.dsm_set_debug_option.restype = ctypes.c_int
+        L.dsm_set_debug_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
+        _libs[check] = L
+    return _libs[check]
 
 
 def pair_seed(id1, id2, user_seed=0):
@@ -156,23 +162,31 @@ def default_two_view_options(**kw):
     return o
 
 
-# the keys dsm_set_debug_option knows (DESIGN.md "Tuning / debugging hooks")
-DEBUG_OPTION_KEYS = ("DSM_MATCH_CHUNK_ROWS", "DSM_K1_DOT4", "DSM_VERIFY_DEBUG", "DSM_SAMPLER_SERIAL", "DSM_LO_PREPARE_WAVE",
-                     "DSM_LO_JACOBI_GROUPS", "DSM_ROOTS_LDS", "DSM_FINAL_WAVES", "DSM_VERIFY_LEGACY", "DSM_VERIFY_LANES",
-                     "DSM_VERIFY_FIXED_BATCH", "DSM_VERIFY_LANE_SPLIT", "DSM_VERIFY_CHUNK_PAIRS", "DSM_VERIFY_GRID_DIV",
-                     "DSM_VERIFY_INLINE_LO", "DSM_LO_TAIL", "DSM_LO_TAIL_MODE", "DSM_VERIFY_ITEM_MODE", "DSM_DEBUG_SAMPLER_MODE",
-                     "DSM_VOCAB_ASSIGN_VALU", "DSM_VERIFY_HOST_LOOP", "DSM_SCORE_PREFILTER", "DSM_VERIFY_REPLAY_GRID", "DSM_ROOTS_REFILL")
+# the keys dsm_set_debug_option knows (csrc/ctx.h): scheduling knobs of the product, and the cross-check switches of the check build
+PRODUCT_OPTION_KEYS = ("DSM_MATCH_CHUNK_ROWS", "DSM_VERIFY_CHUNK_PAIRS", "DSM_VERIFY_LANES", "DSM_VERIFY_INLINE_LO", "DSM_VERIFY_ITEM_MODE",
+                       "DSM_LO_TAIL", "DSM_LO_TAIL_MODE", "DSM_VERIFY_GRID_DIV")
+CHECK_OPTION_KEYS = ("DSM_K1_DOT4", "DSM_VERIFY_DEBUG", "DSM_SAMPLER_SERIAL", "DSM_LO_PREPARE_WAVE", "DSM_LO_JACOBI_GROUPS", "DSM_ROOTS_LDS",
+                     "DSM_FINAL_WAVES", "DSM_VERIFY_LEGACY", "DSM_VERIFY_FIXED_BATCH", "DSM_VERIFY_LANE_SPLIT", "DSM_DEBUG_SAMPLER_MODE",
+                     "DSM_VOCAB_ASSIGN_VALU", "DSM_VERIFY_HOST_LOOP", "DSM_SCORE_PREFILTER", "DSM_VERIFY_REPLAY_GRID")
+DEBUG_OPTION_KEYS = PRODUCT_OPTION_KEYS  # what a deployer's library knows
+
+
+def check_requested():
+    """True when the process environment carries a cross-check switch (or DSM_LIBRARY=check): contexts created now use the check build."""
+    return os.environ.get("DSM_LIBRARY") == "check" or any(os.environ.get(k) is not None for k in CHECK_OPTION_KEYS)
 
 
 class Context:
     """One context = one GPU (SiftFeatureMatcher + FeatureMatcherCache of the reference)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, check=None):
         self._handle = ctypes.c_void_p()
         self._debug = {}
-        rc = lib().dsm_ctx_create(device, ctypes.byref(self._handle))
+        self.check = check_requested() if check is None else bool(check)
+        self._L = lib(self.check)
+        rc = self._L.dsm_ctx_create(device, ctypes.byref(self._handle))
         if rc != 0:
-            raise DsmError("dsm_ctx_create failed (%d): %s" % (rc, lib().dsm_last_error(None).decode()))
+            raise DsmError("dsm_ctx_create failed (%d): %s" % (rc, self._L.dsm_last_error(None).decode()))
         self.n_pairs = 0
 
     @property
@@ -181,7 +195,7 @@ class Context:
         this TEST / TOOL binding forwards the DSM_* debug variables of the process to the context before every call, so
         that `DSM_VERIFY_LANES=1 python tools/...` and monkeypatch.setenv in the tests keep working."""
         if self._handle:
-            for key in DEBUG_OPTION_KEYS:
+            for key in PRODUCT_OPTION_KEYS + CHECK_OPTION_KEYS:  # a check-only switch on a product context fails loudly
                 want = os.environ.get(key)
                 if self._debug.get(key) != want:
                     self.set_debug_option(key, want)
@@ -189,9 +203,7 @@ class Context:
 
     def set_debug_option(self, key, value):
         """dsm_set_debug_option: a scheduling / cross-check switch of this context (None removes it)."""
-        L = lib()
-        L.dsm_set_debug_option.restype = ctypes.c_int
-        L.dsm_set_debug_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
+        L = self._L
         rc = L.dsm_set_debug_option(self._handle, key.encode(), None if value is None else str(value).encode())
         if rc != 0:
             raise DsmError("dsm_set_debug_option(%s) failed (%d)" % (key, rc))
@@ -202,7 +214,7 @@ class Context:
 
     def close(self):
         if self._handle:
-            lib().dsm_ctx_destroy(self._handle)
+            self._L.dsm_ctx_destroy(self._handle)
             self._handle = ctypes.c_void_p()
 
     def __del__(self):
@@ -213,10 +225,10 @@ class Context:
 
     def _chk(self, rc):
         if rc != 0:
-            raise DsmError("dsm error %d: %s" % (rc, lib().dsm_last_error(self._h).decode()))
+            raise DsmError("dsm error %d: %s" % (rc, self._L.dsm_last_error(self._h).decode()))
 
     def sync(self):
-        self._chk(lib().dsm_sync(self._h))
+        self._chk(self._L.dsm_sync(self._h))
 
     def append_images(self, descriptors, keypoints=None, cameras=None):
         """dsm_append_images: adds images behind the resident ones (indices continue), uploading only the new rows."""
@@ -242,8 +254,8 @@ class Context:
         cptr = None
         if cameras is not None:
             cptr = (Camera * max(n, 1))(*cameras)
-        fn = lib().dsm_append_images if _append else lib().dsm_set_images
-        fn.argtypes = lib().dsm_set_images.argtypes
+        fn = self._L.dsm_append_images if _append else self._L.dsm_set_images
+        fn.argtypes = self._L.dsm_set_images.argtypes
         self._chk(fn(self._h, n, nf.ctypes.data_as(u32p), dptr, kptr, stride, cptr))
         self._keep = (descs, kps)
 
@@ -251,7 +263,7 @@ class Context:
         options = options or default_match_options()
         p = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
         self.n_pairs = p.shape[0]
-        self._chk(lib().dsm_match_pairs(self._h, self.n_pairs, p.ctypes.data_as(u32p), ctypes.byref(options)))
+        self._chk(self._L.dsm_match_pairs(self._h, self.n_pairs, p.ctypes.data_as(u32p), ctypes.byref(options)))
 
     def set_matches(self, pairs, matches_per_pair):
         """dsm_set_matches: installs given FeatureMatches for the pair list (the verify-only / resume path of
@@ -262,23 +274,23 @@ class Context:
             off[k + 1] = off[k] + len(m)
         flat = np.ascontiguousarray(np.concatenate([np.asarray(m, dtype=np.uint32).reshape(-1, 2) for m in matches_per_pair] +
                                                    [np.zeros((1, 2), np.uint32)]), dtype=np.uint32)
-        lib().dsm_set_matches.argtypes = [ctypes.c_void_p, ctypes.c_uint32, u32p, ctypes.POINTER(ctypes.c_uint64), u32p]
-        self._chk(lib().dsm_set_matches(self._h, len(pairs), pairs.ctypes.data_as(u32p),
+        self._L.dsm_set_matches.argtypes = [ctypes.c_void_p, ctypes.c_uint32, u32p, ctypes.POINTER(ctypes.c_uint64), u32p]
+        self._chk(self._L.dsm_set_matches(self._h, len(pairs), pairs.ctypes.data_as(u32p),
                                         off.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), flat.ctypes.data_as(u32p)))
         self.n_pairs = len(pairs)
 
     def match_counts(self):
         c = np.zeros(max(self.n_pairs, 1), dtype=np.uint32)
-        self._chk(lib().dsm_get_match_counts(self._h, c.ctypes.data))
+        self._chk(self._L.dsm_get_match_counts(self._h, c.ctypes.data))
         return c[:self.n_pairs]
 
     def matches(self):
         """Returns (offsets[n_pairs+1], matches[total,2])."""
         offs = np.zeros(self.n_pairs + 1, dtype=np.uint64)
-        self._chk(lib().dsm_get_matches(self._h, offs.ctypes.data, None, 0))
+        self._chk(self._L.dsm_get_matches(self._h, offs.ctypes.data, None, 0))
         total = int(offs[-1])
         m = np.zeros((max(total, 1), 2), dtype=np.uint32)
-        self._chk(lib().dsm_get_matches(self._h, None, m.ctypes.data, total))
+        self._chk(self._L.dsm_get_matches(self._h, None, m.ctypes.data, total))
         return offs, m[:total]
 
     def match_sift_features(self, desc1, desc2, options=None):
@@ -288,7 +300,7 @@ class Context:
         d2 = np.ascontiguousarray(desc2, dtype=np.uint8).reshape(-1, 128)
         out = np.zeros((max(d1.shape[0], 1), 2), dtype=np.uint32)
         n = ctypes.c_uint32(0)
-        self._chk(lib().dsm_match_sift_features(self._h, ctypes.byref(options), d1.ctypes.data_as(u8p), d1.shape[0],
+        self._chk(self._L.dsm_match_sift_features(self._h, ctypes.byref(options), d1.ctypes.data_as(u8p), d1.shape[0],
                                                 d2.ctypes.data_as(u8p), d2.shape[0], out.ctypes.data_as(u32p),
                                                 ctypes.byref(n)))
         return out[:n.value].copy()
@@ -300,24 +312,24 @@ class Context:
             self._seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
             assert len(self._seeds) == self.n_pairs
             sp = self._seeds.ctypes.data_as(u32p)
-        self._chk(lib().dsm_verify_pairs(self._h, ctypes.byref(options), sp, user_seed, int(bool(stage_filter))))
+        self._chk(self._L.dsm_verify_pairs(self._h, ctypes.byref(options), sp, user_seed, int(bool(stage_filter))))
 
     def two_view_geometries(self):
         arr = (TwoViewGeometry * max(self.n_pairs, 1))()
-        self._chk(lib().dsm_get_two_view_geometries(self._h, ctypes.addressof(arr)))
+        self._chk(self._L.dsm_get_two_view_geometries(self._h, ctypes.addressof(arr)))
         return list(arr)[:self.n_pairs]
 
     def inlier_matches(self):
         offs = np.zeros(self.n_pairs + 1, dtype=np.uint64)
-        self._chk(lib().dsm_get_inlier_matches(self._h, offs.ctypes.data, None, 0))
+        self._chk(self._L.dsm_get_inlier_matches(self._h, offs.ctypes.data, None, 0))
         total = int(offs[-1])
         m = np.zeros((max(total, 1), 2), dtype=np.uint32)
-        self._chk(lib().dsm_get_inlier_matches(self._h, None, m.ctypes.data, total))
+        self._chk(self._L.dsm_get_inlier_matches(self._h, None, m.ctypes.data, total))
         return offs, m[:total]
 
     def verify_kernel_time(self):
         ms = ctypes.c_double(0)
-        self._chk(lib().dsm_get_verify_kernel_time(self._h, ctypes.byref(ms)))
+        self._chk(self._L.dsm_get_verify_kernel_time(self._h, ctypes.byref(ms)))
         return ms.value
 
     def estimate_two_view_geometry(self, cam1, pts1, cam2, pts2, matches, options=None, seed=0):
@@ -329,7 +341,7 @@ class Context:
         out = TwoViewGeometry()
         inl = np.zeros((max(len(m), 1), 2), dtype=np.uint32)
         dp = ctypes.POINTER(ctypes.c_double)
-        self._chk(lib().dsm_estimate_two_view_geometry(self._h, ctypes.byref(cam1), p1.ctypes.data_as(dp), len(p1),
+        self._chk(self._L.dsm_estimate_two_view_geometry(self._h, ctypes.byref(cam1), p1.ctypes.data_as(dp), len(p1),
                                                        ctypes.byref(cam2), p2.ctypes.data_as(dp), len(p2),
                                                        m.ctypes.data_as(u32p), len(m), ctypes.byref(options), seed,
                                                        ctypes.byref(out), inl.ctypes.data_as(u32p)))
@@ -337,27 +349,27 @@ class Context:
 
     def debug_sample_sequence(self, seed, k, total, n_draws):
         out = np.zeros((n_draws, k), dtype=np.uint32)
-        self._chk(lib().dsm_debug_sample_sequence(self._h, seed, k, total, n_draws, out.ctypes.data_as(u32p)))
+        self._chk(self._L.dsm_debug_sample_sequence(self._h, seed, k, total, n_draws, out.ctypes.data_as(u32p)))
         return out
 
     def debug_image_to_world(self, cam, xy):
         xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
         out = np.zeros_like(xy)
         dp = ctypes.POINTER(ctypes.c_double)
-        self._chk(lib().dsm_debug_image_to_world(self._h, ctypes.byref(cam), len(xy), xy.ctypes.data_as(dp), out.ctypes.data_as(dp)))
+        self._chk(self._L.dsm_debug_image_to_world(self._h, ctypes.byref(cam), len(xy), xy.ctypes.data_as(dp), out.ctypes.data_as(dp)))
         return out
 
     def match_kernel_time(self):
         ms = ctypes.c_double(0)
         n = ctypes.c_uint32(0)
-        self._chk(lib().dsm_get_match_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        self._chk(self._L.dsm_get_match_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
     def guided_match_pairs(self, match_options=None, options=None, stage_filter=False):
         """dsm_guided_match_pairs: replaces the inlier matches of the verified pairs by guided matches."""
         mo = match_options if match_options is not None else default_match_options()
         to = options if options is not None else default_two_view_options()
-        self._chk(lib().dsm_guided_match_pairs(self._h, ctypes.byref(mo), ctypes.byref(to), 1 if stage_filter else 0))
+        self._chk(self._L.dsm_guided_match_pairs(self._h, ctypes.byref(mo), ctypes.byref(to), 1 if stage_filter else 0))
 
     # ---- vocabulary-tree retrieval (candidate pairs)
     def retrieval_set_vocabulary(self, words, projection, thresholds):
@@ -366,12 +378,12 @@ class Context:
         assert self._voc[2].shape[0] == self._voc[0].shape[0]
         v = Vocabulary(num_words=self._voc[0].shape[0], reserved=0, words=self._voc[0].ctypes.data, projection=self._voc[1].ctypes.data,
                        thresholds=self._voc[2].ctypes.data)
-        self._chk(lib().dsm_retrieval_set_vocabulary(self._h, ctypes.byref(v)))
+        self._chk(self._L.dsm_retrieval_set_vocabulary(self._h, ctypes.byref(v)))
 
     def debug_verify_counters(self):
         """dsm_debug_verify_counters: 16 statistics counters of the last verify call (DSM_VERIFY_DEBUG / DSM_SCORE_PREFILTER=check)."""
         out = np.zeros(16, np.uint32)
-        L = lib()
+        L = self._L
         L.dsm_debug_verify_counters.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         self._chk(L.dsm_debug_verify_counters(self._h, out.ctypes.data))
         return out
@@ -379,7 +391,7 @@ class Context:
     def retrieval_set_word_ids(self, index_ids, query_ids):
         """dsm_retrieval_set_word_ids: the caller's word ids (the reference's FLANN answer) instead of the device's exact
         search; index_ids [features], query_ids [features, k].  (None, None): exact search again."""
-        L = lib()
+        L = self._L
         L.dsm_retrieval_set_word_ids.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
         if index_ids is None:
             self._chk(L.dsm_retrieval_set_word_ids(self._h, None, 0, None))
@@ -389,14 +401,14 @@ class Context:
         self._chk(L.dsm_retrieval_set_word_ids(self._h, a.ctypes.data, b.shape[1], b.ctypes.data))
 
     def retrieval_index(self):
-        self._chk(lib().dsm_retrieval_index(self._h))
+        self._chk(self._L.dsm_retrieval_index(self._h))
 
     def retrieval_query(self, n_images, num_neighbors=5, max_num_images=100):
         """Returns a list (per query image, in dsm_set_images order) of (image_idx [c], scores [c]) in retrieval order."""
         cnt = np.zeros(n_images, np.uint32)
         idx = np.zeros((n_images, max_num_images), np.uint32)
         sc = np.zeros((n_images, max_num_images), np.float32)
-        self._chk(lib().dsm_retrieval_query(self._h, num_neighbors, max_num_images, cnt.ctypes.data, idx.ctypes.data, sc.ctypes.data))
+        self._chk(self._L.dsm_retrieval_query(self._h, num_neighbors, max_num_images, cnt.ctypes.data, idx.ctypes.data, sc.ctypes.data))
         return [(idx[q, :cnt[q]].copy(), sc[q, :cnt[q]].copy()) for q in range(n_images)]
 
     def retrieval_matches(self, query_result, num_neighbors=5, max_num_images=100):
@@ -408,7 +420,7 @@ class Context:
         for q, r in enumerate(query_result):
             idx[q, :len(r[0])] = r[0]
         offs = np.zeros(n + 1, np.uint64)
-        L = lib()
+        L = self._L
         L.dsm_retrieval_matches.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.dsm_get_retrieval_matches.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
         self._chk(L.dsm_retrieval_matches(self._h, num_neighbors, max_num_images, cnt.ctypes.data, idx.ctypes.data, offs.ctypes.data))
@@ -419,19 +431,19 @@ class Context:
 
     def retrieval_idf(self, num_words):
         out = np.zeros(num_words, np.float32)
-        L = lib()
+        L = self._L
         L.dsm_get_retrieval_idf.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         self._chk(L.dsm_get_retrieval_idf(self._h, out.ctypes.data, num_words))
         return out
 
     def retrieval_debug_word_ids(self, image, n_feats, k):
         out = np.zeros((max(n_feats, 1), k), np.int32)
-        self._chk(lib().dsm_retrieval_debug_word_ids(self._h, image, k, out.ctypes.data))
+        self._chk(self._L.dsm_retrieval_debug_word_ids(self._h, image, k, out.ctypes.data))
         return out[:n_feats]
 
     def retrieval_time(self):
         a, b = ctypes.c_double(0), ctypes.c_double(0)
-        self._chk(lib().dsm_get_retrieval_time(self._h, ctypes.byref(a), ctypes.byref(b)))
+        self._chk(self._L.dsm_get_retrieval_time(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
     def view_graph_filter_cycles(self, pairs, qvecs, max_loop_error_degrees=5.0):
@@ -441,26 +453,26 @@ class Context:
         assert len(p) == len(q)
         keep = np.zeros(max(len(p), 1), np.uint8)
         nt = ctypes.c_uint64(0)
-        self._chk(lib().dsm_view_graph_filter_cycles(self._h, len(p), p.ctypes.data, q.ctypes.data, max_loop_error_degrees,
+        self._chk(self._L.dsm_view_graph_filter_cycles(self._h, len(p), p.ctypes.data, q.ctypes.data, max_loop_error_degrees,
                                                      keep.ctypes.data, ctypes.addressof(nt)))
         return keep[:len(p)].astype(bool), nt.value
 
     def device_info(self):
         d = DeviceInfo()
-        self._chk(lib().dsm_get_device_info(self._h, ctypes.byref(d)))
+        self._chk(self._L.dsm_get_device_info(self._h, ctypes.byref(d)))
         return d
 
     def match_gather_time(self):
         ms = ctypes.c_double(0)
-        self._chk(lib().dsm_get_match_gather_time(self._h, ctypes.byref(ms)))
+        self._chk(self._L.dsm_get_match_gather_time(self._h, ctypes.byref(ms)))
         return ms.value
 
     def match_tail_time(self):
         ms = ctypes.c_double()
-        self._chk(lib().dsm_get_match_tail_time(self._h, ctypes.byref(ms)))
+        self._chk(self._L.dsm_get_match_tail_time(self._h, ctypes.byref(ms)))
         return ms.value
 
     def match_resolve_time(self):
         ms = ctypes.c_double(0)
-        self._chk(lib().dsm_get_match_resolve_time(self._h, ctypes.byref(ms)))
+        self._chk(self._L.dsm_get_match_resolve_time(self._h, ctypes.byref(ms)))
         return ms.value

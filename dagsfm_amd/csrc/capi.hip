@@ -177,15 +177,14 @@ int dsm_sync(dsm_ctx* ctx) {
 }
 
 int dsm_set_debug_option(dsm_ctx* ctx, const char* key, const char* value) {
-  static const char* const kKnown[] = {
-      "DSM_MATCH_CHUNK_ROWS", "DSM_K1_DOT4", "DSM_VERIFY_DEBUG", "DSM_SAMPLER_SERIAL", "DSM_LO_PREPARE_WAVE", "DSM_LO_JACOBI_GROUPS",
-      "DSM_ROOTS_LDS", "DSM_FINAL_WAVES", "DSM_VERIFY_LEGACY", "DSM_VERIFY_LANES", "DSM_VERIFY_FIXED_BATCH", "DSM_VERIFY_LANE_SPLIT",
-      "DSM_VERIFY_CHUNK_PAIRS", "DSM_VERIFY_GRID_DIV", "DSM_VERIFY_INLINE_LO", "DSM_LO_TAIL", "DSM_LO_TAIL_MODE", "DSM_VERIFY_ITEM_MODE",
-      "DSM_DEBUG_SAMPLER_MODE", "DSM_VOCAB_ASSIGN_VALU", "DSM_VERIFY_HOST_LOOP", "DSM_SCORE_PREFILTER", "DSM_VERIFY_REPLAY_GRID", "DSM_ROOTS_REFILL"};
   if (!ctx || !key) return DSM_ERR_INVALID_ARGUMENT;
   bool known = false;
-  for (const char* k : kKnown) known = known || strcmp(k, key) == 0;
-  if (!known) return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "dsm_set_debug_option: unknown key");
+  for (const char* k : dsm_product_debug_keys) known = known || strcmp(k, key) == 0;
+#ifdef DSM_CHECK_BUILD
+  for (const char* k : dsm_check_debug_keys) known = known || strcmp(k, key) == 0;
+#endif
+  if (!known)
+    return fail(ctx, DSM_ERR_INVALID_ARGUMENT, "dsm_set_debug_option: unknown key (the cross-check switches exist in libdagsfm_mi355x_check.so only)");
   if (value)
     ctx->debug_options[key] = value;
   else
@@ -403,11 +402,17 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
       ctx->ev.push_back(e);
     }
     // DSM_K1_DOT4=1: the LDS-tiled v_dot4 variant of pass 1 (comparison runs only, profiles/r02_k1_variants.md)
+#ifdef DSM_CHECK_BUILD
     const bool k1_dot4 = ctx->dbg("DSM_K1_DOT4") != nullptr;
+#else
+    const bool k1_dot4 = false;
+#endif
     HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used], st));
+#ifdef DSM_CHECK_BUILD
     if (k1_dot4)
       launch_k1_dot4(k1, nc, max_rb, st);
     else
+#endif
       launch_k1(k1, nc, max_rb, st);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 1], st));
@@ -902,6 +907,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   int dev_cus = 256;
   (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
   const uint32_t n_blocks = std::min<uint32_t>(n_pairs, (uint32_t)dev_cus * 16u);
+  (void)n_blocks;  // the grid of the legacy schedule (check build)
   const uint64_t tm = std::max<uint64_t>(total_matches, 1);
   HIPCHK(ctx, ctx->d_pair_state.reserve(std::max<size_t>(n_pairs, 1) * 1280 * 4));
   HIPCHK(ctx, ctx->d_pts_px.reserve(tm * 32));
@@ -965,7 +971,6 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.lo_reg_prepare = ctx->dbg("DSM_LO_PREPARE_WAVE") ? 0 : 1;
   vp.dbg_jacobi_groups = ctx->dbg("DSM_LO_JACOBI_GROUPS") ? 1 : 0;  // the 8-lane-group Jacobi kernel for every problem (round-2 form)
   vp.dbg_roots_lds = ctx->dbg("DSM_ROOTS_LDS") ? 1 : 0;              // k_roots_e_lds instead of the register form
-  vp.dbg_roots_refill = ctx->dbg("DSM_ROOTS_REFILL") ? atoi(ctx->dbg("DSM_ROOTS_REFILL")) : 0;  // experimental: k_roots_e_init / _iter / _finish
   vp.dbg_final_waves = ctx->dbg("DSM_FINAL_WAVES") ? atoi(ctx->dbg("DSM_FINAL_WAVES")) : 0;
   vp.score_prefilter = ctx->dbg("DSM_SCORE_PREFILTER") ? atoi(ctx->dbg("DSM_SCORE_PREFILTER")) : 1;
   // "check": every slot is scored exactly AND held against its bounds (counters [14] violations, [15] slots the filter
@@ -991,8 +996,13 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.lo_jobs = nullptr;
   vp.lo_inl_pool = nullptr;
   vp.job_list = nullptr;
-  const bool legacy = ctx->dbg("DSM_VERIFY_LEGACY") != nullptr;  // single-kernel-per-family schedule (debug)
+#ifdef DSM_CHECK_BUILD
+  const bool legacy = ctx->dbg("DSM_VERIFY_LEGACY") != nullptr;  // single-kernel-per-family schedule (check build only)
+#else
+  const bool legacy = false;
+#endif
   if (legacy) {
+#ifdef DSM_CHECK_BUILD
     HIPCHK(ctx, ctx->d_vscratch.reserve(std::max<size_t>(1, (size_t)n_blocks * verify_scratch_bytes_per_block(n_max))));
     vp.scratch = ctx->d_vscratch.as<double>();
     HIPCHK(ctx, ctx->lanes[0].active.reserve(128));
@@ -1001,6 +1011,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     HIPCHK(ctx, hipEventRecord(ctx->vev0, st));
     launch_verify(vp, n_blocks, st);
     HIPCHK(ctx, hipGetLastError());
+#endif
   } else {
     // phase-split pipeline: per family, rounds of sample -> solve+score -> replay until no pair is active
     VerifyPlan plan;

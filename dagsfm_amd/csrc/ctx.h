@@ -128,8 +128,15 @@ struct dsm_ctx {
 
   dsm_ctx* leaf = nullptr;  // private context of the one-shot leaf entry points
 
-  // dsm_set_debug_option: scheduling / cross-check switches of THIS context (none changes a result).  The library never
-  // reads the process environment: a host application's environment cannot change schedules.
+  // dsm_set_debug_option: switches of THIS context (none changes a result).  The library never reads the process
+  // environment: a host application's environment cannot change schedules.
+  // Two builds of the same sources (Makefile):
+  //   libdagsfm_mi355x.so        the product: only the scheduling knobs a deployer could want (dsm_product_debug_keys);
+  //                              the cross-check schedules are not compiled in
+  //   libdagsfm_mi355x_check.so  -DDSM_CHECK_BUILD: additionally the independent schedules of the same results that
+  //                              tools/check_schedules.py and the schedule-parametrised tests compare the product with
+  //                              (legacy one-kernel LO-RANSAC, fused / LDS forms of the 5-point root finder,
+  //                              the v_dot4 K1 and word assignment, counters of DSM_VERIFY_DEBUG / DSM_SCORE_PREFILTER=check)
   std::map<std::string, std::string> debug_options;
   const char* dbg(const char* key) const {
     const auto it = debug_options.find(key);
@@ -140,6 +147,16 @@ struct dsm_ctx {
 };
 void dsm_retrieval_destroy(dsm_ctx* ctx);     // retrieval.hip
 void dsm_retrieval_invalidate(dsm_ctx* ctx);  // retrieval.hip: the resident images changed
+
+// keys dsm_set_debug_option accepts (an unknown key is an error, so a check-only switch fails loudly on the product build)
+static const char* const dsm_product_debug_keys[] = {"DSM_MATCH_CHUNK_ROWS", "DSM_VERIFY_CHUNK_PAIRS", "DSM_VERIFY_LANES", "DSM_VERIFY_INLINE_LO",
+                                                     "DSM_VERIFY_ITEM_MODE", "DSM_LO_TAIL", "DSM_LO_TAIL_MODE", "DSM_VERIFY_GRID_DIV"};
+#ifdef DSM_CHECK_BUILD
+static const char* const dsm_check_debug_keys[] = {"DSM_K1_DOT4", "DSM_VERIFY_DEBUG", "DSM_SAMPLER_SERIAL", "DSM_LO_PREPARE_WAVE", "DSM_LO_JACOBI_GROUPS",
+                                                   "DSM_ROOTS_LDS", "DSM_FINAL_WAVES", "DSM_VERIFY_LEGACY", "DSM_VERIFY_FIXED_BATCH", "DSM_VERIFY_LANE_SPLIT",
+                                                   "DSM_DEBUG_SAMPLER_MODE", "DSM_VOCAB_ASSIGN_VALU", "DSM_VERIFY_HOST_LOOP", "DSM_SCORE_PREFILTER",
+                                                   "DSM_VERIFY_REPLAY_GRID"};
+#endif
 
 #define HIPCHK(ctx, call)                                                              \
   do {                                                                                 \

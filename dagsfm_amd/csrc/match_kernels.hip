@@ -463,6 +463,7 @@ __global__ __launch_bounds__(256) void k1_resolve_index(const K1Params p) {
   }
 }
 
+#ifdef DSM_CHECK_BUILD  // comparison variant (BASELINE configs[2]): libdagsfm_mi355x_check.so only
 // ------------------------------------------------------------------------------------ K1-dot4 (comparison variant)
 // The LDS-tiled VALU form of pass 1 that BASELINE.json configs[1]/[2] name ("int8 LDS-tiled distance kernel" vs "MFMA
 // int8 distance GEMM"): thread = one row of image a with its 128-byte descriptor in 32 registers, the columns of
@@ -560,6 +561,8 @@ __global__ __launch_bounds__(256) void k1_best_rows_dot4(const K1Params p) {
     p.out[p.d_out_off[d] + row[r]] = res;
   }
 }
+
+#endif  // DSM_CHECK_BUILD
 
 // ------------------------------------------------------------------------------------ KG (guided matching)
 // The guided filters of MatchGuidedSiftFeaturesCPU (sift.cc:838-866) in float, same operation order as
@@ -806,11 +809,13 @@ void launch_k1(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, 
   else
     hipLaunchKernelGGL(k1_best_rows<false>, dim3(n_directed, (max_row_blocks + 1) / 2), dim3(256), 0, st, p);
 }
+#ifdef DSM_CHECK_BUILD
 // comparison variant (DSM_K1_DOT4): pass 1 on the VALU; writes exact column indices, no resolve pass
 void launch_k1_dot4(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st) {
   if (n_directed == 0 || max_row_blocks == 0) return;
   hipLaunchKernelGGL(k1_best_rows_dot4, dim3(n_directed, (max_row_blocks + 1) / 2), dim3(256), 0, st, p);
 }
+#endif
 void launch_k1_resolve(const K1Params& p, uint32_t n_directed, uint32_t max_row_blocks, hipStream_t st) {
   if (n_directed == 0 || max_row_blocks == 0) return;
   if (p.entries)

@@ -54,6 +54,7 @@ struct RetrievalState {
   std::vector<int32_t> host_index_ids, host_query_ids;  // [features] / [features][host_k_query], images back to back
   uint32_t host_k_query = 0;
   bool host_ids = false;
+  bool host_ids_stale = false;  // the resident images changed after dsm_retrieval_set_word_ids: the ids describe other features
   int host_loaded = 0;  // which list d_wid / d_sig hold: 1 index, 2 query
   DevBuf d_words, d_cw, d_projT, d_thr, d_lut;
   DevBuf d_row_img, d_wid, d_sig;                       // per feature row
@@ -72,6 +73,7 @@ struct RetrievalState {
 // ------------------------------------------------------------------------------------ word assignment
 // words: s8 (u8 ^ 0x80) [Wp][128]; cw[j] = 2 * rterm(w_j) - |w_j|^2 (+ INT_MIN/2 for padding words).  desc: the context's
 // s8 descriptors; row_img[r] < 0 marks a padding row.  out: [rows][RK_MAX] word ids, ascending distance.
+#ifdef DSM_CHECK_BUILD  // the VALU form of the word assignment (cross-check of k_vocab_assign_mfma): check build only
 __global__ __launch_bounds__(256) void k_vocab_assign(const int8_t* __restrict__ desc, const int32_t* __restrict__ row_img,
                                                       uint64_t n_rows, const int8_t* __restrict__ words,
                                                       const int32_t* __restrict__ cw, uint32_t num_words, uint32_t words_padded,
@@ -162,6 +164,7 @@ __global__ __launch_bounds__(256) void k_vocab_assign(const int8_t* __restrict__
     for (int q = 0; q < RK_MAX; ++q) o[q] = (valid && q < k && key[r][q] != INT32_MIN) ? id[r][q] : RK_INVALID;
   }
 }
+#endif  // DSM_CHECK_BUILD
 
 // ------------------------------------------------------------------------------------ Hamming signatures
 // proj = P * float(descriptor), each of the 64 sums over the 128 dimensions left to right (oracle/retrieval.cc Project);
@@ -480,6 +483,10 @@ void dsm_retrieval_invalidate(dsm_ctx* ctx) {  // the resident images changed
   ctx->retrieval->indexed = false;
   ctx->retrieval->k_assigned = 0;
   ctx->retrieval->host_loaded = 0;
+  // the caller's word ids belong to the features that WERE resident: with a feature cap a different image set has the same
+  // total row count, so the size check in retrieval_assign cannot see the change -- the ids are refused until
+  // dsm_retrieval_set_word_ids is called again
+  if (ctx->retrieval->host_ids) ctx->retrieval->host_ids_stale = true;
 }
 
 void dsm_retrieval_destroy(dsm_ctx* ctx) {
@@ -655,6 +662,8 @@ static int retrieval_assign(dsm_ctx* ctx, uint32_t k, int purpose) {
   const uint64_t rows = ctx->total_rows;
   if (r->host_ids) {
     // the caller's word ids: scattered into the padded row layout, signatures computed for exactly those words
+    if (r->host_ids_stale)
+      return dsm_fail(ctx, DSM_ERR_NOT_READY, "dsm_retrieval_set_word_ids: the resident images changed since the ids were set");
     if (r->host_loaded == purpose && r->d_wid.p) return DSM_OK;
     uint64_t n_feat = 0;
     for (uint32_t i = 0; i < ctx->n_images; ++i) n_feat += ctx->nfeat[i];
@@ -703,11 +712,13 @@ static int retrieval_assign(dsm_ctx* ctx, uint32_t k, int purpose) {
   RCHK(ctx, r->d_wid.reserve(std::max<uint64_t>(rows, 1) * RK_MAX * 4));
   RCHK(ctx, r->d_sig.reserve(std::max<uint64_t>(rows, 1) * RK_MAX * 8));
   if (rows) {
+#ifdef DSM_CHECK_BUILD
     if (ctx->dbg("DSM_VOCAB_ASSIGN_VALU"))  // the LDS-tiled v_dot4 form (comparison / cross-check)
       hipLaunchKernelGGL(k_vocab_assign, dim3((uint32_t)((rows + 511) / 512)), dim3(256), 0, st, ctx->d_desc.as<int8_t>(),
                          r->d_row_img.as<int32_t>(), rows, r->d_words.as<int8_t>(), r->d_cw.as<int32_t>(), r->num_words, r->words_padded, (int)k,
                          r->d_wid.as<int32_t>());
     else
+#endif
       hipLaunchKernelGGL(k_vocab_assign_mfma, dim3((uint32_t)((rows + 511) / 512)), dim3(256), 0, st, ctx->d_desc.as<int8_t>(),
                          r->d_row_img.as<int32_t>(), rows, r->d_words.as<int8_t>(), r->d_cw.as<int32_t>(), r->num_words, r->words_padded, (int)k,
                          r->d_wid.as<int32_t>());
@@ -783,6 +794,7 @@ int dsm_retrieval_set_word_ids(dsm_ctx* ctx, const int32_t* index_ids, uint32_t 
   r->indexed = false;
   r->k_assigned = 0;
   r->host_loaded = 0;
+  r->host_ids_stale = false;
   if (!index_ids && !query_ids) {  // back to the device's exact search
     r->host_ids = false;
     r->host_index_ids.clear();

@@ -31,7 +31,6 @@
 #include "verify_estimators.h"
 #include "verify_camera.h"
 #include "verify_fivept_coop.h"
-#include "verify_roots_refill.h"
 
 #define BATCH 64
 
@@ -1081,6 +1080,7 @@ __global__ __launch_bounds__(64) void k_verify_prep(const VerifyParams p) {
   }
 }
 
+#ifdef DSM_CHECK_BUILD  // cross-check schedule: libdagsfm_mi355x_check.so only
 template <int FAM>
 __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : (FAM == FAM_F ? 3 : 4))) void k_ransac(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1129,6 +1129,7 @@ __global__ __launch_bounds__(64, (FAM == FAM_H ? 2 : (FAM == FAM_F ? 3 : 4))) vo
   }
 }
 
+#endif  // DSM_CHECK_BUILD
 // WAVES = waves per SIMD the register allocation aims at.  Since the candidate poses moved out (k_final_pose), both
 // instances need 254 VGPRs; <2> spills 12 of them and runs two waves per SIMD, <1> spills none and runs one.  <2> is the
 // product path: verification of config 2 349 -> 341 ms (profiles/r03_check_schedules.txt); DSM_FINAL_WAVES=1 selects the
@@ -1629,6 +1630,7 @@ size_t verify_scratch_bytes_per_block(uint32_t n_max) { return verify_scratch_do
 size_t verify_smem_bytes(uint32_t n_max) { return ((sizeof(VSmem) + 15) / 16) * 16 + (size_t)(n_max > 0 ? n_max : 1) * 4; }
 
 static void launch_final_pose_finish(const VerifyParams& p, uint32_t n_blocks, hipStream_t st);
+#ifdef DSM_CHECK_BUILD  // cross-check schedule: libdagsfm_mi355x_check.so only
 void launch_verify(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
   if (p.n_pairs == 0 || n_blocks == 0) return;
   const size_t smem = verify_smem_bytes(p.n_max);
@@ -1639,6 +1641,7 @@ void launch_verify(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
   hipLaunchKernelGGL(k_verify_final<2>, dim3(n_blocks), dim3(64), smem, st, p);
   launch_final_pose_finish(p, n_blocks, st);
 }
+#endif  // DSM_CHECK_BUILD
 
 // ------------------------------------------------------------------------------------ phase-split pipeline
 // Same LO-RANSAC, different schedule: the sequential part of loransac.h:91-233 is only (a) drawing the
@@ -2344,197 +2347,7 @@ __global__ __launch_bounds__(64, 2) void k_roots_e(const VerifyParams p) {
   const int code = e_roots_body(slot);
   p.nmodels[(size_t)pl * p.batch + t] = e_models_body(slot, code, slot);
 }
-// EXPERIMENTAL, NOT a candidate (DSM_ROOTS_REFILL=1; tools/check_schedules.py --experimental): the same roots with LANE-LEVEL REFILL.
-// Measured once: byte-identical records, 3.3 x SLOWER than k_roots_e (810 vs 242 ms, 4 950 pairs at a 0.25 inlier ratio): k_roots_e_iter
-// needs 580 B of scratch per lane at two waves per SIMD and the spill traffic of every pass outweighs the idle lanes it removes.
-// In k_roots_e a wave runs until its slowest polynomial is done -- 32.5 passes of the iteration for lanes that need 23.5 on average
-// (tools/sim_roots_lanes.py); the counters have 35 % of the lanes active.  Three kernels instead of one:
-//   k_roots_e_init    lane per hypothesis: the determinant polynomial -> its roots where no iteration is needed, else the scaled
-//                     companion matrix (64 Hessenberg entries + scale, norm) into the hypothesis' e_work record; nmodels[] = status
-//   k_roots_e_iter    a wave owns RR_SPAN consecutive hypotheses of the flat (pair, trial) index; a lane whose matrix has
-//                     converged STORES it and LOADS the next pending one (no live values beyond the matrix registers: a first form
-//                     that started and extracted polynomials inside this loop needed 1 KB of scratch per lane), once RR_MIN_IDLE
-//                     lanes are waiting to share the branch
-//   k_roots_e_finish  lane per hypothesis: eigenvalues of the converged matrix, root code, the models of the real roots
-// Per lane the operations are pr_poly_roots' own (verify_roots_refill.h is cut out of verify_linalg.h): the same bits.
-#define RR_SPAN 256
-#define RR_MIN_IDLE 16
-#define RR_PENDING (-2)
-#define RR_ITERATED (-3)
-#define RR_FAILED (-4)
-// e_work record of a pending hypothesis (lane-interleaved like A: element e of hypothesis h at group(h) + e * 64 + (h & 63)):
-// [0..63] the Hessenberg entries (column j: rows 0..min(j + 1, 9)), [64] scale, [65] norm, [66] n, [67] degree
-#define RR_E(h, e) (((size_t)((h) >> 6) * 200 + (size_t)(e)) * 64 + (size_t)((h) & 63))
-DSM_DEV int e_roots_code_store(double* slot, int nroots, const double (&rr)[11], const double (&ri)[11]) {
-  int code = 0;
-  if (nroots > 0) {
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      if (i < nroots) {
-        if (!(fabs(ri[i]) > 1e-10)) code |= 1 << i;
-        slot[EPOLY_COEFFS + i] = rr[i];
-      }
-    }
-    code |= nroots << 16;
-  }
-  return code;
-}
-__global__ __launch_bounds__(64, 2) void k_roots_e_init(const VerifyParams p) {
-  const uint32_t pl = blockIdx.x;
-  const uint32_t pi = p.pair0 + pl;
-  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
-  if (!fs->active) return;
-  const int t = blockIdx.y * 64 + threadIdx.x;
-  if (t >= (int)fs->nb) return;
-  const uint64_t h = (uint64_t)pl * p.batch + t;
-  double* slot = p.models + (size_t)h * 90;
-  double coeffs[11], rr[11], ri[11];
-#pragma unroll
-  for (int k = 0; k < 11; ++k) coeffs[k] = slot[EPOLY_COEFFS + k];
-  PrEigState<10> S;
-  int degree = 0;
-  int nroots = pr_poly_roots_begin<11>(coeffs, rr, ri, S, degree);
-  if (nroots == -2) {
-    if (!pr_eig_init(S)) {  // n == 0 or a matrix of zeros: every eigenvalue is 0
-      double re[10], im[10];
-#pragma unroll
-      for (int i = 0; i < 10; ++i) re[i] = im[i] = 0.0;
-      nroots = pr_poly_roots_end<11>(true, re, im, S.n, degree, rr, ri);
-    } else if (S.iu < 0) {  // nothing to iterate (norm 0)
-      double re[10], im[10];
-      const bool ok = pr_eig_finish(S, re, im);
-      nroots = pr_poly_roots_end<11>(ok, re, im, S.n, degree, rr, ri);
-    } else {
-      int e = 0;
-#pragma unroll
-      for (int j = 0; j < 10; ++j) {
-#pragma unroll
-        for (int i = 0; i < 10; ++i) {
-          if (i <= j + 1) p.e_work[RR_E(h, e++)] = S.T[j * 10 + i];
-        }
-      }
-      p.e_work[RR_E(h, 64)] = S.scale;
-      p.e_work[RR_E(h, 65)] = S.norm;
-      p.e_work[RR_E(h, 66)] = (double)S.n;
-      p.e_work[RR_E(h, 67)] = (double)degree;
-      p.nmodels[h] = RR_PENDING;
-      return;
-    }
-  }
-  p.nmodels[h] = e_roots_code_store(slot, nroots, rr, ri);
-}
-__global__ __launch_bounds__(64, 2) void k_roots_e_iter(const VerifyParams p) {
-  const int lane = threadIdx.x;
-  const uint64_t total = (uint64_t)p.n_chunk * p.batch;
-  const uint64_t span0 = (uint64_t)blockIdx.x * RR_SPAN;
-  if (span0 >= total) return;
-  const uint64_t span1 = span0 + RR_SPAN < total ? span0 + RR_SPAN : total;
-  uint64_t next = span0;  // wave-uniform: the first hypothesis not handed out yet
-  PrEigState<10> S;
-#pragma unroll
-  for (int e = 0; e < 100; ++e) S.T[e] = 0.0;
-  S.scale = S.norm = S.exshift = 0.0;
-  S.n = 0;
-  S.iu = -1;
-  S.iter = S.total_iter = 0;
-  S.failed = false;
-  uint64_t item = 0;
-  bool active = false;  // S holds the unfinished iteration of hypothesis `item`
-  for (;;) {
-    const unsigned long long idle_mask = __ballot(!active);
-    if (idle_mask != 0ull && next < span1) {
-      const int n_idle = (int)__popcll(idle_mask);
-      if (n_idle >= RR_MIN_IDLE || n_idle == 64) {
-        if (!active) {
-          const uint64_t it = next + (uint64_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
-          if (it < span1) {
-            const uint32_t pl = (uint32_t)(it / p.batch);
-            const int t = (int)(it - (uint64_t)pl * p.batch);
-            const FamState* fs = p.fam_state + (size_t)(p.pair0 + pl) * 3 + FAM_E;
-            if (fs->active && t < (int)fs->nb && p.nmodels[it] == RR_PENDING) {
-              int e = 0;
-#pragma unroll
-              for (int j = 0; j < 10; ++j) {
-#pragma unroll
-                for (int i = 0; i < 10; ++i) {
-                  if (i <= j + 1)
-                    S.T[j * 10 + i] = p.e_work[RR_E(it, e++)];
-                  else if (i <= j + 3)
-                    S.T[j * 10 + i] = 0.0;  // the bulge's places: zero between passes
-                }
-              }
-              S.scale = p.e_work[RR_E(it, 64)];
-              S.norm = p.e_work[RR_E(it, 65)];
-              S.n = (int)p.e_work[RR_E(it, 66)];
-              S.exshift = 0.0;
-              S.iter = 0;
-              S.total_iter = 0;
-              S.failed = false;
-              S.iu = S.n - 1;  // (pending records have norm != 0 and n >= 3)
-              item = it;
-              active = true;
-            }
-          }
-        }
-        const uint64_t left = span1 - next;
-        next += (uint64_t)n_idle < left ? (uint64_t)n_idle : left;
-      }
-    }
-    if (__ballot(active) == 0ull) {
-      if (next >= span1) break;
-      continue;
-    }
-    if (active) {
-      pr_eig_step(S);
-      if (S.iu < 0 || S.failed) {
-        int e = 0;
-#pragma unroll
-        for (int j = 0; j < 10; ++j) {
-#pragma unroll
-          for (int i = 0; i < 10; ++i) {
-            if (i <= j + 1) p.e_work[RR_E(item, e++)] = S.T[j * 10 + i];
-          }
-        }
-        p.nmodels[item] = S.failed ? RR_FAILED : RR_ITERATED;
-        active = false;
-      }
-    }
-  }
-}
-__global__ __launch_bounds__(64, 2) void k_roots_e_finish(const VerifyParams p) {
-  const uint32_t pl = blockIdx.x;
-  const uint32_t pi = p.pair0 + pl;
-  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
-  if (!fs->active) return;
-  const int t = blockIdx.y * 64 + threadIdx.x;
-  if (t >= (int)fs->nb) return;
-  const uint64_t h = (uint64_t)pl * p.batch + t;
-  double* slot = p.models + (size_t)h * 90;
-  int code = p.nmodels[h];
-  if (code == RR_ITERATED || code == RR_FAILED) {
-    PrEigState<10> S;
-#pragma unroll
-    for (int e = 0; e < 100; ++e) S.T[e] = 0.0;
-    int e = 0;
-#pragma unroll
-    for (int j = 0; j < 10; ++j) {
-#pragma unroll
-      for (int i = 0; i < 10; ++i) {
-        if (i <= j + 1) S.T[j * 10 + i] = p.e_work[RR_E(h, e++)];
-      }
-    }
-    S.scale = p.e_work[RR_E(h, 64)];
-    S.n = (int)p.e_work[RR_E(h, 66)];
-    const int degree = (int)p.e_work[RR_E(h, 67)];
-    S.failed = code == RR_FAILED;
-    double re[10], im[10], rr[11], ri[11];
-    const bool ok = pr_eig_finish(S, re, im);
-    const int nroots = pr_poly_roots_end<11>(ok, re, im, S.n, degree, rr, ri);
-    code = e_roots_code_store(slot, nroots, rr, ri);
-  }
-  p.nmodels[h] = e_models_body(slot, code, slot);
-}
-
+#ifdef DSM_CHECK_BUILD  // cross-check schedule: libdagsfm_mi355x_check.so only
 // The round-2 form of the same kernel, kept for comparison (DSM_ROOTS_LDS=1): the companion matrix of every lane in
 // lane-interleaved LDS (51 KB per wave), dynamically indexed.
 __global__ __launch_bounds__(64) void k_roots_e_lds(const VerifyParams p) {
@@ -2560,6 +2373,8 @@ __global__ __launch_bounds__(64) void k_roots_e_lds(const VerifyParams p) {
   }
   p.nmodels[(size_t)pl * p.batch + t] = e_models_body(slot, code, slot);
 }
+
+#endif  // DSM_CHECK_BUILD
 
 // The bound step with a lane per MODEL in compacted order.  A five-point hypothesis has 0..10 models (4.6 on average), a seven-point one
 // 1 or 3 (2.46): a lane per (trial, model) SLOT leaves 54 % / 18 % of the lanes without one.  Here a workgroup takes 64 consecutive
@@ -3981,7 +3796,12 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint
                          hipStream_t st) {
   if (!p.n_work || !n_blocks) return;
   const dim3 g4((p.n_work + 64 / LOJ_G - 1) / (64 / LOJ_G)), g64((p.n_work + 63) / 64);
+#ifdef DSM_CHECK_BUILD
   const bool reg_jacobi = !p.dbg_jacobi_groups;  // =1: the 8-lane-group kernel for every problem (round-2 form)
+#else
+  const bool reg_jacobi = true;
+  (void)g4;
+#endif
   const bool reg_prepare = p.lo_reg_prepare && n_wave_prepare < p.n_work;
   // the general kernels work through k_replay_lo's list of the problems that need them (a handful per iteration: the
   // first local optimisations of a pair have 6 - 9 inliers), not through the whole queue
@@ -3996,9 +3816,11 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint
     if (reg_jacobi) {
       hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
       if (n_small_jacobi) hipLaunchKernelGGL((k_lo_jacobi<FAM_E, true>), g4g, dim3(64), 0, st, pg);
-    } else {
-      hipLaunchKernelGGL((k_lo_jacobi<FAM_E, false>), g4, dim3(64), 0, st, p);
     }
+#ifdef DSM_CHECK_BUILD
+    else
+      hipLaunchKernelGGL((k_lo_jacobi<FAM_E, false>), g4, dim3(64), 0, st, p);
+#endif
     hipLaunchKernelGGL(k_lo_e_build, g64, dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_lo_e_lu, g64, dim3(64), ELU_SMEM, st, p);
     hipLaunchKernelGGL(k_lo_e_roots_models, g64, dim3(64), 0, st, p);
@@ -4009,9 +3831,11 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint
     if (reg_jacobi) {
       hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
       if (n_small_jacobi) hipLaunchKernelGGL((k_lo_jacobi<FAM_F, true>), g4g, dim3(64), 0, st, pg);
-    } else {
-      hipLaunchKernelGGL((k_lo_jacobi<FAM_F, false>), g4, dim3(64), 0, st, p);
     }
+#ifdef DSM_CHECK_BUILD
+    else
+      hipLaunchKernelGGL((k_lo_jacobi<FAM_F, false>), g4, dim3(64), 0, st, p);
+#endif
     hipLaunchKernelGGL(k_lo_finish<FAM_F>, g64, dim3(64), 0, st, p);
   }
   if (fam == FAM_H) {  // every H problem takes the general prepare: the list is the queue
@@ -4019,9 +3843,11 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint
     if (reg_jacobi) {
       hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
       if (n_small_jacobi) hipLaunchKernelGGL((k_lo_jacobi<FAM_H, true>), g4g, dim3(64), 0, st, pg);
-    } else {
-      hipLaunchKernelGGL((k_lo_jacobi<FAM_H, false>), g4, dim3(64), 0, st, p);
     }
+#ifdef DSM_CHECK_BUILD
+    else
+      hipLaunchKernelGGL((k_lo_jacobi<FAM_H, false>), g4, dim3(64), 0, st, p);
+#endif
     hipLaunchKernelGGL(k_lo_finish<FAM_H>, g64, dim3(64), 0, st, p);
   }
 }
@@ -4044,17 +3870,12 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
   if (fam == FAM_E) {
     hipLaunchKernelGGL(k_solve_e_build, grid, dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_solve_e_lu, grid, dim3(64), ELU_SMEM, st, p);
-    const bool roots_lds = p.dbg_roots_lds != 0;
-    if (roots_lds) {
+#ifdef DSM_CHECK_BUILD
+    if (p.dbg_roots_lds != 0)
       hipLaunchKernelGGL(k_roots_e_lds, grid, dim3(64), 100 * 64 * sizeof(double), st, p);
-    } else if (p.dbg_roots_refill) {  // experimental: lane-level refill (three kernels), see k_roots_e_iter
-      const uint64_t total = (uint64_t)p.n_chunk * p.batch;
-      hipLaunchKernelGGL(k_roots_e_init, grid, dim3(64), 0, st, p);
-      hipLaunchKernelGGL(k_roots_e_iter, dim3((uint32_t)((total + RR_SPAN - 1) / RR_SPAN)), dim3(64), 0, st, p);
-      hipLaunchKernelGGL(k_roots_e_finish, grid, dim3(64), 0, st, p);
-    } else {
+    else
+#endif
       hipLaunchKernelGGL(k_roots_e, grid, dim3(64), 0, st, p);
-    }
     // scoring: a lane per model (k_prescore_compact<E> -> k_score_needed<E>), or the wave-per-hypothesis kernel with the bound step fused in
     // (DSM_SCORE_PREFILTER=3; also what =0 runs, without its bound step)
     const size_t smem2e = smem + (size_t)p.batch * 10 * 2;
@@ -4062,8 +3883,10 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
     if ((p.score_prefilter & 1) && !(p.score_prefilter & 2) && p.batch * 10 <= 65535 && smem2e <= 64 * 1024) {  // 1, and 5 = check
       hipLaunchKernelGGL(k_prescore_compact<FAM_E>, dim3(p.n_chunk, (p.batch * 10 + 63) / 64), dim3(64), smem, st, p);
       hipLaunchKernelGGL(k_score_needed<FAM_E>, dim3(nb_needed_e), dim3(64), smem2e, st, p);
+#ifdef DSM_CHECK_BUILD
     } else if (p.score_prefilter & 4) {
       hipLaunchKernelGGL(k_models_score_e<true>, grid, dim3(64), smem, st, p);
+#endif
     } else {
       hipLaunchKernelGGL(k_models_score_e<false>, grid, dim3(64), smem, st, p);
     }
@@ -4111,9 +3934,11 @@ static void launch_final_pose_finish(const VerifyParams& p, uint32_t n_blocks, h
 }
 void launch_vp_final(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
   if (!p.n_pairs || !n_blocks) return;
+#ifdef DSM_CHECK_BUILD
   if (p.dbg_final_waves == 1)
     hipLaunchKernelGGL(k_verify_final<1>, dim3(n_blocks), dim3(64), verify_smem_bytes(p.n_max), st, p);
   else
+#endif
     hipLaunchKernelGGL(k_verify_final<2>, dim3(n_blocks), dim3(64), verify_smem_bytes(p.n_max), st, p);
   launch_final_pose_finish(p, n_blocks, st);
 }

@@ -462,6 +462,7 @@ void Database::DeleteInlierMatches(image_t a, image_t b) const {
 
 void Database::BeginTransaction() const { Exec("BEGIN TRANSACTION;"); }
 void Database::EndTransaction() const { Exec("END TRANSACTION;"); }
+bool Database::InTransaction() const { return database_ != nullptr && sqlite3_get_autocommit(database_) == 0; }
 void Database::SetBulkLoadJournal(bool in_memory) const { Exec(in_memory ? "PRAGMA journal_mode=MEMORY;" : "PRAGMA journal_mode=WAL;"); }
 
 void Database::RollbackTransaction() const {

@@ -62,6 +62,7 @@ class Database {
   void BeginTransaction() const;
   void EndTransaction() const;
   void RollbackTransaction() const;
+  bool InTransaction() const;  // sqlite3_get_autocommit() == 0
   // Bulk-load setting for a run that only APPENDS rows (extension; measured in tools/sqlite_ceiling.py): the rollback journal
   // in memory instead of the write-ahead log, so that every page of the new rows is written once instead of twice (WAL +
   // checkpoint).  ROLLBACK keeps working; a process that dies inside the transaction can leave the file damaged where WAL

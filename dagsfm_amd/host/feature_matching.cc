@@ -103,13 +103,20 @@ const FeatureDescriptors& FeatureMatcherCache::GetDescriptors(image_t image_id) 
   return f.descriptors;
 }
 
+// Run() owns its block loop and Flush()es at its end, so its matcher may leave the last slice of a block in flight while the
+// next block is on the devices (SiftMatchingOptions::defer_write_back); the transactions are then the writer thread's.
+static SiftMatchingOptions RunLoopOptions(SiftMatchingOptions o) {
+  o.defer_write_back = o.async_write_back;
+  return o;
+}
+
 ExhaustiveFeatureMatcher::ExhaustiveFeatureMatcher(const ExhaustiveMatchingOptions& options,
                                                    const SiftMatchingOptions& match_options, const std::string& database_path)
     : options_(options),
       match_options_(match_options),
       database_(database_path),
       cache_(5 * options_.block_size, &database_),
-      matcher_(match_options, &database_, &cache_) {
+      matcher_(RunLoopOptions(match_options), &database_, &cache_) {
   if (!options_.Check()) throw std::invalid_argument("ExhaustiveMatchingOptions::Check failed");
 }
 
@@ -152,15 +159,23 @@ bool ExhaustiveFeatureMatcher::Run() {
   const auto t_run = std::chrono::steady_clock::now();
   struct JournalGuard {  // WAL again however Run() ends
     const Database* db;
+    SiftFeatureMatcher* matcher;
     ~JournalGuard() {
       if (db) {
+        // on the exception path a writer thread may still hold an open transaction on this connection: leaving the
+        // rollback-journal mode rewrites the file header and fails inside a transaction, so the writer is
+        // joined first; its own error, if any, has been or will be reported by whoever unwinds
+        try {
+          matcher->Flush();
+        } catch (...) {
+        }
         try {
           db->SetBulkLoadJournal(false);
         } catch (...) {
         }
       }
     }
-  } journal_guard{match_options_.bulk_load_journal ? &database_ : nullptr};
+  } journal_guard{match_options_.bulk_load_journal ? &database_ : nullptr, &matcher_};
   if (match_options_.bulk_load_journal) database_.SetBulkLoadJournal(true);
   const size_t block_size = static_cast<size_t>(options_.block_size);
   const size_t num_blocks = (image_ids.size() + block_size - 1) / block_size;
@@ -180,7 +195,9 @@ bool ExhaustiveFeatureMatcher::Run() {
           }
         }
       }
-      if (match_options_.async_write_back) {  // the write-back thread owns the transaction of its rows
+      if (match_options_.async_write_back) {
+        // the write-back thread owns the transaction of its rows, one per slice: a failure leaves the earlier slices of
+        // the block committed (complete rows of pairs a re-run skips) and rolls back the failing slice only
         matcher_.Match(image_pairs);
       } else {
         DatabaseTransaction database_transaction(&database_);
@@ -534,17 +551,23 @@ using namespace dagsfm_amd;
 extern "C" {
 
 // Runs ExhaustiveFeatureMatcher over database_path.  Returns 0 on success.
-// gpu_index: SiftMatchingOptions::gpu_index ("-1" or null: all devices); async_write_back: this repository's extension.
+// gpu_index: SiftMatchingOptions::gpu_index ("-1" or null: all devices).
+// async_write_back: SiftMatchingOptions::async_write_back -- 0 off, > 0 on, < 0 the option's default (on).
+// flags: DSM_HOST_FLAG_* below, each bit one thing (the old entry points packed them into async_write_back).
 // Nothing here reads the process environment: the CLI parses its own flags (exhaustive_matcher_main.cc).
 // match_slice_pairs: SiftMatchingOptions::match_slice_pairs (< 0: its default).
-int dsm_host_exhaustive_matcher_ex3(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,
+enum {
+  DSM_HOST_FLAG_PRINT_TIMING = 1u,       // one line of stage timers on stderr
+  DSM_HOST_FLAG_BULK_LOAD_JOURNAL = 2u,  // SiftMatchingOptions::bulk_load_journal
+  DSM_HOST_FLAG_SERIAL_SETUP = 4u        // ExhaustiveMatchingOptions::overlap_setup = false
+};
+int dsm_host_exhaustive_matcher_ex4(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,
                                     double max_ratio, double max_distance, int cross_check, int min_num_inliers,
                                     int guided_matching, int multiple_models, const char* gpu_index, int async_write_back,
-                                    int match_slice_pairs) {
-  const bool print_timing = async_write_back & 2;  // bit 1 of the flag word: print the stage timers
-  const bool bulk_load_journal = async_write_back & 4;  // bit 2: SiftMatchingOptions::bulk_load_journal
-  const bool serial_setup = async_write_back & 8;       // bit 3: ExhaustiveMatchingOptions::overlap_setup = false
-  async_write_back &= 1;
+                                    unsigned flags, int match_slice_pairs) {
+  const bool print_timing = flags & DSM_HOST_FLAG_PRINT_TIMING;
+  const bool bulk_load_journal = flags & DSM_HOST_FLAG_BULK_LOAD_JOURNAL;
+  const bool serial_setup = flags & DSM_HOST_FLAG_SERIAL_SETUP;
   try {
     ExhaustiveMatchingOptions eo;
     eo.block_size = block_size;
@@ -558,7 +581,7 @@ int dsm_host_exhaustive_matcher_ex3(const char* database_path, int block_size, i
     }
     mo.guided_matching = guided_matching != 0;
     mo.multiple_models = multiple_models != 0;
-    mo.async_write_back = async_write_back != 0;  // overlap SQLite with the device
+    if (async_write_back >= 0) mo.async_write_back = async_write_back != 0;  // overlap SQLite with the device (default: on)
     mo.bulk_load_journal = bulk_load_journal;
     if (match_slice_pairs >= 0) mo.match_slice_pairs = match_slice_pairs;
     if (gpu_index && *gpu_index) mo.gpu_index = gpu_index;
@@ -579,6 +602,16 @@ int dsm_host_exhaustive_matcher_ex3(const char* database_path, int block_size, i
     std::cerr << "ERROR: " << e.what() << std::endl;
     return 1;
   }
+}
+
+// The older entry points: async_write_back is a boolean here (any non-zero value = on, nothing else is read from it).
+int dsm_host_exhaustive_matcher_ex3(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,
+                                    double max_ratio, double max_distance, int cross_check, int min_num_inliers,
+                                    int guided_matching, int multiple_models, const char* gpu_index, int async_write_back,
+                                    int match_slice_pairs) {
+  return dsm_host_exhaustive_matcher_ex4(database_path, block_size, use_prior_defaults, random_seed, max_ratio, max_distance, cross_check,
+                                         min_num_inliers, guided_matching, multiple_models, gpu_index, async_write_back != 0, 0u,
+                                         match_slice_pairs);
 }
 
 int dsm_host_exhaustive_matcher_ex2(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,

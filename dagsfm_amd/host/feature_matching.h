@@ -125,6 +125,10 @@ class FeatureMatcherCache {
     std::lock_guard<std::recursive_mutex> lock(mutex_);
     database_->EndTransaction();
   }
+  bool InTransaction() const {  // the connection is inside a BEGIN ... END (whoever opened it)
+    std::lock_guard<std::recursive_mutex> lock(mutex_);
+    return database_->InTransaction();
+  }
   // After a failed batch: drops the open transaction's rows (if one is open) and re-reads which pairs the database
   // holds, so that ExistsMatches / ExistsInlierMatches answer for the database again (not in the reference, whose
   // CHECKs abort the process instead of unwinding).
@@ -210,6 +214,8 @@ struct NativeTraits {
   }
   static uint32_t RandomSeed(const Options& o) { return o.random_seed; }
   static bool AsyncWriteBack(const Options& o) { return o.async_write_back; }
+  static bool DeferWriteBack(const Options& o) { return o.async_write_back && o.defer_write_back; }
+  static bool InTransaction(const Cache* c) { return c->InTransaction(); }
   static size_t MatchSlicePairs(const Options& o) { return o.match_slice_pairs > 0 ? static_cast<size_t>(o.match_slice_pairs) : 0; }
 };
 

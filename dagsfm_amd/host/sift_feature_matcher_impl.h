@@ -203,6 +203,8 @@ class SiftFeatureMatcherT {
     to.multiple_models = options_.multiple_models ? 1 : 0;  // multiple_ignore_watermark stays at its default (true)
     Run(to_match, nullptr, stale_inliers_match, mo, to);
     Run(to_verify_only, &existing, stale_inliers_verify, mo, to);
+    // every row of this call is written when Match() returns (unless the caller asked for the deferred form and Flush()es)
+    FlushUnlessDeferred(std::integral_constant<bool, Traits::kAsyncWriteBack>());
   }
 
  private:
@@ -430,6 +432,11 @@ class SiftFeatureMatcherT {
     }
   };
 
+  void FlushUnlessDeferred(std::false_type) {}
+  void FlushUnlessDeferred(std::true_type) {
+    if (!Traits::DeferWriteBack(options_)) Flush();
+  }
+
   // host projects without this repository's asynchronous write-back extension (the reference's own Options / Cache)
   bool WriteBackAsync(const std::shared_ptr<WriteBatch>&, std::false_type) { return false; }
 
@@ -445,23 +452,34 @@ class SiftFeatureMatcherT {
       for (const auto& pr : batch->prs) cache_->MarkPending(pr.first, pr.second);
     }
     SiftFeatureMatcherT* const self = this;
-    writer_ = std::thread([self, batch]() {
+    // a caller that holds a transaction on the connection (the reference's Run(): one DatabaseTransaction around Match(),
+    // matching.cc:903) keeps owning it: the rows go into it, and Match() joins the writer before it returns.  Read here, on
+    // the caller's thread, with no writer in flight.  The deferred form outlives Match(): its writer must own the transaction.
+    const bool callers_transaction = Traits::InTransaction(cache_);
+    if (callers_transaction && Traits::DeferWriteBack(options_))
+      throw std::logic_error("SiftFeatureMatcher: defer_write_back needs the connection outside a transaction (the writer thread owns its own)");
+    writer_ = std::thread([self, batch, callers_transaction]() {
       typename Traits::Cache* const cache = batch->cache;
       bool open = false;
       try {
         const Clock::time_point t_write = Clock::now();
-        cache->BeginTransaction();
-        open = true;
+        if (!callers_transaction) {
+          cache->BeginTransaction();
+          open = true;
+        }
         batch->Write();
-        cache->EndTransaction();  // a failing COMMIT (SQLITE_BUSY, SQLITE_FULL) leaves the transaction open:
-        open = false;             // only a COMMIT that returned has closed it
+        if (!callers_transaction) {
+          cache->EndTransaction();  // a failing COMMIT (SQLITE_BUSY, SQLITE_FULL) leaves the transaction open:
+          open = false;             // only a COMMIT that returned has closed it
+        }
         self->timings_.write_s += Seconds(t_write);  // (one write-back in flight: Flush() joins before the next starts)
       } catch (...) {
         self->writer_error_ = std::current_exception();
         // close the transaction without its rows and make the cache say what the database says again: the batch's
-        // pairs were marked as present above and must not be skipped by a later Match()
+        // pairs were marked as present above and must not be skipped by a later Match().  (In a caller's transaction the
+        // rows are the caller's to roll back: Match() rethrows this error from its Flush().)
         try {
-          cache->RollbackTransaction(open);
+          if (!callers_transaction) cache->RollbackTransaction(open);
         } catch (...) {
         }
       }

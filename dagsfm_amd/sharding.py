@@ -174,7 +174,7 @@ class CtxSource:
         import ctypes
         from . import capi
         self.ctx, self.n, self.dev = ctx, n_pairs, device
-        self.L = capi.lib()
+        self.L = ctx._L
         self.tvg_bytes = ctypes.sizeof(capi.TwoViewGeometry)
 
     def _chk(self, rc):

@@ -19,11 +19,31 @@ def declared_symbols():
 def test_library_exports_every_declared_symbol():
     from dagsfm_amd import capi
     assert os.path.exists(capi.LIB_PATH), "build the library first (python -c 'import __graft_entry__ as g; g.build()')"
-    lib = ctypes.CDLL(capi.LIB_PATH)
     syms = declared_symbols()
     assert len(syms) >= 10
-    for s in syms:
-        assert hasattr(lib, s), "missing export: " + s
+    for path in (capi.LIB_PATH, capi.CHECK_LIB_PATH):  # the product and the check build of the same sources
+        assert os.path.exists(path), path
+        lib = ctypes.CDLL(path)
+        for s in syms:
+            assert hasattr(lib, s), "missing export in %s: %s" % (os.path.basename(path), s)
+
+
+def test_product_library_is_lean():
+    """the cross-check schedules live in the check build; the product knows at most 8 scheduling knobs, its
+    kernels do not include the legacy / comparison ones, and it stays under 3.5 MB."""
+    import subprocess
+    from dagsfm_amd import capi
+    assert len(capi.PRODUCT_OPTION_KEYS) <= 8 and not set(capi.PRODUCT_OPTION_KEYS) & set(capi.CHECK_OPTION_KEYS)
+    assert os.path.getsize(capi.LIB_PATH) <= 3.5 * 2 ** 20
+    ctx_h = open(os.path.join(ROOT, "dagsfm_amd", "csrc", "ctx.h")).read()
+    for key in capi.PRODUCT_OPTION_KEYS + capi.CHECK_OPTION_KEYS:  # the binding's key lists are the library's
+        assert '"%s"' % key in ctx_h, key
+    names = {}
+    for path in (capi.LIB_PATH, capi.CHECK_LIB_PATH):
+        names[path] = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    for kernel in ("k_ransac", "k1_best_rows_dot4", "k_roots_e_lds"):
+        assert kernel not in names[capi.LIB_PATH], kernel
+        assert kernel in names[capi.CHECK_LIB_PATH], kernel
 
 
 def test_option_defaults_match_reference():

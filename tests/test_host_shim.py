@@ -107,6 +107,7 @@ def test_database_round_trip_and_dagsfm_columns(tmp_path):
 # with the asynchronous write-back -- slice k is written while slice k + 1 is on the device; test_bulk_load_journal_... slices a
 # blocking run
 _SLICED = ["--SiftMatching.async_write_back", "1", "--SiftMatching.match_slice_pairs", "4"]
+_BLOCKING = ["--SiftMatching.async_write_back", "0"]  # (the asynchronous write-back is the default since round 5)
 
 
 @pytest.mark.gpu
@@ -114,7 +115,7 @@ _SLICED = ["--SiftMatching.async_write_back", "1", "--SiftMatching.match_slice_p
 def test_exhaustive_matcher_drop_in(tmp_path, oracle, async_write, monkeypatch):
     """colmap exhaustive_matcher equivalent over a synthetic database.db == oracle, incl. resume semantics; also with
     the write-back on a background thread (SiftMatchingOptions::async_write_back, DSM_ASYNC_WRITE_BACK)."""
-    extra = _SLICED if async_write == "sliced" else []
+    extra = _SLICED if async_write == "sliced" else (_BLOCKING if async_write is False else [])
     if async_write is True:
         monkeypatch.setenv("DSM_ASYNC_WRITE_BACK", "1")
     from dagsfm_amd import capi, synthetic
@@ -184,7 +185,7 @@ def _visit_order(n, block_size):
 def test_exhaustive_matcher_blocks_and_swapped_pairs(tmp_path, oracle, async_write, monkeypatch):
     """block_size < #images: some pairs are visited as (larger id, smaller id); the rows are stored swapped /
     inverted exactly as Database::WriteMatches / WriteTwoViewGeometry do (database.cc:681-751)."""
-    extra = [_SLICED[0], _SLICED[1], _SLICED[2], "2"] if async_write == "sliced" else []
+    extra = [_SLICED[0], _SLICED[1], _SLICED[2], "2"] if async_write == "sliced" else (_BLOCKING if async_write is False else [])
     if async_write is True:  # several Match() calls: the write-back of one block overlaps the device work of the next
         monkeypatch.setenv("DSM_ASYNC_WRITE_BACK", "1")
     from dagsfm_amd import capi, synthetic
@@ -327,7 +328,7 @@ def test_failed_device_call_leaves_existing_rows_alone(tmp_path, async_write, mo
     were gone.  Now the deletes travel with the new rows.  Set-up: a finished database, one two_view_geometries row
     removed (so that pair is on the resume path: its `matches` row would be deleted and rewritten), and a camera
     model id the device rejects -- the run must fail and every row must still be there."""
-    extra = [_SLICED[0], _SLICED[1], _SLICED[2], "2"] if async_write == "sliced" else []
+    extra = [_SLICED[0], _SLICED[1], _SLICED[2], "2"] if async_write == "sliced" else (_BLOCKING if async_write is False else [])
     if async_write is True:
         monkeypatch.setenv("DSM_ASYNC_WRITE_BACK", "1")
     from dagsfm_amd import synthetic

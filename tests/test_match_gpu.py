@@ -204,7 +204,8 @@ def test_dot4_variant_matches_mfma_kernel(dsm, oracle, monkeypatch):
     dsm.set_images(descs)
     dsm.match_pairs(pairs)
     offs0, m0 = dsm.matches()
-    monkeypatch.setenv("DSM_K1_DOT4", "1")
+    monkeypatch.setenv("DSM_K1_DOT4", "1")  # a check-build kernel: from here on `dsm` is the check library's context
+    dsm.set_images(descs)
     dsm.match_pairs(pairs)
     offs1, m1 = dsm.matches()
     assert (offs0 == offs1).all() and (m0 == m1).all() and len(m0) > 100

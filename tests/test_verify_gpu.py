@@ -35,7 +35,8 @@ def test_sampler_matches_libstdcxx(dsm, oracle):
         ref = oracle.sample_sequence(seed, k, total, draws)
         # 1 = the wave sampler of the product path (parallel regeneration / tempering / Lemire, serial swaps),
         # 0 = plain lane-0 loop, 2 = the wave sampler's serial replay path (taken after a Lemire rejection)
-        for mode in ("1", "0", "2"):
+        assert (dsm.debug_sample_sequence(seed, k, total, draws) == ref).all(), (seed, k, total, draws, "product")
+        for mode in ("1", "0", "2"):  # (a check-build switch: these calls go to the check library's context)
             os.environ["DSM_DEBUG_SAMPLER_MODE"] = mode
             try:
                 assert (dsm.debug_sample_sequence(seed, k, total, draws) == ref).all(), (seed, k, total, draws, mode)
@@ -512,7 +513,8 @@ def test_scoring_bounds_hold_on_every_slot(oracle, monkeypatch):
     import importlib.util
     import sys
     monkeypatch.setenv("DSM_SCORE_PREFILTER", "check")
-    ctx = capi.Context(0)
+    ctx = capi.Context(0)  # (the check build: a cross-check switch is in the environment)
+    assert ctx.check
     skipped_ordinary = None
     for planar, outlier_frac, prior, max_error in ((False, 0.2, 1, 4.0), (True, 0.2, 1, 4.0), (False, 0.5, 1, 4.0), (False, 0.2, 0, 1.0),
                                                   (False, 0.2, 1, 12.0)):
@@ -561,7 +563,16 @@ def test_scoring_bounds_hold_on_every_slot(oracle, monkeypatch):
 def test_debug_options_are_per_context_and_checked():
     """dsm_set_debug_option (round 4): the library reads no environment; a switch belongs to ONE context, an unknown key is an
     error, NULL removes a key.  (The Python binding forwards DSM_* variables of the process through this call.)"""
-    a, b = capi.Context(0), capi.Context(0)
+    a, b = capi.Context(0, check=True), capi.Context(0)  # a: the check build (cross-check switches), b: the product
+    assert len(capi.PRODUCT_OPTION_KEYS) <= 8
+    for key in capi.PRODUCT_OPTION_KEYS:  # the product knows its scheduling knobs ...
+        b.set_debug_option(key, "1")
+        b.set_debug_option(key, None)
+    for key in capi.CHECK_OPTION_KEYS:  # ... and refuses every cross-check switch; the check build takes both kinds
+        with pytest.raises(capi.DsmError):
+            b.set_debug_option(key, "1")
+        a.set_debug_option(key, "1")
+        a.set_debug_option(key, None)
     a.set_debug_option("DSM_VERIFY_LANES", "1")
     assert a._debug.get("DSM_VERIFY_LANES") == "1" and "DSM_VERIFY_LANES" not in b._debug
     with pytest.raises(capi.DsmError):

@@ -12,14 +12,14 @@ def run(ctx, opts, env):
     os.environ.update(env)
     ctx.verify_pairs(opts, user_seed=0, stage_filter=True)
     recs = np.zeros((ctx.n_pairs, ctypes.sizeof(capi.TwoViewGeometry)), dtype=np.uint8)
-    assert capi.lib().dsm_get_two_view_geometries(ctx._h, recs.ctypes.data) == 0
+    assert ctx._L.dsm_get_two_view_geometries(ctx._h, recs.ctypes.data) == 0
     return recs, [t for t in ctx.two_view_geometries()]
 
 n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 scene = synthetic.Scene(n_img, 4096, seed=0)
 ims = [scene.image(i) for i in range(n_img)]
 pairs = synthetic.exhaustive_pairs(n_img)
-ctx = capi.Context(0)
+ctx = capi.Context(0, check=True)
 cams = [capi.simple_pinhole(scene.focal, scene.width / 2.0, scene.height / 2.0, scene.width, scene.height, 1) for _ in range(n_img)]
 ctx.set_images([im[0] for im in ims], [im[1] for im in ims], cams)
 ctx.match_pairs(pairs)

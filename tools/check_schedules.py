@@ -8,11 +8,14 @@ produce byte-identical TwoViewGeometry records and inlier matches on the whole w
             the default since round 3 computes the tail's local optimisations as parallel items, k_tail_enum / k_tail_lo)
   final_1wave   k_verify_final compiled for one wave per SIMD (no register spill; DSM_FINAL_WAVES=1)
   no_prefilter  F / H scoring by the plain k_score instead of bound + exact (DSM_SCORE_PREFILTER=0; round 4)
-  roots_refill  (--experimental) the 5-point roots by k_roots_e_init / _iter / _finish: lane-level refill (DSM_ROOTS_REFILL=1)
   e_fused       the essential family's scoring by the wave-per-hypothesis kernel with the bound step fused in (k_models_score_e,
                 DSM_SCORE_PREFILTER=3) instead of a lane per model (k_prescore_compact + k_score_needed; with it F takes the slot-per-lane k_prescore)
   one_lane  the batched schedule on a single lane (DSM_VERIFY_LANES=1; the default deals the list out to two lanes)
   legacy    one k_ransac kernel per family, lane-0 sampler, per-lane scratch solvers (DSM_VERIFY_LEGACY=1; --legacy)
+The schedules marked * exist in the CHECK build only (libdagsfm_mi355x_check.so, csrc/ctx.h): `batched` and the scheduling knobs
+run on the PRODUCT library, the * schedules on a second context of the check library over the same matches, and every
+one is compared with the product's `batched` records -- so the comparison also shows that the two builds agree.
+  * no_prefilter, e_fused, final_1wave, legacy
 This exercises the paths too rare for the oracle-sized tests (a Lemire rejection in the sampler happens for a few
 dozen pairs of config 2; pairs with > 15 local optimisations in one round).
 
@@ -40,9 +43,6 @@ def run(ctx, opts, schedule):
         os.environ["DSM_SCORE_PREFILTER"] = "0"
     if schedule == "e_fused":
         os.environ["DSM_SCORE_PREFILTER"] = "3"
-    os.environ.pop("DSM_ROOTS_REFILL", None)
-    if schedule == "roots_refill":
-        os.environ["DSM_ROOTS_REFILL"] = "1"
     os.environ.pop("DSM_FINAL_WAVES", None)
     if schedule == "final_1wave":
         os.environ["DSM_FINAL_WAVES"] = "1"
@@ -55,7 +55,7 @@ def run(ctx, opts, schedule):
         os.environ["DSM_VERIFY_LEGACY"] = "1"
     ctx.verify_pairs(opts, user_seed=0, stage_filter=True)
     recs = np.zeros((ctx.n_pairs, ctypes.sizeof(capi.TwoViewGeometry)), dtype=np.uint8)
-    rc = capi.lib().dsm_get_two_view_geometries(ctx._h, recs.ctypes.data)
+    rc = ctx._L.dsm_get_two_view_geometries(ctx._h, recs.ctypes.data)
     assert rc == 0
     ioffs, inl = ctx.inlier_matches()
     return recs, np.array(ioffs).copy(), np.array(inl).copy(), ctx.verify_kernel_time()
@@ -66,26 +66,36 @@ def main():
     ap.add_argument("--images", type=int, default=500)
     ap.add_argument("--feats", type=int, default=4096)
     ap.add_argument("--legacy", action="store_true", help="also run the (slow) single-kernel-per-family schedule")
-    ap.add_argument("--experimental", action="store_true",
-                    help="also run the schedules that have not been adopted: roots_refill (DSM_ROOTS_REFILL=1: the 5-point roots with lane-level refill)")
     ap.add_argument("--outlier-frac", type=float, default=0.2, help="0.5: the 0.25-inlier-ratio regime (thousands of trials per pair)")
     ap.add_argument("--uncalibrated", action="store_true", help="cameras without a focal-length prior: the F + H path of the decision tree")
     a = ap.parse_args()
     scene = synthetic.Scene(a.images, a.feats, seed=0, outlier_frac=a.outlier_frac)
     ims = [scene.image(i) for i in range(a.images)]
     pairs = synthetic.exhaustive_pairs(a.images)
-    ctx = capi.Context(0)
+    for k in capi.CHECK_OPTION_KEYS:
+        os.environ.pop(k, None)
     cams = [capi.simple_pinhole(scene.focal, scene.width / 2.0, scene.height / 2.0, scene.width, scene.height, 0 if a.uncalibrated else 1) for _ in range(a.images)]
-    ctx.set_images([im[0] for im in ims], [im[1] for im in ims], cams)
-    ctx.match_pairs(pairs)
+    ctxs = {}
+    for check in (False, True):  # the same images and the same matches in both builds
+        c = capi.Context(0, check=check)
+        c.set_images([im[0] for im in ims], [im[1] for im in ims], cams)
+        c.match_pairs(pairs)
+        ctxs[check] = c
+    mo = [np.array(x).copy() for x in ctxs[False].matches()], [np.array(x).copy() for x in ctxs[True].matches()]
+    assert all((u == v).all() for u, v in zip(*mo)), "the two builds must produce the same matches"
     opts = capi.default_two_view_options()
-    r0 = run(ctx, opts, "batched")
+    r0 = run(ctxs[False], opts, "batched")
     ok = True
-    for name in (["roots_refill"] if a.experimental else []) + ["no_prefilter", "e_fused", "one_lane", "no_tail", "tail_inline", "final_1wave", "inline"] + (["legacy"] if a.legacy else []):
-        r1 = run(ctx, opts, name)
+    CHECK_ONLY = ("no_prefilter", "e_fused", "final_1wave", "legacy")
+    for name in ["batched_check_build", "no_prefilter", "e_fused", "one_lane", "no_tail", "tail_inline", "final_1wave", "inline"] + (["legacy"] if a.legacy else []):
+        use_check = name in CHECK_ONLY or name == "batched_check_build"
+        r1 = run(ctxs[use_check], opts, "batched" if name == "batched_check_build" else name)
+        for k in capi.CHECK_OPTION_KEYS:  # the product context must not see a check-only switch
+            os.environ.pop(k, None)
         same = (r0[0] == r1[0]).all() and (r0[1] == r1[1]).all() and (r0[2] == r1[2]).all()
         # num_trials / num_models are the last 32 bytes of the record
-        print("pairs %d  inlier matches %d  batched %.0f ms  %s %.0f ms  identical: %s" % (len(pairs), len(r0[2]), r0[3], name, r1[3], same))
+        print("pairs %d  inlier matches %d  batched (product) %.0f ms  %s (%s build) %.0f ms  identical: %s" % (
+            len(pairs), len(r0[2]), r0[3], name, "check" if use_check else "product", r1[3], same))
         if not same:
             bad = np.nonzero((r0[0] != r1[0]).any(axis=1))[0]
             print("first differing pairs:", bad[:10])
