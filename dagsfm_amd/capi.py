@@ -12,6 +12,9 @@ LIB_PATH = os.environ.get("DSM_LIB_PATH") or os.path.join(_HERE, "libdagsfm_mi35
 # environment when the context is created; everything else, bench.py and the shim included, runs the product library.
 CHECK_LIB_PATH = os.environ.get("DSM_CHECK_LIB_PATH") or os.path.join(_HERE, "libdagsfm_mi355x_check.so")
 
+# the RCCL companion (include/dagsfm_gather.h): multi-GPU assembly of the match graph below the host language
+GATHER_LIB_PATH = os.path.join(_HERE, "libdagsfm_gather.so")
+
 u8p = ctypes.POINTER(ctypes.c_uint8)
 u32p = ctypes.POINTER(ctypes.c_uint32)
 u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -475,4 +478,82 @@ class Context:
     def match_resolve_time(self):
         ms = ctypes.c_double(0)
         self._chk(self._L.dsm_get_match_resolve_time(self._h, ctypes.byref(ms)))
+        return ms.value
+
+
+_gather_lib = None
+
+
+def gather_lib():
+    """libdagsfm_gather.so (include/dagsfm_gather.h); maps librccl, so it is loaded on first use only."""
+    global _gather_lib
+    if _gather_lib is None:
+        if not os.path.exists(GATHER_LIB_PATH):
+            raise DsmError("%s is missing: make -C dagsfm_amd/csrc" % GATHER_LIB_PATH)
+        lib()  # the companion links the product library: resolve it to the in-tree one first
+        G = ctypes.CDLL(GATHER_LIB_PATH)
+        vp = ctypes.c_void_p
+        G.dsm_gather_create.argtypes = [ctypes.POINTER(vp), ctypes.c_uint32, ctypes.POINTER(vp)]
+        G.dsm_gather_destroy.argtypes = [vp]
+        G.dsm_gather_destroy.restype = None
+        G.dsm_gather_last_error.argtypes = [vp]
+        G.dsm_gather_last_error.restype = ctypes.c_char_p
+        G.dsm_gather_match_graph.argtypes = [vp, u32p, ctypes.c_int32]
+        G.dsm_gather_sizes.argtypes = [vp, u64p, u64p, u64p]
+        G.dsm_gather_fetch.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp]
+        G.dsm_gather_device_arrays.argtypes = [vp, ctypes.c_uint32] + [ctypes.POINTER(vp)] * 5
+        G.dsm_gather_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+        _gather_lib = G
+    return _gather_lib
+
+
+class Gather:
+    """dsm_gather over product contexts on distinct devices of this process (one context: a one-rank communicator)."""
+
+    def __init__(self, ctxs):
+        self.ctxs = list(ctxs)
+        assert all(not c.check for c in self.ctxs), "the companion library links the product build"
+        self._G = gather_lib()
+        arr = (ctypes.c_void_p * len(self.ctxs))(*[c._h for c in self.ctxs])
+        self._g = ctypes.c_void_p()
+        rc = self._G.dsm_gather_create(arr, len(self.ctxs), ctypes.byref(self._g))
+        if rc != 0:
+            raise DsmError("dsm_gather_create failed (%d)" % rc)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DsmError("dsm_gather error %d: %s" % (rc, self._G.dsm_gather_last_error(self._g).decode()))
+
+    def close(self):
+        if self._g:
+            self._G.dsm_gather_destroy(self._g)
+            self._g = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def match_graph(self, n_pairs, with_geometry=True, rank=0):
+        """Assembles the shares and fetches the graph from `rank`'s device: (match offsets, matches, records, inlier offsets, inlier matches)."""
+        npairs = np.ascontiguousarray(n_pairs, np.uint32)
+        assert len(npairs) == len(self.ctxs)
+        self._chk(self._G.dsm_gather_match_graph(self._g, npairs.ctypes.data_as(u32p), 1 if with_geometry else 0))
+        N, M, I = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        self._chk(self._G.dsm_gather_sizes(self._g, ctypes.byref(N), ctypes.byref(M), ctypes.byref(I)))
+        moff = np.zeros(N.value + 1, np.uint64)
+        m = np.zeros((max(M.value, 1), 2), np.uint32)
+        if not with_geometry:
+            self._chk(self._G.dsm_gather_fetch(self._g, rank, moff.ctypes.data, m.ctypes.data, None, None, None))
+            return moff, m[:M.value]
+        tv = (TwoViewGeometry * max(N.value, 1))()
+        ioff = np.zeros(N.value + 1, np.uint64)
+        im = np.zeros((max(I.value, 1), 2), np.uint32)
+        self._chk(self._G.dsm_gather_fetch(self._g, rank, moff.ctypes.data, m.ctypes.data, ctypes.addressof(tv), ioff.ctypes.data, im.ctypes.data))
+        return moff, m[:M.value], list(tv)[:N.value], ioff, im[:I.value]
+
+    def time_ms(self):
+        ms = ctypes.c_double()
+        self._chk(self._G.dsm_gather_time(self._g, ctypes.byref(ms)))
         return ms.value

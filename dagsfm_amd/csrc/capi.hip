@@ -1755,6 +1755,8 @@ int dsm_debug_image_to_world(dsm_ctx* ctx, const dsm_camera* camera, uint32_t n,
   return DSM_OK;
 }
 
+int dsm_ctx_device(const dsm_ctx* ctx) { return ctx ? ctx->device : -1; }
+
 int dsm_get_match_kernel_time(dsm_ctx* ctx, double* total_ms, uint32_t* n_launches) {
   if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
   if (!ctx->matched) return fail(ctx, DSM_ERR_NOT_READY, "dsm_match_pairs has not run");

@@ -2068,6 +2068,157 @@ __global__ __launch_bounds__(64, 8) void k_prescore(const VerifyParams p) {
   }
 }
 
+#ifdef DSM_CHECK_BUILD
+// ------------------------------------------------------------------------------------ the H bound step on the matrix pipe (round 5)
+// MEASURED AND NOT ADOPTED -- check build only (DSM_SCORE_PREFILTER=9), kept as the A/B the round-4 verdict asked for:
+// config 2, one lane: k_prescore_h_mfma 44.3 ms against k_prescore<H> 35.6 ms (profiles/r05_prescore_mfma_ab.txt); whole step
+// 525.1 vs 514.2 ms, alternated twice on one box.  Same parity (113 GPU tests), 0 bound violations on ~9 x 10^8 slots.
+// Why it loses: per 16 models x 16 points the VALU form spends 18 x 16 = 288 wave-instructions, this form 14 x 16 = 224 plus
+// twelve v_mfma_f64_16x16x4_f64.  On MI355X the FP64 matrix peak EQUALS the FP64 vector peak (78.6 TF: a 16x16x4 f64 MFMA
+// holds the SIMD's FP64 datapath for 64 cycles), and the measured time is the SUM of the two streams, not their maximum
+// (1 770 cycles per wave and step = 12 x 64 + 224 x ~4.5): the f64 MFMA is another way to issue the same FMAs -- with a
+// quarter of them spent on the zero column of K = (s_0, s_1, 1, 0) -- not a second pipe next to the VALU.  The f32 matrix
+// pipe is separate, but its results would have to be widened again (3 v_cvt per evaluation) or the whole test redone in f32
+// with re-derived margins.
+// k_prescore<H> is VALU-issue-bound (18 FP64 VALU per model x point, profiles/r04_verify_pmc.json) and a third of that is a
+// K = 3 contraction: pd_k = H_k . (s_0, s_1, 1) for the three rows of 64 models against every point -- a 16 x 16 x 4 matrix
+// product per 16 models x 16 points (v_mfma_f64_16x16x4_f64, K = (s_0, s_1, 1, 0)).  Here the matrix pipe computes the three
+// pd rows and the VALU keeps e_k = d_k pd_2 - pd_k, L = e_0^2 + e_1^2, the three compares and the counts: 13 instead of 18.
+// Layout (guide: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D: col = l & 15, row = (l >> 4) + 4 reg):
+//   a wave = 64 consecutive trials as 4 groups of 16 models; lane l feeds group g's A with coefficient (l >> 4) of row r of model
+//   16 g + (l & 15), feeds B with coordinate (l >> 4) of point base + (l & 15), and receives pd_r of models 16 g + (l >> 4) + 4 i
+//   (i = 0..3) at point base + (l & 15): sixteen (model, point) evaluations per lane and 16-point step, their counts summed over
+//   the sixteen lanes that share (l >> 4) at the end (lane (l & 15) = 4 g + i writes model 16 g + (l >> 4) + 4 i).
+// Bounds: the analysis above k_prescore holds with two changes.  (1) The matrix pipe's evaluation order of the K = 4 sum is
+//   not documented; whatever it is -- fused or not -- at most 3 products and 3 additions round (the k = 3 term is exactly 0),
+//   so pd_k lies within 6u A_k (1 + 3u) of the exact value: E_k = PRESCORE_CU_MFMA A_k with PRESCORE_CU_MFMA = 8u in place of 4u (the
+//   thresholds P_min scale with it, every inequality of the derivation is unchanged).  (2) Instead of a per-model P_min in
+//   registers, the model is scaled by the power of two s = 2^-ilogb(P_min) (exact; the test L <= T pd_2^2 is homogeneous in H)
+//   and |s pd_2| is compared with the constant 2 >= s P_min: a stricter test, i.e. at most more uncertain points.  Entries that
+//   underflow under s < 1 are below 2^-1022 where |s pd_2| >= 2 is required of a classified point: a perturbation of 2^-1008
+//   relative, inside the slack between 6u and 8u.  NaN / Inf from an overflowing scale make every compare false (uncertain).
+//   A model whose classification is off (P_min = NaN), a slot without a model: A = 0, nothing is ever classified.
+// Pairs whose points do not fit the LDS take the VALU loop of k_prescore<H> (same results; rigorous bounds either way).
+#define PRESCORE_CU_MFMA 0x1p-50 /* 8u */
+typedef double dsm_f64x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64, 4) void k_prescore_h_mfma(const VerifyParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* spts = reinterpret_cast<double*>(smem_raw);  // min(n_max, VP_LDS_PTS) x 4 doubles
+  const uint32_t pl = blockIdx.x;
+  const uint32_t pi = p.pair0 + pl;
+  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_H;
+  if (!fs->active) return;
+  const int lane = threadIdx.x;
+  const int nb = (int)fs->nb;
+  const int t0 = (int)blockIdx.y * 64;
+  if (t0 >= nb) return;
+  const uint64_t moff = p.match_off[pi];
+  const int n = (int)(p.match_off[pi + 1] - moff);
+  const double* gpts = p.pts_px + 4 * moff;
+  const bool in_lds = n <= VP_LDS_PTS;
+  const double T = p.opt.max_error * p.opt.max_error;
+  const int32_t* nmod = p.nmodels + (size_t)pl * p.batch;
+  const double* gmod = p.models + (size_t)pl * p.batch * 9;
+  int32_t* counts = p.counts + (size_t)pl * p.batch;
+  double* sums = p.sums + (size_t)pl * p.batch;
+  // ---- lane = model: its P_min and the scale that brings it into [1, 2)
+  const int t = t0 + lane;
+  const bool has_slot = t < nb;
+  const bool has_model = has_slot && nmod[has_slot ? t : 0] > 0;
+  double M[9];
+  for (int k = 0; k < 9; ++k) M[k] = has_model ? gmod[(size_t)t * 9 + k] : 0.0;
+  double mx[4];
+  stage_points_with_maxima(gpts, n, in_lds, spts, lane, mx);
+  if (!in_lds) {  // the VALU form (k_prescore<H>'s loop over wave-uniform global addresses)
+    int lb = 0, sure_out = n + 1;
+    if (has_model) {
+      const PreBounds b = prescore_bounds<FAM_H>(M, mx, T);
+      sure_out = 0;
+#pragma unroll 4
+      for (int i = 0; i < n; ++i) prescore_point<FAM_H>(M, b, gpts + (size_t)i * 4, lb, sure_out);
+    }
+    if (has_slot) {
+      counts[t] = n - sure_out;
+      reinterpret_cast<int32_t*>(sums + t)[0] = lb;
+    }
+    return;
+  }
+  double scale = 0.0;
+  {
+    const double t_ok = (T >= 0x1p-6) && (T <= 0x1p40);
+    const bool x_ok = (mx[0] <= 0x1p14) && (mx[1] <= 0x1p14) && (mx[2] <= 0x1p14) && (mx[3] <= 0x1p14);
+    const double A0 = fabs(M[0]) * mx[0] + fabs(M[1]) * mx[1] + fabs(M[2]);
+    const double A1 = fabs(M[3]) * mx[0] + fabs(M[4]) * mx[1] + fabs(M[5]);
+    const double A2 = fabs(M[6]) * mx[0] + fabs(M[7]) * mx[1] + fabs(M[8]);
+    const double E01 = PRESCORE_CU_MFMA * fmax(A0, A1), E2 = PRESCORE_CU_MFMA * A2;
+    const double pmin = fmax(fmax(0x1p34 * E2, 0x1p26 * E01), 0x1p-400);
+    if (has_model && t_ok != 0.0 && x_ok && pmin <= 0x1p300) scale = ldexp(1.0, -ilogb(pmin));  // (NaN fails pmin <= ...: scale 0)
+  }
+  // ---- A operands: coefficient kq = lane >> 4 of row r of model 16 g + (lane & 15), scaled (kq = 3: the zero column)
+  const int kq = lane >> 4, jq = lane & 15;
+  double a[4][3];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int ta = t0 + 16 * g + jq;
+    const double sg = __shfl(scale, 16 * g + jq);
+    const bool live = kq < 3 && sg != 0.0;  // (sg = 0: no slot / no model / classification off -- nothing is read)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) a[g][r] = live ? gmod[(size_t)ta * 9 + 3 * r + kq] * sg : 0.0;
+  }
+  const double t_lo = T * (1.0 - PRESCORE_DELTA), t_hi = T * (1.0 + PRESCORE_DELTA);
+  const dsm_f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+  uint32_t cnt[4][4];  // low half: surely inliers, high half: surely outliers (n <= VP_LDS_PTS < 65 536)
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cnt[g][i] = 0u;
+  for (int base = 0; base < n; base += 16) {
+    const int pt = base + jq;
+    const bool valid = pt < n;
+    const double* q = spts + (size_t)(valid ? pt : n - 1) * 4;
+    const double sv = q[kq & 1];  // (lanes 32..63 read a coordinate they do not use: no divergence around the LDS read)
+    const double bq = kq < 2 ? sv : (kq == 2 ? 1.0 : 0.0);
+    const double d0 = q[2], d1 = q[3];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const dsm_f64x4 pd0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][0], bq, zero4, 0, 0, 0);
+      const dsm_f64x4 pd1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][1], bq, zero4, 0, 0, 0);
+      const dsm_f64x4 pd2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][2], bq, zero4, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double e0 = __builtin_fma(d0, pd2[i], -pd0[i]);
+        const double e1 = __builtin_fma(d1, pd2[i], -pd1[i]);
+        const double L = __builtin_fma(e0, e0, e1 * e1);
+        const double q2 = pd2[i] * pd2[i];
+        const bool ok = valid && fabs(pd2[i]) >= 2.0;
+        const bool sure_in = ok && (L <= t_lo * q2);
+        const bool sure_out = ok && (L >= t_hi * q2);
+        cnt[g][i] += (sure_in ? 1u : 0u) + (sure_out ? 0x10000u : 0u);
+      }
+    }
+  }
+  // ---- totals over the sixteen lanes of a row group; lane (lane & 15) = 4 g + i writes model 16 g + (lane >> 4) + 4 i
+  uint32_t mine = 0u;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t v = cnt[g][i];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+      if (jq == 4 * g + i) mine = v;
+    }
+  const int mw = 16 * (jq >> 2) + kq + 4 * (jq & 3);
+  const int tw = t0 + mw;
+  if (tw < nb) {
+    const bool model_w = nmod[tw] > 0;
+    counts[tw] = model_w ? n - (int)(mine >> 16) : -1;  // -1: no model in this slot
+    reinterpret_cast<int32_t*>(sums + tw)[0] = model_w ? (int)(mine & 0xffffu) : 0;
+  }
+}
+
+#endif  // DSM_CHECK_BUILD
+
 // dynamic LDS: the points (as k_score) + the list of the slots to score exactly (uint16 each, batch * MAXM of them)
 template <int FAM>
 __global__ __launch_bounds__(64, 8) void k_score_needed(const VerifyParams p) {
@@ -3911,7 +4062,13 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
     hipLaunchKernelGGL(k_solve<FAM_H>, grid, dim3(64), 0, st, p);
     const size_t smem2 = smem + (size_t)p.batch * 2;
     if (p.score_prefilter && p.batch <= 65535 && smem2 <= 64 * 1024) {
-      hipLaunchKernelGGL(k_prescore<FAM_H>, grid, dim3(64), smem, st, p);
+      // DSM_SCORE_PREFILTER=9 (check build): the bound step's K = 3 products on the FP64 matrix pipe -- measured slower, see k_prescore_h_mfma
+#ifdef DSM_CHECK_BUILD
+      if (p.score_prefilter & 8)
+        hipLaunchKernelGGL(k_prescore_h_mfma, grid, dim3(64), smem, st, p);
+      else
+#endif
+        hipLaunchKernelGGL(k_prescore<FAM_H>, grid, dim3(64), smem, st, p);
       hipLaunchKernelGGL(k_score_needed<FAM_H>, dim3(nb_needed), dim3(64), smem2, st, p);
     } else {
       hipLaunchKernelGGL(k_score<FAM_H>, grid, dim3(64), smem, st, p);

@@ -891,4 +891,41 @@ int dsm_host_cache_lru_probe(const char* database_path, uint32_t cache_size, con
   }
 }
 
+// Probe of SiftFeatureMatcher::Match's contract under the DEFAULT options (async_write_back on): the caller -- like the
+// reference's ExhaustiveFeatureMatcher::Run, matching.cc:903 -- holds one DatabaseTransaction around Match() over all
+// image pairs, in slices of `match_slice_pairs`.  When Match() has returned every row must already be written INTO THAT
+// transaction (no writer in flight, nothing committed behind the caller's back): rows_inside = what the connection sees
+// before the transaction ends; then the transaction is committed (commit != 0) or rolled back.  Returns 0 on success.
+int dsm_host_probe_match_in_callers_transaction(const char* database_path, int match_slice_pairs, int commit, uint32_t random_seed,
+                                                uint64_t* rows_inside_matches, uint64_t* rows_inside_geometries, int* still_in_transaction) {
+  try {
+    Database db(database_path);
+    FeatureMatcherCache cache(1000, &db);
+    SiftMatchingOptions mo;  // the defaults: async_write_back on, defer_write_back off
+    if (match_slice_pairs >= 0) mo.match_slice_pairs = match_slice_pairs;
+    mo.random_seed = random_seed;
+    if (!mo.async_write_back || mo.defer_write_back) return 3;
+    SiftFeatureMatcher matcher(mo, &db, &cache);
+    if (!matcher.Setup()) return 2;
+    cache.Setup();
+    const std::vector<image_t> ids = cache.GetImageIds();
+    std::vector<std::pair<image_t, image_t>> pairs;
+    for (size_t i = 0; i < ids.size(); ++i)
+      for (size_t j = i + 1; j < ids.size(); ++j) pairs.emplace_back(ids[i], ids[j]);
+    DatabaseTransaction transaction(&db);
+    matcher.Match(pairs);
+    if (still_in_transaction) *still_in_transaction = db.InTransaction() ? 1 : 0;
+    if (rows_inside_matches) *rows_inside_matches = db.NumMatchedImagePairs();
+    if (rows_inside_geometries) *rows_inside_geometries = db.ReadPairIds(true).size();
+    if (commit)
+      transaction.Commit();
+    else
+      transaction.Rollback();
+    return 0;
+  } catch (const std::exception& e) {
+    std::cerr << "ERROR: " << e.what() << std::endl;
+    return 1;
+  }
+}
+
 }  // extern "C"

@@ -126,6 +126,9 @@ int dsm_device_count(void);
  * DSM_ERR_NO_DEVICE where Setup() would return false. */
 int dsm_ctx_create(int device, dsm_ctx** out_ctx);
 void dsm_ctx_destroy(dsm_ctx* ctx);
+/* The HIP device the context is bound to (-1 for NULL): what a companion library needs to place its own buffers and
+ * communicators next to the context (include/dagsfm_gather.h). */
+int dsm_ctx_device(const dsm_ctx* ctx);
 /* Last error text for this context (or for ctx creation when ctx == NULL). */
 const char* dsm_last_error(const dsm_ctx* ctx);
 /* Blocks until all work queued by this context has finished. */

@@ -7,25 +7,42 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    syms = set()
-    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
-        text = open(h).read()
-        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        syms.update(re.findall(r"\b(dsm_[a-z0-9_]+)\s*\(", text))
-    return sorted(syms)
+def declared_symbols(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dsm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_header_is_covered():
+    assert sorted(os.path.basename(h) for h in glob.glob(os.path.join(ROOT, "include", "*.h"))) == ["dagsfm_gather.h", "dagsfm_mi355x.h"]
 
 
 def test_library_exports_every_declared_symbol():
     from dagsfm_amd import capi
     assert os.path.exists(capi.LIB_PATH), "build the library first (python -c 'import __graft_entry__ as g; g.build()')"
-    syms = declared_symbols()
+    syms = declared_symbols("dagsfm_mi355x.h")
     assert len(syms) >= 10
     for path in (capi.LIB_PATH, capi.CHECK_LIB_PATH):  # the product and the check build of the same sources
         assert os.path.exists(path), path
         lib = ctypes.CDLL(path)
         for s in syms:
             assert hasattr(lib, s), "missing export in %s: %s" % (os.path.basename(path), s)
+
+
+def test_gather_library_exports_every_declared_symbol():
+    """include/dagsfm_gather.h = libdagsfm_gather.so, the RCCL companion (maps librccl: a library of its own for that reason)."""
+    from dagsfm_amd import capi
+    assert os.path.exists(capi.GATHER_LIB_PATH), capi.GATHER_LIB_PATH
+    lib = ctypes.CDLL(capi.GATHER_LIB_PATH)
+    syms = [s for s in declared_symbols("dagsfm_gather.h") if s.startswith("dsm_gather_")]
+    assert len(syms) == 8, syms
+    for s in syms:
+        assert hasattr(lib, s), "missing export: " + s
+    import subprocess
+    needed = subprocess.run(["ldd", capi.GATHER_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "librccl" in needed and "libdagsfm_mi355x.so" in needed
+    product = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "librccl" not in product, "a single-GPU host must not map RCCL"
 
 
 def test_product_library_is_lean():

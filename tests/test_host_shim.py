@@ -440,3 +440,44 @@ def test_bulk_load_journal_writes_the_same_rows_and_restores_wal(tmp_path):
         for pid in base_m:
             assert (m[pid] == base_m[pid]).all() and t[pid]["config"] == base_t[pid]["config"] and (t[pid]["inliers"] == base_t[pid]["inliers"]).all()
             assert t[pid]["F"] == base_t[pid]["F"] and t[pid]["E"] == base_t[pid]["E"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("commit", [1, 0])
+def test_match_returns_with_every_row_written_into_the_callers_transaction(tmp_path, commit):
+    """Round 5: the asynchronous write-back is the DEFAULT (SiftMatchingOptions::async_write_back).  The contract a reference
+    caller relies on must hold with it: ExhaustiveFeatureMatcher::Run wraps Match() in one DatabaseTransaction
+    (/root/reference/src/feature/matching.cc:903) and Match() writes before it returns (:819-836).  Here Match() runs over all
+    pairs in slices of 4 (slice k's rows on the writer thread while slice k + 1 is on the device) inside the caller's
+    transaction: when it returns the connection already sees every row, the transaction is still the caller's, a rollback
+    removes them all and a commit keeps them -- identical to the blocking CLI run."""
+    from dagsfm_amd import synthetic
+    L = host()
+    u64 = ctypes.c_uint64
+    L.dsm_host_probe_match_in_callers_transaction.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,
+                                                              ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_int)]
+    n_img = 6
+    scene = synthetic.Scene(n_img, 640, seed=33, n_pool=1800)
+    ims = [scene.image(i) for i in range(n_img)]
+    path = str(tmp_path / "database.db")
+    dbutil.create(path, [(im[0], im[1]) for im in ims], prior=True)
+    nm, ng, open_ = u64(0), u64(0), ctypes.c_int(0)
+    rc = L.dsm_host_probe_match_in_callers_transaction(path.encode(), 4, commit, 5, ctypes.byref(nm), ctypes.byref(ng), ctypes.byref(open_))
+    assert rc == 0
+    n_pairs = n_img * (n_img - 1) // 2
+    assert open_.value == 1, "Match() must leave the caller's transaction open"
+    assert nm.value == n_pairs and ng.value == n_pairs, "every row is written when Match() returns"
+    matches, tvgs = dbutil.read_results(path)
+    if not commit:
+        assert len(matches) == 0 and len(tvgs) == 0, "the rows were the caller's transaction's: its rollback removes them"
+        return
+    assert len(matches) == n_pairs == len(tvgs)
+    ref = str(tmp_path / "blocking.db")
+    dbutil.create(ref, [(im[0], im[1]) for im in ims], prior=True)
+    subprocess.check_call([CLI, "--database_path", ref, "--random_seed", "5"] + _BLOCKING)
+    rm, rt = dbutil.read_results(ref)
+    assert matches.keys() == rm.keys() and tvgs.keys() == rt.keys()
+    for pid in rm:
+        assert (matches[pid] == rm[pid]).all()
+        a, b = tvgs[pid], rt[pid]
+        assert a["config"] == b["config"] and (a["inliers"] == b["inliers"]).all() and a["F"] == b["F"] and a["E"] == b["E"] and a["H"] == b["H"]
