@@ -754,7 +754,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
     const uint32_t nb_heavy = std::min<uint32_t>(vp.n_chunk, std::max<uint32_t>(64u, (uint32_t)plan.dev_cus * 16u / plan.grid_div));
     // the replay scans are latency-bound and light (four waves per SIMD fit): their grid may be larger than the heavy kernels'
     // (a lane's scratch holds dev_cus * 16 workgroups)
-    const uint32_t nb_replay = std::min<uint32_t>(vp.n_chunk, std::min<uint32_t>((uint32_t)plan.dev_cus * 16u, std::max<uint32_t>(64u, (uint32_t)plan.dev_cus * 16u * plan.replay_grid_mul / plan.grid_div)));
+    const uint32_t nb_replay = std::min<uint32_t>(vp.n_chunk, std::min<uint32_t>((uint32_t)plan.dev_cus * 4u * DSM_REPLAY_WAVES, std::max<uint32_t>(64u, (uint32_t)plan.dev_cus * 4u * DSM_REPLAY_WAVES * plan.replay_grid_mul / plan.grid_div)));
     vp.batch = 0;
     launch_vp_prep(vp, nb_light, st);
     LANECHK(L, hipGetLastError());
@@ -1137,7 +1137,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
         for (uint32_t li = 0; li < n_lanes; ++li) {
           VerifyLane& L = ctx->lanes[li];
           const uint32_t chunk = plan.chunk[li];
-          const uint32_t lane_blocks = std::min<uint32_t>(chunk, (uint32_t)dev_cus * 16u);
+          const uint32_t lane_blocks = std::min<uint32_t>(chunk, (uint32_t)dev_cus * 4u * DSM_REPLAY_WAVES);
           if (!L.stream) LRES(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
           if (!L.done) LRES(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
           if (!L.host_ctr) LRES(hipHostMalloc(reinterpret_cast<void**>(&L.host_ctr), 128, hipHostMallocDefault));

@@ -128,6 +128,12 @@ struct TailItem {
 };
 
 // Two-view verification: one 64-lane workgroup per image pair (grid-stride over the pair list).
+// waves per SIMD the replay scans (k_replay_lo, modes 0 and 2) are compiled for; their persistent grid and the lanes' per-workgroup
+// scratch are sized with it (capi.hip)
+#ifndef DSM_REPLAY_WAVES
+#define DSM_REPLAY_WAVES 4
+#endif
+
 struct VerifyParams {
   const uint32_t* pairs;       // [n_pairs][2] image indices
   const uint64_t* match_off;   // [n_pairs+1] offsets into matches

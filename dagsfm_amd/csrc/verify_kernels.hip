@@ -2978,7 +2978,7 @@ __host__ __device__ inline bool lo_prepare_in_registers(int ninl) {
 // and k_tail_lo computed their outcomes (TailItem); this scan takes the outcome where k_replay would run the
 // optimisation.  A step that is not among the pair's items (more than TAIL_KMAX candidates) suspends the pair as in mode 0.
 template <int FAM, int MODE>
-__global__ __launch_bounds__(64, (MODE == 1 ? 1 : 4)) void k_replay_lo(const VerifyParams p) {
+__global__ __launch_bounds__(64, (MODE == 1 ? 1 : DSM_REPLAY_WAVES)) void k_replay_lo(const VerifyParams p) {
   constexpr bool TAIL = MODE == 1;
   constexpr bool LOOKUP = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

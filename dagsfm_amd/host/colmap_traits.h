@@ -89,6 +89,7 @@ struct DsmColmapTraits {
   }
   static uint32_t RandomSeed(const Options&) { return 0; }
   static bool AsyncWriteBack(const Options&) { return false; }
+  static bool AssembleOnDevice(const Options&) { return false; }  // (the reference's options have no such switch)
 };
 
 // Same name, constructor and methods as the class it replaces (matching.h:334-368).

@@ -13,7 +13,7 @@ int main(int argc, char** argv) {
   std::string db;
   int block = 1000;  // the reference's default of 50 bounds its host cache; here a large block amortises the per-call costs
   unsigned seed = 0;
-  int guided = 0, multiple = 0, timing = 0, bulk = 0, overlap = 1, slice = -1;  // slice < 0: SiftMatchingOptions' default
+  int guided = 0, multiple = 0, timing = 0, bulk = 0, overlap = 1, slice = -1, on_device = 0;  // slice < 0: SiftMatchingOptions' default
   std::string gpu_index = "-1";  // all visible devices
   // < 0: SiftMatchingOptions' default (on since round 5).  This executable's own switch for the tests / tools (the libraries
   // read no environment): DSM_ASYNC_WRITE_BACK=0 / =1 is --SiftMatching.async_write_back 0 / 1
@@ -32,14 +32,15 @@ int main(int argc, char** argv) {
     else if (k == "--SiftMatching.bulk_load_journal") bulk = std::atoi(argv[i + 1]);
     else if (k == "--SiftMatching.match_slice_pairs") slice = std::atoi(argv[i + 1]);
     else if (k == "--ExhaustiveMatching.overlap_setup") overlap = std::atoi(argv[i + 1]);
+    else if (k == "--SiftMatching.assemble_on_device") on_device = std::atoi(argv[i + 1]);
   }
   if (db.empty()) {
     std::cerr << "usage: dsm_exhaustive_matcher --database_path database.db [--ExhaustiveMatching.block_size 1000] [--random_seed 0]"
                  " [--SiftMatching.guided_matching 0] [--SiftMatching.multiple_models 0] [--SiftMatching.gpu_index -1]"
                  " [--SiftMatching.async_write_back 1] [--SiftMatching.bulk_load_journal 0] [--SiftMatching.match_slice_pairs 32768]"
-                 " [--ExhaustiveMatching.overlap_setup 1] [--timing 0]\n";
+                 " [--ExhaustiveMatching.overlap_setup 1] [--SiftMatching.assemble_on_device 0] [--timing 0]\n";
     return 64;
   }
   return dsm_host_exhaustive_matcher_ex4(db.c_str(), block, 1, seed, 0, 0, 1, 15, guided, multiple, gpu_index.c_str(), async_write_back,
-                                         (timing ? 1u : 0u) | (bulk ? 2u : 0u) | (overlap ? 0u : 4u), slice);
+                                         (timing ? 1u : 0u) | (bulk ? 2u : 0u) | (overlap ? 0u : 4u) | (on_device ? 8u : 0u), slice);
 }

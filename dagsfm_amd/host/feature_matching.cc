@@ -559,7 +559,8 @@ extern "C" {
 enum {
   DSM_HOST_FLAG_PRINT_TIMING = 1u,       // one line of stage timers on stderr
   DSM_HOST_FLAG_BULK_LOAD_JOURNAL = 2u,  // SiftMatchingOptions::bulk_load_journal
-  DSM_HOST_FLAG_SERIAL_SETUP = 4u        // ExhaustiveMatchingOptions::overlap_setup = false
+  DSM_HOST_FLAG_SERIAL_SETUP = 4u,       // ExhaustiveMatchingOptions::overlap_setup = false
+  DSM_HOST_FLAG_ASSEMBLE_ON_DEVICE = 8u  // SiftMatchingOptions::assemble_on_device (RCCL, libdagsfm_gather.so)
 };
 int dsm_host_exhaustive_matcher_ex4(const char* database_path, int block_size, int use_prior_defaults, uint32_t random_seed,
                                     double max_ratio, double max_distance, int cross_check, int min_num_inliers,
@@ -583,6 +584,7 @@ int dsm_host_exhaustive_matcher_ex4(const char* database_path, int block_size, i
     mo.multiple_models = multiple_models != 0;
     if (async_write_back >= 0) mo.async_write_back = async_write_back != 0;  // overlap SQLite with the device (default: on)
     mo.bulk_load_journal = bulk_load_journal;
+    mo.assemble_on_device = (flags & DSM_HOST_FLAG_ASSEMBLE_ON_DEVICE) != 0;
     if (match_slice_pairs >= 0) mo.match_slice_pairs = match_slice_pairs;
     if (gpu_index && *gpu_index) mo.gpu_index = gpu_index;
     mo.random_seed = random_seed;

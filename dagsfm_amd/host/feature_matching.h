@@ -214,6 +214,7 @@ struct NativeTraits {
   }
   static uint32_t RandomSeed(const Options& o) { return o.random_seed; }
   static bool AsyncWriteBack(const Options& o) { return o.async_write_back; }
+  static bool AssembleOnDevice(const Options& o) { return o.assemble_on_device; }
   static bool DeferWriteBack(const Options& o) { return o.async_write_back && o.defer_write_back; }
   static bool InTransaction(const Cache* c) { return c->InTransaction(); }
   static size_t MatchSlicePairs(const Options& o) { return o.match_slice_pairs > 0 ? static_cast<size_t>(o.match_slice_pairs) : 0; }

@@ -14,7 +14,9 @@
 //              ToDsmCamera(camera, &out); CameraIdOf(image); KeypointData(kps, &n, &stride_in_floats);
 //              DescriptorData(desc, &rows, &cols); AppendFlat(matches, &flat); MakeMatches(flat, n);
 //              MakeTwoViewGeometry(record or nullptr, inliers, n); RandomSeed(options); AsyncWriteBack(options);
-//              MatchSlicePairs(options) (only with kAsyncWriteBack: this repository's Options)
+//              MatchSlicePairs(options) (only with kAsyncWriteBack: this repository's Options);
+//              AssembleOnDevice(options): the shares of the devices are assembled by RCCL (libdagsfm_gather.so) instead of
+//              fetched one by one (false for the reference's Options)
 //
 // feature_matching.h instantiates it with this repository's own types (NativeTraits); colmap_traits.h with the
 // reference's (compile-checked against tests/colmap_stub, which carries the reference's exact signatures).
@@ -38,6 +40,8 @@
 #include <utility>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "../../include/dagsfm_mi355x.h"
 
 namespace dagsfm_amd {
@@ -57,6 +61,48 @@ struct RawU32Buffer {
   void swap(RawU32Buffer& o) {
     p.swap(o.p);
     std::swap(n, o.n);
+  }
+};
+
+// libdagsfm_gather.so (include/dagsfm_gather.h), loaded on first use from the directory of libdagsfm_mi355x.so: only a host that
+// asks for the on-device assembly maps librccl (0.5 s of load time).  Plain function pointers: this header stays free of RCCL.
+struct DeviceGatherApi {
+  void* handle;
+  int (*create)(dsm_ctx* const*, uint32_t, void**);
+  void (*destroy)(void*);
+  const char* (*last_error)(const void*);
+  int (*match_graph)(void*, const uint32_t*, int32_t);
+  int (*sizes)(const void*, uint64_t*, uint64_t*, uint64_t*);
+  int (*fetch)(void*, uint32_t, uint64_t*, uint32_t*, dsm_two_view_geometry*, uint64_t*, uint32_t*);
+  DeviceGatherApi() : handle(nullptr), create(nullptr), destroy(nullptr), last_error(nullptr), match_graph(nullptr), sizes(nullptr), fetch(nullptr) {}
+  bool Load(std::string* error) {
+    if (handle) return true;
+    std::string path = "libdagsfm_gather.so";
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void*>(&dsm_ctx_create), &info) && info.dli_fname) {
+      const std::string lib(info.dli_fname);
+      const size_t slash = lib.rfind('/');
+      if (slash != std::string::npos) path = lib.substr(0, slash + 1) + path;
+    }
+    handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!handle) {
+      const char* e = dlerror();
+      *error = std::string("cannot load ") + path + ": " + (e ? e : "?");
+      return false;
+    }
+    create = reinterpret_cast<int (*)(dsm_ctx* const*, uint32_t, void**)>(dlsym(handle, "dsm_gather_create"));
+    destroy = reinterpret_cast<void (*)(void*)>(dlsym(handle, "dsm_gather_destroy"));
+    last_error = reinterpret_cast<const char* (*)(const void*)>(dlsym(handle, "dsm_gather_last_error"));
+    match_graph = reinterpret_cast<int (*)(void*, const uint32_t*, int32_t)>(dlsym(handle, "dsm_gather_match_graph"));
+    sizes = reinterpret_cast<int (*)(const void*, uint64_t*, uint64_t*, uint64_t*)>(dlsym(handle, "dsm_gather_sizes"));
+    fetch = reinterpret_cast<int (*)(void*, uint32_t, uint64_t*, uint32_t*, dsm_two_view_geometry*, uint64_t*, uint32_t*)>(dlsym(handle, "dsm_gather_fetch"));
+    if (!create || !destroy || !last_error || !match_graph || !sizes || !fetch) {
+      *error = path + " lacks a dsm_gather_* entry point";
+      dlclose(handle);
+      handle = nullptr;
+      return false;
+    }
+    return true;
   }
 };
 
@@ -81,6 +127,7 @@ class SiftFeatureMatcherT {
         std::fprintf(stderr, "dagsfm_amd::SiftFeatureMatcher: asynchronous write-back failed and was rolled back\n");
       }
     }
+    if (gather_) gather_api_.destroy(gather_);  // (before the contexts it was created over)
     for (dsm_ctx* c : ctxs_) dsm_ctx_destroy(c);
   }
   SiftFeatureMatcherT(const SiftFeatureMatcherT&) = delete;
@@ -219,7 +266,7 @@ class SiftFeatureMatcherT {
   };
 
   void RunShare(dsm_ctx* ctx, const PairList& prs, const std::vector<typename Traits::FeatureMatches>* given,
-                const dsm_match_options& mo, const dsm_two_view_options& to, Share* sh) const {
+                const dsm_match_options& mo, const dsm_two_view_options& to, Share* sh, bool fetch) const {
     const uint32_t np = sh->end - sh->begin;
     if (np == 0) return;
     std::vector<uint32_t> idx(2 * static_cast<size_t>(np)), seeds(np);
@@ -253,6 +300,7 @@ class SiftFeatureMatcherT {
       return;
     }
     sh->verify_s = Seconds(t_verify);
+    if (!fetch) return;  // the shares are assembled on the devices (AssembleShares)
     const Clock::time_point t_fetch = Clock::now();
     sh->moff.assign(np + 1, 0);
     sh->ioff.assign(np + 1, 0);
@@ -322,12 +370,13 @@ class SiftFeatureMatcherT {
       shares[d].end = at;
     }
     shares[nd - 1].end = np;
+    const bool on_device = Traits::AssembleOnDevice(options_);
     const Clock::time_point t_device = Clock::now();
     if (nd == 1) {
-      RunShare(ctxs_[0], prs, given, mo, to, &shares[0]);
+      RunShare(ctxs_[0], prs, given, mo, to, &shares[0], !on_device);
     } else {
       std::vector<std::thread> th;
-      for (size_t d = 0; d < nd; ++d) th.emplace_back([&, d]() { RunShare(ctxs_[d], prs, given, mo, to, &shares[d]); });
+      for (size_t d = 0; d < nd; ++d) th.emplace_back([&, d]() { RunShare(ctxs_[d], prs, given, mo, to, &shares[d], !on_device); });
       for (auto& t : th) t.join();
     }
     timings_.device_s += Seconds(t_device);
@@ -347,7 +396,13 @@ class SiftFeatureMatcherT {
     std::vector<uint64_t> moff, ioff;
     std::vector<dsm_two_view_geometry> tv;
     RawU32Buffer m, im;
-    if (nd == 1) {
+    if (on_device) {
+      const Clock::time_point t_gather = Clock::now();
+      AssembleShares(shares, nd, &moff, &m, &tv, &ioff, &im);
+      const double s_gather = Seconds(t_gather);
+      timings_.device_s += s_gather;
+      timings_.fetch_s += s_gather;
+    } else if (nd == 1) {
       moff.swap(shares[0].moff);
       ioff.swap(shares[0].ioff);
       tv.swap(shares[0].tv);
@@ -395,6 +450,44 @@ class SiftFeatureMatcherT {
     const Clock::time_point t_write = Clock::now();
     batch->Write();
     timings_.write_s += Seconds(t_write);
+  }
+
+  // SiftMatchingOptions::assemble_on_device: the devices' shares are assembled ON the devices by RCCL -- one communicator over
+  // the gpu_index devices (ncclCommInitAll), grouped all-gather of the fixed-size records, exact-size broadcasts of the
+  // match lists (include/dagsfm_gather.h) -- and the host fetches the whole graph from device 0 with one copy per array,
+  // instead of one fetch per device merged through host memory.  Also taken with ONE device (a one-rank communicator), which
+  // is how a one-GPU box exercises the path.
+  void AssembleShares(const std::vector<Share>& shares, size_t nd, std::vector<uint64_t>* moff, RawU32Buffer* m,
+                      std::vector<dsm_two_view_geometry>* tv, std::vector<uint64_t>* ioff, RawU32Buffer* im) {
+    std::string error;
+    if (!gather_api_.Load(&error)) throw std::runtime_error(error);
+    if (gather_ && gather_ranks_ != nd) {  // (a slice shorter than the device count uses fewer devices)
+      gather_api_.destroy(gather_);
+      gather_ = nullptr;
+    }
+    if (!gather_) {
+      if (gather_api_.create(ctxs_.data(), static_cast<uint32_t>(nd), &gather_) != DSM_OK || !gather_)
+        throw std::runtime_error("dsm_gather_create failed (RCCL needs the gpu_index devices to be distinct)");
+      gather_ranks_ = nd;
+    }
+    std::vector<uint32_t> np(nd);
+    uint64_t total = 0;
+    for (size_t d = 0; d < nd; ++d) {
+      np[d] = shares[d].end - shares[d].begin;
+      total += np[d];
+    }
+    if (gather_api_.match_graph(gather_, np.data(), 1) != DSM_OK)
+      throw std::runtime_error(std::string("dsm_gather_match_graph: ") + gather_api_.last_error(gather_));
+    uint64_t n_pairs = 0, n_matches = 0, n_inliers = 0;
+    if (gather_api_.sizes(gather_, &n_pairs, &n_matches, &n_inliers) != DSM_OK || n_pairs != total)
+      throw std::runtime_error("dsm_gather_sizes: the assembled graph does not cover the pair list");
+    moff->assign(n_pairs + 1, 0);
+    ioff->assign(n_pairs + 1, 0);
+    tv->resize(n_pairs);
+    m->Allocate(2 * std::max<uint64_t>(n_matches, 1));
+    im->Allocate(2 * std::max<uint64_t>(n_inliers, 1));
+    if (gather_api_.fetch(gather_, 0, moff->data(), m->data(), tv->data(), ioff->data(), im->data()) != DSM_OK)
+      throw std::runtime_error(std::string("dsm_gather_fetch: ") + gather_api_.last_error(gather_));
   }
 
   typedef std::chrono::steady_clock Clock;
@@ -596,6 +689,9 @@ class SiftFeatureMatcherT {
   std::unordered_map<image_id_t, uint32_t> image_index_;  // image_id -> device image index
   std::string last_error_;
   Timings timings_ = Timings();
+  DeviceGatherApi gather_api_;
+  void* gather_ = nullptr;  // dsm_gather over ctxs_[0 .. gather_ranks_)
+  size_t gather_ranks_ = 0;
   std::thread writer_;  // at most one write-back in flight
   std::exception_ptr writer_error_;
 };

@@ -96,6 +96,12 @@ struct SiftMatchingOptions {  // feature/sift.h:116-165, same names and defaults
   // sliced) -- bounded device scratch (the first call of a process allocates it), and with async_write_back slice k's rows are
   // written while slice k + 1 is on the devices
   int match_slice_pairs = 32768;
+  // extension: the devices' shares of a Match() are assembled on the devices by RCCL (libdagsfm_gather.so: one communicator over
+  // the gpu_index devices, grouped all-gather + broadcasts over xGMI) and fetched from device 0 in one copy per array, instead
+  // of one fetch per device merged in host memory.  Off by default: every GPU has its own PCIe link, so N parallel fetches
+  // reach the host faster than one N-times-larger fetch behind an all-gather; the switch is for hosts that consume the graph
+  // on the device next (dsm_gather_device_arrays) and for exercising the RCCL path.  The gpu_index devices must be distinct.
+  bool assemble_on_device = false;
   // extension: Database::SetBulkLoadJournal(true) for the run (ExhaustiveFeatureMatcher::Run restores WAL at its end)
   bool bulk_load_journal = false;
   // not in the reference: seed of the per-pair PRNG schedule (the reference seeds from the clock)

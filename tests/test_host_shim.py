@@ -481,3 +481,38 @@ def test_match_returns_with_every_row_written_into_the_callers_transaction(tmp_p
         assert (matches[pid] == rm[pid]).all()
         a, b = tvgs[pid], rt[pid]
         assert a["config"] == b["config"] and (a["inliers"] == b["inliers"]).all() and a["F"] == b["F"] and a["E"] == b["E"] and a["H"] == b["H"]
+
+
+@pytest.mark.gpu
+def test_shares_assembled_on_the_device_by_rccl_write_the_same_rows(tmp_path):
+    """SiftMatchingOptions::assemble_on_device (round 5): the C++ drop-in hands the devices' shares to libdagsfm_gather.so -- one
+    communicator over the gpu_index devices (ncclCommInitAll), grouped all-gather of the fixed-size records, broadcasts of the
+    match lists -- and fetches the assembled graph from device 0 in one copy per array.  A one-GPU box runs it with a one-rank
+    communicator; the rows must be those of the direct fetch, also with several slices and blocks per run.  (Reference analogue:
+    one matcher per gpu_index device, outputs collected by the caller, /root/reference/src/feature/matching.cc:631-645, 814-836.)"""
+    from dagsfm_amd import synthetic
+    n_img = 7
+    scene = synthetic.Scene(n_img, 512, seed=37, n_pool=1400)
+    ims = [scene.image(i) for i in range(n_img)]
+    blocks = ["--SiftMatching.match_slice_pairs", "3", "--ExhaustiveMatching.block_size", "4"]  # several Match() calls, several slices each
+    n_compared = 0
+    for k, common in enumerate([[], blocks]):  # (a block visit order changes which image of a pair is "first": compare like with like)
+        res = []
+        for flags in ([], ["--SiftMatching.assemble_on_device", "1"]):
+            path = str(tmp_path / ("database%d_%d.db" % (k, len(flags))))
+            dbutil.create(path, [(im[0], im[1]) for im in ims], prior=True)
+            r = subprocess.run([CLI, "--database_path", path, "--random_seed", "4", "--timing", "1"] + common + flags, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            res.append(dbutil.read_results(path))
+        (base_m, base_t), (m, t) = res
+        assert len(base_m) == n_img * (n_img - 1) // 2 and sum(len(v) for v in base_m.values()) > 500
+        assert m.keys() == base_m.keys() and t.keys() == base_t.keys()
+        for pid in base_m:
+            assert m[pid].shape == base_m[pid].shape and (m[pid] == base_m[pid]).all()
+            a, b = t[pid], base_t[pid]
+            assert a["config"] == b["config"] and (a["inliers"] == b["inliers"]).all() and a["F"] == b["F"] and a["E"] == b["E"] and a["H"] == b["H"]
+            n_compared += 1
+    assert n_compared == 2 * n_img * (n_img - 1) // 2
+    # the CLI maps RCCL only when asked to
+    needed = subprocess.run(["ldd", CLI], capture_output=True, text=True).stdout
+    assert "rccl" not in needed
