@@ -38,6 +38,7 @@
 #include <vector>
 
 #include "ctx.h"
+#include "flann_search.h"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -55,7 +56,8 @@ struct RetrievalState {
   uint32_t host_k_query = 0;
   bool host_ids = false;
   bool host_ids_stale = false;  // the resident images changed after dsm_retrieval_set_word_ids: the ids describe other features
-  int host_loaded = 0;  // which list d_wid / d_sig hold: 1 index, 2 query
+  int host_loaded = 0;  // which list d_wid / d_sig hold: 1 index, 2 query (caller's ids or the device FLANN search)
+  FlannDevice* flann = nullptr;  // dsm_retrieval_set_flann_index: the reference's word search on the device (flann_search.hip)
   DevBuf d_words, d_cw, d_projT, d_thr, d_lut;
   DevBuf d_row_img, d_wid, d_sig;                       // per feature row
   DevBuf d_keys, d_keys2, d_vals, d_vals2, d_tmp;        // sort scratch
@@ -497,6 +499,8 @@ void dsm_retrieval_destroy(dsm_ctx* ctx) {
                     &r->d_idf, &r->d_img_start, &r->d_normc, &r->d_qnorm, &r->d_nfeat, &r->d_wcounts, &r->d_acc, &r->d_first, &r->d_skeys, &r->d_skeys2,
                     &r->d_svals, &r->d_svals2, &r->d_seg, &r->d_out_cnt, &r->d_out_idx, &r->d_out_score};
   for (DevBuf* b : bufs) b->release();
+  flann_device_destroy(r->flann);
+  r->flann = nullptr;
   if (r->ev0) (void)hipEventDestroy(r->ev0);
   if (r->ev1) (void)hipEventDestroy(r->ev1);
   delete r;
@@ -699,6 +703,33 @@ static int retrieval_assign(dsm_ctx* ctx, uint32_t k, int purpose) {
     r->host_loaded = purpose;
     return DSM_OK;
   }
+  if (r->flann) {
+    // the reference's approximate search over the file's own FLANN index, a lane per feature (flann_search.hip): 1 neighbour
+    // when a feature is indexed, num_neighbors when it is queried -- two searches, as in VisualIndex::Add / ::Query
+    const uint32_t kk = purpose == ASSIGN_FOR_INDEX ? 1u : k;
+    if (r->host_loaded == purpose && r->k_assigned == kk && r->d_wid.p) return DSM_OK;
+    std::vector<int32_t> row_img(std::max<uint64_t>(rows, 1), -1);
+    r->img_valid_start.assign(ctx->n_images + 1, 0);
+    for (uint32_t i = 0; i < ctx->n_images; ++i) {
+      for (uint32_t f = 0; f < ctx->nfeat[i]; ++f) row_img[(uint64_t)ctx->row0[i] + f] = (int32_t)i;
+      r->img_valid_start[i + 1] = r->img_valid_start[i] + ctx->nfeat[i];
+    }
+    RCHK(ctx, r->d_row_img.reserve(row_img.size() * 4));
+    RCHK(ctx, hipMemcpy(r->d_row_img.p, row_img.data(), row_img.size() * 4, hipMemcpyHostToDevice));
+    RCHK(ctx, r->d_wid.reserve(std::max<uint64_t>(rows, 1) * RK_MAX * 4));
+    RCHK(ctx, r->d_sig.reserve(std::max<uint64_t>(rows, 1) * RK_MAX * 8));
+    if (rows) {
+      const int rc = flann_device_search(ctx, r->flann, r->d_words.as<int8_t>(), ctx->d_desc.as<int8_t>(), r->d_row_img.as<int32_t>(), rows, kk,
+                                         r->d_wid.as<int32_t>(), nullptr, RK_MAX, st);
+      if (rc != DSM_OK) return rc;
+      hipLaunchKernelGGL(k_vocab_signature, dim3(2048), dim3(256), 0, st, ctx->d_desc.as<int8_t>(), rows, r->d_projT.as<float>(),
+                         r->d_thr.as<float>(), r->d_wid.as<int32_t>(), (int)kk, r->d_sig.as<uint64_t>());
+      RCHK(ctx, hipGetLastError());
+    }
+    r->k_assigned = kk;
+    r->host_loaded = purpose;
+    return DSM_OK;
+  }
   if (r->k_assigned >= k && r->d_wid.p) return DSM_OK;
   // row -> image (padding rows: -1)
   std::vector<int32_t> row_img(std::max<uint64_t>(rows, 1), -1);
@@ -778,6 +809,9 @@ int dsm_retrieval_set_vocabulary(dsm_ctx* ctx, const dsm_vocabulary* v) {
   r->num_words = W;
   r->words_padded = Wp;
   r->have_vocab = true;
+  flann_device_destroy(r->flann);  // an index belongs to the vocabulary it was built over
+  r->flann = nullptr;
+  r->host_loaded = 0;
   r->indexed = false;
   r->k_assigned = 0;
   if (!r->ev0) {
@@ -814,6 +848,26 @@ int dsm_retrieval_set_word_ids(dsm_ctx* ctx, const int32_t* index_ids, uint32_t 
   r->host_k_query = k_query;
   r->host_ids = true;
   return DSM_OK;
+}
+
+int dsm_retrieval_set_flann_index(dsm_ctx* ctx, const dsm_flann_index* index) {
+  if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
+  RetrievalState* r = ctx->retrieval;
+  if (!r || !r->have_vocab) return dsm_fail(ctx, DSM_ERR_NOT_READY, "dsm_retrieval_set_vocabulary has not run");
+  r->indexed = false;
+  r->k_assigned = 0;
+  r->host_loaded = 0;
+  RCHK(ctx, hipSetDevice(ctx->device));
+  return flann_device_set_index(ctx, &r->flann, index, r->d_words.as<int8_t>(), r->num_words);
+}
+
+int dsm_retrieval_flann_search(dsm_ctx* ctx, const uint8_t* descriptors, uint32_t n, uint32_t k, int32_t* ids, float* dists, double* ms) {
+  if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
+  RetrievalState* r = ctx->retrieval;
+  if (!r || !r->have_vocab || !r->flann) return dsm_fail(ctx, DSM_ERR_NOT_READY, "dsm_retrieval_set_flann_index has not run");
+  const int rc = flann_device_search_host(ctx, r->flann, r->d_words.as<int8_t>(), descriptors, n, k, ids, dists);
+  if (ms) *ms = flann_device_last_ms(r->flann);
+  return rc;
 }
 
 int dsm_retrieval_index(dsm_ctx* ctx) {
@@ -926,8 +980,8 @@ int dsm_retrieval_query(dsm_ctx* ctx, uint32_t num_neighbors, uint32_t max_num_i
   const uint32_t NI = ctx->n_images;
   if (NI == 0) return DSM_OK;
   const int k = (int)num_neighbors;
-  if (r->host_ids) {
-    if (num_neighbors != r->host_k_query) return dsm_fail(ctx, DSM_ERR_INVALID_ARGUMENT, "num_neighbors differs from the k of dsm_retrieval_set_word_ids");
+  if (r->host_ids || r->flann) {  // the query's own word search (num_neighbors words), not the one the index was built with
+    if (r->host_ids && num_neighbors != r->host_k_query) return dsm_fail(ctx, DSM_ERR_INVALID_ARGUMENT, "num_neighbors differs from the k of dsm_retrieval_set_word_ids");
     const int rca = retrieval_assign(ctx, num_neighbors, ASSIGN_FOR_QUERY);
     if (rca != DSM_OK) return rca;
   }
@@ -1003,8 +1057,8 @@ int dsm_retrieval_matches(dsm_ctx* ctx, uint32_t num_neighbors, uint32_t max_num
   offsets[0] = 0;
   r->m_total = 0;
   if (NI == 0) return DSM_OK;
-  if (r->host_ids) {
-    if (num_neighbors != r->host_k_query) return dsm_fail(ctx, DSM_ERR_INVALID_ARGUMENT, "num_neighbors differs from the k of dsm_retrieval_set_word_ids");
+  if (r->host_ids || r->flann) {
+    if (r->host_ids && num_neighbors != r->host_k_query) return dsm_fail(ctx, DSM_ERR_INVALID_ARGUMENT, "num_neighbors differs from the k of dsm_retrieval_set_word_ids");
     RCHK(ctx, hipSetDevice(ctx->device));
     const int rca = retrieval_assign(ctx, num_neighbors, ASSIGN_FOR_QUERY);
     if (rca != DSM_OK) return rca;
@@ -1079,7 +1133,7 @@ int dsm_retrieval_debug_word_ids(dsm_ctx* ctx, uint32_t image, uint32_t k, int32
   RCHK(ctx, hipSetDevice(ctx->device));
   r->k_assigned = 0;
   r->host_loaded = 0;
-  int rc = retrieval_assign(ctx, RK_MAX, ASSIGN_FOR_QUERY);
+  int rc = retrieval_assign(ctx, r->flann ? k : RK_MAX, ASSIGN_FOR_QUERY);  // (an approximate search's first k of 8 are not its k of k)
   if (rc != DSM_OK) return rc;
   RCHK(ctx, hipStreamSynchronize(ctx->stream));
   std::vector<int32_t> all((size_t)ctx->nfeat[image] * RK_MAX);

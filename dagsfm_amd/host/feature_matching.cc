@@ -429,34 +429,49 @@ bool VocabSimilarityGraph::Run() {
   std::vector<float> sc(static_cast<size_t>(n) * max_images);
   int rc = dsm_set_images(ctx, n, nfeat.data(), desc.data(), nullptr, 0, nullptr);
   if (rc == DSM_OK) rc = dsm_retrieval_set_vocabulary(ctx, &v);
-  if (rc == DSM_OK && options_.word_search == VocabSimilaritySearchOptions::kFlann) {
+  VocabSimilaritySearchOptions::WordSearch word_search = options_.word_search;
+  if (word_search == VocabSimilaritySearchOptions::kAuto)
+    word_search = voc.flann_framed ? VocabSimilaritySearchOptions::kFlann : VocabSimilaritySearchOptions::kExact;
+  word_search_used_ = word_search;
+  FlannIndex flann;  // (outlives the dsm_retrieval_set_flann_index call that reads its arrays)
+  if (rc == DSM_OK && (word_search == VocabSimilaritySearchOptions::kFlann || word_search == VocabSimilaritySearchOptions::kFlannHost)) {
     // the reference's own word ids: FindWordIds with 1 neighbour for VisualIndex::Add (IndexOptions::num_neighbors,
     // visual_index.h:62-73, 201-243; IndexImagesInVisualIndex passes the same num_checks, similarity_graph.cpp:56-85) and
     // with num_nearest_neighbors for the query, over the index loaded from the vocabulary file
-    FlannIndex flann;
     size_t at = 0;
     if (!voc.flann_framed || !flann.Load(voc.flann_blob.data(), voc.flann_blob.size(), &at, voc.words.data(), voc.num_words)) {
       last_error_ = "word_search = flann: " + (voc.flann_framed ? flann.error() : std::string("the vocabulary file carries no FLANN index"));
       dsm_ctx_destroy(ctx);
       return false;
     }
-    uint64_t total = 0;
-    for (uint32_t i = 0; i < n; ++i) total += nfeat[i];
     const uint32_t kq = static_cast<uint32_t>(options_.num_nearest_neighbors);
-    std::vector<int32_t> index_ids(std::max<uint64_t>(total, 1)), query_ids(std::max<uint64_t>(total, 1) * kq);
-    uint64_t f0 = 0;
-    bool ok = kq >= 1;
-    for (uint32_t i = 0; ok && i < n; ++i) {
-      ok = flann.FindWordIds(desc[i], nfeat[i], 1, options_.num_checks, options_.num_threads, index_ids.data() + f0, nullptr) &&
-           flann.FindWordIds(desc[i], nfeat[i], kq, options_.num_checks, options_.num_threads, query_ids.data() + f0 * kq, nullptr);
-      f0 += nfeat[i];
+    if (word_search == VocabSimilaritySearchOptions::kFlann) {
+      // on the device: the trees go over once, dsm_retrieval_index / _query search them (csrc/flann_search.hip)
+      dsm_flann_index flat;
+      if (kq < 1 || !flann.Export(options_.num_checks, &flat)) {
+        last_error_ = "word_search = flann: the search refused num_nearest_neighbors / num_checks";
+        dsm_ctx_destroy(ctx);
+        return false;
+      }
+      rc = dsm_retrieval_set_flann_index(ctx, &flat);
+    } else {
+      uint64_t total = 0;
+      for (uint32_t i = 0; i < n; ++i) total += nfeat[i];
+      std::vector<int32_t> index_ids(std::max<uint64_t>(total, 1)), query_ids(std::max<uint64_t>(total, 1) * kq);
+      uint64_t f0 = 0;
+      bool ok = kq >= 1;
+      for (uint32_t i = 0; ok && i < n; ++i) {
+        ok = flann.FindWordIds(desc[i], nfeat[i], 1, options_.num_checks, options_.num_threads, index_ids.data() + f0, nullptr) &&
+             flann.FindWordIds(desc[i], nfeat[i], kq, options_.num_checks, options_.num_threads, query_ids.data() + f0 * kq, nullptr);
+        f0 += nfeat[i];
+      }
+      if (!ok) {
+        last_error_ = "word_search = flann: the search refused num_nearest_neighbors / num_checks";
+        dsm_ctx_destroy(ctx);
+        return false;
+      }
+      rc = dsm_retrieval_set_word_ids(ctx, index_ids.data(), kq, query_ids.data());
     }
-    if (!ok) {
-      last_error_ = "word_search = flann: the search refused num_nearest_neighbors / num_checks";
-      dsm_ctx_destroy(ctx);
-      return false;
-    }
-    rc = dsm_retrieval_set_word_ids(ctx, index_ids.data(), kq, query_ids.data());
   }
   if (rc == DSM_OK) rc = dsm_retrieval_index(ctx);
   if (rc == DSM_OK)
@@ -757,6 +772,36 @@ int dsm_host_flann_find_word_ids(const char* vocab_path, const uint8_t* descript
   if (n && !index.FindWordIds(descriptors, n, k, num_checks, num_threads, out_ids, out_dists)) return -3;
   return index.algorithm();
 }
+// The same search ON THE DEVICE (csrc/flann_search.hip through dsm_retrieval_set_flann_index / dsm_retrieval_flann_search): the
+// file's index parsed here, its trees handed to a context on `device`.  Returns the algorithm (>= 0) or a negative error;
+// *kernel_ms (may be null) = the search kernel's device time.
+int dsm_host_flann_device_search(const char* vocab_path, int device, const uint8_t* descriptors, uint32_t n, uint32_t k, int num_checks,
+                                 int32_t* out_ids, float* out_dists, double* kernel_ms) {
+  VocabularyFile v;
+  if (!v.ReadReferenceLayout(vocab_path) || !v.flann_framed) return -1;
+  FlannIndex index;
+  size_t at = 0;
+  if (!index.Load(v.flann_blob.data(), v.flann_blob.size(), &at, v.words.data(), v.num_words)) {
+    std::cerr << "ERROR: " << index.error() << std::endl;
+    return -2;
+  }
+  dsm_flann_index flat;
+  if (!index.Export(num_checks, &flat)) return -3;
+  dsm_ctx* ctx = nullptr;
+  if (dsm_ctx_create(device, &ctx) != DSM_OK) return -4;
+  dsm_vocabulary voc;
+  voc.num_words = v.num_words;
+  voc.reserved = 0;
+  voc.words = v.words.data();
+  voc.projection = v.projection.data();
+  voc.thresholds = v.thresholds.data();
+  int rc = dsm_retrieval_set_vocabulary(ctx, &voc);
+  if (rc == DSM_OK) rc = dsm_retrieval_set_flann_index(ctx, &flat);
+  if (rc == DSM_OK) rc = dsm_retrieval_flann_search(ctx, descriptors, n, k, out_ids, out_dists, kernel_ms);
+  if (rc != DSM_OK) std::cerr << "ERROR: " << dsm_last_error(ctx) << std::endl;
+  dsm_ctx_destroy(ctx);
+  return rc == DSM_OK ? index.algorithm() : -5;
+}
 // where ReadReferenceLayout found the FLANN index of a vocabulary file in the reference's layout: begin / end offsets,
 // *framed = 1 when it walked FLANN's archive framing (0: located the inverted index by its header).  Returns num_words.
 uint32_t dsm_host_vocabulary_index_range(const char* path, uint64_t* begin, uint64_t* end, int* framed) {
@@ -825,9 +870,9 @@ int64_t dsm_host_vocab_candidate_pairs3(const char* database_path, const char* v
                                         int max_num_features, int num_images_after_verification, uint32_t* pairs, float* scores,
                                         uint64_t capacity) {
   return dsm_host_vocab_candidate_pairs4(database_path, vocab_path, num_images, num_nearest_neighbors, max_num_features,
-                                         num_images_after_verification, 0, 256, pairs, scores, capacity);
+                                         num_images_after_verification, 0, 256, pairs, scores, capacity);  // (this older entry point: the exact search)
 }
-// word_search_flann != 0: VocabSimilaritySearchOptions::word_search = kFlann with `num_checks`
+// word_search_flann: VocabSimilaritySearchOptions::WordSearch (0 exact, 1 FLANN on the device, 2 FLANN on host threads, 3 auto) with `num_checks`
 int64_t dsm_host_vocab_candidate_pairs4(const char* database_path, const char* vocab_path, int num_images, int num_nearest_neighbors,
                                         int max_num_features, int num_images_after_verification, int word_search_flann, int num_checks,
                                         uint32_t* pairs, float* scores, uint64_t capacity) {
@@ -839,7 +884,7 @@ int64_t dsm_host_vocab_candidate_pairs4(const char* database_path, const char* v
     o.max_num_features = max_num_features;
     o.num_images_after_verification = num_images_after_verification;
     o.vocab_tree_path = vocab_path;
-    o.word_search = word_search_flann ? VocabSimilaritySearchOptions::kFlann : VocabSimilaritySearchOptions::kExact;
+    o.word_search = static_cast<VocabSimilaritySearchOptions::WordSearch>(word_search_flann < 0 || word_search_flann > 3 ? 3 : word_search_flann);
     o.num_checks = num_checks;
     VocabSimilarityGraph g(o, db);
     if (!g.Run()) {

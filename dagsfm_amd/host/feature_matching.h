@@ -254,13 +254,19 @@ class ExhaustiveFeatureMatcher {
 struct VocabSimilaritySearchOptions {  // similarity_graph.h:52-76
   int num_images = 100;
   int num_nearest_neighbors = 5;
-  int num_checks = 256;                   // FLANN search effort (QueryOptions::num_checks); only word_search = kFlann consults it
-  // How a feature's visual words are found.  kExact (default): the true nearest words, searched on the device.  kFlann: the
-  // reference's own answer -- the approximate search of the flann::AutotunedIndex stored in the vocabulary file
-  // (visual_index.h:695-738), restated on the host (flann_index.h) bit for bit; needs a vocabulary file in the reference's
-  // layout (this library's flat file carries no index).
-  enum WordSearch { kExact = 0, kFlann = 1 };
-  WordSearch word_search = kExact;
+  int num_checks = 256;                   // FLANN search effort (QueryOptions::num_checks); the FLANN word searches consult it
+  // How a feature's visual words are found.
+  //   kAuto (default since round 5)  kFlann when the vocabulary file carries a FLANN index (every file the reference wrote does),
+  //                     kExact otherwise (this library's flat file has none)
+  //   kFlann            the reference's own answer: the approximate search of the flann::AutotunedIndex stored in the vocabulary
+  //                     file (visual_index.h:695-738), ON THE DEVICE (csrc/flann_search.hip: FLANN's visit order, heap and result
+  //                     set, a lane per feature; ids equal the reference's knnSearch bit for bit)
+  //   kFlannHost        the same search on host threads (flann_index.h) with the ids handed to the device: the cross-check of
+  //                     kFlann, and the fallback for a vocabulary whose branch heaps outgrow the device's per-lane capacity
+  //   kExact            the TRUE nearest words (int8 MFMA search on the device) -- a deviation from the reference: on tree indices
+  //                     it agrees with FLANN's top word for about a fifth of the features (profiles/r04_flann_agreement.json)
+  enum WordSearch { kExact = 0, kFlann = 1, kFlannHost = 2, kAuto = 3 };
+  WordSearch word_search = kAuto;
   int num_images_after_verification = 0;  // > 0: spatial re-ranking of the retrieved images (spatial_verification.h); 0 = off is the reference's default
   int max_num_features = -1;              // > 0: index and query only the features of largest scale (ExtractTopScaleFeatures)
   int num_threads = 8;
@@ -305,9 +311,12 @@ class VocabSimilarityGraph {
   const std::vector<std::pair<image_t, image_t>>& ImagePairs() const { return image_pairs_; }
   const std::vector<float>& Scores() const { return scores_; }
   const std::string& LastError() const { return last_error_; }
+  // what kAuto resolved to in the last Run()
+  VocabSimilaritySearchOptions::WordSearch WordSearchUsed() const { return word_search_used_; }
 
  private:
   VocabSimilaritySearchOptions options_;
+  VocabSimilaritySearchOptions::WordSearch word_search_used_ = VocabSimilaritySearchOptions::kExact;
   const Database* database_;
   FeatureMatcherCache cache_;
   std::vector<std::pair<image_t, image_t>> image_pairs_;

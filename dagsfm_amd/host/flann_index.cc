@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstddef>
 #include <cstring>
 #include <limits>
 #include <thread>
@@ -436,6 +437,36 @@ void FlannIndex::KmFindNN(int32_t node_index, ResultSet* result, const uint8_t* 
     }
     node_index = childs[best_index];
   }
+}
+
+bool FlannIndex::Export(int num_checks, dsm_flann_index* out) const {
+  static_assert(sizeof(KdNode) == sizeof(dsm_flann_kd_node) && offsetof(KdNode, child2) == offsetof(dsm_flann_kd_node, child2), "kd node layout");
+  static_assert(sizeof(KmNode) == sizeof(dsm_flann_km_node) && offsetof(KmNode, first_point) == offsetof(dsm_flann_km_node, first_point) &&
+                    offsetof(KmNode, num_childs) == offsetof(dsm_flann_km_node, num_childs),
+                "k-means node layout");
+  if (algorithm_ < 0 || !out) return false;
+  if (num_checks == -2) num_checks = autotuned_checks_;
+  if (num_checks < 0 && algorithm_ != kLinear) return false;
+  std::memset(out, 0, sizeof(*out));
+  out->algorithm = algorithm_;
+  out->num_checks = num_checks < 0 ? 0 : num_checks;
+  out->num_words = num_words_;
+  out->branching = branching_;
+  out->cb_index = cb_index_;
+  out->km_root = km_root_;
+  out->n_kd_nodes = static_cast<uint32_t>(kd_nodes_.size());
+  out->n_kd_roots = static_cast<uint32_t>(kd_roots_.size());
+  out->kd_nodes = reinterpret_cast<const dsm_flann_kd_node*>(kd_nodes_.data());
+  out->kd_roots = kd_roots_.data();
+  out->n_km_nodes = static_cast<uint32_t>(km_nodes_.size());
+  out->km_nodes = reinterpret_cast<const dsm_flann_km_node*>(km_nodes_.data());
+  out->n_km_childs = km_childs_.size();
+  out->km_childs = km_childs_.data();
+  out->n_km_points = km_points_.size();
+  out->km_points = km_points_.data();
+  out->n_pivot_floats = pivots_.size();
+  out->pivots = pivots_.data();
+  return true;
 }
 
 void FlannIndex::SearchOne(const uint8_t* vec, int num_checks, ResultSet* result) const {

@@ -21,6 +21,8 @@
 #include <string>
 #include <vector>
 
+#include "../../include/dagsfm_mi355x.h"
+
 namespace dagsfm_amd {
 
 // flann::IndexHeaderStruct (lib/FLANN/util/serialization.h:15-24): 80 bytes on the LP64 targets the reference builds for
@@ -58,6 +60,10 @@ class FlannIndex {
   // another result set, nn_index.h:316-340; VocabTreeMatching asks for 1 and num_nearest_neighbors = 5).
   bool FindWordIds(const uint8_t* descriptors, uint32_t n, uint32_t k, int num_checks, int num_threads, int32_t* out_ids,
                    float* out_dists) const;
+  // The loaded trees as the flat arrays dsm_retrieval_set_flann_index takes (pointers into this object: it must outlive the call);
+  // num_checks: SearchParams::checks, -2 = the index's own autotuned estimate (FLANN_CHECKS_AUTOTUNED).  False for an
+  // unlimited walk (-1) on a tree index, like FindWordIds.
+  bool Export(int num_checks, dsm_flann_index* out) const;
   int algorithm() const { return algorithm_; }
   int autotuned_checks() const { return autotuned_checks_; }
   const std::string& error() const { return error_; }

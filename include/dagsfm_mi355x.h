@@ -315,6 +315,53 @@ int dsm_retrieval_set_vocabulary(dsm_ctx* ctx, const dsm_vocabulary* vocabulary)
  * features of all resident images back to back, kInvalidWordId (INT_MAX) where FLANN returned fewer.  Later
  * dsm_retrieval_index / _query / _matches use them (num_neighbors must equal k_query); both NULL: exact search again. */
 int dsm_retrieval_set_word_ids(dsm_ctx* ctx, const int32_t* index_ids, uint32_t k_query, const int32_t* query_ids);
+/* The reference's word search ON THE DEVICE (round 5): the FLANN index the vocabulary file carries -- what
+ * flann::AutotunedIndex::loadIndex reads (visual_index.h:564-574) -- as flat arrays, searched by a lane per feature with
+ * FLANN's own visit order, branch heap and result set (csrc/flann_search.hip <- lib/FLANN/algorithms/kdtree_index.h:
+ * 543-617, kmeans_index.h:717-833, linear_index.h:130-146; ids and float distances equal the reference's knnSearch bit
+ * for bit).  The host shim parses the file (dagsfm_amd/host/flann_index.cc) and hands the trees over here; afterwards
+ * dsm_retrieval_index searches with 1 neighbour and dsm_retrieval_query / _matches with num_neighbors, both with
+ * `num_checks` (IndexOptions / QueryOptions::num_checks).  Every node, child and point index is validated on upload
+ * (DSM_ERR_OUT_OF_RANGE).  NULL: the device's exact search again.  Word ids set with dsm_retrieval_set_word_ids win. */
+typedef struct dsm_flann_kd_node {
+  int32_t divfeat;        /* inner node: split dimension (0..127); leaf: the word's index */
+  float divval;
+  int32_t child1, child2; /* node indices, greater than the node's own; -1 / -1 marks a leaf */
+} dsm_flann_kd_node;
+typedef struct dsm_flann_km_node {
+  uint64_t pivot;         /* offset of the node's centre in `pivots`, in floats (a multiple of 128) */
+  float radius, variance;
+  int32_t size;           /* leaf: number of points */
+  uint32_t first_child;   /* inner node: `branching` entries of km_childs from here */
+  uint32_t num_childs;    /* 0 for a leaf, else == branching */
+  uint32_t reserved;
+  uint64_t first_point;   /* leaf: `size` entries of km_points from here */
+} dsm_flann_km_node;
+typedef struct dsm_flann_index {
+  int32_t algorithm;      /* flann_algorithm_t: 0 linear, 1 randomised kd-trees, 2 hierarchical k-means */
+  int32_t num_checks;     /* SearchParams::checks, >= 0 on a tree index */
+  uint32_t num_words;     /* must equal the vocabulary's */
+  int32_t branching;      /* k-means */
+  float cb_index;         /* k-means */
+  int32_t km_root;        /* k-means: index of the root node */
+  uint32_t n_kd_nodes, n_kd_roots;
+  const dsm_flann_kd_node* kd_nodes;
+  const int32_t* kd_roots;
+  uint32_t n_km_nodes, reserved;
+  const dsm_flann_km_node* km_nodes;
+  uint64_t n_km_childs;
+  const int32_t* km_childs;
+  uint64_t n_km_points;
+  const uint64_t* km_points;
+  uint64_t n_pivot_floats;
+  const float* pivots;
+} dsm_flann_index;
+int dsm_retrieval_set_flann_index(dsm_ctx* ctx, const dsm_flann_index* index);
+/* The same search for caller-supplied descriptors (n x 128 uint8, host memory): ids [n][k] (INT_MAX where FLANN returned
+ * fewer) and, if not NULL, FLANN's squared L2 distances [n][k]; 1 <= k <= 8.  What the parity tests and
+ * tools/bench_retrieval.py call; *ms (may be NULL) receives the kernel's device time. */
+int dsm_retrieval_flann_search(dsm_ctx* ctx, const uint8_t* descriptors, uint32_t n, uint32_t k, int32_t* ids, float* dists,
+                               double* ms);
 /* VisualIndex::Add (IndexOptions::num_neighbors = 1) for every resident image in list order, then Prepare()
  * (visual_index.h:201-243, 501-505): inverted files sorted by image, IDF weights, normalisation constants. */
 int dsm_retrieval_index(dsm_ctx* ctx);

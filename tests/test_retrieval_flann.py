@@ -210,7 +210,7 @@ def test_word_search_flann_equals_the_oracle_over_the_references_flann(tmp_path,
     L.dsm_host_vocab_candidate_pairs4.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
     res = {}
-    for mode in (1, 0):
+    for mode in (1, 2, 3, 0):  # FLANN on the device, FLANN on host threads, auto (= FLANN: the file carries an index), exact
         pairs = np.zeros((1000, 2), np.uint32)
         scores = np.zeros(1000, np.float32)
         n = L.dsm_host_vocab_candidate_pairs4(dpath.encode(), vpath.encode(), max_images, k, -1, 0, mode, checks, pairs.ctypes.data,
@@ -230,7 +230,8 @@ def test_word_search_flann_equals_the_oracle_over_the_references_flann(tmp_path,
             if q < int(d):
                 exp_pairs.append((q + 1, int(d) + 1))
                 exp_scores.append(np.float32(s) * np.float32(1e3))
-    assert res[1][0] == exp_pairs and (res[1][1] == np.array(exp_scores, np.float32)).all()
+    for mode in (1, 2, 3):
+        assert res[mode][0] == exp_pairs and (res[mode][1] == np.array(exp_scores, np.float32)).all(), mode
     # the approximate search at 24 checks is not the exact one: the two modes score differently
     assert res[0][0] != res[1][0] or not np.array_equal(res[0][1], res[1][1])
     # and the device entry point itself, fed the reference's ids directly
@@ -245,3 +246,108 @@ def test_word_search_flann_equals_the_oracle_over_the_references_flann(tmp_path,
         ids, sc = orc.query(im[0], k, max_images)
         assert list(got[q][0]) == list(ids) and (got[q][1] == sc).all()
     ref.close()
+
+
+# ------------------------------------------------------------------------------------------- the FLANN search ON THE DEVICE (round 5)
+def _device_search(L, path, queries, k, checks):
+    L.dsm_host_flann_device_search.restype = ctypes.c_int
+    L.dsm_host_flann_device_search.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int,
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+    q = np.ascontiguousarray(queries, np.uint8)
+    ids = np.zeros((len(q), k), np.int32)
+    dists = np.zeros((len(q), k), np.float32)
+    ms = ctypes.c_double(0)
+    algo = L.dsm_host_flann_device_search(path.encode(), 0, q.ctypes.data, len(q), k, checks, ids.ctypes.data, dists.ctypes.data, ctypes.byref(ms))
+    return algo, ids, dists, ms.value
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,algo", [("linear", 0), ("kdtree", 1), ("kmeans", 2)])
+def test_device_flann_search_equals_the_references_answers_on_the_goldens(name, algo):
+    """csrc/flann_search.hip against the committed answers of the reference's own knnSearch over the loaded index
+    (tools/make_flann_golden.py): ids AND float distances, k = 5, num_checks 32 and 256; and against the host restatement for
+    k = 1 (VisualIndex::Add's search) and k = 8, where the goldens hold no answer."""
+    L = _host()
+    exp = np.load(os.path.join(GOLDEN, "vocab_flann_expected.npz"))
+    path = os.path.join(GOLDEN, "vocab_flann_%s.bin" % name)
+    for checks in (32, 256):
+        a, ids, dists, ms = _device_search(L, path, exp["queries"], 5, checks)
+        assert a == algo
+        assert (ids == exp["%s_ids_%d" % (name, checks)]).all(), int((ids != exp["%s_ids_%d" % (name, checks)]).sum())
+        assert (dists == exp["%s_dists_%d" % (name, checks)]).all()
+        for k in (1, 8):
+            a, ids, dists, ms = _device_search(L, path, exp["queries"], k, checks)
+            ha, hids, hdists, _ = _product_search(L, path, exp["queries"], k, checks, 2)
+            assert a == ha == algo and (ids == hids).all() and (dists == hdists).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo,p1,p2,n_words", [(flann_ref.KDTREE, 1, 0, 700), (flann_ref.KDTREE, 8, 0, 3000), (flann_ref.KMEANS, 16, 5, 3000),
+                                                (flann_ref.KMEANS, 3, 1, 500), (flann_ref.KMEANS, 32, 15, 9000), (flann_ref.LINEAR, 0, 0, 300),
+                                                (flann_ref.KDTREE, 4, 0, 20000)])
+def test_device_flann_search_equals_the_references_flann_on_fresh_indices(tmp_path, algo, p1, p2, n_words):
+    """Fresh indices built, written and re-loaded by the reference's FLANN (oracle/_ref/libflann_ref.so): clustered words with exact
+    duplicates (equal distances: the heap's and the result set's tie order matters), queries near and far, more queries than one
+    wave holds; k = 1 and 5; num_checks 1, 32, 256 and the index's own autotuned estimate."""
+    _need_ref()
+    L = _host()
+    rng = np.random.default_rng(n_words + 31 * algo + p1)
+    centers = _sift_like(rng, 40)
+    words = np.clip(centers[rng.integers(0, 40, n_words)].astype(np.int32) + rng.integers(-12, 13, (n_words, 128)), 0, 255).astype(np.uint8)
+    words[5] = words[6]
+    words[100:110] = words[99]
+    proj = rng.standard_normal((64, 128)).astype(np.float32)
+    thr = rng.standard_normal((n_words, 64)).astype(np.float32)
+    ix = flann_ref.Index.build_forced(words, algo, p1, p2, autotuned_checks=17, seed=n_words)
+    path = str(tmp_path / "vocab.bin")
+    begin, end = flann_ref.write_reference_vocabulary(path, words, proj, thr, ix, rng, with_entries=True)
+    ix.close()
+    ref = flann_ref.Index.load(words, path, begin)
+    queries = np.concatenate([np.clip(centers[rng.integers(0, 40, 700)].astype(np.int32) + rng.integers(-20, 21, (700, 128)), 0, 255),
+                              words[:120], rng.integers(0, 256, (80, 128))]).astype(np.uint8)
+    for k in (1, 5):
+        for checks in (1, 32, 256, -2):
+            rids, rd = ref.knn(queries, k, num_checks=checks, with_dists=True)
+            a, ids, dists, ms = _device_search(L, path, queries, k, checks)
+            assert a == algo
+            assert (ids == rids).all(), (k, checks, int((ids != rids).sum()))
+            assert (dists == rd).all()
+    ref.close()
+
+
+@pytest.mark.gpu
+def test_device_flann_index_upload_is_bounds_checked(dsm):
+    """dsm_retrieval_set_flann_index validates every index the kernel would follow: a child that points backwards (a cycle), a
+    leaf outside the vocabulary, a pivot outside its array are errors at upload."""
+    from dagsfm_amd import capi
+    rng = np.random.default_rng(3)
+    words = rng.integers(0, 256, (64, 128)).astype(np.uint8)
+    dsm.retrieval_set_vocabulary(words, rng.standard_normal((64, 128)).astype(np.float32), rng.standard_normal((64, 64)).astype(np.float32))
+
+    class KdNode(ctypes.Structure):
+        _fields_ = [("divfeat", ctypes.c_int32), ("divval", ctypes.c_float), ("child1", ctypes.c_int32), ("child2", ctypes.c_int32)]
+
+    class FlannIndex(ctypes.Structure):
+        _fields_ = [("algorithm", ctypes.c_int32), ("num_checks", ctypes.c_int32), ("num_words", ctypes.c_uint32), ("branching", ctypes.c_int32),
+                    ("cb_index", ctypes.c_float), ("km_root", ctypes.c_int32), ("n_kd_nodes", ctypes.c_uint32), ("n_kd_roots", ctypes.c_uint32),
+                    ("kd_nodes", ctypes.c_void_p), ("kd_roots", ctypes.c_void_p), ("n_km_nodes", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                    ("km_nodes", ctypes.c_void_p), ("n_km_childs", ctypes.c_uint64), ("km_childs", ctypes.c_void_p), ("n_km_points", ctypes.c_uint64),
+                    ("km_points", ctypes.c_void_p), ("n_pivot_floats", ctypes.c_uint64), ("pivots", ctypes.c_void_p)]
+
+    def try_upload(nodes):
+        arr = (KdNode * len(nodes))(*[KdNode(*n) for n in nodes])
+        roots = (ctypes.c_int32 * 1)(0)
+        ix = FlannIndex(algorithm=1, num_checks=8, num_words=64, n_kd_nodes=len(nodes), n_kd_roots=1,
+                        kd_nodes=ctypes.cast(arr, ctypes.c_void_p), kd_roots=ctypes.cast(roots, ctypes.c_void_p))
+        L = dsm._L
+        L.dsm_retrieval_set_flann_index.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        return L.dsm_retrieval_set_flann_index(dsm._h, ctypes.byref(ix))
+
+    good = [(5, 100.0, 1, 2), (3, 0.0, -1, -1), (9, 0.0, -1, -1)]
+    assert try_upload(good) == 0
+    assert try_upload([(5, 100.0, 0, 2), (3, 0.0, -1, -1), (9, 0.0, -1, -1)]) != 0   # a child that is the node itself: a cycle
+    assert try_upload([(5, 100.0, 1, 2), (3, 0.0, -1, -1), (64, 0.0, -1, -1)]) != 0  # leaf outside the vocabulary
+    assert try_upload([(128, 100.0, 1, 2), (3, 0.0, -1, -1), (9, 0.0, -1, -1)]) != 0  # split dimension outside the descriptor
+    assert try_upload([(5, 100.0, 1, 7), (3, 0.0, -1, -1), (9, 0.0, -1, -1)]) != 0   # child outside the node array
+    L = dsm._L
+    assert L.dsm_retrieval_set_flann_index(dsm._h, None) == 0  # back to the exact search
