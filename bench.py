@@ -151,6 +151,9 @@ def parse_args():
                          "line then carries the measured exchange time")
     ap.add_argument("--no-second-regime", action="store_true",
                     help="skip the low-inlier-ratio side measurement (extra.low_inlier_regime) after the timed region")
+    ap.add_argument("--no-config3", action="store_true",
+                    help="skip the 2 000-image matching-only side measurement (extra.config3_match_only: BASELINE configs[2], the shape north_star's "
+                         ">= 10x the host CPU on 2 000-image exhaustive matching target is stated on) after the timed region")
     ap.add_argument("--dump-line", default="", help="rank 0 also writes the long form of the result (with the prose notes) to this file")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="debug: all ranks on device 0 over gloo (exercises the multi-rank path on a 1-GPU box)")
@@ -187,7 +190,7 @@ def cpu_baseline(orc, label, build, scene_images, pairs, budget_s, verify, cams,
     per host core like the reference's matcher/verifier thread pools (/root/reference/src/feature/matching.cc:640-674)."""
     import threading
     from dagsfm_amd import capi
-    kps = [None if im is None else im[1].astype(np.float64) for im in scene_images]
+    kps = [im[1].astype(np.float64) if (verify and im is not None) else None for im in scene_images]
     order = np.linspace(0, len(pairs) - 1, min(len(pairs), 65536)).astype(np.int64)
     lock = threading.Lock()
     state = {"next": 0, "pairs": 0, "models": 0}
@@ -516,10 +519,45 @@ def main():
                     "pairs_per_s": len(pairs2) * len(t_steps) / sum(t_steps), "verify_us_per_pair": 1e3 * kv2 / len(t_steps) / len(pairs2),
                     "ms_per_step": 1e3 * sum(t_steps) / len(t_steps), "pairs": int(len(pairs2)),
                     "pairs_with_geometry": int(sum(1 for t in tv2 if t.config > 1)),
-                    "workload": "%d images x %d feats, exhaustive, outlier_frac 0.5 (putative inlier ratio 0.25), %s; 2 steps after "
-                                "the timed region, not part of value" % (n2, args.feats, fam)}}
+                    "workload": "%d images x %d feats, exhaustive, inlier ratio 0.25" % (n2, args.feats),
+                    "workload_note": "outlier_frac 0.5 (putative inlier ratio 0.25), %s; 2 steps after the timed region, not part of value" % fam}}
             except Exception as e:  # the side measurement must never cost the headline line
                 out["extra"] = {"low_inlier_regime": {"error": repr(e)}}
+        # ---- BASELINE configs[2] in the driver's line (missing 6): 2 000 images x the same feature count, exhaustive,
+        # matching only (descriptors resident, one warm-up + one timed pass), with the CPU matcher of oracle/ on the host's cores
+        # beside it -- the shape north_star's ">= 10x the host-CPU baseline on 2 000-image exhaustive matching" target names.
+        # After the timed region; never part of `value`.
+        if world == 1 and not args.no_config3 and args.shard_of == 1 and not args.max_pairs and args.images == 500 and args.pairs == "exhaustive" \
+                and not args.fixed_trials and verify:
+            try:
+                n3 = 2000
+                scene3 = synthetic.Scene(n3, args.feats, seed=args.seed, outlier_frac=args.outlier_frac)
+                desc3 = [scene3.image(i)[0] for i in range(n3)]
+                pairs3 = synthetic.exhaustive_pairs(n3)
+                ctx.set_images(desc3)
+                t3 = []
+                for it in range(2):
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                    ctx.match_pairs(pairs3, opts)
+                    ctx.sync()
+                    t3.append(time.perf_counter() - ts)
+                k1_3, _ = ctx.match_kernel_time()
+                c3 = {"pairs": int(len(pairs3)), "pairs_per_s": len(pairs3) / t3[1], "s_per_step": t3[1], "k1_pass1_ms": k1_3,
+                      "total_matches": int(ctx.match_counts().sum()),
+                      "workload": "%d images x %d feats, exhaustive, match only" % (n3, args.feats),
+                      "workload_note": "BASELINE configs[2]; one pass after a warm-up, after the timed region, not part of value"}
+                if args.cpu_seconds > 0:
+                    from tests import oracle_lib
+                    cb = cpu_baseline(oracle_lib.load(), "-O3", "-O3", [(d,) for d in desc3], pairs3, min(5.0, args.cpu_seconds), False, None, None, 0,
+                                      min(host_cores(), 256))
+                    c3["cpu_pairs_per_s"] = cb["value"]
+                    c3["cpu_sample_note"] = cb["sample"]
+                    c3["gpu_over_cpu"] = c3["pairs_per_s"] / max(cb["value"], 1e-9)
+                out.setdefault("extra", {})["config3_match_only"] = c3
+                del desc3
+            except Exception as e:
+                out.setdefault("extra", {})["config3_match_only"] = {"error": repr(e)}
         if world == 1 and args.cpu_seconds > 0:
             from tests import oracle_lib
             cores = min(host_cores(), 256)
