@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cstddef>
 #include <cstring>
+#include <new>
 #include <limits>
 #include <thread>
 
@@ -15,6 +16,7 @@ const size_t kBlockBytes = 1024 * 64;  // BLOCK_BYTES, util/serialization.h:374
 // LZ4_COMPRESSBOUND(BLOCK_BYTES): LoadArchive::loadBlock refuses larger blocks (serialization.h:677-681)
 const uint64_t kMaxCompressedBlock = kBlockBytes + kBlockBytes / 255 + 16;
 const int kVecLen = 128;
+const size_t kMaxDecodedArchive = size_t(16) << 30;  // 16 GiB: ~ 8 kd-trees / a k-means tree with float centres over 2^24 words
 const int kMaxTreeDepth = 4096;  // recursion guard of the loader (FLANN splits at the mean / by cluster: real trees are tens of levels deep; a damaged file must not overflow the stack)
 
 // One LZ4 block (the format of ext/lz4.c's LZ4_decompress_safe_continue): sequences of token, literal run, 2-byte
@@ -118,6 +120,9 @@ bool FlannReadArchive(const uint8_t* buf, size_t size, size_t* at, std::vector<u
     if (block == 0) break;
     if (block >= kMaxCompressedBlock || size - pos < block) return false;
     if (out && !Lz4DecodeBlock(buf + pos, static_cast<size_t>(block), &payload)) return false;
+    // an LZ4 block of a few bytes can expand to 64 KiB: without a bound a crafted file of some MB decodes to tens of GB
+    // (ADVICE r04).  A real index is its points' references plus a tree over them: generously below this.
+    if (payload.size() > kMaxDecodedArchive) return false;
     pos += static_cast<size_t>(block);
   }
   if (out) {
@@ -231,6 +236,16 @@ bool FlannIndex::ReadKmNode(const uint8_t* s, size_t n, size_t* at, int32_t* ind
 }
 
 bool FlannIndex::Load(const uint8_t* buf, size_t size, size_t* at, const uint8_t* words, uint32_t num_words) {
+  try {
+    return LoadImpl(buf, size, at, words, num_words);
+  } catch (const std::bad_alloc&) {  // a file that asks for more memory than the host has is a bad file, not a crash
+    algorithm_ = -1;
+    error_ = "out of memory while reading the FLANN index";
+    return false;
+  }
+}
+
+bool FlannIndex::LoadImpl(const uint8_t* buf, size_t size, size_t* at, const uint8_t* words, uint32_t num_words) {
   algorithm_ = -1;
   words_ = words;
   num_words_ = num_words;

@@ -88,6 +88,7 @@ class FlannIndex {
   void KdSearchLevel(ResultSet* result, const uint8_t* vec, int32_t node, float mindist, int* check_count, int max_check,
                      BranchHeap* heap, std::vector<uint64_t>* checked) const;
   void KmFindNN(int32_t node, ResultSet* result, const uint8_t* vec, int* checks, int max_checks, BranchHeap* heap) const;
+  bool LoadImpl(const uint8_t* buf, size_t size, size_t* at, const uint8_t* words, uint32_t num_words);
   bool ReadKdNode(const uint8_t* s, size_t n, size_t* at, int32_t* index, int depth);
   bool ReadKmNode(const uint8_t* s, size_t n, size_t* at, int32_t* index, int depth);
 
