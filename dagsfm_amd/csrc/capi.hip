@@ -1035,7 +1035,9 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     // stream, own host thread, own scratch; see VerifyLane).  A pair's three families cannot overlap -- F starts from
     // the generator state E ends with -- but different pairs can, and the replay / local-optimisation launches of
     // one lane are latency chains that leave most of the chip idle.
-    uint32_t n_lanes = n_pairs >= 4096 ? 2 : 1;
+    // (two lanes from 1 024 pairs on: config 1's 1 225 pairs 7.97 vs 8.27 ms per step, a 15 594-pair shard 78.4 vs 85.3; three or four lanes
+    // lose on both, profiles/r05_lanes_short_lists.txt)
+    uint32_t n_lanes = n_pairs >= 1024 ? 2 : 1;
     if (const char* e = ctx->dbg("DSM_VERIFY_LANES")) n_lanes = (uint32_t)std::max(1, std::min(DSM_VERIFY_MAX_LANES, atoi(e)));
     n_lanes = std::max<uint32_t>(1, std::min<uint32_t>(n_lanes, n_pairs));
     // Scratch of the speculated trials: as much of the pair list per chunk as memory allows (every chunk pays the
