@@ -367,6 +367,10 @@ class FlannIndex::BranchHeap {
     std::push_heap(heap_.begin(), heap_.end(), Compare());
     ++count_;
   }
+  void Clear() {  // a fresh heap for the next query, the allocation kept (FLANN allocates one per search: same behaviour, no malloc)
+    heap_.clear();
+    count_ = 0;
+  }
   bool PopMin(Branch* value) {
     if (count_ == 0) return false;
     *value = heap_[0];
@@ -484,15 +488,26 @@ bool FlannIndex::Export(int num_checks, dsm_flann_index* out) const {
   return true;
 }
 
-void FlannIndex::SearchOne(const uint8_t* vec, int num_checks, ResultSet* result) const {
+// What one search needs beyond the result set: the branch heap (FLANN: `new Heap<BranchSt>((int)size_)` per query) and the kd-trees'
+// `checked` bitset (DynamicBitset(size_) per query).  Here one of each per WORKER, reset between queries -- the same contents at the
+// start of every search without two allocations of num_words entries per descriptor.
+struct FlannIndex::SearchScratch {
+  BranchHeap heap;
+  std::vector<uint64_t> checked;
+  SearchScratch(uint32_t num_words, bool kd) : heap(static_cast<int>(num_words)), checked(kd ? num_words / 64 + 1 : 0, 0) {}
+};
+
+void FlannIndex::SearchOne(const uint8_t* vec, int num_checks, ResultSet* result, SearchScratch* scratch) const {
   if (algorithm_ == kLinear) {  // LinearIndex::findNeighbors, linear_index.h:130-146
     for (uint32_t i = 0; i < num_words_; ++i) result->AddPoint(DistU8U8(words_ + static_cast<size_t>(i) * kVecLen, vec), i);
     return;
   }
-  BranchHeap heap(static_cast<int>(num_words_));  // new Heap<BranchSt>((int)size_)
+  BranchHeap& heap = scratch->heap;
+  heap.Clear();
   Branch branch;
   if (algorithm_ == kKdTree) {  // KDTreeIndex::getNeighbors, kdtree_index.h:543-566
-    std::vector<uint64_t> checked(num_words_ / 64 + 1, 0);
+    std::vector<uint64_t>& checked = scratch->checked;
+    std::fill(checked.begin(), checked.end(), 0);
     int check_count = 0;
     for (size_t t = 0; t < kd_roots_.size(); ++t) KdSearchLevel(result, vec, kd_roots_[t], 0.0f, &check_count, num_checks, &heap, &checked);
     while (heap.PopMin(&branch) && (check_count < num_checks || !result->Full()))
@@ -517,9 +532,10 @@ bool FlannIndex::FindWordIds(const uint8_t* descriptors, uint32_t n, uint32_t k,
   auto run = [&](uint32_t begin, uint32_t end) {
    try {
     ResultSet result(k);
+    SearchScratch scratch(algorithm_ == kLinear ? 0u : num_words_, algorithm_ == kKdTree);
     for (uint32_t i = begin; i < end; ++i) {
       result.Clear();
-      SearchOne(descriptors + static_cast<size_t>(i) * kVecLen, num_checks, &result);
+      SearchOne(descriptors + static_cast<size_t>(i) * kVecLen, num_checks, &result, &scratch);
       const size_t m = std::min<size_t>(result.count_, k);
       for (size_t j = 0; j < m; ++j) {
         out_ids[static_cast<size_t>(i) * k + j] = static_cast<int32_t>(static_cast<int>(result.dist_index_[j].index));  // word_ids.cast<int>()

@@ -84,7 +84,8 @@ class FlannIndex {
   struct ResultSet;
   struct Branch;
   class BranchHeap;
-  void SearchOne(const uint8_t* vec, int num_checks, ResultSet* result) const;
+  struct SearchScratch;
+  void SearchOne(const uint8_t* vec, int num_checks, ResultSet* result, SearchScratch* scratch) const;
   void KdSearchLevel(ResultSet* result, const uint8_t* vec, int32_t node, float mindist, int* check_count, int max_check,
                      BranchHeap* heap, std::vector<uint64_t>* checked) const;
   void KmFindNN(int32_t node, ResultSet* result, const uint8_t* vec, int* checks, int max_checks, BranchHeap* heap) const;

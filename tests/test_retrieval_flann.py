@@ -316,6 +316,34 @@ def test_device_flann_search_equals_the_references_flann_on_fresh_indices(tmp_pa
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("algo,p1,p2,n_words", [(flann_ref.KDTREE, 1, 0, 2), (flann_ref.KDTREE, 4, 0, 33), (flann_ref.KMEANS, 2, 1, 5),
+                                                (flann_ref.KMEANS, 4, 2, 70), (flann_ref.LINEAR, 0, 0, 1), (flann_ref.LINEAR, 0, 0, 7)])
+def test_device_flann_search_on_tiny_vocabularies(tmp_path, algo, p1, p2, n_words):
+    """Fewer words than neighbours asked for (the rest of the row is kInvalidWordId), trees of one or two levels, zero checks: the
+    device search, the host restatement and the reference's FLANN agree."""
+    _need_ref()
+    L = _host()
+    rng = np.random.default_rng(1000 + n_words + algo)
+    words = _sift_like(rng, n_words)
+    ix = flann_ref.Index.build_forced(words, algo, p1, p2, autotuned_checks=3, seed=n_words)
+    path = str(tmp_path / "vocab.bin")
+    begin, end = flann_ref.write_reference_vocabulary(path, words, rng.standard_normal((64, 128)).astype(np.float32),
+                                                      rng.standard_normal((n_words, 64)).astype(np.float32), ix)
+    ix.close()
+    ref = flann_ref.Index.load(words, path, begin)
+    queries = np.concatenate([_sift_like(rng, 130), words]).astype(np.uint8)
+    for k in (1, 5, 8):
+        for checks in (0, 1, 256):
+            rids, rd = ref.knn(queries, k, num_checks=checks, with_dists=True)
+            a, ids, dists, ms = _device_search(L, path, queries, k, checks)
+            ha, hids, hd, _ = _product_search(L, path, queries, k, checks, 1)
+            assert a == ha == algo
+            assert (hids == rids).all() and (hd == rd).all(), ("host", k, checks)
+            assert (ids == rids).all() and (dists == rd).all(), ("device", k, checks)
+    ref.close()
+
+
+@pytest.mark.gpu
 def test_device_flann_index_upload_is_bounds_checked(dsm):
     """dsm_retrieval_set_flann_index validates every index the kernel would follow: a child that points backwards (a cycle), a
     leaf outside the vocabulary, a pivot outside its array are errors at upload."""
