@@ -154,6 +154,7 @@ def parse_args():
     ap.add_argument("--no-config3", action="store_true",
                     help="skip the 2 000-image matching-only side measurement (extra.config3_match_only: BASELINE configs[2], the shape north_star's "
                          ">= 10x the host CPU on 2 000-image exhaustive matching target is stated on) after the timed region")
+    ap.add_argument("--ctx-after-pg", action="store_true", help="experiment: create the dsm contexts after the process group (the order of rounds 1 - 4)")
     ap.add_argument("--dump-line", default="", help="rank 0 also writes the long form of the result (with the prose notes) to this file")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="debug: all ranks on device 0 over gloo (exercises the multi-rank path on a 1-GPU box)")
@@ -250,6 +251,11 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     comm_dev = dev
+    # The contexts come BEFORE the process group: a context creates its streams at once (its own + the second verification lane's) and
+    # the HIP runtime hands out hardware queues in creation order; behind RCCL's streams the two lanes shared a queue and the
+    # verification lost the overlap of its lanes (322 vs 288 ms per step).  --ctx-after-pg: the old order (A/B).
+    n_ctx = max(1, args.contexts)
+    ctxs = [] if args.ctx_after_pg else [capi.Context(dev_index) for _ in range(n_ctx)]
     if world > 1:
         if args.oversubscribe:  # several ranks on one GPU: RCCL refuses that, gloo moves host copies
             dist.init_process_group("gloo")
@@ -292,8 +298,8 @@ def main():
     bounds = sharding.shard_bounds(len(pairs), world, costs)
     my_pairs = pairs[bounds[rank]:bounds[rank + 1]]
 
-    n_ctx = max(1, args.contexts)
-    ctxs = [capi.Context(dev_index) for _ in range(n_ctx)]
+    if not ctxs:
+        ctxs = [capi.Context(dev_index) for _ in range(n_ctx)]
     ctx = ctxs[0]
     info = ctx.device_info()
     cams = [capi.simple_pinhole(scene.focal, scene.width / 2.0, scene.height / 2.0, scene.width, scene.height, calibrated)
@@ -569,11 +575,24 @@ def main():
                 out["cpu_baseline_native"] = cpu_baseline(native, "built -O3 -march=native on this host (labelled second baseline, SURVEY 8d)",
                                                           "-O3 -march=native", images, pairs, args.cpu_seconds - share, verify, cams,
                                                           topts, user_seed, cores)
-        print(format_line(out, args.dump_line), flush=True)
+        result_line = format_line(out, args.dump_line)
+    # RCCL prints a version banner through C stdio when the first communicator comes up; redirected to a file or a pipe it sits
+    # in the C buffer until exit -- i.e. it would land BEHIND the result line.  Every rank flushes the C streams now, the ranks
+    # meet, and only then does rank 0 print: the JSON line is the last thing on stdout.
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     if world > 1:
         dist.barrier()
+    if rank == 0:
+        print(result_line, flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

@@ -97,6 +97,13 @@ int dsm_ctx_create(int device, dsm_ctx** out_ctx) {
     g_create_error = "hipStreamCreate failed";
     return DSM_ERR_HIP;
   }
+  // The second verification lane's stream, created NOW (lane 0 runs on c->stream): the runtime hands a stream its hardware queue
+  // when the stream is created, from a small pool (ROCclr: 4 by default), and two busy streams on one queue serialise.  A host
+  // that creates its contexts first -- before RCCL, before worker streams of its own -- gives the two lanes queues of their
+  // own; created lazily at the first dsm_verify_pairs they got whatever was left (bench.py --force-collectives: 322 ms of
+  // verification against 288, profiles/r05_lanes_hw_queues.txt).  Not fatal if it fails here: the lane creates it when it runs.
+  c->lanes[0].stream = c->stream;
+  if (hipStreamCreateWithFlags(&c->lanes[1].stream, hipStreamNonBlocking) != hipSuccess) c->lanes[1].stream = nullptr;
   // acos LUT over the integer dot product, built with the host libm so that the float
   // compares of sift.cc:140-155 are reproduced bit for bit.
   std::vector<float> lut(262145);
@@ -141,7 +148,7 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
       b->release();
     if (L.done) (void)hipEventDestroy(L.done);
     if (L.host_ctr) (void)hipHostFree(L.host_ctr);
-    if (L.stream) (void)hipStreamDestroy(L.stream);
+    if (L.stream && L.stream != ctx->stream) (void)hipStreamDestroy(L.stream);
   }
   if (ctx->vev0) (void)hipEventDestroy(ctx->vev0);
   if (ctx->vev1) (void)hipEventDestroy(ctx->vev1);
@@ -1140,7 +1147,17 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
           VerifyLane& L = ctx->lanes[li];
           const uint32_t chunk = plan.chunk[li];
           const uint32_t lane_blocks = std::min<uint32_t>(chunk, (uint32_t)dev_cus * 4u * DSM_REPLAY_WAVES);
-          if (!L.stream) LRES(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+          // Lane 0 runs on the context's own stream, the others get one each.  The runtime maps a process's streams onto a small
+          // pool of hardware queues (ROCclr: GPU_MAX_HW_QUEUES = 4 by default) and streams that share a queue serialise: with
+          // the null stream, the context's stream and one stream per lane, THREE lanes made five streams -- measured as "three
+          // lanes are slower than one" until the queue pool was raised (profiles/r05_lanes_hw_queues.txt).  One stream fewer
+          // keeps three lanes inside the default pool.
+          if (!L.stream) {
+            if (li == 0)
+              L.stream = ctx->stream;
+            else
+              LRES(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+          }
           if (!L.done) LRES(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
           if (!L.host_ctr) LRES(hipHostMalloc(reinterpret_cast<void**>(&L.host_ctr), 128, hipHostMallocDefault));
           LRES(L.active.reserve(128));
