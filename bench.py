@@ -154,6 +154,7 @@ def parse_args():
     ap.add_argument("--no-config3", action="store_true",
                     help="skip the 2 000-image matching-only side measurement (extra.config3_match_only: BASELINE configs[2], the shape north_star's "
                          ">= 10x the host CPU on 2 000-image exhaustive matching target is stated on) after the timed region")
+    ap.add_argument("--no-match-lock", action="store_true", help="experiment: with --contexts > 1, let the contexts' matching calls overlap")
     ap.add_argument("--ctx-after-pg", action="store_true", help="experiment: create the dsm contexts after the process group (the order of rounds 1 - 4)")
     ap.add_argument("--dump-line", default="", help="rank 0 also writes the long form of the result (with the prose notes) to this file")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -336,8 +337,11 @@ def main():
         # several contexts: the matching calls take turns (they all want the matrix pipe), each context's verification
         # (FP64 VALU, latency chains) then runs next to the following context's matching -- the reference's matcher and
         # verifier thread pools overlap the same way (/root/reference/src/feature/matching.cc:640-674)
-        with match_turn:
+        if args.no_match_lock:
             ctxs[k].match_pairs(cparts[k], opts)
+        else:
+            with match_turn:
+                ctxs[k].match_pairs(cparts[k], opts)
         if verify:
             ctxs[k].verify_pairs(topts, user_seed=user_seed, stage_filter=True)
 
