@@ -67,3 +67,19 @@ def test_a_missing_contract_key_is_refused():
     out["roofline"].pop("traffic")
     with pytest.raises(SystemExit):
         bench.format_line(out)
+
+
+def test_contexts_are_created_before_the_process_group():
+    """profiles/r05_lanes_hw_queues.txt: the HIP runtime hands a stream its hardware queue at creation; a context created BEHIND an
+    RCCL communicator found the pool exhausted, its two verification lanes shared a queue and every rank of an N > 1 run verified
+    20 % slower.  bench.py must create its contexts (dsm_ctx_create creates both lane streams) before init_process_group, and print
+    the result line after flushing the C streams (RCCL's banner must not land behind it)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    first_ctx = main.index("capi.Context(dev_index)")
+    assert first_ctx < main.index('dist.init_process_group("nccl"'), "contexts first, then the RCCL process group"
+    assert main.index("fflush(None)") < main.index("print(result_line"), "C streams flushed before the JSON line"
+    capi_src = open(os.path.join(ROOT, "dagsfm_amd", "csrc", "capi.hip")).read()
+    create = capi_src[capi_src.index("dsm_ctx_create(int device"):]
+    create = create[:create.index("\n}\n")]
+    assert "lanes[1].stream" in create and "lanes[0].stream = c->stream" in create, "both lane streams exist when dsm_ctx_create returns"
