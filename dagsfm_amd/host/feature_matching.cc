@@ -802,6 +802,20 @@ int dsm_host_flann_device_search(const char* vocab_path, int device, const uint8
   dsm_ctx_destroy(ctx);
   return rc == DSM_OK ? index.algorithm() : -5;
 }
+// Hands the FLANN index of a vocabulary file (reference layout) to an EXISTING context whose vocabulary is that file's:
+// dsm_retrieval_set_flann_index over the parsed trees.  For tools that drive the C-ABI themselves (tools/bench_retrieval.py);
+// `ctx` is the dsm_ctx* of the same libdagsfm_mi355x.so instance.  Returns the algorithm (>= 0) or a negative error.
+int dsm_host_flann_attach(const char* vocab_path, void* ctx, int num_checks) {
+  VocabularyFile v;
+  if (!ctx || !v.ReadReferenceLayout(vocab_path) || !v.flann_framed) return -1;
+  FlannIndex index;
+  size_t at = 0;
+  if (!index.Load(v.flann_blob.data(), v.flann_blob.size(), &at, v.words.data(), v.num_words)) return -2;
+  dsm_flann_index flat;
+  if (!index.Export(num_checks, &flat)) return -3;
+  if (dsm_retrieval_set_flann_index(static_cast<dsm_ctx*>(ctx), &flat) != DSM_OK) return -5;
+  return index.algorithm();
+}
 // where ReadReferenceLayout found the FLANN index of a vocabulary file in the reference's layout: begin / end offsets,
 // *framed = 1 when it walked FLANN's archive framing (0: located the inverted index by its header).  Returns num_words.
 uint32_t dsm_host_vocabulary_index_range(const char* path, uint64_t* begin, uint64_t* end, int* framed) {

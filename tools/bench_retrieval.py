@@ -30,6 +30,11 @@ def main():
     ap.add_argument("--num-images", type=int, default=100)
     ap.add_argument("--neighbors", type=int, default=5)
     ap.add_argument("--cpu-images", type=int, default=0, help="time the CPU oracle's word assignment on this many images (0 = skip)")
+    ap.add_argument("--flann", default="", choices=["", "kdtree", "kmeans"],
+                    help="word_search = kFlann: a FLANN index (kd-trees x 4 / k-means branching 32) built over the vocabulary by the reference's own "
+                         "FLANN (oracle/_ref/libflann_ref.so), written into a vocabulary file in the reference's layout, parsed by the host shim and "
+                         "searched on the device (csrc/flann_search.hip) with --checks; default: the exact MFMA search")
+    ap.add_argument("--checks", type=int, default=256)
     ap.add_argument("--verify", type=int, default=0, help="num_images_after_verification: also time the spatial re-ranking")
     a = ap.parse_args()
     scene = synthetic.Scene(a.images, a.feats, seed=0)
@@ -38,6 +43,22 @@ def main():
     ctx = capi.Context(0)
     ctx.set_images([im[0] for im in ims])
     ctx.retrieval_set_vocabulary(*voc)
+    if a.flann:
+        import ctypes
+        import tempfile
+        from tests import flann_ref
+        if flann_ref.load() is None:
+            raise SystemExit("oracle/_ref/libflann_ref.so is missing (make -C oracle ref where /root/reference exists)")
+        algo, p1, p2 = (flann_ref.KDTREE, 4, 0) if a.flann == "kdtree" else (flann_ref.KMEANS, 32, 5)
+        ix = flann_ref.Index.build_forced(voc[0], algo, p1, p2, autotuned_checks=32, seed=3)
+        vpath = os.path.join(tempfile.mkdtemp(), "vocab_tree.bin")
+        flann_ref.write_reference_vocabulary(vpath, voc[0], voc[1], voc[2], ix)
+        ix.close()
+        H = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dagsfm_amd", "libdagsfm_host.so"))
+        H.dsm_host_flann_attach.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int]
+        rc = H.dsm_host_flann_attach(vpath.encode(), ctx._h, a.checks)
+        if rc != algo:
+            raise SystemExit("dsm_host_flann_attach failed: %d" % rc)
     ctx.retrieval_index()  # warm-up (allocations)
     t0 = time.perf_counter()
     ctx.retrieval_index()
@@ -55,7 +76,9 @@ def main():
            "unit": "images/s", "images": a.images, "feats": a.feats, "words": a.words, "neighbors": a.neighbors,
            "images_per_query": a.num_images, "index_s": t1 - t0, "query_s": t2 - t1, "index_device_ms": t_index,
            "query_device_ms": t_query, "candidate_pairs": len(pairs), "queries_retrieving_themselves_first": self_first,
-           "word_assignment_int8_ops_per_image": 2.0 * 128 * a.feats * a.words}
+           "word_assignment_int8_ops_per_image": 2.0 * 128 * a.feats * a.words,
+           "word_search": ("flann %s, num_checks %d (the reference's approximate search on the device: csrc/flann_search.hip)" % (a.flann, a.checks)) if a.flann
+                          else "exact (int8 MFMA; a deviation from the reference)"}
     if a.verify > 0:
         # spatial re-ranking (QueryOptions::num_images_after_verification): candidate tuples on the device, then the host
         # shim's SpatialRerank per query (called here one query after the other through its C export; the shim itself
