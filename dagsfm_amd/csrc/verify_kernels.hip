@@ -2068,6 +2068,183 @@ __global__ __launch_bounds__(64, 8) void k_prescore(const VerifyParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------ the H bound step with an f32 first stage (round 5)
+// k_prescore<H> spends 18 FP64 VALU instructions on every (model, point) to learn what a much coarser test decides for almost all of
+// them: is the transfer error below, or above, the threshold?  k_prescore_h2 classifies every point first in PACKED f32 (v_pk_fma_f32:
+// two points per instruction) against a BAND of +- 12.5 % around the threshold radius,
+//   L~ < 0.875^2 (1 - 2^-8) T Q~  -> surely in        L~ > 1.125^2 (1 + 2^-8) T Q~  -> surely out        (both only if |p~_2| >= g)
+//   (L~ = e~_0^2 + e~_1^2, e~_k = d_k p~_2 - p~_k, Q~ = p~_2^2; all f32),
+// and only the points in between -- a residual within an eighth of the threshold radius: a few per model -- go, per lane, onto a short
+// list that the FP64 test of prescore_flags works off afterwards.  (A first form sent a point to the FP64 test whenever ANY lane of the
+// wave failed to reject it: with 64 models per wave that is nearly every point -- 72 ms against k_prescore<H>'s 36;
+// profiles/r05_prescore_f32_stage.txt.)  The band is what makes f32 safe without fine margins (u = 2^-24; H scaled by a power of two so
+// that its largest entry is in [1, 2), which the homogeneous test does not see; A_k as in prescore_bounds, on the scaled model):
+//   inputs rounded to f32 and two fused roundings per row: |p~_k - P_k| <= 5u A_k;  |e~_k - e*_k| <= u (G_k + 1.01 |e*_k|) with
+//   G_k = 6.01 max|d_k| A_2 + 5 A_k;  sqrt(L~) within 2.03u ||e*|| + 1.02u G of ||e*|| (G = G_0 + G_1), sqrt(Q~) within 5.6u A_2 of |P_2|.
+//   out:  L~ > fl(K_out Q~), K_out >= 1.1272^2 T  =>  ||e*|| >= [1.1272 sqrt(T) (1 - u) (|P_2| - 5.6u A_2) - 1.02u G] / (1 + 2.03u)
+//         >= 1.004 sqrt(T) |P_2|   once   |P_2| >= u (51.3 A_2 + 8.29 G / sqrt(T));
+//   in:   L~ < fl(K_in Q~),  K_in <= 0.8733^2 T   =>  ||e*|| <= [0.8733 sqrt(T) (1 + u) (|P_2| + 5.6u A_2) + 1.02u G] / (1 - 2.03u)
+//         <= 0.996 sqrt(T) |P_2|   once   |P_2| >= u (40 A_2 + 8.4 G / sqrt(T)).
+//   The guard on the COMPUTED value, |p~_2| >= g = max(u (58 A_2 + 8.6 G / sqrt(T)), 2^-16 A_2, 2^-24 max(A_0, A_1), 2^-60), covers both
+//   (|P_2| >= |p~_2| - 5u A_2), covers the entries that flush to zero in f32 after the scaling (below 2^-126: they move p~_k by at most
+//   2^-110), and implies the FP64 test's own precondition |P_2| >= P_min (2^34 E_2 = 2^-17 A_2, 2^26 E_01 = 2^-25 A_01), under which the
+//   reference's evaluation is within 2^-20 px (1 + 2^-5) + 2^-33 |dd| of the exact residual (analysis above k_prescore): an exact
+//   residual <= 0.996 sqrt(T) is an inlier of the reference, one >= 1.004 sqrt(T) an outlier, for T >= 2^-6 and coordinates below 2^14
+//   (t_ok, x_ok: otherwise the f32 stage is off, like the FP64 one).  Inf / NaN (a model beyond f32's range) make every compare
+//   false: the point goes to the FP64 test.  tools/check_score_bounds.py holds every slot's exact count against [lower, upper].
+// Cost per (model, point): 12 packed instructions per TWO points, three compares and two counts per point: ~12 instead of 18, plus the
+// FP64 test for the listed points (the wave loops to its longest list).
+typedef float dsm_f32x2 __attribute__((ext_vector_type(2)));
+DSM_DEV dsm_f32x2 pk_fma(dsm_f32x2 a, dsm_f32x2 b, dsm_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+DSM_DEV dsm_f32x2 pk2(float x) {
+  dsm_f32x2 v = {x, x};
+  return v;
+}
+#define PRESCORE_LIST_CAP 24
+__global__ __launch_bounds__(64, 6) void k_prescore_h2(const VerifyParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* s32 = reinterpret_cast<float*>(smem_raw);  // the points as f32 pairs (16 bytes per point), then the lanes' lists; the FP64 points stay in global memory / L2
+  // (with the FP64 copy in the LDS as well -- 15 KB per 256 points -- the kernel runs at 2.5 waves per SIMD: 57 ms instead of 33)
+  const uint32_t pl = blockIdx.x;
+  const uint32_t pi = p.pair0 + pl;
+  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_H;
+  if (!fs->active) return;
+  const int lane = threadIdx.x;
+  const int nb = (int)fs->nb;
+  const int t = blockIdx.y * 64 + lane;
+  if ((int)(blockIdx.y * 64) >= nb) return;
+  const uint64_t moff = p.match_off[pi];
+  const int n = (int)(p.match_off[pi + 1] - moff);
+  const double* gpts = p.pts_px + 4 * moff;
+  const bool in_lds = n <= VP_LDS_PTS;
+  const double T = p.opt.max_error * p.opt.max_error;
+  const bool has_slot = t < nb;
+  const bool has_model = has_slot && 0 < p.nmodels[(size_t)pl * p.batch + (has_slot ? t : 0)];
+  const double* gm = p.models + ((size_t)pl * p.batch + (has_slot ? t : 0)) * 9;
+  double M[9];
+  for (int k = 0; k < 9; ++k) M[k] = has_model ? gm[k] : 0.0;
+  int lb = 0, sure_out = n + 1;
+  double mx[4];
+  stage_points_with_maxima(gpts, n, false, nullptr, lane, mx);
+  if (!in_lds) {  // the points do not fit the LDS: the FP64 loop over wave-uniform global addresses, as k_prescore<H>
+    if (has_model) {
+      const PreBounds b = prescore_bounds<FAM_H>(M, mx, T);
+      sure_out = 0;
+#pragma unroll 4
+      for (int i = 0; i < n; ++i) prescore_point<FAM_H>(M, b, gpts + (size_t)i * 4, lb, sure_out);
+    }
+  } else {
+    // the points once more as f32, two points per 32-byte record: (s0a, s0b, s1a, s1b, d0a, d0b, d1a, d1b); an odd last point twice
+    const int npair = (n + 1) / 2;
+    uint16_t* lst = reinterpret_cast<uint16_t*>(s32 + (size_t)8 * npair);  // entry k of lane l at [k * 64 + l]
+    for (int j = lane; j < npair; j += 64) {
+      const int ia = 2 * j, ib = 2 * j + 1 < n ? 2 * j + 1 : 2 * j;
+      float4 lo, hi;
+      lo.x = (float)gpts[ia * 4 + 0];
+      lo.y = (float)gpts[ib * 4 + 0];
+      lo.z = (float)gpts[ia * 4 + 1];
+      lo.w = (float)gpts[ib * 4 + 1];
+      hi.x = (float)gpts[ia * 4 + 2];
+      hi.y = (float)gpts[ib * 4 + 2];
+      hi.z = (float)gpts[ia * 4 + 3];
+      hi.w = (float)gpts[ib * 4 + 3];
+      reinterpret_cast<float4*>(s32)[2 * j] = lo;
+      reinterpret_cast<float4*>(s32)[2 * j + 1] = hi;
+    }
+    __syncthreads();
+    const PreBounds b = prescore_bounds<FAM_H>(M, mx, T);
+    // ---- the model in f32 (largest entry scaled into [1, 2)), the guard g, the band's constants
+    float H[9], g = __builtin_inff(), k_out = __builtin_inff(), k_in = -1.0f;
+    {
+      double big = 0.0;
+      for (int k = 0; k < 9; ++k) big = fmax(big, fabs(M[k]));
+      const bool usable = has_model && (b.c0 == b.c0) && big >= 0x1p-900 && big <= 0x1p900;  // (c0 is NaN when t_ok / x_ok fail)
+      const double sc = usable ? ldexp(1.0, -ilogb(big)) : 0.0;
+      double Ms[9];
+      for (int k = 0; k < 9; ++k) {
+        Ms[k] = M[k] * sc;
+        H[k] = (float)Ms[k];
+      }
+      const double A0 = fabs(Ms[0]) * mx[0] + fabs(Ms[1]) * mx[1] + fabs(Ms[2]);
+      const double A1 = fabs(Ms[3]) * mx[0] + fabs(Ms[4]) * mx[1] + fabs(Ms[5]);
+      const double A2 = fabs(Ms[6]) * mx[0] + fabs(Ms[7]) * mx[1] + fabs(Ms[8]);
+      const double G = 6.01 * (mx[2] + mx[3]) * A2 + 5.0 * (A0 + A1 + 2.0 * A2);
+      const double gd = fmax(fmax(0x1p-24 * (58.0 * A2 + 8.6 * G / sqrt(T)), 0x1p-16 * A2), fmax(0x1p-24 * fmax(A0, A1), 0x1p-60)) * 1.001;
+      if (usable && gd <= 0x1p100) {
+        g = (float)gd * 1.0001f;                                     // rounded up
+        k_out = (float)(1.265625 * T * (1.0 + 0x1p-8)) * 1.0001f;      // rounded up
+        k_in = (float)(0.765625 * T * (1.0 - 0x1p-8)) * 0.9999f;       // rounded down
+      }
+    }
+    int cnt = 0;
+    if (has_model) {
+      sure_out = 0;
+      const dsm_f32x2 h0 = pk2(H[0]), h1 = pk2(H[1]), h2 = pk2(H[2]), h3 = pk2(H[3]), h4 = pk2(H[4]), h5 = pk2(H[5]), h6 = pk2(H[6]), h7 = pk2(H[7]),
+                      h8 = pk2(H[8]), ko = pk2(k_out), ki = pk2(k_in);
+      for (int j = 0; j < npair; ++j) {
+        const float4 lo = reinterpret_cast<const float4*>(s32)[2 * j], hi = reinterpret_cast<const float4*>(s32)[2 * j + 1];
+        const dsm_f32x2 s0 = {lo.x, lo.y}, s1 = {lo.z, lo.w}, d0 = {hi.x, hi.y}, d1 = {hi.z, hi.w};
+        const dsm_f32x2 p0 = pk_fma(h0, s0, pk_fma(h1, s1, h2));
+        const dsm_f32x2 p1 = pk_fma(h3, s0, pk_fma(h4, s1, h5));
+        const dsm_f32x2 p2 = pk_fma(h6, s0, pk_fma(h7, s1, h8));
+        const dsm_f32x2 e0 = pk_fma(d0, p2, -p0);
+        const dsm_f32x2 e1 = pk_fma(d1, p2, -p1);
+        const dsm_f32x2 L = pk_fma(e0, e0, e1 * e1);
+        const dsm_f32x2 Q = p2 * p2;
+        const dsm_f32x2 QO = ko * Q, QI = ki * Q;
+        const bool two = 2 * j + 1 < n;
+        const bool ok_a = fabsf(p2.x) >= g, ok_b = two && fabsf(p2.y) >= g;
+        const bool out_a = ok_a && (L.x > QO.x), out_b = ok_b && (L.y > QO.y);
+        const bool in_a = ok_a && (L.x < QI.x), in_b = ok_b && (L.y < QI.y);
+        sure_out += (out_a ? 1 : 0) + (out_b ? 1 : 0);
+        lb += (in_a ? 1 : 0) + (in_b ? 1 : 0);
+        if (!(in_a || out_a)) {  // inside the band (or unguarded): the FP64 test decides, later
+          if (cnt < PRESCORE_LIST_CAP) lst[cnt * 64 + lane] = (uint16_t)(2 * j);
+          ++cnt;
+        }
+        if (two && !(in_b || out_b)) {
+          if (cnt < PRESCORE_LIST_CAP) lst[cnt * 64 + lane] = (uint16_t)(2 * j + 1);
+          ++cnt;
+        }
+      }
+    }
+    // ---- the listed points in FP64; a lane whose list overflowed (a model the f32 stage cannot judge) redoes all of its points
+    const bool overflow = cnt > PRESCORE_LIST_CAP;
+    if (overflow) {
+      lb = 0;
+      sure_out = 0;
+      for (int i = 0; i < n; ++i) prescore_point<FAM_H>(M, b, gpts + (size_t)i * 4, lb, sure_out);
+      cnt = 0;
+    }
+    int maxc = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o));
+    // four listed points per trip, their loads issued together (a trip pays one memory round trip, not four)
+    for (int k0 = 0; k0 < maxc; k0 += 4) {
+      double q[4][4];
+      bool on[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        on[u] = k0 + u < cnt;
+        const double* src = gpts + (size_t)(on[u] ? lst[(k0 + u) * 64 + lane] : 0) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[u][c] = src[c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bool in, out;
+        prescore_flags<FAM_H>(M, b, q[u], in, out);
+        lb += (on[u] && in) ? 1 : 0;
+        sure_out += (on[u] && out) ? 1 : 0;
+      }
+    }
+  }
+  if (has_slot) {
+    p.counts[(size_t)pl * p.batch + t] = n - sure_out;  // -1: no model in this slot
+    reinterpret_cast<int32_t*>(p.sums + (size_t)pl * p.batch + t)[0] = lb;
+  }
+}
+
 #ifdef DSM_CHECK_BUILD
 // ------------------------------------------------------------------------------------ the H bound step on the matrix pipe (round 5)
 // MEASURED AND NOT ADOPTED -- check build only (DSM_SCORE_PREFILTER=9), kept as the A/B the round-4 verdict asked for:
@@ -4062,13 +4239,18 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
     hipLaunchKernelGGL(k_solve<FAM_H>, grid, dim3(64), 0, st, p);
     const size_t smem2 = smem + (size_t)p.batch * 2;
     if (p.score_prefilter && p.batch <= 65535 && smem2 <= 64 * 1024) {
-      // DSM_SCORE_PREFILTER=9 (check build): the bound step's K = 3 products on the FP64 matrix pipe -- measured slower, see k_prescore_h_mfma
+      // the bound step with its packed-f32 first stage (k_prescore_h2: the points once more as f32 behind the FP64 copy in the LDS).
+      // Check build: DSM_SCORE_PREFILTER=17 the pure FP64 k_prescore<H> (round 4's form), =9 its K = 3 products on the FP64 matrix
+      // pipe (k_prescore_h_mfma: measured slower)
+      const size_t smem_h2 = (size_t)(p.n_max < VP_LDS_PTS ? (p.n_max > 0 ? p.n_max : 1) : VP_LDS_PTS) * 16 + 32 + (size_t)PRESCORE_LIST_CAP * 64 * 2;
 #ifdef DSM_CHECK_BUILD
       if (p.score_prefilter & 8)
         hipLaunchKernelGGL(k_prescore_h_mfma, grid, dim3(64), smem, st, p);
+      else if (p.score_prefilter & 16)
+        hipLaunchKernelGGL(k_prescore<FAM_H>, grid, dim3(64), smem, st, p);
       else
 #endif
-        hipLaunchKernelGGL(k_prescore<FAM_H>, grid, dim3(64), smem, st, p);
+        hipLaunchKernelGGL(k_prescore_h2, grid, dim3(64), smem_h2, st, p);
       hipLaunchKernelGGL(k_score_needed<FAM_H>, dim3(nb_needed), dim3(64), smem2, st, p);
     } else {
       hipLaunchKernelGGL(k_score<FAM_H>, grid, dim3(64), smem, st, p);
