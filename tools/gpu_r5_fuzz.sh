@@ -6,6 +6,8 @@ out=gpurun_out/r5fuzz
 mkdir -p $out
 run() { name=$1; shift; echo "== $name: $(timeout 900 "$@" 2>&1 | grep 'FUZZ RESULT' | tail -1)" | tee -a $out/summary.txt; }
 run fuzz_seed261_product python tools/fuzz_verify.py --batches 8 --pairs 2500 --seed 261
+run fuzz_seed265_product_h2 python tools/fuzz_verify.py --batches 6 --pairs 2500 --seed 265
+DSM_SCORE_PREFILTER=17 run fuzz_seed266_h_fp64_check_build python tools/fuzz_verify.py --batches 3 --pairs 2000 --seed 266
 DSM_SCORE_PREFILTER=9 run fuzz_seed262_h_bound_on_matrix_pipe_check_build python tools/fuzz_verify.py --batches 4 --pairs 2000 --seed 262
 DSM_SCORE_PREFILTER=0 run fuzz_seed263_no_prefilter_check_build python tools/fuzz_verify.py --batches 4 --pairs 2000 --seed 263
 DSM_VERIFY_LANES=2 DSM_VERIFY_CHUNK_PAIRS=37 run fuzz_sched_1_product python tools/fuzz_verify.py --batches 4 --pairs 2000 --seed 271
