@@ -1775,6 +1775,7 @@ int dsm_debug_image_to_world(dsm_ctx* ctx, const dsm_camera* camera, uint32_t n,
 }
 
 int dsm_ctx_device(const dsm_ctx* ctx) { return ctx ? ctx->device : -1; }
+uint32_t dsm_ctx_num_pairs(const dsm_ctx* ctx) { return (ctx && ctx->matched) ? ctx->n_pairs : 0u; }
 
 int dsm_get_match_kernel_time(dsm_ctx* ctx, double* total_ms, uint32_t* n_launches) {
   if (!ctx) return DSM_ERR_INVALID_ARGUMENT;

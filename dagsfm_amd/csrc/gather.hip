@@ -199,6 +199,10 @@ int dsm_gather_match_graph(dsm_gather* g, const uint32_t* n_pairs, int32_t with_
     pad = std::max(pad, n_pairs[k]);
   }
   if (N > 0xfffffff0ull) return gfail(g, DSM_ERR_OUT_OF_RANGE, "pair list too long");
+  // the getters below write what the CONTEXT holds: a share length that is not the context's would overrun the staging blocks
+  for (uint32_t k = 0; k < n; ++k)
+    if (n_pairs[k] && dsm_ctx_num_pairs(g->ranks[k].ctx) != n_pairs[k])
+      return gfail(g, DSM_ERR_INVALID_ARGUMENT, "dsm_gather_match_graph: n_pairs[k] is not the length of the list context k matched");
   const size_t off_block = 2 * ((size_t)pad + 1);  // uint64 per rank: [matches | inliers][pad + 1]
   // ---- 1. local offsets -> send buffers; all-gather
   for (uint32_t k = 0; k < n; ++k) {

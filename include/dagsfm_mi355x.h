@@ -129,6 +129,8 @@ void dsm_ctx_destroy(dsm_ctx* ctx);
 /* The HIP device the context is bound to (-1 for NULL): what a companion library needs to place its own buffers and
  * communicators next to the context (include/dagsfm_gather.h). */
 int dsm_ctx_device(const dsm_ctx* ctx);
+/* Number of pairs of the context's last dsm_match_pairs / dsm_set_matches (0 before any). */
+uint32_t dsm_ctx_num_pairs(const dsm_ctx* ctx);
 /* Last error text for this context (or for ctx creation when ctx == NULL). */
 const char* dsm_last_error(const dsm_ctx* ctx);
 /* Blocks until all work queued by this context has finished. */

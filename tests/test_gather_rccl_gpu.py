@@ -49,6 +49,12 @@ for n_use in (n_img, 5):
 ptrs = [ctypes.c_void_p() for _ in range(5)]
 rc = capi.gather_lib().dsm_gather_device_arrays(g._g, 0, *[ctypes.byref(p) for p in ptrs])
 ok = ok and rc == 0 and ptrs[0].value and ptrs[1].value and not ptrs[2].value  # (the last call was without geometry)
+# a share length that is not the context's is refused (it would overrun the staging blocks)
+try:
+    g.match_graph([len(pairs) + 3], False)
+    ok = False
+except capi.DsmError:
+    pass
 # an empty share list
 moffe, me = g.match_graph([0], False)
 ok = ok and len(moffe) == 1 and moffe[0] == 0 and len(me) == 0
