@@ -858,7 +858,12 @@ int dsm_retrieval_set_flann_index(dsm_ctx* ctx, const dsm_flann_index* index) {
   r->k_assigned = 0;
   r->host_loaded = 0;
   RCHK(ctx, hipSetDevice(ctx->device));
-  return flann_device_set_index(ctx, &r->flann, index, r->d_words.as<int8_t>(), r->num_words);
+  const int rc = flann_device_set_index(ctx, &r->flann, index, r->d_words.as<int8_t>(), r->num_words);
+  if (rc != DSM_OK) {  // a refused or half-uploaded index must not stay behind: the exact search again
+    flann_device_destroy(r->flann);
+    r->flann = nullptr;
+  }
+  return rc;
 }
 
 int dsm_retrieval_flann_search(dsm_ctx* ctx, const uint8_t* descriptors, uint32_t n, uint32_t k, int32_t* ids, float* dists, double* ms) {
