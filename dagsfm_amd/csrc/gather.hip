@@ -81,6 +81,16 @@ static int gfail(dsm_gather* g, int code, const std::string& msg) {
     const ncclResult_t r_ = (call);                                                        \
     if (r_ != ncclSuccess) return gfail(g, DSM_ERR_HIP, std::string(#call) + ": " + ncclGetErrorString(r_)); \
   } while (0)
+// inside ncclGroupStart / ncclGroupEnd: a failed call closes the group before it returns, or the next collective of the
+// process would be queued into a group nobody ends
+#define GNCCL_GROUPED(g, call)                                                             \
+  do {                                                                                     \
+    const ncclResult_t r_ = (call);                                                        \
+    if (r_ != ncclSuccess) {                                                               \
+      (void)ncclGroupEnd();                                                                \
+      return gfail(g, DSM_ERR_HIP, std::string(#call) + ": " + ncclGetErrorString(r_));    \
+    }                                                                                      \
+  } while (0)
 #define GDSM(g, r, call)                                                                   \
   do {                                                                                     \
     const int rc_ = (call);                                                                \
@@ -96,7 +106,7 @@ __global__ void k_gather_totals(const uint64_t* gathered, const uint32_t* n_pair
 }
 
 // One workgroup per share and 256-pair tile: offsets rebased to list order (+ the totals of the shares before it), records
-// copied out of their padded block (as 16-byte words: sizeof(dsm_two_view_geometry) is a multiple of 8, checked on the host).
+// copied out of their padded block (as 8-byte words: sizeof(dsm_two_view_geometry) is a multiple of 8, checked on the host).
 __global__ __launch_bounds__(256) void k_gather_compact(const uint64_t* gathered, const uint8_t* tvg_padded, const uint32_t* n_pairs,
                                                         const uint64_t* totals, uint32_t n, uint32_t pad, uint32_t rec_bytes,
                                                         uint64_t* match_off, uint64_t* inl_off, uint8_t* tvg) {
@@ -227,7 +237,7 @@ int dsm_gather_match_graph(dsm_gather* g, const uint32_t* n_pairs, int32_t with_
   GNCCL(g, ncclGroupStart());
   for (uint32_t k = 0; k < n; ++k) {
     Rank& r = g->ranks[k];
-    GNCCL(g, ncclAllGather(r.off_send.p, r.off_recv.p, off_block, ncclUint64, r.comm, r.stream));
+    GNCCL_GROUPED(g, ncclAllGather(r.off_send.p, r.off_recv.p, off_block, ncclUint64, r.comm, r.stream));
   }
   GNCCL(g, ncclGroupEnd());
   // ---- 2. totals of every share (rank 0's copy; all copies are equal)
@@ -281,18 +291,18 @@ int dsm_gather_match_graph(dsm_gather* g, const uint32_t* n_pairs, int32_t with_
       Rank& r = g->ranks[k];
       if (totals[2 * root]) {
         void* slice = static_cast<uint32_t*>(r.matches.p) + 2 * base_m[root];
-        GNCCL(g, ncclBroadcast(slice, slice, totals[2 * root], ncclUint64, (int)root, r.comm, r.stream));  // one match = 2 x uint32
+        GNCCL_GROUPED(g, ncclBroadcast(slice, slice, totals[2 * root], ncclUint64, (int)root, r.comm, r.stream));  // one match = 2 x uint32
       }
       if (with_geometry && totals[2 * root + 1]) {
         void* slice = static_cast<uint32_t*>(r.inliers.p) + 2 * base_i[root];
-        GNCCL(g, ncclBroadcast(slice, slice, totals[2 * root + 1], ncclUint64, (int)root, r.comm, r.stream));
+        GNCCL_GROUPED(g, ncclBroadcast(slice, slice, totals[2 * root + 1], ncclUint64, (int)root, r.comm, r.stream));
       }
     }
   }
   if (with_geometry && pad)
     for (uint32_t k = 0; k < n; ++k) {
       Rank& r = g->ranks[k];
-      GNCCL(g, ncclAllGather(r.tvg_send.p, r.tvg_recv.p, (size_t)pad * rec, ncclUint8, r.comm, r.stream));
+      GNCCL_GROUPED(g, ncclAllGather(r.tvg_send.p, r.tvg_recv.p, (size_t)pad * rec, ncclUint8, r.comm, r.stream));
     }
   GNCCL(g, ncclGroupEnd());
   // ---- 4. offsets in list order, records out of their padded blocks
