@@ -305,8 +305,11 @@ def main():
     info = ctx.device_info()
     cams = [capi.simple_pinhole(scene.focal, scene.width / 2.0, scene.height / 2.0, scene.width, scene.height, calibrated)
             for _ in range(len(images))]
+    handover_s = []
     for c in ctxs:
-        c.set_images([im[0] for im in images], [im[1] for im in images], cams)
+        th = time.perf_counter()
+        c.set_images([im[0] for im in images], [im[1] for im in images], cams)  # (synchronous: the images are in HBM when it returns)
+        handover_s.append(time.perf_counter() - th)
     cbounds = sharding.shard_bounds(len(my_pairs), n_ctx)
     cparts = [my_pairs[cbounds[k]:cbounds[k + 1]] for k in range(n_ctx)]
     opts = capi.default_match_options()
@@ -487,6 +490,11 @@ def main():
                            "note": "device-to-device fetch through the C-ABI getters + the collectives of sharding.gather_match_graph "
                                    "(rank 0's wall time, inside the timed region)"}
         out["kernel_ms_per_step"]["exchange"] = out["exchange"]["gather_ms_per_step"]
+        # the boundary hands over HOST buffers (dsm_set_images): outside the timed region, once per job.  Its measured time and
+        # the rate a job would see that paid it before EVERY step (never `value`)
+        image_bytes = sum(im[0].nbytes + (im[1].nbytes if im[1] is not None else 0) for im in images)
+        out["host_handover"] = {"ms": 1e3 * min(handover_s), "bytes": image_bytes,
+                                "value_if_paid_every_step": n_pairs / (ms_per_step / 1e3 + min(handover_s)) if world == 1 else None}
         if pass1_s > 0 and res["matches"] >= 0:
             # what the matrix pipe executed: pass 1 = the whole matrix; pass 2 = gathered rows in 128-row wave units
             out["roofline"]["frac_pass1_only"] = ops_per_pair * pairs_per_launch / pass1_s / int8_peak
