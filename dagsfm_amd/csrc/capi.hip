@@ -39,6 +39,72 @@ static int fail(dsm_ctx* ctx, int code, const char* msg) {
   return code;
 }
 
+// ---------------------------------------------------------------------------------- hand-over of host buffers
+// The reference's FeatureDescriptors / FeatureKeypoints are Eigen matrices and std::vectors in PAGEABLE memory
+// (/root/reference/src/feature/types.h:102-104), one allocation per image.  hipMemcpy from pageable memory goes through the
+// runtime's own staging at 4 - 5 GB/s (measured: 278 MB of config 2 in 57 ms).  staged_upload moves `total` bytes that a
+// callback can produce for any byte range: host threads fill one pinned slot while the DMA engine drains the other (and,
+// for descriptors, k0_prepare converts the slot that just arrived), all device work on ctx->stream.  Buffers that are pinned
+// already (the shim's FeatureMatcherCache slabs) skip this and are copied where they lie.
+static const uint64_t kStageSlot = 16ull << 20;
+static const unsigned kStageThreads = 8;  // (images that are cold in the host's caches: 4 threads read them at 8 GB/s, hot ones at 32 GB/s)
+
+static bool host_pointer_is_pinned(const void* ptr) {
+  hipPointerAttribute_t at;
+  memset(&at, 0, sizeof(at));
+  if (hipPointerGetAttributes(&at, ptr) != hipSuccess) {
+    (void)hipGetLastError();  // pageable memory is "invalid value" to the runtime: not an error of ours
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
+// fill(dst, begin, end) writes bytes [begin, end) of the stream to dst; arrived(slot_dev, begin, end) enqueues what follows a
+// slot's copy on the stream (nullptr: the copy went straight to dev_dst + begin).
+template <typename Fill, typename Arrived>
+static int staged_upload(dsm_ctx* ctx, uint64_t total, uint8_t* dev_dst, bool through_device_slot, Fill fill, Arrived arrived) {
+  if (!total) return DSM_OK;
+  if (!ctx->h_stage) HIPCHK(ctx, hipHostMalloc(&ctx->h_stage, 2 * kStageSlot, hipHostMallocDefault));
+  for (hipEvent_t& e : ctx->stage_ev)
+    if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (through_device_slot) HIPCHK(ctx, ctx->d_stage.reserve(2 * kStageSlot));
+  const unsigned hw = std::thread::hardware_concurrency();
+  const unsigned n_thr = std::max(1u, std::min(kStageThreads, hw / 4));  // (the shim hands over to every device of gpu_index at once)
+  uint64_t begin = 0;
+  for (uint32_t piece = 0; begin < total; ++piece) {
+    const uint32_t slot = piece & 1u;
+    const uint64_t end = std::min(total, begin + kStageSlot);
+    uint8_t* host = static_cast<uint8_t*>(ctx->h_stage) + slot * kStageSlot;
+    if (piece >= 2) HIPCHK(ctx, hipEventSynchronize(ctx->stage_ev[slot]));  // the copy out of this slot two pieces ago is done
+    {
+      // equal shares of the piece, cut at 4 KB; the caller's thread takes the first
+      const uint64_t share = ((end - begin + n_thr - 1) / n_thr + 4095) / 4096 * 4096;
+      std::vector<std::thread> helpers;
+      for (unsigned t = 1; t < n_thr; ++t) {
+        const uint64_t b = begin + t * share, e = std::min(end, b + share);
+        if (b >= end) break;
+        try {
+          helpers.emplace_back([&fill, host, begin, b, e]() { fill(host + (b - begin), b, e); });
+        } catch (const std::system_error&) {  // no thread to be had: this one does the share itself
+          fill(host + (b - begin), b, e);
+        }
+      }
+      fill(host, begin, std::min(end, begin + share));
+      for (std::thread& th : helpers) th.join();
+    }
+    uint8_t* dev = through_device_slot ? ctx->d_stage.as<uint8_t>() + slot * kStageSlot : dev_dst + begin;
+    HIPCHK(ctx, hipMemcpyAsync(dev, host, end - begin, hipMemcpyHostToDevice, ctx->stream));
+    if (through_device_slot) {
+      const int rc = arrived(dev, begin, end);
+      if (rc != DSM_OK) return rc;
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->stage_ev[slot], ctx->stream));
+    begin = end;
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return DSM_OK;
+}
+
 extern "C" {
 
 void dsm_default_match_options(dsm_match_options* o) {
@@ -150,6 +216,10 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
     if (L.host_ctr) (void)hipHostFree(L.host_ctr);
     if (L.stream && L.stream != ctx->stream) (void)hipStreamDestroy(L.stream);
   }
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  for (hipEvent_t e : ctx->stage_ev)
+    if (e) (void)hipEventDestroy(e);
+  ctx->d_stage.release();
   if (ctx->vev0) (void)hipEventDestroy(ctx->vev0);
   if (ctx->vev1) (void)hipEventDestroy(ctx->vev1);
   for (DevBuf* b : bufs) b->release();
@@ -263,7 +333,23 @@ static int upload_images(dsm_ctx* ctx, bool append, uint32_t n_new, const uint32
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_img_row0.as<uint32_t>() + n_old, row0.data(), (size_t)n_new * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_img_rows.as<uint32_t>() + n_old, rows.data(), (size_t)n_new * 4, hipMemcpyHostToDevice, ctx->stream));
   }
-  if (rows_new) {
+  // pinned already (judged by the first image that has rows): copied where they lie
+  bool pinned = false;
+  for (uint32_t i = 0; i < n_new; ++i)
+    if (n_feats[i]) {
+      pinned = host_pointer_is_pinned(desc[i]) && (!kp_xy || host_pointer_is_pinned(kp_xy[i]));
+      break;
+    }
+  // first image whose padded rows end behind relative row r
+  auto image_of_row = [&](uint64_t r) -> uint32_t {
+    uint32_t lo = 0, hi = n_new;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if ((uint64_t)row0[mid] - rows_old + rows[mid] > r) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+  };
+  if (rows_new && pinned) {
     // stage the padded u8 rows of the new images in a temporary device buffer, convert with K0
     DevBuf tmp;
     HIPCHK(ctx, tmp.reserve(rows_new * 128));
@@ -277,18 +363,56 @@ static int upload_images(dsm_ctx* ctx, bool append, uint32_t n_new, const uint32
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     tmp.release();
+  } else if (rows_new) {
+    // pageable: the padded u8 rows stream through the pinned slots; k0_prepare converts every slot as it arrives
+    auto fill = [&](uint8_t* dst, uint64_t begin, uint64_t end) {
+      uint64_t at = begin;
+      for (uint32_t i = image_of_row(begin / 128); i < n_new && at < end; ++i) {
+        const uint64_t img0 = ((uint64_t)row0[i] - rows_old) * 128, data_end = img0 + (uint64_t)n_feats[i] * 128, img_end = img0 + (uint64_t)rows[i] * 128;
+        if (at < data_end) {
+          const uint64_t e = std::min(end, data_end);
+          memcpy(dst + (at - begin), desc[i] + (at - img0), e - at);
+          at = e;
+        }
+        if (at < end && at < img_end) {  // the zero rows that pad the image to 256
+          const uint64_t e = std::min(end, img_end);
+          memset(dst + (at - begin), 0, e - at);
+          at = e;
+        }
+      }
+    };
+    auto arrived = [&](uint8_t* slot_dev, uint64_t begin, uint64_t end) -> int {
+      launch_k0(slot_dev, ctx->d_desc.as<int8_t>() + rows_old * 128 + begin, ctx->d_rterm.as<int32_t>() + rows_old + begin / 128, (end - begin) / 128,
+                ctx->stream);
+      HIPCHK(ctx, hipGetLastError());
+      return DSM_OK;
+    };
+    const int rc = staged_upload(ctx, rows_new * 128, nullptr, true, fill, arrived);
+    if (rc != DSM_OK) return rc;
   }
   if (kp_xy && rows_new) {
-    std::vector<double> kp(rows_new * 2, 0.0);
-    for (uint32_t i = 0; i < n_new; ++i) {
-      if (!n_feats[i]) continue;
-      double* dst = kp.data() + ((uint64_t)row0[i] - rows_old) * 2;
-      for (uint32_t k = 0; k < n_feats[i]; ++k) {
-        dst[2 * k + 0] = (double)kp_xy[i][(uint64_t)k * kp_stride + 0];
-        dst[2 * k + 1] = (double)kp_xy[i][(uint64_t)k * kp_stride + 1];
+    // FeatureKeypoint's float x, y (types.h:44-81) -> the double pairs the verification reads (Vector2d, matching.cc:585-592)
+    auto convert = [&](uint8_t* dst8, uint64_t begin, uint64_t end) {
+      double* dst = reinterpret_cast<double*>(dst8);
+      uint64_t r = begin / 16;
+      const uint64_t r_end = end / 16;
+      for (uint32_t i = image_of_row(r); i < n_new && r < r_end; ++i) {
+        const uint64_t img0 = (uint64_t)row0[i] - rows_old, data_end = img0 + n_feats[i], img_end = img0 + rows[i];
+        const float* src = kp_xy[i];
+        for (; r < r_end && r < data_end; ++r) {
+          const uint64_t k = r - img0;
+          dst[2 * (r - begin / 16) + 0] = (double)src[k * kp_stride + 0];
+          dst[2 * (r - begin / 16) + 1] = (double)src[k * kp_stride + 1];
+        }
+        for (; r < r_end && r < img_end; ++r) {
+          dst[2 * (r - begin / 16) + 0] = 0.0;
+          dst[2 * (r - begin / 16) + 1] = 0.0;
+        }
       }
-    }
-    HIPCHK(ctx, hipMemcpy(ctx->d_kp.as<double>() + rows_old * 2, kp.data(), rows_new * 16, hipMemcpyHostToDevice));
+    };
+    auto nothing = [](uint8_t*, uint64_t, uint64_t) -> int { return DSM_OK; };
+    const int rc = staged_upload(ctx, rows_new * 16, reinterpret_cast<uint8_t*>(ctx->d_kp.as<double>() + rows_old * 2), false, convert, nothing);
+    if (rc != DSM_OK) return rc;
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return DSM_OK;

@@ -87,6 +87,11 @@ struct dsm_ctx {
   std::vector<dsm_camera> cameras;
   bool have_kp = false;
   DevBuf d_desc, d_rterm, d_kp, d_img_row0, d_img_rows, d_lut;
+  // hand-over of pageable host buffers (capi.hip: staged_upload): two pinned host slots, their device mirror for the descriptor
+  // rows on their way through k0_prepare, one event per slot; allocated by the first upload that needs them
+  void* h_stage = nullptr;
+  DevBuf d_stage;
+  hipEvent_t stage_ev[2] = {nullptr, nullptr};
 
   // last dsm_match_pairs
   bool matched = false;

@@ -166,7 +166,9 @@ int dsm_get_device_info(dsm_ctx* ctx, dsm_device_info* out);
  *                   keypoints (6 for FeatureKeypoint, types.h:44-81); may be NULL when
  *                   only matching is wanted
  *   cameras[i]      camera of image i; may be NULL when only matching is wanted
- * Pointers are host pointers, borrowed for the duration of the call. */
+ * Pointers are host pointers, borrowed for the duration of the call.  Pageable memory (the reference's Eigen
+ * matrices and std::vectors) is read by a few host threads of the library's own into pinned staging slots
+ * (32 MB per context, allocated by the first such call); memory that is pinned already is copied where it lies. */
 int dsm_set_images(dsm_ctx* ctx, uint32_t n_images, const uint32_t* n_feats,
                    const uint8_t* const* desc, const float* const* kp_xy,
                    uint32_t kp_stride, const dsm_camera* cameras);
