@@ -829,6 +829,8 @@ static int ensure_nt_tables_t(dsm_ctx* ctx, const dsm_two_view_options* o, const
   return DSM_OK;
 }
 
+// a lane's counters: 32 classic words + the 64 hand-out counters of grab_seg on a 128-byte line each (verify_kernels.hip)
+#define LANE_CTR_BYTES (128 + 64 * 128)
 // What the lanes of one dsm_verify_pairs call share
 struct VerifyPlan {
   uint32_t batch[3] = {0, 0, 0}, bmax = 0;
@@ -860,7 +862,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
   LANECHK(L, hipSetDevice(ctx->device));
   hipStream_t st = L.stream;
   LANECHK(L, hipStreamWaitEvent(st, ctx->vev0, 0));
-  LANECHK(L, hipMemsetAsync(L.active.p, 0, 128, st));
+  LANECHK(L, hipMemsetAsync(L.active.p, 0, LANE_CTR_BYTES, st));
   const uint32_t chunk = plan.chunk[li];
   vp.scratch = L.vscratch.as<double>();
   vp.samples = L.samples.as<uint32_t>();
@@ -871,6 +873,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
   vp.models = L.models.as<double>();
   vp.e_work = L.ework.as<double>();
   vp.active_count = L.active.as<uint32_t>();
+  vp.grab_ctr = vp.active_count + 32;  // the replay scans' segmented hand-out counters (grab_seg), right behind the classic 32 words
   vp.lo_work = L.lo_work.as<double>();
   vp.lo_models = L.lo_models.as<double>();
   vp.lo_slots = L.lo_slots.as<double>();
@@ -968,7 +971,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
             uint32_t* cnt_dev = L.active.as<uint32_t>() + 20 + cur;
             // this queue's length [20 + cur], the work counter [16], [22] / [23]: queued problems for the general LO kernels;
             // [17] - [19], the other queue's length (read by the host after the launch that filled it) and [24] are dead here
-            LANECHK(L, hipMemsetAsync(actr + 64, 0, 36, st));
+            LANECHK(L, hipMemsetAsync(actr + 64, 0, LANE_CTR_BYTES - 64, st));  // ... and the replay's segmented hand-out counters behind them: one fill
             vp.lo_queue = queues + (size_t)cur * chunk;
             vp.lo_count = cnt_dev;
             launch_vp_replay_lo(vp, f, std::min<uint32_t>(nb_replay, vp.n_work), mode, st);
@@ -1100,6 +1103,8 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.first_batch[0] = vp.first_batch[1] = vp.first_batch[2] = 0;
   vp.stats = ctx->dbg("DSM_VERIFY_DEBUG") ? 1 : 0;
   vp.lo_reg_prepare = ctx->dbg("DSM_LO_PREPARE_WAVE") ? 0 : 1;
+  vp.rp_cap = std::min<uint32_t>(n_max, 256u);  // RP_CAP (verify_kernels.hip)
+  vp.replay_legacy = ctx->dbg("DSM_REPLAY_LEGACY") ? 1 : 0;
   vp.dbg_jacobi_groups = ctx->dbg("DSM_LO_JACOBI_GROUPS") ? 1 : 0;  // the 8-lane-group Jacobi kernel for every problem (round-2 form)
   vp.dbg_roots_lds = ctx->dbg("DSM_ROOTS_LDS") ? 1 : 0;              // k_roots_e_lds instead of the register form
   vp.dbg_final_waves = ctx->dbg("DSM_FINAL_WAVES") ? atoi(ctx->dbg("DSM_FINAL_WAVES")) : 0;
@@ -1136,8 +1141,8 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
 #ifdef DSM_CHECK_BUILD
     HIPCHK(ctx, ctx->d_vscratch.reserve(std::max<size_t>(1, (size_t)n_blocks * verify_scratch_bytes_per_block(n_max))));
     vp.scratch = ctx->d_vscratch.as<double>();
-    HIPCHK(ctx, ctx->lanes[0].active.reserve(128));
-    HIPCHK(ctx, hipMemsetAsync(ctx->lanes[0].active.p, 0, 128, st));
+    HIPCHK(ctx, ctx->lanes[0].active.reserve(LANE_CTR_BYTES));
+    HIPCHK(ctx, hipMemsetAsync(ctx->lanes[0].active.p, 0, LANE_CTR_BYTES, st));
     vp.active_count = ctx->lanes[0].active.as<uint32_t>();
     HIPCHK(ctx, hipEventRecord(ctx->vev0, st));
     launch_verify(vp, n_blocks, st);
@@ -1284,7 +1289,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
           }
           if (!L.done) LRES(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
           if (!L.host_ctr) LRES(hipHostMalloc(reinterpret_cast<void**>(&L.host_ctr), 128, hipHostMallocDefault));
-          LRES(L.active.reserve(128));
+          LRES(L.active.reserve(LANE_CTR_BYTES));
           LRES(L.vscratch.reserve(std::max<size_t>(1, (size_t)lane_blocks * verify_scratch_bytes_per_block(n_max))));
           LRES(L.samples.reserve((size_t)chunk * plan.bmax * 7 * 4));
           LRES(L.draws_end.reserve((size_t)chunk * plan.bmax * 4));

@@ -987,6 +987,51 @@ DSM_DEV uint32_t grab_item(WorkGrab& g, uint32_t* counter, uint32_t* s_slot, int
   return g.next++;
 }
 
+// The hand-out counter split 64 ways (round 6).  A device-scope atomicAdd is served at ~11.4 ns PER ADDRESS whoever issues it and
+// whether or not the value is used (tools/exp/atomic_rate.hip on MI355X: 131 072 of them on one counter from 4 096 waves 1.49 ms,
+// on 64 counters 128 bytes apart 0.035 ms; the eight XCDs' L2s are not coherent with each other, so a device-scope atomic is
+// resolved behind them), and the replay scans issued 1.3 - 1.5 of them per visited pair on ONE 128-byte line (hand-out, queue append,
+// "still active"): 124 750 pairs = 2.3 ms, which WAS the launch (profiles/r06_replay_dispatches_before.txt).  Here segment s of the
+// work list -- items [s * seg_len, (s + 1) * seg_len) -- has its own counter on its own line; a wave starts on segment
+// blockIdx.x % 64 and, when that is used up, moves on to the next segment that still has items (found with one plain load per lane,
+// not with atomics).  Returns an item index, possibly >= n_items inside the last grain (the caller skips it), or GRAB_DONE.
+#define GRAB_SEGS 64
+#define GRAB_STRIDE 32  // words: one counter per 128-byte line
+#define GRAB_AREA_WORDS (GRAB_SEGS * GRAB_STRIDE)
+#define GRAB_DONE 0xffffffffu
+struct SegGrab {
+  uint32_t next = 0, left = 0, seg = 0xffffffffu;
+};
+DSM_DEV uint32_t grab_seg(SegGrab& g, uint32_t* ctrs, uint32_t n_items, int lane, uint32_t gr) {
+  if (g.left == 0) {
+    const uint32_t seg_len = ((n_items + GRAB_SEGS * gr - 1) / (GRAB_SEGS * gr)) * gr;  // a multiple of gr
+    uint32_t s = g.seg == 0xffffffffu ? blockIdx.x % GRAB_SEGS : g.seg;
+    for (;;) {
+      uint32_t v = 0;
+      if (lane == 0) v = atomicAdd(ctrs + s * GRAB_STRIDE, gr);
+      v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+      const uint32_t start = s * seg_len + v;
+      if (v < seg_len && start < n_items) {
+        g.next = start;
+        g.left = gr;
+        g.seg = s;
+        break;
+      }
+      const uint32_t c = __hip_atomic_load(ctrs + lane * GRAB_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool has = c < seg_len && (uint32_t)lane * seg_len + c < n_items;
+      const unsigned long long m = __ballot(has);
+      if (!m) {
+        g.seg = s;
+        return GRAB_DONE;
+      }
+      const unsigned long long above = s < 63u ? ((m >> (s + 1u)) << (s + 1u)) : 0ull;  // the next one after s, cyclically
+      s = (uint32_t)(__ffsll((long long)(above ? above : m)) - 1);
+    }
+  }
+  g.left--;
+  return g.next++;
+}
+
 struct WgScratch {
   double *resid, *tall, *models, *pts3d_a, *pts3d_b, *ipts;
   int* inl;
@@ -3416,6 +3461,377 @@ __global__ __launch_bounds__(64, (MODE == 1 ? 1 : DSM_REPLAY_WAVES)) void k_repl
   }
 }
 
+// ------------------------------------------------------------------------------------ replay with the pair resident in LDS (round 6)
+// k_replay_lo<fam, 0 / 2> is latency: a visit of a pair (one per local-optimisation step: 4 - 5 per pair, family and round) scored
+// every model it looked at straight from global memory -- four dependent round trips through the pair's points per model (one per
+// 64 correspondences, each behind the in-order walk of the chunk before it), the residuals written to memory and read back for the
+// compaction, every model and every count fetched where it was needed: ~60 dependent round trips, 65 - 77 us of a wave per visit
+// at four waves per SIMD (profiles/r06_replay_dispatches_before.txt: 2.36 ms for the first launch of 124 750 pairs on 4 096 waves),
+// VALU issue 0.05 - 0.18.  k_replay_rp is the same scan with what a visit needs fetched ONCE, in batches that are in flight together:
+//   * the pair's correspondences go to LDS at the start of the visit (n <= rp_cap = min(n_max, RP_CAP); a longer pair reads them
+//     from global memory as before), together with the models the local optimisation returned;
+//   * a trial's models, counts and sums are fetched in one batch when the scan stops at it;
+//   * the inlier set of the model scored last stays in LDS as a bit mask (one 64-bit word per 64 correspondences): the compaction
+//     and the final mask read the bits, no residual goes through memory.
+// Same operations on the same values in the same order as k_replay_lo (which stays, modes 0 and 2, as a cross-check schedule of the
+// check build: DSM_REPLAY_LEGACY; mode 1, the inline tail, is still k_replay_lo's).
+#define RP_CAP 256
+#define RP_QL 32  // pairs a wave suspends before it appends them to the queue with ONE atomic (grab_seg's note)
+__host__ __device__ inline size_t rp_lds_bytes(uint32_t cap, uint32_t n_max) {
+  return (size_t)cap * 32 + 90 * 8 + 10 * 8 + 12 * 4 + (size_t)((n_max + 63) / 64) * 8 + RP_QL * 4;
+}
+struct RpLds {
+  double* pts;               // cap x 4
+  double* mdl;               // 90: the models being looked at (a local optimisation's, then a trial's)
+  double* sums;              // 10: the trial's in-order sums (F, H)
+  int* cnts;                 // 10 counts + the trial's model count
+  unsigned long long* bits;  // inlier mask of the model scored last with KEEP
+  uint32_t* ql;              // RP_QL: the pairs this wave has suspended and not yet appended to the queue
+};
+DSM_DEV RpLds rp_lds(unsigned char* raw, uint32_t cap, uint32_t n_max) {
+  RpLds l;
+  l.pts = reinterpret_cast<double*>(raw);
+  l.mdl = l.pts + (size_t)cap * 4;
+  l.sums = l.mdl + 90;
+  l.cnts = reinterpret_cast<int*>(l.sums + 10);
+  l.bits = reinterpret_cast<unsigned long long*>(l.cnts + 12);
+  l.ql = reinterpret_cast<uint32_t*>(l.bits + (n_max + 63) / 64);
+  return l;
+}
+// Residuals of model M over the pair: the inlier count; SUM: InlierSupportMeasurer::Evaluate's residual_sum in index order
+// (support_measurement.cc:43-48: the walk over the inliers of every 64-chunk in ascending lane order, as score_and_sum);
+// KEEP: the inlier mask -> bits[].
+template <int FAM, bool SUM, bool KEEP>
+DSM_DEV double rp_score(const double* M, int n, bool in_lds, const double* spts, const double* gpts, double max_residual,
+                        uint32_t* count_out, unsigned long long* bits, int lane) {
+  double s = 0;
+  uint32_t count = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    bool in = false;
+    double r = 0.0;
+    if (i < n) {
+      double q[4];
+      if (in_lds) {  // (two branches, not one selected pointer: that would compile to flat loads)
+        for (int k = 0; k < 4; ++k) q[k] = spts[(size_t)i * 4 + k];
+      } else {
+        for (int k = 0; k < 4; ++k) q[k] = gpts[(size_t)i * 4 + k];
+      }
+      r = fam_residual<FAM>(M, q);
+      in = r <= max_residual;
+    }
+    unsigned long long mask = __ballot(in);
+    count += (uint32_t)__popcll(mask);
+    if (KEEP && lane == 0) bits[base >> 6] = mask;
+    if (SUM) {
+      while (mask) {
+        const int k = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        s += wv_readlane_f64(r, k);
+      }
+    }
+  }
+  if (KEEP) wv_sync();
+  *count_out = count;
+  return s;
+}
+// ordered compaction of the inliers of bits[] into inl[]; returns the count
+DSM_DEV int rp_compact(const unsigned long long* bits, int n, int* inl, int lane) {
+  int total = 0;
+  for (int base = 0; base < n; base += 64) {
+    const unsigned long long bal = bits[base >> 6];
+    if ((bal >> lane) & 1ull) inl[total + __popcll(bal & ((1ull << lane) - 1ull))] = base + lane;
+    total += __popcll(bal);
+  }
+  return total;
+}
+
+template <int FAM, bool LOOKUP>
+__global__ __launch_bounds__(64, DSM_REPLAY_WAVES) void k_replay_rp(const VerifyParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  typedef Fam<FAM> F;
+  constexpr int MAXM = F::MAXM;
+  const int lane = threadIdx.x;
+  const RpLds L = rp_lds(smem_raw, p.rp_cap, p.n_max);
+  SegGrab wgrab;
+  const uint32_t grain = work_grain(p.n_work);
+  // what this wave owes the lane's counters: appended / added with one atomic each when the list is full and at the end
+  uint32_t q_n = 0, q_gmask = 0, q_small = 0, n_active = 0;
+  auto flush_queue = [&]() {
+    wv_sync();
+    uint32_t base = 0, base_g = 0;
+    if (lane == 0) {
+      base = atomicAdd(p.lo_count, q_n);
+      if (q_gmask) base_g = atomicAdd(p.active_count + 22, (uint32_t)__popc(q_gmask));
+      if (q_small) atomicAdd(p.active_count + 23, q_small);
+    }
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    base_g = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_g);
+    if ((uint32_t)lane < q_n) {
+      const uint32_t e = L.ql[lane];
+      p.lo_queue[base + (uint32_t)lane] = e;
+      if ((q_gmask >> lane) & 1u) p.lo_queue_g[base_g + (uint32_t)__popc(q_gmask & ((1u << lane) - 1u))] = e;
+    }
+    q_n = 0;
+    q_gmask = 0;
+    q_small = 0;
+    wv_sync();
+  };
+  for (;;) {
+    wv_sync();
+    const uint32_t widx = grab_seg(wgrab, p.grab_ctr, p.n_work, lane, grain);
+    if (widx == GRAB_DONE) break;
+    if (widx >= p.n_work) continue;
+    const uint32_t pl = p.worklist ? p.worklist[widx] : widx;
+    const uint32_t pi = p.pair0 + pl;
+    FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
+    if (!fs->active) continue;
+    const uint64_t moff = p.match_off[pi];
+    const int n = (int)(p.match_off[pi + 1] - moff);
+    const double* gpts = (FAM == FAM_E ? p.pts_norm : p.pts_px) + 4 * moff;
+    const bool in_lds = n <= (int)p.rp_cap;
+    // ---- batch 1: the state, the models of a returned local optimisation and the points, all in flight together
+    const bool lo_wait = fs->lo_wait != 0;
+    int nlo = lo_wait ? (int)fs->lo_nm : 0;
+    if (LOOKUP) nlo = 0;
+    double lm0 = 0.0, lm1 = 0.0;
+    {
+      const double* glom = p.lo_models + (size_t)pl * 90;
+      if (lane < nlo * 9) lm0 = glom[lane];
+      if (lane + 64 < nlo * 9) lm1 = glom[lane + 64];
+    }
+    uint32_t best_n = fs->rep.num_inliers;
+    double best_sum = fs->rep.residual_sum;
+    double best_model[9];
+    for (int k = 0; k < 9; ++k) best_model[k] = fs->rep.model[k];
+    uint32_t dyn_max = fs->dyn_max;
+    uint32_t num_models = fs->rep.num_models;
+    const uint32_t T0 = fs->rep.num_trials;
+    const int nb = (int)fs->nb;
+    int t = (int)fs->t_pos;
+    int m_start = (int)fs->m_pos;
+    const uint32_t* nt_table = p.nt_table + p.nt_off[n] + (size_t)FAM * (size_t)(n + 1);
+    double max_error = p.opt.max_error;
+    if (FAM == FAM_E) {
+      const dsm_camera& cam1 = p.cams[p.pairs[2 * pi]];
+      const dsm_camera& cam2 = p.cams[p.pairs[2 * pi + 1]];
+      max_error = (image_to_world_threshold(cam1, p.opt.max_error) + image_to_world_threshold(cam2, p.opt.max_error)) / 2;
+    }
+    if (in_lds) (void)stage_points_batched<true, false>(gpts, 4 * n, L.pts, lane);
+    if (lane < nlo * 9) L.mdl[lane] = lm0;
+    if (lane + 64 < nlo * 9) L.mdl[lane + 64] = lm1;
+    wv_sync();
+    const double max_residual = max_error * max_error;
+    const uint32_t min_trials = (uint32_t)p.opt.min_num_trials;
+    const uint32_t max_num_trials = p.max_trials[FAM];
+    const int32_t* nmod = p.nmodels + (size_t)pl * p.batch;
+    const int32_t* cnts = p.counts + (size_t)pl * p.batch * MAXM;
+    const double* sums = p.sums + (size_t)pl * p.batch * MAXM;  // F and H only
+    const double* mods = p.models + (size_t)pl * p.batch * MAXM * 9;
+    int* inl = reinterpret_cast<int*>(p.lo_inl + moff);  // the compaction's output IS the hand-over to the LO kernels
+
+    bool abort = false, suspended = false;
+    int t_stop = nb - 1;
+    uint32_t trial_abs = T0 + (uint32_t)t;
+    bool in_trial = false;  // resume inside trial t at model m_start
+    if (lo_wait) {
+      // the local optimisation of (trial t, model m_start - 1) has returned: loransac.h:160-178
+      if constexpr (LOOKUP) {  // item 0 of the pair is the pending step
+        const TailItem& it = p.tail_items[(size_t)widx * TAIL_KMAX];
+        num_models += it.nlo;
+        best_n = it.out_n;
+        best_sum = it.out_sum;
+        for (int k = 0; k < 9; ++k) best_model[k] = it.out_model[k];
+      }
+      for (int l = 0; l < nlo; ++l) {
+        num_models += 1;
+        double M[9];
+        for (int k = 0; k < 9; ++k) M[k] = L.mdl[l * 9 + k];
+        uint32_t lc;
+        const double lsum = rp_score<FAM, true, false>(M, n, in_lds, L.pts, gpts, max_residual, &lc, L.bits, lane);
+        if (lc > best_n || (lc == best_n && lsum < best_sum)) {
+          best_n = lc;
+          best_sum = lsum;
+          for (int k = 0; k < 9; ++k) best_model[k] = M[k];
+        }
+      }
+      dyn_max = nt_table[best_n];
+      if (trial_abs >= dyn_max && trial_abs >= min_trials) {
+        abort = true;
+        t_stop = t;
+      }
+      in_trial = true;
+    }
+    while (!abort && t < nb) {
+      if (!in_trial) {
+        // ---- skip ahead to the next trial that can change anything
+        t = replay_next_event<FAM>(t, nb, nmod, cnts, sums, best_n, best_sum, dyn_max > min_trials ? dyn_max : min_trials, T0, &num_models, lane);
+        if (t >= nb) break;
+        m_start = 0;
+      }
+      in_trial = false;
+      trial_abs = T0 + (uint32_t)t;
+      // ---- batch 2: the trial's model count, counts, sums and models, in flight together
+      wv_sync();  // (the models of the step before are no longer read)
+      {
+        const double a0 = mods[(size_t)t * MAXM * 9 + (lane < MAXM * 9 ? lane : 0)];
+        double a1 = 0.0;
+        if (MAXM * 9 > 64) a1 = mods[(size_t)t * MAXM * 9 + (lane + 64 < MAXM * 9 ? lane + 64 : 0)];
+        int c = 0;
+        double sm_ = 0.0;
+        if (lane < MAXM) c = cnts[(size_t)t * MAXM + lane];
+        if (FAM != FAM_E && lane < MAXM) sm_ = sums[(size_t)t * MAXM + lane];
+        if (lane == MAXM) c = nmod[t];
+        if (lane < MAXM * 9) L.mdl[lane] = a0;
+        if (MAXM * 9 > 64 && lane + 64 < MAXM * 9) L.mdl[lane + 64] = a1;
+        if (lane <= MAXM) L.cnts[lane] = c;
+        if (FAM != FAM_E && lane < MAXM) L.sums[lane] = sm_;
+      }
+      wv_sync();
+      // ---- exact sequential processing of trial t (loransac.h:142-198)
+      const int nm = L.cnts[MAXM];
+      for (int m = m_start; m < nm; ++m) {
+        num_models += 1;
+        const uint32_t cnt = (uint32_t)L.cnts[m];
+        if (cnt >= best_n) {
+          if (p.stats && lane == 0) atomicAdd(p.active_count + 1 + FAM * 2, 1u);
+          double M[9];
+          for (int k = 0; k < 9; ++k) M[k] = L.mdl[m * 9 + k];
+          double sum;
+          bool have_bits = false;
+          if constexpr (FAM == FAM_E) {
+            uint32_t cnt_again;
+            sum = rp_score<FAM, true, true>(M, n, in_lds, L.pts, gpts, max_residual, &cnt_again, L.bits, lane);
+            have_bits = true;
+          } else {
+            sum = L.sums[m];  // k_score's in-order sum
+          }
+          if (cnt > best_n || (cnt == best_n && sum < best_sum)) {
+            best_n = cnt;
+            best_sum = sum;
+            for (int k = 0; k < 9; ++k) best_model[k] = M[k];
+            if (cnt > (uint32_t)F::K && cnt >= (uint32_t)F::LO_MIN) {
+              if (p.stats && lane == 0) atomicAdd(p.active_count + 2 + FAM * 2, 1u);
+              bool looked_up = false;
+              if constexpr (LOOKUP) {
+                const uint32_t ni = p.tail_n[widx];
+                for (uint32_t k = 0; k < ni; ++k) {  // (a pending item 0 is the model the pair was suspended at: it cannot come again)
+                  const TailItem& it = p.tail_items[(size_t)widx * TAIL_KMAX + k];
+                  if (it.t == (uint32_t)t && it.m == (uint32_t)m) {
+                    num_models += it.nlo;
+                    best_n = it.out_n;
+                    best_sum = it.out_sum;
+                    for (int q = 0; q < 9; ++q) best_model[q] = it.out_model[q];
+                    looked_up = true;
+                    break;
+                  }
+                }
+              }
+              if (looked_up) {
+                dyn_max = nt_table[best_n];
+                if (trial_abs >= dyn_max && trial_abs >= min_trials) {
+                  abort = true;
+                  break;
+                }
+                continue;
+              }
+              if (!have_bits) {  // the inliers of the new best model, for the compaction
+                uint32_t c2;
+                (void)rp_score<FAM, false, true>(M, n, in_lds, L.pts, gpts, max_residual, &c2, L.bits, lane);
+              }
+              const int ninl = rp_compact(L.bits, n, inl, lane);  // -> lo_inl
+              if (lane == 0) {
+                fs->t_pos = (uint32_t)t;
+                fs->m_pos = (uint32_t)(m + 1);
+                fs->lo_wait = 1;
+                fs->lo_ninl = (uint32_t)ninl;
+                L.ql[q_n] = pl;
+              }
+              if (!(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) q_gmask |= 1u << q_n;
+              if ((FAM == FAM_H ? 2 * ninl : ninl) < 9) q_small += 1;
+              q_n += 1;
+              suspended = true;
+              break;
+            }
+            dyn_max = nt_table[best_n];
+          }
+        }
+        if (trial_abs >= dyn_max && trial_abs >= min_trials) {
+          abort = true;
+          break;
+        }
+      }
+      if (suspended) break;
+      if (abort) {
+        t_stop = t;
+        break;
+      }
+      t += 1;
+    }
+    if (suspended) {
+      if (lane == 0) {
+        fs->rep.num_models = num_models;
+        fs->rep.num_inliers = best_n;
+        fs->rep.residual_sum = best_sum;
+        for (int k = 0; k < 9; ++k) fs->rep.model[k] = best_model[k];
+        fs->dyn_max = dyn_max;
+      }
+      if (q_n == RP_QL) flush_queue();
+      continue;
+    }
+
+    uint32_t trials_done;
+    bool finished;
+    uint32_t* st = p.pair_state + (size_t)pi * PAIR_STATE_WORDS;
+    if (abort) {
+      trials_done = (trial_abs + 1 < max_num_trials) ? trial_abs + 2 : trial_abs + 1;  // loransac.h:129-134
+      finished = true;
+      if (lane == 0) {
+        if (t_stop != nb - 1) {  // later samples of this round were speculation: resume from the snapshot
+          st[PS_SKIP] = p.draws_end[(size_t)pl * p.batch + t_stop];
+          st[PS_USE_SNAP] = 1;
+        }
+      }
+    } else {
+      trials_done = T0 + (uint32_t)nb;
+      finished = trials_done >= max_num_trials;
+    }
+    if (lane == 0) {
+      fs->rep.num_trials = trials_done;
+      fs->rep.num_models = num_models;
+      fs->rep.num_inliers = best_n;
+      fs->rep.residual_sum = best_sum;
+      for (int k = 0; k < 9; ++k) fs->rep.model[k] = best_model[k];
+      fs->dyn_max = dyn_max;
+      fs->rounds += 1;
+      fs->lo_wait = 0;
+      fs->active = finished ? 0u : 1u;
+    }
+    if (!finished) n_active += 1;
+    if (finished) {
+      const bool success = best_n >= (uint32_t)F::K;
+      if (success) {
+        uint32_t c2;
+        (void)rp_score<FAM, false, true>(best_model, n, in_lds, L.pts, gpts, max_residual, &c2, L.bits, lane);
+        unsigned char* mask = p.masks + (size_t)FAM * p.mask_stride + moff;
+        for (int i = lane; i < n; i += 64) mask[i] = (unsigned char)((L.bits[i >> 6] >> lane) & 1ull);
+      }
+      if (lane == 0) {
+        RansacReport rep;
+        rep.success = success;
+        rep.num_trials = trials_done;
+        rep.num_models = num_models;
+        rep.num_inliers = best_n;
+        rep.residual_sum = best_sum;
+        for (int k = 0; k < 9; ++k) rep.model[k] = best_model[k];
+        p.reports[(size_t)pi * 3 + FAM] = rep;
+      }
+    }
+  }
+  if (q_n) flush_queue();
+  if (n_active && lane == 0) atomicAdd(p.active_count, n_active);
+}
+
 // ------------------------------------------------------------------------------------ item passes
 // The chain of k_replay_lo costs one iteration of launches per local-optimisation step of the SLOWEST pair (14 - 16 per
 // round at the benchmark shape), and every iteration its full serial latency (~1 ms for the E family: tall QR, 9 x 9
@@ -4084,10 +4500,25 @@ __global__ __launch_bounds__(64) void k_lo_e_roots_models(const VerifyParams p) 
 void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, int mode, hipStream_t st) {
   if (!p.n_work || !n_blocks) return;
   const size_t smem = ((offsetof(VSmem, gen) + 15) / 16) * 16;
+  if (mode != 1 && !p.replay_legacy) {  // the scans with the pair resident in LDS
+    const size_t rs = rp_lds_bytes(p.rp_cap, p.n_max);
+    if (mode == 2) {
+      if (fam == FAM_E) hipLaunchKernelGGL((k_replay_rp<FAM_E, true>), dim3(n_blocks), dim3(64), rs, st, p);
+      if (fam == FAM_F) hipLaunchKernelGGL((k_replay_rp<FAM_F, true>), dim3(n_blocks), dim3(64), rs, st, p);
+      if (fam == FAM_H) hipLaunchKernelGGL((k_replay_rp<FAM_H, true>), dim3(n_blocks), dim3(64), rs, st, p);
+    } else {
+      if (fam == FAM_E) hipLaunchKernelGGL((k_replay_rp<FAM_E, false>), dim3(n_blocks), dim3(64), rs, st, p);
+      if (fam == FAM_F) hipLaunchKernelGGL((k_replay_rp<FAM_F, false>), dim3(n_blocks), dim3(64), rs, st, p);
+      if (fam == FAM_H) hipLaunchKernelGGL((k_replay_rp<FAM_H, false>), dim3(n_blocks), dim3(64), rs, st, p);
+    }
+    return;
+  }
   if (mode == 1) {  // F and H only: the E instance would still spill 134 VGPRs at 512 (its 16-lane 5-point finish is inlined)
     if (fam == FAM_F) hipLaunchKernelGGL((k_replay_lo<FAM_F, 1>), dim3(n_blocks), dim3(64), smem, st, p);
     if (fam == FAM_H) hipLaunchKernelGGL((k_replay_lo<FAM_H, 1>), dim3(n_blocks), dim3(64), smem, st, p);
-  } else if (mode == 2) {
+  }
+#ifdef DSM_CHECK_BUILD
+  else if (mode == 2) {
     if (fam == FAM_E) hipLaunchKernelGGL((k_replay_lo<FAM_E, 2>), dim3(n_blocks), dim3(64), smem, st, p);
     if (fam == FAM_F) hipLaunchKernelGGL((k_replay_lo<FAM_F, 2>), dim3(n_blocks), dim3(64), smem, st, p);
     if (fam == FAM_H) hipLaunchKernelGGL((k_replay_lo<FAM_H, 2>), dim3(n_blocks), dim3(64), smem, st, p);
@@ -4096,6 +4527,7 @@ void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, int 
     if (fam == FAM_F) hipLaunchKernelGGL((k_replay_lo<FAM_F, 0>), dim3(n_blocks), dim3(64), smem, st, p);
     if (fam == FAM_H) hipLaunchKernelGGL((k_replay_lo<FAM_H, 0>), dim3(n_blocks), dim3(64), smem, st, p);
   }
+#endif
 }
 // item pass, step by step (the host reads the job count between enum and the rest)
 void launch_vp_items_enum(const VerifyParams& p, int fam, hipStream_t st) {

@@ -102,7 +102,11 @@ def summarize_verify(res):
         }
     total_ms = sum(r["ms_per_step"] for r in rows.values())
     total_flops = sum(r["executed_fp64_tflops"] * r["ms_per_step"] for r in rows.values())
+    sc = [r for k, r in rows.items() if k.startswith(("k_prescore", "k_score", "k_models_score"))]
+    sc_ms = sum(r["ms_per_step"] for r in sc)
     res["summary"] = {"kernels": dict(sorted(rows.items(), key=lambda kv: -kv[1]["ms_per_step"])),
+                      "scoring_kernels_ms_per_step": sc_ms,
+                      "scoring_kernels_executed_frac": (sum(r["executed_frac"] * r["ms_per_step"] for r in sc) / sc_ms) if sc_ms else None,
                       "all_kernels_ms_per_step": total_ms,
                       "executed_fp64_tflops_over_all": total_flops / total_ms if total_ms else None,
                       "executed_frac_over_all": total_flops / total_ms * 1e12 / fp64_peak if total_ms else None,
@@ -139,6 +143,11 @@ def _arg(name, default):
 
 
 res["images"], res["feats"] = _arg("--images", 500), _arg("--feats", 4096)
+# what the collection depends on: bench.py refuses a committed profile whose hash is not that of the sources it runs with
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+res["source_hash"] = {k: bench.source_hash(ROOT, k) for k in bench.PROFILE_SOURCES}
+res["commit"] = os.environ.get("DSM_COMMIT")  # the GPU box has no .git: the session script passes `git rev-parse --short HEAD` of the snapshot
 res["pairs"] = res["images"] * (res["images"] - 1) // 2 if "--pairs" not in bench_args else None
 res["variant"] = "dot4 (DSM_K1_DOT4)" if os.environ.get("DSM_K1_DOT4") else "mfma"
 f, w = res.get("FETCH_SIZE", {}), res.get("WRITE_SIZE", {})
