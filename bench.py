@@ -54,11 +54,15 @@ def _round_floats(x, sig=6):
     return x
 
 
+# keys that only the --dump-line file carries
+LONG_FORM_ONLY = ("peak_source", "sample_note", "top5_ms_execfrac_laneutil", "ranks_seen_by_process_group", "stale_files", "side_pose_max_rel")
+
+
 def _drop_notes(x):
     """The prose (what each figure means) lives in README.md "Measurement" and in the --dump-line file, not on stdout."""
     if isinstance(x, dict):
         return {k: _drop_notes(v) for k, v in x.items()
-                if not (k == "note" or k.endswith("_note") or k in ("peak_source", "sample_note", "top5_ms_execfrac_laneutil"))}
+                if not (k == "note" or k.endswith("_note") or k in LONG_FORM_ONLY)}
     return x
 
 
@@ -141,7 +145,8 @@ def profile_figures(root, images, feats, n_pairs, verify_too):
                                 "scoring_kernels_frac": sm.get("scoring_kernels_executed_frac"),
                                 "top5_ms_execfrac_laneutil": {k: [v.get("ms_per_step"), v.get("executed_frac"), v.get("lane_util")] for k, v in ks}}
     if stale:
-        fp["stale"] = sorted(set(stale))
+        fp["stale"] = len(set(stale))  # committed collections of OTHER sources than this tree's: refused
+        fp["stale_files"] = sorted(set(stale))
     return fp
 
 
@@ -615,7 +620,7 @@ def main():
                          "traffic_note": "HBM bytes per launch of both passes, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read "
                                          "correction) + WRITE_SIZE in separate passes, read from the committed collection "
                                          "traffic_file (an earlier run of this workload); null when not collected for it",
-                         "kernel": "k1_best_rows (pass 1 over all rows + gathered pass 2 of the cross-check)",
+                         "kernel": "k1_best_rows (pass 1 + gathered pass 2)",
                          "avg_launch_ms": 1e3 * (pass1_s + pass2_s), "avg_launch_ms_pass1": 1e3 * pass1_s,
                          "avg_launch_ms_pass2": 1e3 * pass2_s, "launches": k1_launches, "peak_source": peaks_note,
                          "note": "int8 ops (2 per MAC) counted as flops; algorithmic = ONE 2*128*N1*N2 distance matrix per pair "
@@ -696,6 +701,8 @@ def main():
                 r["parity_sample"] = parity_sample(keep, ctx_view(len(pr), with_geometry), with_geometry, int(topts.min_num_inliers))
                 if parity_failed(r["parity_sample"]):
                     failures.append(r["parity_sample"])
+                if "pose_max_rel" in r["parity_sample"]:  # (the headline's parity_sample keeps it in the line)
+                    r["parity_sample"]["side_pose_max_rel"] = r["parity_sample"].pop("pose_max_rel")
             return r
 
         extra = {}
@@ -706,7 +713,7 @@ def main():
                 n2 = 150
                 scene2 = synthetic.Scene(n2, args.feats, seed=args.seed, outlier_frac=0.5)
                 r = side_run([scene2.image(i) for i in range(n2)], synthetic.exhaustive_pairs(n2), cams[:n2], 2, True, min(2.0, args.cpu_seconds))
-                r["workload"] = "%d images x %d feats, exhaustive, inlier ratio 0.25" % (n2, args.feats)
+                r["workload"] = "%d x %d, inlier ratio 0.25" % (n2, args.feats)
                 extra["low_inlier_regime"] = r
             except Exception as e:  # a side measurement must never cost the headline line
                 extra["low_inlier_regime"] = {"error": repr(e)}
@@ -717,7 +724,7 @@ def main():
                 cams_u = [capi.simple_pinhole(scene.focal, scene.width / 2.0, scene.height / 2.0, scene.width, scene.height, False)
                           for _ in range(len(images))]
                 r = side_run(images, pairs, cams_u, 2, True, min(3.0, args.cpu_seconds))
-                r["workload"] = "%d images x %d feats, exhaustive, uncalibrated: F+H" % (args.images, args.feats)
+                r["workload"] = "%d x %d, uncalibrated: F+H" % (args.images, args.feats)
                 extra["uncalibrated"] = r
             except Exception as e:
                 extra["uncalibrated"] = {"error": repr(e)}
@@ -730,7 +737,7 @@ def main():
                          for _ in range(n1)]
                 r = side_run([scene1.image(i) for i in range(n1)], synthetic.exhaustive_pairs(n1), cams1, 10, True,
                              min(60.0, 6.0 * args.cpu_seconds), every_pair=True)
-                r["workload"] = "50 images x 1024 feats, exhaustive, uncalibrated: F+H (BASELINE configs[0]); every pair checked"
+                r["workload"] = "50 x 1024, uncalibrated: F+H (BASELINE configs[0]), every pair checked"
                 extra["config1"] = r
             except Exception as e:
                 extra["config1"] = {"error": repr(e)}
@@ -743,7 +750,7 @@ def main():
                 im3 = [(scene3.image(i)[0], None) for i in range(n3)]
                 r = side_run(im3, synthetic.exhaustive_pairs(n3), None, 1, False, min(5.0, args.cpu_seconds))
                 r["k1_pass1_ms"] = ctx.match_kernel_time()[0]
-                r["workload"] = "%d images x %d feats, exhaustive, match only" % (n3, args.feats)
+                r["workload"] = "%d x %d, match only (BASELINE configs[2])" % (n3, args.feats)
                 if "cpu_pairs_per_s" in r:
                     r["gpu_over_cpu"] = r["pairs_per_s"] / max(r["cpu_pairs_per_s"], 1e-9)
                 extra["config3_match_only"] = r
