@@ -160,6 +160,10 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--pairs", default="exhaustive", help="exhaustive | knn:K (K pseudo-neighbours per image from a seeded "
                                                           "kNN over the camera centres, id1<id2 dedupe; SURVEY 8d config 4)")
+    ap.add_argument("--cut", default="interleaved", choices=["contiguous", "interleaved"],
+                    help="how the pair list is cut between the ranks (and by --shard-of): one contiguous cost-balanced stretch per rank, or "
+                         "blocks of 256 pairs dealt out round-robin / heaviest-first (sharding.interleaved_parts): every rank a uniform sample "
+                         "of the list")
     ap.add_argument("--shard-of", type=int, default=1, help="run only one 1/S of the pair list: one GPU's shard of an S-GPU config")
     ap.add_argument("--shard-index", type=int, default=0, help="which of the --shard-of shards (0-based): tools/shard_sweep.py runs them all")
     ap.add_argument("--outlier-frac", type=float, default=0.2,
@@ -264,8 +268,8 @@ def cpu_baseline(orc, label, build, scene_images, pairs, budget_s, verify, cams,
     dt = time.perf_counter() - t0
     return {"value": state["pairs"] / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "build": build,
             "hypotheses_per_s": state["models"] / dt,
-            "sample": "%d of %d pairs, evenly spaced (%s), %.1f s on %d threads; oracle/ %s"
-                      % (state["pairs"], len(pairs), "match only" if not verify else "match + verify", dt, cores, build),
+            "sample": "%d of %d pairs, %s (%s), %.1f s on %d threads"
+                      % (state["pairs"], len(pairs), "all" if every_pair else "evenly spaced", "match only" if not verify else "match + verify", dt, cores),
             "sample_note": "host has %d usable cores; oracle/ = the reference CPU path restated (MatchSiftFeaturesCPU + "
                            "TwoViewGeometry::Estimate), %s" % (host_cores(), label)}
 
@@ -416,7 +420,10 @@ def main():
     if args.shard_of > 1:
         if not 0 <= args.shard_index < args.shard_of:
             raise SystemExit("--shard-index must be in [0, --shard-of)")
-        pairs = sharding.shard(pairs, args.shard_index, args.shard_of)
+        if args.cut == "interleaved":
+            pairs = pairs[sharding.interleaved_parts(len(pairs), args.shard_of)[args.shard_index]]
+        else:
+            pairs = sharding.shard(pairs, args.shard_index, args.shard_of)
     if args.max_pairs and len(pairs) > args.max_pairs:
         pairs = pairs[:args.max_pairs]
     # only the images the (sharded / truncated) list touches are generated and made resident
@@ -427,8 +434,14 @@ def main():
     pairs = remap[pairs.astype(np.int64)].astype(np.uint32)
     # cut by cost (N1 * N2 + a per-pair term), like the C++ shim cuts between the devices of gpu_index
     costs = sharding.pair_costs(pairs, [len(im[0]) for im in images])
-    bounds = sharding.shard_bounds(len(pairs), world, costs)
-    my_pairs = pairs[bounds[rank]:bounds[rank + 1]]
+    order = None
+    if args.cut == "interleaved" and world > 1:
+        parts = sharding.interleaved_parts(len(pairs), world, costs)
+        bounds, order = sharding.parts_bounds_and_order(parts)
+        my_pairs = pairs[parts[rank]]
+    else:
+        bounds = sharding.shard_bounds(len(pairs), world, costs)
+        my_pairs = pairs[bounds[rank]:bounds[rank + 1]]
 
     if not ctxs:
         ctxs = [capi.Context(dev_index) for _ in range(n_ctx)]
@@ -495,7 +508,7 @@ def main():
             for t in th:
                 t.join()
         tg = time.perf_counter()
-        g = sharding.gather_match_graph(dist, gsource, rank, world, bounds, verify, force_collectives=force)
+        g = sharding.gather_match_graph(dist, gsource, rank, world, bounds, verify, force_collectives=force, order=order)
         torch.cuda.synchronize()  # inside the timed region on purpose: a step ends when the assembled graph is complete in HBM
         gather_s[0] += time.perf_counter() - tg
         return g
@@ -601,12 +614,13 @@ def main():
             "config": {"workload": "%d images x %d feats, %s (%d pairs)%s, %s" % (
                 args.images, args.feats, pairs_desc, n_pairs, shard_note,
                 ("match + two-view LO-RANSAC (%s)" % fam) if verify else "match only"),
-                "pairs": n_pairs, "images_resident": len(images), "total_matches": res["matches"],
+                "pairs": n_pairs, **({"images_resident": len(images)} if len(images) != args.images else {}), "total_matches": res["matches"],
                 "total_inlier_matches": res["inliers"], "pairs_with_geometry": res["verified"],
                 "hypotheses_per_step": res["models"],
                 "putative_match_inlier_ratio": round((1.0 - args.outlier_frac) ** 2, 4),
-                "contexts_per_gpu": n_ctx,
-                "parallelism": "pair-sharded x%d + %s all-gather of the match graph" % (world, "gloo (debug, oversubscribed)" if args.oversubscribe else "RCCL")},
+                **({"contexts_per_gpu": n_ctx} if n_ctx != 1 else {}),
+                "parallelism": "pair-sharded x%d (%s cut) + %s all-gather of the match graph" % (
+                    world, args.cut, "gloo (debug, oversubscribed)" if args.oversubscribe else "RCCL")},
             "hypotheses_per_s": res["models"] * args.steps / dt if verify else None,
             "device": {"name": info.name.decode(), "arch": info.arch.decode(), "compute_units": cus, "clock_mhz": clk / 1e6,
                        "hbm_gb": info.total_memory / 2 ** 30, "ranks_seen_by_process_group": world},
@@ -630,7 +644,7 @@ def main():
         # ---- the exchange: fetch of the rank's results into torch tensors + all-gather / broadcast of the match graph
         result_bytes = 16 * n_pairs + 8 * res["matches"] + (ctypes.sizeof(capi.TwoViewGeometry) * n_pairs + 8 * res["inliers"] if verify else 0)
         out["exchange"] = {"gather_ms_per_step": 1e3 * gather_s[0] / args.steps, "bytes_per_step": result_bytes,
-                           "backend": (dist.get_backend() if dist.is_initialized() else "none (single rank, no collective)"),
+                           "backend": (dist.get_backend() if dist.is_initialized() else "none"),
                            "forced_on_one_rank": bool(world == 1 and force),
                            "note": "device-to-device fetch through the C-ABI getters + the collectives of sharding.gather_match_graph "
                                    "(rank 0's wall time, inside the timed region)"}

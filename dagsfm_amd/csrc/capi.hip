@@ -829,8 +829,11 @@ static int ensure_nt_tables_t(dsm_ctx* ctx, const dsm_two_view_options* o, const
   return DSM_OK;
 }
 
-// a lane's counters: 32 classic words + the 64 hand-out counters of grab_seg on a 128-byte line each (verify_kernels.hip)
-#define LANE_CTR_BYTES (128 + 64 * 128)
+// a lane's counter block: [k_sample's hand-out counters][32 classic words][the replay's][k_lo_prepare's][k_verify_final's] -- every
+// area 64 counters on a 128-byte line each (grab_seg, verify_kernels.hip GRAB_*); laid out so that the counters a phase resets are
+// contiguous: one fill per phase, as before
+#define LANE_CTR_AREA (64 * 128)
+#define LANE_CTR_BYTES (LANE_CTR_AREA + 128 + 3 * LANE_CTR_AREA)
 // What the lanes of one dsm_verify_pairs call share
 struct VerifyPlan {
   uint32_t batch[3] = {0, 0, 0}, bmax = 0;
@@ -872,13 +875,12 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
   vp.sums = L.vsums.as<double>();
   vp.models = L.models.as<double>();
   vp.e_work = L.ework.as<double>();
-  vp.active_count = L.active.as<uint32_t>();
-  vp.grab_ctr = vp.active_count + 32;  // the replay scans' segmented hand-out counters (grab_seg), right behind the classic 32 words
+  vp.active_count = L.active.as<uint32_t>() + LANE_CTR_AREA / 4;
   vp.lo_work = L.lo_work.as<double>();
   vp.lo_models = L.lo_models.as<double>();
   vp.lo_slots = L.lo_slots.as<double>();
   vp.lo_ework = L.lo_ework.as<double>();
-  char* const actr = static_cast<char*>(L.active.p);
+  char* const actr = static_cast<char*>(L.active.p) + LANE_CTR_AREA;  // the classic words
   for (uint64_t c0 = plan.begin[li]; c0 < plan.end[li]; c0 += chunk) {
     vp.pair0 = (uint32_t)c0;
     vp.n_chunk = (uint32_t)std::min<uint64_t>(chunk, plan.end[li] - c0);
@@ -901,10 +903,10 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
         // counters that are dead at that point are zeroed along with them, so that each phase costs ONE fill, not one per
         // counter (a fill is a kernel launch: 33 of them made 0.7 ms of the 8.7 ms a 1 225-pair list takes)
         if (vp.stats) {  // DSM_VERIFY_DEBUG keeps its statistics in [1] - [13] across the rounds
-          LANECHK(L, hipMemsetAsync(actr, 0, 4, st));
+          LANECHK(L, hipMemsetAsync(actr - LANE_CTR_AREA, 0, LANE_CTR_AREA + 4, st));
           LANECHK(L, hipMemsetAsync(actr + 64, 0, 36, st));
         } else {
-          LANECHK(L, hipMemsetAsync(actr, 0, 100, st));  // round start: [0] and [18] are live, the rest is dead here
+          LANECHK(L, hipMemsetAsync(actr - LANE_CTR_AREA, 0, LANE_CTR_AREA + 100, st));  // round start: k_sample's hand-out counters and [0] are live, the rest is dead here
         }
         launch_vp_sample(vp, f, nb_light, st);
         launch_vp_solve_score(vp, f, st);
@@ -946,7 +948,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
               vj.job_list = L.job_list.as<uint32_t>();
               vj.lo_inl_pool = ctx->d_lo_inl_pool.as<uint32_t>();
               vj.lo_queue_g = queues + (size_t)2 * chunk;  // (the general kernels' list: job slots here)
-              LANECHK(L, hipMemsetAsync(actr + 76, 0, 24, st));
+              LANECHK(L, hipMemsetAsync(actr + 76, 0, 52 + 2 * LANE_CTR_AREA, st));  // ... through k_lo_prepare's hand-out counters (the replay's, in between, are dead here)
               launch_vp_items_enum(vj, f, st);
               LANECHK(L, hipGetLastError());
               LANECHK(L, hipMemcpyAsync(host_ctr, actr, 128, hipMemcpyDeviceToHost, st));
@@ -968,10 +970,10 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
               mode = 2;
               pass_items = false;
             }
-            uint32_t* cnt_dev = L.active.as<uint32_t>() + 20 + cur;
+            uint32_t* cnt_dev = vp.active_count + 20 + cur;
             // this queue's length [20 + cur], the work counter [16], [22] / [23]: queued problems for the general LO kernels;
             // [17] - [19], the other queue's length (read by the host after the launch that filled it) and [24] are dead here
-            LANECHK(L, hipMemsetAsync(actr + 64, 0, LANE_CTR_BYTES - 64, st));  // ... and the replay's segmented hand-out counters behind them: one fill
+            LANECHK(L, hipMemsetAsync(actr + 64, 0, 64 + LANE_CTR_AREA, st));  // ... and the replay's hand-out counters behind them: one fill
             vp.lo_queue = queues + (size_t)cur * chunk;
             vp.lo_count = cnt_dev;
             launch_vp_replay_lo(vp, f, std::min<uint32_t>(nb_replay, vp.n_work), mode, st);
@@ -998,7 +1000,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
               active = host_ctr[0];
               break;
             }
-            LANECHK(L, hipMemsetAsync(actr + 76, 0, 4, st));  // k_lo_prepare's work counter [19]
+            LANECHK(L, hipMemsetAsync(actr + 128 + LANE_CTR_AREA, 0, LANE_CTR_AREA, st));  // k_lo_prepare's hand-out counters
             launch_vp_local_opt(vp, f, nb_heavy, host_ctr[22], host_ctr[23], st);
             LANECHK(L, hipGetLastError());
           }
@@ -1007,7 +1009,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
         if (active == 0) break;
       }
     }
-    LANECHK(L, hipMemsetAsync(actr + 68, 0, 4, st));  // k_verify_final's work counter
+    LANECHK(L, hipMemsetAsync(actr + 128 + 2 * LANE_CTR_AREA, 0, LANE_CTR_AREA, st));  // k_verify_final's hand-out counters
     launch_vp_final(vp, nb_heavy, st);
     LANECHK(L, hipGetLastError());
   }
@@ -1143,7 +1145,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     vp.scratch = ctx->d_vscratch.as<double>();
     HIPCHK(ctx, ctx->lanes[0].active.reserve(LANE_CTR_BYTES));
     HIPCHK(ctx, hipMemsetAsync(ctx->lanes[0].active.p, 0, LANE_CTR_BYTES, st));
-    vp.active_count = ctx->lanes[0].active.as<uint32_t>();
+    vp.active_count = ctx->lanes[0].active.as<uint32_t>() + LANE_CTR_AREA / 4;
     HIPCHK(ctx, hipEventRecord(ctx->vev0, st));
     launch_verify(vp, n_blocks, st);
     HIPCHK(ctx, hipGetLastError());

@@ -179,12 +179,12 @@ struct VerifyParams {
   int dbg_jacobi_groups, dbg_roots_lds, dbg_final_waves;  // dsm_set_debug_option switches the launch helpers read
   int score_prefilter;         // F / H scoring as bound + exact (k_prescore, k_score_needed); 0: plain k_score (DSM_SCORE_PREFILTER=0)
   int stats;                   // DSM_VERIFY_DEBUG: count candidates / local optimisations (one-address atomics) in the replay
-  uint32_t* grab_ctr;          // segmented hand-out counters of the persistent grids (grab_seg): active_count + 32, GRAB_AREA_WORDS each
   uint32_t rp_cap;             // k_replay_rp: correspondences of a pair its LDS holds (min(n_max, RP_CAP)); longer pairs read global memory
   int replay_legacy;           // check build, DSM_REPLAY_LEGACY: the replay scans as k_replay_lo<fam, 0 / 2> (points and residuals through memory)
   double* models;              // [n_chunk][batch][maxm][9]
   uint32_t* sidx_g;            // [total] RandomSampler's persistent index array of every pair (at match offsets)
-  uint32_t* active_count;      // pairs that still need trials after a replay round
+  uint32_t* active_count;      // the lane's 32 classic counters ([0]: pairs that still need trials after a replay round); the segmented
+                               // hand-out counters of the persistent grids lie around them (verify_kernels.hip GRAB_*, capi.hip LANE_CTR_*)
   uint32_t pair0, n_chunk;     // chunk of the pair list handled by this launch
   uint32_t batch;              // trials speculated per round for the family being launched
   uint32_t n_pairs;

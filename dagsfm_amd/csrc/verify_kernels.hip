@@ -999,6 +999,13 @@ DSM_DEV uint32_t grab_item(WorkGrab& g, uint32_t* counter, uint32_t* s_slot, int
 #define GRAB_STRIDE 32  // words: one counter per 128-byte line
 #define GRAB_AREA_WORDS (GRAB_SEGS * GRAB_STRIDE)
 #define GRAB_DONE 0xffffffffu
+// the four areas of a lane's counter block (capi.hip lays them out so that every phase still costs ONE fill), relative to
+// VerifyParams::active_count (the classic 32 words): k_sample's in front of it, the replay's (grab_ctr), k_lo_prepare's and
+// k_verify_final's behind it
+#define GRAB_SAMPLE(p) ((p).active_count - GRAB_AREA_WORDS)
+#define GRAB_REPLAY(p) ((p).active_count + 32)
+#define GRAB_PREPARE(p) ((p).active_count + 32 + GRAB_AREA_WORDS)
+#define GRAB_FINAL(p) ((p).active_count + 32 + 2 * GRAB_AREA_WORDS)
 struct SegGrab {
   uint32_t next = 0, left = 0, seg = 0xffffffffu;
 };
@@ -1190,8 +1197,7 @@ __global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p
   int* inl = ws.inl;
   double* pts3d_a = ws.pts3d_a;
 
-  __shared__ uint32_t s_next;
-  WorkGrab wgrab;
+  SegGrab wgrab;
   const uint32_t grain = work_grain(p.n_chunk);
   uint32_t pl_static = blockIdx.x;
   for (;;) {
@@ -1201,8 +1207,10 @@ __global__ __launch_bounds__(64, WAVES) void k_verify_final(const VerifyParams p
       if (pl_static >= p.n_final) break;
       pl = p.final_list[pl_static] - p.pair0;
       pl_static += gridDim.x;
-    } else if (p.active_count != nullptr) {  // pipeline: pairs handed out dynamically (work counter [17])
-      pl = grab_item(wgrab, p.active_count + 17, &s_next, threadIdx.x, grain);
+    } else if (p.active_count != nullptr) {  // pipeline: pairs handed out dynamically (segmented work counters)
+      pl = grab_seg(wgrab, GRAB_FINAL(p), p.n_chunk, threadIdx.x, grain);
+      if (pl == GRAB_DONE) break;
+      if (pl >= p.n_chunk) continue;
     } else {
       pl = pl_static;
       pl_static += gridDim.x;
@@ -1723,15 +1731,16 @@ __global__ __launch_bounds__(64) void k_sample(const VerifyParams p) {
   uint32_t* sidx = reinterpret_cast<uint32_t*>(smem_raw + SAMPLER_PREFIX);
   typedef Fam<FAM> F;
   const int lane = threadIdx.x;
-  __shared__ uint32_t s_next;
-  WorkGrab wgrab;
+  SegGrab wgrab;
   const uint32_t grain = work_grain(p.n_chunk);
   uint32_t pl_static = blockIdx.x;
   for (;;) {
     wv_sync();
     uint32_t pl;
     if (FAM == FAM_H) {  // thousands of draws per pair: dynamic hand-out as in k_replay; E / F rounds are too short for it
-      pl = grab_item(wgrab, p.active_count + 18, &s_next, lane, grain);
+      pl = grab_seg(wgrab, GRAB_SAMPLE(p), p.n_chunk, lane, grain);
+      if (pl == GRAB_DONE) break;
+      if (pl >= p.n_chunk) continue;
     } else {
       pl = pl_static;
       pl_static += gridDim.x;
@@ -3378,7 +3387,7 @@ __global__ __launch_bounds__(64, (MODE == 1 ? 1 : DSM_REPLAY_WAVES)) void k_repl
                   fs->lo_wait = 1;
                   fs->lo_ninl = (uint32_t)ninl;
                   p.lo_queue[atomicAdd(p.lo_count, 1u)] = pl;
-                  if (!(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) p.lo_queue_g[atomicAdd(p.active_count + 22, 1u)] = pl;
+                  if (FAM != FAM_H && !(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) p.lo_queue_g[atomicAdd(p.active_count + 22, 1u)] = pl;
                   if ((FAM == FAM_H ? 2 * ninl : ninl) < 9) atomicAdd(p.active_count + 23, 1u);
                 }
                 suspended = true;
@@ -3476,6 +3485,7 @@ __global__ __launch_bounds__(64, (MODE == 1 ? 1 : DSM_REPLAY_WAVES)) void k_repl
 // Same operations on the same values in the same order as k_replay_lo (which stays, modes 0 and 2, as a cross-check schedule of the
 // check build: DSM_REPLAY_LEGACY; mode 1, the inline tail, is still k_replay_lo's).
 #define RP_CAP 256
+#define ITEMS_GROUP 8  // waves (= pairs) per workgroup of k_items_enum (x TAIL_KMAX items = the 64 lanes of the wave that lists the jobs)
 #define RP_QL 32  // pairs a wave suspends before it appends them to the queue with ONE atomic (grab_seg's note)
 __host__ __device__ inline size_t rp_lds_bytes(uint32_t cap, uint32_t n_max) {
   return (size_t)cap * 32 + 90 * 8 + 10 * 8 + 12 * 4 + (size_t)((n_max + 63) / 64) * 8 + RP_QL * 4;
@@ -3579,7 +3589,7 @@ __global__ __launch_bounds__(64, DSM_REPLAY_WAVES) void k_replay_rp(const Verify
   };
   for (;;) {
     wv_sync();
-    const uint32_t widx = grab_seg(wgrab, p.grab_ctr, p.n_work, lane, grain);
+    const uint32_t widx = grab_seg(wgrab, GRAB_REPLAY(p), p.n_work, lane, grain);
     if (widx == GRAB_DONE) break;
     if (widx >= p.n_work) continue;
     const uint32_t pl = p.worklist ? p.worklist[widx] : widx;
@@ -3747,7 +3757,7 @@ __global__ __launch_bounds__(64, DSM_REPLAY_WAVES) void k_replay_rp(const Verify
                 fs->lo_ninl = (uint32_t)ninl;
                 L.ql[q_n] = pl;
               }
-              if (!(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) q_gmask |= 1u << q_n;
+              if (FAM != FAM_H && !(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) q_gmask |= 1u << q_n;  // (H: the whole queue takes k_lo_prepare)
               if ((FAM == FAM_H ? 2 * ninl : ninl) < 9) q_small += 1;
               q_n += 1;
               suspended = true;
@@ -3851,11 +3861,20 @@ __global__ __launch_bounds__(64, DSM_REPLAY_WAVES) void k_replay_rp(const Verify
 //   k_replay_lo<FAM, 2>  the sequential scan; takes the outcome where it would otherwise suspend.
 // One pass finishes the round of every pair with at most TAIL_KMAX candidate steps; the others are queued once more.
 template <int FAM>
-__global__ __launch_bounds__(64) void k_items_enum(const VerifyParams p) {
+__global__ __launch_bounds__(64 * ITEMS_GROUP) void k_items_enum(const VerifyParams p) {
   typedef Fam<FAM> F;
   constexpr int MAXM = F::MAXM;
-  const int lane = threadIdx.x;
-  for (uint32_t widx = blockIdx.x; widx < p.n_work; widx += gridDim.x) {
+  // a workgroup = ITEMS_GROUP waves, a wave per pair as before; the group's job slots are taken with ONE atomicAdd (a same-address
+  // device atomic costs 11.4 ns whoever issues it: one per pair was 0.18 ms of every pass over a 15 600-pair shard; grab_seg's note)
+  const int lane = threadIdx.x & 63;
+  const uint32_t q = threadIdx.x >> 6;
+  __shared__ uint32_t g_n[ITEMS_GROUP], g_pend[ITEMS_GROUP], g_ninl[ITEMS_GROUP], g_pl[ITEMS_GROUP];
+  for (uint32_t w0 = blockIdx.x * ITEMS_GROUP; w0 < p.n_work; w0 += gridDim.x * ITEMS_GROUP) {
+   __syncthreads();
+   if (threadIdx.x < ITEMS_GROUP) g_n[threadIdx.x] = 0;
+   __syncthreads();
+   for (uint32_t once = 0; once < 1u && w0 + q < p.n_work; ++once) {
+    const uint32_t widx = w0 + q;
     const uint32_t pl = p.worklist ? p.worklist[widx] : widx;
     const uint32_t pi = p.pair0 + pl;
     const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
@@ -3948,22 +3967,38 @@ __global__ __launch_bounds__(64) void k_items_enum(const VerifyParams p) {
       n_items = min((uint32_t)TAIL_KMAX, n_items + (uint32_t)total);
       rm = max(rm, __shfl(incl, last));
     }
-    // the jobs of this pair: job index = item slot (widx * TAIL_KMAX + k), listed compactly for the kernels that follow
-    uint32_t base = 0;
     if (lane == 0) {
       p.tail_n[widx] = n_items;
-      if (n_items) base = atomicAdd(p.active_count + 24, n_items);
+      g_n[q] = n_items;
+      g_pend[q] = pending ? 1u : 0u;
+      g_ninl[q] = pending ? fs->lo_ninl : 0u;
+      g_pl[q] = pl;
     }
-    base = __shfl(base, 0);
-    if ((uint32_t)lane < n_items) {
-      const uint32_t slot = widx * TAIL_KMAX + (uint32_t)lane;
-      LoJob* j = p.lo_jobs + slot;
-      j->pl = pl;
-      j->ninl = pending && lane == 0 ? fs->lo_ninl : 0u;
-      j->pending = pending && lane == 0 ? 1u : 0u;
-      j->nm = 0;
-      p.job_list[base + (uint32_t)lane] = slot;
-    }
+   }
+   // the jobs of the group's pairs: job index = item slot (widx * TAIL_KMAX + k), listed compactly for the kernels that follow
+   __syncthreads();
+   static_assert(ITEMS_GROUP * TAIL_KMAX == 64, "one lane of the first wave per (pair of the group, item)");
+   if (q == 0) {
+     const uint32_t qq = (uint32_t)lane / TAIL_KMAX, k = (uint32_t)lane % TAIL_KMAX;
+     uint32_t before = 0, total = 0;
+     for (uint32_t r = 0; r < ITEMS_GROUP; ++r) {
+       const uint32_t c = g_n[r];
+       if (r < qq) before += c;
+       total += c;
+     }
+     uint32_t base = 0;
+     if (lane == 0 && total) base = atomicAdd(p.active_count + 24, total);
+     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+     if (k < g_n[qq]) {
+       const uint32_t slot = (w0 + qq) * TAIL_KMAX + k;
+       LoJob* j = p.lo_jobs + slot;
+       j->pl = g_pl[qq];
+       j->ninl = k == 0 ? g_ninl[qq] : 0u;
+       j->pending = k == 0 ? g_pend[qq] : 0u;
+       j->nm = 0;
+       p.job_list[base + before + k] = slot;
+     }
+   }
   }
 }
 
@@ -4021,7 +4056,7 @@ __global__ __launch_bounds__(64, 4) void k_items_inliers(const VerifyParams p) {
       if (lane == 0) j->ninl = (uint32_t)ninl;
     }
     if (lane == 0) {
-      if (!(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) p.lo_queue_g[atomicAdd(p.active_count + 22, 1u)] = slot;
+      if (FAM != FAM_H && !(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) p.lo_queue_g[atomicAdd(p.active_count + 22, 1u)] = slot;
       if ((FAM == FAM_H ? 2 * ninl : ninl) < 9) atomicAdd(p.active_count + 23, 1u);
     }
   }
@@ -4310,13 +4345,13 @@ __global__ __launch_bounds__(64, 2) void k_lo_prepare(const VerifyParams p) {  /
   __shared__ WvSvdShared svd;
   const int lane = threadIdx.x;
   const WgScratch ws = wg_scratch(p);
-  __shared__ uint32_t s_next;
-  WorkGrab wgrab;
+  SegGrab wgrab;
   const uint32_t grain = work_grain(p.n_work);
   for (;;) {
     wv_sync();
-    const uint32_t widx = grab_item(wgrab, p.active_count + 19, &s_next, lane, grain);
-    if (widx >= p.n_work) break;
+    const uint32_t widx = grab_seg(wgrab, GRAB_PREPARE(p), p.n_work, lane, grain);
+    if (widx == GRAB_DONE) break;
+    if (widx >= p.n_work) continue;
     const LoRef ref = lo_ref<FAM>(p, widx);
     const uint32_t pi = p.pair0 + ref.pl;
     const uint64_t moff = p.match_off[pi];
@@ -4532,10 +4567,11 @@ void launch_vp_replay_lo(const VerifyParams& p, int fam, uint32_t n_blocks, int 
 // item pass, step by step (the host reads the job count between enum and the rest)
 void launch_vp_items_enum(const VerifyParams& p, int fam, hipStream_t st) {
   if (!p.n_work) return;
-  const uint32_t ne = p.n_work < 8192u ? p.n_work : 8192u;
-  if (fam == FAM_E) hipLaunchKernelGGL(k_items_enum<FAM_E>, dim3(ne), dim3(64), 0, st, p);
-  if (fam == FAM_F) hipLaunchKernelGGL(k_items_enum<FAM_F>, dim3(ne), dim3(64), 0, st, p);
-  if (fam == FAM_H) hipLaunchKernelGGL(k_items_enum<FAM_H>, dim3(ne), dim3(64), 0, st, p);
+  const uint32_t ng = (p.n_work + ITEMS_GROUP - 1) / ITEMS_GROUP;
+  const uint32_t ne = ng < 8192u ? ng : 8192u;
+  if (fam == FAM_E) hipLaunchKernelGGL(k_items_enum<FAM_E>, dim3(ne), dim3(64 * ITEMS_GROUP), 0, st, p);
+  if (fam == FAM_F) hipLaunchKernelGGL(k_items_enum<FAM_F>, dim3(ne), dim3(64 * ITEMS_GROUP), 0, st, p);
+  if (fam == FAM_H) hipLaunchKernelGGL(k_items_enum<FAM_H>, dim3(ne), dim3(64 * ITEMS_GROUP), 0, st, p);
 }
 // p.n_work = number of jobs, p.job_list their slots
 void launch_vp_items_inliers(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st) {
@@ -4598,11 +4634,12 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint
 #endif
     hipLaunchKernelGGL(k_lo_finish<FAM_F>, g64, dim3(64), 0, st, p);
   }
-  if (fam == FAM_H) {  // every H problem takes the general prepare: the list is the queue
-    if (n_wave_prepare) hipLaunchKernelGGL(k_lo_prepare<FAM_H>, dim3(nb_prep), dim3(64), 0, st, pg);
+  if (fam == FAM_H) {  // every H problem takes the general prepare: its list IS the queue (nobody appends to lo_queue_g for H)
+    const uint32_t nb_h = p.n_work < n_blocks ? p.n_work : n_blocks;
+    hipLaunchKernelGGL(k_lo_prepare<FAM_H>, dim3(nb_h), dim3(64), 0, st, p);
     if (reg_jacobi) {
       hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
-      if (n_small_jacobi) hipLaunchKernelGGL((k_lo_jacobi<FAM_H, true>), g4g, dim3(64), 0, st, pg);
+      if (n_small_jacobi) hipLaunchKernelGGL((k_lo_jacobi<FAM_H, true>), dim3((p.n_work + 64 / LOJ_G - 1) / (64 / LOJ_G)), dim3(64), 0, st, p);
     }
 #ifdef DSM_CHECK_BUILD
     else

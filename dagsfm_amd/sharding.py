@@ -41,6 +41,52 @@ def shard(pairs, rank, world_size, costs=None):
     return pairs[b[rank]:b[rank + 1]]
 
 
+INTERLEAVE_BLOCK = 256   # pairs per block of the interleaved cut
+
+
+def interleaved_parts(n_pairs, world_size, costs=None, block=None):
+    """The interleaved cut: the list in blocks of `block` consecutive pairs, dealt out to the ranks -- round-robin when the
+    blocks cost the same (equal feature counts), else heaviest block first to the rank with the least work so far (LPT).  A
+    rank's share is then a uniform sample of the whole list instead of one contiguous stretch of it: the number of RANSAC
+    trials a pair needs -- which no a-priori cost model sees -- depends on WHERE in the list the pair is (an exhaustive list
+    walks the image index; neighbouring images overlap more), so contiguous shares differ in verification time by the
+    share's place in the list, interleaved ones do not.  Returns, per rank, the ascending global pair indices it owns."""
+    if block is None:  # 256 pairs, fewer on a short list: every rank still gets at least eight blocks from all over the list
+        block = max(1, min(INTERLEAVE_BLOCK, n_pairs // (8 * world_size)))
+    n_blocks = (n_pairs + block - 1) // block
+    starts = np.arange(n_blocks, dtype=np.int64) * block
+    sizes = np.minimum(block, n_pairs - starts)
+    if costs is None:
+        bc = sizes.astype(np.float64)
+    else:
+        cum = np.concatenate([[0.0], np.cumsum(np.asarray(costs, dtype=np.float64))])
+        bc = cum[starts + sizes] - cum[starts]
+    owner = np.zeros(n_blocks, dtype=np.int64)
+    if n_blocks and np.all(bc[:-1] == bc[0]):
+        owner = np.arange(n_blocks, dtype=np.int64) % world_size       # equal blocks (the last may be short): round-robin
+    else:
+        load = np.zeros(world_size)
+        for b in np.argsort(-bc, kind="stable"):                       # LPT; ties keep list order, so the deal is deterministic
+            r = int(np.argmin(load))
+            owner[b] = r
+            load[r] += bc[b]
+    parts = []
+    for r in range(world_size):
+        mine = np.nonzero(owner == r)[0]
+        parts.append(np.concatenate([np.arange(starts[b], starts[b] + sizes[b], dtype=np.int64) for b in mine])
+                     if len(mine) else np.zeros(0, dtype=np.int64))
+    return parts
+
+
+def parts_bounds_and_order(parts):
+    """Rank-major layout of an interleaved cut: bounds[r] .. bounds[r + 1] = rank r's positions, order[k] = the global pair index
+    at rank-major position k (what gather_match_graph needs to put the gathered results back into list order)."""
+    sizes = np.array([len(p) for p in parts], dtype=np.int64)
+    bounds = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    order = np.concatenate(parts) if len(parts) else np.zeros(0, dtype=np.int64)
+    return bounds, order
+
+
 def all_gather_fixed(dist, local, max_rows, world_size):
     """All-gather of per-pair fixed-size records: `local` [rows, k] torch tensor, rows <= max_rows.
     Returns [world_size * max_rows, k]; rank r's rows start at r * max_rows."""
@@ -114,8 +160,24 @@ class MatchGraph:
         self.inlier_matches = inlier_matches  # [sum, 2] int32 or None
 
 
-def gather_match_graph(dist, source, rank, world_size, bounds, verify, force_collectives=None):
+def reorder_rows(counts_rm, rows_rm, pos):
+    """Variable-length rows from rank-major order into list order: pair p (list order) sits at rank-major position pos[p]."""
+    import torch
+    off_rm = torch.cumsum(counts_rm, 0) - counts_rm
+    cnt = counts_rm[pos]
+    out_off = torch.cumsum(cnt, 0) - cnt
+    total = int(cnt.sum().item())
+    if total == 0:
+        return cnt, rows_rm[:0]
+    idx = torch.repeat_interleave(off_rm[pos] - out_off, cnt) + torch.arange(total, dtype=torch.int64, device=rows_rm.device)
+    return cnt, rows_rm[idx]
+
+
+def gather_match_graph(dist, source, rank, world_size, bounds, verify, force_collectives=None, order=None):
     """Assembles the match graph of the whole pair list on every rank from the per-rank shards.
+
+    `order` (interleaved cut, parts_bounds_and_order): the ranks' shares are not contiguous stretches of the list; the gathered
+    results arrive rank by rank and are put back into list order on the device (one index build + one gather per array).
 
     force_collectives ("padded" / "broadcast" / True = the exchange the sizes pick): a single rank ALSO goes through
     every collective (all_gather_into_tensor of the int64 counts, the uint8 records and the int32 rows; the per-rank
@@ -163,6 +225,14 @@ def gather_match_graph(dist, source, rank, world_size, bounds, verify, force_col
         ioffs = source.inlier_offsets()
         g.inlier_counts = gather_counts(ioffs)
         g.inlier_matches = gather_rows(source.inlier_matches(int(ioffs[-1].item())))
+    if order is not None and world_size > 1:
+        pos = torch.empty(len(order), dtype=torch.int64)
+        pos[torch.as_tensor(np.asarray(order, dtype=np.int64))] = torch.arange(len(order), dtype=torch.int64)
+        pos = pos.to(g.match_counts.device)
+        g.match_counts, g.matches = reorder_rows(g.match_counts, g.matches, pos)
+        if verify:
+            g.tvg = g.tvg[pos]
+            g.inlier_counts, g.inlier_matches = reorder_rows(g.inlier_counts, g.inlier_matches, pos)
     return g
 
 

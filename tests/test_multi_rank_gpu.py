@@ -26,11 +26,15 @@ def _bench(tmp_path, tag, extra):
     return json.loads(line), dict(np.load(out))
 
 
-@pytest.mark.parametrize("pairs", ["exhaustive", "knn:6"])
-def test_two_ranks_assemble_the_single_rank_graph(tmp_path, pairs):
+@pytest.mark.parametrize("pairs,cut", [("exhaustive", "interleaved"), ("knn:6", "interleaved"), ("exhaustive", "contiguous")])
+def test_two_ranks_assemble_the_single_rank_graph(tmp_path, pairs, cut):
     one, g1 = _bench(tmp_path, "one", ["--pairs", pairs])
-    two, g2 = _bench(tmp_path, "two", ["--pairs", pairs, "--gpus", "2", "--oversubscribe"])
-    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["device"]["ranks_seen_by_process_group"] == 2
+    two, g2 = _bench(tmp_path, "two", ["--pairs", pairs, "--gpus", "2", "--oversubscribe", "--cut", cut])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and cut in two["config"]["parallelism"]
+    # what every rank did (min, mean, max over the ranks): both ranks had pairs, and the slowest rank's step is the job's
+    pr = two["per_rank"]
+    assert pr["pairs"][0] > 0 and sum(pr["pairs"]) > 0 and pr["ms_per_step"][2] <= two["ms_per_step"] * 1.5
+    assert "per_rank" not in one
     assert one["config"]["pairs"] == two["config"]["pairs"] == len(g1["match_counts"])
     assert one["config"]["pairs_with_geometry"] > 10
     for k in ("match_counts", "matches", "tvg", "inlier_counts", "inlier_matches"):

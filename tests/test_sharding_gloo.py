@@ -246,3 +246,71 @@ def test_single_rank_forced_through_the_collectives():
     for got in out[1:]:
         for a, b in zip(got, out[0]):
             assert a.shape == b.shape and (a == b).all()
+
+
+# ---- the interleaved cut (round 6): blocks of the list dealt out to the ranks, results put back into list order
+
+def test_interleaved_parts_partition_and_balance():
+    from dagsfm_amd import sharding
+    for n in (0, 1, 5, 256, 257, 1000, 124750):
+        for w in (1, 2, 4, 8):
+            parts = sharding.interleaved_parts(n, w, block=64)
+            allp = np.concatenate(parts) if n else np.zeros(0, np.int64)
+            assert sorted(allp.tolist()) == list(range(n))                      # a partition of the list
+            assert all((np.diff(p) > 0).all() for p in parts)                   # every share ascending
+            sizes = np.array([len(p) for p in parts])
+            assert sizes.max() - sizes.min() <= 64                              # equal blocks: at most one block apart
+            b, order = sharding.parts_bounds_and_order(parts)
+            assert b[0] == 0 and b[-1] == n and (order == allp).all()
+    # every rank sees the whole list: with 8 ranks and blocks of 256 the first and the last eighth of config 2's list are in every share
+    parts = sharding.interleaved_parts(124750, 8)
+    for p in parts:
+        assert p.min() < 124750 // 8 and p.max() >= 124750 - 124750 // 8
+    # unequal costs (images of different sizes): heaviest block first to the least loaded rank
+    rng = np.random.default_rng(1)
+    nfeat = rng.integers(500, 9000, 80)
+    pairs = np.array([(i, j) for i in range(80) for j in range(i + 1, 80)])
+    costs = sharding.pair_costs(pairs, nfeat)
+    parts = sharding.interleaved_parts(len(pairs), 8, costs, block=32)
+    per = np.array([costs[p].sum() for p in parts])
+    blocks = np.add.reduceat(costs, np.arange(0, len(costs), 32))
+    assert per.max() <= costs.sum() / 8 + blocks.max()                          # the LPT bound: no rank more than one block above its share
+    assert sorted(np.concatenate(parts).tolist()) == list(range(len(pairs)))
+
+
+def _interleaved_graph_worker(rank, world, port, n_images, block, q):
+    from dagsfm_amd import sharding, synthetic
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    pairs = synthetic.exhaustive_pairs(n_images).astype(np.int64)
+    parts = sharding.interleaved_parts(len(pairs), world, block=block)
+    bounds, order = sharding.parts_bounds_and_order(parts)
+    out = []
+    for exch in (None, "padded", "broadcast"):
+        g = sharding.gather_match_graph(dist, _StubSource(pairs[parts[rank]], True), rank, world, bounds, True, force_collectives=exch, order=order)
+        out.append(_graph_to_numpy(g))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_images,block", [(2, 9, 4), (4, 9, 2), (8, 4, 1), (2, 12, 256)])
+def test_gather_match_graph_interleaved_cut_equals_single_process(world, n_images, block):
+    """The interleaved cut through the real assembly code: every rank ends with the graph of the whole list IN LIST ORDER, the
+    same arrays a single process produces -- also with more ranks than blocks (empty shares) and a block longer than the list."""
+    from dagsfm_amd import sharding, synthetic
+    pairs = synthetic.exhaustive_pairs(n_images).astype(np.int64)
+    ref = _graph_to_numpy(sharding.gather_match_graph(None, _StubSource(pairs, True), 0, 1, sharding.shard_bounds(len(pairs), 1), True))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_interleaved_graph_worker, args=(r, world, port, n_images, block, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, outs in res:
+        for got in outs:
+            for a, b in zip(got, ref):
+                assert a.shape == b.shape and (a == b).all(), rank

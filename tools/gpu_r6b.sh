@@ -21,7 +21,7 @@ for v in new old; do
 done | tee $out/ab_shard.txt
 unset DSM_REPLAY_LEGACY
 timeout 900 python tools/check_schedules.py > $out/check_schedules.txt 2>&1; tail -14 $out/check_schedules.txt
-(cd /tmp && DSM_VERIFY_LANES=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/prof1 -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-seconds 0 --no-config3 --no-second-regime > $GRAFT_REPO_ROOT/$out/bench_trace1.json 2> $GRAFT_REPO_ROOT/$out/err1.txt)
+(cd /tmp && DSM_VERIFY_LANES=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/prof1 -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-seconds 0 --no-config3 --no-second-regime --no-extra-configs > $GRAFT_REPO_ROOT/$out/bench_trace1.json 2> $GRAFT_REPO_ROOT/$out/err1.txt)
 find $out/prof1 -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} $out/kernel_trace_lanes1.csv
 rm -rf $out/prof1
 python3 tools/trace_dispatches.py $out/kernel_trace_lanes1.csv k_replay > $out/dispatches_lanes1.txt

@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--outlier-frac", type=float, default=0.2)
     ap.add_argument("--max-pairs", type=int, default=0, help="truncate the list (bounded runs)")
     ap.add_argument("--skip-whole", action="store_true", help="do not time the unsharded list (too long for the big configs)")
+    ap.add_argument("--cut", default="both", choices=["contiguous", "interleaved", "both"],
+                    help="the cut(s) to sweep: one contiguous cost-balanced stretch per rank / blocks of 256 pairs dealt out (sharding.interleaved_parts)")
     a = ap.parse_args()
     scene_args = (a.images, a.feats, a.seed, a.outlier_frac)
     _init(scene_args)
@@ -63,7 +65,12 @@ def main():
     cams = [capi.simple_pinhole(_SCENE.focal, _SCENE.width / 2.0, _SCENE.height / 2.0, _SCENE.width, _SCENE.height, 1) for _ in range(a.images)]
     ctx.set_images([im[0] for im in images], [im[1] for im in images], cams)
     mo, to = capi.default_match_options(), capi.default_two_view_options()
-    bounds = sharding.shard_bounds(len(pairs), a.shards, sharding.pair_costs(pairs, [len(im[0]) for im in images]))
+    costs = sharding.pair_costs(pairs, [len(im[0]) for im in images])
+    bounds = sharding.shard_bounds(len(pairs), a.shards, costs)
+    cuts = {"contiguous": [pairs[bounds[r]:bounds[r + 1]] for r in range(a.shards)],
+            "interleaved": [pairs[ix] for ix in sharding.interleaved_parts(len(pairs), a.shards, costs)]}
+    if a.cut != "both":
+        cuts = {a.cut: cuts[a.cut]}
 
     def run(pl):
         ctx.match_pairs(pl, mo)
@@ -82,28 +89,30 @@ def main():
         result_bytes = len(pl) * (8 + 328) + 8 * (int(offs[-1]) + int(ioffs[-1]))
         return wall, k1 / max(n, 1) + ctx.match_gather_time() + ctx.match_resolve_time(), ctx.verify_kernel_time(), result_bytes
 
-    rows = []
-    for r in range(a.shards):
-        pl = pairs[bounds[r]:bounds[r + 1]]
-        wall, km, kv, nbytes = timed(pl)
-        rows.append({"shard": r, "pairs": int(len(pl)), "ms": wall, "match_ms": km, "verify_ms": kv, "result_bytes": nbytes})
-        print("shard %d/%d: %7d pairs  %8.1f ms/step  (matching %.1f, verification %.1f)" % (r + 1, a.shards, len(pl), wall, km, kv), flush=True)
-    ms = np.array([x["ms"] for x in rows])
-    total_bytes = sum(x["result_bytes"] for x in rows)
-    gather_ms = 1e3 * total_bytes * (a.shards - 1) / a.shards / (153e9 * 0.6)
+    whole = None if a.skip_whole else timed(pairs)
     out = {"workload": "%d images x %d feats, %s, %d pairs, outlier_frac %.2f" % (a.images, a.feats, a.pairs, len(pairs), a.outlier_frac),
-           "shards": a.shards, "per_shard": rows, "max_ms": float(ms.max()), "mean_ms": float(ms.mean()),
-           "imbalance_max_over_mean": float(ms.max() / ms.mean()), "scene_generation_s": t_gen,
-           "all_gather_estimate_ms": gather_ms,
-           "all_gather_note": "ESTIMATE, not measured: %.0f MB of results x (S-1)/S over one 153 GB/s xGMI link direction at 60 %% efficiency" % (total_bytes / 1e6)}
-    if not a.skip_whole:
-        wall, km, kv, _ = timed(pairs)
-        out["whole_list_ms"] = wall
-        out["whole_list_match_ms"], out["whole_list_verify_ms"] = km, kv
-        out["projected_scaling"] = wall / (float(ms.max()) + gather_ms)
-        out["projected_scaling_note"] = "T_whole / (max shard + all-gather estimate), all on ONE GPU: unmeasured on 8 GPUs"
-        print("whole list: %.1f ms/step -> projected %d-GPU strong scaling %.2fx (max shard %.1f ms, mean %.1f, gather est. %.1f ms)" %
-              (wall, a.shards, out["projected_scaling"], ms.max(), ms.mean(), gather_ms))
+           "shards": a.shards, "scene_generation_s": t_gen, "cuts": {}}
+    if whole:
+        out["whole_list_ms"], out["whole_list_match_ms"], out["whole_list_verify_ms"] = whole[0], whole[1], whole[2]
+        print("whole list: %.1f ms/step (matching %.1f, verification %.1f)" % whole[:3], flush=True)
+    for name, lists in cuts.items():
+        rows = []
+        for r, pl in enumerate(lists):
+            wall, km, kv, nbytes = timed(pl)
+            rows.append({"shard": r, "pairs": int(len(pl)), "ms": wall, "match_ms": km, "verify_ms": kv, "result_bytes": nbytes})
+            print("%s shard %d/%d: %7d pairs  %8.1f ms/step  (matching %.1f, verification %.1f)" % (name, r + 1, a.shards, len(pl), wall, km, kv), flush=True)
+        ms = np.array([x["ms"] for x in rows])
+        total_bytes = sum(x["result_bytes"] for x in rows)
+        gather_ms = 1e3 * total_bytes * (a.shards - 1) / a.shards / (153e9 * 0.6)
+        c = {"per_shard": rows, "max_ms": float(ms.max()), "mean_ms": float(ms.mean()), "imbalance_max_over_mean": float(ms.max() / ms.mean()),
+             "max_verify_ms": float(max(x["verify_ms"] for x in rows)), "all_gather_estimate_ms": gather_ms,
+             "all_gather_note": "ESTIMATE, not measured: %.0f MB of results x (S-1)/S over one 153 GB/s xGMI link direction at 60 %% efficiency" % (total_bytes / 1e6)}
+        if whole:
+            c["projected_scaling"] = whole[0] / (float(ms.max()) + gather_ms)
+            c["projected_scaling_note"] = "T_whole / (max shard + all-gather estimate), all on ONE GPU: unmeasured on 8 GPUs"
+            print("%s cut: projected %d-GPU strong scaling %.2fx (max shard %.1f ms, mean %.1f, max verification %.1f, gather est. %.1f ms)" %
+                  (name, a.shards, c["projected_scaling"], ms.max(), ms.mean(), c["max_verify_ms"], gather_ms), flush=True)
+        out["cuts"][name] = c
     print(json.dumps(out))
 
 
