@@ -2834,6 +2834,205 @@ __global__ __launch_bounds__(64, 8) void k_prescore_compact(const VerifyParams p
   reinterpret_cast<int32_t*>(p.sums + (size_t)pl * p.batch * F::MAXM + slot)[0] = lb;
 }
 
+// ------------------------------------------------------------------------------------ the E / F bound step with an f32 first stage (round 6)
+// k_prescore_compact spends 24 FP64 VALU instructions per (model, point) on the Sampson test; like k_prescore_h2 for the homographies,
+// k_prescore_compact2 classifies every point first in PACKED f32 (two points per instruction: 19 v_pk_* per two points) against a band
+// of +- 12.5 % around the threshold,
+//   C~^2 < 0.875^2 (1 - 2^-8) T D~ -> surely in        C~^2 > 1.125^2 (1 + 2^-8) T D~ -> surely out        (both only if D~ >= g_D^2),
+// and sends the few points inside the band, per lane, to the FP64 test of prescore_flags.  Error analysis (u = 2^-24; the model scaled by
+// a power of two so that its largest entry is in [1, 2): the test is homogeneous in F; B_k, Bt_j, S_C = max|x2_0| B_0 + max|x2_1| B_1 + B_2
+// as in prescore_bounds, on the scaled model; Bn = B_0 + B_1 + Bt_0 + Bt_1 >= the 2-norm of the four bounds):
+//   every input rounded to f32 and two fused roundings per row: |g~_k - g*_k| <= 4.03u B_k <= 5u B_k, |h~_j - h*_j| <= 5u Bt_j;
+//   C~ = fma(x2_0, g~_0, fma(x2_1, g~_1, g~_2)): |C~ - C*| <= 6.01u (n_0 B_0 + n_1 B_1) + 5u B_2 + 2.02u S_C <= E_C = 8.1u S_C;
+//   sqrt(D~) within e = 5u Bn of sqrt(D*) before, and 2.03u relative after, the four roundings of the sum of squares.
+//   out:  C~^2 > fl(K_out D~), K_out >= 1.1272^2 T  =>  |C*| >= 1.1272 sqrt(T) (1 - 2u) (sqrt(D*) (1 - 2.03u) - e) - E_C
+//         >= 1.004 sqrt(T D*)   once   sqrt(D*) >= 9.16 e + 8.13 E_C / sqrt(T);
+//   in:   C~^2 < fl(K_in D~),  K_in <= 0.8733^2 T   =>  |C*| <= 0.8733 sqrt(T) (1 + 2u) (sqrt(D*) (1 + 2.03u) + e) + E_C
+//         <= 0.996 sqrt(T D*)   once   sqrt(D*) >= 7.12 e + 8.15 E_C / sqrt(T).
+//   The guard on the COMPUTED value, D~ >= g_D^2 with g_D = max(1.01 (10.2 e + 8.2 E_C / sqrt(T)), 2^-40), covers both (sqrt(D*) >= (sqrt(D~) -
+//   e) / (1 + 2.03u)); it is > 2^6 x the FP64 test's own precondition D >= D_min (sqrt: 2^-25 Bn, 2^-34 S_C / sqrt(T)), under which the
+//   reference's evaluation is within 2^-14 relative of the exact residual (analysis above k_prescore): an exact |C*| <= 0.996 sqrt(T D*)
+//   is an inlier of the reference, one >= 1.004 sqrt(T D*) an outlier.  f32 range: coordinates below 2^14 and T in [2^-40, 2^40] (else the
+//   f32 stage is off) keep every quantity of a guarded point normal -- D~ >= 2^-80, K D~ >= 2^-121 -- except C~^2, which may flush to zero
+//   for |C~| < 2^-63: "in" then, and rightly (0.996 sqrt(T D*) >= 4 E_C + 0.49 x 2^-60).  Entries and results that flush to zero move g, h,
+//   C by at most 2^-111: relative 2^-70 of the guard.  Inf / NaN make every compare false: the point goes to the FP64 test.
+// tools/check_score_bounds.py (DSM_SCORE_PREFILTER=check) holds every slot's exact count against [lower, upper]; DSM_SCORE_PREFILTER=33
+// (check build) runs the pure FP64 k_prescore_compact instead.
+template <int FAM>
+__global__ __launch_bounds__(64, 6) void k_prescore_compact2(const VerifyParams p) {
+  typedef Fam<FAM> F;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ uint16_t s_map[64];
+  float* s32 = reinterpret_cast<float*>(smem_raw);  // the points as f32 pairs (16 bytes per point), then the lanes' lists
+  const uint32_t pl = blockIdx.x;
+  const uint32_t pi = p.pair0 + pl;
+  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
+  if (!fs->active) return;
+  const int lane = threadIdx.x;
+  const int nb = (int)fs->nb;
+  const int c0 = (int)blockIdx.y * 64;  // first compacted entry of this workgroup
+  if (c0 >= nb * F::MAXM) return;
+  const int32_t* nmod = p.nmodels + (size_t)pl * p.batch;
+  int run = 0;
+  for (int base = 0; base < nb; base += 64) {
+    const int t = base + lane;
+    const int nm = t < nb ? nmod[t] : 0;
+    int incl = nm;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    const int off = run + incl - nm;  // compacted index of this hypothesis' first model
+    if (off < c0 + 64 && off + nm > c0) {
+      for (int m = 0; m < nm; ++m) {
+        const int c = off + m - c0;
+        if (c >= 0 && c < 64) s_map[c] = (uint16_t)(t * F::MAXM + m);
+      }
+    }
+    run += __shfl(incl, 63);
+    if (run >= c0 + 64) break;  // (wave-uniform) the later hypotheses' models belong to later workgroups
+  }
+  if (c0 >= run) return;  // wave-uniform: no model of the pair is left for this workgroup
+  const uint64_t moff = p.match_off[pi];
+  const int n = (int)(p.match_off[pi + 1] - moff);
+  const double* gpts = (FAM == FAM_E ? p.pts_norm : p.pts_px) + 4 * moff;
+  const bool in_lds = n <= VP_LDS_PTS;
+  double T = p.opt.max_error * p.opt.max_error;
+  if (FAM == FAM_E) {
+    const double max_error = (image_to_world_threshold(p.cams[p.pairs[2 * pi]], p.opt.max_error) +
+                              image_to_world_threshold(p.cams[p.pairs[2 * pi + 1]], p.opt.max_error)) / 2;
+    T = max_error * max_error;
+  }
+  double mx[4];
+  stage_points_with_maxima(gpts, n, false, nullptr, lane, mx);
+  const int npair = (n + 1) / 2;
+  uint16_t* lst = reinterpret_cast<uint16_t*>(s32 + (size_t)8 * (in_lds ? npair : 0));  // entry k of lane l at [k * 64 + l]
+  if (in_lds) {
+    // the points as f32, two points per 32-byte record: (x1_0a, x1_0b, x1_1a, x1_1b, x2_0a, x2_0b, x2_1a, x2_1b); an odd last point twice
+    for (int j = lane; j < npair; j += 64) {
+      const int ia = 2 * j, ib = 2 * j + 1 < n ? 2 * j + 1 : 2 * j;
+      float4 lo, hi;
+      lo.x = (float)gpts[ia * 4 + 0];
+      lo.y = (float)gpts[ib * 4 + 0];
+      lo.z = (float)gpts[ia * 4 + 1];
+      lo.w = (float)gpts[ib * 4 + 1];
+      hi.x = (float)gpts[ia * 4 + 2];
+      hi.y = (float)gpts[ib * 4 + 2];
+      hi.z = (float)gpts[ia * 4 + 3];
+      hi.w = (float)gpts[ib * 4 + 3];
+      reinterpret_cast<float4*>(s32)[2 * j] = lo;
+      reinterpret_cast<float4*>(s32)[2 * j + 1] = hi;
+    }
+  }
+  __syncthreads();  // (also publishes s_map)
+  const bool has_model = c0 + lane < run;
+  const int slot = has_model ? (int)s_map[lane] : 0;
+  const double* gm = p.models + ((size_t)pl * p.batch * F::MAXM + (size_t)slot) * 9;
+  double M[9];
+  for (int k = 0; k < 9; ++k) M[k] = has_model ? gm[k] : 0.0;
+  const PreBounds b = prescore_bounds<FAM>(M, mx, T);
+  int lb = 0, sure_out = 0;
+  if (!in_lds) {  // the points do not fit the LDS: the FP64 loop over wave-uniform global addresses, as k_prescore_compact
+    if (has_model) {
+#pragma unroll 4
+      for (int i = 0; i < n; ++i) prescore_point<FAM>(M, b, gpts + (size_t)i * 4, lb, sure_out);
+    }
+  } else {
+    // ---- the model in f32 (largest entry scaled into [1, 2)), the guard, the band's constants
+    float Ff[9], gd2 = __builtin_inff(), k_out = __builtin_inff(), k_in = -1.0f;
+    {
+      double big = 0.0;
+      for (int k = 0; k < 9; ++k) big = fmax(big, fabs(M[k]));
+      const bool usable = has_model && (b.c0 == b.c0) && big >= 0x1p-900 && big <= 0x1p900 && T >= 0x1p-40 && T <= 0x1p40;  // (c0 is NaN when t_ok / x_ok fail)
+      const double sc = usable ? ldexp(1.0, -ilogb(big)) : 0.0;
+      double Ms[9];
+      for (int k = 0; k < 9; ++k) {
+        Ms[k] = M[k] * sc;
+        Ff[k] = (float)Ms[k];
+      }
+      const double B0 = fabs(Ms[0]) * mx[0] + fabs(Ms[1]) * mx[1] + fabs(Ms[2]);
+      const double B1 = fabs(Ms[3]) * mx[0] + fabs(Ms[4]) * mx[1] + fabs(Ms[5]);
+      const double B2 = fabs(Ms[6]) * mx[0] + fabs(Ms[7]) * mx[1] + fabs(Ms[8]);
+      const double Bt0 = fabs(Ms[0]) * mx[2] + fabs(Ms[3]) * mx[3] + fabs(Ms[6]);
+      const double Bt1 = fabs(Ms[1]) * mx[2] + fabs(Ms[4]) * mx[3] + fabs(Ms[7]);
+      const double e = 5.0 * 0x1p-24 * (B0 + B1 + Bt0 + Bt1);
+      const double EC = 8.1 * 0x1p-24 * (mx[2] * B0 + mx[3] * B1 + B2);
+      const double gD = fmax(1.01 * (10.2 * e + 8.2 * EC / sqrt(T)), 0x1p-40);
+      if (usable && gD <= 0x1p40) {
+        gd2 = (float)(gD * gD * 1.001) * 1.0001f;                      // rounded up
+        k_out = (float)(1.265625 * T * (1.0 + 0x1p-8)) * 1.0001f;      // rounded up
+        k_in = (float)(0.765625 * T * (1.0 - 0x1p-8)) * 0.9999f;       // rounded down
+      }
+    }
+    int cnt = 0;
+    if (has_model) {
+      const dsm_f32x2 f0 = pk2(Ff[0]), f1 = pk2(Ff[1]), f2 = pk2(Ff[2]), f3 = pk2(Ff[3]), f4 = pk2(Ff[4]), f5 = pk2(Ff[5]), f6 = pk2(Ff[6]), f7 = pk2(Ff[7]),
+                      f8 = pk2(Ff[8]), ko = pk2(k_out), ki = pk2(k_in);
+      for (int j = 0; j < npair; ++j) {
+        const float4 lo = reinterpret_cast<const float4*>(s32)[2 * j], hi = reinterpret_cast<const float4*>(s32)[2 * j + 1];
+        const dsm_f32x2 x10 = {lo.x, lo.y}, x11 = {lo.z, lo.w}, x20 = {hi.x, hi.y}, x21 = {hi.z, hi.w};
+        const dsm_f32x2 g0 = pk_fma(f0, x10, pk_fma(f1, x11, f2));
+        const dsm_f32x2 g1 = pk_fma(f3, x10, pk_fma(f4, x11, f5));
+        const dsm_f32x2 g2 = pk_fma(f6, x10, pk_fma(f7, x11, f8));
+        const dsm_f32x2 h0 = pk_fma(f0, x20, pk_fma(f3, x21, f6));
+        const dsm_f32x2 h1 = pk_fma(f1, x20, pk_fma(f4, x21, f7));
+        const dsm_f32x2 C = pk_fma(x20, g0, pk_fma(x21, g1, g2));
+        const dsm_f32x2 num = C * C;
+        const dsm_f32x2 D = pk_fma(g0, g0, pk_fma(g1, g1, pk_fma(h0, h0, h1 * h1)));
+        const dsm_f32x2 DO = ko * D, DI = ki * D;
+        const bool two = 2 * j + 1 < n;
+        const bool ok_a = D.x >= gd2, ok_b = two && D.y >= gd2;
+        const bool out_a = ok_a && (num.x > DO.x), out_b = ok_b && (num.y > DO.y);
+        const bool in_a = ok_a && (num.x < DI.x), in_b = ok_b && (num.y < DI.y);
+        sure_out += (out_a ? 1 : 0) + (out_b ? 1 : 0);
+        lb += (in_a ? 1 : 0) + (in_b ? 1 : 0);
+        if (!(in_a || out_a)) {  // inside the band (or unguarded): the FP64 test decides, later
+          if (cnt < PRESCORE_LIST_CAP) lst[cnt * 64 + lane] = (uint16_t)(2 * j);
+          ++cnt;
+        }
+        if (two && !(in_b || out_b)) {
+          if (cnt < PRESCORE_LIST_CAP) lst[cnt * 64 + lane] = (uint16_t)(2 * j + 1);
+          ++cnt;
+        }
+      }
+    }
+    // ---- the listed points in FP64; a lane whose list overflowed (a model the f32 stage cannot judge) redoes all of its points
+    const bool overflow = cnt > PRESCORE_LIST_CAP;
+    if (overflow) {
+      lb = 0;
+      sure_out = 0;
+      for (int i = 0; i < n; ++i) prescore_point<FAM>(M, b, gpts + (size_t)i * 4, lb, sure_out);
+      cnt = 0;
+    }
+    int maxc = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o));
+    for (int k0 = 0; k0 < maxc; k0 += 4) {  // four listed points per trip, their loads issued together
+      double q[4][4];
+      bool on[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        on[u] = k0 + u < cnt;
+        const double* src = gpts + (size_t)(on[u] ? lst[(k0 + u) * 64 + lane] : 0) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[u][c] = src[c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bool in, out;
+        prescore_flags<FAM>(M, b, q[u], in, out);
+        lb += (on[u] && in) ? 1 : 0;
+        sure_out += (on[u] && out) ? 1 : 0;
+      }
+    }
+  }
+  if (has_model) {
+    p.counts[(size_t)pl * p.batch * F::MAXM + slot] = n - sure_out;
+    reinterpret_cast<int32_t*>(p.sums + (size_t)pl * p.batch * F::MAXM + slot)[0] = lb;
+  }
+}
+
 // the inlier counts of ALL models of the block's 64 hypotheses (built by k_roots_e) with the lanes spread over the
 // correspondences (a hypothesis has 0..10 models: scoring them
 // lane-per-hypothesis would run every lane as long as the one with the most models).
@@ -4664,6 +4863,8 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
   if (!p.n_chunk) return;
   const dim3 grid(p.n_chunk, (p.batch + 63) / 64);
   const size_t smem = (size_t)(p.n_max < VP_LDS_PTS ? (p.n_max > 0 ? p.n_max : 1) : VP_LDS_PTS) * 32;
+  // the bound steps with an f32 first stage: the points as f32 (16 bytes each, padded to a pair) + the lanes' lists of band points
+  const size_t smem_c2 = (size_t)(p.n_max < VP_LDS_PTS ? (p.n_max > 0 ? p.n_max : 1) : VP_LDS_PTS) * 16 + 32 + (size_t)PRESCORE_LIST_CAP * 64 * 2;
   if (fam == FAM_E) {
     hipLaunchKernelGGL(k_solve_e_build, grid, dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_solve_e_lu, grid, dim3(64), ELU_SMEM, st, p);
@@ -4678,7 +4879,13 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
     const size_t smem2e = smem + (size_t)p.batch * 10 * 2;
     const uint32_t nb_needed_e = p.n_chunk < 256u * 32u ? p.n_chunk : 256u * 32u;
     if ((p.score_prefilter & 1) && !(p.score_prefilter & 2) && p.batch * 10 <= 65535 && smem2e <= 64 * 1024) {  // 1, and 5 = check
-      hipLaunchKernelGGL(k_prescore_compact<FAM_E>, dim3(p.n_chunk, (p.batch * 10 + 63) / 64), dim3(64), smem, st, p);
+      // the bound step with its packed-f32 first stage (k_prescore_compact2); check build, DSM_SCORE_PREFILTER=33: the pure FP64 form
+#ifdef DSM_CHECK_BUILD
+      if (p.score_prefilter & 32)
+        hipLaunchKernelGGL(k_prescore_compact<FAM_E>, dim3(p.n_chunk, (p.batch * 10 + 63) / 64), dim3(64), smem, st, p);
+      else
+#endif
+        hipLaunchKernelGGL(k_prescore_compact2<FAM_E>, dim3(p.n_chunk, (p.batch * 10 + 63) / 64), dim3(64), smem_c2, st, p);
       hipLaunchKernelGGL(k_score_needed<FAM_E>, dim3(nb_needed_e), dim3(64), smem2e, st, p);
 #ifdef DSM_CHECK_BUILD
     } else if (p.score_prefilter & 4) {
@@ -4697,8 +4904,12 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
     if (p.score_prefilter && p.batch * 3 <= 65535 && smem2 <= 64 * 1024) {
       if (p.score_prefilter & 2)  // DSM_SCORE_PREFILTER=3: a lane per slot
         hipLaunchKernelGGL(k_prescore<FAM_F>, dim3(p.n_chunk, (p.batch * 3 + 63) / 64), dim3(64), smem, st, p);
-      else
+#ifdef DSM_CHECK_BUILD
+      else if (p.score_prefilter & 32)
         hipLaunchKernelGGL(k_prescore_compact<FAM_F>, dim3(p.n_chunk, (p.batch * 3 + 63) / 64), dim3(64), smem, st, p);
+#endif
+      else
+        hipLaunchKernelGGL(k_prescore_compact2<FAM_F>, dim3(p.n_chunk, (p.batch * 3 + 63) / 64), dim3(64), smem_c2, st, p);
       hipLaunchKernelGGL(k_score_needed<FAM_F>, dim3(nb_needed), dim3(64), smem2, st, p);
     } else {
       hipLaunchKernelGGL(k_score<FAM_F>, dim3(p.n_chunk, (p.batch * 3 + 63) / 64), dim3(64), smem, st, p);

@@ -86,5 +86,5 @@ def test_bench_force_collectives_reports_the_exchange(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     ex = d["exchange"]
-    assert ex["backend"] == "nccl" and ex["forced_on_one_rank"] and d["device"]["ranks_seen_by_process_group"] == 1
+    assert ex["backend"] == "nccl" and ex["forced_on_one_rank"] and d["n_gpus"] == 1
     assert ex["gather_ms_per_step"] > 0 and ex["bytes_per_step"] > 0

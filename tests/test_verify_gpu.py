@@ -478,7 +478,7 @@ def test_differential_fuzz_stage_calls(dsm):
     assert total > 200 and stats["guided"] > 30
 
 
-@pytest.mark.parametrize("prefilter", ["1", "0", "9", "17"])  # 1: the product (H: packed-f32 first stage + FP64 list); 17: the pure FP64 k_prescore<H> of round 4; 9: its products on the FP64 matrix pipe (both check build)
+@pytest.mark.parametrize("prefilter", ["1", "0", "9", "17", "33"])  # 1: the product (H: packed-f32 first stage + FP64 list); 17: the pure FP64 k_prescore<H> of round 4; 9: its products on the FP64 matrix pipe (both check build)
 def test_bound_and_exact_scoring_regimes(dsm, oracle, prefilter, monkeypatch):
     """Round 4: F / H / E scoring as bound + exact (k_prescore, k_score_needed).  The bounds switch
     themselves off where their margins do not hold -- a threshold below 2^-6 px^2, coordinates beyond 2^14 px -- and every

@@ -16,7 +16,8 @@ The schedules marked * exist in the CHECK build only (libdagsfm_mi355x_check.so,
 run on the PRODUCT library, the * schedules on a second context of the check library over the same matches, and every
 one is compared with the product's `batched` records -- so the comparison also shows that the two builds agree.
   * no_prefilter, e_fused, final_1wave, legacy, h_mfma (DSM_SCORE_PREFILTER=9: the H bound step's products on the FP64 matrix pipe),
-    h_f64 (=17: the pure FP64 H bound step of round 4; the product's has a packed-f32 first stage), replay_legacy (DSM_REPLAY_LEGACY:
+    h_f64 (=17: the pure FP64 H bound step of round 4; the product's has a packed-f32 first stage), ef_f64 (=33: the pure FP64 E / F
+    bound step k_prescore_compact; the product's k_prescore_compact2 has a packed-f32 first stage since round 6), replay_legacy (DSM_REPLAY_LEGACY:
     the replay scans of rounds 2 - 5, k_replay_lo<fam, 0 / 2>, points and residuals through global memory; the product's k_replay_rp
     keeps the pair in LDS)
 This exercises the paths too rare for the oracle-sized tests (a Lemire rejection in the sampler happens for a few
@@ -50,6 +51,8 @@ def run(ctx, opts, schedule):
         os.environ["DSM_SCORE_PREFILTER"] = "9"
     if schedule == "h_f64":
         os.environ["DSM_SCORE_PREFILTER"] = "17"
+    if schedule == "ef_f64":
+        os.environ["DSM_SCORE_PREFILTER"] = "33"
     os.environ.pop("DSM_FINAL_WAVES", None)
     if schedule == "final_1wave":
         os.environ["DSM_FINAL_WAVES"] = "1"
@@ -96,8 +99,8 @@ def main():
     opts = capi.default_two_view_options()
     r0 = run(ctxs[False], opts, "batched")
     ok = True
-    CHECK_ONLY = ("no_prefilter", "e_fused", "final_1wave", "legacy", "h_mfma", "h_f64", "replay_legacy")
-    for name in ["batched_check_build", "replay_legacy", "no_prefilter", "e_fused", "h_mfma", "h_f64", "one_lane", "no_tail", "tail_inline", "final_1wave", "inline"] + (["legacy"] if a.legacy else []):
+    CHECK_ONLY = ("no_prefilter", "e_fused", "final_1wave", "legacy", "h_mfma", "h_f64", "ef_f64", "replay_legacy")
+    for name in ["batched_check_build", "replay_legacy", "no_prefilter", "e_fused", "h_mfma", "h_f64", "ef_f64", "one_lane", "no_tail", "tail_inline", "final_1wave", "inline"] + (["legacy"] if a.legacy else []):
         use_check = name in CHECK_ONLY or name == "batched_check_build"
         r1 = run(ctxs[use_check], opts, "batched" if name == "batched_check_build" else name)
         for k in capi.CHECK_OPTION_KEYS:  # the product context must not see a check-only switch
