@@ -194,6 +194,8 @@ def parse_args():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the two further side measurements after the timed region: the same pair list with cameras without a focal prior "
                          "(extra.uncalibrated: F + H) and BASELINE configs[0] on the GPU (extra.config1: 50 x 1 024, every pair checked)")
+    ap.add_argument("--memory-budget-gib", type=float, default=0.0,
+                    help="dsm_ctx_set_memory_budget: GiB of transient chunk scratch the matcher and the verifier may hold (0: the defaults)")
     ap.add_argument("--no-match-lock", action="store_true", help="experiment: with --contexts > 1, let the contexts' matching calls overlap")
     ap.add_argument("--ctx-after-pg", action="store_true", help="experiment: create the dsm contexts after the process group (the order of rounds 1 - 4)")
     ap.add_argument("--dump-line", default="", help="rank 0 also writes the long form of the result (with the prose notes) to this file")
@@ -446,6 +448,9 @@ def main():
     if not ctxs:
         ctxs = [capi.Context(dev_index) for _ in range(n_ctx)]
     ctx = ctxs[0]
+    if args.memory_budget_gib > 0:
+        for c in ctxs:
+            c.set_memory_budget(int(args.memory_budget_gib * (1 << 30)))
     info = ctx.device_info()
     cams = [capi.simple_pinhole(scene.focal, scene.width / 2.0, scene.height / 2.0, scene.width, scene.height, calibrated)
             for _ in range(len(images))]
@@ -671,6 +676,9 @@ def main():
             out["from_profiles"] = fp
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if args.memory_budget_gib > 0:
+            res_b, scr_b = ctx.memory_footprint()
+            out["memory"] = {"budget_gib": args.memory_budget_gib, "scratch_gib": scr_b / 2 ** 30, "resident_gib": res_b / 2 ** 30}
         # ---- side measurements after the timed region (never part of `value`), each held against the oracle on a bounded sample of
         # its own pairs (`parity_sample`): what is timed is what is checked
         side_ok = (world == 1 and verify and args.shard_of == 1 and not args.max_pairs and args.pairs == "exhaustive" and not args.fixed_trials

@@ -204,6 +204,18 @@ class Context:
                     self.set_debug_option(key, want)
         return self._handle
 
+    def set_memory_budget(self, nbytes):
+        """dsm_ctx_set_memory_budget: bytes of transient chunk scratch the matcher and the verifier may hold (0: the defaults)."""
+        self._L.dsm_ctx_set_memory_budget.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+        self._chk(self._L.dsm_ctx_set_memory_budget(self._handle, ctypes.c_uint64(int(nbytes))))
+
+    def memory_footprint(self):
+        """dsm_ctx_memory_footprint -> (resident_bytes, scratch_bytes) the context holds on the device right now."""
+        r, s = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._L.dsm_ctx_memory_footprint.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+        self._chk(self._L.dsm_ctx_memory_footprint(self._handle, ctypes.byref(r), ctypes.byref(s)))
+        return int(r.value), int(s.value)
+
     def set_debug_option(self, key, value):
         """dsm_set_debug_option: a scheduling / cross-check switch of this context (None removes it)."""
         L = self._L

@@ -269,6 +269,50 @@ int dsm_set_debug_option(dsm_ctx* ctx, const char* key, const char* value) {
   return DSM_OK;
 }
 
+// Both stages keep their scratch between calls (a step re-uses it), so the budget is split: the matcher's chunk outputs get a
+// quarter of it (at most their default 8 GiB), the verifier the rest.
+static inline uint64_t match_budget_share(uint64_t budget) { return std::min<uint64_t>(8ull << 30, budget / 4); }
+
+static std::vector<DevBuf*> scratch_buffers(dsm_ctx* ctx) {
+  std::vector<DevBuf*> v = {&ctx->d_m, &ctx->d_ms, &ctx->d_entries, &ctx->d_out2, &ctx->d_out2s, &ctx->d_dpairs, &ctx->d_dpairs2, &ctx->d_doutoff, &ctx->d_pair_dir,
+                            &ctx->d_order, &ctx->d_ecnt, &ctx->d_eoff, &ctx->d_vscratch};
+  for (VerifyLane& L : ctx->lanes)
+    for (DevBuf* b : {&L.samples, &L.draws_end, &L.nmodels, &L.vcounts, &L.vsums, &L.models, &L.ework, &L.active, &L.vscratch, &L.lo_queue, &L.lo_work,
+                      &L.lo_models, &L.lo_slots, &L.lo_ework, &L.tail_items, &L.tail_n, &L.lo_jobs, &L.job_list})
+      v.push_back(b);
+  return v;
+}
+
+int dsm_ctx_set_memory_budget(dsm_ctx* ctx, uint64_t bytes) {
+  if (!ctx) return DSM_ERR_INVALID_ARGUMENT;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->memory_budget = bytes;
+  if (bytes) {  // scratch held from an earlier, larger call is given back now: the next call allocates inside the budget
+    uint64_t held = 0;
+    for (DevBuf* b : scratch_buffers(ctx)) held += b->cap;
+    if (held > bytes)
+      for (DevBuf* b : scratch_buffers(ctx)) b->release();
+  }
+  return DSM_OK;
+}
+
+int dsm_ctx_memory_footprint(const dsm_ctx* cctx, uint64_t* resident_bytes, uint64_t* scratch_bytes) {
+  if (!cctx) return DSM_ERR_INVALID_ARGUMENT;
+  dsm_ctx* ctx = const_cast<dsm_ctx*>(cctx);
+  uint64_t scratch = 0, resident = 0;
+  for (DevBuf* b : scratch_buffers(ctx)) scratch += b->cap;
+  for (DevBuf* b : {&ctx->d_stage, &ctx->d_desc, &ctx->d_rterm, &ctx->d_kp, &ctx->d_img_row0, &ctx->d_img_rows, &ctx->d_lut, &ctx->d_counts, &ctx->d_offsets, &ctx->d_matches,
+                    &ctx->d_total, &ctx->d_etotal, &ctx->d_cams, &ctx->d_pairs_dev, &ctx->d_seeds, &ctx->d_tvg, &ctx->d_inl, &ctx->d_inl_counts, &ctx->d_inl_off,
+                    &ctx->d_inl_compact, &ctx->d_inl_total, &ctx->d_nt_table, &ctx->d_nt_off, &ctx->d_nt_off_t, &ctx->d_pair_state, &ctx->d_pts_px,
+                    &ctx->d_pts_norm, &ctx->d_reports, &ctx->d_masks, &ctx->d_fam_state, &ctx->d_sidx, &ctx->d_lo_inl, &ctx->d_nt_table_t, &ctx->d_wm_redo,
+                    &ctx->d_wm_total, &ctx->d_wm_count, &ctx->d_lo_inl_pool, &ctx->d_pose_jobs})
+    resident += b->cap;
+  if (resident_bytes) *resident_bytes = resident;
+  if (scratch_bytes) *scratch_bytes = scratch;
+  return DSM_OK;
+}
+
 // dsm_set_images (append = false: the resident set is replaced) and dsm_append_images (append = true: the images
 // already on the device stay where they are, the new ones get the next indices and only THEIR rows cross PCIe).
 static int upload_images(dsm_ctx* ctx, bool append, uint32_t n_new, const uint32_t* n_feats, const uint8_t* const* desc,
@@ -459,6 +503,8 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
 
   // Chunk the pair list so that the K1 output scratch stays below a fixed budget.
   uint64_t budget_rows = (8ull << 30) / 8;  // two int32 per row: the result and K1's second-best value for K1b
+  // (dsm_ctx_set_memory_budget: the chunk's scratch is those 8 bytes per row + ~4 bytes per row of entry lists / second-pass outputs)
+  if (ctx->memory_budget) budget_rows = std::max<uint64_t>(1, std::min<uint64_t>(budget_rows, match_budget_share(ctx->memory_budget) / 12));
   if (const char* e = ctx->dbg("DSM_MATCH_CHUNK_ROWS")) budget_rows = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // test hook
   std::vector<uint2> dpairs, dpairs2;
   std::vector<uint64_t> doff;
@@ -1193,6 +1239,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
         budget = std::min<uint64_t>(96ull << 30, std::max<uint64_t>(4ull << 30, (uint64_t)((free_b + have) * 0.4)));
       }
     }
+    if (ctx->memory_budget) budget = ctx->memory_budget - match_budget_share(ctx->memory_budget);  // dsm_ctx_set_memory_budget: the host application's word
     // Round buffers: a pair's FIRST round speculates first_batch trials (sized for the easy regime: E / F stop after
     // ~60 / ~150 trials at a 64 % inlier ratio), every later round what its dynamic stop still asks for.  At a 25 %
     // ratio that is thousands of trials (E 5 400, F 10 000: measured), i.e. a hundred rounds of 64 -- so the buffers
@@ -1267,6 +1314,55 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     // The lane scratch was sized from what hipMemGetInfo reported a moment ago; other contexts of this process (bench
     // --contexts, several host threads) may have taken that memory since.  An allocation failure here is not an
     // error: release the lanes' scratch, halve the chunks, try again (a chunk of one pair always fits or nothing does).
+    // what a lane holds for a chunk of `chunk` pairs, buffer by buffer (reserve_lanes below allocates exactly these)
+    struct LaneBytes {
+      size_t v[18];
+      size_t total() const {
+        size_t t = 0;
+        for (size_t x : v) t += x + x / 8 + 256;  // (DevBuf::reserve rounds up by an eighth)
+        return t;
+      }
+    };
+    auto lane_bytes = [&](uint32_t chunk) {
+      LaneBytes z;
+      const uint32_t lane_blocks = std::min<uint32_t>(chunk, (uint32_t)dev_cus * 4u * DSM_REPLAY_WAVES);
+      // item passes: over the whole chunk (item_mode) or over a queue of <= lo_tail pairs
+      const size_t item_pairs = plan.item_mode ? chunk : std::min<uint32_t>(chunk, std::max<uint32_t>(plan.lo_tail, 1));
+      const size_t slots = std::max<size_t>(chunk, item_pairs * TAIL_KMAX);  // records of the batched LO kernels: per pair or per job
+      z.v[0] = LANE_CTR_BYTES;
+      z.v[1] = std::max<size_t>(1, (size_t)lane_blocks * verify_scratch_bytes_per_block(n_max));
+      z.v[2] = (size_t)chunk * plan.bmax * 7 * 4;
+      z.v[3] = (size_t)chunk * plan.bmax * 4;
+      z.v[4] = (size_t)chunk * plan.bmax * 4;
+      z.v[5] = (size_t)chunk * bm_max * 4;
+      z.v[6] = (size_t)chunk * bm_max * 8;
+      z.v[7] = (size_t)chunk * bm_max * 72;
+      z.v[8] = (size_t)chunk * plan.batch[0] * 200 * 8;
+      z.v[9] = ((size_t)chunk * 2 + std::max<size_t>(chunk, item_pairs * TAIL_KMAX)) * 4;  // two alternating queues + the general-kernel list (pairs or job slots)
+      z.v[10] = item_pairs * TAIL_KMAX * sizeof(TailItem);
+      z.v[11] = item_pairs * 4;
+      z.v[12] = item_pairs * TAIL_KMAX * sizeof(LoJob);
+      z.v[13] = item_pairs * TAIL_KMAX * 4;
+      z.v[14] = slots * LO_WORK_DOUBLES * 8;
+      z.v[15] = slots * 90 * 8;
+      z.v[16] = slots * 90 * 8;
+      z.v[17] = slots * 200 * 8;
+      return z;
+    };
+    if (ctx->memory_budget) {
+      // the host application's budget is a promise about what is ALLOCATED: shrink the chunks until the lanes' buffers -- fixed
+      // parts, item-pass records and DevBuf's rounding included -- fit it (a chunk of one pair always runs)
+      for (;;) {
+        size_t total = 0;
+        uint32_t largest = 0;
+        for (uint32_t li = 0; li < n_lanes; ++li) {
+          total += lane_bytes(plan.chunk[li]).total();
+          largest = std::max(largest, plan.chunk[li]);
+        }
+        if (total <= ctx->memory_budget - match_budget_share(ctx->memory_budget) || largest <= 1) break;
+        for (uint32_t li = 0; li < n_lanes; ++li) plan.chunk[li] = std::max<uint32_t>(1, (uint32_t)(plan.chunk[li] * 0.9));
+      }
+    }
     for (;;) {
       auto reserve_lanes = [&]() -> hipError_t {
 #define LRES(call)                          \
@@ -1277,7 +1373,6 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
         for (uint32_t li = 0; li < n_lanes; ++li) {
           VerifyLane& L = ctx->lanes[li];
           const uint32_t chunk = plan.chunk[li];
-          const uint32_t lane_blocks = std::min<uint32_t>(chunk, (uint32_t)dev_cus * 4u * DSM_REPLAY_WAVES);
           // Lane 0 runs on the context's own stream, the others get one each.  The runtime maps a process's streams onto a small
           // pool of hardware queues (ROCclr: GPU_MAX_HW_QUEUES = 4 by default) and streams that share a queue serialise: with
           // the null stream, the context's stream and one stream per lane, THREE lanes made five streams -- measured as "three
@@ -1291,27 +1386,25 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
           }
           if (!L.done) LRES(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
           if (!L.host_ctr) LRES(hipHostMalloc(reinterpret_cast<void**>(&L.host_ctr), 128, hipHostMallocDefault));
-          LRES(L.active.reserve(LANE_CTR_BYTES));
-          LRES(L.vscratch.reserve(std::max<size_t>(1, (size_t)lane_blocks * verify_scratch_bytes_per_block(n_max))));
-          LRES(L.samples.reserve((size_t)chunk * plan.bmax * 7 * 4));
-          LRES(L.draws_end.reserve((size_t)chunk * plan.bmax * 4));
-          LRES(L.nmodels.reserve((size_t)chunk * plan.bmax * 4));
-          LRES(L.vcounts.reserve((size_t)chunk * bm_max * 4));
-          LRES(L.vsums.reserve((size_t)chunk * bm_max * 8));
-          LRES(L.models.reserve((size_t)chunk * bm_max * 72));
-          LRES(L.ework.reserve((size_t)chunk * plan.batch[0] * 200 * 8));
-          LRES(L.lo_queue.reserve(((size_t)chunk * 2 + std::max<size_t>(chunk, (size_t)(plan.item_mode ? chunk : std::min<uint32_t>(chunk, std::max<uint32_t>(plan.lo_tail, 1))) * TAIL_KMAX)) * 4));  // two alternating queues + the general-kernel list (pairs or job slots)
-          // item passes: over the whole chunk (item_mode) or over a queue of <= lo_tail pairs
-          const size_t item_pairs = plan.item_mode ? chunk : std::min<uint32_t>(chunk, std::max<uint32_t>(plan.lo_tail, 1));
-          const size_t slots = std::max<size_t>(chunk, item_pairs * TAIL_KMAX);  // records of the batched LO kernels: per pair or per job
-          LRES(L.tail_items.reserve(item_pairs * TAIL_KMAX * sizeof(TailItem)));
-          LRES(L.tail_n.reserve(item_pairs * 4));
-          LRES(L.lo_jobs.reserve(item_pairs * TAIL_KMAX * sizeof(LoJob)));
-          LRES(L.job_list.reserve(item_pairs * TAIL_KMAX * 4));
-          LRES(L.lo_work.reserve(slots * LO_WORK_DOUBLES * 8));
-          LRES(L.lo_models.reserve(slots * 90 * 8));
-          LRES(L.lo_slots.reserve(slots * 90 * 8));
-          LRES(L.lo_ework.reserve(slots * 200 * 8));
+          const LaneBytes z = lane_bytes(chunk);
+          LRES(L.active.reserve(z.v[0]));
+          LRES(L.vscratch.reserve(z.v[1]));
+          LRES(L.samples.reserve(z.v[2]));
+          LRES(L.draws_end.reserve(z.v[3]));
+          LRES(L.nmodels.reserve(z.v[4]));
+          LRES(L.vcounts.reserve(z.v[5]));
+          LRES(L.vsums.reserve(z.v[6]));
+          LRES(L.models.reserve(z.v[7]));
+          LRES(L.ework.reserve(z.v[8]));
+          LRES(L.lo_queue.reserve(z.v[9]));
+          LRES(L.tail_items.reserve(z.v[10]));
+          LRES(L.tail_n.reserve(z.v[11]));
+          LRES(L.lo_jobs.reserve(z.v[12]));
+          LRES(L.job_list.reserve(z.v[13]));
+          LRES(L.lo_work.reserve(z.v[14]));
+          LRES(L.lo_models.reserve(z.v[15]));
+          LRES(L.lo_slots.reserve(z.v[16]));
+          LRES(L.lo_ework.reserve(z.v[17]));
         }
 #undef LRES
         return hipSuccess;

@@ -148,6 +148,10 @@ struct dsm_ctx {
     return it == debug_options.end() ? nullptr : it->second.c_str();
   }
 
+  // dsm_ctx_set_memory_budget: bytes the chunk planners of dsm_match_pairs / dsm_verify_pairs may spend on their transient
+  // scratch (0: the default policy -- 8 GiB of K1 output per chunk, 40 % of the free memory, 4 .. 96 GiB, for the verifier)
+  uint64_t memory_budget = 0;
+
   struct RetrievalState* retrieval = nullptr;  // vocabulary-tree retrieval (retrieval.hip), created on first use
 };
 void dsm_retrieval_destroy(dsm_ctx* ctx);     // retrieval.hip

@@ -142,6 +142,22 @@ int dsm_sync(dsm_ctx* ctx);
  * SiftMatchingOptions, src/feature/sift.h:139-195).  DSM_ERR_INVALID_ARGUMENT for an unknown key. */
 int dsm_set_debug_option(dsm_ctx* ctx, const char* key, const char* value);
 
+/* A memory budget at the boundary.  The reference documents its GPU matcher's footprint and leaves the rest of the device to the
+ * host application (doc/faq.rst:353-356: "4 n^2 + 4 n 256 bytes"; the mapper's dense stages run on the same GPU next).  This
+ * library's stages cut their pair list into chunks sized by the memory they may use for TRANSIENT scratch -- the matcher's
+ * per-row outputs of K1 (default: 8 GiB per chunk), the verifier's speculated trials of a chunk of pairs (default: 40 % of what
+ * is free at the call, at least 4 GiB, at most 96 GiB) -- and `bytes` > 0 replaces both defaults: the two stages together then
+ * hold at most `bytes` of chunk scratch (a quarter of it, at most 8 GiB, for the matcher; the rest for the verifier's lanes; both
+ * keep their scratch between calls).  Smaller chunks cost time, never results
+ * (tests/test_memory_budget_gpu.py; profiles/r06_memory_budget.txt has the step time of config 2 at 8 / 16 / 38 GiB).  The
+ * RESIDENT set -- descriptors, keypoints, matches, per-pair state and results of the current list -- follows from the inputs and
+ * is not chunked; dsm_ctx_memory_footprint reports both.  Scratch already held beyond a new, smaller budget is released at once.
+ * bytes == 0 restores the defaults.  A budget too small for one pair's scratch still runs (a chunk is never shorter than one pair). */
+int dsm_ctx_set_memory_budget(dsm_ctx* ctx, uint64_t bytes);
+/* Device memory the context holds right now: *resident_bytes = images + the last calls' inputs / results / per-pair state,
+ * *scratch_bytes = the chunk scratch the budget governs.  Either pointer may be NULL. */
+int dsm_ctx_memory_footprint(const dsm_ctx* ctx, uint64_t* resident_bytes, uint64_t* scratch_bytes);
+
 /* What the device reports about itself (hipDeviceProp_t): used by bench.py to derive the roofline peaks from
  * the hardware instead of hard-coding them. */
 typedef struct dsm_device_info {
