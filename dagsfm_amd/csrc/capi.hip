@@ -47,6 +47,7 @@ static int fail(dsm_ctx* ctx, int code, const char* msg) {
 // for descriptors, k0_prepare converts the slot that just arrived), all device work on ctx->stream.  Buffers that are pinned
 // already (the shim's FeatureMatcherCache slabs) skip this and are copied where they lie.
 static const uint64_t kStageSlot = 16ull << 20;
+static const uint64_t kStageSmall = 1ull << 20;  // at and below: one plain copy (the staging machinery costs a leaf call more than it saves)
 static const unsigned kStageThreads = 8;  // (images that are cold in the host's caches: 4 threads read them at 8 GB/s, hot ones at 32 GB/s)
 
 static bool host_pointer_is_pinned(const void* ptr) {
@@ -64,6 +65,29 @@ static bool host_pointer_is_pinned(const void* ptr) {
 template <typename Fill, typename Arrived>
 static int staged_upload(dsm_ctx* ctx, uint64_t total, uint8_t* dev_dst, bool through_device_slot, Fill fill, Arrived arrived) {
   if (!total) return DSM_OK;
+  if (total <= kStageSmall) {
+    // a leaf call's two images (dsm_match_sift_features, dsm_estimate_two_view_geometry) or a handful of keypoints: no pinned slots,
+    // no device mirror of 32 MB each, no helper threads -- gather into one host buffer, one copy
+    std::vector<uint8_t> tmp;
+    try {
+      tmp.resize(total);
+    } catch (const std::exception&) {
+      return dsm_fail(ctx, DSM_ERR_HIP, "staged_upload: out of host memory");
+    }
+    fill(tmp.data(), 0, total);
+    uint8_t* dev = dev_dst;
+    if (through_device_slot) {
+      HIPCHK(ctx, ctx->d_stage.reserve(total));
+      dev = ctx->d_stage.as<uint8_t>();
+    }
+    HIPCHK(ctx, hipMemcpyAsync(dev, tmp.data(), total, hipMemcpyHostToDevice, ctx->stream));
+    if (through_device_slot) {
+      const int rc = arrived(dev, 0, total);
+      if (rc != DSM_OK) return rc;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (tmp is read until here)
+    return DSM_OK;
+  }
   if (!ctx->h_stage) HIPCHK(ctx, hipHostMalloc(&ctx->h_stage, 2 * kStageSlot, hipHostMallocDefault));
   for (hipEvent_t& e : ctx->stage_ev)
     if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -80,17 +104,24 @@ static int staged_upload(dsm_ctx* ctx, uint64_t total, uint8_t* dev_dst, bool th
       // equal shares of the piece, cut at 4 KB; the caller's thread takes the first
       const uint64_t share = ((end - begin + n_thr - 1) / n_thr + 4095) / 4096 * 4096;
       std::vector<std::thread> helpers;
+      struct JoinAll {  // whatever leaves this scope -- an exception of fill or of the vector included -- finds no joinable thread behind
+        std::vector<std::thread>& v;
+        ~JoinAll() {
+          for (std::thread& th : v)
+            if (th.joinable()) th.join();
+        }
+      } join_all{helpers};
+      helpers.reserve(n_thr);
       for (unsigned t = 1; t < n_thr; ++t) {
         const uint64_t b = begin + t * share, e = std::min(end, b + share);
         if (b >= end) break;
         try {
           helpers.emplace_back([&fill, host, begin, b, e]() { fill(host + (b - begin), b, e); });
-        } catch (const std::system_error&) {  // no thread to be had: this one does the share itself
+        } catch (const std::exception&) {  // no thread (or no memory for one) to be had: this one does the share itself
           fill(host + (b - begin), b, e);
         }
       }
       fill(host, begin, std::min(end, begin + share));
-      for (std::thread& th : helpers) th.join();
     }
     uint8_t* dev = through_device_slot ? ctx->d_stage.as<uint8_t>() + slot * kStageSlot : dev_dst + begin;
     HIPCHK(ctx, hipMemcpyAsync(dev, host, end - begin, hipMemcpyHostToDevice, ctx->stream));
@@ -608,6 +639,10 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
     k2.matches = nullptr;
     uint64_t total = 0;
     if (!cross) {
+      // (no pass 2: the gather interval [3, 4) is empty and the compaction below falls into the tail interval [4, 5), so that
+      // the four timers still sum to the call -- ADVICE r05)
+      HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 3], st));
+      HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 4], st));
       k2.counts = ctx->d_counts.as<uint32_t>() + c0;
       k2.offsets = ctx->d_offsets.as<uint64_t>() + c0;
       launch_k2(k2, nc, false, st);
@@ -620,8 +655,6 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
       k2.matches = ctx->d_matches.as<uint32_t>();
       launch_k2(k2, nc, true, st);
       HIPCHK(ctx, hipGetLastError());
-      HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 3], st));
-      HIPCHK(ctx, hipEventRecord(ctx->ev[ev_used + 4], st));
     } else {
       HIPCHK(ctx, ctx->d_ecnt.reserve(std::max<uint32_t>(nc, 1) * 4));
       HIPCHK(ctx, ctx->d_eoff.reserve(((size_t)nc + 1) * 8));
@@ -693,6 +726,8 @@ int dsm_match_pairs(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* pairs, const
   for (size_t k = 0; k + 5 < ev_used; k += 6) {
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[k + 4], ctx->ev[k + 5]));
+    ctx->k1t_ms += ms;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[k + 2], ctx->ev[k + 3]));  // the entry list of pass 2 (k2 + scan + the host's wait)
     ctx->k1t_ms += ms;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[k], ctx->ev[k + 1]));
     ctx->k1_ms += ms;

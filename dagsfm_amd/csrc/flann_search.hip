@@ -467,12 +467,17 @@ int flann_device_set_index(dsm_ctx* ctx, FlannDevice** slot, const dsm_flann_ind
   } else if (ix->algorithm == 2) {
     if (!ix->km_nodes || ix->n_km_nodes == 0 || !ix->pivots || ix->branching < 2 || ix->km_root < 0 || (uint32_t)ix->km_root >= ix->n_km_nodes)
       return dsm_fail(ctx, DSM_ERR_INVALID_ARGUMENT, "k-means index without nodes");
+    // (the offsets are 64-bit in the file and 32-bit on the device: sums are never formed -- an offset near 2^64 must not wrap past the
+    // check -- and everything that is narrowed is shown to fit first)
+    if (ix->n_pivot_floats < 128 || ix->n_pivot_floats / 128 > 0xffffffffull || ix->n_km_points > 0xffffffffull)
+      return dsm_fail(ctx, DSM_ERR_OUT_OF_RANGE, "k-means index: pivot / point arrays beyond 32-bit device offsets");
     km.resize(ix->n_km_nodes);
     for (uint32_t i = 0; i < ix->n_km_nodes; ++i) {
       const dsm_flann_km_node& nd = ix->km_nodes[i];
-      if (nd.pivot % 128 != 0 || nd.pivot + 128 > ix->n_pivot_floats) return dsm_fail(ctx, DSM_ERR_OUT_OF_RANGE, "k-means pivot offset");
+      if (nd.pivot % 128 != 0 || nd.pivot > ix->n_pivot_floats - 128) return dsm_fail(ctx, DSM_ERR_OUT_OF_RANGE, "k-means pivot offset");
       if (nd.num_childs == 0) {
-        if (nd.size < 0 || nd.first_point + (uint64_t)nd.size > ix->n_km_points || (nd.size > 0 && !ix->km_points)) return dsm_fail(ctx, DSM_ERR_OUT_OF_RANGE, "k-means leaf points");
+        if (nd.size < 0 || (uint64_t)nd.size > ix->n_km_points || nd.first_point > ix->n_km_points - (uint64_t)nd.size || (nd.size > 0 && !ix->km_points))
+          return dsm_fail(ctx, DSM_ERR_OUT_OF_RANGE, "k-means leaf points");
       } else {
         if (nd.num_childs != (uint32_t)ix->branching || (uint64_t)nd.first_child + nd.num_childs > ix->n_km_childs || !ix->km_childs)
           return dsm_fail(ctx, DSM_ERR_OUT_OF_RANGE, "k-means child list");

@@ -569,10 +569,12 @@ class SiftFeatureMatcherT {
       } catch (...) {
         self->writer_error_ = std::current_exception();
         // close the transaction without its rows and make the cache say what the database says again: the batch's
-        // pairs were marked as present above and must not be skipped by a later Match().  (In a caller's transaction the
-        // rows are the caller's to roll back: Match() rethrows this error from its Flush().)
+        // pairs were marked as present above and must not be skipped by a later Match().  In a caller's transaction the
+        // rows are the caller's to roll back (Match() rethrows this error from its Flush()) -- no ROLLBACK is issued here, but
+        // the marks are undone all the same: the cache re-reads which pairs the connection really holds (a caller
+        // who rolls back and calls Match() again found the never-written pairs still marked, and they were skipped).
         try {
-          if (!callers_transaction) cache->RollbackTransaction(open);
+          cache->RollbackTransaction(callers_transaction ? false : open);
         } catch (...) {
         }
       }

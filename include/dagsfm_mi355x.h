@@ -244,8 +244,9 @@ int dsm_get_match_kernel_time(dsm_ctx* ctx, double* total_ms, uint32_t* n_launch
 int dsm_get_match_resolve_time(dsm_ctx* ctx, double* total_ms);
 /* Same for the gathered second pass of the cross-check (k1_best_rows over the rows matches12 points at). */
 int dsm_get_match_gather_time(dsm_ctx* ctx, double* total_ms);
-/* Same for everything after pass 2 on the stream: its k1_resolve_index and the compaction of the mutual matches
- * (k2_entries + scan, the host's wait for the total included), so that the four match timers sum to the call. */
+/* Same for everything else on the stream: the entry list of pass 2 (k2 + scan between pass 1's resolve and pass 2), pass 2's
+ * k1_resolve_index and the compaction of the mutual matches (k2_entries + scan, the host's waits for the totals included) --
+ * without the cross-check: the compaction of the one-way matches -- so that the four match timers sum to the call in both modes. */
 int dsm_get_match_tail_time(dsm_ctx* ctx, double* total_ms);
 
 /* ------------------------------------------------------------------ verification */

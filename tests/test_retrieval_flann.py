@@ -377,5 +377,29 @@ def test_device_flann_index_upload_is_bounds_checked(dsm):
     assert try_upload([(5, 100.0, 1, 2), (3, 0.0, -1, -1), (64, 0.0, -1, -1)]) != 0  # leaf outside the vocabulary
     assert try_upload([(128, 100.0, 1, 2), (3, 0.0, -1, -1), (9, 0.0, -1, -1)]) != 0  # split dimension outside the descriptor
     assert try_upload([(5, 100.0, 1, 7), (3, 0.0, -1, -1), (9, 0.0, -1, -1)]) != 0   # child outside the node array
+    # k-means trees: 64-bit file offsets narrowed to 32-bit device offsets -- an offset near 2^64 must not wrap past the check
+    class KmNode(ctypes.Structure):
+        _fields_ = [("pivot", ctypes.c_uint64), ("radius", ctypes.c_float), ("variance", ctypes.c_float), ("size", ctypes.c_int32),
+                    ("first_child", ctypes.c_uint32), ("num_childs", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("first_point", ctypes.c_uint64)]
+
+    def try_km(pivot0, first_point1, size1=32):
+        # a root with two leaves of 32 points each
+        nodes = (KmNode * 3)(KmNode(pivot0, 1.0, 1.0, 64, 0, 2, 0, 0), KmNode(128, 1.0, 1.0, size1, 0, 0, 0, first_point1), KmNode(256, 1.0, 1.0, 32, 0, 0, 0, 32))
+        childs = (ctypes.c_int32 * 2)(1, 2)
+        points = (ctypes.c_uint64 * 64)(*range(64))
+        pivots = (ctypes.c_float * 384)()
+        ix = FlannIndex(algorithm=2, num_checks=8, num_words=64, branching=2, cb_index=0.2, km_root=0, n_km_nodes=3,
+                        km_nodes=ctypes.cast(nodes, ctypes.c_void_p), n_km_childs=2, km_childs=ctypes.cast(childs, ctypes.c_void_p),
+                        n_km_points=64, km_points=ctypes.cast(points, ctypes.c_void_p), n_pivot_floats=384, pivots=ctypes.cast(pivots, ctypes.c_void_p))
+        L = dsm._L
+        L.dsm_retrieval_set_flann_index.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        return L.dsm_retrieval_set_flann_index(dsm._h, ctypes.byref(ix))
+
+    assert try_km(0, 0) == 0
+    assert try_km(384, 0) != 0                            # one node past the pivot array
+    assert try_km(2 ** 64 - 128, 0) != 0                  # pivot + 128 wraps to 0
+    assert try_km(0, 2 ** 64 - 16) != 0                   # first_point + size wraps to 16
+    assert try_km(0, 40) != 0                             # 40 + 32 > 64 points
+    assert try_km(0, 0, size1=-1) != 0
     L = dsm._L
     assert L.dsm_retrieval_set_flann_index(dsm._h, None) == 0  # back to the exact search
