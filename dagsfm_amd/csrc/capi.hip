@@ -928,6 +928,7 @@ struct VerifyPlan {
   uint32_t replay_grid_mul = 1;
   bool tail_items = true;   // the tail of a round (<= lo_tail pairs queued) as an item pass; false: the inline tail of round 2
   bool item_mode = false;   // item passes from the start of every round (short pair lists)
+  uint32_t item_rounds = 0xffffffffu;  // ... of the first item_rounds rounds of a family only (later rounds: the chain)
 };
 
 #define LANECHK(L, call)                                              \
@@ -1018,7 +1019,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
           // plan.item_mode: item passes from the start of a round (short lists: every iteration of the chain is
           // latency-bound there); otherwise the chain, and item passes once <= lo_tail pairs are left in the queue.
           int mode = 0;
-          bool pass_items = plan.item_mode;
+          bool pass_items = plan.item_mode && round < plan.item_rounds;
           for (uint32_t cur = 0;; cur ^= 1u) {
             uint32_t* host_ctr = L.host_ctr;
             if (pass_items) {
@@ -1338,7 +1339,10 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     // item passes from the start of every round for short lists: 4 950 pairs 24.3 vs 28.5 ms, 15 593 pairs (1/8 of config 2)
     // 55.8 vs 57.5, 31 187 pairs level, 124 750 pairs 395 vs 366 (the speculative half of the items is throughput there)
     plan.item_mode = n_pairs <= 24000u;
-    if (const char* e = ctx->dbg("DSM_VERIFY_ITEM_MODE")) plan.item_mode = atoi(e) != 0;
+    if (const char* e = ctx->dbg("DSM_VERIFY_ITEM_MODE")) {  // 0: never, 1: every round, 1 + k: the first k rounds of a family only
+      plan.item_mode = atoi(e) != 0;
+      if (atoi(e) > 1) plan.item_rounds = (uint32_t)atoi(e) - 1u;
+    }
     HIPCHK(ctx, ctx->d_fam_state.reserve(std::max<size_t>(n_pairs, 1) * 3 * sizeof(FamState)));
     HIPCHK(ctx, ctx->d_sidx.reserve(tm * 4));
     HIPCHK(ctx, ctx->d_lo_inl.reserve(tm * 4));

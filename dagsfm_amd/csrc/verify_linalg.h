@@ -915,6 +915,9 @@ DSM_DEV bool pr_hessenberg_eigenvalues(double (&T)[N * N], int n, double (&re)[N
       if (i <= j + 1) norm += fabs(RT(i, j));  // entries outside n x n are zeros: + 0.0 changes nothing
   }
   bool failed = false;
+  // 2 x 2 blocks split off with exshift == 0 whose Givens step is still owed (bit I: the block of rows I - 1, I); see the note at
+  // the split below
+  unsigned pending = 0;
   if (norm != 0.0) {
     while (iu >= 0) {
       // il = the largest L <= iu with a negligible sub-diagonal entry (L, L-1), else 0
@@ -942,6 +945,22 @@ DSM_DEV bool pr_hessenberg_eigenvalues(double (&T)[N * N], int n, double (&re)[N
           }
         }
         iu--;
+        iter = 0;
+      } else if (il == iu - 1 && exshift == 0.0) {
+        // A 2 x 2 block splits off (RealSchur::splitOffTwoRows).  Its Givens step -- a square root, two divisions, the rotation of two
+        // rows and two columns: ~450 instructions -- touches the block itself and entries ABOVE it (rows < iu - 1 of its two columns),
+        // and nothing the iteration does afterwards reads or writes the block again (the window ends at iu - 2; the left reflectors'
+        // updates of the deflated columns stay in rows <= iu - 2, which never feed back).  In lockstep a wave paid those 450
+        // instructions in nearly every iteration, because SOME lane splits a block off (3.7 per polynomial x 64 lanes over ~32
+        // iterations: 14 400 of a wave's 66 500 instruction slots, tools/sim_roots_lanes.py).  So the step is OWED here (one bit) and
+        // paid after the loop, where all lanes take it together, on exactly the values it would have seen -- provided exshift is 0
+        // (it is, unless this lane took an exceptional shift: then the branch below runs the step at once, as before).  Same
+        // operations on the same operands: the block's four entries, hence its eigenvalues, are bit for bit the same.
+        pending |= 1u << iu;
+#pragma unroll
+        for (int I = 2; I < N; ++I)
+          if (I == iu) RT(I - 1, I - 2) = 0.0;
+        iu -= 2;
         iter = 0;
       } else if (il == iu - 1) {
         double a11 = 0.0, a22 = 0.0, a21 = 0.0, a12 = 0.0;  // (iu-1, iu-1), (iu, iu), (iu, iu-1), (iu-1, iu)
@@ -1200,6 +1219,62 @@ DSM_DEV bool pr_hessenberg_eigenvalues(double (&T)[N * N], int n, double (&re)[N
     }
   }
   if (failed) return false;
+  if (pending) {
+    // the owed Givens steps (exshift was 0 when each block split off: `+ zero` is the reference's `+= exshift`, kept for -0.0)
+    double zero = 0.0;
+    asm volatile("" : "+v"(zero));
+#pragma unroll
+    for (int I = 1; I < N; ++I) {
+      if ((pending >> I) & 1u) {
+        const double a11 = RT(I - 1, I - 1), a22 = RT(I, I), a21 = RT(I, I - 1), a12 = RT(I - 1, I);
+        const double p = 0.5 * (a11 - a22);
+        const double q = p * p + a21 * a12;
+        RT(I, I) += zero;
+        RT(I - 1, I - 1) += zero;
+        if (q >= 0.0) {
+          const double z = sqrt(fabs(q));
+          const double gp = (p >= 0.0) ? (p + z) : (p - z);
+          const double gq = a21;
+          double gc, gs;
+          if (gq == 0.0) {
+            gc = gp < 0.0 ? -1.0 : 1.0;
+            gs = 0.0;
+          } else if (gp == 0.0) {
+            gc = 0.0;
+            gs = gq < 0.0 ? 1.0 : -1.0;
+          } else if (fabs(gp) > fabs(gq)) {
+            const double t = gq / gp;
+            double u = sqrt(1.0 + t * t);
+            if (gp < 0.0) u = -u;
+            gc = 1.0 / u;
+            gs = -t * gc;
+          } else {
+            const double t = gp / gq;
+            double u = sqrt(1.0 + t * t);
+            if (gq < 0.0) u = -u;
+            gs = -1.0 / u;
+            gc = -t * gs;
+          }
+          const bool rotate = !(gc == 1.0 && -gs == 0.0);
+          if (rotate) {
+#pragma unroll
+            for (int c = I - 1; c <= I; ++c) {  // rows I-1, I with (gc, -gs)
+              const double xi = RT(I - 1, c), yi = RT(I, c);
+              RT(I - 1, c) = gc * xi + (-gs) * yi;
+              RT(I, c) = gs * xi + gc * yi;
+            }
+#pragma unroll
+            for (int r = I - 1; r <= I; ++r) {  // columns I-1, I with (gc, -gs): the block's own rows (the rows above never feed back)
+              const double xi = RT(r, I - 1), yi = RT(r, I);
+              RT(r, I - 1) = gc * xi + (-gs) * yi;
+              RT(r, I) = gs * xi + gc * yi;
+            }
+          }
+          RT(I, I - 1) = 0.0;
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < N; ++j) {
 #pragma unroll
