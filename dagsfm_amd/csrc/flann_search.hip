@@ -83,6 +83,7 @@ struct FlannSearchParams {
   uint32_t* overflow;     // number of queries whose heap would have passed heap_cap < num_words ...
   uint32_t* overflow_rows;  // ... and their rows (null: not recorded); such a query writes no result
   const uint32_t* row_list; // null, or the rows to search (the second pass over the overflowed queries); n_rows = its length
+  uint32_t* stats;          // null, or 16 counters of the group kernel (DSM_FLANN_STATS, check build): see flann_launch_kd_grp
 };
 
 namespace {
@@ -390,6 +391,210 @@ __global__ __launch_bounds__(64) void k_flann_search(const FlannSearchParams p) 
   }
 }
 
+#ifdef DSM_CHECK_BUILD
+// ------------------------------------------------------------------------------------------------ kd-trees, a 16-lane group per query (round 6)
+// MEASURED AND NOT ADOPTED -- check build only (DSM_FLANN_GROUP), kept as the A/B the round-5 verdict asked for with the counters that
+// say why (profiles/r06_flann_group_per_query.txt).  A query belongs to a GROUP of 16 lanes (one DPP row), four queries per wave: a tree
+// node, the `checked` word and the query byte vec[divfeat] (LDS) are read once per group, a leaf's word is split over the lanes (8 bytes,
+// two v_dot4 each, the sixteen integer partial sums added across the row: the float distance is the lane-per-query kernel's bit for
+// bit), every lane runs libstdc++'s heap code on the same addresses, the result set is kept redundantly in every lane.  Same visit
+// order, same heap order, same capacity semantics as k_flann_search<1>: identical ids and distances (tests/test_retrieval_flann.py
+// and tools/bench_flann_search.py passed with it as the default path of both builds before it moved here).
+// What the counters of this kernel say about the search itself (kd-trees x 4 over 65 536 words, 256 checks, per query): 1 305 tree nodes
+// visited, 256 leaves, 260 pops and 1 042 PUSHES, the branch heap reaching 1 168 entries -- more than 511 for 99.99 % of the queries.
+// So (1) the heap does not fit LDS at any useful residency: with 512 entries per query in LDS (the first form) all but 80 of 819 200
+// queries overflowed into the second pass (1.67 M searches/s); (2) with the heap in global memory, contiguous per query, a query is
+// ~7 000 DEPENDENT memory round trips (every heap level is one) of ~1.8 us each = 12.6 ms, and only 24 576 queries are in flight
+// (96 per CU): 2.05 M searches/s against the lane-per-query kernel's 3.6 M/s, which keeps 131 072 queries in flight and is bound by L2
+// sector throughput (~13 000 sector accesses per query).  The search is a pointer chase through a priority queue: its rate is
+// queries-in-flight / latency, and a group spends 16 lanes on one chase.  10 M searches/s would need ~2 000 round trips per query with
+// 20 000 queries in flight, i.e. the whole heap (9 KB) in LDS for each of them: 180 MB.
+#define FLANN_GRP 16u
+namespace {
+struct LdsHeap {  // BranchHeap over an LDS array (all lanes of the group run the same code on the same addresses)
+  uint2* base;
+  uint32_t cap, count;
+  bool flann_cap;
+  __device__ __forceinline__ uint2 at(uint32_t e) const { return base[e]; }
+  __device__ __forceinline__ void put(uint32_t e, uint2 v) { base[e] = v; }
+  __device__ __forceinline__ void push_from(uint32_t hole, uint32_t top, uint2 value) {  // std::__push_heap
+    const float vk = __uint_as_float(value.y);
+    while (hole > top) {
+      const uint32_t parent = (hole - 1) / 2;
+      const uint2 pv = at(parent);
+      if (!(vk < __uint_as_float(pv.y))) break;
+      put(hole, pv);
+      hole = parent;
+    }
+    put(hole, value);
+  }
+  __device__ __forceinline__ bool insert(int32_t node, float mindist) {
+    if (count == cap) return flann_cap;
+    push_from(count, 0u, make_uint2((uint32_t)node, __float_as_uint(mindist)));
+    ++count;
+    return true;
+  }
+  __device__ __forceinline__ void pop_min(int32_t* node, float* mindist) {  // count > 0
+    const uint2 top = at(0);
+    *node = (int32_t)top.x;
+    *mindist = __uint_as_float(top.y);
+    --count;
+    if (count == 0) return;
+    const uint2 value = at(count);
+    const uint32_t len = count;
+    uint32_t hole = 0, second = 0;
+    while (second < (len - 1) / 2) {
+      second = 2 * (second + 1);
+      const uint2 a = at(second), b = at(second - 1);
+      uint2 pick = a;
+      if (__uint_as_float(b.y) < __uint_as_float(a.y)) {
+        --second;
+        pick = b;
+      }
+      put(hole, pick);
+      hole = second;
+    }
+    if ((len & 1u) == 0u && second == (len - 2) / 2) {
+      second = 2 * (second + 1);
+      put(hole, at(second - 1));
+      hole = second - 1;
+    }
+    push_from(hole, 0u, value);
+  }
+};
+__device__ __forceinline__ int row16_sum(int v) {  // the sum over the 16 lanes of the group, in every lane
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+}  // namespace
+
+__global__ __launch_bounds__(64) void k_flann_search_kd_grp(const FlannSearchParams p) {
+  __shared__ uint32_t s_q[64 / FLANN_GRP][32];  // the groups' queries (s8 dwords): vec[divfeat] is a dynamic index
+  const int lane = threadIdx.x;
+  const uint32_t g = (uint32_t)lane / FLANN_GRP, gl = (uint32_t)lane % FLANN_GRP;
+  const uint32_t n_groups = gridDim.x * (64u / FLANN_GRP);
+  const uint32_t G = blockIdx.x * (64u / FLANN_GRP) + g;
+  LdsHeap heap;
+  heap.base = p.heap + (size_t)G * p.heap_cap;  // (contiguous per query: an access of the group is ONE address)
+  heap.cap = p.heap_cap;
+  heap.flann_cap = p.heap_cap >= p.num_words;
+  uint32_t* checked = p.checked + (size_t)G * p.checked_words;  // (this kernel's layout: a query's bitset and list are contiguous)
+  uint32_t* clist = p.checked_list + (size_t)G * p.list_cap;
+  ResultSet rs;
+  const int k = (int)p.k;
+  const int max_check = p.num_checks;
+  for (uint64_t slot = G; slot < p.n_rows; slot += n_groups) {
+    const uint64_t row = p.row_list ? (uint64_t)p.row_list[slot] : slot;
+    const bool has_query = !p.row_img || p.row_img[row] >= 0;
+    // this lane's 8 bytes of the query
+    const int2 qv = reinterpret_cast<const int2*>(p.desc + (size_t)row * 128)[gl];
+    __syncthreads();  // (one-wave workgroup: a fence; the previous query's readers of s_q are this wave's earlier instructions)
+    s_q[g][2 * gl] = (uint32_t)qv.x;
+    s_q[g][2 * gl + 1] = (uint32_t)qv.y;
+    __syncthreads();
+    const int qn = row16_sum(__builtin_amdgcn_sdot4(qv.y, qv.y, __builtin_amdgcn_sdot4(qv.x, qv.x, 0, false), false));
+    rs.clear(k);
+    heap.count = 0;
+    bool lost = false;
+    uint32_t st_nodes = 0, st_pops = 0, st_push = 0, st_maxheap = 0;
+    if (has_query) {
+      uint32_t n_list = 0;
+      bool list_lost = false;
+      int check_count = 0;
+      uint32_t root_i = 0;
+      for (;;) {
+        int32_t node;
+        float mindist;
+        if (root_i < p.n_kd_roots) {
+          node = p.kd_roots[root_i++];
+          mindist = 0.0f;
+        } else {
+          if (heap.count == 0) break;
+          heap.pop_min(&node, &mindist);
+          ++st_pops;
+          if (!(check_count < max_check || !rs.full())) break;
+        }
+        for (;;) {  // searchLevel; the recursion into the best child as a loop
+          if (rs.worst < mindist) break;
+          ++st_nodes;
+          const dsm_flann_kd_node nd = p.kd_nodes[node];
+          if (nd.child1 < 0 && nd.child2 < 0) {
+            const uint32_t index = (uint32_t)nd.divfeat;
+            const uint32_t cell = checked[index >> 5];
+            const uint32_t bit = 1u << (index & 31u);
+            if ((cell & bit) != 0u || (check_count >= max_check && rs.full())) break;
+            checked[index >> 5] = cell | bit;
+            if (n_list < p.list_cap)
+              clist[n_list] = index;
+            else
+              list_lost = true;
+            ++n_list;
+            ++check_count;
+            const int2 wv = reinterpret_cast<const int2*>(p.words + (size_t)index * 128)[gl];
+            const int dot = row16_sum(__builtin_amdgcn_sdot4(qv.y, wv.y, __builtin_amdgcn_sdot4(qv.x, wv.x, 0, false), false));
+            const int dist = qn + p.wnorm[index] - 2 * dot;
+            rs.add((float)dist, (int32_t)index);
+            break;
+          }
+          const uint32_t word = s_q[g][nd.divfeat >> 2];
+          const uint32_t val = ((word >> (8 * (nd.divfeat & 3))) & 0xffu) ^ 0x80u;
+          const float diff = (float)val - nd.divval;
+          const int32_t best_child = diff < 0 ? nd.child1 : nd.child2;
+          const int32_t other_child = diff < 0 ? nd.child2 : nd.child1;
+          const float new_distsq = mindist + diff * diff;
+          if (new_distsq * 1.0f < rs.worst || !rs.full()) {
+            if (!heap.insert(other_child, new_distsq)) lost = true;
+            ++st_push;
+            st_maxheap = heap.count > st_maxheap ? heap.count : st_maxheap;
+          }
+          node = best_child;
+        }
+      }
+      if (p.stats && gl == 0) {  // (debug) [0] queries [1] nodes visited [2] leaves checked [3] pops [4] pushes [5] max heap; [6..11] queries whose heap passed 32 / 64 / 128 / 256 / 384 / 511
+        atomicAdd(p.stats + 0, 1u);
+        atomicAdd(p.stats + 1, st_nodes);
+        atomicAdd(p.stats + 2, (uint32_t)check_count);
+        atomicAdd(p.stats + 3, st_pops);
+        atomicAdd(p.stats + 4, st_push);
+        atomicMax(p.stats + 5, st_maxheap);
+        const uint32_t lim[6] = {32, 64, 128, 256, 384, 511};
+        for (int b = 0; b < 6; ++b)
+          if (st_maxheap > lim[b]) atomicAdd(p.stats + 6 + b, 1u);
+      }
+      // the bitset goes back to zero for the group's next query
+      if (list_lost) {
+        for (uint32_t c = gl; c < p.checked_words; c += FLANN_GRP) checked[c] = 0u;
+      } else {
+        for (uint32_t c = gl; c < n_list; c += FLANN_GRP) checked[clist[c] >> 5] = 0u;
+      }
+      __threadfence_block();
+    }
+    if (lost && gl == 0) {  // the LDS heap was too small for this query: no result from this pass
+      const uint32_t at = atomicAdd(p.overflow, 1u);
+      if (p.overflow_rows) p.overflow_rows[at] = (uint32_t)row;
+    }
+    if (!lost && gl < p.out_stride) {
+      // lane j of the group writes entry j (the result set is the same in every lane)
+      float dj = 0.0f;
+      int32_t ij = FLANN_INVALID;
+#pragma unroll
+      for (int j = 0; j < FLANN_K_MAX; ++j) {
+        if ((uint32_t)j == gl && has_query && j < k && j < rs.count) {
+          dj = rs.d[j];
+          ij = rs.i[j];
+        }
+      }
+      p.out_ids[(size_t)row * p.out_stride + gl] = ij;
+      if (p.out_dists) p.out_dists[(size_t)row * p.out_stride + gl] = dj;
+    }
+  }
+}
+
+#endif  // DSM_CHECK_BUILD
+
 __global__ void k_flann_word_norms(const int8_t* words, uint32_t n, int32_t* out) {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n) return;
@@ -410,7 +615,10 @@ struct FlannDevice {
   float cb_index = 0.f;
   uint32_t num_words = 0, n_kd_roots = 0;
   DevBuf kd_nodes, kd_roots, km_nodes, km_childs, km_points, pivots, wnorm;
-  DevBuf heap, checked, clist, domain, overflow, overflow_rows, q_s8, q_u8, out_ids, out_dists;
+  DevBuf heap, checked, clist, domain, overflow, overflow_rows, overflow_rows2, q_s8, q_u8, out_ids, out_dists;
+  DevBuf stats;
+  DevBuf checked_g, clist_g;  // the group-per-query kernel's bitsets and lists ([group][word]: its own layout)
+  uint32_t n_groups = 0;
   uint32_t n_lanes = 0;
   double last_ms = 0.0;
   uint32_t last_retried = 0;  // queries of the last search that took the second pass
@@ -420,7 +628,8 @@ struct FlannDevice {
 void flann_device_destroy(FlannDevice* f) {
   if (!f) return;
   for (DevBuf* b : {&f->kd_nodes, &f->kd_roots, &f->km_nodes, &f->km_childs, &f->km_points, &f->pivots, &f->wnorm, &f->heap, &f->checked, &f->clist,
-                    &f->domain, &f->overflow, &f->overflow_rows, &f->q_s8, &f->q_u8, &f->out_ids, &f->out_dists})
+                    &f->domain, &f->overflow, &f->overflow_rows, &f->overflow_rows2, &f->checked_g, &f->clist_g, &f->stats, &f->q_s8, &f->q_u8, &f->out_ids,
+                    &f->out_dists})
     b->release();
   if (f->ev0) (void)hipEventDestroy(f->ev0);
   if (f->ev1) (void)hipEventDestroy(f->ev1);
@@ -609,6 +818,88 @@ static int flann_launch(dsm_ctx* ctx, FlannDevice* f, const int8_t* d_words_s8, 
   return DSM_OK;
 }
 
+#ifdef DSM_CHECK_BUILD
+// check build, DSM_FLANN_GROUP: the kd-trees' first pass as a 16-lane group per query (k_flann_search_kd_grp; measured slower)
+static int flann_launch_kd_grp(dsm_ctx* ctx, FlannDevice* f, const int8_t* d_words_s8, const int8_t* desc, const int32_t* row_img, uint64_t n_items,
+                               uint32_t k, int32_t* out_ids, float* out_dists, uint32_t out_stride, uint32_t* overflow_rows, hipStream_t st,
+                               uint32_t* overflow_out) {
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+  const uint32_t per_wave = 64u / FLANN_GRP;
+  const uint32_t checked_words = (f->num_words + 31) / 32;
+  const uint32_t list_cap = std::min<uint32_t>(f->num_words, (uint32_t)std::min<int64_t>((int64_t)f->num_checks + 64, 1 << 20));
+  const uint32_t heap_cap = std::min<uint32_t>(f->num_words, FLANN_HEAP_CAP);
+  // resident waves: 24 per CU (78 VGPRs), fewer when the heaps and bitsets would pass 4 GiB
+  uint64_t blocks = std::min<uint64_t>((n_items + per_wave - 1) / per_wave, (uint64_t)cus * 24);
+  while (blocks > 1 && blocks * per_wave * (((uint64_t)checked_words + list_cap) * 4 + (uint64_t)heap_cap * 8) > (4ull << 30)) blocks = (blocks + 1) / 2;
+  const uint32_t n_groups = (uint32_t)blocks * per_wave;
+  FCHK(ctx, f->heap.reserve((size_t)heap_cap * n_groups * 8));
+  {
+    const size_t bytes = (size_t)checked_words * n_groups * 4;
+    const bool fresh = f->checked_g.cap < bytes || f->n_groups != n_groups;
+    FCHK(ctx, f->checked_g.reserve(bytes));
+    if (fresh) FCHK(ctx, hipMemsetAsync(f->checked_g.p, 0, f->checked_g.cap, st));  // every query leaves its group's bits cleared again
+    FCHK(ctx, f->clist_g.reserve((size_t)std::max<uint32_t>(list_cap, 1) * n_groups * 4));
+    f->n_groups = n_groups;
+  }
+  FCHK(ctx, f->overflow.reserve(4));
+  FCHK(ctx, hipMemsetAsync(f->overflow.p, 0, 4, st));
+  FlannSearchParams p = FlannSearchParams();
+  p.algorithm = 1;
+  p.num_checks = f->num_checks;
+  p.num_words = f->num_words;
+  p.kd_nodes = f->kd_nodes.as<dsm_flann_kd_node>();
+  p.kd_roots = f->kd_roots.as<int32_t>();
+  p.n_kd_roots = f->n_kd_roots;
+  p.words = d_words_s8;
+  p.wnorm = f->wnorm.as<int32_t>();
+  p.desc = desc;
+  p.row_img = row_img;
+  p.n_rows = n_items;
+  p.k = k;
+  p.heap = f->heap.as<uint2>();
+  p.heap_cap = heap_cap;
+  p.checked = f->checked_g.as<uint32_t>();
+  p.checked_words = checked_words;
+  p.checked_list = f->clist_g.as<uint32_t>();
+  p.list_cap = list_cap;
+  p.out_ids = out_ids;
+  p.out_dists = out_dists;
+  p.out_stride = out_stride;
+  p.overflow = f->overflow.as<uint32_t>();
+  p.overflow_rows = overflow_rows;
+  p.row_list = nullptr;
+  p.stats = nullptr;
+#ifdef DSM_CHECK_BUILD
+  if (ctx->dbg("DSM_FLANN_STATS")) {
+    FCHK(ctx, f->stats.reserve(64));
+    FCHK(ctx, hipMemsetAsync(f->stats.p, 0, 64, st));
+    p.stats = f->stats.as<uint32_t>();
+  }
+#endif
+  FCHK(ctx, hipEventRecord(f->ev0, st));
+  hipLaunchKernelGGL(k_flann_search_kd_grp, dim3((uint32_t)blocks), dim3(64), 0, st, p);
+  FCHK(ctx, hipGetLastError());
+  FCHK(ctx, hipEventRecord(f->ev1, st));
+  FCHK(ctx, hipMemcpyAsync(overflow_out, f->overflow.p, 4, hipMemcpyDeviceToHost, st));
+  FCHK(ctx, hipStreamSynchronize(st));
+  float ms = 0.f;
+  FCHK(ctx, hipEventElapsedTime(&ms, f->ev0, f->ev1));
+  f->last_ms += ms;
+#ifdef DSM_CHECK_BUILD
+  if (p.stats) {
+    uint32_t h[16];
+    FCHK(ctx, hipMemcpy(h, f->stats.p, 64, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[flann kd grp] queries %u  nodes/query %.1f  leaves/query %.1f  pops/query %.1f  pushes/query %.1f  max heap %u  heap > 32/64/128/256/384/511: %u %u %u %u %u %u  overflow %u  %.1f ms\n",
+            h[0], (double)h[1] / std::max(h[0], 1u), (double)h[2] / std::max(h[0], 1u), (double)h[3] / std::max(h[0], 1u), (double)h[4] / std::max(h[0], 1u), h[5], h[6], h[7],
+            h[8], h[9], h[10], h[11], *overflow_out, ms);
+  }
+#endif
+  return DSM_OK;
+}
+
+#endif
+
 // Searches the s8 rows `desc` (padding rows: row_img < 0) for their k words: out_ids [rows][out_stride] on the device.
 // Two passes at most: all queries with FLANN_HEAP_CAP heap entries per lane at full residency; the queries whose heap needed
 // more (deep, unbalanced trees push one branch per level and descent) once more with FLANN's own capacity (num_words, at most
@@ -622,10 +913,28 @@ int flann_device_search(dsm_ctx* ctx, FlannDevice* f, const int8_t* d_words_s8, 
   FCHK(ctx, f->overflow_rows.reserve((size_t)n_rows * 4));
   uint32_t overflow = 0;
   f->last_ms = 0.0;
-  int rc = flann_launch(ctx, f, d_words_s8, desc, row_img, n_rows, nullptr, k, out_ids, out_dists, out_stride, std::min<uint32_t>(f->num_words, FLANN_HEAP_CAP),
-                        f->overflow_rows.as<uint32_t>(), st, &overflow);
+  int rc;
+  const uint32_t* todo = nullptr;  // the rows still to search (nullptr: all of them)
+  uint64_t n_todo = n_rows;
+#ifdef DSM_CHECK_BUILD
+  if (f->algorithm == 1 && ctx->dbg("DSM_FLANN_GROUP") != nullptr) {
+    // the A/B: kd-trees as a 16-lane group per query; the queries whose heap needed more than the first pass's capacity go on to the
+    // lane-per-query kernel below
+    rc = flann_launch_kd_grp(ctx, f, d_words_s8, desc, row_img, n_rows, k, out_ids, out_dists, out_stride, f->overflow_rows.as<uint32_t>(), st, &overflow);
+    if (rc != DSM_OK) return rc;
+    f->last_retried = overflow;
+    if (!overflow) return DSM_OK;
+    FCHK(ctx, f->overflow_rows2.reserve((size_t)overflow * 4));
+    FCHK(ctx, hipMemcpyAsync(f->overflow_rows2.p, f->overflow_rows.p, (size_t)overflow * 4, hipMemcpyDeviceToDevice, st));
+    todo = f->overflow_rows2.as<uint32_t>();
+    n_todo = overflow;
+    overflow = 0;
+  }
+#endif
+  rc = flann_launch(ctx, f, d_words_s8, desc, row_img, n_todo, todo, k, out_ids, out_dists, out_stride, std::min<uint32_t>(f->num_words, FLANN_HEAP_CAP),
+                    f->overflow_rows.as<uint32_t>(), st, &overflow);
   if (rc != DSM_OK) return rc;
-  f->last_retried = overflow;
+  if (!todo) f->last_retried = overflow;
   if (overflow) {
     const uint32_t n_retry = overflow;
     rc = flann_launch(ctx, f, d_words_s8, desc, row_img, n_retry, f->overflow_rows.as<uint32_t>(), k, out_ids, out_dists, out_stride,
