@@ -18,7 +18,8 @@
 //              context already holds; against a k-means pivot (float) the functor's own order: four differences, their
 //              squares summed left to right, one addition into the running sum (-ffp-contract=off: no FMA)
 //
-// Per-lane state that does not fit registers lives in global memory, lane-interleaved (element e of lane L at [e][L]): the
+// Per-lane state that does not fit registers lives in global memory -- the `checked` bitset, its list and the k-means domain
+// distances lane-interleaved (element e of lane L at [e][L]), the branch heap contiguous per lane -- : the
 // branch heap (FLANN sizes it num_words and drops inserts when full: the same here up to FLANN_HEAP_CAP entries; a lane that
 // would need more raises `overflow` and the call fails -- never a silent difference), the `checked` bitset with the list of
 // set bits (cleared bit by bit after the query), the k-means domain distances.  The query's 128 bytes sit in registers
@@ -222,8 +223,11 @@ __global__ __launch_bounds__(64) void k_flann_search(const FlannSearchParams p) 
   const int lane = threadIdx.x;
   const uint32_t L = blockIdx.x * 64u + (uint32_t)lane;
   BranchHeap heap;
-  heap.base = p.heap + L;
-  heap.stride = p.n_lanes;
+  // a lane's heap is CONTIGUOUS (round 6: the two children of a node share a 64-byte sector, the top three levels sit in one; the
+  // lane-interleaved layout of round 5 -- entry e of lane L at [e][L] -- only coalesces while the lanes are at the same entry:
+  // kd-trees 3.65 -> 3.84 M searches/s, k-means 3.52 -> 3.90, profiles/r06_flann_group_per_query.txt)
+  heap.base = p.heap + (size_t)L * p.heap_cap;
+  heap.stride = 1;
   heap.cap = p.heap_cap;
   heap.flann_cap = p.heap_cap >= p.num_words;
   ResultSet rs;
