@@ -160,10 +160,12 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--pairs", default="exhaustive", help="exhaustive | knn:K (K pseudo-neighbours per image from a seeded "
                                                           "kNN over the camera centres, id1<id2 dedupe; SURVEY 8d config 4)")
-    ap.add_argument("--cut", default="interleaved", choices=["contiguous", "interleaved"],
+    ap.add_argument("--cut", default="contiguous", choices=["contiguous", "interleaved"],
                     help="how the pair list is cut between the ranks (and by --shard-of): one contiguous cost-balanced stretch per rank, or "
                          "blocks of 256 pairs dealt out round-robin / heaviest-first (sharding.interleaved_parts): every rank a uniform sample "
-                         "of the list")
+                         "of the list, at the price of putting the gathered results back into list order (1.5 - 1.8 ms at config 2).  On the "
+                         "synthetic exhaustive list the two have the same slowest shard (profiles/r06_shard_sweep_config2.txt), so the default "
+                         "stays the cut without a reorder")
     ap.add_argument("--shard-of", type=int, default=1, help="run only one 1/S of the pair list: one GPU's shard of an S-GPU config")
     ap.add_argument("--shard-index", type=int, default=0, help="which of the --shard-of shards (0-based): tools/shard_sweep.py runs them all")
     ap.add_argument("--outlier-frac", type=float, default=0.2,
