@@ -1913,6 +1913,49 @@ DSM_DEV void exact_support(const double* M, int n, bool in_lds, const double* sp
   }
 }
 
+// exact_support of ONE model by a QUAD of lanes (round 6, k_score_needed): lane ql of the quad computes the residuals of the points
+// i = 4 j + ql, and all four lanes walk the in-order sum together -- the quad's residuals are read in index order through DPP
+// quad_perm broadcasts, a point that is no inlier contributes + 0.0 (exact: the sum is a sum of squares, never - 0.0 before an inlier
+// made it positive) -- so count and residual_sum are bit for bit those of the one-lane walk (support_measurement.cc:43-48), at a
+// quarter of its residual arithmetic per lane.  Every lane of the quad returns the same (cnt, sum).
+template <int K>
+DSM_DEV double quad_bcast_f64(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);  // quad_perm:[K, K, K, K]
+  const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(u & 0xffffffffull), ctrl, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(u >> 32), ctrl, 0xf, 0xf, true);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int FAM>
+DSM_DEV void exact_support_quad(const double* M, int n, bool in_lds, const double* spts, const double* gpts, double max_residual, int lane, int& cnt,
+                                double& sum) {
+  const int ql = lane & 3;
+  cnt = 0;
+  sum = 0.0;
+  for (int base = 0; base < n; base += 4) {
+    const int i = base + ql;
+    double r = 0.0;
+    bool in = false;
+    if (i < n) {
+      double q[4];
+      if (in_lds) {  // (two branches, not one selected pointer: that would compile to flat loads)
+        for (int k = 0; k < 4; ++k) q[k] = spts[(size_t)i * 4 + k];
+      } else {
+        for (int k = 0; k < 4; ++k) q[k] = gpts[(size_t)i * 4 + k];
+      }
+      r = fam_residual<FAM>(M, q);
+      in = r <= max_residual;
+    }
+    const double a = in ? r : 0.0;
+    sum += quad_bcast_f64<0>(a);
+    sum += quad_bcast_f64<1>(a);
+    sum += quad_bcast_f64<2>(a);
+    sum += quad_bcast_f64<3>(a);
+    const unsigned long long bal = __ballot(in);
+    cnt += __popcll((bal >> (lane & ~3)) & 0xfull);
+  }
+}
+
 template <int FAM>
 __global__ __launch_bounds__(64, 8) void k_score(const VerifyParams p) {
   typedef Fam<FAM> F;
@@ -2513,15 +2556,39 @@ __global__ __launch_bounds__(64, 8) void k_score_needed(const VerifyParams p) {
                                 image_to_world_threshold(p.cams[p.pairs[2 * pi + 1]], p.opt.max_error)) / 2;
       max_residual = max_error * max_error;
     }
-    for (int base = 0; base < n_list; base += 64) {
-      if (base + lane < n_list) {
-        const int slot = list[base + lane];
+    // the listed slots: a lane per slot while at least 48 are left (a full wave's walk: ~46 000 cycles for up to 64 slots), then a QUAD
+    // of lanes per slot, sixteen slots per trip (~14 000 cycles each).  A pair of config 2 lists 15 - 20 of its slots: a lane per slot
+    // left three quarters of the wave idle through a 256-point walk (exact_support_quad's note); at a 0.25 inlier ratio the lists
+    // are long and the full-wave walk is the cheaper one.
+    int done = 0;
+    for (; n_list - done >= 48; done += 64) {
+      if (done + lane < n_list) {
+        const int slot = list[done + lane];
         const double* gm = p.models + (size_t)pl * p.batch * F::MAXM * 9 + (size_t)slot * 9;
         double M[9];
         for (int k = 0; k < 9; ++k) M[k] = gm[k];
         int cnt;
         double sum;
         exact_support<FAM>(M, n, in_lds, spts, gpts, max_residual, cnt, sum);
+        if (p.score_prefilter & 4) {  // lower bound <= exact count <= upper bound, or the margins of k_prescore are wrong
+          const int ub = counts[slot], lb = reinterpret_cast<const int32_t*>(sums + slot)[0];
+          if (cnt < lb || cnt > ub) atomicAdd(p.active_count + 14, 1u);
+        }
+        counts[slot] = cnt;
+        sums[slot] = sum;
+      }
+    }
+    for (int base = done; base < n_list; base += 16) {
+      const int e = base + (lane >> 2);
+      const bool on = e < n_list;
+      const int slot = list[on ? e : base];
+      const double* gm = p.models + (size_t)pl * p.batch * F::MAXM * 9 + (size_t)slot * 9;
+      double M[9];
+      for (int k = 0; k < 9; ++k) M[k] = gm[k];
+      int cnt;
+      double sum;
+      exact_support_quad<FAM>(M, n, in_lds, spts, gpts, max_residual, lane, cnt, sum);
+      if (on && (lane & 3) == 0) {
         if (p.score_prefilter & 4) {  // lower bound <= exact count <= upper bound, or the margins of k_prescore are wrong
           const int ub = counts[slot], lb = reinterpret_cast<const int32_t*>(sums + slot)[0];
           if (cnt < lb || cnt > ub) atomicAdd(p.active_count + 14, 1u);
