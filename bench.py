@@ -142,7 +142,7 @@ def profile_figures(root, images, feats, n_pairs, verify_too):
                                 "all_kernels_ms_per_step": sm.get("all_kernels_ms_per_step"),
                                 "executed_fp64_tflops_over_all": sm.get("executed_fp64_tflops_over_all"),
                                 "executed_frac_over_all": sm.get("executed_frac_over_all"),
-                                "scoring_kernels_frac": sm.get("scoring_kernels_executed_frac"),
+                                "scoring_kernels_frac": sm.get("scoring_kernels_executed_frac"), "scoring_kernels_valu_issue": sm.get("scoring_kernels_valu_issue"),
                                 "top5_ms_execfrac_laneutil": {k: [v.get("ms_per_step"), v.get("executed_frac"), v.get("lane_util")] for k, v in ks}}
     if stale:
         fp["stale"] = len(set(stale))  # committed collections of OTHER sources than this tree's: refused

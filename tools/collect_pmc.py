@@ -107,6 +107,8 @@ def summarize_verify(res):
     res["summary"] = {"kernels": dict(sorted(rows.items(), key=lambda kv: -kv[1]["ms_per_step"])),
                       "scoring_kernels_ms_per_step": sc_ms,
                       "scoring_kernels_executed_frac": (sum(r["executed_frac"] * r["ms_per_step"] for r in sc) / sc_ms) if sc_ms else None,
+                      # (the bound steps classify in PACKED f32 since rounds 5 / 6: the FP64 counters do not see that work, the issue rate does)
+                      "scoring_kernels_valu_issue": (sum(r["valu_issue_util"] * r["ms_per_step"] for r in sc) / sc_ms) if sc_ms else None,
                       "all_kernels_ms_per_step": total_ms,
                       "executed_fp64_tflops_over_all": total_flops / total_ms if total_ms else None,
                       "executed_frac_over_all": total_flops / total_ms * 1e12 / fp64_peak if total_ms else None,
