@@ -55,7 +55,8 @@ def _round_floats(x, sig=6):
 
 
 # keys that only the --dump-line file carries
-LONG_FORM_ONLY = ("peak_source", "sample_note", "top5_ms_execfrac_laneutil", "ranks_seen_by_process_group", "stale_files", "side_pose_max_rel")
+LONG_FORM_ONLY = ("peak_source", "sample_note", "top5_ms_execfrac_laneutil", "ranks_seen_by_process_group", "stale_files", "side_pose_max_rel",
+                  "source_hash", "executed_fp64_tflops_over_all", "traffic_file", "avg_launch_ms")
 
 
 def _drop_notes(x):

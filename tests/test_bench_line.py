@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _stub_result():
     """A full-size result: the long form of a real round-6 run of the driver's command (every key the bench emits, real
     magnitudes), with `from_profiles` as a FRESH pair of counter collections would fill it."""
-    out = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_default_first_long.json")))
+    out = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_default_long.json")))
     out["from_profiles"] = {
         "k1": {"file": "profiles/r06_k1_pmc.json", "commit": "0123abc", "source_hash": "0123456789ab", "hbm_bytes_per_launch": 91181200000.0,
                "mfma_i8_insts_per_launch": 8809640000.0, "executed_frac_at_this_runs_time": 0.568622},
@@ -47,7 +47,8 @@ def test_line_fits_and_has_the_contract_keys(tmp_path):
     assert "note" not in d["roofline"] and "note" in json.load(open(dump))["roofline"]
     # figures read from committed files are labelled as such, with the file they came from, its commit and the hash of its sources
     for k in ("k1", "verify"):
-        assert d["from_profiles"][k]["file"].startswith("profiles/") and d["from_profiles"][k]["commit"] and d["from_profiles"][k]["source_hash"]
+        assert d["from_profiles"][k]["file"].startswith("profiles/") and d["from_profiles"][k]["commit"]
+        assert json.load(open(dump))["from_profiles"][k]["source_hash"]  # (long form: the hash bench.py compared with this tree's sources)
     assert "top5_ms_execfrac_laneutil" not in d["from_profiles"]["verify"]          # long form only
     assert len(json.load(open(dump))["from_profiles"]["verify"]["top5_ms_execfrac_laneutil"]) == 5
     # the timed graph held against the oracle, in the line, and the side measurements with theirs
