@@ -2926,7 +2926,7 @@ __global__ __launch_bounds__(64, 8) void k_prescore_compact(const VerifyParams p
 // tools/check_score_bounds.py (DSM_SCORE_PREFILTER=check) holds every slot's exact count against [lower, upper]; DSM_SCORE_PREFILTER=33
 // (check build) runs the pure FP64 k_prescore_compact instead.
 template <int FAM>
-__global__ __launch_bounds__(64, 6) void k_prescore_compact2(const VerifyParams p) {
+__global__ __launch_bounds__(64, 4) void k_prescore_compact2(const VerifyParams p) {  // (LDS -- points + lists, ~11 KB -- allows ~3.5 waves per SIMD anyway; at 6 the stretch loop spills)
   typedef Fam<FAM> F;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ uint16_t s_map[64];
@@ -3032,11 +3032,17 @@ __global__ __launch_bounds__(64, 6) void k_prescore_compact2(const VerifyParams 
         k_in = (float)(0.765625 * T * (1.0 - 0x1p-8)) * 0.9999f;       // rounded down
       }
     }
-    int cnt = 0;
-    if (has_model) {
-      const dsm_f32x2 f0 = pk2(Ff[0]), f1 = pk2(Ff[1]), f2 = pk2(Ff[2]), f3 = pk2(Ff[3]), f4 = pk2(Ff[4]), f5 = pk2(Ff[5]), f6 = pk2(Ff[6]), f7 = pk2(Ff[7]),
-                      f8 = pk2(Ff[8]), ko = pk2(k_out), ki = pk2(k_in);
-      for (int j = 0; j < npair; ++j) {
+    // The WAVE walks the points in stretches: the packed-f32 loop runs until some lane's list of band points is about to fill up (or to
+    // the end), then all lanes work their lists off in FP64 together and the loop goes on where it stopped.  (The first form redid ALL
+    // points of a lane in FP64 once its list overflowed: with the ~500-match pairs of configs[4] -- 8 192 features -- most lanes
+    // overflow, and the step was 25 % slower than pure FP64: profiles/r06_prescore_ef_f32_stage.txt.  At config 2's 256 matches a
+    // list almost never fills: one stretch, one drain.)
+    const dsm_f32x2 f0 = pk2(Ff[0]), f1 = pk2(Ff[1]), f2 = pk2(Ff[2]), f3 = pk2(Ff[3]), f4 = pk2(Ff[4]), f5 = pk2(Ff[5]), f6 = pk2(Ff[6]), f7 = pk2(Ff[7]),
+                    f8 = pk2(Ff[8]), ko = pk2(k_out), ki = pk2(k_in);
+    int j = 0;
+    while (j < npair) {
+      int cnt = 0;
+      for (; j < npair; ++j) {
         const float4 lo = reinterpret_cast<const float4*>(s32)[2 * j], hi = reinterpret_cast<const float4*>(s32)[2 * j + 1];
         const dsm_f32x2 x10 = {lo.x, lo.y}, x11 = {lo.z, lo.w}, x20 = {hi.x, hi.y}, x21 = {hi.z, hi.w};
         const dsm_f32x2 g0 = pk_fma(f0, x10, pk_fma(f1, x11, f2));
@@ -3054,43 +3060,40 @@ __global__ __launch_bounds__(64, 6) void k_prescore_compact2(const VerifyParams 
         const bool in_a = ok_a && (num.x < DI.x), in_b = ok_b && (num.y < DI.y);
         sure_out += (out_a ? 1 : 0) + (out_b ? 1 : 0);
         lb += (in_a ? 1 : 0) + (in_b ? 1 : 0);
-        if (!(in_a || out_a)) {  // inside the band (or unguarded): the FP64 test decides, later
-          if (cnt < PRESCORE_LIST_CAP) lst[cnt * 64 + lane] = (uint16_t)(2 * j);
+        if (has_model && !(in_a || out_a)) {  // inside the band (or unguarded): the FP64 test decides, at the end of the stretch
+          lst[cnt * 64 + lane] = (uint16_t)(2 * j);
           ++cnt;
         }
-        if (two && !(in_b || out_b)) {
-          if (cnt < PRESCORE_LIST_CAP) lst[cnt * 64 + lane] = (uint16_t)(2 * j + 1);
+        if (has_model && two && !(in_b || out_b)) {
+          lst[cnt * 64 + lane] = (uint16_t)(2 * j + 1);
           ++cnt;
         }
+        if (__any(cnt > PRESCORE_LIST_CAP - 2)) {  // (a trip adds at most two entries: no list passes PRESCORE_LIST_CAP)
+          ++j;
+          break;
+        }
       }
-    }
-    // ---- the listed points in FP64; a lane whose list overflowed (a model the f32 stage cannot judge) redoes all of its points
-    const bool overflow = cnt > PRESCORE_LIST_CAP;
-    if (overflow) {
-      lb = 0;
-      sure_out = 0;
-      for (int i = 0; i < n; ++i) prescore_point<FAM>(M, b, gpts + (size_t)i * 4, lb, sure_out);
-      cnt = 0;
-    }
-    int maxc = cnt;
+      // ---- the listed points in FP64, four per trip with their loads issued together
+      int maxc = cnt;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o));
-    for (int k0 = 0; k0 < maxc; k0 += 4) {  // four listed points per trip, their loads issued together
-      double q[4][4];
-      bool on[4];
+      for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o));
+      for (int k0 = 0; k0 < maxc; k0 += 4) {
+        double q[4][4];
+        bool on[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        on[u] = k0 + u < cnt;
-        const double* src = gpts + (size_t)(on[u] ? lst[(k0 + u) * 64 + lane] : 0) * 4;
+        for (int u = 0; u < 4; ++u) {
+          on[u] = k0 + u < cnt;
+          const double* src = gpts + (size_t)(on[u] ? lst[(k0 + u) * 64 + lane] : 0) * 4;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) q[u][c] = src[c];
-      }
+          for (int c = 0; c < 4; ++c) q[u][c] = src[c];
+        }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        bool in, out;
-        prescore_flags<FAM>(M, b, q[u], in, out);
-        lb += (on[u] && in) ? 1 : 0;
-        sure_out += (on[u] && out) ? 1 : 0;
+        for (int u = 0; u < 4; ++u) {
+          bool in, out;
+          prescore_flags<FAM>(M, b, q[u], in, out);
+          lb += (on[u] && in) ? 1 : 0;
+          sure_out += (on[u] && out) ? 1 : 0;
+        }
       }
     }
   }
