@@ -1189,6 +1189,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.lo_reg_prepare = ctx->dbg("DSM_LO_PREPARE_WAVE") ? 0 : 1;
   vp.rp_cap = std::min<uint32_t>(n_max, 256u);  // RP_CAP (verify_kernels.hip)
   vp.replay_legacy = ctx->dbg("DSM_REPLAY_LEGACY") ? 1 : 0;
+  vp.dbg_elu_lds = ctx->dbg("DSM_ELU_LDS") ? 1 : 0;
   vp.dbg_jacobi_groups = ctx->dbg("DSM_LO_JACOBI_GROUPS") ? 1 : 0;  // the 8-lane-group Jacobi kernel for every problem (round-2 form)
   vp.dbg_roots_lds = ctx->dbg("DSM_ROOTS_LDS") ? 1 : 0;              // k_roots_e_lds instead of the register form
   vp.dbg_final_waves = ctx->dbg("DSM_FINAL_WAVES") ? atoi(ctx->dbg("DSM_FINAL_WAVES")) : 0;

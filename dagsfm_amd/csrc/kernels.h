@@ -176,6 +176,7 @@ struct VerifyParams {
   int32_t* counts;             // [n_chunk][batch][maxm]
   double* sums;                // [n_chunk][batch][maxm] in-order residual sums of the inliers (F and H; k_score)
   int lo_reg_prepare;          // k_lo_prepare_reg takes the tall problems, k_lo_prepare only the rest
+  int dbg_elu_lds;             // check build, DSM_ELU_LDS: k_solve_e_lu (the 10 x 10 elimination in LDS) instead of k_solve_e_lu_reg
   int dbg_jacobi_groups, dbg_roots_lds, dbg_final_waves;  // dsm_set_debug_option switches the launch helpers read
   int score_prefilter;         // F / H scoring as bound + exact (k_prescore, k_score_needed); 0: plain k_score (DSM_SCORE_PREFILTER=0)
   int stats;                   // DSM_VERIFY_DEBUG: count candidates / local optimisations (one-address atomics) in the replay

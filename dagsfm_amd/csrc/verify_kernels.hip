@@ -2732,6 +2732,110 @@ DSM_DEV void e_lu_body(double* Ag_rw, double* slot, double* Al, unsigned char* i
   for (int k = 0; k < 39; ++k) slot[EPOLY_B + k] = B[k];
   for (int k = 0; k < 11; ++k) slot[EPOLY_COEFFS + k] = coeffs[k];
 }
+// The same elimination with the 10 x 10 matrix in REGISTERS (round 6).  e_lu_body keeps the lane's matrix in lane-interleaved LDS
+// because the pivot row is the lane's own (a dynamic index): 51 KB per wave, three waves per CU, every element access an LDS round trip
+// -- 8.1 ms per step at a VALU issue rate of 0.17, and a third of what the 5-point pipeline costs at a 0.25 inlier ratio.  Here every
+// index is a compile-time constant and the lane's pivot only appears in PREDICATES (pr_colpiv_qr9's construction): the row swap is a
+// chain of predicated exchanges over the candidate rows, the factor stays in 200 VGPRs (one wave per SIMD, no LDS at all), the ten
+// right-hand sides follow the pivoting as ten loads by permuted row index -- the next column's issued while this one is solved, as
+// before.  Same operations on the same values in the same order per element: PartialPivLU's unblocked elimination (first largest
+// |a| of the column, whole rows exchanged, the column divided by the pivot, one rank-1 update per k), unit-lower forward
+// substitution, backward substitution for the six rows B(z) needs.
+template <int ES = 1>
+DSM_DEV void e_lu_body_reg(double* Ag_rw, double* slot) {
+  const double* Ag = Ag_rw;
+  double* Sg = Ag_rw;  // the solution's way out of the registers (rows 0..5 of the left block, dead by then), as e_lu_body
+  double a[10][10];
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+#pragma unroll
+    for (int c = 0; c < 10; ++c) a[r][c] = Ag[(r * 20 + c) * ES];
+  }
+  int perm[10];  // perm[i]: the original row now in row i
+#pragma unroll
+  for (int i = 0; i < 10; ++i) perm[i] = i;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    int r = k;
+    double best = fabs(a[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < 10; ++i) {
+      const double v = fabs(a[i][k]);
+      const bool up = v > best;
+      best = up ? v : best;
+      r = up ? i : r;
+    }
+    if (best != 0.0) {
+      // exchange rows k and r (r == k: nothing moves): unconditional stores of selected VALUES
+#pragma unroll
+      for (int i = k + 1; i < 10; ++i) {
+        const bool sw = r == i;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+          const double x = a[k][j], y = a[i][j];
+          a[k][j] = sw ? y : x;
+          a[i][j] = sw ? x : y;
+        }
+        const int pk = perm[k], pi = perm[i];
+        perm[k] = sw ? pi : pk;
+        perm[i] = sw ? pk : pi;
+      }
+      const double piv = a[k][k];
+#pragma unroll
+      for (int i = k + 1; i < 10; ++i) a[i][k] /= piv;
+    }
+#pragma unroll
+    for (int j = k + 1; j < 10; ++j) {
+      const double akj = a[k][j];
+#pragma unroll
+      for (int i = k + 1; i < 10; ++i) a[i][j] -= a[i][k] * akj;
+    }
+  }
+  int prow[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) prow[i] = (perm[i] * 20 + 10) * ES;
+#pragma unroll 1
+  for (int j = 0; j < 10; ++j) {
+    double b[10];  // (no prefetch of the next column: two waves per SIMD hide the loads, and the twenty registers are what lets two fit)
+#pragma unroll
+    for (int i = 0; i < 10; ++i) b[i] = Ag[prow[i] + j * ES];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      double sacc = b[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) sacc -= a[i][k] * b[k];
+      b[i] = sacc;
+    }
+#pragma unroll
+    for (int i = 9; i >= 4; --i) {
+      double sacc = b[i];
+#pragma unroll
+      for (int k = 9; k > i; --k) sacc -= a[i][k] * b[k];
+      b[i] = sacc / a[i][i];
+    }
+#pragma unroll
+    for (int i = 4; i < 10; ++i) Sg[((i - 4) * 20 + j) * ES] = b[i];
+  }
+  double S[60];  // S[(r-4)*10 + c] = solution(r, c), rows 4..9
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+#pragma unroll
+    for (int c = 0; c < 10; ++c) S[r * 10 + c] = Sg[(r * 20 + c) * ES];
+  }
+  double B[39], coeffs[11];
+  five_point_B_det(S, B, coeffs);
+  for (int k = 0; k < 39; ++k) slot[EPOLY_B + k] = B[k];
+  for (int k = 0; k < 11; ++k) slot[EPOLY_COEFFS + k] = coeffs[k];
+}
+__global__ __launch_bounds__(64, 2) void k_solve_e_lu_reg(const VerifyParams p) {
+  const uint32_t pl = blockIdx.x;
+  const uint32_t pi = p.pair0 + pl;
+  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
+  if (!fs->active) return;
+  const int t = blockIdx.y * 64 + threadIdx.x;
+  if (t >= (int)fs->nb) return;
+  e_lu_body_reg<64>(p.e_work + ((size_t)pl * p.batch + (size_t)blockIdx.y * 64) * 200 + threadIdx.x, p.models + ((size_t)pl * p.batch + t) * 90);
+}
 __global__ __launch_bounds__(64) void k_solve_e_lu(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* Al = reinterpret_cast<double*>(smem_raw) + threadIdx.x;
@@ -4791,6 +4895,12 @@ __global__ __launch_bounds__(64) void k_lo_e_lu(const VerifyParams p) {
   const uint32_t sl = p.worklist ? p.worklist[widx] : widx;  // lo_ref's slot
   e_lu_body(p.lo_ework + (size_t)sl * 200, p.lo_slots + (size_t)sl * 90, Al, idx);
 }
+__global__ __launch_bounds__(64, 2) void k_lo_e_lu_reg(const VerifyParams p) {
+  const uint32_t widx = blockIdx.x * 64u + threadIdx.x;
+  if (widx >= p.n_work) return;
+  const uint32_t sl = p.worklist ? p.worklist[widx] : widx;  // lo_ref's slot
+  e_lu_body_reg(p.lo_ework + (size_t)sl * 200, p.lo_slots + (size_t)sl * 90);
+}
 __global__ __launch_bounds__(64) void k_lo_e_roots_models(const VerifyParams p) {
   const uint32_t widx = blockIdx.x * 64u + threadIdx.x;
   if (widx >= p.n_work) return;
@@ -4887,7 +4997,10 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint
       hipLaunchKernelGGL((k_lo_jacobi<FAM_E, false>), g4, dim3(64), 0, st, p);
 #endif
     hipLaunchKernelGGL(k_lo_e_build, g64, dim3(64), 0, st, p);
-    hipLaunchKernelGGL(k_lo_e_lu, g64, dim3(64), ELU_SMEM, st, p);
+    if (p.dbg_elu_lds)
+      hipLaunchKernelGGL(k_lo_e_lu, g64, dim3(64), ELU_SMEM, st, p);
+    else
+      hipLaunchKernelGGL(k_lo_e_lu_reg, g64, dim3(64), 0, st, p);
     hipLaunchKernelGGL(k_lo_e_roots_models, g64, dim3(64), 0, st, p);
   }
   if (fam == FAM_F) {
@@ -4937,7 +5050,10 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
   const size_t smem_c2 = (size_t)(p.n_max < VP_LDS_PTS ? (p.n_max > 0 ? p.n_max : 1) : VP_LDS_PTS) * 16 + 32 + (size_t)PRESCORE_LIST_CAP * 64 * 2;
   if (fam == FAM_E) {
     hipLaunchKernelGGL(k_solve_e_build, grid, dim3(64), 0, st, p);
-    hipLaunchKernelGGL(k_solve_e_lu, grid, dim3(64), ELU_SMEM, st, p);
+    if (p.dbg_elu_lds)  // check build, DSM_ELU_LDS: the elimination in lane-interleaved LDS (rounds 2 - 5)
+      hipLaunchKernelGGL(k_solve_e_lu, grid, dim3(64), ELU_SMEM, st, p);
+    else
+      hipLaunchKernelGGL(k_solve_e_lu_reg, grid, dim3(64), 0, st, p);
 #ifdef DSM_CHECK_BUILD
     if (p.dbg_roots_lds != 0)
       hipLaunchKernelGGL(k_roots_e_lds, grid, dim3(64), 100 * 64 * sizeof(double), st, p);
