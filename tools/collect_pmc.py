@@ -95,7 +95,10 @@ def summarize_verify(res):
             "executed_frac": flops / (ms * 1e-3) / fp64_peak,
             "lane_util": (tot("SQ_THREAD_CYCLES_VALU", k) / (64.0 * tot("SQ_ACTIVE_INST_VALU", k))) if tot("SQ_ACTIVE_INST_VALU", k) else None,
             "clock_ghz_while_busy": busy_cu / cus / (ms * 1e-3) / 1e9 if busy_cu else None,
-            "waves_per_simd_avg": wave_cyc / (4.0 * busy_cu) if busy_cu else None,
+            # SQ_WAVE_CYCLES counts QUAD-cycles (MI355X_MICROARCH.md, "SQ PMC units"), SQ_BUSY_CU_CYCLES cycles: resident waves per CU =
+            # 4 wave_cyc / busy_cu, per SIMD a quarter of that.  (Files collected before the last commit of round 6 divided by four once
+            # too often: their figure is a quarter of the truth -- 0.25 there is ONE wave per SIMD, 0.5 two.)
+            "waves_per_simd_avg": wave_cyc / busy_cu if busy_cu else None,
             "wait_inst_any_share": tot("SQ_WAIT_INST_ANY", k) / wave_cyc if wave_cyc else None,
             "lds_insts": tot("SQ_INSTS_LDS", k), "lds_bank_conflict_cycles": tot("SQ_LDS_BANK_CONFLICT", k),
             "salu_insts": tot("SQ_INSTS_SALU", k), "vmem_insts": tot("SQ_INSTS_VMEM", k),

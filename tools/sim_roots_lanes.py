@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 from dagsfm_amd import synthetic  # noqa: E402
 from tests import oracle_lib  # noqa: E402
 
-C_SEARCH, C_D1, C_D2, C_FINIT, C_POS, C_FTAIL = 60, 40, 450, 300, 230, 100
+C_SEARCH, C_D1, C_D2, C_FINIT, C_POS, C_FTAIL = [int(x) for x in os.environ.get("SIM_WEIGHTS", "60,40,450,300,230,100").split(",")]
 
 
 def traces(lib_path, n_pairs=30, trials=64, seed=0):
