@@ -241,7 +241,7 @@ void dsm_ctx_destroy(dsm_ctx* ctx) {
                     &ctx->d_wm_count, &ctx->d_pose_jobs};
   for (VerifyLane& L : ctx->lanes) {
     for (DevBuf* b : {&L.samples, &L.draws_end, &L.nmodels, &L.vcounts, &L.vsums, &L.models, &L.ework, &L.active, &L.vscratch, &L.lo_queue,
-                      &L.lo_work, &L.lo_models, &L.lo_slots, &L.lo_ework, &L.tail_items, &L.tail_n, &L.lo_jobs, &L.job_list})
+                      &L.lo_work, &L.lo_models, &L.lo_slots, &L.lo_ework, &L.tail_items, &L.tail_n, &L.lo_jobs, &L.job_list, &L.hyp_map})
       b->release();
     if (L.done) (void)hipEventDestroy(L.done);
     if (L.host_ctr) (void)hipHostFree(L.host_ctr);
@@ -309,7 +309,7 @@ static std::vector<DevBuf*> scratch_buffers(dsm_ctx* ctx) {
                             &ctx->d_order, &ctx->d_ecnt, &ctx->d_eoff, &ctx->d_vscratch};
   for (VerifyLane& L : ctx->lanes)
     for (DevBuf* b : {&L.samples, &L.draws_end, &L.nmodels, &L.vcounts, &L.vsums, &L.models, &L.ework, &L.active, &L.vscratch, &L.lo_queue, &L.lo_work,
-                      &L.lo_models, &L.lo_slots, &L.lo_ework, &L.tail_items, &L.tail_n, &L.lo_jobs, &L.job_list})
+                      &L.lo_models, &L.lo_slots, &L.lo_ework, &L.tail_items, &L.tail_n, &L.lo_jobs, &L.job_list, &L.hyp_map})
       v.push_back(b);
   return v;
 }
@@ -929,6 +929,7 @@ struct VerifyPlan {
   bool tail_items = true;   // the tail of a round (<= lo_tail pairs queued) as an item pass; false: the inline tail of round 2
   bool item_mode = false;   // item passes from the start of every round (short pair lists)
   uint32_t item_rounds = 0xffffffffu;  // ... of the first item_rounds rounds of a family only (later rounds: the chain)
+  bool hyp_compact = true;  // the lane-per-hypothesis solvers of E / F take later rounds' hypotheses 64 per wave across the pairs (hyp_of_lane)
 };
 
 #define LANECHK(L, call)                                              \
@@ -990,6 +991,10 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
         } else {
           LANECHK(L, hipMemsetAsync(actr - LANE_CTR_AREA, 0, LANE_CTR_AREA + 100, st));  // round start: k_sample's hand-out counters and [0] are live, the rest is dead here
         }
+        // E / F after a pair's first round (whole waves): the solvers take the round's hypotheses from k_sample's list, 64 per wave
+        // across the pairs (verify_kernels.hip hyp_of_lane); its segment counters are k_sample's hand-out counters, zeroed above
+        vp.hyp_map = (plan.hyp_compact && f != 2 && round > 0) ? L.hyp_map.as<uint32_t>() : nullptr;
+        vp.hyp_seg_cap = (uint32_t)(((size_t)(chunk + 63u) / 64u) * vp.batch);
         launch_vp_sample(vp, f, nb_light, st);
         launch_vp_solve_score(vp, f, st);
         uint32_t active = 0;
@@ -1188,6 +1193,8 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.stats = ctx->dbg("DSM_VERIFY_DEBUG") ? 1 : 0;
   vp.lo_reg_prepare = ctx->dbg("DSM_LO_PREPARE_WAVE") ? 0 : 1;
   vp.rp_cap = std::min<uint32_t>(n_max, 256u);  // RP_CAP (verify_kernels.hip)
+  vp.hyp_map = nullptr;  // (set per round by verify_lane_run)
+  vp.hyp_seg_cap = 0;
   vp.replay_legacy = ctx->dbg("DSM_REPLAY_LEGACY") ? 1 : 0;
   vp.dbg_elu_lds = ctx->dbg("DSM_ELU_LDS") ? 1 : 0;
   vp.dbg_jacobi_groups = ctx->dbg("DSM_LO_JACOBI_GROUPS") ? 1 : 0;  // the 8-lane-group Jacobi kernel for every problem (round-2 form)
@@ -1250,7 +1257,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
       }
       if (bmax_out) *bmax_out = bmax;
       if (bm_out) *bm_out = bm;
-      return (uint64_t)bmax * (7 * 4 + 4 + 4) + bm * (4 + 8 + 72) + (uint64_t)b[0] * 200 * 8 + (LO_WORK_DOUBLES + 90 + 90 + 200) * 8 + 12;
+      return (uint64_t)bmax * (7 * 4 + 4 + 4) + bm * (4 + 8 + 72) + (uint64_t)b[0] * 200 * 8 + (LO_WORK_DOUBLES + 90 + 90 + 200) * 8 + 12 + (uint64_t)std::max(b[0], b[1]) * 4;
     };
     // Lanes: the pair list is dealt out in chunks to up to DSM_VERIFY_MAX_LANES lanes that run concurrently (own
     // stream, own host thread, own scratch; see VerifyLane).  A pair's three families cannot overlap -- F starts from
@@ -1312,7 +1319,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
       plan.end[li] = at + cnt;
       at += cnt;
       const uint64_t lane_budget = (uint64_t)(budget * ((double)cnt / n_pairs));
-      plan.chunk[li] = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cnt, lane_budget / per_pair));
+      plan.chunk[li] = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(cnt, (1u << 21) - 64u), lane_budget / per_pair));  // (< 2^21 pairs: an entry of the hypothesis list holds pl in 21 bits)
       if (cp) plan.chunk[li] = std::max<uint32_t>(1, std::min<uint32_t>(plan.chunk[li], (uint32_t)atoi(cp)));
     }
     plan.n_lanes = n_lanes;
@@ -1344,6 +1351,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
       plan.item_mode = atoi(e) != 0;
       if (atoi(e) > 1) plan.item_rounds = (uint32_t)atoi(e) - 1u;
     }
+    if (const char* e = ctx->dbg("DSM_HYP_GRID")) plan.hyp_compact = strcmp(e, "pair") != 0;  // check build: "pair" = the (pair, 64 trials) grid in every round
     HIPCHK(ctx, ctx->d_fam_state.reserve(std::max<size_t>(n_pairs, 1) * 3 * sizeof(FamState)));
     HIPCHK(ctx, ctx->d_sidx.reserve(tm * 4));
     HIPCHK(ctx, ctx->d_lo_inl.reserve(tm * 4));
@@ -1356,13 +1364,16 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
     // error: release the lanes' scratch, halve the chunks, try again (a chunk of one pair always fits or nothing does).
     // what a lane holds for a chunk of `chunk` pairs, buffer by buffer (reserve_lanes below allocates exactly these)
     struct LaneBytes {
-      size_t v[18];
+      size_t v[19];
       size_t total() const {
         size_t t = 0;
         for (size_t x : v) t += x + x / 8 + 256;  // (DevBuf::reserve rounds up by an eighth)
         return t;
       }
     };
+    // the list of a round's hypotheses for the compact solver grids: 64 segments of ceil(chunk / 64) pairs x the larger of the E / F round sizes
+    auto hyp_seg_cap = [&](uint32_t chunk, uint32_t batch) { return (size_t)((chunk + 63u) / 64u) * batch; };
+    auto hyp_entries = [&](uint32_t chunk) { return 64 * hyp_seg_cap(chunk, std::max(plan.batch[0], plan.batch[1])); };
     auto lane_bytes = [&](uint32_t chunk) {
       LaneBytes z;
       const uint32_t lane_blocks = std::min<uint32_t>(chunk, (uint32_t)dev_cus * 4u * DSM_REPLAY_WAVES);
@@ -1387,6 +1398,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
       z.v[15] = slots * 90 * 8;
       z.v[16] = slots * 90 * 8;
       z.v[17] = slots * 200 * 8;
+      z.v[18] = hyp_entries(chunk) * 4;
       return z;
     };
     if (ctx->memory_budget) {
@@ -1445,6 +1457,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
           LRES(L.lo_models.reserve(z.v[15]));
           LRES(L.lo_slots.reserve(z.v[16]));
           LRES(L.lo_ework.reserve(z.v[17]));
+          LRES(L.hyp_map.reserve(z.v[18]));
         }
 #undef LRES
         return hipSuccess;
@@ -1460,7 +1473,7 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
       }
       for (VerifyLane& L : ctx->lanes)
         for (DevBuf* b : {&L.samples, &L.draws_end, &L.nmodels, &L.vcounts, &L.vsums, &L.models, &L.ework, &L.vscratch, &L.lo_queue, &L.lo_work,
-                          &L.lo_models, &L.lo_slots, &L.lo_ework, &L.tail_items, &L.tail_n, &L.lo_jobs, &L.job_list})
+                          &L.lo_models, &L.lo_slots, &L.lo_ework, &L.tail_items, &L.tail_n, &L.lo_jobs, &L.job_list, &L.hyp_map})
           b->release();
       for (uint32_t li = 0; li < n_lanes; ++li) plan.chunk[li] = std::max<uint32_t>(1, plan.chunk[li] / 2);
     }

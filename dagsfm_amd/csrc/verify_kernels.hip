@@ -999,6 +999,7 @@ DSM_DEV uint32_t grab_item(WorkGrab& g, uint32_t* counter, uint32_t* s_slot, int
 #define GRAB_STRIDE 32  // words: one counter per 128-byte line
 #define GRAB_AREA_WORDS (GRAB_SEGS * GRAB_STRIDE)
 #define GRAB_DONE 0xffffffffu
+#define HYP_T_BITS 11  // an entry of the hypothesis list (hyp_of_lane): pl << 11 | t (t < batch <= 2048; the planner keeps a chunk below 2^21 pairs)
 // the four areas of a lane's counter block (capi.hip lays them out so that every phase still costs ONE fill), relative to
 // VerifyParams::active_count (the classic 32 words): k_sample's in front of it, the replay's (grab_ctr), k_lo_prepare's and
 // k_verify_final's behind it
@@ -1775,10 +1776,18 @@ __global__ __launch_bounds__(64) void k_sample(const VerifyParams p) {
       if (need < want) want = need;
     }
     const int nb = (int)(remaining < want ? remaining : want);
+    // the round's list of hypotheses for the compact solver grids (hyp_of_lane): this pair's nb entries in segment pl % 64
+    uint32_t hyp_base = 0;
+    if (FAM != FAM_H && p.hyp_map && lane == 0) hyp_base = atomicAdd(GRAB_SAMPLE(p) + (pl % GRAB_SEGS) * GRAB_STRIDE, (uint32_t)nb);
     generator_store(gen, st + PS_SNAP, lane);  // snapshot before this round's draws
     wv_sync();
     wv_draw_samples<F::K>(gen, ws, sidx, (uint32_t)n, nb, p.samples + ((size_t)pl * p.batch) * 7,
                           p.draws_end + (size_t)pl * p.batch, lane, p.sampler_serial != 0);
+    if (FAM != FAM_H && p.hyp_map) {
+      hyp_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)hyp_base);
+      uint32_t* hm = p.hyp_map + (size_t)(pl % GRAB_SEGS) * p.hyp_seg_cap + hyp_base;
+      for (int i = lane; i < nb; i += 64) hm[i] = (pl << HYP_T_BITS) | (uint32_t)i;
+    }
     if (lane == 0) {
       fs->nb = (uint32_t)nb;
       fs->t_pos = 0;
@@ -1825,6 +1834,34 @@ DSM_DEV double stage_points_batched(const double* gpts, int n4, double* spts, in
   }
   return m;
 }
+// Which (pair, trial) does this lane solve?  Two grids for the lane-per-hypothesis solvers (k_solve<F>, k_solve_e_build / _lu /
+// k_roots_e):
+//   identity  grid (n_chunk, batch / 64): workgroup (pl, b) takes the trials 64 b .. 64 b + 63 of pair pl.  A pair's FIRST round
+//             speculates whole waves (64 / 128 trials); every later round only what its dynamic stop still asks for (k_sample), a
+//             partial wave per pair: 18 % of the E solvers' lanes and 30 % of k_solve<F>'s had no trial (round 6 counters).
+//   compact   from the second round on k_sample lists the round's hypotheses of ALL pairs (p.hyp_map) and the solvers take 64
+//             consecutive entries of that list per wave, whatever pairs they belong to.  The list has GRAB_SEGS segments (pair pl
+//             appends to segment pl % 64, one atomic per pair and round on the segment's own cache line -- a single counter would
+//             serialise 10^5 same-address atomics at 11.4 ns each); segment s holds hyp_seg_cap entries from s * hyp_seg_cap, its
+//             length is k_sample's hand-out counter s (zeroed at round start, unused by the E / F samplers otherwise).
+// Which lane computes a hypothesis does not enter its result: both grids write the same bytes to the same slots.
+DSM_DEV bool hyp_of_lane(const VerifyParams& p, int fam, uint32_t& pl, int& t) {
+  if (p.hyp_map) {
+    const uint32_t s = blockIdx.x % GRAB_SEGS, w = blockIdx.x / GRAB_SEGS;
+    const uint32_t cnt = GRAB_SAMPLE(p)[s * GRAB_STRIDE];
+    const uint32_t i = w * 64 + threadIdx.x;
+    if (i >= cnt) return false;
+    const uint32_t e = p.hyp_map[(size_t)s * p.hyp_seg_cap + i];
+    pl = e >> HYP_T_BITS;
+    t = (int)(e & ((1u << HYP_T_BITS) - 1u));
+    return true;
+  }
+  pl = blockIdx.x;
+  const FamState* fs = p.fam_state + (size_t)(p.pair0 + pl) * 3 + fam;
+  if (!fs->active) return false;
+  t = blockIdx.y * 64 + threadIdx.x;
+  return t < (int)fs->nb;
+}
 // F and H: solver and inlier counting as two kernels.  k_solve keeps the solver's working set (F: the 9 x 7
 // matrix in lane-interleaved LDS; H: ~220 VGPRs) away from the counting loop, which is pure FP64 VALU work
 // with a 9-double model per lane and wants many resident waves; k_score gives every (trial, model) slot its
@@ -1832,12 +1869,10 @@ DSM_DEV double stage_points_batched(const double* gpts, int n4, double* spts, in
 template <int FAM>
 __global__ __launch_bounds__(64, 2) void k_solve(const VerifyParams p) {
   typedef Fam<FAM> F;
-  const uint32_t pl = blockIdx.x;
+  uint32_t pl;
+  int t;
+  if (!hyp_of_lane(p, FAM, pl, t)) return;
   const uint32_t pi = p.pair0 + pl;
-  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM;
-  if (!fs->active) return;
-  const int t = blockIdx.y * 64 + threadIdx.x;
-  if (t >= (int)fs->nb) return;
   const double* pts = p.pts_px + 4 * p.match_off[pi];
   const uint32_t* smp = p.samples + ((size_t)pl * p.batch + t) * 7;
   double xs[F::K * 4];
@@ -2609,15 +2644,18 @@ __global__ __launch_bounds__(64, 8) void k_score_needed(const VerifyParams p) {
 // round-2 LDS form -- element e of lane l at T[e * 64 + l], 51 KB per wave -- is k_roots_e_lds); k_models_score_e
 // builds and scores the models at full occupancy.  Same operations, same order.
 #define EPOLY_EB 0
+// the 10 x 20 constraint matrix of trial t of pair pl: blocks of 64 trials interleaved, element e of the trial at block + e * 64 +
+// t % 64 (batch is a multiple of 64)
+DSM_DEV double* e_work_of(const VerifyParams& p, uint32_t pl, int t) {
+  return p.e_work + ((size_t)pl * p.batch + (size_t)(t & ~63)) * 200 + (t & 63);
+}
 #define EPOLY_B 36
 #define EPOLY_COEFFS 75
 __global__ __launch_bounds__(64, 2) void k_solve_e_build(const VerifyParams p) {
-  const uint32_t pl = blockIdx.x;
+  uint32_t pl;
+  int t;
+  if (!hyp_of_lane(p, FAM_E, pl, t)) return;
   const uint32_t pi = p.pair0 + pl;
-  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
-  if (!fs->active) return;
-  const int t = blockIdx.y * 64 + threadIdx.x;
-  if (t >= (int)fs->nb) return;
   const double* pts = p.pts_norm + 4 * p.match_off[pi];
   const uint32_t* smp = p.samples + ((size_t)pl * p.batch + t) * 7;
   double xs[20];
@@ -2631,7 +2669,7 @@ __global__ __launch_bounds__(64, 2) void k_solve_e_build(const VerifyParams p) {
   double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
   for (int k = 0; k < 36; ++k) slot[EPOLY_EB + k] = Eb[k];
   // the wave's 64 hypotheses interleaved: element e of lane l at block + e * 64 + l (batch is a multiple of 64)
-  five_point_build_A<64>(Eb, p.e_work + ((size_t)pl * p.batch + (size_t)blockIdx.y * 64) * 200 + threadIdx.x);
+  five_point_build_A<64>(Eb, e_work_of(p, pl, t));
 }
 
 // A[:, :10].partialPivLu().solve(A[:, 10:]) (essential_matrix.cc:80) with the 10 x 10 factor in lane-interleaved
@@ -2828,25 +2866,19 @@ DSM_DEV void e_lu_body_reg(double* Ag_rw, double* slot) {
   for (int k = 0; k < 11; ++k) slot[EPOLY_COEFFS + k] = coeffs[k];
 }
 __global__ __launch_bounds__(64, 2) void k_solve_e_lu_reg(const VerifyParams p) {
-  const uint32_t pl = blockIdx.x;
-  const uint32_t pi = p.pair0 + pl;
-  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
-  if (!fs->active) return;
-  const int t = blockIdx.y * 64 + threadIdx.x;
-  if (t >= (int)fs->nb) return;
-  e_lu_body_reg<64>(p.e_work + ((size_t)pl * p.batch + (size_t)blockIdx.y * 64) * 200 + threadIdx.x, p.models + ((size_t)pl * p.batch + t) * 90);
+  uint32_t pl;
+  int t;
+  if (!hyp_of_lane(p, FAM_E, pl, t)) return;
+  e_lu_body_reg<64>(e_work_of(p, pl, t), p.models + ((size_t)pl * p.batch + t) * 90);
 }
 __global__ __launch_bounds__(64) void k_solve_e_lu(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* Al = reinterpret_cast<double*>(smem_raw) + threadIdx.x;
   unsigned char* idx = smem_raw + 100 * 64 * 8 + threadIdx.x;  // idx[i*64]: original row now in row i
-  const uint32_t pl = blockIdx.x;
-  const uint32_t pi = p.pair0 + pl;
-  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
-  if (!fs->active) return;
-  const int t = blockIdx.y * 64 + threadIdx.x;
-  if (t >= (int)fs->nb) return;
-  e_lu_body<64>(p.e_work + ((size_t)pl * p.batch + (size_t)blockIdx.y * 64) * 200 + threadIdx.x, p.models + ((size_t)pl * p.batch + t) * 90, Al, idx);
+  uint32_t pl;
+  int t;
+  if (!hyp_of_lane(p, FAM_E, pl, t)) return;
+  e_lu_body<64>(e_work_of(p, pl, t), p.models + ((size_t)pl * p.batch + t) * 90, Al, idx);
 }
 
 // slot coefficients -> slot roots (real parts); returns the code for nmodels: bits 0..9 root i is real
@@ -2889,12 +2921,9 @@ DSM_DEV int e_models_body(const double* slot, int code, double* out) {
 // roots of the determinant polynomial and the essential matrices of its real roots: slot (Eb, B, coefficients) ->
 // slot models + nmodels for k_models_score_e
 __global__ __launch_bounds__(64, 2) void k_roots_e(const VerifyParams p) {
-  const uint32_t pl = blockIdx.x;
-  const uint32_t pi = p.pair0 + pl;
-  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
-  if (!fs->active) return;
-  const int t = blockIdx.y * 64 + threadIdx.x;
-  if (t >= (int)fs->nb) return;
+  uint32_t pl;
+  int t;
+  if (!hyp_of_lane(p, FAM_E, pl, t)) return;
   // roots, then the models of the real roots in place of the hypothesis' record (its inputs are in registers by then)
   double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
   const int code = e_roots_body(slot);
@@ -2906,12 +2935,9 @@ __global__ __launch_bounds__(64, 2) void k_roots_e(const VerifyParams p) {
 __global__ __launch_bounds__(64) void k_roots_e_lds(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* Tl = reinterpret_cast<double*>(smem_raw) + threadIdx.x;  // this lane's companion matrix, stride 64
-  const uint32_t pl = blockIdx.x;
-  const uint32_t pi = p.pair0 + pl;
-  const FamState* fs = p.fam_state + (size_t)pi * 3 + FAM_E;
-  if (!fs->active) return;
-  const int t = blockIdx.y * 64 + threadIdx.x;
-  if (t >= (int)fs->nb) return;
+  uint32_t pl;
+  int t;
+  if (!hyp_of_lane(p, FAM_E, pl, t)) return;
   double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
   double coeffs[11], rr[11], ri[11];
   for (int k = 0; k < 11; ++k) coeffs[k] = slot[EPOLY_COEFFS + k];
@@ -5045,21 +5071,27 @@ void launch_vp_sample(const VerifyParams& p, int fam, uint32_t n_blocks, hipStre
 void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
   if (!p.n_chunk) return;
   const dim3 grid(p.n_chunk, (p.batch + 63) / 64);
+  // the lane-per-hypothesis solvers: the compact grid (hyp_of_lane) when the round has a list; its non-empty workgroups come first
+  const dim3 grid_hyp = p.hyp_map ? dim3((uint32_t)GRAB_SEGS * (p.hyp_seg_cap / 64u)) : grid;
   const size_t smem = (size_t)(p.n_max < VP_LDS_PTS ? (p.n_max > 0 ? p.n_max : 1) : VP_LDS_PTS) * 32;
   // the bound steps with an f32 first stage: the points as f32 (16 bytes each, padded to a pair) + the lanes' lists of band points
   const size_t smem_c2 = (size_t)(p.n_max < VP_LDS_PTS ? (p.n_max > 0 ? p.n_max : 1) : VP_LDS_PTS) * 16 + 32 + (size_t)PRESCORE_LIST_CAP * 64 * 2;
   if (fam == FAM_E) {
-    hipLaunchKernelGGL(k_solve_e_build, grid, dim3(64), 0, st, p);
+    hipLaunchKernelGGL(k_solve_e_build, grid_hyp, dim3(64), 0, st, p);
+    // (the elimination stays on the pair grid: it streams the 1.6 KB of e_work per hypothesis from a wave-uniform base + lane, and with a
+    // base per lane it was 14 % slower -- 6.4 vs 5.6 ms per step at config 2 -- for the sixth of its lanes the compact grid would fill)
+    VerifyParams pg = p;
+    pg.hyp_map = nullptr;
     if (p.dbg_elu_lds)  // check build, DSM_ELU_LDS: the elimination in lane-interleaved LDS (rounds 2 - 5)
-      hipLaunchKernelGGL(k_solve_e_lu, grid, dim3(64), ELU_SMEM, st, p);
+      hipLaunchKernelGGL(k_solve_e_lu, grid, dim3(64), ELU_SMEM, st, pg);
     else
-      hipLaunchKernelGGL(k_solve_e_lu_reg, grid, dim3(64), 0, st, p);
+      hipLaunchKernelGGL(k_solve_e_lu_reg, grid, dim3(64), 0, st, pg);
 #ifdef DSM_CHECK_BUILD
     if (p.dbg_roots_lds != 0)
-      hipLaunchKernelGGL(k_roots_e_lds, grid, dim3(64), 100 * 64 * sizeof(double), st, p);
+      hipLaunchKernelGGL(k_roots_e_lds, grid_hyp, dim3(64), 100 * 64 * sizeof(double), st, p);
     else
 #endif
-      hipLaunchKernelGGL(k_roots_e, grid, dim3(64), 0, st, p);
+      hipLaunchKernelGGL(k_roots_e, grid_hyp, dim3(64), 0, st, p);
     // scoring: a lane per model (k_prescore_compact<E> -> k_score_needed<E>), or the wave-per-hypothesis kernel with the bound step fused in
     // (DSM_SCORE_PREFILTER=3; also what =0 runs, without its bound step)
     const size_t smem2e = smem + (size_t)p.batch * 10 * 2;
@@ -5085,7 +5117,7 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
   // fit 16-bit indices and, with the points, the LDS
   const uint32_t nb_needed = p.n_chunk < 256u * 32u ? p.n_chunk : 256u * 32u;
   if (fam == FAM_F) {
-    hipLaunchKernelGGL(k_solve<FAM_F>, grid, dim3(64), 0, st, p);
+    hipLaunchKernelGGL(k_solve<FAM_F>, grid_hyp, dim3(64), 0, st, p);
     const size_t smem2 = smem + (size_t)p.batch * 3 * 2;
     if (p.score_prefilter && p.batch * 3 <= 65535 && smem2 <= 64 * 1024) {
       if (p.score_prefilter & 2)  // DSM_SCORE_PREFILTER=3: a lane per slot
