@@ -170,7 +170,7 @@ PRODUCT_OPTION_KEYS = ("DSM_MATCH_CHUNK_ROWS", "DSM_VERIFY_CHUNK_PAIRS", "DSM_VE
                        "DSM_LO_TAIL", "DSM_LO_TAIL_MODE", "DSM_VERIFY_GRID_DIV")
 CHECK_OPTION_KEYS = ("DSM_K1_DOT4", "DSM_VERIFY_DEBUG", "DSM_SAMPLER_SERIAL", "DSM_LO_PREPARE_WAVE", "DSM_LO_JACOBI_GROUPS", "DSM_ROOTS_LDS",
                      "DSM_FINAL_WAVES", "DSM_VERIFY_LEGACY", "DSM_VERIFY_FIXED_BATCH", "DSM_VERIFY_LANE_SPLIT", "DSM_DEBUG_SAMPLER_MODE",
-                     "DSM_VOCAB_ASSIGN_VALU", "DSM_VERIFY_HOST_LOOP", "DSM_SCORE_PREFILTER", "DSM_VERIFY_REPLAY_GRID", "DSM_REPLAY_LEGACY", "DSM_FLANN_GROUP", "DSM_FLANN_STATS", "DSM_ELU_LDS", "DSM_HYP_GRID")
+                     "DSM_VOCAB_ASSIGN_VALU", "DSM_VERIFY_HOST_LOOP", "DSM_SCORE_PREFILTER", "DSM_VERIFY_REPLAY_GRID", "DSM_REPLAY_LEGACY", "DSM_FLANN_GROUP", "DSM_FLANN_STATS", "DSM_ELU_LDS", "DSM_HYP_GRID", "DSM_SPEC_MARGIN")
 DEBUG_OPTION_KEYS = PRODUCT_OPTION_KEYS  # what a deployer's library knows
 
 

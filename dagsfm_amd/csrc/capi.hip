@@ -1193,6 +1193,15 @@ static int verify_core(dsm_ctx* ctx, uint32_t n_pairs, const uint32_t* d_pairs, 
   vp.stats = ctx->dbg("DSM_VERIFY_DEBUG") ? 1 : 0;
   vp.lo_reg_prepare = ctx->dbg("DSM_LO_PREPARE_WAVE") ? 0 : 1;
   vp.rp_cap = std::min<uint32_t>(n_max, 256u);  // RP_CAP (verify_kernels.hip)
+  vp.spec_margin[0] = 8;
+  vp.spec_margin[1] = vp.spec_margin[2] = 4;
+  if (const char* e = ctx->dbg("DSM_SPEC_MARGIN")) {  // check build: "e,f"
+    unsigned a = 8, b = 4;
+    if (sscanf(e, "%u,%u", &a, &b) == 2) {
+      vp.spec_margin[0] = a;
+      vp.spec_margin[1] = b;
+    }
+  }
   vp.hyp_map = nullptr;  // (set per round by verify_lane_run)
   vp.hyp_seg_cap = 0;
   vp.replay_legacy = ctx->dbg("DSM_REPLAY_LEGACY") ? 1 : 0;

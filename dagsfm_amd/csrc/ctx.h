@@ -165,7 +165,7 @@ static const char* const dsm_product_debug_keys[] = {"DSM_MATCH_CHUNK_ROWS", "DS
 static const char* const dsm_check_debug_keys[] = {"DSM_K1_DOT4", "DSM_VERIFY_DEBUG", "DSM_SAMPLER_SERIAL", "DSM_LO_PREPARE_WAVE", "DSM_LO_JACOBI_GROUPS",
                                                    "DSM_ROOTS_LDS", "DSM_FINAL_WAVES", "DSM_VERIFY_LEGACY", "DSM_VERIFY_FIXED_BATCH", "DSM_VERIFY_LANE_SPLIT",
                                                    "DSM_DEBUG_SAMPLER_MODE", "DSM_VOCAB_ASSIGN_VALU", "DSM_VERIFY_HOST_LOOP", "DSM_SCORE_PREFILTER",
-                                                   "DSM_VERIFY_REPLAY_GRID", "DSM_REPLAY_LEGACY", "DSM_FLANN_GROUP", "DSM_FLANN_STATS", "DSM_ELU_LDS", "DSM_HYP_GRID"};
+                                                   "DSM_VERIFY_REPLAY_GRID", "DSM_REPLAY_LEGACY", "DSM_FLANN_GROUP", "DSM_FLANN_STATS", "DSM_ELU_LDS", "DSM_HYP_GRID", "DSM_SPEC_MARGIN"};
 #endif
 
 #define HIPCHK(ctx, call)                                                              \

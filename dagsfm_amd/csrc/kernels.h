@@ -180,6 +180,7 @@ struct VerifyParams {
   int dbg_jacobi_groups, dbg_roots_lds, dbg_final_waves;  // dsm_set_debug_option switches the launch helpers read
   int score_prefilter;         // F / H scoring as bound + exact (k_prescore, k_score_needed); 0: plain k_score (DSM_SCORE_PREFILTER=0)
   int stats;                   // DSM_VERIFY_DEBUG: count candidates / local optimisations (one-address atomics) in the replay
+  uint32_t spec_margin[3];     // k_sample: trials a later round speculates beyond what the dynamic stop asks for (samples without a model)
   uint32_t* hyp_map;           // E / F rounds after a pair's first: the round's hypotheses of all pairs, listed by k_sample in 64 segments
   uint32_t hyp_seg_cap;        // (verify_kernels.hip hyp_of_lane); nullptr: the solvers run the (pair, block of 64 trials) grid.  Entries per segment
   uint32_t rp_cap;             // k_replay_rp: correspondences of a pair its LDS holds (min(n_max, RP_CAP)); longer pairs read global memory

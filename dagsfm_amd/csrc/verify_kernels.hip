@@ -1771,7 +1771,7 @@ __global__ __launch_bounds__(64) void k_sample(const VerifyParams p) {
       const uint32_t mt = (uint32_t)p.opt.min_num_trials;
       const uint32_t thr = fs->dyn_max > mt ? fs->dyn_max : mt;
       const uint32_t T0 = fs->rep.num_trials;
-      const uint32_t margin = FAM == FAM_E ? 8u : 4u;
+      const uint32_t margin = p.spec_margin[FAM];  // (E 8, F / H 4: capi.hip)
       const uint32_t need = (thr > T0 ? thr - T0 : 0u) + margin;
       if (need < want) want = need;
     }
