@@ -4551,10 +4551,26 @@ DSM_DEV LoRef lo_ref(const VerifyParams& p, uint32_t widx) {
 // LO step 1 with the constraint matrix in registers (wr_colpiv_qr9): a wave per queued pair, lane l owns rows l,
 // l + 64, ...; the pair's inlier points are loaded once and serve the in-order normalisation sums (the four / two
 // independent chains of CenterAndNormalizeImagePoints advance together) and the rows.  Same operations as k_lo_prepare.
+// ((0 + v[0]) + v[stride]) + ... over n operands in LDS, by this lane alone (n = 0: the lane has no chain): eight loads in flight
+// ahead of the dependent adds
+DSM_DEV double lds_chain_sum(const double* v, int stride, int n) {
+  double s = 0.0;
+  int k = 0;
+  for (; k + 8 <= n; k += 8) {
+    double x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = v[(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += x[u];
+  }
+  for (; k < n; ++k) s += v[k * stride];
+  return s;
+}
 template <int FAM>
 __global__ __launch_bounds__(64) void k_lo_prepare_reg(const VerifyParams p) {
   constexpr int PPL = LOP_PPL;
   constexpr int RPL = FAM == FAM_H ? 2 * PPL : PPL;
+  __shared__ double lo_prep_lds[FAM == FAM_E ? 1 : 64 * PPL * 4];  // the operands of the normalisation's in-order sums (F, H)
   const int lane = threadIdx.x;
   const uint32_t widx = blockIdx.x;
   if (widx >= p.n_work) return;
@@ -4580,37 +4596,36 @@ __global__ __launch_bounds__(64) void k_lo_prepare_reg(const VerifyParams p) {
   }
   double n1[3] = {0, 0, 0}, n2[3] = {0, 0, 0};
   if (FAM != FAM_E) {
-    // CenterAndNormalizeImagePoints (utils.cc:40-64) for both images: sums in index order
-    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    // CenterAndNormalizeImagePoints (utils.cc:40-64) for both images: sums in index order.  The four coordinate sums and then the
+    // two sums of squared distances are independent sequential chains over the inliers: the operands go through LDS and lane c
+    // walks chain c -- one add per inlier and chain member for the wave.  (Rounds 3 - 5 walked every chain on all 64 lanes through
+    // v_readlane: two readlanes and an add per operand, 3 000 of the 8 200 instructions an F problem cost.)
+    double* sp = lo_prep_lds;
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
-      if (64 * r < ninl) {
-        const int cnt = (ninl - 64 * r) < 64 ? (ninl - 64 * r) : 64;
-        for (int k = 0; k < cnt; ++k) {
+      const int i = lane + 64 * r;
+      if (i < ninl) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) s[c] += wv_readlane_f64(px[r][c], k);
-        }
+        for (int c = 0; c < 4; ++c) sp[i * 4 + c] = px[r][c];
       }
     }
-    const double cx1 = s[0] / ninl, cy1 = s[1] / ninl, cx2 = s[2] / ninl, cy2 = s[3] / ninl;
-    double d[PPL][2];
+    wv_sync();
+    double sc = lds_chain_sum(sp + lane, 4, lane < 4 ? ninl : 0);
+    wv_sync();
+    const double cx1 = wv_readlane_f64(sc, 0) / ninl, cy1 = wv_readlane_f64(sc, 1) / ninl, cx2 = wv_readlane_f64(sc, 2) / ninl,
+                 cy2 = wv_readlane_f64(sc, 3) / ninl;
 #pragma unroll
     for (int r = 0; r < PPL; ++r) {
+      const int i = lane + 64 * r;
       const double dx1 = px[r][0] - cx1, dy1 = px[r][1] - cy1, dx2 = px[r][2] - cx2, dy2 = px[r][3] - cy2;
-      d[r][0] = dx1 * dx1 + dy1 * dy1;
-      d[r][1] = dx2 * dx2 + dy2 * dy2;
-    }
-    double q1 = 0.0, q2 = 0.0;
-#pragma unroll
-    for (int r = 0; r < PPL; ++r) {
-      if (64 * r < ninl) {
-        const int cnt = (ninl - 64 * r) < 64 ? (ninl - 64 * r) : 64;
-        for (int k = 0; k < cnt; ++k) {
-          q1 += wv_readlane_f64(d[r][0], k);
-          q2 += wv_readlane_f64(d[r][1], k);
-        }
+      if (i < ninl) {
+        sp[i * 2 + 0] = dx1 * dx1 + dy1 * dy1;
+        sp[i * 2 + 1] = dx2 * dx2 + dy2 * dy2;
       }
     }
+    wv_sync();
+    sc = lds_chain_sum(sp + (lane & 1), 2, lane < 2 ? ninl : 0);
+    const double q1 = wv_readlane_f64(sc, 0), q2 = wv_readlane_f64(sc, 1);
     const double rms1 = sqrt(q1 / ninl), rms2 = sqrt(q2 / ninl);
     n1[0] = sqrt(2.0) / rms1; n1[1] = -n1[0] * cx1; n1[2] = -n1[0] * cy1;
     n2[0] = sqrt(2.0) / rms2; n2[1] = -n2[0] * cx2; n2[2] = -n2[0] * cy2;
