@@ -947,8 +947,18 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
   VerifyLane& L = ctx->lanes[li];
   LANECHK(L, hipSetDevice(ctx->device));
   hipStream_t st = L.stream;
+  // the lane's counter fills and read-backs as one-wave kernels, not as the runtime's blit kernels (verify_kernels.hip k_lane_counters:
+  // an eight-wave blit workgroup starves for tens of ms behind the other lane's register-filling kernels)
+  auto ctr_zero = [st](void* at, size_t bytes) {
+    launch_lane_counters(nullptr, nullptr, 0, at, bytes, st);
+    return hipGetLastError();
+  };
+  auto ctr_read = [st](uint32_t* host, const void* src, uint32_t bytes) {
+    launch_lane_counters(src, host, bytes, nullptr, 0, st);
+    return hipGetLastError();
+  };
   LANECHK(L, hipStreamWaitEvent(st, ctx->vev0, 0));
-  LANECHK(L, hipMemsetAsync(L.active.p, 0, LANE_CTR_BYTES, st));
+  LANECHK(L, ctr_zero(L.active.p, LANE_CTR_BYTES));
   const uint32_t chunk = plan.chunk[li];
   vp.scratch = L.vscratch.as<double>();
   vp.samples = L.samples.as<uint32_t>();
@@ -989,7 +999,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
           LANECHK(L, hipMemsetAsync(actr - LANE_CTR_AREA, 0, LANE_CTR_AREA + 4, st));
           LANECHK(L, hipMemsetAsync(actr + 64, 0, 36, st));
         } else {
-          LANECHK(L, hipMemsetAsync(actr - LANE_CTR_AREA, 0, LANE_CTR_AREA + 100, st));  // round start: k_sample's hand-out counters and [0] are live, the rest is dead here
+          LANECHK(L, ctr_zero(actr - LANE_CTR_AREA, LANE_CTR_AREA + 112));  // round start: k_sample's hand-out counters and [0] are live, the rest ([1] - [27]) is dead here
         }
         // E / F after a pair's first round (whole waves): the solvers take the round's hypotheses from k_sample's list, 64 per wave
         // across the pairs (verify_kernels.hip hyp_of_lane); its segment counters are k_sample's hand-out counters, zeroed above
@@ -999,10 +1009,10 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
         launch_vp_solve_score(vp, f, st);
         uint32_t active = 0;
         if (plan.inline_lo) {
-          LANECHK(L, hipMemsetAsync(actr + 64, 0, 4, st));  // k_replay's work counter
+          LANECHK(L, ctr_zero(actr + 64, 16));  // k_replay's work counter ([17] - [19] are unused words)
           launch_vp_replay(vp, f, nb_heavy, st);
           LANECHK(L, hipGetLastError());
-          LANECHK(L, hipMemcpyAsync(L.host_ctr, actr, 4, hipMemcpyDeviceToHost, st));
+          LANECHK(L, ctr_read(L.host_ctr, actr, 4));
           LANECHK(L, hipStreamSynchronize(st));
           active = L.host_ctr[0];
         } else {
@@ -1035,10 +1045,10 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
               vj.job_list = L.job_list.as<uint32_t>();
               vj.lo_inl_pool = ctx->d_lo_inl_pool.as<uint32_t>();
               vj.lo_queue_g = queues + (size_t)2 * chunk;  // (the general kernels' list: job slots here)
-              LANECHK(L, hipMemsetAsync(actr + 76, 0, 52 + 2 * LANE_CTR_AREA, st));  // ... through k_lo_prepare's hand-out counters (the replay's, in between, are dead here)
+              LANECHK(L, ctr_zero(actr + 64, 64 + 2 * LANE_CTR_AREA));  // from [16] (dead here, like [17] - [18]) through k_lo_prepare's hand-out counters (the replay's, in between, are dead too)
               launch_vp_items_enum(vj, f, st);
               LANECHK(L, hipGetLastError());
-              LANECHK(L, hipMemcpyAsync(host_ctr, actr, 128, hipMemcpyDeviceToHost, st));
+              LANECHK(L, ctr_read(host_ctr, actr, 128));
               LANECHK(L, hipStreamSynchronize(st));
               const uint32_t n_jobs = host_ctr[24];
               if (n_jobs) {
@@ -1046,7 +1056,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
                 vj.n_work = n_jobs;
                 launch_vp_items_inliers(vj, f, nb_heavy, st);
                 LANECHK(L, hipGetLastError());
-                LANECHK(L, hipMemcpyAsync(host_ctr, actr, 128, hipMemcpyDeviceToHost, st));
+                LANECHK(L, ctr_read(host_ctr, actr, 128));
                 LANECHK(L, hipStreamSynchronize(st));
                 launch_vp_local_opt(vj, f, nb_heavy, host_ctr[22], host_ctr[23], st);  // ([19] zeroed above)
                 LANECHK(L, hipGetLastError());
@@ -1060,12 +1070,12 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
             uint32_t* cnt_dev = vp.active_count + 20 + cur;
             // this queue's length [20 + cur], the work counter [16], [22] / [23]: queued problems for the general LO kernels;
             // [17] - [19], the other queue's length (read by the host after the launch that filled it) and [24] are dead here
-            LANECHK(L, hipMemsetAsync(actr + 64, 0, 64 + LANE_CTR_AREA, st));  // ... and the replay's hand-out counters behind them: one fill
+            LANECHK(L, ctr_zero(actr + 64, 64 + LANE_CTR_AREA));  // ... and the replay's hand-out counters behind them: one fill
             vp.lo_queue = queues + (size_t)cur * chunk;
             vp.lo_count = cnt_dev;
             launch_vp_replay_lo(vp, f, std::min<uint32_t>(nb_replay, vp.n_work), mode, st);
             LANECHK(L, hipGetLastError());
-            LANECHK(L, hipMemcpyAsync(host_ctr, actr, 128, hipMemcpyDeviceToHost, st));
+            LANECHK(L, ctr_read(host_ctr, actr, 128));
             LANECHK(L, hipStreamSynchronize(st));
             active = host_ctr[0];
             const uint32_t nq = host_ctr[20 + cur];
@@ -1079,15 +1089,15 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
             L.lo_iters[f]++;
             if (nq <= plan.lo_tail && f != 0) {  // DSM_LO_TAIL_MODE=inline (not for E: its inline solver does not fit the registers)
               // round-2 form of the tail: the wave runs its pair's remaining local optimisations inline, one after the other
-              LANECHK(L, hipMemsetAsync(actr + 64, 0, 4, st));  // work counter [16]
+              LANECHK(L, ctr_zero(actr + 64, 16));  // work counter [16]
               launch_vp_replay_lo(vp, f, std::min<uint32_t>(nb_heavy, nq), 1, st);
               LANECHK(L, hipGetLastError());
-              LANECHK(L, hipMemcpyAsync(host_ctr, actr, 4, hipMemcpyDeviceToHost, st));
+              LANECHK(L, ctr_read(host_ctr, actr, 4));
               LANECHK(L, hipStreamSynchronize(st));
               active = host_ctr[0];
               break;
             }
-            LANECHK(L, hipMemsetAsync(actr + 128 + LANE_CTR_AREA, 0, LANE_CTR_AREA, st));  // k_lo_prepare's hand-out counters
+            LANECHK(L, ctr_zero(actr + 128 + LANE_CTR_AREA, LANE_CTR_AREA));  // k_lo_prepare's hand-out counters
             launch_vp_local_opt(vp, f, nb_heavy, host_ctr[22], host_ctr[23], st);
             LANECHK(L, hipGetLastError());
           }
@@ -1096,7 +1106,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
         if (active == 0) break;
       }
     }
-    LANECHK(L, hipMemsetAsync(actr + 128 + 2 * LANE_CTR_AREA, 0, LANE_CTR_AREA, st));  // k_verify_final's hand-out counters
+    LANECHK(L, ctr_zero(actr + 128 + 2 * LANE_CTR_AREA, LANE_CTR_AREA));  // k_verify_final's hand-out counters
     launch_vp_final(vp, nb_heavy, st);
     LANECHK(L, hipGetLastError());
   }

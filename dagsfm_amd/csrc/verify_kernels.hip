@@ -5072,6 +5072,25 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint
   }
 }
 
+// The lanes' counter traffic as ONE-WAVE kernels.  hipMemcpyAsync (device -> pinned host) and hipMemsetAsync are blit kernels of the
+// runtime with 512- / 256-thread workgroups; a lane issues one after every replay launch, and while the OTHER lane has a kernel in
+// flight that fills every SIMD's register file (k_solve<H>, k_roots_e, k_final_pose, k_prescore_h2: tens of ms each) an eight-wave
+// workgroup never finds its eight slots on one CU free at the same time -- the trace of a config-2 step shows two such 128-byte copies
+// taking 15 - 20 ms and 7 - 16 ms, the lane's chain of short launches parked behind them (profiles/r06_lane_counter_kernels.txt).  A
+// single wave is handed the first slot that frees up (k_lo_jacobi_reg, 512 VGPRs, starts within microseconds in the same situation).
+__global__ __launch_bounds__(64) void k_lane_counters(const uint32_t* src, uint32_t* dst_host, uint32_t n_copy, uint4* zero, uint32_t n_zero16) {
+  const uint32_t lane = threadIdx.x;
+  // read-back first: the copied words may lie inside the zeroed range
+  for (uint32_t i = lane; i < n_copy; i += 64) __hip_atomic_store(dst_host + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  for (uint32_t i = lane; i < n_zero16; i += 64) zero[i] = make_uint4(0u, 0u, 0u, 0u);
+  __threadfence_system();
+}
+void launch_lane_counters(const void* src, uint32_t* dst_host, uint32_t copy_bytes, void* zero, size_t zero_bytes, hipStream_t st) {
+  // zero_bytes is rounded up to 16 (every caller's range ends inside the lane's counter block, which is padded for it)
+  hipLaunchKernelGGL(k_lane_counters, dim3(1), dim3(64), 0, st, static_cast<const uint32_t*>(src), dst_host, copy_bytes / 4u,
+                     static_cast<uint4*>(zero), (uint32_t)((zero_bytes + 15) / 16));
+}
+
 void launch_vp_prep(const VerifyParams& p, uint32_t n_blocks, hipStream_t st) {
   if (!p.n_pairs || !n_blocks) return;
   hipLaunchKernelGGL(k_verify_prep, dim3(n_blocks), dim3(64), 0, st, p);
