@@ -3884,7 +3884,10 @@ __global__ __launch_bounds__(64, (MODE == 1 ? 1 : DSM_REPLAY_WAVES)) void k_repl
 // Same operations on the same values in the same order as k_replay_lo (which stays, modes 0 and 2, as a cross-check schedule of the
 // check build: DSM_REPLAY_LEGACY; mode 1, the inline tail, is still k_replay_lo's).
 #define RP_CAP 256
-#define ITEMS_GROUP 8  // waves (= pairs) per workgroup of k_items_enum (x TAIL_KMAX items = the 64 lanes of the wave that lists the jobs)
+#ifndef ITEMS_GROUP
+#define ITEMS_GROUP 8
+#endif
+// ITEMS_GROUP: waves (= pairs) per workgroup of k_items_enum (x TAIL_KMAX items = the 64 lanes of the wave that lists the jobs)
 #define RP_QL 32  // pairs a wave suspends before it appends them to the queue with ONE atomic (grab_seg's note)
 __host__ __device__ inline size_t rp_lds_bytes(uint32_t cap, uint32_t n_max) {
   return (size_t)cap * 32 + 90 * 8 + 10 * 8 + 12 * 4 + (size_t)((n_max + 63) / 64) * 8 + RP_QL * 4;
@@ -4376,9 +4379,10 @@ __global__ __launch_bounds__(64 * ITEMS_GROUP) void k_items_enum(const VerifyPar
    }
    // the jobs of the group's pairs: job index = item slot (widx * TAIL_KMAX + k), listed compactly for the kernels that follow
    __syncthreads();
-   static_assert(ITEMS_GROUP * TAIL_KMAX == 64, "one lane of the first wave per (pair of the group, item)");
+   static_assert(ITEMS_GROUP * TAIL_KMAX <= 64, "one lane of the first wave per (pair of the group, item)");
    if (q == 0) {
-     const uint32_t qq = (uint32_t)lane / TAIL_KMAX, k = (uint32_t)lane % TAIL_KMAX;
+     const uint32_t qq = ((uint32_t)lane / TAIL_KMAX) % ITEMS_GROUP, k = (uint32_t)lane % TAIL_KMAX;
+     const bool lister = (uint32_t)lane < ITEMS_GROUP * TAIL_KMAX;
      uint32_t before = 0, total = 0;
      for (uint32_t r = 0; r < ITEMS_GROUP; ++r) {
        const uint32_t c = g_n[r];
@@ -4388,7 +4392,7 @@ __global__ __launch_bounds__(64 * ITEMS_GROUP) void k_items_enum(const VerifyPar
      uint32_t base = 0;
      if (lane == 0 && total) base = atomicAdd(p.active_count + 24, total);
      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-     if (k < g_n[qq]) {
+     if (lister && k < g_n[qq]) {
        const uint32_t slot = (w0 + qq) * TAIL_KMAX + k;
        LoJob* j = p.lo_jobs + slot;
        j->pl = g_pl[qq];
