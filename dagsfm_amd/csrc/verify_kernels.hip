@@ -1845,8 +1845,12 @@ DSM_DEV double stage_points_batched(const double* gpts, int n4, double* spts, in
 //             serialise 10^5 same-address atomics at 11.4 ns each); segment s holds hyp_seg_cap entries from s * hyp_seg_cap, its
 //             length is k_sample's hand-out counter s (zeroed at round start, unused by the E / F samplers otherwise).
 // Which lane computes a hypothesis does not enter its result: both grids write the same bytes to the same slots.
+// COMPACT is a template parameter of the kernels, not a run-time branch: on the pair grid pl is the workgroup's (a scalar) and the
+// kernels address the pair's records from a wave-uniform base + lane; behind a run-time branch pl became a vector value on BOTH grids
+// and k_solve_e_lu_reg, which streams 1.6 KB per hypothesis, ran 6.7 instead of 5.6 ms.
+template <bool COMPACT>
 DSM_DEV bool hyp_of_lane(const VerifyParams& p, int fam, uint32_t& pl, int& t) {
-  if (p.hyp_map) {
+  if (COMPACT) {
     const uint32_t s = blockIdx.x % GRAB_SEGS, w = blockIdx.x / GRAB_SEGS;
     const uint32_t cnt = GRAB_SAMPLE(p)[s * GRAB_STRIDE];
     const uint32_t i = w * 64 + threadIdx.x;
@@ -1866,12 +1870,12 @@ DSM_DEV bool hyp_of_lane(const VerifyParams& p, int fam, uint32_t& pl, int& t) {
 // matrix in lane-interleaved LDS; H: ~220 VGPRs) away from the counting loop, which is pure FP64 VALU work
 // with a 9-double model per lane and wants many resident waves; k_score gives every (trial, model) slot its
 // own lane, so a 7-point sample with three roots costs three lanes instead of three passes of its lane.
-template <int FAM>
+template <int FAM, bool COMPACT = false>
 __global__ __launch_bounds__(64, 2) void k_solve(const VerifyParams p) {
   typedef Fam<FAM> F;
   uint32_t pl;
   int t;
-  if (!hyp_of_lane(p, FAM, pl, t)) return;
+  if (!hyp_of_lane<COMPACT>(p, FAM, pl, t)) return;
   const uint32_t pi = p.pair0 + pl;
   const double* pts = p.pts_px + 4 * p.match_off[pi];
   const uint32_t* smp = p.samples + ((size_t)pl * p.batch + t) * 7;
@@ -2646,15 +2650,18 @@ __global__ __launch_bounds__(64, 8) void k_score_needed(const VerifyParams p) {
 #define EPOLY_EB 0
 // the 10 x 20 constraint matrix of trial t of pair pl: blocks of 64 trials interleaved, element e of the trial at block + e * 64 +
 // t % 64 (batch is a multiple of 64)
+template <bool COMPACT>
 DSM_DEV double* e_work_of(const VerifyParams& p, uint32_t pl, int t) {
-  return p.e_work + ((size_t)pl * p.batch + (size_t)(t & ~63)) * 200 + (t & 63);
+  if (COMPACT) return p.e_work + ((size_t)pl * p.batch + (size_t)(t & ~63)) * 200 + (t & 63);
+  return p.e_work + ((size_t)pl * p.batch + (size_t)blockIdx.y * 64) * 200 + threadIdx.x;  // (pair grid: a wave-uniform base + lane)
 }
 #define EPOLY_B 36
 #define EPOLY_COEFFS 75
+template <bool COMPACT>
 __global__ __launch_bounds__(64, 2) void k_solve_e_build(const VerifyParams p) {
   uint32_t pl;
   int t;
-  if (!hyp_of_lane(p, FAM_E, pl, t)) return;
+  if (!hyp_of_lane<COMPACT>(p, FAM_E, pl, t)) return;
   const uint32_t pi = p.pair0 + pl;
   const double* pts = p.pts_norm + 4 * p.match_off[pi];
   const uint32_t* smp = p.samples + ((size_t)pl * p.batch + t) * 7;
@@ -2669,7 +2676,7 @@ __global__ __launch_bounds__(64, 2) void k_solve_e_build(const VerifyParams p) {
   double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
   for (int k = 0; k < 36; ++k) slot[EPOLY_EB + k] = Eb[k];
   // the wave's 64 hypotheses interleaved: element e of lane l at block + e * 64 + l (batch is a multiple of 64)
-  five_point_build_A<64>(Eb, e_work_of(p, pl, t));
+  five_point_build_A<64>(Eb, e_work_of<COMPACT>(p, pl, t));
 }
 
 // A[:, :10].partialPivLu().solve(A[:, 10:]) (essential_matrix.cc:80) with the 10 x 10 factor in lane-interleaved
@@ -2868,8 +2875,8 @@ DSM_DEV void e_lu_body_reg(double* Ag_rw, double* slot) {
 __global__ __launch_bounds__(64, 2) void k_solve_e_lu_reg(const VerifyParams p) {
   uint32_t pl;
   int t;
-  if (!hyp_of_lane(p, FAM_E, pl, t)) return;
-  e_lu_body_reg<64>(e_work_of(p, pl, t), p.models + ((size_t)pl * p.batch + t) * 90);
+  if (!hyp_of_lane<false>(p, FAM_E, pl, t)) return;  // (always the pair grid: launch_vp_solve_score)
+  e_lu_body_reg<64>(e_work_of<false>(p, pl, t), p.models + ((size_t)pl * p.batch + t) * 90);
 }
 __global__ __launch_bounds__(64) void k_solve_e_lu(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -2877,8 +2884,8 @@ __global__ __launch_bounds__(64) void k_solve_e_lu(const VerifyParams p) {
   unsigned char* idx = smem_raw + 100 * 64 * 8 + threadIdx.x;  // idx[i*64]: original row now in row i
   uint32_t pl;
   int t;
-  if (!hyp_of_lane(p, FAM_E, pl, t)) return;
-  e_lu_body<64>(e_work_of(p, pl, t), p.models + ((size_t)pl * p.batch + t) * 90, Al, idx);
+  if (!hyp_of_lane<false>(p, FAM_E, pl, t)) return;
+  e_lu_body<64>(e_work_of<false>(p, pl, t), p.models + ((size_t)pl * p.batch + t) * 90, Al, idx);
 }
 
 // slot coefficients -> slot roots (real parts); returns the code for nmodels: bits 0..9 root i is real
@@ -2920,10 +2927,11 @@ DSM_DEV int e_models_body(const double* slot, int code, double* out) {
 
 // roots of the determinant polynomial and the essential matrices of its real roots: slot (Eb, B, coefficients) ->
 // slot models + nmodels for k_models_score_e
+template <bool COMPACT>
 __global__ __launch_bounds__(64, 2) void k_roots_e(const VerifyParams p) {
   uint32_t pl;
   int t;
-  if (!hyp_of_lane(p, FAM_E, pl, t)) return;
+  if (!hyp_of_lane<COMPACT>(p, FAM_E, pl, t)) return;
   // roots, then the models of the real roots in place of the hypothesis' record (its inputs are in registers by then)
   double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
   const int code = e_roots_body(slot);
@@ -2932,12 +2940,13 @@ __global__ __launch_bounds__(64, 2) void k_roots_e(const VerifyParams p) {
 #ifdef DSM_CHECK_BUILD  // cross-check schedule: libdagsfm_mi355x_check.so only
 // The round-2 form of the same kernel, kept for comparison (DSM_ROOTS_LDS=1): the companion matrix of every lane in
 // lane-interleaved LDS (51 KB per wave), dynamically indexed.
+template <bool COMPACT>
 __global__ __launch_bounds__(64) void k_roots_e_lds(const VerifyParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* Tl = reinterpret_cast<double*>(smem_raw) + threadIdx.x;  // this lane's companion matrix, stride 64
   uint32_t pl;
   int t;
-  if (!hyp_of_lane(p, FAM_E, pl, t)) return;
+  if (!hyp_of_lane<COMPACT>(p, FAM_E, pl, t)) return;
   double* slot = p.models + ((size_t)pl * p.batch + t) * 90;
   double coeffs[11], rr[11], ri[11];
   for (int k = 0; k < 11; ++k) coeffs[k] = slot[EPOLY_COEFFS + k];
@@ -5115,21 +5124,28 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
   // the bound steps with an f32 first stage: the points as f32 (16 bytes each, padded to a pair) + the lanes' lists of band points
   const size_t smem_c2 = (size_t)(p.n_max < VP_LDS_PTS ? (p.n_max > 0 ? p.n_max : 1) : VP_LDS_PTS) * 16 + 32 + (size_t)PRESCORE_LIST_CAP * 64 * 2;
   if (fam == FAM_E) {
-    hipLaunchKernelGGL(k_solve_e_build, grid_hyp, dim3(64), 0, st, p);
+    if (p.hyp_map)
+      hipLaunchKernelGGL(k_solve_e_build<true>, grid_hyp, dim3(64), 0, st, p);
+    else
+      hipLaunchKernelGGL(k_solve_e_build<false>, grid, dim3(64), 0, st, p);
     // (the elimination stays on the pair grid: it streams the 1.6 KB of e_work per hypothesis from a wave-uniform base + lane, and with a
     // base per lane it was 14 % slower -- 6.4 vs 5.6 ms per step at config 2 -- for the sixth of its lanes the compact grid would fill)
-    VerifyParams pg = p;
-    pg.hyp_map = nullptr;
     if (p.dbg_elu_lds)  // check build, DSM_ELU_LDS: the elimination in lane-interleaved LDS (rounds 2 - 5)
-      hipLaunchKernelGGL(k_solve_e_lu, grid, dim3(64), ELU_SMEM, st, pg);
+      hipLaunchKernelGGL(k_solve_e_lu, grid, dim3(64), ELU_SMEM, st, p);
     else
-      hipLaunchKernelGGL(k_solve_e_lu_reg, grid, dim3(64), 0, st, pg);
+      hipLaunchKernelGGL(k_solve_e_lu_reg, grid, dim3(64), 0, st, p);
 #ifdef DSM_CHECK_BUILD
-    if (p.dbg_roots_lds != 0)
-      hipLaunchKernelGGL(k_roots_e_lds, grid_hyp, dim3(64), 100 * 64 * sizeof(double), st, p);
-    else
+    if (p.dbg_roots_lds != 0) {
+      if (p.hyp_map)
+        hipLaunchKernelGGL(k_roots_e_lds<true>, grid_hyp, dim3(64), 100 * 64 * sizeof(double), st, p);
+      else
+        hipLaunchKernelGGL(k_roots_e_lds<false>, grid, dim3(64), 100 * 64 * sizeof(double), st, p);
+    } else
 #endif
-      hipLaunchKernelGGL(k_roots_e, grid_hyp, dim3(64), 0, st, p);
+    if (p.hyp_map)
+      hipLaunchKernelGGL(k_roots_e<true>, grid_hyp, dim3(64), 0, st, p);
+    else
+      hipLaunchKernelGGL(k_roots_e<false>, grid, dim3(64), 0, st, p);
     // scoring: a lane per model (k_prescore_compact<E> -> k_score_needed<E>), or the wave-per-hypothesis kernel with the bound step fused in
     // (DSM_SCORE_PREFILTER=3; also what =0 runs, without its bound step)
     const size_t smem2e = smem + (size_t)p.batch * 10 * 2;
@@ -5155,7 +5171,10 @@ void launch_vp_solve_score(const VerifyParams& p, int fam, hipStream_t st) {
   // fit 16-bit indices and, with the points, the LDS
   const uint32_t nb_needed = p.n_chunk < 256u * 32u ? p.n_chunk : 256u * 32u;
   if (fam == FAM_F) {
-    hipLaunchKernelGGL(k_solve<FAM_F>, grid_hyp, dim3(64), 0, st, p);
+    if (p.hyp_map)
+      hipLaunchKernelGGL((k_solve<FAM_F, true>), grid_hyp, dim3(64), 0, st, p);
+    else
+      hipLaunchKernelGGL((k_solve<FAM_F, false>), grid, dim3(64), 0, st, p);
     const size_t smem2 = smem + (size_t)p.batch * 3 * 2;
     if (p.score_prefilter && p.batch * 3 <= 65535 && smem2 <= 64 * 1024) {
       if (p.score_prefilter & 2)  // DSM_SCORE_PREFILTER=3: a lane per slot
