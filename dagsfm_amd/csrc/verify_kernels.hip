@@ -3589,11 +3589,15 @@ __global__ __launch_bounds__(64, (FAM == FAM_E ? 1 : 2)) void k_replay(const Ver
 
 // Which problems k_lo_prepare_reg takes: a tall matrix (more than nine constraint rows) whose rows fit the lanes'
 // registers -- up to LOP_PPL inliers per lane.
-#define LOP_PPL 6  // 384 inliers; beyond that (and for H) the general kernel
+#define LOP_PPL 6  // E / F: 384 inliers; beyond that the general kernel
+// H: ONE inlier, two rows per lane -- up to 64 inliers, which is every local optimisation of a non-planar scene (its best homographies
+// hold 7 - 30 of 256 matches).  (Round 3 measured the register form for H with LOP_PPL = 6 -- twelve rows per lane, 288 shuffles to
+// deal the rows out -- slower than k_lo_prepare and left H to the general kernel; with one slot the same code is 9 x 2 doubles per lane.)
+#define LOP_PPL_H 1
 template <int FAM>
 __host__ __device__ inline bool lo_prepare_in_registers(int ninl) {
   const int m = FAM == FAM_H ? 2 * ninl : ninl;
-  return FAM != FAM_H && m > 9 && ninl <= 64 * LOP_PPL;  // H (2n rows, 8 per lane) measured slower than k_lo_prepare
+  return m > 9 && ninl <= 64 * (FAM == FAM_H ? LOP_PPL_H : LOP_PPL);
 }
 
 // ------------------------------------------------------------------------------------ replay with batched local optimisation
@@ -3795,7 +3799,7 @@ __global__ __launch_bounds__(64, (MODE == 1 ? 1 : DSM_REPLAY_WAVES)) void k_repl
                   fs->lo_wait = 1;
                   fs->lo_ninl = (uint32_t)ninl;
                   p.lo_queue[atomicAdd(p.lo_count, 1u)] = pl;
-                  if (FAM != FAM_H && !(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) p.lo_queue_g[atomicAdd(p.active_count + 22, 1u)] = pl;
+                  if (!(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) p.lo_queue_g[atomicAdd(p.active_count + 22, 1u)] = pl;
                   if ((FAM == FAM_H ? 2 * ninl : ninl) < 9) atomicAdd(p.active_count + 23, 1u);
                 }
                 suspended = true;
@@ -4168,7 +4172,7 @@ __global__ __launch_bounds__(64, DSM_REPLAY_WAVES) void k_replay_rp(const Verify
                 fs->lo_ninl = (uint32_t)ninl;
                 L.ql[q_n] = pl;
               }
-              if (FAM != FAM_H && !(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) q_gmask |= 1u << q_n;  // (H: the whole queue takes k_lo_prepare)
+              if (!(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) q_gmask |= 1u << q_n;
               if ((FAM == FAM_H ? 2 * ninl : ninl) < 9) q_small += 1;
               q_n += 1;
               suspended = true;
@@ -4468,7 +4472,7 @@ __global__ __launch_bounds__(64, 4) void k_items_inliers(const VerifyParams p) {
       if (lane == 0) j->ninl = (uint32_t)ninl;
     }
     if (lane == 0) {
-      if (FAM != FAM_H && !(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) p.lo_queue_g[atomicAdd(p.active_count + 22, 1u)] = slot;
+      if (!(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) p.lo_queue_g[atomicAdd(p.active_count + 22, 1u)] = slot;
       if ((FAM == FAM_H ? 2 * ninl : ninl) < 9) atomicAdd(p.active_count + 23, 1u);
     }
   }
@@ -4581,7 +4585,7 @@ DSM_DEV double lds_chain_sum(const double* v, int stride, int n) {
 }
 template <int FAM>
 __global__ __launch_bounds__(64) void k_lo_prepare_reg(const VerifyParams p) {
-  constexpr int PPL = LOP_PPL;
+  constexpr int PPL = FAM == FAM_H ? LOP_PPL_H : LOP_PPL;
   constexpr int RPL = FAM == FAM_H ? 2 * PPL : PPL;
   __shared__ double lo_prep_lds[FAM == FAM_E ? 1 : 64 * PPL * 4];  // the operands of the normalisation's in-order sums (F, H)
   const int lane = threadIdx.x;
@@ -5070,12 +5074,12 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint
 #endif
     hipLaunchKernelGGL(k_lo_finish<FAM_F>, g64, dim3(64), 0, st, p);
   }
-  if (fam == FAM_H) {  // every H problem takes the general prepare: its list IS the queue (nobody appends to lo_queue_g for H)
-    const uint32_t nb_h = p.n_work < n_blocks ? p.n_work : n_blocks;
-    hipLaunchKernelGGL(k_lo_prepare<FAM_H>, dim3(nb_h), dim3(64), 0, st, p);
+  if (fam == FAM_H) {
+    if (reg_prepare) hipLaunchKernelGGL(k_lo_prepare_reg<FAM_H>, dim3(p.n_work), dim3(64), 0, st, p);
+    if (n_wave_prepare) hipLaunchKernelGGL(k_lo_prepare<FAM_H>, dim3(nb_prep), dim3(64), 0, st, pg);
     if (reg_jacobi) {
       hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
-      if (n_small_jacobi) hipLaunchKernelGGL((k_lo_jacobi<FAM_H, true>), dim3((p.n_work + 64 / LOJ_G - 1) / (64 / LOJ_G)), dim3(64), 0, st, p);
+      if (n_small_jacobi) hipLaunchKernelGGL((k_lo_jacobi<FAM_H, true>), g4g, dim3(64), 0, st, pg);
     }
 #ifdef DSM_CHECK_BUILD
     else

@@ -21,7 +21,9 @@ one is compared with the product's `batched` records -- so the comparison also s
     the replay scans of rounds 2 - 5, k_replay_lo<fam, 0 / 2>, points and residuals through global memory; the product's k_replay_rp
     keeps the pair in LDS), elu_lds (DSM_ELU_LDS: the 5-point solver's 10 x 10 elimination in lane-interleaved LDS, rounds 2 - 5; the
     product's k_solve_e_lu_reg keeps the matrix in registers), hyp_pair_grid (DSM_HYP_GRID=pair: the lane-per-hypothesis solvers of E / F on the
-    (pair, 64 trials) grid in every round; the product's take the hypotheses of later rounds 64 per wave across the pairs)
+    (pair, 64 trials) grid in every round; the product's take the hypotheses of later rounds 64 per wave across the pairs), lo_prepare_wave
+    (DSM_LO_PREPARE_WAVE: every local optimisation's design matrix + pivoted QR by the general kernel k_lo_prepare, matrix in memory; the
+    product's k_lo_prepare_reg keeps it in registers for E / F up to 384 inliers and H up to 64)
 This exercises the paths too rare for the oracle-sized tests (a Lemire rejection in the sampler happens for a few
 dozen pairs of config 2; pairs with > 15 local optimisations in one round).
 
@@ -69,6 +71,9 @@ def run(ctx, opts, schedule):
     os.environ.pop("DSM_ELU_LDS", None)
     if schedule == "elu_lds":
         os.environ["DSM_ELU_LDS"] = "1"
+    os.environ.pop("DSM_LO_PREPARE_WAVE", None)
+    if schedule == "lo_prepare_wave":
+        os.environ["DSM_LO_PREPARE_WAVE"] = "1"
     os.environ.pop("DSM_HYP_GRID", None)
     if schedule == "hyp_pair_grid":
         os.environ["DSM_HYP_GRID"] = "pair"
@@ -107,8 +112,8 @@ def main():
     opts = capi.default_two_view_options()
     r0 = run(ctxs[False], opts, "batched")
     ok = True
-    CHECK_ONLY = ("no_prefilter", "e_fused", "final_1wave", "legacy", "h_mfma", "h_f64", "ef_f64", "replay_legacy", "elu_lds", "hyp_pair_grid")
-    for name in ["batched_check_build", "replay_legacy", "elu_lds", "hyp_pair_grid", "no_prefilter", "e_fused", "h_mfma", "h_f64", "ef_f64", "one_lane", "no_tail", "tail_inline", "final_1wave", "inline"] + (["legacy"] if a.legacy else []):
+    CHECK_ONLY = ("no_prefilter", "e_fused", "final_1wave", "legacy", "h_mfma", "h_f64", "ef_f64", "replay_legacy", "elu_lds", "hyp_pair_grid", "lo_prepare_wave")
+    for name in ["batched_check_build", "replay_legacy", "elu_lds", "hyp_pair_grid", "lo_prepare_wave", "no_prefilter", "e_fused", "h_mfma", "h_f64", "ef_f64", "one_lane", "no_tail", "tail_inline", "final_1wave", "inline"] + (["legacy"] if a.legacy else []):
         use_check = name in CHECK_ONLY or name == "batched_check_build"
         r1 = run(ctxs[use_check], opts, "batched" if name == "batched_check_build" else name)
         for k in capi.CHECK_OPTION_KEYS:  # the product context must not see a check-only switch

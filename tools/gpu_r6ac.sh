@@ -19,7 +19,7 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('shard 3/8:', round(d['value']), round(d['ms_per_step'],1), 'verify', d['kernel_ms_per_step'].get('k_verify_pairs'))"
 timeout 1200 python tools/check_schedules.py > $out/check_schedules.txt 2>&1
 timeout 600 python tools/check_schedules.py --images 150 --outlier-frac 0.5 >> $out/check_schedules.txt 2>&1
-timeout 600 python tools/check_schedules.py --images 200 --uncalibrated >> $out/check_schedules.txt 2>&1; grep -c "identical: True" $out/check_schedules.txt; grep -c "identical: False" $out/check_schedules.txt; grep "hyp_pair_grid\|batched_check_build" $out/check_schedules.txt
+timeout 600 python tools/check_schedules.py --images 200 --uncalibrated >> $out/check_schedules.txt 2>&1; grep -c "identical: True" $out/check_schedules.txt; grep -c "identical: False" $out/check_schedules.txt; grep "hyp_pair_grid\|batched_check_build\|lo_prepare_wave" $out/check_schedules.txt
 (cd /tmp && DSM_VERIFY_LANES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof1 -o bench -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-second-regime --no-config3 --no-extra-configs > /dev/null 2> $R/$out/rocprof1.err)
 find $out/prof1 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/verify_kernel_stats_1lane.csv
 rm -rf $out/prof1
