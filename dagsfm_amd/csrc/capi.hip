@@ -992,12 +992,12 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
       for (uint32_t round = 0; round < 100000; ++round) {
         // counters of the lane (uint32 at actr): [0] pairs still active after the round, [16] replay work counter, [17]
         // k_verify_final's, [18] k_sample's, [19] k_lo_prepare's, [20] / [21] lengths of the two alternating queues, [22] /
-        // [23] problems for the general LO kernels, [24] jobs of an item pass.  Every launch below finds its counters zeroed;
+        // [23] problems for the general LO kernels, [24] jobs of an item pass, [25] problems for the larger register prepare.  Every launch below finds its counters zeroed;
         // counters that are dead at that point are zeroed along with them, so that each phase costs ONE fill, not one per
         // counter (a fill is a kernel launch: 33 of them made 0.7 ms of the 8.7 ms a 1 225-pair list takes)
         if (vp.stats) {  // DSM_VERIFY_DEBUG keeps its statistics in [1] - [13] across the rounds
           LANECHK(L, hipMemsetAsync(actr - LANE_CTR_AREA, 0, LANE_CTR_AREA + 4, st));
-          LANECHK(L, hipMemsetAsync(actr + 64, 0, 36, st));
+          LANECHK(L, hipMemsetAsync(actr + 64, 0, 40, st));  // [16] - [25]
         } else {
           LANECHK(L, ctr_zero(actr - LANE_CTR_AREA, LANE_CTR_AREA + 112));  // round start: k_sample's hand-out counters and [0] are live, the rest ([1] - [27]) is dead here
         }
@@ -1058,7 +1058,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
                 LANECHK(L, hipGetLastError());
                 LANECHK(L, ctr_read(host_ctr, actr, 128));
                 LANECHK(L, hipStreamSynchronize(st));
-                launch_vp_local_opt(vj, f, nb_heavy, host_ctr[22], host_ctr[23], st);  // ([19] zeroed above)
+                launch_vp_local_opt(vj, f, nb_heavy, host_ctr[22], host_ctr[23], host_ctr[25], st);  // ([19] zeroed above)
                 LANECHK(L, hipGetLastError());
                 launch_vp_items_outcome(vj, f, nb_heavy, st);
                 LANECHK(L, hipGetLastError());
@@ -1098,7 +1098,7 @@ static void verify_lane_run(dsm_ctx* ctx, uint32_t li, VerifyParams vp, VerifyPl
               break;
             }
             LANECHK(L, ctr_zero(actr + 128 + LANE_CTR_AREA, LANE_CTR_AREA));  // k_lo_prepare's hand-out counters
-            launch_vp_local_opt(vp, f, nb_heavy, host_ctr[22], host_ctr[23], st);
+            launch_vp_local_opt(vp, f, nb_heavy, host_ctr[22], host_ctr[23], host_ctr[25], st);
             LANECHK(L, hipGetLastError());
           }
         }

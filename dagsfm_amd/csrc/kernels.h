@@ -233,7 +233,7 @@ void launch_vp_items_inliers(const VerifyParams& p, int fam, uint32_t n_blocks, 
 void launch_vp_items_outcome(const VerifyParams& p, int fam, uint32_t n_blocks, hipStream_t st);
 // over p.worklist / p.n_work; n_wave_prepare / n_small_jacobi: how many of the queued problems need the general kernels
 // (k_lo_prepare: not register-preparable; k_lo_jacobi: smaller than 9 x 9), counted by k_replay_lo at [22] / [23]
-void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint32_t n_wave_prepare, uint32_t n_small_jacobi, hipStream_t st);
+void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint32_t n_wave_prepare, uint32_t n_small_jacobi, uint32_t n_big_prepare, hipStream_t st);
 void launch_lane_counters(const void* src, uint32_t* dst_host, uint32_t copy_bytes, void* zero, size_t zero_bytes, hipStream_t st);
 uint32_t vp_batch(int fam, uint32_t max_trials, uint32_t min_trials);
 uint32_t vp_maxm(int fam);

@@ -3599,6 +3599,14 @@ __host__ __device__ inline bool lo_prepare_in_registers(int ninl) {
   const int m = FAM == FAM_H ? 2 * ninl : ninl;
   return m > 9 && ninl <= 64 * (FAM == FAM_H ? LOP_PPL_H : LOP_PPL);
 }
+// E / F: the register kernel exists in two sizes -- LOP_PPL_SMALL inliers per lane (192: 54 instead of 108 registers of matrix, three waves
+// per SIMD instead of two, 15 % faster per problem) and LOP_PPL for the problems beyond that, which the replay counts ([25]) so that the
+// second launch only happens when it has work
+#define LOP_PPL_SMALL 3
+template <int FAM>
+__host__ __device__ inline bool lo_prepare_big(int ninl) {
+  return FAM != FAM_H && lo_prepare_in_registers<FAM>(ninl) && ninl > 64 * LOP_PPL_SMALL;
+}
 
 // ------------------------------------------------------------------------------------ replay with batched local optimisation
 // k_replay runs a pair's local optimisations inline: ONE problem on a 64-lane wave, most of it scalar chains
@@ -3801,6 +3809,7 @@ __global__ __launch_bounds__(64, (MODE == 1 ? 1 : DSM_REPLAY_WAVES)) void k_repl
                   p.lo_queue[atomicAdd(p.lo_count, 1u)] = pl;
                   if (!(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) p.lo_queue_g[atomicAdd(p.active_count + 22, 1u)] = pl;
                   if ((FAM == FAM_H ? 2 * ninl : ninl) < 9) atomicAdd(p.active_count + 23, 1u);
+                  if (p.lo_reg_prepare && lo_prepare_big<FAM>(ninl)) atomicAdd(p.active_count + 25, 1u);
                 }
                 suspended = true;
                 break;
@@ -3981,7 +3990,7 @@ __global__ __launch_bounds__(64, DSM_REPLAY_WAVES) void k_replay_rp(const Verify
   SegGrab wgrab;
   const uint32_t grain = work_grain(p.n_work);
   // what this wave owes the lane's counters: appended / added with one atomic each when the list is full and at the end
-  uint32_t q_n = 0, q_gmask = 0, q_small = 0, n_active = 0;
+  uint32_t q_n = 0, q_gmask = 0, q_small = 0, q_big = 0, n_active = 0;
   auto flush_queue = [&]() {
     wv_sync();
     uint32_t base = 0, base_g = 0;
@@ -3989,6 +3998,7 @@ __global__ __launch_bounds__(64, DSM_REPLAY_WAVES) void k_replay_rp(const Verify
       base = atomicAdd(p.lo_count, q_n);
       if (q_gmask) base_g = atomicAdd(p.active_count + 22, (uint32_t)__popc(q_gmask));
       if (q_small) atomicAdd(p.active_count + 23, q_small);
+      if (q_big) atomicAdd(p.active_count + 25, q_big);
     }
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     base_g = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_g);
@@ -4000,6 +4010,7 @@ __global__ __launch_bounds__(64, DSM_REPLAY_WAVES) void k_replay_rp(const Verify
     q_n = 0;
     q_gmask = 0;
     q_small = 0;
+    q_big = 0;
     wv_sync();
   };
   for (;;) {
@@ -4174,6 +4185,7 @@ __global__ __launch_bounds__(64, DSM_REPLAY_WAVES) void k_replay_rp(const Verify
               }
               if (!(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) q_gmask |= 1u << q_n;
               if ((FAM == FAM_H ? 2 * ninl : ninl) < 9) q_small += 1;
+              if (p.lo_reg_prepare && lo_prepare_big<FAM>(ninl)) q_big += 1;
               q_n += 1;
               suspended = true;
               break;
@@ -4474,6 +4486,7 @@ __global__ __launch_bounds__(64, 4) void k_items_inliers(const VerifyParams p) {
     if (lane == 0) {
       if (!(p.lo_reg_prepare && lo_prepare_in_registers<FAM>(ninl))) p.lo_queue_g[atomicAdd(p.active_count + 22, 1u)] = slot;
       if ((FAM == FAM_H ? 2 * ninl : ninl) < 9) atomicAdd(p.active_count + 23, 1u);
+      if (p.lo_reg_prepare && lo_prepare_big<FAM>(ninl)) atomicAdd(p.active_count + 25, 1u);
     }
   }
 }
@@ -4583,9 +4596,8 @@ DSM_DEV double lds_chain_sum(const double* v, int stride, int n) {
   for (; k < n; ++k) s += v[k * stride];
   return s;
 }
-template <int FAM>
+template <int FAM, int PPL>
 __global__ __launch_bounds__(64) void k_lo_prepare_reg(const VerifyParams p) {
-  constexpr int PPL = FAM == FAM_H ? LOP_PPL_H : LOP_PPL;
   constexpr int RPL = FAM == FAM_H ? 2 * PPL : PPL;
   __shared__ double lo_prep_lds[FAM == FAM_E ? 1 : 64 * PPL * 4];  // the operands of the normalisation's in-order sums (F, H)
   const int lane = threadIdx.x;
@@ -4595,6 +4607,7 @@ __global__ __launch_bounds__(64) void k_lo_prepare_reg(const VerifyParams p) {
   const uint32_t pi = p.pair0 + ref.pl;
   const int ninl = ref.ninl;
   if (!lo_prepare_in_registers<FAM>(ninl)) return;
+  if (FAM != FAM_H && lo_prepare_big<FAM>(ninl) != (PPL == LOP_PPL)) return;  // the other size's
   const uint64_t moff = p.match_off[pi];
   const double* pts = (FAM == FAM_E ? p.pts_norm : p.pts_px) + 4 * moff;
   const int* inl = ref.inl;
@@ -5026,7 +5039,7 @@ void launch_vp_items_outcome(const VerifyParams& p, int fam, uint32_t n_blocks, 
   if (fam == FAM_H) hipLaunchKernelGGL(k_items_outcome<FAM_H>, dim3(nb), dim3(64), 0, st, p);
 }
 void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint32_t n_wave_prepare, uint32_t n_small_jacobi,
-                         hipStream_t st) {
+                         uint32_t n_big_prepare, hipStream_t st) {
   if (!p.n_work || !n_blocks) return;
   const dim3 g4((p.n_work + 64 / LOJ_G - 1) / (64 / LOJ_G)), g64((p.n_work + 63) / 64);
 #ifdef DSM_CHECK_BUILD
@@ -5044,7 +5057,8 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint
   const uint32_t nb_prep = pg.n_work < n_blocks ? pg.n_work : n_blocks;  // one scratch area per workgroup (wg_scratch)
   const dim3 g4g((pg.n_work + 64 / LOJ_G - 1) / (64 / LOJ_G));
   if (fam == FAM_E) {
-    if (reg_prepare) hipLaunchKernelGGL(k_lo_prepare_reg<FAM_E>, dim3(p.n_work), dim3(64), 0, st, p);
+    if (reg_prepare && n_big_prepare < p.n_work) hipLaunchKernelGGL((k_lo_prepare_reg<FAM_E, LOP_PPL_SMALL>), dim3(p.n_work), dim3(64), 0, st, p);
+    if (reg_prepare && n_big_prepare) hipLaunchKernelGGL((k_lo_prepare_reg<FAM_E, LOP_PPL>), dim3(p.n_work), dim3(64), 0, st, p);
     if (n_wave_prepare) hipLaunchKernelGGL(k_lo_prepare<FAM_E>, dim3(nb_prep), dim3(64), 0, st, pg);
     if (reg_jacobi) {
       hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
@@ -5062,7 +5076,8 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint
     hipLaunchKernelGGL(k_lo_e_roots_models, g64, dim3(64), 0, st, p);
   }
   if (fam == FAM_F) {
-    if (reg_prepare) hipLaunchKernelGGL(k_lo_prepare_reg<FAM_F>, dim3(p.n_work), dim3(64), 0, st, p);
+    if (reg_prepare && n_big_prepare < p.n_work) hipLaunchKernelGGL((k_lo_prepare_reg<FAM_F, LOP_PPL_SMALL>), dim3(p.n_work), dim3(64), 0, st, p);
+    if (reg_prepare && n_big_prepare) hipLaunchKernelGGL((k_lo_prepare_reg<FAM_F, LOP_PPL>), dim3(p.n_work), dim3(64), 0, st, p);
     if (n_wave_prepare) hipLaunchKernelGGL(k_lo_prepare<FAM_F>, dim3(nb_prep), dim3(64), 0, st, pg);
     if (reg_jacobi) {
       hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
@@ -5075,7 +5090,7 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint
     hipLaunchKernelGGL(k_lo_finish<FAM_F>, g64, dim3(64), 0, st, p);
   }
   if (fam == FAM_H) {
-    if (reg_prepare) hipLaunchKernelGGL(k_lo_prepare_reg<FAM_H>, dim3(p.n_work), dim3(64), 0, st, p);
+    if (reg_prepare) hipLaunchKernelGGL((k_lo_prepare_reg<FAM_H, LOP_PPL_H>), dim3(p.n_work), dim3(64), 0, st, p);
     if (n_wave_prepare) hipLaunchKernelGGL(k_lo_prepare<FAM_H>, dim3(nb_prep), dim3(64), 0, st, pg);
     if (reg_jacobi) {
       hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);
