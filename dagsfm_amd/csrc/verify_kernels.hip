@@ -3594,18 +3594,21 @@ __global__ __launch_bounds__(64, (FAM == FAM_E ? 1 : 2)) void k_replay(const Ver
 // hold 7 - 30 of 256 matches).  (Round 3 measured the register form for H with LOP_PPL = 6 -- twelve rows per lane, 288 shuffles to
 // deal the rows out -- slower than k_lo_prepare and left H to the general kernel; with one slot the same code is 9 x 2 doubles per lane.)
 #define LOP_PPL_H 1
+// ... and three inliers = six rows per lane (the register footprint of E / F at LOP_PPL) for the homographies of PLANAR scenes: up to 192
+// inliers; beyond that the general kernel
+#define LOP_PPL_H_BIG 3
 template <int FAM>
 __host__ __device__ inline bool lo_prepare_in_registers(int ninl) {
   const int m = FAM == FAM_H ? 2 * ninl : ninl;
-  return m > 9 && ninl <= 64 * (FAM == FAM_H ? LOP_PPL_H : LOP_PPL);
+  return m > 9 && ninl <= 64 * (FAM == FAM_H ? LOP_PPL_H_BIG : LOP_PPL);
 }
-// E / F: the register kernel exists in two sizes -- LOP_PPL_SMALL inliers per lane (192: 54 instead of 108 registers of matrix, three waves
+// The register kernel exists in two sizes per family -- E / F: LOP_PPL_SMALL inliers per lane (192: 54 instead of 108 registers of matrix, three waves
 // per SIMD instead of two, 15 % faster per problem) and LOP_PPL for the problems beyond that, which the replay counts ([25]) so that the
 // second launch only happens when it has work
 #define LOP_PPL_SMALL 3
 template <int FAM>
 __host__ __device__ inline bool lo_prepare_big(int ninl) {
-  return FAM != FAM_H && lo_prepare_in_registers<FAM>(ninl) && ninl > 64 * LOP_PPL_SMALL;
+  return lo_prepare_in_registers<FAM>(ninl) && ninl > 64 * (FAM == FAM_H ? LOP_PPL_H : LOP_PPL_SMALL);
 }
 
 // ------------------------------------------------------------------------------------ replay with batched local optimisation
@@ -4607,7 +4610,7 @@ __global__ __launch_bounds__(64) void k_lo_prepare_reg(const VerifyParams p) {
   const uint32_t pi = p.pair0 + ref.pl;
   const int ninl = ref.ninl;
   if (!lo_prepare_in_registers<FAM>(ninl)) return;
-  if (FAM != FAM_H && lo_prepare_big<FAM>(ninl) != (PPL == LOP_PPL)) return;  // the other size's
+  if (lo_prepare_big<FAM>(ninl) != (PPL == (FAM == FAM_H ? LOP_PPL_H_BIG : LOP_PPL))) return;  // the other size's
   const uint64_t moff = p.match_off[pi];
   const double* pts = (FAM == FAM_E ? p.pts_norm : p.pts_px) + 4 * moff;
   const int* inl = ref.inl;
@@ -5090,7 +5093,8 @@ void launch_vp_local_opt(const VerifyParams& p, int fam, uint32_t n_blocks, uint
     hipLaunchKernelGGL(k_lo_finish<FAM_F>, g64, dim3(64), 0, st, p);
   }
   if (fam == FAM_H) {
-    if (reg_prepare) hipLaunchKernelGGL((k_lo_prepare_reg<FAM_H, LOP_PPL_H>), dim3(p.n_work), dim3(64), 0, st, p);
+    if (reg_prepare && n_big_prepare < p.n_work) hipLaunchKernelGGL((k_lo_prepare_reg<FAM_H, LOP_PPL_H>), dim3(p.n_work), dim3(64), 0, st, p);
+    if (reg_prepare && n_big_prepare) hipLaunchKernelGGL((k_lo_prepare_reg<FAM_H, LOP_PPL_H_BIG>), dim3(p.n_work), dim3(64), 0, st, p);
     if (n_wave_prepare) hipLaunchKernelGGL(k_lo_prepare<FAM_H>, dim3(nb_prep), dim3(64), 0, st, pg);
     if (reg_jacobi) {
       hipLaunchKernelGGL(k_lo_jacobi_reg, g64, dim3(64), 0, st, p);

@@ -93,9 +93,10 @@ def main():
     ap.add_argument("--feats", type=int, default=4096)
     ap.add_argument("--legacy", action="store_true", help="also run the (slow) single-kernel-per-family schedule")
     ap.add_argument("--outlier-frac", type=float, default=0.2, help="0.5: the 0.25-inlier-ratio regime (thousands of trials per pair)")
+    ap.add_argument("--planar", action="store_true", help="a planar scene: H is the model, its local optimisations have hundreds of inliers")
     ap.add_argument("--uncalibrated", action="store_true", help="cameras without a focal-length prior: the F + H path of the decision tree")
     a = ap.parse_args()
-    scene = synthetic.Scene(a.images, a.feats, seed=0, outlier_frac=a.outlier_frac)
+    scene = synthetic.Scene(a.images, a.feats, seed=0, outlier_frac=a.outlier_frac, planar=a.planar)
     ims = [scene.image(i) for i in range(a.images)]
     pairs = synthetic.exhaustive_pairs(a.images)
     for k in capi.CHECK_OPTION_KEYS:
