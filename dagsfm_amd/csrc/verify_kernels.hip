@@ -3606,6 +3606,9 @@ __host__ __device__ inline bool lo_prepare_in_registers(int ninl) {
 // per SIMD instead of two, 15 % faster per problem) and LOP_PPL for the problems beyond that, which the replay counts ([25]) so that the
 // second launch only happens when it has work
 #define LOP_PPL_SMALL 3
+#ifndef LOP_SMALL_WAVES
+#define LOP_SMALL_WAVES 3
+#endif
 template <int FAM>
 __host__ __device__ inline bool lo_prepare_big(int ninl) {
   return lo_prepare_in_registers<FAM>(ninl) && ninl > 64 * (FAM == FAM_H ? LOP_PPL_H : LOP_PPL_SMALL);
@@ -4600,7 +4603,7 @@ DSM_DEV double lds_chain_sum(const double* v, int stride, int n) {
   return s;
 }
 template <int FAM, int PPL>
-__global__ __launch_bounds__(64) void k_lo_prepare_reg(const VerifyParams p) {
+__global__ __launch_bounds__(64, (FAM == FAM_H ? 2 * PPL : PPL) <= 3 ? LOP_SMALL_WAVES : 2) void k_lo_prepare_reg(const VerifyParams p) {  // (three waves per SIMD for the small sizes: 173 / 185 VGPRs left to itself)
   constexpr int RPL = FAM == FAM_H ? 2 * PPL : PPL;
   __shared__ double lo_prep_lds[FAM == FAM_E ? 1 : 64 * PPL * 4];  // the operands of the normalisation's in-order sums (F, H)
   const int lane = threadIdx.x;
