@@ -2533,8 +2533,11 @@ __global__ __launch_bounds__(64, 4) void k_prescore_h_mfma(const VerifyParams p)
 #endif  // DSM_CHECK_BUILD
 
 // dynamic LDS: the points (as k_score) + the list of the slots to score exactly (uint16 each, batch * MAXM of them)
+#ifndef K_SCORE_NEEDED_WAVES
+#define K_SCORE_NEEDED_WAVES 4
+#endif
 template <int FAM>
-__global__ __launch_bounds__(64, 8) void k_score_needed(const VerifyParams p) {
+__global__ __launch_bounds__(64, K_SCORE_NEEDED_WAVES) void k_score_needed(const VerifyParams p) {
   typedef Fam<FAM> F;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* spts = reinterpret_cast<double*>(smem_raw);
