@@ -149,8 +149,9 @@ DSM_DEV void mt_skip_wave(MtState* s, uint32_t target, int lane) {
 
 // LDS work area of wv_draw_samples
 struct WvSampler {
-  uint32_t raw[640];  // tempered outputs not yet consumed (<= 6 left over + one regenerated block)
-  uint32_t jb[640];   // swap partners of the draws of one block
+  uint32_t raw[640];  // tempered outputs not yet consumed (<= 6 left over + one regenerated block); the draws of the block being worked
+                      // on are replaced IN PLACE by their swap partners (jb = raw + pos) once the block is known to hold no rejection --
+                      // a second array for them was 2.5 of the 8.7 KB that bound k_sample<H>'s occupancy
   uint64_t plain[10];  // per 64 trials of the block: the trials whose swaps are independent of each other
 };
 
@@ -191,19 +192,22 @@ DSM_DEV void wv_draw_samples(MtState* gen, WvSampler* ws, uint32_t* sidx, uint32
     for (int e = lane; e < nd; e += 64) {
       const uint32_t i = (uint32_t)(e % K_);  // a block starts at a trial boundary
       const uint32_t range = n - i;
-      const uint64_t product = (uint64_t)ws->raw[pos + e] * (uint64_t)range;
-      const uint32_t low = (uint32_t)product;
+      const uint32_t low = (uint32_t)((uint64_t)ws->raw[pos + e] * (uint64_t)range);
       if (low < range) {
         const uint32_t threshold = (0u - range) % range;
         if (low < threshold) rej = true;
       }
-      ws->jb[e] = (uint32_t)(product >> 32) + i;
     }
-    wv_sync();
-    if (__ballot(rej) != 0ull) {
+    if (__ballot(rej) != 0ull) {  // (the serial replay below reads the block's raw outputs: nothing has been overwritten yet)
       serial = true;
       break;
     }
+    uint32_t* const jb = ws->raw + pos;
+    for (int e = lane; e < nd; e += 64) {  // every lane replaces the entries it read itself
+      const uint32_t i = (uint32_t)(e % K_);
+      jb[e] = (uint32_t)(((uint64_t)jb[e] * (uint64_t)(n - i)) >> 32) + i;
+    }
+    wv_sync();
     // Which trials are "plain" -- every partner outside the head (j >= K_) and no partner named twice -- depends on the
     // draws alone, not on the index array: decided for the whole block by a lane per trial, as ballot masks.  The
     // generator position after each trial goes out on the same occasion.
@@ -213,7 +217,7 @@ DSM_DEV void wv_draw_samples(MtState* gen, WvSampler* ws, uint32_t* sidx, uint32
       if (tt < nt) {
         uint32_t j[K_];
 #pragma unroll
-        for (int i = 0; i < K_; ++i) j[i] = ws->jb[tt * K_ + i];
+        for (int i = 0; i < K_; ++i) j[i] = jb[tt * K_ + i];
         plain = true;
 #pragma unroll
         for (int i = 0; i < K_; ++i) plain = plain && j[i] >= (uint32_t)K_;
@@ -243,7 +247,7 @@ DSM_DEV void wv_draw_samples(MtState* gen, WvSampler* ws, uint32_t* sidx, uint32
     {
       const bool mine = lane < K_;
       uint32_t h = mine ? sidx[lane] : 0u;
-      uint32_t jn = mine ? ws->jb[lane] : 0u;
+      uint32_t jn = mine ? jb[lane] : 0u;
       for (int c = 0; c < nt; c += 64) {
         const uint64_t pm = ws->plain[c >> 6];
         // (the builtin returns int: through uint32_t, or the low word's bit 31 would be sign-extended over the high word)
@@ -259,7 +263,7 @@ DSM_DEV void wv_draw_samples(MtState* gen, WvSampler* ws, uint32_t* sidx, uint32
           if (run > 0) {
             if (mine) {
               uint32_t* out = smp + (size_t)(t + tt) * 7 + lane;
-              const uint32_t* jp = ws->jb + (tt + 1) * K_ + lane;  // (one trial past the block's last is inside jb[]: read, never used)
+              const uint32_t* jp = jb + (tt + 1) * K_ + lane;  // (one trial past the block's last is inside raw[]: read, never used)
               uint32_t j = jn;
               jn = *jp;
               jp += K_;
@@ -281,14 +285,14 @@ DSM_DEV void wv_draw_samples(MtState* gen, WvSampler* ws, uint32_t* sidx, uint32
             u += run;
           } else {
             if (mine) {
-              jn = ws->jb[(tt + 1) * K_ + lane];
+              jn = jb[(tt + 1) * K_ + lane];
               sidx[lane] = h;
             }
             wv_sync();
             if (lane == 0) {
 #pragma unroll
               for (int i = 0; i < K_; ++i) {
-                const uint32_t ji = ws->jb[tt * K_ + i];
+                const uint32_t ji = jb[tt * K_ + i];
                 const uint32_t a = sidx[i];
                 sidx[i] = sidx[ji];
                 sidx[ji] = a;
