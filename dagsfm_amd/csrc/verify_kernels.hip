@@ -290,12 +290,14 @@ DSM_DEV void wv_draw_samples(MtState* gen, WvSampler* ws, uint32_t* sidx, uint32
             }
             wv_sync();
             if (lane == 0) {
+              uint32_t pj[K_];  // the partners first, all at once: read inside the loop they cost every swap a second LDS round trip
+#pragma unroll
+              for (int i = 0; i < K_; ++i) pj[i] = jb[tt * K_ + i];
 #pragma unroll
               for (int i = 0; i < K_; ++i) {
-                const uint32_t ji = jb[tt * K_ + i];
                 const uint32_t a = sidx[i];
-                sidx[i] = sidx[ji];
-                sidx[ji] = a;
+                sidx[i] = sidx[pj[i]];
+                sidx[pj[i]] = a;
               }
             }
             wv_sync();
