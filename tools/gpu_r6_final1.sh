@@ -30,5 +30,8 @@ rm -rf $out/prof1
 head -8 $out/bench_kernel_stats.csv | cut -c1-110
 timeout 1200 python tools/check_schedules.py --legacy > $out/check_schedules.txt 2>&1
 timeout 600 python tools/check_schedules.py --images 150 --outlier-frac 0.5 --legacy >> $out/check_schedules.txt 2>&1
-timeout 600 python tools/check_schedules.py --images 200 --uncalibrated --legacy >> $out/check_schedules.txt 2>&1; grep -c "identical: True" $out/check_schedules.txt; grep -c "identical: False" $out/check_schedules.txt
+timeout 600 python tools/check_schedules.py --images 200 --uncalibrated --legacy >> $out/check_schedules.txt 2>&1
+echo "# planar scene, 200 images (H is the model: k_lo_prepare_reg<H, 3>), calibrated / uncalibrated" >> $out/check_schedules.txt
+timeout 600 python tools/check_schedules.py --images 200 --planar >> $out/check_schedules.txt 2>&1
+timeout 600 python tools/check_schedules.py --images 200 --planar --uncalibrated >> $out/check_schedules.txt 2>&1; grep -c "identical: True" $out/check_schedules.txt; grep -c "identical: False" $out/check_schedules.txt
 ( timeout 600 python tools/check_score_bounds.py; timeout 600 python tools/check_score_bounds.py --images 150 --outlier-frac 0.5; timeout 600 python tools/check_score_bounds.py --images 200 --uncalibrated ) 2>&1 | grep -v amdgpu.ids | tee $out/score_bounds_check.txt
