@@ -217,8 +217,11 @@ __device__ __forceinline__ float dist_u8_f32(const int (&q)[32], const float* b)
 
 }  // namespace
 
+#ifndef FLANN_LANE_WAVES
+#define FLANN_LANE_WAVES 4
+#endif
 template <int ALGO>  // 0 linear, 1 kd-trees, 2 k-means: one instance each (the union of their live state spills scalar registers)
-__global__ __launch_bounds__(64) void k_flann_search(const FlannSearchParams p) {
+__global__ __launch_bounds__(64, FLANN_LANE_WAVES) void k_flann_search(const FlannSearchParams p) {
   __shared__ uint32_t qs[32][64];  // the queries of the wave, dword d of lane l at [d][l]
   const int lane = threadIdx.x;
   const uint32_t L = blockIdx.x * 64u + (uint32_t)lane;
