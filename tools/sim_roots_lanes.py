@@ -117,6 +117,36 @@ def simulate(wave, fuse_deflations):
     return cost, iters
 
 
+def simulate_capped(wave, cap):
+    """The present schedule for at most `cap` iterations of the wave; returns the cost and what is left of every lane's sequence."""
+    pos = [0] * len(wave)
+    cost = iters = 0
+    while iters < cap and any(p < len(e) for p, e in zip(pos, wave)):
+        iters += 1
+        kinds = kinds_of(wave, pos)
+        cost += C_SEARCH + (C_D1 if 1 in kinds else 0) + (C_D2 if 2 in kinds else 0)
+        for l, k in enumerate(kinds):
+            if k in (1, 2):
+                pos[l] += 1
+        if 3 in kinds:
+            cost += francis(wave, pos, kinds)
+    return cost, [e[p:] for p, e in zip(pos, wave) if p < len(e)]
+
+
+def two_launches(tr, cap, rng, n_waves=60):
+    """A capped first launch, the unfinished polynomials compacted into full waves for a second one (the round-5 verdict's item 6)."""
+    cost1, rest = 0, []
+    for w in range(n_waves):
+        idx = rng.choice(len(tr), 64, replace=False)
+        c, r = simulate_capped([tr[i] for i in idx], cap)
+        cost1 += c
+        rest += r
+    cost2 = 0
+    for w in range(0, len(rest), 64):
+        cost2 += simulate(rest[w:w + 64], False)[0] * (len(rest[w:w + 64]) / 64.0 if len(rest[w:w + 64]) < 64 else 1.0)
+    return (cost1 + cost2) / n_waves, len(rest) / (64.0 * n_waves)
+
+
 def main():
     tr = traces(sys.argv[1] if len(sys.argv) > 1 else "/tmp/liboracle_trace.so")
     cnt = lambda e, k: sum(1 for x in e if x[0] == k)  # noqa: E731
@@ -135,6 +165,13 @@ def main():
             costs.append(c)
             its.append(it)
         print("%-60s wave cost %.0f (one lane's own work %.0f: utilisation %.2f), iterations %.1f" % (name, np.mean(costs), ideal, ideal / np.mean(costs), np.mean(its)))
+    base = None
+    for cap in (0, 14, 16, 18, 20, 22, 24, 26):
+        c, frac = two_launches(tr, cap if cap else 10 ** 6, np.random.default_rng(1))
+        if not cap:
+            base = c
+        print("two launches, the first capped at %2s iterations: wave cost %.0f (utilisation %.2f, %+.1f %% against one launch), %.0f %% of the polynomials go on to the second" % (
+            cap if cap else "no", c, ideal / c, 100.0 * (base / c - 1.0), 100.0 * frac))
     order = np.argsort([len(e) for e in tr])
     costs = []
     for w in range(0, len(order) - 63, 64):
