@@ -485,9 +485,7 @@ DSM_DEV void fivept_launder(double& x) { asm volatile("" : "+v"(x)); }
 // Left to itself the optimiser merges the common sub-products e[i]*e[j] of all 5 600 terms into hundreds of
 // long-lived values (968 spilled VGPRs); a fence after every FIVEPT_GROUP statements confines merging and
 // scheduling to the group -- the arithmetic of every statement is untouched.
-#ifndef FIVEPT_GROUP
 #define FIVEPT_GROUP 4
-#endif
 template <int ES = 1>
 DSM_DEV void five_point_build_A(const double (&Eb)[36], double* out) {
   LSEC_BEGIN();
