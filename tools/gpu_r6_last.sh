@@ -14,3 +14,5 @@ print('parity_sample', d['parity_sample'])
 for k, v in d['extra'].items(): print(k, {a: b for a, b in v.items() if a != 'workload'})
 print(d.get('from_profiles'))
 PY
+# the N > 1 line as the driver will see it (two ranks sharing this one GPU over gloo: the format and per_rank, not a scaling number)
+timeout 900 python bench.py --gpus 2 --oversubscribe --steps 5 --warmup 2 --cpu-seconds 0 --no-second-regime --no-config3 --no-extra-configs > $out/bench_two_ranks_one_gpu.json 2> $out/two_ranks.err; tail -c 1500 $out/bench_two_ranks_one_gpu.json
