@@ -223,6 +223,51 @@ def test_stage_match_and_verify_many_pairs(dsm, oracle, prior, sampler_serial, l
     assert dsm.verify_kernel_time() > 0
 
 
+@pytest.mark.parametrize("form", ["product", "hyp_pair_grid", "lo_prepare_wave", "elu_lds", "replay_legacy"])
+@pytest.mark.parametrize("planar,outlier_frac", [(False, 0.5), (True, 0.2)])
+def test_round6_forms_on_many_rounds_and_planar_scenes(dsm, oracle, form, planar, outlier_frac, monkeypatch):
+    """Round 6's scheduling forms against the oracle where they matter: a 0.25 inlier ratio (E / F run MANY rounds: from a pair's
+    second round on the lane-per-hypothesis solvers take the hypotheses of all pairs from k_sample's list, verify_kernels.hip
+    hyp_of_lane) and a planar scene (the local optimisations of H have hundreds of inliers: k_lo_prepare_reg<H, 3>; those of a general
+    scene a handful: <H, 1>).  `product` is the product library; the other forms are the check build's older ones of the same results
+    (DSM_HYP_GRID=pair: the (pair, 64 trials) grid in every round; DSM_LO_PREPARE_WAVE: every design matrix through the general kernel
+    k_lo_prepare; DSM_ELU_LDS: the 5-point elimination in LDS; DSM_REPLAY_LEGACY: the replay scans of rounds 2 - 5), batched schedule,
+    two lanes and three chunks each, so that list segments, chunk boundaries and lanes all occur."""
+    env = {"hyp_pair_grid": ("DSM_HYP_GRID", "pair"), "lo_prepare_wave": ("DSM_LO_PREPARE_WAVE", "1"), "elu_lds": ("DSM_ELU_LDS", "1"),
+           "replay_legacy": ("DSM_REPLAY_LEGACY", "1")}.get(form)
+    if env:
+        monkeypatch.setenv(*env)
+    monkeypatch.setenv("DSM_VERIFY_INLINE_LO", "0")
+    monkeypatch.setenv("DSM_VERIFY_LANES", "2")
+    monkeypatch.setenv("DSM_VERIFY_CHUNK_PAIRS", "6")
+    monkeypatch.setenv("DSM_LO_TAIL", "3")
+    n_img = 8
+    scene = synthetic.Scene(n_img, 768, seed=61 + planar, n_pool=2048, planar=planar, outlier_frac=outlier_frac)
+    ims = [scene.image(i) for i in range(n_img)]
+    cams = [capi.simple_pinhole(800.0, 500.0, 375.0, 1000, 750, 1) for _ in range(n_img)]
+    ctx = dsm  # (the fixture hands out the check build's context while a check-only switch is set)
+    ctx.set_images([im[0] for im in ims], [im[1] for im in ims], cams)
+    pairs = synthetic.exhaustive_pairs(n_img)
+    ctx.match_pairs(pairs)
+    opts = capi.default_two_view_options()
+    ctx.verify_pairs(opts, user_seed=7, stage_filter=False)
+    offs, m = ctx.matches()
+    tvgs = ctx.two_view_geometries()
+    ioffs, im = ctx.inlier_matches()
+    n_geo = n_many = 0
+    for k, (i, j) in enumerate(pairs):
+        mk = m[int(offs[k]):int(offs[k + 1])]
+        ref, ref_inl = oracle.estimate_two_view_geometry(cams[i], ims[i][1].astype(np.float64), cams[j], ims[j][1].astype(np.float64), mk, opts,
+                                                         capi.pair_seed(int(i), int(j), 7))
+        tvg_equal(tvgs[k], ref, (form, planar, i, j))
+        assert (im[int(ioffs[k]):int(ioffs[k + 1])] == ref_inl).all()
+        n_geo += ref.config > 1
+        n_many += ref.num_trials[0] > 64 or ref.num_trials[1] > 128   # E / F went beyond their first round
+    assert n_geo >= 10
+    if not planar:
+        assert n_many >= 10, "the workload must take E / F beyond their first round"
+
+
 @pytest.mark.parametrize("schedule", ["default", "batched"])
 def test_radial_camera_and_small_lo_systems(dsm, oracle, schedule, monkeypatch):
     """SIMPLE_RADIAL cameras (iterative undistortion) and tiny inlier sets (6..9-row LO systems).  "batched": the
