@@ -3073,8 +3073,11 @@ __global__ __launch_bounds__(64, 8) void k_prescore_compact(const VerifyParams p
 //   C by at most 2^-111: relative 2^-70 of the guard.  Inf / NaN make every compare false: the point goes to the FP64 test.
 // tools/check_score_bounds.py (DSM_SCORE_PREFILTER=check) holds every slot's exact count against [lower, upper]; DSM_SCORE_PREFILTER=33
 // (check build) runs the pure FP64 k_prescore_compact instead.
+#ifndef K_PRESCORE_C2_WAVES
+#define K_PRESCORE_C2_WAVES 5  // 96 VGPRs + 24 bytes of scratch per lane: 12.5 + 10.5 ms against 13.1 + 10.8 at four waves per SIMD (100 VGPRs); six spill the stretch loop
+#endif
 template <int FAM>
-__global__ __launch_bounds__(64, 4) void k_prescore_compact2(const VerifyParams p) {  // (LDS -- points + lists, ~11 KB -- allows ~3.5 waves per SIMD anyway; at 6 the stretch loop spills)
+__global__ __launch_bounds__(64, K_PRESCORE_C2_WAVES) void k_prescore_compact2(const VerifyParams p) {
   typedef Fam<FAM> F;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ uint16_t s_map[64];

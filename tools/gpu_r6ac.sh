@@ -23,4 +23,4 @@ timeout 600 python tools/check_schedules.py --images 200 --uncalibrated >> $out/
 (cd /tmp && DSM_VERIFY_LANES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof1 -o bench -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-second-regime --no-config3 --no-extra-configs > /dev/null 2> $R/$out/rocprof1.err)
 find $out/prof1 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/verify_kernel_stats_1lane.csv
 rm -rf $out/prof1
-grep -E "k_solve_e_lu_reg|k_solve_e_build" $out/verify_kernel_stats_1lane.csv | cut -c1-120
+grep -E "k_prescore_compact2" $out/verify_kernel_stats_1lane.csv | cut -c1-120
